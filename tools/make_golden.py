@@ -1,0 +1,348 @@
+#!/usr/bin/env python3
+"""Record golden vectors by running the *reference* (genomematt/xenomapper v1.0.2).
+
+Runs only in the build container, where the reference is mounted read-only at
+/root/reference; it refuses to run anywhere else.  Only the recorded inputs/outputs
+(tests/golden/*.json) and the data files the reference's own tests hold
+(tests/golden/ref_data/*.sam) are committed -- no reference source travels.
+
+    python tools/make_golden.py            # rewrites tests/golden/
+
+Vectors:
+  G1  get_mapping_state truth table: lattice {-inf,-7,-1,0,1,3}^4 x m in {-inf,-2,0,2}
+      plus the 17 rows of the reference test (tests/test_xenomapper.py:165-183)
+  G2  tag / CIGAR parser table incl. adversarial lines and error rows
+  G3  end-to-end runs of the three main loops on the reference's four SAM fixtures and on
+      build-generated synthetic SAM text: per-unit (index, fwd, rev, bin), category_counts,
+      SHA-224 + length of each of the six bin texts, the stderr summary text
+"""
+import hashlib
+import io
+import itertools
+import json
+import os
+import shutil
+import sys
+
+REF_ROOT = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+if not os.path.isdir(os.path.join(REF_ROOT, "xenomapper")):
+    sys.exit("make_golden.py: reference not mounted at %s -- golden vectors can only be "
+             "recorded in the build container" % REF_ROOT)
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF_ROOT)
+sys.path.insert(0, REPO)
+from xenomapper import xenomapper as ref            # noqa: E402  (the reference)
+from xenomapper_amd import synth                     # noqa: E402  (the build's generator)
+
+NEG = float("-inf")
+STATES = ["primary_specific", "secondary_specific", "primary_multi", "secondary_multi",
+          "unresolved", "unassigned"]
+SIDX = {s: i for i, s in enumerate(STATES)}
+BIN_ARGS = STATES          # keyword names of the six sinks == state names
+
+
+def num(x):
+    """JSON-safe number: -inf/inf/nan become strings."""
+    if isinstance(x, float) and (x != x or x in (NEG, -NEG)):
+        return repr(x)
+    return x
+
+
+# ------------------------------------------------------------------ G1
+def g1():
+    vals = [NEG, -7, -1, 0, 1, 3]
+    mins = [NEG, -2, 0, 2]
+    digits = []
+    for m in mins:
+        for a1, x1, a2, x2 in itertools.product(vals, repeat=4):
+            digits.append(str(SIDX[ref.get_mapping_state(a1, x1, a2, x2, m)]))
+    extra_in = [
+        (200, 199, 199, 198, NEG), (200, 200, 199, 198, NEG), (199, 198, 200, 198, NEG),
+        (199, 198, 200, 200, NEG), (NEG, NEG, NEG, NEG, NEG), (200, 199, 200, 198, NEG),
+        (200, 199, 199, 199, NEG), (200, 200, 199, 199, NEG), (199, 199, 200, 199, NEG),
+        (199, 199, 200, 200, NEG), (9, 8, 8, 8, 10), (200, 200, 200, 200, NEG),
+        (-6, NEG, NEG, NEG, NEG), (NEG, NEG, -6, NEG, NEG), (-6, NEG, -2, NEG, NEG),
+        (0, NEG, -2, NEG, NEG), (-2, NEG, 0, NEG, NEG),
+        # build-authored rows: the XS == 0 quirk, fractional thresholds, large values
+        (0, 0, -5, NEG, NEG), (0, 0, 0, 0, NEG), (-3, 0, -9, 0, NEG), (5, 0, 7, 0, 4),
+        (10, 9, 10, 9, 9.5), (10, 9, 9, 9, 9.5), (9, 9, 10, 10, 9.5), (10, 10, 10, 10, 10),
+        (2147483647, 2147483646, 2147483646, 0, NEG), (-2147483647, NEG, NEG, NEG, NEG),
+        (12.5, 12.25, 12.5, NEG, NEG), (12.5, 12.5, 12.25, NEG, 12.4), (3, NEG, 4, 4, 3.999),
+        (1, 1, 1, 1, -NEG), (NEG, 5, NEG, 5, NEG),
+    ]
+    rows = [[num(v) for v in r] + [SIDX[ref.get_mapping_state(*r)]] for r in extra_in]
+    return {"lattice_values": [num(v) for v in vals], "lattice_min_scores": [num(m) for m in mins],
+            "lattice_states": "".join(digits),
+            "lattice_order": "for m in min_scores: for (AS1,XS1,AS2,XS2) in product(values, repeat=4)",
+            "rows": rows, "row_format": "AS1,XS1,AS2,XS2,min_score,state"}
+
+
+# ------------------------------------------------------------------ G2
+def g2():
+    unmapped = ['HWI-ST960:63:D0CYJACXX:4:1101:21264:2228', '4', '*', '0', '0', '*', '*', '0', '0',
+                'TGGTAGTATTGGTTATGGTTCATTGTCCGGAGAGTATATTGTTGAAGAGG',
+                'BBCBDFDDHHHGFHHIIIIIJIJJJIGJJJGIAF:CFEGHGGHEEEG@HI', 'YT:Z:UU']
+    blank = [''] * 5
+
+    def rec(cigar, *opts):
+        return blank + [cigar] + [''] * 5 + list(opts)
+
+    cases = []
+    funcs = {"get_tag": ref.get_tag, "get_tag_with_ZS_as_XS": ref.get_tag_with_ZS_as_XS,
+             "get_cigarbased_AS_tag": ref.get_cigarbased_AS_tag}
+
+    def add(func, fields, tag):
+        try:
+            val = funcs[func](fields, tag=tag)
+            out = {"value": num(val), "type": type(val).__name__}
+        except Exception as exc:            # record the exception type only
+            out = {"error": type(exc).__name__}
+        cases.append({"func": func, "fields": fields, "tag": tag, "expect": out})
+
+    # rows of the reference's own tests (tests/test_xenomapper.py:191-197, :203-209, :215-232)
+    for tag in ("AS", "XS", "NM"):
+        add("get_tag", unmapped, tag)
+        add("get_tag", rec('50M', 'NM:i:0', 'AS:i:101', 'XS:i:99'), tag)
+        add("get_tag", rec('50M', 'NM:i:0', 'AS:i:100', 'XS:i:99'), tag)
+        add("get_tag_with_ZS_as_XS", unmapped, tag)
+        add("get_tag_with_ZS_as_XS", rec('50M', 'NM:i:0', 'AS:i:101', 'XS:A:+', 'ZS:i:99'), tag)
+        add("get_tag_with_ZS_as_XS", rec('50M', 'NM:i:0', 'AS:i:100', 'XS:A:+', 'ZS:i:99'), tag)
+    for cigar, opts in [('*', None), ('50M', ['NM:i:0']), ('1S49M', ['NM:i:0']), ('50M', ['NM:i:2']),
+                        ('50M', ['NM:i:0', 'AS:i:100', 'XS:i:99']), ('10M1I39M', ['NM:i:0']),
+                        ('10M1D39M', ['NM:i:0']), ('10M2D38M', ['NM:i:0']),
+                        ('10M1I10M1D28M', ['NM:i:0']), ('10M1234N40M', ['NM:i:0'])]:
+        fields = unmapped if opts is None else rec(cigar, *opts)
+        add("get_cigarbased_AS_tag", fields, "AS")
+        add("get_cigarbased_AS_tag", fields, "XS")
+    # build-authored adversarial rows
+    adv = [
+        rec('50M', 'AS:i:-12', 'XS:i:0'), rec('50M', 'AS:i:0', 'XS:i:-0'),
+        rec('50M', 'AS:f:12.5', 'XS:f:1e2'), rec('50M', 'AS:i:7', 'RG:Z:BASS'),
+        rec('50M', 'AS:i:7', 'XS:A:+'), rec('50M', 'AS:i:7', 'XS:A:+', 'ZS:i:3'),
+        rec('50M', 'AS:i:7', 'XS:i:5', 'ZS:i:3', 'YS:i:9'), rec('50M', 'AS:i:'), rec('50M', 'AS'),
+        rec('50M', 'xAS:i:44'), rec('50M', 'AS:i:4:5'), rec('50M', 'AS:i: 9'.strip()),
+        rec('50M', 'AS:i:+9', 'XS:i:1_0'), rec('50M', 'AS:i:inf', 'XS:i:nan'),
+        rec('50M', 'AS:i:3000000000', 'XS:i:-3000000000'), rec('50M', 'XS:i:4', 'XS:i:4'),
+        rec('*', 'NM:i:3'), rec('5H10M2I3M1D4M6S7H', 'NM:i:4'), rec('3=2X1P4N5M', 'NM:i:1'),
+        rec('10M2I3M2I3M4D1M', 'NM:i:0'), rec('0010S40M', 'NM:i:00'), rec('7S', 'XN:Z:NM', 'NM:i:2'),
+        rec('10Q5S', 'NM:i:1'), rec('5S10', 'NM:i:1'), rec('M5S', 'NM:i:1'), rec('50M', 'NM:i:x'),
+        rec('50M', 'NM:i:1.0'), rec('50M', 'NM:i:2', 'NM:i:3'), rec('50M', 'NM:i:-2'),
+        rec('1I1D1S', 'NM:i:0', 'AS:i:5', 'XS:i:-17'), rec('50M'), blank + ['50M'] + [''] * 5,
+        blank + ['50M'] + [''] * 4, rec('50M', 'NM:i:1', 'XS:i:2', 'XS:i:2'),
+    ]
+    for fields in adv:
+        for func in funcs:
+            for tag in ("AS", "XS"):
+                add(func, fields, tag)
+    return {"cases": cases}
+
+
+# ------------------------------------------------------------------ G3
+def run_reference(text1, text2, mode, tag_func_name="get_tag", min_score=NEG, skip_repeated=False,
+                  sinks="all"):
+    sam1, sam2 = io.StringIO(text1), io.StringIO(text2)
+    outs = {name: io.StringIO() for name in BIN_ARGS}
+    if sinks == "two":        # as tests/test_xenomapper.py:107 does for the headers
+        hdr_outs = {k: outs[k] for k in ("primary_specific", "secondary_specific")}
+    else:
+        hdr_outs = outs
+    ref.process_headers(sam1, sam2, **hdr_outs)
+    tag_func = getattr(ref, tag_func_name)
+    pairs = list(ref.getReadPairs(sam1, sam2, skip_repeated_reads=skip_repeated))
+    loop = {"se": ref.main_single_end, "pe": ref.main_paired_end,
+            "pe_conservative": ref.conservative_main_paired_end}[mode]
+    counts = loop(iter(pairs), min_score=min_score, tag_func=tag_func, **outs)
+    # per-unit record: recomputed with the reference's own functions on the same pairs
+    units = []
+    prev = None
+    for i, (l1, l2) in enumerate(pairs):
+        if mode == "se":
+            s = SIDX[ref.get_mapping_state(tag_func(l1, tag='AS'), tag_func(l1, tag='XS'),
+                                           tag_func(l2, tag='AS'), tag_func(l2, tag='XS'), min_score)]
+            units.append([i, s, s])
+        else:
+            if prev is not None and prev[0][0] == l1[0]:
+                f = SIDX[ref.get_mapping_state(tag_func(prev[0], tag='AS'), tag_func(prev[0], tag='XS'),
+                                               tag_func(prev[1], tag='AS'), tag_func(prev[1], tag='XS'),
+                                               min_score)]
+                r = SIDX[ref.get_mapping_state(tag_func(l1, tag='AS'), tag_func(l1, tag='XS'),
+                                               tag_func(l2, tag='AS'), tag_func(l2, tag='XS'), min_score)]
+                units.append([i, f, r])
+            prev = (l1, l2)
+    # cross-check the recomputed units against the Counter the reference returned
+    from collections import Counter
+    chk = Counter()
+    for _, f, r in units:
+        chk[STATES[r] if mode == "se" else (STATES[f], STATES[r])] += 1
+    assert chk == counts, (chk, counts)
+    summary = io.StringIO()
+    ref.output_summary(counts, outfile=summary)
+    bins = {}
+    for name in BIN_ARGS:
+        text = outs[name].getvalue()
+        bins[name] = {"sha224": hashlib.sha224(text.encode("latin-1")).hexdigest(), "len": len(text),
+                      "lines": text.count("\n")}
+    return {
+        "n_records": len(pairs),
+        "unit_index": [u[0] for u in units],
+        "unit_fwd": "".join(str(u[1]) for u in units),
+        "unit_rev": "".join(str(u[2]) for u in units),
+        "counts": {("|".join(k) if isinstance(k, tuple) else k): v for k, v in sorted(counts.items())},
+        "bins": bins,
+        "summary": summary.getvalue(),
+    }
+
+
+def all36_text():
+    """Hand-built pairs hitting all 36 (fwd, rev) tuples, with XS = 0 / AS = 0 / negative scores,
+    a triple-QNAME run, singletons and mixed whitespace."""
+    # one record realising each state: (AS1, XS1, AS2, XS2); None = tag absent
+    realise = {
+        0: [(10, 5, 3, None), (0, 0, -5, None), (-3, None, None, None), (7, 0, 7 - 1, 9)],
+        1: [(3, None, 10, 5), (-5, None, 0, 0), (None, None, -3, None), (6, 9, 7, 0)],
+        2: [(10, 10, 3, None), (-4, -2, -9, None), (5, 7, None, None)],
+        3: [(3, None, 10, 10), (-9, None, -4, -2), (None, None, 5, 7)],
+        4: [(10, 5, 10, 5), (0, 0, 0, 0), (-7, None, -7, -7)],
+        5: [(None, None, None, None), (None, 4, None, 4)],
+    }
+    lines = [["@HD\tVN:1.0"], ["@HD\tVN:1.0", "@PG\tID:aligner\tPN:x"]]
+    q = 0
+
+    def emit(name, vals, k):
+        for f in range(2):
+            a, x = vals[2 * f], vals[2 * f + 1]
+            cols = [name, str(64 + 64 * (k & 1)), "chr%d" % (f + 1), str(100 + q), "30",
+                    "20M" if a is not None else "*", "=", "0", "0", "ACGTACGTACGTACGTACGT", "IIIIIIIIIIIIIIIIIIII"]
+            if a is not None:
+                cols.append("AS:i:%d" % a)
+            if x is not None:
+                cols.append("XS:i:%d" % x)
+            cols.append("YT:Z:CP")
+            sep = "\t" if (q + k) % 5 else " "
+            lines[f].append(sep.join(cols))
+
+    for f_state in range(6):
+        for r_state in range(6):
+            for rep in range(2):
+                name = "pair%03d" % q
+                emit(name, realise[f_state][(q + rep) % len(realise[f_state])], 0)
+                emit(name, realise[r_state][(q // 2 + rep) % len(realise[r_state])], 1)
+                q += 1
+            if (f_state * 6 + r_state) % 7 == 3:          # a singleton
+                emit("single%03d" % q, realise[r_state][0], 0)
+                q += 1
+            if (f_state * 6 + r_state) % 9 == 4:          # three records with one name
+                name = "triple%03d" % q
+                emit(name, realise[f_state][0], 0)
+                emit(name, realise[r_state][0], 1)
+                emit(name, realise[(f_state + r_state) % 6][0], 0)
+                q += 1
+    return "\n".join(lines[0]) + "\n", "\n".join(lines[1]) + "\n"
+
+
+def g3():
+    data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
+    out_dir = os.path.join(GOLDEN, "ref_data")
+    os.makedirs(out_dir, exist_ok=True)
+    fixtures = {}
+    for name in ("test_human_in.sam", "test_mouse_in.sam",
+                 "paired_end_testdata_human.sam", "paired_end_testdata_mouse.sam"):
+        shutil.copyfile(os.path.join(data_dir, name), os.path.join(out_dir, name))
+        os.chmod(os.path.join(out_dir, name), 0o644)
+        with open(os.path.join(data_dir, name), "rt") as fh:
+            fixtures[name] = fh.read()
+    se = ("test_human_in.sam", "test_mouse_in.sam")
+    pe = ("paired_end_testdata_human.sam", "paired_end_testdata_mouse.sam")
+
+    cases = []
+
+    def add(name, inputs, mode, **kw):
+        if inputs[0] == "ref":
+            t1, t2 = fixtures[inputs[1]], fixtures[inputs[2]]
+            src = {"kind": "ref_data", "files": [inputs[1], inputs[2]]}
+        elif inputs[0] == "synth":
+            t1, t2, _ = synth.sam_text_pair(**inputs[1])
+            src = {"kind": "synth", "args": inputs[1],
+                   "sha224": [hashlib.sha224(t.encode()).hexdigest() for t in (t1, t2)]}
+        else:
+            t1, t2 = all36_text()
+            src = {"kind": "inline", "text": [t1, t2]}
+        res = run_reference(t1, t2, mode, **kw)
+        opts = {"tag_func": kw.get("tag_func_name", "get_tag"), "min_score": num(kw.get("min_score", NEG)),
+                "skip_repeated": kw.get("skip_repeated", False), "header_sinks": kw.get("sinks", "all")}
+        cases.append({"name": name, "source": src, "mode": mode, "options": opts, "expect": res})
+
+    # the reference's fixtures, each mode; "two" reproduces the header layout of its own tests
+    add("ref_se", ("ref",) + se, "se")
+    add("ref_se_skip_repeated", ("ref",) + se, "se", skip_repeated=True)
+    add("ref_se_min60", ("ref",) + se, "se", min_score=60.0)
+    add("ref_se_cigar", ("ref",) + se, "se", tag_func_name="get_cigarbased_AS_tag")
+    add("ref_pe_liberal_testlayout", ("ref",) + pe, "pe", sinks="two")
+    add("ref_pe_conservative_testlayout", ("ref",) + pe, "pe_conservative", sinks="two")
+    add("ref_pe_liberal", ("ref",) + pe, "pe")
+    add("ref_pe_conservative", ("ref",) + pe, "pe_conservative")
+    add("ref_pe_liberal_cigar", ("ref",) + pe, "pe", tag_func_name="get_cigarbased_AS_tag")
+    add("ref_pe_conservative_cigar_min", ("ref",) + pe, "pe_conservative",
+        tag_func_name="get_cigarbased_AS_tag", min_score=-30.5)
+    add("ref_pe_liberal_min150", ("ref",) + pe, "pe", min_score=150.0)
+    add("ref_pe_conservative_min99_5", ("ref",) + pe, "pe_conservative", min_score=99.5)
+    add("ref_pe_as_se", ("ref",) + pe, "se", skip_repeated=True)
+    # hand-built: all 36 tuples
+    add("all36_liberal", ("inline",), "pe")
+    add("all36_conservative", ("inline",), "pe_conservative")
+    add("all36_liberal_min0", ("inline",), "pe", min_score=0.0)
+    add("all36_se", ("inline",), "se")
+    add("all36_se_skip", ("inline",), "se", skip_repeated=True)
+    # synthetic text twins of the BASELINE.json configs (same score model, small n)
+    cfg1 = dict(n_pairs=3000, seed=1001, profile="bowtie2", paired=False, read_len=50, mixed_ws=0.2,
+                irregular=0.05)
+    cfg2 = dict(n_pairs=1500, seed=2002, profile="bowtie2", paired=True, read_len=150, irregular=0.02)
+    cfg3 = dict(n_pairs=1200, seed=3003, profile="cigar", paired=True, read_len=150, irregular=0.02)
+    cfg5 = dict(n_pairs=1500, seed=5005, profile="hisat", paired=True, read_len=150, irregular=0.02,
+                mixed_ws=0.05)
+    add("cfg1_se", ("synth", cfg1), "se")
+    add("cfg1_se_cli", ("synth", cfg1), "se", skip_repeated=True)
+    add("cfg2_pe_liberal", ("synth", cfg2), "pe")
+    add("cfg2_pe_conservative_min100", ("synth", cfg2), "pe_conservative", min_score=100.0)
+    add("cfg3_pe_cigar", ("synth", cfg3), "pe", tag_func_name="get_cigarbased_AS_tag")
+    add("cfg3_pe_cigar_conservative", ("synth", cfg3), "pe_conservative",
+        tag_func_name="get_cigarbased_AS_tag", min_score=-20.0)
+    add("cfg5_pe_zs_conservative", ("synth", cfg5), "pe_conservative",
+        tag_func_name="get_tag_with_ZS_as_XS")
+    add("cfg5_pe_zs_liberal", ("synth", cfg5), "pe", tag_func_name="get_tag_with_ZS_as_XS")
+    return {"cases": cases}
+
+
+def header_golden():
+    """process_headers on the PE fixtures (tests/test_xenomapper.py:29-54): full texts."""
+    data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
+    outs = {name: io.StringIO() for name in BIN_ARGS}
+    with open(os.path.join(data_dir, "paired_end_testdata_human.sam")) as s1, \
+            open(os.path.join(data_dir, "paired_end_testdata_mouse.sam")) as s2:
+        ref.process_headers(s1, s2, **outs)
+    return {name: outs[name].getvalue() for name in BIN_ARGS}
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    payload = {"g1_mapping_state.json": g1(), "g2_tag_parsers.json": g2(), "g3_end_to_end.json": g3(),
+               "g4_headers.json": header_golden()}
+    for name, obj in payload.items():
+        with open(os.path.join(GOLDEN, name), "wt") as fh:
+            json.dump(obj, fh, indent=None, separators=(",", ":"), sort_keys=True)
+            fh.write("\n")
+        print(name, os.path.getsize(os.path.join(GOLDEN, name)), "bytes")
+    g3c = payload["g3_end_to_end.json"]["cases"]
+    seen = set()
+    for c in g3c:
+        if c["mode"] != "se":
+            seen.update(c["expect"]["counts"])
+    print("G3 cases:", len(g3c), "distinct paired tuples covered:", len(seen))
+
+
+if __name__ == "__main__":
+    main()
