@@ -1,0 +1,162 @@
+/*
+ * xenomapper_hip.h -- C ABI of the MI355X (gfx950) xenograft read classifier.
+ *
+ * The reference (genomematt/xenomapper v1.0.2) is pure Python and has no FFI; its operator
+ * interface for this path is the trio of main loops plus their pluggable score extractor
+ * (/root/reference/xenomapper/xenomapper.py:291-299, :354-362, :456-464, tag_func :176-256,
+ * get_mapping_state :258).  This header is what a maintainer's ctypes binding for those
+ * functions would bind (INTEGRATION.md shows the stub).  Each entry point names the
+ * reference code it replaces.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no exceptions across the boundary,
+ * int status (0 = ok, negative = error, xm_strerror() gives text), caller-allocated
+ * buffers, the library never frees caller memory.  A context belongs to one device; use one
+ * context per thread.  There is no CPU fallback: without a usable gfx950 device
+ * xm_ctx_create() fails with XM_ERR_NO_DEVICE and nothing else can be called.
+ *
+ * Data model (one "record" = one SAM line index i, present in both the primary- and the
+ * secondary-species file; columns are structure-of-arrays, one element per record):
+ *   as1, xs1, as2, xs2   scores of record i in species 1 / 2.  int32 columns use
+ *                        XM_ABSENT (INT32_MIN) for "tag absent" = the reference's
+ *                        float('-inf') (xenomapper.py:187-188); f64 columns use -inf itself.
+ *   unit_bits            packed little-endian bit mask, bit (i & 63) of word (i >> 6):
+ *                        record i closes a unit.  Paired modes: name[i] == name[i-1]
+ *                        (xenomapper.py:402-405); single-end: record i was yielded by the
+ *                        reader (xenomapper.py:321).  ceil(n/64) words.
+ *   code                 one byte per record: XM_NO_UNIT (0xFF) or the unit's category
+ *                        code -- state (single-end) or fwd*8 + rev (paired), states 0..5 =
+ *                        primary_specific, secondary_specific, primary_multi,
+ *                        secondary_multi, unresolved, unassigned (priority order of
+ *                        xenomapper.py:364-367); state 6 = the reference's RuntimeError
+ *                        fall-through (xenomapper.py:289; reachable with NaN only).
+ *   counts[64]           category_counts (xenomapper.py:330, :420, :520) indexed by code.
+ */
+#ifndef XENOMAPPER_HIP_H
+#define XENOMAPPER_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XM_ABI_VERSION 1
+
+#define XM_ABSENT   INT32_MIN
+#define XM_NO_UNIT  0xFFu
+
+/* loop selection (which reference main loop the call stands for) */
+#define XM_MODE_SE              0   /* main_single_end               xenomapper.py:291-352 */
+#define XM_MODE_PE_LIBERAL      1   /* main_paired_end               xenomapper.py:354-454 */
+#define XM_MODE_PE_CONSERVATIVE 2   /* conservative_main_paired_end  xenomapper.py:456-556 */
+
+/* status codes */
+#define XM_OK               0
+#define XM_ERR_INVALID_ARG (-1)
+#define XM_ERR_NO_DEVICE   (-2)   /* no gfx950 device / HIP runtime unusable            */
+#define XM_ERR_HIP         (-3)   /* a HIP call failed; xm_last_hip_error() has details */
+#define XM_ERR_OOM         (-4)
+#define XM_ERR_RANGE       (-5)   /* a CIGAR-derived score does not fit the int32 column */
+
+typedef struct xm_ctx xm_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int         xm_abi_version(void);
+const char *xm_strerror(int status);
+/* Text of the last failing HIP call on this context (empty string if none); with ctx == NULL,
+ * why the last xm_ctx_create() failed. */
+const char *xm_last_hip_error(const xm_ctx *ctx);
+/* Binds to HIP device `device_id`; fails with XM_ERR_NO_DEVICE if it is not a gfx950 part. */
+int xm_ctx_create(int device_id, xm_ctx **out);
+int xm_ctx_destroy(xm_ctx *ctx);
+/* Number of compute units and name of the bound device (diagnostics). */
+int xm_ctx_device_info(const xm_ctx *ctx, int *n_cu, char *name, size_t name_len);
+
+/* ---- host-buffer entry points (H2D copy, kernels, D2H copy; blocking) ----------------- */
+
+/*
+ * Replaces the score->state->pair-combination part of the three main loops
+ * (xenomapper.py:323-330, :408-420, :508-520; get_mapping_state :258-289) for n_records
+ * records at once.  min_score_floor = floor(min_score) clamped to int32 (-inf -> INT32_MIN,
+ * +inf -> INT32_MAX).  code_out: n_records bytes.  counts: 64 words (may be NULL).
+ */
+int xm_classify(xm_ctx *ctx, int mode, uint64_t n_records,
+                const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                const uint64_t *unit_bits, int32_t min_score_floor,
+                uint8_t *code_out, uint64_t counts[64]);
+
+/* Same in the reference's own arithmetic (binary64): for non-integral scores, scores outside
+ * int32, or a NaN min_score.  Absent = -inf. */
+int xm_classify_f64(xm_ctx *ctx, int mode, uint64_t n_records,
+                    const double *as1, const double *xs1, const double *as2, const double *xs2,
+                    const uint64_t *unit_bits, double min_score,
+                    uint8_t *code_out, uint64_t counts[64]);
+
+/*
+ * Replaces get_cigarbased_AS_tag(tag='AS') (xenomapper.py:228-256) on pre-parsed columns:
+ * nm[i] = NM value or XM_ABSENT when no field contains 'NM' (:247-249); CIGAR as CSR,
+ * cig_off[n_records+1] into cig_oplen[], each op packed BAM-style len<<4 | op with ops
+ * "MIDNSHP=X" = 0..8 (only I, D, S contribute, :252-255).  as_out[i] = XM_ABSENT or
+ * -6*NM - 5*(#I+#D) - 3*(sumI+sumD) - 2*sumS.  XM_ERR_RANGE if a score leaves int32.
+ */
+int xm_cigar_scores(xm_ctx *ctx, uint64_t n_records, const int32_t *nm,
+                    const uint32_t *cig_off, const uint32_t *cig_oplen, int32_t *as_out);
+
+/*
+ * Replaces the bin routing of the main loops (the if/elif chains xenomapper.py:332-350,
+ * :423-448, :521-550) and category_counts: a stable split of the unit indices by output bin.
+ * idx_out (capacity >= number of units, n_records always suffices) receives, bin after bin,
+ * the record index of each unit in input order; bin b is idx_out[bin_offsets[b] ..
+ * bin_offsets[b+1]) for b = 0..5; slot 6 collects units holding state 6; bin_offsets[7] =
+ * number of units.  counts (may be NULL) = category_counts indexed by code.
+ * Emission rule for the caller: bins 0,2,5 -> lines of file 1; 1,3 -> file 2; 4 -> file 1's
+ * lines then file 2's; paired units cover records idx-1 and idx.
+ */
+int xm_compact(xm_ctx *ctx, int mode, uint64_t n_records, const uint8_t *code,
+               uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
+
+/* ---- device-resident entry points (asynchronous on `stream`) -------------------------- */
+/*
+ * All pointers are device memory of the context's device; `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream).  Nothing is synchronised or allocated: the calls
+ * only enqueue work (graph-capturable).  Column base pointers must be 16-byte aligned and
+ * code 4-byte aligned (any hipMalloc / torch allocation is).  n_records <= XM_MAX_RECORDS.
+ */
+#define XM_MAX_RECORDS 0xFFFFF000ull
+
+int xm_classify_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                    const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                    const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out);
+
+int xm_classify_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                        const double *as1, const double *xs1, const double *as2, const double *xs2,
+                        const uint64_t *unit_bits, double min_score, uint8_t *code_out);
+
+/* range_flag: one device uint32, set non-zero when a score left int32 (may be NULL). */
+int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n_records, const int32_t *nm,
+                        const uint32_t *cig_off, const uint32_t *cig_oplen, int32_t *as_out,
+                        uint32_t *range_flag);
+
+/* bin_offsets: 8 device uint64; counts: 64 device uint64 (both overwritten). */
+int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, const uint8_t *code,
+                   uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
+
+/* ---- per-kernel timing (HIP events on the launch stream) ------------------------------ */
+#define XM_K_CLASSIFY 0
+#define XM_K_HIST     1
+#define XM_K_SCAN     2
+#define XM_K_SCATTER  3
+#define XM_K_CIGAR    4
+#define XM_K_COUNT    5
+/* When enabled, every *_dev call brackets each kernel it launches with hipEventRecord on the
+ * launch stream.  xm_timing_read() synchronises the recorded events and adds their elapsed
+ * times: ms[k] = total milliseconds, launches[k] = number of launches since the last reset. */
+int xm_timing_enable(xm_ctx *ctx, int on);
+int xm_timing_reset(xm_ctx *ctx);
+int xm_timing_read(xm_ctx *ctx, double ms[XM_K_COUNT], uint64_t launches[XM_K_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XENOMAPPER_HIP_H */

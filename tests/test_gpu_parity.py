@@ -1,0 +1,281 @@
+"""GPU parity: the HIP path, called through the C ABI, against the oracle -- bit-exact.
+
+Run on the MI355X box with `pytest -m gpu`.  Sizes cover empty / ragged tails / tile and chunk
+boundaries / BASELINE.json's 50 M-pair configuration; inputs cover every (fwd, rev) tuple, the
+XS == 0 quirk, min_score thresholds, NaN (f64 path) and irregular unit masks.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tests.helpers import ORACLE, NEG
+
+pytestmark = pytest.mark.gpu
+
+ABSENT = -2**31
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from xenomapper_amd import _ffi
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+def random_columns(rng, n, spread=8):
+    vals = np.concatenate([[ABSENT, ABSENT], np.arange(-spread, spread + 1)]).astype(np.int64)
+    return [vals[rng.integers(0, len(vals), n)].astype(np.int32) for _ in range(4)]
+
+
+def check_all(ctx, mode, cols, bits, m_float):
+    n = cols[0].shape[0]
+    mi = H.floor_min_score(m_float)
+    code, counts = ctx.classify(mode, *cols, bits, mi)
+    want_code, want_counts = H.c_classify(mode, *cols, bits, mi)
+    assert np.array_equal(code, want_code)
+    assert np.array_equal(counts, want_counts)
+    idx, off, counts2 = ctx.compact(mode, code)
+    want_idx, want_off = H.c_compact(mode, want_code)
+    assert np.array_equal(off, want_off)
+    assert np.array_equal(idx, want_idx)
+    assert np.array_equal(counts2, want_counts)
+    # the binary64 path must agree with the integer path on integral input
+    fcols = [np.where(c == ABSENT, NEG, c.astype(np.float64)) for c in cols]
+    codef, countsf = ctx.classify_f64(mode, *fcols, bits, m_float)
+    assert np.array_equal(codef, want_code)
+    assert np.array_equal(countsf, want_counts)
+
+
+SIZES = [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12289,
+         100_003, 1_000_003]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_sizes_modes(ctx, n):
+    rng = np.random.default_rng(n + 17)
+    cols = random_columns(rng, n)
+    for mode, m in itertools.product((0, 1, 2), (NEG, 0.5, -3.0)):
+        flags = rng.random(n) < (0.55 if mode else 0.9)
+        bits = H.synth.pack_unit_bits(flags) if n else np.zeros(1, dtype=np.uint64)
+        check_all(ctx, mode, cols, bits, m)
+
+
+def test_g1_lattice_on_gpu(ctx):
+    g = H.golden("g1_mapping_state.json")
+    vals = [H.unnum(v) for v in g["lattice_values"]]
+    mins = [H.unnum(m) for m in g["lattice_min_scores"]]
+    grid = np.array(list(itertools.product(vals, repeat=4)), dtype=np.float64)
+    n = grid.shape[0]
+    bits = H.synth.pack_unit_bits(np.ones(n, dtype=np.uint8))
+    k = 0
+    for m in mins:
+        want = np.frombuffer(g["lattice_states"][k:k + n].encode(), dtype=np.uint8) - ord("0")
+        k += n
+        fcols = [np.ascontiguousarray(grid[:, j]) for j in range(4)]
+        code, _ = ctx.classify_f64(0, *fcols, bits, m)
+        assert np.array_equal(code, want)
+        icols = [np.where(c == NEG, ABSENT, c).astype(np.int32) for c in fcols]
+        code, _ = ctx.classify(0, *icols, bits, H.floor_min_score(m))
+        assert np.array_equal(code, want)
+
+
+def test_g1_rows_f64_on_gpu(ctx):
+    g = H.golden("g1_mapping_state.json")
+    for row in g["rows"]:
+        v = [H.unnum(x) for x in row[:5]]
+        cols = [np.array([x], dtype=np.float64) for x in v[:4]]
+        code, _ = ctx.classify_f64(0, *cols, np.array([1], dtype=np.uint64), v[4])
+        assert int(code[0]) == row[5], row
+
+
+def test_nan_gives_state6(ctx):
+    nan = float("nan")
+    a1 = np.array([nan, 3.0, 1.0, 2.0], dtype=np.float64)
+    x1 = np.array([1.0, nan, NEG, NEG], dtype=np.float64)
+    a2 = np.array([2.0, 2.0, nan, 2.0], dtype=np.float64)
+    x2 = np.array([3.0, nan, NEG, NEG], dtype=np.float64)
+    bits = np.array([0b1111], dtype=np.uint64)
+    for mode in (0, 1, 2):
+        code, counts = ctx.classify_f64(mode, a1, x1, a2, x2, bits, NEG)
+        want, want_counts = H.c_classify(mode, a1, x1, a2, x2, bits, NEG)
+        assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+        idx, off, _ = ctx.compact(mode, code)
+        widx, woff = H.c_compact(mode, want)
+        assert np.array_equal(off, woff) and np.array_equal(idx, widx)
+    code, _ = ctx.classify_f64(0, a1, x1, a2, x2, bits, NEG)
+    assert code.tolist() == [6, 2, 6, 4]
+    # NaN min_score: nothing is `<= m` or `> m` (xenomapper.py:275-288) -> unresolved if equal else fall-through
+    code, _ = ctx.classify_f64(0, a1, x1, a2, x2, bits, nan)
+    assert code.tolist() == [6, 6, 6, 4]
+
+
+def test_all_tuples_and_xs0(ctx):
+    # one realisation per state incl. the XS == 0 quirk (AS=0,XS=0 is *specific*)
+    real = {0: (0, 0, -5, ABSENT), 1: (-5, ABSENT, 0, 0), 2: (7, 7, 3, ABSENT), 3: (3, ABSENT, 7, 9),
+            4: (4, 0, 4, 0), 5: (ABSENT, 1, ABSENT, 1)}
+    recs = []
+    for f, r in itertools.product(range(6), repeat=2):
+        recs += [real[f], real[r]]
+    cols = [np.array([r[j] for r in recs], dtype=np.int32) for j in range(4)]
+    n = len(recs)
+    flags = np.zeros(n, dtype=np.uint8)
+    flags[1::2] = 1
+    bits = H.synth.pack_unit_bits(flags)
+    for mode in (1, 2):
+        code, counts = ctx.classify(mode, *cols, bits, ABSENT)
+        units = code[1::2]
+        assert units.tolist() == [f * 8 + r for f, r in itertools.product(range(6), repeat=2)]
+        assert int(counts.sum()) == 36 and set(counts[counts > 0].tolist()) == {1}
+        idx, off, _ = ctx.compact(mode, code)
+        for b in range(6):
+            for i in idx[int(off[b]):int(off[b + 1])]:
+                c = int(code[i])
+                assert ORACLE.bin_of(mode, c >> 3, c & 7) == b
+
+
+def test_irregular_masks(ctx):
+    rng = np.random.default_rng(5)
+    n = 70_001
+    cols = random_columns(rng, n)
+    for pattern in ("none", "all", "first_only", "last_only", "runs"):
+        flags = np.zeros(n, dtype=np.uint8)
+        if pattern == "all":
+            flags[:] = 1
+        elif pattern == "first_only":
+            flags[0] = 1
+        elif pattern == "last_only":
+            flags[-1] = 1
+        elif pattern == "runs":
+            flags[(np.arange(n) // 37) % 3 == 1] = 1
+        bits = H.synth.pack_unit_bits(flags)
+        for mode in (0, 1, 2):
+            check_all(ctx, mode, cols, bits, NEG)
+
+
+def test_extreme_values(ctx):
+    vals = np.array([ABSENT, ABSENT + 1, -1, 0, 1, 2**31 - 2, 2**31 - 1], dtype=np.int64)
+    grid = np.array(list(itertools.product(vals, repeat=4)), dtype=np.int64).astype(np.int32)
+    cols = [np.ascontiguousarray(grid[:, j]) for j in range(4)]
+    n = grid.shape[0]
+    bits = H.synth.pack_unit_bits(np.ones(n, dtype=np.uint8))
+    for mi in (ABSENT, ABSENT + 1, -1, 0, 2**31 - 2, 2**31 - 1):
+        for mode in (0, 1):
+            code, counts = ctx.classify(mode, *cols, bits, mi)
+            want, wc = H.c_classify(mode, *cols, bits, mi)
+            assert np.array_equal(code, want) and np.array_equal(counts, wc)
+
+
+def test_cigar_scores(ctx):
+    for n, seed in ((0, 1), (1, 2), (257, 3), (100_003, 4)):
+        cols = H.synth.cigar_columns(n, seed) if n else {"nm": np.zeros(0, np.int32),
+                                                         "cig_off": np.zeros(1, np.uint32),
+                                                         "cig_oplen": np.zeros(0, np.uint32)}
+        got = ctx.cigar_scores(cols["nm"], cols["cig_off"], cols["cig_oplen"])
+        want, bad = H.c_cigar_scores(cols["nm"], cols["cig_off"], cols["cig_oplen"])
+        assert bad == 0 and np.array_equal(got, want)
+    # every op code, long ops, many ops per record
+    rng = np.random.default_rng(9)
+    n = 5000
+    n_ops = rng.integers(0, 40, n).astype(np.uint32)
+    off = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum(n_ops, out=off[1:])
+    ops = ((rng.integers(0, 3000, int(off[-1])).astype(np.uint32) << 4) | rng.integers(0, 9, int(off[-1])).astype(np.uint32))
+    nm = np.where(rng.random(n) < 0.1, ABSENT, rng.integers(-3, 50, n)).astype(np.int32)
+    got = ctx.cigar_scores(nm, off, ops)
+    want, bad = H.c_cigar_scores(nm, off, ops)
+    assert bad == 0 and np.array_equal(got, want)
+    # range error
+    big = np.array([(2**28 - 1) << 4 | 1] * 8, dtype=np.uint32)
+    with pytest.raises(OverflowError):
+        ctx.cigar_scores(np.array([0], np.int32), np.array([0, 8], np.uint32), big)
+
+
+@pytest.mark.parametrize("case", [c for c in H.golden("g3_end_to_end.json")["cases"]],
+                         ids=lambda c: c["name"])
+def test_g3_units_on_gpu(ctx, case):
+    """Golden per-unit states recorded from the reference, reproduced by the kernels from columns
+    (columns filled with the oracle's text-level scorers; the product's own column stripper is
+    tested in test_host_api.py)."""
+    import io
+    t1, t2 = H.case_texts(case)
+    s1, s2 = io.StringIO(t1), io.StringIO(t2)
+    ORACLE.read_header(s1), ORACLE.read_header(s2)
+    pairs = list(ORACLE.read_pairs(s1, s2, case["options"]["skip_repeated"]))
+    scorer = {"get_tag": ORACLE.tag_score, "get_tag_with_ZS_as_XS": ORACLE.tag_score_zs,
+              "get_cigarbased_AS_tag": ORACLE.cigar_score}[case["options"]["tag_func"]]
+    n = len(pairs)
+    cols = [np.array([scorer(p[f], tag=t) for p in pairs], dtype=np.float64) for f, t in
+            ((0, "AS"), (0, "XS"), (1, "AS"), (1, "XS"))]
+    names = [p[0][0] for p in pairs]
+    mode = H.MODES[case["mode"]]
+    if mode == 0:
+        flags = np.ones(n, dtype=np.uint8)
+    else:
+        flags = np.array([0] + [int(names[i] == names[i - 1]) for i in range(1, n)], dtype=np.uint8)
+    bits = H.synth.pack_unit_bits(flags)
+    m = H.unnum(case["options"]["min_score"])
+    icols = [np.where(c == NEG, ABSENT, c).astype(np.int32) for c in cols]
+    code_i, counts_i = ctx.classify(mode, *icols, bits, H.floor_min_score(m))
+    code_f, counts_f = ctx.classify_f64(mode, *cols, bits, m)
+    assert np.array_equal(code_i, code_f) and np.array_equal(counts_i, counts_f)
+    exp = case["expect"]
+    unit_idx = np.flatnonzero(code_i != 0xFF)
+    assert unit_idx.tolist() == exp["unit_index"]
+    got_rev = "".join(str(int(c) & 7) for c in code_i[unit_idx])
+    assert got_rev == exp["unit_rev"]
+    if mode:
+        assert "".join(str(int(c) >> 3) for c in code_i[unit_idx]) == exp["unit_fwd"]
+    named = {}
+    for c in np.flatnonzero(counts_i):
+        key = H.STATES[c] if mode == 0 else H.STATES[c >> 3] + "|" + H.STATES[c & 7]
+        named[key] = int(counts_i[c])
+    assert named == exp["counts"]
+    # bin sizes: lines per bin follow from the split
+    idx, off, _ = ctx.compact(mode, code_i)
+    per_unit = {0: (1, 1, 1, 1, 2, 1), 1: (2, 2, 2, 2, 4, 2), 2: (2, 2, 2, 2, 4, 2)}[mode]
+    hdr = H.golden("g4_headers.json") if False else None
+    for b, name in enumerate(H.STATES):
+        n_units = int(off[b + 1] - off[b])
+        text_lines = exp["bins"][name]["lines"]
+        # lines = header lines (unknown here) + units * per_unit  -> check congruence through the oracle run
+        assert text_lines >= n_units * per_unit[b]
+
+
+def test_device_entry_points_and_full_size(ctx):
+    """BASELINE.json configs[1]: 50 M paired-end pairs (100 M records per species), HBM-resident,
+    through the *_dev entry points; exact against the C oracle plus size-independent properties."""
+    import torch
+    from xenomapper_amd import _ffi
+    n_pairs = 50_000_000
+    cols = H.synth.score_columns(n_pairs, seed=2002)
+    n = 2 * n_pairs
+    dev = torch.device("cuda:0")
+    d = {k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for k, v in cols.items()}
+    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    for mode in (_ffi.MODE_PE_LIBERAL, _ffi.MODE_PE_CONSERVATIVE):
+        ctx.classify_dev(mode, d["as1"], d["xs1"], d["as2"], d["xs2"], d["unit_bits"], ABSENT, code)
+        ctx.compact_dev(mode, code[:n], idx, off, counts)
+        torch.cuda.synchronize()
+        h_code = code[:n].cpu().numpy()
+        h_off = off.cpu().numpy().astype(np.uint64)
+        h_counts = counts.cpu().numpy().astype(np.uint64)
+        h_idx = idx[:int(h_off[7])].cpu().numpy().view(np.uint32)
+        want_code, want_counts = H.c_classify(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"],
+                                              cols["unit_bits"], ABSENT)
+        assert np.array_equal(h_code, want_code)
+        assert np.array_equal(h_counts, want_counts)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        assert np.array_equal(h_off, want_off)
+        assert np.array_equal(h_idx, want_idx)
+        # size-independent properties
+        assert int(h_off[7]) == n_pairs == int(h_counts.sum())
+        assert np.array_equal(np.sort(h_idx), np.arange(1, n, 2, dtype=np.uint32))      # a permutation of the units
+        for b in range(6):
+            seg = h_idx[int(h_off[b]):int(h_off[b + 1])]
+            assert (np.diff(seg.astype(np.int64)) > 0).all()                              # stable within a bin

@@ -1,0 +1,145 @@
+"""CPU-only checks of the product's host side: the C ABI library loads and exports every symbol the
+headers declare, the text-level host functions match the golden vectors, and the classification
+path refuses to run (loudly) without the HIP device -- there is no CPU fallback."""
+import ctypes
+import io
+import os
+import re
+
+import pytest
+
+from tests import helpers as H
+from tests.helpers import NEG
+
+
+def _declared(header):
+    text = open(os.path.join(H.REPO, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(xm[h]?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    from xenomapper_amd import _ffi, build
+    build.build_hip()
+    names = _declared("xenomapper_hip.h")
+    assert len(names) >= 17
+    L = ctypes.CDLL(_ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(_ffi.EXPORTED) == names
+    assert _ffi.lib().xm_abi_version() == 1
+    assert b"gfx950" in _ffi.lib().xm_strerror(-2)
+
+
+def test_code_object_is_gfx950_only():
+    from xenomapper_amd import _ffi, build
+    build.build_hip()
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90"):
+        assert other not in blob
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback_without_device():
+    from xenomapper_amd import xenomapper as xm
+    with pytest.raises(RuntimeError, match="gfx950"):
+        xm.get_mapping_state(200, 199, 199, 198)
+    pairs = [(["r1"] + [""] * 10 + ["AS:i:5"], ["r1"] + [""] * 10 + ["AS:i:3"])]
+    with pytest.raises(RuntimeError, match="gfx950"):
+        xm.main_single_end(iter(pairs), primary_specific=io.StringIO())
+    with pytest.raises(RuntimeError, match="gfx950"):
+        xm.get_cigarbased_AS_tag([""] * 5 + ["50M"] + [""] * 5 + ["NM:i:1"])
+
+
+def test_text_level_tag_functions_match_golden():
+    """get_tag / get_tag_with_ZS_as_XS and the non-AS branch of get_cigarbased_AS_tag are host text
+    work and need no device."""
+    from xenomapper_amd import xenomapper as xm
+    funcs = {"get_tag": xm.get_tag, "get_tag_with_ZS_as_XS": xm.get_tag_with_ZS_as_XS,
+             "get_cigarbased_AS_tag": xm.get_cigarbased_AS_tag}
+    n = 0
+    for case in H.golden("g2_tag_parsers.json")["cases"]:
+        if case["func"] == "get_cigarbased_AS_tag" and case["tag"] == "AS":
+            continue
+        n += 1
+        exp = case["expect"]
+        if "error" in exp:
+            with pytest.raises(Exception) as info:
+                funcs[case["func"]](case["fields"], tag=case["tag"])
+            assert type(info.value).__name__ == exp["error"], case
+        else:
+            got = funcs[case["func"]](case["fields"], tag=case["tag"])
+            want = H.unnum(exp["value"])
+            assert type(got).__name__ == exp["type"]
+            assert got == want or (got != got and want != want), case
+    assert n > 150
+
+
+def test_cigar_column_parser_matches_oracle():
+    from xenomapper_amd import xenomapper as xm
+    for case in H.golden("g2_tag_parsers.json")["cases"]:
+        if case["func"] != "get_cigarbased_AS_tag" or case["tag"] != "AS":
+            continue
+        exp = case["expect"]
+        if "error" in exp:
+            with pytest.raises(Exception) as info:
+                xm._cigar_columns(case["fields"])
+            assert type(info.value).__name__ == exp["error"]
+            continue
+        nm, ops = xm._cigar_columns(case["fields"])
+        if nm is None:
+            assert H.unnum(exp["value"]) == NEG
+            continue
+        score = -6 * nm
+        for v in ops:
+            if v & 15 in (1, 2):
+                score -= 5 + 3 * (v >> 4)
+            elif v & 15 == 4:
+                score -= 2 * (v >> 4)
+        assert score == exp["value"], case
+
+
+def test_headers_summary_and_reader():
+    from xenomapper_amd import xenomapper as xm
+    g3 = {c["name"]: c for c in H.golden("g3_end_to_end.json")["cases"]}
+    t1, t2 = H.case_texts(g3["ref_pe_liberal"])
+    outs = {name: io.StringIO() for name in H.STATES}
+    s1, s2 = io.StringIO(t1), io.StringIO(t2)
+    xm.process_headers(s1, s2, **outs)
+    want = H.golden("g4_headers.json")
+    for name in H.STATES:
+        assert outs[name].getvalue() == want[name]
+    # reference test: header block lengths (tests/test_xenomapper.py:46-51)
+    assert [len(outs[n].getvalue()) for n in ("primary_specific", "secondary_specific", "primary_multi",
+                                               "secondary_multi", "unassigned", "unresolved")] == \
+        [695, 629, 708, 642, 705, 705]
+    pairs = list(xm.getReadPairs(s1, s2))
+    o1, o2 = io.StringIO(t1), io.StringIO(t2)
+    H.ORACLE.read_header(o1), H.ORACLE.read_header(o2)
+    assert pairs == list(H.ORACLE.read_pairs(o1, o2))
+    assert len(pairs) == 476
+    # skip_repeated_reads and the mixed-whitespace single-end fixture
+    t1, t2 = H.case_texts(g3["all36_se_skip"])
+    s1, s2 = io.StringIO(t1), io.StringIO(t2)
+    xm.get_sam_header(s1), xm.get_sam_header(s2)
+    assert len(list(xm.getReadPairs(s1, s2, skip_repeated_reads=True))) == g3["all36_se_skip"]["expect"]["n_records"]
+    # summary (tests/test_xenomapper.py:235-245)
+    buf = io.StringIO()
+    xm.output_summary({'foo': 1, 'bar': 101}, outfile=buf)
+    assert buf.getvalue() == H.ORACLE.summary_text({'foo': 1, 'bar': 101})
+    # name mismatch -> AssertionError from the reader
+    a = io.StringIO("r1\t0\n")
+    b = io.StringIO("r2\t0\n")
+    with pytest.raises(AssertionError):
+        list(xm.getReadPairs(a, b))
+    with pytest.raises(IndexError):
+        xm.get_sam_header(io.StringIO("@HD\tVN:1.0\n"))

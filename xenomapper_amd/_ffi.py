@@ -1,0 +1,251 @@
+"""ctypes binding of the C ABI in include/xenomapper_hip.h.
+
+There is no CPU fallback: if libxenomapper_hip.so is missing, or no gfx950 device is present,
+every entry point raises.  `Context` mirrors the C calls one to one; NumPy arrays go through the
+host-buffer entry points, torch device tensors through the *_dev entry points.
+"""
+from __future__ import annotations
+
+import ctypes
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libxenomapper_hip.so")
+
+MODE_SE, MODE_PE_LIBERAL, MODE_PE_CONSERVATIVE = 0, 1, 2
+NO_UNIT = 0xFF
+ABSENT = -2**31
+MAX_RECORDS = 0xFFFFF000
+KERNELS = ("classify", "hist", "scan", "scatter", "cigar")
+
+XM_OK = 0
+_ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, -5: OverflowError}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 (soname libamdhip64.so.7)
+    but asks for it as `libamdhip64.so`, so if this library pulled in /opt/rocm's copy first, a later
+    `import torch` would bring up a second runtime and one of the two would see no device.  When torch
+    is installed, load its copy first; both then resolve to the same runtime."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def lib():
+    """The loaded shared library; raises HipExtensionMissing when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            "%s is missing: build it with `python -m xenomapper_amd.build` (there is no CPU fallback)" % LIB_PATH)
+    _preload_hip_runtime()
+    L = ctypes.CDLL(LIB_PATH)
+    P, I, U64, I32, F64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int32, ctypes.c_double
+    sig = {
+        "xm_abi_version": ([], I),
+        "xm_strerror": ([I], ctypes.c_char_p),
+        "xm_last_hip_error": ([P], ctypes.c_char_p),
+        "xm_ctx_create": ([I, ctypes.POINTER(P)], I),
+        "xm_ctx_destroy": ([P], I),
+        "xm_ctx_device_info": ([P, ctypes.POINTER(I), ctypes.c_char_p, ctypes.c_size_t], I),
+        "xm_classify": ([P, I, U64, P, P, P, P, P, I32, P, P], I),
+        "xm_classify_f64": ([P, I, U64, P, P, P, P, P, F64, P, P], I),
+        "xm_cigar_scores": ([P, U64, P, P, P, P], I),
+        "xm_compact": ([P, I, U64, P, P, P, P], I),
+        "xm_classify_dev": ([P, P, I, U64, P, P, P, P, P, I32, P], I),
+        "xm_classify_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P], I),
+        "xm_cigar_scores_dev": ([P, P, U64, P, P, P, P, P], I),
+        "xm_compact_dev": ([P, P, I, U64, P, P, P, P], I),
+        "xm_timing_enable": ([P, I], I),
+        "xm_timing_reset": ([P], I),
+        "xm_timing_read": ([P, P, P], I),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = L
+    return L
+
+
+EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create", "xm_ctx_destroy",
+            "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_compact",
+            "xm_classify_dev", "xm_classify_f64_dev", "xm_cigar_scores_dev", "xm_compact_dev",
+            "xm_timing_enable", "xm_timing_reset", "xm_timing_read")
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _as(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class Context(object):
+    """One classifier context on one GPU (xm_ctx)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = ctypes.c_void_p()
+        rc = self._L.xm_ctx_create(int(device), ctypes.byref(h))
+        if rc != XM_OK:
+            raise _ERRORS.get(rc, RuntimeError)(
+                "xm_ctx_create(device=%d): %s [%s]" % (device, self._L.xm_strerror(rc).decode(),
+                                                       self._L.xm_last_hip_error(None).decode()))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.xm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc == XM_OK:
+            return
+        msg = "%s: %s" % (what, self._L.xm_strerror(rc).decode())
+        detail = self._L.xm_last_hip_error(self._h).decode()
+        if detail and rc in (-3, -4):
+            msg += " [" + detail + "]"
+        raise _ERRORS.get(rc, RuntimeError)(msg)
+
+    def device_info(self):
+        n_cu = ctypes.c_int()
+        buf = ctypes.create_string_buffer(128)
+        self._check(self._L.xm_ctx_device_info(self._h, ctypes.byref(n_cu), buf, 128), "xm_ctx_device_info")
+        return {"n_cu": n_cu.value, "name": buf.value.decode()}
+
+    # ---- host-buffer entry points (NumPy) --------------------------------------------------
+    def classify(self, mode, as1, xs1, as2, xs2, unit_bits, min_score_floor):
+        cols = [_as(c, np.int32) for c in (as1, xs1, as2, xs2)]
+        n = cols[0].shape[0]
+        bits = _as(unit_bits, np.uint64)
+        assert bits.shape[0] >= (n + 63) // 64 and all(c.shape[0] == n for c in cols)
+        code = np.empty(n, dtype=np.uint8)
+        counts = np.zeros(64, dtype=np.uint64)
+        rc = self._L.xm_classify(self._h, mode, n, *[_np_ptr(c) for c in cols], _np_ptr(bits),
+                                 int(min_score_floor), _np_ptr(code), _np_ptr(counts))
+        self._check(rc, "xm_classify")
+        return code, counts
+
+    def classify_f64(self, mode, as1, xs1, as2, xs2, unit_bits, min_score):
+        cols = [_as(c, np.float64) for c in (as1, xs1, as2, xs2)]
+        n = cols[0].shape[0]
+        bits = _as(unit_bits, np.uint64)
+        assert bits.shape[0] >= (n + 63) // 64 and all(c.shape[0] == n for c in cols)
+        code = np.empty(n, dtype=np.uint8)
+        counts = np.zeros(64, dtype=np.uint64)
+        rc = self._L.xm_classify_f64(self._h, mode, n, *[_np_ptr(c) for c in cols], _np_ptr(bits),
+                                     float(min_score), _np_ptr(code), _np_ptr(counts))
+        self._check(rc, "xm_classify_f64")
+        return code, counts
+
+    def cigar_scores(self, nm, cig_off, cig_oplen):
+        nm = _as(nm, np.int32)
+        off = _as(cig_off, np.uint32)
+        ops = _as(cig_oplen, np.uint32)
+        n = nm.shape[0]
+        assert off.shape[0] == n + 1 and ops.shape[0] >= (int(off[-1]) if n else 0)
+        if ops.shape[0] == 0:
+            ops = np.zeros(1, dtype=np.uint32)
+        out = np.empty(n, dtype=np.int32)
+        rc = self._L.xm_cigar_scores(self._h, n, _np_ptr(nm), _np_ptr(off), _np_ptr(ops), _np_ptr(out))
+        self._check(rc, "xm_cigar_scores")
+        return out
+
+    def compact(self, mode, code):
+        code = _as(code, np.uint8)
+        n = code.shape[0]
+        idx = np.empty(max(n, 1), dtype=np.uint32)
+        off = np.zeros(8, dtype=np.uint64)
+        counts = np.zeros(64, dtype=np.uint64)
+        rc = self._L.xm_compact(self._h, mode, n, _np_ptr(code), _np_ptr(idx), _np_ptr(off), _np_ptr(counts))
+        self._check(rc, "xm_compact")
+        return idx[:int(off[7])], off, counts
+
+    # ---- device-resident entry points (torch tensors on this context's GPU) --------------
+    @staticmethod
+    def _stream_handle(stream):
+        if stream is None:
+            import torch
+            return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ctypes.c_void_p(getattr(stream, "cuda_stream", stream))
+
+    def classify_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, code_out, stream=None):
+        """Columns int32 (min_score = int floor) or float64 (min_score = float).  Asynchronous."""
+        n = as1.numel()
+        st = self._stream_handle(stream)
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (as1, xs1, as2, xs2, unit_bits)]
+        if as1.element_size() == 4:
+            rc = self._L.xm_classify_dev(self._h, st, mode, n, *ptrs, int(min_score),
+                                         ctypes.c_void_p(code_out.data_ptr()))
+        else:
+            rc = self._L.xm_classify_f64_dev(self._h, st, mode, n, *ptrs, float(min_score),
+                                             ctypes.c_void_p(code_out.data_ptr()))
+        self._check(rc, "xm_classify_dev")
+
+    def cigar_scores_dev(self, nm, cig_off, cig_oplen, as_out, range_flag=None, stream=None):
+        rc = self._L.xm_cigar_scores_dev(
+            self._h, self._stream_handle(stream), nm.numel(), ctypes.c_void_p(nm.data_ptr()),
+            ctypes.c_void_p(cig_off.data_ptr()), ctypes.c_void_p(cig_oplen.data_ptr()),
+            ctypes.c_void_p(as_out.data_ptr()),
+            ctypes.c_void_p(range_flag.data_ptr()) if range_flag is not None else None)
+        self._check(rc, "xm_cigar_scores_dev")
+
+    def compact_dev(self, mode, code, idx_out, bin_offsets, counts, stream=None):
+        rc = self._L.xm_compact_dev(
+            self._h, self._stream_handle(stream), mode, code.numel(), ctypes.c_void_p(code.data_ptr()),
+            ctypes.c_void_p(idx_out.data_ptr()), ctypes.c_void_p(bin_offsets.data_ptr()),
+            ctypes.c_void_p(counts.data_ptr()))
+        self._check(rc, "xm_compact_dev")
+
+    # ---- timing --------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self._L.xm_timing_enable(self._h, 1 if on else 0), "xm_timing_enable")
+
+    def timing_reset(self):
+        self._check(self._L.xm_timing_reset(self._h), "xm_timing_reset")
+
+    def timing_read(self):
+        ms = (ctypes.c_double * len(KERNELS))()
+        launches = (ctypes.c_uint64 * len(KERNELS))()
+        self._check(self._L.xm_timing_read(self._h, ms, launches), "xm_timing_read")
+        return {k: {"ms": ms[i], "launches": int(launches[i])} for i, k in enumerate(KERNELS)}

@@ -1,0 +1,79 @@
+"""In-tree build of the native parts (hipcc cross-compiles gfx950 without a GPU).
+
+    python -m xenomapper_amd.build        # libxenomapper_hip.so (+ host parser when present)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HIP_LIB = os.path.join(PKG, "libxenomapper_hip.so")
+HOST_LIB = os.path.join(PKG, "libxenomapper_host.so")
+
+HIP_SOURCES = ["xm_kernels.hip", "xm_api.hip"]
+HOST_SOURCES = ["xm_sam.cpp"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "xm_kernels.h"), os.path.join(REPO, "include", "xenomapper_hip.h")]
+    if not force and not _stale(HIP_LIB, deps):
+        return HIP_LIB
+    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+           "-I", os.path.join(REPO, "include")] + srcs + ["-o", HIP_LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_host(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    if not all(os.path.exists(s) for s in srcs):
+        return None
+    deps = srcs + [os.path.join(REPO, "include", "xenomapper_host.h")]
+    if not force and not _stale(HOST_LIB, deps):
+        return HOST_LIB
+    cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra",
+           "-I", os.path.join(REPO, "include")] + srcs + ["-o", HOST_LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_oracle(verbose=False):
+    """The C oracle is test infrastructure; building it here is not using it."""
+    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s"])
+    return os.path.join(REPO, "oracle", "libxm_oracle.so")
+
+
+def build_all(force=False, verbose=False):
+    out = [build_hip(force, verbose)]
+    host = build_host(force, verbose)
+    if host:
+        out.append(host)
+    return out
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force="--force" in sys.argv, verbose=True)))

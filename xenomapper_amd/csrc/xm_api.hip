@@ -1,0 +1,440 @@
+// xm_api.hip -- the C ABI declared in include/xenomapper_hip.h: context, workspace, the
+// host-buffer convenience entry points, the device-resident entry points and per-kernel timing.
+// No CPU fallback lives here: every entry point needs a context, and a context needs a gfx950 device.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "xm_kernels.h"
+
+struct TimedSpan {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+struct xm_ctx {
+    int device;
+    int n_cu;
+    char name[128];
+    uint32_t max_blocks;            // grid cap for the streaming kernels: 8 workgroups per CU
+    // K2 workspace (fixed size, allocated once)
+    uint32_t *d_chunk_counts;
+    uint32_t *d_chunk_off;
+    // scratch of the host-buffer entry points (grown on demand, never inside *_dev calls)
+    void *d_scratch[8];
+    size_t scratch_bytes[8];
+    // timing
+    bool timing;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> free_events;
+    double acc_ms[XM_K_COUNT];
+    uint64_t acc_launches[XM_K_COUNT];
+    std::string last_error;
+};
+
+namespace {
+
+std::string g_create_error;      // why the last xm_ctx_create() failed (read with xm_last_hip_error(NULL))
+
+int fail_hip(xm_ctx *ctx, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    if (ctx) ctx->last_error = buf;
+    else g_create_error = buf;
+    return (e == hipErrorOutOfMemory) ? XM_ERR_OOM : XM_ERR_HIP;
+}
+
+int no_device(const char *what, hipError_t e)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s%s%s", what, e == hipSuccess ? "" : ": ", e == hipSuccess ? "" : hipGetErrorString(e));
+    g_create_error = buf;
+    return XM_ERR_NO_DEVICE;
+}
+
+#define XM_HIP(ctx, call)                                        \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return fail_hip((ctx), e_, #call); \
+    } while (0)
+
+int ensure_scratch(xm_ctx *ctx, int slot, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (ctx->scratch_bytes[slot] >= bytes) return XM_OK;
+    if (ctx->d_scratch[slot]) {
+        XM_HIP(ctx, hipFree(ctx->d_scratch[slot]));
+        ctx->d_scratch[slot] = nullptr;
+        ctx->scratch_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    XM_HIP(ctx, hipMalloc(&ctx->d_scratch[slot], want));
+    ctx->scratch_bytes[slot] = want;
+    return XM_OK;
+}
+
+hipEvent_t take_event(xm_ctx *ctx)
+{
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct Span {
+    xm_ctx *ctx;
+    hipStream_t st;
+    TimedSpan sp;
+    bool on;
+    Span(xm_ctx *c, hipStream_t s, int kernel) : ctx(c), st(s), on(c->timing)
+    {
+        if (!on) return;
+        sp.kernel = kernel;
+        sp.start = take_event(ctx);
+        sp.stop = take_event(ctx);
+        if (!sp.start || !sp.stop) { on = false; return; }
+        (void)hipEventRecord(sp.start, st);
+    }
+    ~Span()
+    {
+        if (!on) return;
+        (void)hipEventRecord(sp.stop, st);
+        ctx->spans.push_back(sp);
+    }
+};
+
+int check_launch(xm_ctx *ctx, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(ctx, e, what);
+    return XM_OK;
+}
+
+bool bad_mode(int mode) { return mode < XM_MODE_SE || mode > XM_MODE_PE_CONSERVATIVE; }
+
+}  // namespace
+
+extern "C" {
+
+int xm_abi_version(void) { return XM_ABI_VERSION; }
+
+const char *xm_strerror(int status)
+{
+    switch (status) {
+    case XM_OK: return "ok";
+    case XM_ERR_INVALID_ARG: return "invalid argument";
+    case XM_ERR_NO_DEVICE: return "no usable gfx950 (MI355X) device";
+    case XM_ERR_HIP: return "HIP runtime error";
+    case XM_ERR_OOM: return "out of device memory";
+    case XM_ERR_RANGE: return "CIGAR-derived score outside int32";
+    default: return "unknown status";
+    }
+}
+
+const char *xm_last_hip_error(const xm_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int xm_ctx_create(int device_id, xm_ctx **out)
+{
+    if (!out) return XM_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t he = hipGetDeviceCount(&n_dev);
+    if (he != hipSuccess || n_dev <= 0) return no_device("hipGetDeviceCount found no device", he);
+    if (device_id < 0 || device_id >= n_dev) return XM_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if ((he = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return no_device("hipGetDeviceProperties", he);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {                           // code objects are gfx950 only
+        char buf[200];
+        snprintf(buf, sizeof buf, "device %d is %s, not gfx950", device_id, prop.gcnArchName);
+        return no_device(buf, hipSuccess);
+    }
+    if ((he = hipSetDevice(device_id)) != hipSuccess) return no_device("hipSetDevice", he);
+
+    xm_ctx *ctx = new xm_ctx();
+    ctx->device = device_id;
+    ctx->n_cu = prop.multiProcessorCount;
+    snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+    ctx->max_blocks = (uint32_t)ctx->n_cu * 8u;
+    ctx->d_chunk_counts = nullptr;
+    ctx->d_chunk_off = nullptr;
+    for (int i = 0; i < 8; ++i) { ctx->d_scratch[i] = nullptr; ctx->scratch_bytes[i] = 0; }
+    ctx->timing = false;
+    for (int k = 0; k < XM_K_COUNT; ++k) { ctx->acc_ms[k] = 0.0; ctx->acc_launches[k] = 0; }
+    const size_t ws = (size_t)XM_MAX_CHUNKS * 8 * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void **)&ctx->d_chunk_counts, ws);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_chunk_off, ws);
+    if (e != hipSuccess) {
+        if (ctx->d_chunk_counts) (void)hipFree(ctx->d_chunk_counts);
+        delete ctx;
+        return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
+    }
+    *out = ctx;
+    return XM_OK;
+}
+
+int xm_ctx_destroy(xm_ctx *ctx)
+{
+    if (!ctx) return XM_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }
+    for (auto &e : ctx->free_events) (void)hipEventDestroy(e);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
+    (void)hipFree(ctx->d_chunk_counts);
+    (void)hipFree(ctx->d_chunk_off);
+    delete ctx;
+    return XM_OK;
+}
+
+int xm_ctx_device_info(const xm_ctx *ctx, int *n_cu, char *name, size_t name_len)
+{
+    if (!ctx) return XM_ERR_INVALID_ARG;
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (name && name_len) snprintf(name, name_len, "%s", ctx->name);
+    return XM_OK;
+}
+
+/* ---- device-resident entry points ------------------------------------------------------ */
+
+int xm_classify_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                    const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                    const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 15u) || ((uintptr_t)code_out & 3u))
+        return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_i32(st, ctx->max_blocks, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out);
+    }
+    return check_launch(ctx, "classify_kernel<int32>");
+}
+
+int xm_classify_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                        const double *as1, const double *xs1, const double *as2, const double *xs2,
+                        const uint64_t *unit_bits, double min_score, uint8_t *code_out)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || ((uintptr_t)code_out & 3u))
+        return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_f64(st, ctx->max_blocks, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out);
+    }
+    return check_launch(ctx, "classify_kernel<f64>");
+}
+
+int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n, const int32_t *nm,
+                        const uint32_t *cig_off, const uint32_t *cig_oplen, int32_t *as_out,
+                        uint32_t *range_flag)
+{
+    if (!ctx || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!nm || !cig_off || !cig_oplen || !as_out) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Span span(ctx, st, XM_K_CIGAR);
+        xm::launch_cigar(st, ctx->max_blocks, n, nm, cig_off, cig_oplen, as_out, range_flag);
+    }
+    return check_launch(ctx, "cigar_kernel");
+}
+
+int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_t *code,
+                   uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    XM_HIP(ctx, hipMemsetAsync(counts, 0, 64 * sizeof(uint64_t), st));
+    if (n == 0) {
+        XM_HIP(ctx, hipMemsetAsync(bin_offsets, 0, 8 * sizeof(uint64_t), st));
+        return XM_OK;
+    }
+    if (!code || !idx_out || ((uintptr_t)code & 15u)) return XM_ERR_INVALID_ARG;
+    const xm::ChunkPlan plan = xm::plan_chunks(n, XM_MAX_CHUNKS);
+    int rc;
+    {
+        Span span(ctx, st, XM_K_HIST);
+        xm::launch_hist(st, plan, mode, n, code, ctx->d_chunk_counts, counts);
+    }
+    if ((rc = check_launch(ctx, "hist_kernel")) != XM_OK) return rc;
+    {
+        Span span(ctx, st, XM_K_SCAN);
+        xm::launch_scan(st, plan, ctx->d_chunk_counts, ctx->d_chunk_off, bin_offsets);
+    }
+    if ((rc = check_launch(ctx, "scan_kernel")) != XM_OK) return rc;
+    {
+        Span span(ctx, st, XM_K_SCATTER);
+        xm::launch_scatter(st, plan, mode, n, code, ctx->d_chunk_off, idx_out);
+    }
+    return check_launch(ctx, "scatter_kernel");
+}
+
+/* ---- host-buffer entry points ------------------------------------------------------------ */
+
+static int classify_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const void *as1, const void *xs1,
+                         const void *as2, const void *xs2, const uint64_t *unit_bits, int32_t mi, double mf,
+                         uint8_t *code_out, uint64_t counts[64])
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (counts) memset(counts, 0, 64 * sizeof(uint64_t));
+    if (n == 0) return XM_OK;
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t col_bytes = (size_t)n * elem;
+    const size_t bits_bytes = (size_t)((n + 63) / 64) * 8;
+    const void *src[4] = {as1, xs1, as2, xs2};
+    int rc;
+    for (int c = 0; c < 4; ++c) {
+        if ((rc = ensure_scratch(ctx, c, col_bytes)) != XM_OK) return rc;
+        XM_HIP(ctx, hipMemcpy(ctx->d_scratch[c], src[c], col_bytes, hipMemcpyHostToDevice));
+    }
+    if ((rc = ensure_scratch(ctx, 4, bits_bytes)) != XM_OK) return rc;
+    XM_HIP(ctx, hipMemcpy(ctx->d_scratch[4], unit_bits, bits_bytes, hipMemcpyHostToDevice));
+    if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
+    if (elem == 4)
+        rc = xm_classify_dev(ctx, nullptr, mode, n, (const int32_t *)ctx->d_scratch[0], (const int32_t *)ctx->d_scratch[1],
+                             (const int32_t *)ctx->d_scratch[2], (const int32_t *)ctx->d_scratch[3],
+                             (const uint64_t *)ctx->d_scratch[4], mi, d_code);
+    else
+        rc = xm_classify_f64_dev(ctx, nullptr, mode, n, (const double *)ctx->d_scratch[0], (const double *)ctx->d_scratch[1],
+                                 (const double *)ctx->d_scratch[2], (const double *)ctx->d_scratch[3],
+                                 (const uint64_t *)ctx->d_scratch[4], mf, d_code);
+    if (rc != XM_OK) return rc;
+    XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
+    if (counts) {
+        for (uint64_t i = 0; i < n; ++i)
+            if (code_out[i] != XM_NO_UNIT) counts[code_out[i] & 63u]++;
+    }
+    return XM_OK;
+}
+
+int xm_classify(xm_ctx *ctx, int mode, uint64_t n,
+                const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint64_t counts[64])
+{
+    return classify_host(ctx, mode, n, sizeof(int32_t), as1, xs1, as2, xs2, unit_bits, min_score_floor, 0.0,
+                         code_out, counts);
+}
+
+int xm_classify_f64(xm_ctx *ctx, int mode, uint64_t n,
+                    const double *as1, const double *xs1, const double *as2, const double *xs2,
+                    const uint64_t *unit_bits, double min_score, uint8_t *code_out, uint64_t counts[64])
+{
+    return classify_host(ctx, mode, n, sizeof(double), as1, xs1, as2, xs2, unit_bits, 0, min_score, code_out, counts);
+}
+
+int xm_cigar_scores(xm_ctx *ctx, uint64_t n, const int32_t *nm, const uint32_t *cig_off,
+                    const uint32_t *cig_oplen, int32_t *as_out)
+{
+    if (!ctx || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!nm || !cig_off || !as_out) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_ops = cig_off[n];
+    if (n_ops && !cig_oplen) return XM_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, n * 4)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 1, (n + 1) * 4)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 2, n_ops * 4)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 3, n * 4)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 6, 16)) != XM_OK) return rc;
+    XM_HIP(ctx, hipMemcpy(ctx->d_scratch[0], nm, n * 4, hipMemcpyHostToDevice));
+    XM_HIP(ctx, hipMemcpy(ctx->d_scratch[1], cig_off, (n + 1) * 4, hipMemcpyHostToDevice));
+    if (n_ops) XM_HIP(ctx, hipMemcpy(ctx->d_scratch[2], cig_oplen, n_ops * 4, hipMemcpyHostToDevice));
+    XM_HIP(ctx, hipMemset(ctx->d_scratch[6], 0, 16));
+    rc = xm_cigar_scores_dev(ctx, nullptr, n, (const int32_t *)ctx->d_scratch[0], (const uint32_t *)ctx->d_scratch[1],
+                             (const uint32_t *)ctx->d_scratch[2], (int32_t *)ctx->d_scratch[3],
+                             (uint32_t *)ctx->d_scratch[6]);
+    if (rc != XM_OK) return rc;
+    uint32_t flag = 0;
+    XM_HIP(ctx, hipMemcpy(as_out, ctx->d_scratch[3], n * 4, hipMemcpyDeviceToHost));
+    XM_HIP(ctx, hipMemcpy(&flag, ctx->d_scratch[6], 4, hipMemcpyDeviceToHost));
+    return flag ? XM_ERR_RANGE : XM_OK;
+}
+
+int xm_compact(xm_ctx *ctx, int mode, uint64_t n, const uint8_t *code, uint32_t *idx_out,
+               uint64_t bin_offsets[8], uint64_t counts[64])
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || !bin_offsets) return XM_ERR_INVALID_ARG;
+    memset(bin_offsets, 0, 8 * sizeof(uint64_t));
+    if (counts) memset(counts, 0, 64 * sizeof(uint64_t));
+    if (n == 0) return XM_OK;
+    if (!code || !idx_out) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 6, (size_t)n * 4)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 7, 72 * sizeof(uint64_t))) != XM_OK) return rc;
+    uint64_t *d_off = (uint64_t *)ctx->d_scratch[7];
+    uint64_t *d_counts = d_off + 8;
+    XM_HIP(ctx, hipMemcpy(ctx->d_scratch[5], code, (size_t)n, hipMemcpyHostToDevice));
+    rc = xm_compact_dev(ctx, nullptr, mode, n, (const uint8_t *)ctx->d_scratch[5], (uint32_t *)ctx->d_scratch[6],
+                        d_off, d_counts);
+    if (rc != XM_OK) return rc;
+    uint64_t host[72];
+    XM_HIP(ctx, hipMemcpy(host, d_off, sizeof host, hipMemcpyDeviceToHost));
+    memcpy(bin_offsets, host, 8 * sizeof(uint64_t));
+    if (counts) memcpy(counts, host + 8, 64 * sizeof(uint64_t));
+    if (host[7]) XM_HIP(ctx, hipMemcpy(idx_out, ctx->d_scratch[6], (size_t)host[7] * 4, hipMemcpyDeviceToHost));
+    return XM_OK;
+}
+
+/* ---- timing -------------------------------------------------------------------------------- */
+
+int xm_timing_enable(xm_ctx *ctx, int on)
+{
+    if (!ctx) return XM_ERR_INVALID_ARG;
+    ctx->timing = on != 0;
+    return XM_OK;
+}
+
+static int drain_spans(xm_ctx *ctx)
+{
+    for (auto &sp : ctx->spans) {
+        XM_HIP(ctx, hipEventSynchronize(sp.stop));
+        float ms = 0.f;
+        XM_HIP(ctx, hipEventElapsedTime(&ms, sp.start, sp.stop));
+        ctx->acc_ms[sp.kernel] += (double)ms;
+        ctx->acc_launches[sp.kernel] += 1;
+        ctx->free_events.push_back(sp.start);
+        ctx->free_events.push_back(sp.stop);
+    }
+    ctx->spans.clear();
+    return XM_OK;
+}
+
+int xm_timing_reset(xm_ctx *ctx)
+{
+    if (!ctx) return XM_ERR_INVALID_ARG;
+    int rc = drain_spans(ctx);
+    for (int k = 0; k < XM_K_COUNT; ++k) { ctx->acc_ms[k] = 0.0; ctx->acc_launches[k] = 0; }
+    return rc;
+}
+
+int xm_timing_read(xm_ctx *ctx, double ms[XM_K_COUNT], uint64_t launches[XM_K_COUNT])
+{
+    if (!ctx || !ms || !launches) return XM_ERR_INVALID_ARG;
+    int rc = drain_spans(ctx);
+    for (int k = 0; k < XM_K_COUNT; ++k) { ms[k] = ctx->acc_ms[k]; launches[k] = ctx->acc_launches[k]; }
+    return rc;
+}
+
+}  // extern "C"

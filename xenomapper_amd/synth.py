@@ -19,6 +19,8 @@ second-best score lives in a ZS:i field and XS:A:+/- is a strand tag.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 ABSENT = np.int32(np.iinfo(np.int32).min)      # the integer stand-in for float('-inf')
@@ -305,3 +307,80 @@ def sam_text_pair(n_pairs, seed, profile="bowtie2", paired=True, read_len=150,
         texts.append("\n".join(lines) + "\n")
     info = {"n_records": n, "name_of": name_of, "as1": as1, "xs1": xs1, "as2": as2, "xs2": xs2, "cigar": cig}
     return texts[0], texts[1], info
+
+
+# ----------------------------------------------------------------------------------------
+# device-side generator for the large configurations (same score model, torch RNG)
+# ----------------------------------------------------------------------------------------
+
+def score_columns_torch(n_pairs, seed, device, profile="bowtie2", chunk_pairs=1 << 24):
+    """score_columns() drawn with torch on `device` (so 50 M pairs take milliseconds on the GPU
+    instead of a minute of NumPy).  Same distributions, different random stream.  Returns torch
+    tensors: as1, xs1, as2, xs2 int32[2*n_pairs], unit_bits int64[ceil(n/64)] (bit pattern of uint64)."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    absent = int(ABSENT)
+    n = 2 * n_pairs
+    out = {k: torch.empty(n, dtype=torch.int32, device=device) for k in ("as1", "xs1", "as2", "xs2")}
+
+    def rand(m):
+        return torch.rand(m, generator=gen, device=device)
+
+    def randint(lo, hi, m):
+        return torch.randint(lo, hi, (m,), generator=gen, device=device, dtype=torch.int32)
+
+    def geometric(p, m):          # support 1, 2, ...
+        u = rand(m).clamp_min(1e-12)
+        return (torch.log(u) / math.log1p(-p)).floor().to(torch.int32) + 1
+
+    def where_absent(keep, v):
+        return torch.where(keep, v, torch.full_like(v, absent))
+
+    def home(m):
+        mapped = rand(m) < 0.98
+        if profile == "hisat":
+            a = -torch.clamp(3 * (geometric(0.25, m) - 1), max=90)
+            has_x = rand(m) < 0.35
+            same = rand(m) < 0.25
+            x = torch.where(same, a, a - randint(1, 31, m))
+        else:
+            a = torch.clamp(300 - 2 * (geometric(0.08, m) - 1), 61, 300)
+            has_x = rand(m) < 0.35
+            same = rand(m) < 0.25
+            below = 61 + (rand(m) * torch.clamp(a - 61, min=1)).to(torch.int32)
+            below = torch.minimum(below, torch.clamp(a - 1, min=61))
+            x = torch.where(same, a, below)
+        return where_absent(mapped, a), where_absent(mapped & has_x, x)
+
+    def away(m):
+        mapped = rand(m) < 0.15
+        has_x = rand(m) < 0.4
+        if profile == "hisat":
+            a = -randint(10, 91, m)
+            x = a - randint(0, 31, m)
+        else:
+            a = randint(61, 221, m)
+            x = torch.minimum(61 + (rand(m) * (a - 60)).to(torch.int32), a)
+        return where_absent(mapped, a), where_absent(mapped & has_x, x)
+
+    for p0 in range(0, n_pairs, chunk_pairs):
+        p1 = min(n_pairs, p0 + chunk_pairs)
+        m = 2 * (p1 - p0)
+        u = rand(p1 - p0)
+        origin = ((u >= 0.86).to(torch.int8) + (u >= 0.95).to(torch.int8) + (u >= 0.98).to(torch.int8))
+        origin = origin.repeat_interleave(2)
+        ha, hx = home(m)
+        oa, ox = away(m)
+        _, hx2 = home(m)
+        sec, both, none = origin == 1, origin == 2, origin == 3
+        as1 = torch.where(sec, oa, ha)
+        xs1 = torch.where(sec, ox, hx)
+        as2 = torch.where(sec | both, ha, oa)
+        cx = torch.where((hx2 == absent) | (ha == absent), torch.full_like(ha, absent), torch.minimum(hx2, ha))
+        xs2 = torch.where(sec, hx, torch.where(both, cx, ox))
+        for k, col in zip(("as1", "xs1", "as2", "xs2"), (as1, xs1, as2, xs2)):
+            out[k][2 * p0:2 * p1] = torch.where(none, torch.full_like(col, absent), col)
+    bits = torch.from_numpy(interleaved_unit_bits(n).view(np.int64)).to(device)
+    out["unit_bits"] = bits
+    return out

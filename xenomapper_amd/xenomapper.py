@@ -1,0 +1,628 @@
+"""Drop-in host interface of the MI355X xenograft read classifier.
+
+Same names, argument meaning and error behaviour as the reference module
+``xenomapper/xenomapper.py`` (genomematt/xenomapper v1.0.2) for the classification path:
+
+    get_tag / get_tag_with_ZS_as_XS / get_cigarbased_AS_tag   (:176-256)  the tag_func plugins
+    get_mapping_state                                          (:258-289)
+    main_single_end / main_paired_end / conservative_main_paired_end  (:291-556)
+    getReadPairs, get_sam_header, add_pg_tag, process_headers, output_summary, main (CLI)
+
+What differs is where the work happens.  The host only does text work: it splits lines,
+finds tag fields, compares read names, and writes lines.  Scores travel as structure-of-arrays
+columns through the C ABI (include/xenomapper_hip.h) to HIP kernels on the GPU, which evaluate
+the CIGAR score, the state function, the pair rules, category_counts and the stable split of
+units into the six output bins.  There is no CPU fallback for any of that: without the HIP
+library and a gfx950 device every function below that classifies raises.
+
+Records are buffered in blocks (``BLOCK_RECORDS``); memory stays bounded, and output appears
+block by block instead of line by line.  Everything already decided before an input error is
+written before the exception propagates, as with the reference.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import re
+import subprocess
+import sys
+import textwrap
+from collections import Counter
+
+import numpy as np
+
+from . import _ffi
+
+__version__ = "1.0.2"        # the reference version this is a drop-in for; written into @PG VN (:128)
+
+STATE_NAMES = ("primary_specific", "secondary_specific", "primary_multi", "secondary_multi",
+               "unresolved", "unassigned")
+BLOCK_RECORDS = 1 << 17
+
+_NEG_INF = float("-inf")
+_ABSENT = _ffi.ABSENT
+_I32_MAX = 2**31 - 1
+
+# --------------------------------------------------------------------------------------------
+# device context
+# --------------------------------------------------------------------------------------------
+_context = None
+
+
+def default_context():
+    """The process-wide classifier context (device from XENOMAPPER_DEVICE, else LOCAL_RANK, else 0)."""
+    global _context
+    if _context is None:
+        dev = int(os.environ.get("XENOMAPPER_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _context = _ffi.Context(dev)
+    return _context
+
+
+def set_context(ctx):
+    global _context
+    _context = ctx
+
+
+# --------------------------------------------------------------------------------------------
+# SAM input / headers (host text work)
+# --------------------------------------------------------------------------------------------
+
+def get_sam_header(samfile):
+    """Header lines of a seekable SAM stream; leaves it at the first record (ref :36-46)."""
+    header = []
+    while True:
+        mark = samfile.tell()
+        text = samfile.readline().strip("\n")
+        if text[0] != "@":            # IndexError on a header-only file, as the reference
+            break
+        header.append(text)
+    samfile.seek(mark)
+    return header
+
+
+def _samtools_lines(handle, args):  # pragma: no cover - needs samtools
+    proc = subprocess.Popen("samtools view %s -" % args, stdin=handle, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, shell=True)
+    for raw in proc.stdout:
+        yield raw.decode("ascii")
+
+
+def get_bam_header(bamfile):  # pragma: no cover - needs samtools
+    """Header of a BAM file via `samtools view -H` (ref :48-54)."""
+    lines = [text.strip("\n") for text in _samtools_lines(bamfile, "-H")]
+    bamfile.seek(0)
+    return lines
+
+
+def bam_lines(f):  # pragma: no cover - needs samtools
+    """SAM text lines of a BAM file via `samtools view` (ref :56-64)."""
+    return _samtools_lines(f, "")
+
+
+def _lockstep(next1, next2, skip_repeated_reads):
+    rec1, rec2 = next1(), next2()
+    while rec1 and rec2:
+        assert rec1[0] == rec2[0]
+        yield rec1, rec2
+        name1, name2 = rec1[0], rec2[0]
+        if skip_repeated_reads:
+            while rec1 and rec2 and rec1[0] == name1:
+                rec1 = next1()
+            while rec1 and rec2 and rec2[0] == name2:
+                rec2 = next2()
+        else:
+            rec1, rec2 = next1(), next2()
+
+
+def getReadPairs(sam1, sam2, skip_repeated_reads=False):
+    """Yield (fields1, fields2) for the same read from two SAM streams (ref :95-118).
+
+    Fields are split on any whitespace; iteration ends at the first blank line or EOF of either
+    stream; names must agree (AssertionError); with skip_repeated_reads each stream skips further
+    lines that carry the name just yielded."""
+    return _lockstep(lambda: sam1.readline().strip("\n").split(),
+                     lambda: sam2.readline().strip("\n").split(), skip_repeated_reads)
+
+
+def getBamReadPairs(bamfile1, bamfile2, skip_repeated_reads=False):  # pragma: no cover - needs samtools
+    """As getReadPairs for BAM input read through samtools (ref :66-93)."""
+    it1, it2 = bam_lines(bamfile1), bam_lines(bamfile2)
+
+    class _Done(Exception):
+        pass
+
+    def nxt(it):
+        def f():
+            try:
+                return next(it).strip("\n").split()
+            except StopIteration:
+                raise _Done()
+        return f
+    try:
+        for pair in _lockstep(nxt(it1), nxt(it2), skip_repeated_reads):
+            yield pair
+    except _Done:
+        return
+
+
+def add_pg_tag(sam_header_list, comment=None):
+    """Header plus an @PG line for this program, chained to a trailing @PG, and an optional @CO
+    (ref :120-131)."""
+    header = list(sam_header_list)
+    if any(entry[0] != "@" for entry in header):
+        raise ValueError("Incorrect SAM header format :\n{0}".format("\n".join(header)))
+    chain = ""
+    if header[-1][:3] == "@PG":
+        ident = [tok for tok in header[-1].split() if tok[:2] == "ID"][0]
+        chain = "PP" + ident[2:] + "\t"
+    header.append("@PG\tID:Xenomapper\tPN:Xenomapper\t" + chain + "VN:{0}".format(__version__))
+    if comment:
+        header.append("@CO\t" + comment)
+    return header
+
+
+_HEADER_PLAN = (            # sink keyword, which input's header, @CO text   (ref :151-173)
+    ("primary_specific", 0, "species specific reads"),
+    ("secondary_specific", 1, "species specific reads"),
+    ("primary_multi", 0, "species specific multimapping reads"),
+    ("secondary_multi", 1, "species specific multimapping reads"),
+    ("unassigned", 0, "reads that could not be assigned"),
+    ("unresolved", 0, "reads that could not be resolved"),
+)
+
+
+def process_headers(file1, file2, primary_specific=sys.stdout, secondary_specific=None, primary_multi=None,
+                    secondary_multi=None, unassigned=None, unresolved=None, bam=False):
+    """Read both headers and write each open sink its header (ref :133-174).  primary_specific is
+    written unconditionally; secondary bins get file2's header, the rest file1's."""
+    reader = get_bam_header if bam else get_sam_header
+    headers = (reader(file1), reader(file2))
+    sinks = dict(primary_specific=primary_specific, secondary_specific=secondary_specific,
+                 primary_multi=primary_multi, secondary_multi=secondary_multi, unassigned=unassigned,
+                 unresolved=unresolved)
+    for key, which, comment in _HEADER_PLAN:
+        if key == "primary_specific" or sinks[key]:
+            print("\n".join(add_pg_tag(headers[which], comment=comment)), file=sinks[key])
+
+
+def output_summary(category_counts, outfile=sys.stderr):
+    """Markdown table of the category counts (ref :558-566)."""
+    print("-" * 80, file=outfile)
+    print("Read Count Category Summary\n", file=outfile)
+    print("|       {0:45s}|     {1:10s}  |".format("Category", "Count"), file=outfile)
+    print("|:", "-" * 50, ":|:", "-" * 15, ":|", sep="", file=outfile)
+    for category in sorted(category_counts):
+        print("|  {0:50s}|{1:15d}  |".format(str(category), category_counts[category]), file=outfile)
+    print(file=outfile)
+
+
+# --------------------------------------------------------------------------------------------
+# tag_func plugins
+# --------------------------------------------------------------------------------------------
+
+def _field_with(sam_line, tag):
+    """The single optional field containing `tag` as a substring, or None (ref :186-190)."""
+    found = None
+    for opt in sam_line[11:]:
+        if tag in opt:
+            if found is not None:
+                raise ValueError("SAM line has multiple values of {0}: {1}".format(tag, sam_line))
+            found = opt
+    return found
+
+
+def get_tag(sam_line, tag="AS"):
+    """Value of a numeric optional field as float, -inf when absent (ref :176-191)."""
+    opt = _field_with(sam_line, tag)
+    if opt is None:
+        return _NEG_INF
+    return float(opt.split(":")[-1])
+
+
+def get_tag_with_ZS_as_XS(sam_line, tag="AS"):
+    """get_tag, with requests for XS answered from ZS (HISAT; ref :193-206)."""
+    return get_tag(sam_line, "ZS" if tag == "XS" else tag)
+
+
+_CIGAR_OP = re.compile(r"([0-9]+)([MIDNSHPX=])")
+_OP_CODE = {c: i for i, c in enumerate("MIDNSHP=X")}
+
+
+def _cigar_columns(sam_line):
+    """(NM or None, packed ops) of one line, the pre-parsed form the CIGAR kernel consumes.
+    NM is the first field containing 'NM' (ref :247-250); ops are every <digits><op> match in the
+    CIGAR column (ref :251), packed BAM-style len<<4|op."""
+    nm = None
+    for opt in sam_line[11:]:
+        if "NM" in opt:
+            nm = int(opt.split(":")[-1])
+            break
+    if nm is None:
+        return None, ()
+    if not -_I32_MAX <= nm <= _I32_MAX:
+        raise OverflowError("NM value %d does not fit the int32 column" % nm)
+    ops = []
+    for length, op in _CIGAR_OP.findall(sam_line[5]):
+        length = int(length)
+        if length >= 1 << 28:
+            raise OverflowError("CIGAR operation length %d does not fit the packed column" % length)
+        ops.append((length << 4) | _OP_CODE[op])
+    return nm, ops
+
+
+def get_cigarbased_AS_tag(sam_line, tag="AS"):
+    """AS rebuilt from CIGAR and NM: -6*NM -5*(#I+#D) -3*(sumI+sumD) -2*sumS; other tags as get_tag
+    (ref :228-256).  The arithmetic runs in the CIGAR kernel (xm_cigar_scores)."""
+    if tag != "AS":
+        return get_tag(sam_line, tag)
+    nm, ops = _cigar_columns(sam_line)
+    if nm is None:
+        return _NEG_INF
+    off = np.array([0, len(ops)], dtype=np.uint32)
+    out = default_context().cigar_scores(np.array([nm], dtype=np.int32), off, np.array(ops, dtype=np.uint32))
+    return int(out[0])
+
+
+def get_mapping_state(AS1, XS1, AS2, XS2, min_score=float("-inf")):
+    """Name of the mapping state of one read (ref :258-289), evaluated by the classify kernel in
+    the reference's own arithmetic (binary64)."""
+    cols = [np.array([float(v)], dtype=np.float64) for v in (AS1, XS1, AS2, XS2)]
+    code, _ = default_context().classify_f64(_ffi.MODE_SE, *cols, np.array([1], dtype=np.uint64), float(min_score))
+    state = int(code[0])
+    if state > 5:
+        raise RuntimeError("Error in processing logic with values {0} ".format((AS1, XS1, AS2, XS2)))
+    return STATE_NAMES[state]
+
+
+# --------------------------------------------------------------------------------------------
+# block engine behind the three main loops
+# --------------------------------------------------------------------------------------------
+
+def _floor_min_score(m):
+    if m == _NEG_INF:
+        return _ABSENT
+    if m == -_NEG_INF:
+        return _I32_MAX
+    return int(max(_ABSENT, min(_I32_MAX, math.floor(m))))
+
+
+def _to_int_column(values):
+    """float scores -> int32 column, or None when a value is not representable (then binary64 is used)."""
+    arr = np.asarray(values, dtype=np.float64)
+    present = arr != _NEG_INF
+    ok = np.isfinite(arr[present]).all() and (np.abs(arr[present]) <= _I32_MAX).all() \
+        and (arr[present] == np.floor(arr[present])).all()
+    if not ok:
+        return None
+    out = np.full(arr.shape[0], _ABSENT, dtype=np.int32)
+    out[present] = arr[present].astype(np.int64).astype(np.int32)
+    return out
+
+
+class _Block(object):
+    __slots__ = ("rec1", "rec2", "flags")
+
+    def __init__(self):
+        self.rec1, self.rec2, self.flags = [], [], []
+
+
+def _score_block(block, needed, tag_func, cigar_mode):
+    """Score columns of a block.  Returns (columns dict, n_scored, error): records are scored in
+    index order, each as file-1 AS, file-1 XS, file-2 AS, file-2 XS (the order of ref :408-415);
+    on an exception scoring stops and n_scored is the index of the failing record."""
+    n = len(block.rec1)
+    vals = [[_NEG_INF] * n for _ in range(4)]
+    nm = [[None] * n, [None] * n]
+    ops = [[()] * n, [()] * n]
+    err = None
+    scored = n
+    for i in range(n):
+        if not needed[i]:
+            continue
+        try:
+            for f, rec in ((0, block.rec1[i]), (1, block.rec2[i])):
+                if cigar_mode:
+                    nm[f][i], ops[f][i] = _cigar_columns(rec)
+                    vals[2 * f + 1][i] = get_tag(rec, "XS")
+                else:
+                    vals[2 * f][i] = tag_func(rec, tag="AS")
+                    vals[2 * f + 1][i] = tag_func(rec, tag="XS")
+        except Exception as exc:      # input error: classify what precedes it, then re-raise
+            err = exc
+            scored = i
+            break
+    return vals, nm, ops, scored, err
+
+
+def _cigar_as_column(ctx, nm, ops, n):
+    counts = np.fromiter((len(o) for o in ops[:n]), dtype=np.uint32, count=n)
+    off = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum(counts, out=off[1:])
+    flat = np.fromiter((v for o in ops[:n] for v in o), dtype=np.uint32, count=int(off[-1]))
+    nm_col = np.fromiter((_ABSENT if v is None else v for v in nm[:n]), dtype=np.int32, count=n)
+    return ctx.cigar_scores(nm_col, off, flat)
+
+
+def _classify_block(ctx, mode, block, n, vals, nm, ops, cigar_mode, min_score):
+    """-> (code u8[n], idx u32[units], bin_offsets u64[8], counts u64[64])"""
+    flags = np.asarray(block.flags[:n], dtype=np.uint8)
+    bits = np.packbits(np.concatenate([flags, np.zeros((-n) % 64, dtype=np.uint8)]), bitorder="little").view(np.uint64)
+    int_cols = []
+    for c in range(4):
+        if cigar_mode and c in (0, 2):
+            int_cols.append(_cigar_as_column(ctx, nm[c // 2], ops[c // 2], n))
+        else:
+            int_cols.append(_to_int_column(vals[c][:n]))
+    if all(col is not None for col in int_cols) and min_score == min_score:
+        code, counts = ctx.classify(mode, *int_cols, bits, _floor_min_score(min_score))
+    else:
+        fcols = []
+        for c in range(4):
+            if cigar_mode and c in (0, 2):
+                col = int_cols[c]
+                fcols.append(np.where(col == _ABSENT, _NEG_INF, col.astype(np.float64)))
+            else:
+                fcols.append(np.asarray(vals[c][:n], dtype=np.float64))
+        code, counts = ctx.classify_f64(mode, *fcols, bits, float(min_score))
+    idx, off, _ = ctx.compact(mode, code)
+    return code, idx, off, counts
+
+
+def _lines_of(block, mode, b, i):
+    """Records a unit contributes to bin b (ref :332-350, :423-448, :521-550)."""
+    if mode == _ffi.MODE_SE:
+        ones, twos = (block.rec1[i],), (block.rec2[i],)
+    else:
+        ones, twos = (block.rec1[i - 1], block.rec1[i]), (block.rec2[i - 1], block.rec2[i])
+    if b in (0, 2, 5):
+        return ones
+    if b in (1, 3):
+        return twos
+    return ones + twos
+
+
+def _emit_block(block, mode, code, idx, off, sinks, limit):
+    """Write the units with index < limit.  Bin by bin from the compacted lists when the sinks are
+    distinct objects; in unit order when two bins share a sink (so interleaving matches the reference)."""
+    active = [s for s in sinks if s]
+    if len(set(id(s) for s in active)) == len(active):
+        for b in range(6):
+            sink = sinks[b]
+            if not sink:
+                continue
+            seg = idx[int(off[b]):int(off[b + 1])]
+            if limit is not None:
+                seg = seg[seg < limit]
+            if len(seg) == 0:
+                continue
+            parts = []
+            for i in seg.tolist():
+                for rec in _lines_of(block, mode, b, i):
+                    parts.append("\t".join(rec))
+                    parts.append("\n")
+            sink.write("".join(parts))
+    else:
+        units = np.flatnonzero(code != _ffi.NO_UNIT)
+        bins = np.empty(code.shape[0], dtype=np.uint8)
+        for b in range(6):
+            bins[idx[int(off[b]):int(off[b + 1])]] = b
+        for i in units.tolist():
+            if limit is not None and i >= limit:
+                break
+            b = int(bins[i])
+            if sinks[b]:
+                for rec in _lines_of(block, mode, b, i):
+                    print("\t".join(rec), file=sinks[b])
+
+
+def _run(mode, readpairs, sinks, min_score, tag_func):
+    ctx = default_context()
+    paired = mode != _ffi.MODE_SE
+    cigar_mode = tag_func is get_cigarbased_AS_tag
+    totals = Counter()
+    key_order = []
+
+    def flush(block, pending_error=None):
+        """Classify + emit one block; raises the pending input error (or the state error) afterwards."""
+        n = len(block.rec1)
+        if n:
+            if paired:
+                needed = [False] * n
+                for i in range(1, n):
+                    if block.flags[i]:
+                        needed[i - 1] = needed[i] = True
+            else:
+                needed = [True] * n
+            vals, nm, ops, scored, err = _score_block(block, needed, tag_func, cigar_mode)
+            if err is not None:
+                n = scored                      # units closing at index >= scored are not reached
+                pending_error = err
+            if n:
+                code, idx, off, counts = _classify_block(ctx, mode, block, n, vals, nm, ops, cigar_mode, min_score)
+                limit = None
+                state_error = None
+                if int(off[7]) != int(off[6]):      # a unit fell through every branch (ref :289)
+                    first = int(idx[int(off[6]):int(off[7])].min())
+                    limit = first
+                    c = int(code[first])
+                    j = first - 1 if (paired and (c >> 3) > 5) else first
+                    state_error = RuntimeError("Error in processing logic with values {0} ".format(
+                        tuple(vals[k][j] for k in range(4))))
+                _emit_block(block, mode, code, idx, off, sinks, limit)
+                if state_error is not None:
+                    raise state_error
+                unit_codes = code[code != _ffi.NO_UNIT]
+                uniq, first_at = np.unique(unit_codes, return_index=True)
+                for c in uniq[np.argsort(first_at)].tolist():
+                    key = STATE_NAMES[c] if not paired else (STATE_NAMES[c >> 3], STATE_NAMES[c & 7])
+                    if key not in totals:
+                        key_order.append(key)
+                    totals[key] += int(counts[c])
+        if pending_error is not None:
+            raise pending_error
+
+    block = _Block()
+    prev_name = None
+    iterator = iter(readpairs)
+    while True:
+        try:
+            rec1, rec2 = next(iterator)
+        except StopIteration:
+            break
+        except BaseException as exc:            # the reader failed (e.g. names disagree): drain, then raise
+            flush(block, exc)
+            raise
+        if rec1[0] != rec2[0]:
+            flush(block, AssertionError())
+        block.rec1.append(rec1)
+        block.rec2.append(rec2)
+        if paired:
+            # a record closes a unit when its name equals the previous record's (ref :402-405)
+            block.flags.append(1 if (prev_name is not None and prev_name == rec1[0]) else 0)
+            prev_name = rec1[0]
+        else:
+            block.flags.append(1)
+        if len(block.rec1) >= BLOCK_RECORDS:
+            flush(block)
+            nxt = _Block()
+            if paired:                          # the last record may be the forward mate of the next
+                nxt.rec1.append(block.rec1[-1])
+                nxt.rec2.append(block.rec2[-1])
+                nxt.flags.append(0)
+            block = nxt
+    flush(block)
+    ordered = Counter()
+    for key in key_order:
+        ordered[key] = totals[key]
+    return ordered
+
+
+def _sinks(primary_specific, secondary_specific, primary_multi, secondary_multi, unassigned, unresolved):
+    # indexed by state: 0 PS, 1 SS, 2 PM, 3 SM, 4 unresolved, 5 unassigned
+    return [primary_specific, secondary_specific, primary_multi, secondary_multi, unresolved, unassigned]
+
+
+def main_single_end(readpairs, primary_specific=sys.stdout, secondary_specific=None, primary_multi=None,
+                    secondary_multi=None, unassigned=None, unresolved=None, min_score=float("-inf"),
+                    tag_func=get_tag):
+    """Classify single-end reads (ref :291-352).  Returns a Counter keyed by state name."""
+    return _run(_ffi.MODE_SE, readpairs, _sinks(primary_specific, secondary_specific, primary_multi,
+                                                secondary_multi, unassigned, unresolved), min_score, tag_func)
+
+
+def main_paired_end(readpairs, primary_specific=sys.stdout, secondary_specific=None, primary_multi=None,
+                    secondary_multi=None, unassigned=None, unresolved=None, min_score=float("-inf"),
+                    tag_func=get_tag):
+    """Liberal paired-end loop: a pair goes to the highest-priority state of its mates (ref :354-454).
+    Returns a Counter keyed by (forward_state, reverse_state)."""
+    return _run(_ffi.MODE_PE_LIBERAL, readpairs, _sinks(primary_specific, secondary_specific, primary_multi,
+                                                        secondary_multi, unassigned, unresolved), min_score, tag_func)
+
+
+def conservative_main_paired_end(readpairs, primary_specific=sys.stdout, secondary_specific=None,
+                                 primary_multi=None, secondary_multi=None, unassigned=None, unresolved=None,
+                                 min_score=float("-inf"), tag_func=get_tag):
+    """Conservative paired-end loop: any unassigned mate -> unassigned; unresolved or species-discordant
+    -> unresolved; else highest priority (ref :456-556)."""
+    return _run(_ffi.MODE_PE_CONSERVATIVE, readpairs, _sinks(primary_specific, secondary_specific, primary_multi,
+                                                             secondary_multi, unassigned, unresolved), min_score, tag_func)
+
+
+# --------------------------------------------------------------------------------------------
+# command line (same flags as ref :568-678; wiring as ref :681-743)
+# --------------------------------------------------------------------------------------------
+
+def command_line_interface(*args, **kw):
+    parser = argparse.ArgumentParser(
+        prog="xenomapper", formatter_class=argparse.RawDescriptionHelpFormatter,
+        description=textwrap.dedent("""\
+            Sort reads that were aligned to two genomes (e.g. a human xenograft grown in mouse, a
+            pathogen on its host) into species specific, multimapping, unresolved and unassigned
+            SAM files by comparing the alignment scores of each read in both species.
+
+            Both inputs must hold the same reads in the same order with AS and XS score tags where
+            higher is better (Bowtie2 --local; with -p also use --reorder).  Aligners without AS/XS
+            are supported through --cigar_scores.  Inputs must be seekable files.
+
+            This build evaluates the scores on an AMD MI355X GPU."""),
+        epilog=textwrap.dedent("""\
+            To write BAM from a bash shell use process substitution:
+                xenomapper --primary_specific >(samtools view -bS - > outfilename.bam)
+            """))
+    rt, wt = argparse.FileType("rt"), argparse.FileType("wt")
+    parser.add_argument("--primary_sam", type=rt, default=None,
+                        help="SAM file of the reads aligned to the primary species of interest")
+    parser.add_argument("--secondary_sam", type=rt, default=None,
+                        help="SAM file of the same reads aligned to the secondary or contaminating species")
+    parser.add_argument("--primary_bam", type=argparse.FileType("rb"), default=None,
+                        help="BAM file of the reads aligned to the primary species (needs samtools)")
+    parser.add_argument("--secondary_bam", type=argparse.FileType("rb"), default=None,
+                        help="BAM file of the same reads aligned to the secondary species (needs samtools)")
+    parser.add_argument("--primary_specific", type=wt, default=sys.stdout,
+                        help="SAM output: reads mapping to a specific location in the primary species")
+    parser.add_argument("--secondary_specific", type=wt, default=None,
+                        help="SAM output: reads mapping to a specific location in the secondary species")
+    parser.add_argument("--primary_multi", type=wt, default=None,
+                        help="SAM output: reads multi mapping in the primary species")
+    parser.add_argument("--secondary_multi", type=wt, default=None,
+                        help="SAM output: reads multi mapping in the secondary species")
+    parser.add_argument("--unassigned", type=wt, default=None,
+                        help="SAM output: unassigned (non-mapping) reads")
+    parser.add_argument("--unresolved", type=wt, default=None,
+                        help="SAM output: unresolved reads (map equally well in both species)")
+    parser.add_argument("--paired", action="store_true",
+                        help="the SAM files hold paired reads, forward and reverse once each and interlaced")
+    parser.add_argument("--conservative", action="store_true",
+                        help="conservative allocation of pairs whose mates disagree: species-discordant pairs "
+                             "are unresolved and pairs with an unassigned mate are unassigned")
+    parser.add_argument("--min_score", type=float, default=float("-inf"),
+                        help="reads scoring less than or equal to this are considered unassigned")
+    parser.add_argument("--cigar_scores", action="store_true",
+                        help="derive the score from the CIGAR string and the NM tag (-6 per mismatch, -5 per "
+                             "indel open, -3 per indel base, -2 per soft clipped base) for aligners without AS")
+    parser.add_argument("--use_zs", action="store_true",
+                        help="take the next-best score from the ZS tag instead of XS (HISAT)")
+    parser.add_argument("--version", action="store_true", help="print version information and exit")
+    ns = parser.parse_args(*args, **kw)
+    if ns.version:
+        print(__version__)
+        sys.exit()
+    if (not ns.primary_sam or not ns.secondary_sam) and (not ns.primary_bam or not ns.secondary_bam):
+        print("ERROR: You must provide --primary_sam and --secondary_sam\n or --primary_bam and --secondary_bam\n")
+        parser.print_help()
+        sys.exit(1)
+    return ns
+
+
+def main(argv=None):
+    args = command_line_interface(argv) if argv is not None else command_line_interface()
+    if args.cigar_scores:
+        tag_func = get_cigarbased_AS_tag
+    elif args.use_zs:
+        tag_func = get_tag_with_ZS_as_XS
+    else:
+        tag_func = get_tag
+    sinks = dict(primary_specific=args.primary_specific, secondary_specific=args.secondary_specific,
+                 primary_multi=args.primary_multi, secondary_multi=args.secondary_multi,
+                 unassigned=args.unassigned, unresolved=args.unresolved)
+    skip_repeated = not args.paired
+    if args.primary_sam:
+        process_headers(args.primary_sam, args.secondary_sam, **sinks)
+        readpairs = getReadPairs(args.primary_sam, args.secondary_sam, skip_repeated_reads=skip_repeated)
+    else:  # pragma: no cover - needs samtools
+        process_headers(args.primary_bam, args.secondary_bam, bam=True, **sinks)
+        readpairs = getBamReadPairs(args.primary_bam, args.secondary_bam, skip_repeated_reads=skip_repeated)
+    if args.paired:
+        loop = conservative_main_paired_end if args.conservative else main_paired_end
+    else:
+        loop = main_single_end
+    category_counts = loop(readpairs, min_score=args.min_score, tag_func=tag_func, **sinks)
+    output_summary(category_counts=category_counts)
+    for sink in sinks.values():
+        if sink and sink not in (sys.stdout, sys.stderr):
+            sink.flush()
+
+
+if __name__ == "__main__":  # pragma: no cover
+    main()
