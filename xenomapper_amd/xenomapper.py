@@ -618,7 +618,7 @@ def main(argv=None):
     else:
         loop = main_single_end
     category_counts = loop(readpairs, min_score=args.min_score, tag_func=tag_func, **sinks)
-    output_summary(category_counts=category_counts)
+    output_summary(category_counts=category_counts, outfile=sys.stderr)
     for sink in sinks.values():
         if sink and sink not in (sys.stdout, sys.stderr):
             sink.flush()
