@@ -1,0 +1,125 @@
+// tune_kernels.hip -- on-box A/B harness for the classify kernel variants (not shipped).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I include -I xenomapper_amd/csrc tools/tune_kernels.hip -o /tmp/tune && /tmp/tune
+// Variants are interleaved in one process (guide rule 24); prints median/min per variant.
+#include "../xenomapper_amd/csrc/xm_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// streaming ceiling with the same footprint: 4 x 16 B loads + 4 B store per lane, no arithmetic
+template <bool NT>
+__global__ void __launch_bounds__(256) copy_like(const xm::v4i32 *a, const xm::v4i32 *b, const xm::v4i32 *c, const xm::v4i32 *d, uint32_t *out, uint64_t ngroups)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += stride) {
+        xm::v4i32 va = NT ? __builtin_nontemporal_load(a + g) : a[g];
+        xm::v4i32 vb = NT ? __builtin_nontemporal_load(b + g) : b[g];
+        xm::v4i32 vc = NT ? __builtin_nontemporal_load(c + g) : c[g];
+        xm::v4i32 vd = NT ? __builtin_nontemporal_load(d + g) : d[g];
+        uint32_t r = (uint32_t)(va.x ^ vb.y ^ vc.z ^ vd.w ^ va.w ^ vb.x ^ vc.y ^ vd.z ^ va.y ^ va.z ^ vb.z ^ vb.w ^ vc.x ^ vc.w ^ vd.x ^ vd.y);
+        if (NT) __builtin_nontemporal_store(r, out + g); else out[g] = r;
+    }
+}
+
+struct Variant { const char *name; void (*run)(int grid); };
+
+static int32_t *A1, *X1, *A2, *X2; static uint8_t *BITS; static uint8_t *CODE; static uint64_t N;
+
+template <bool NT, int BLOCK> static void run_cls(int)
+{
+    const uint64_t per_block = (uint64_t)BLOCK * 4;
+    const int grid = (int)((N + per_block - 1) / per_block);
+    xm::classify_kernel<int32_t, true, NT, BLOCK><<<grid, BLOCK>>>(A1, X1, A2, X2, BITS, INT32_MIN, CODE, N);
+}
+template <bool NT, int BLOCK> static void run_cls_se(int)
+{
+    const uint64_t per_block = (uint64_t)BLOCK * 4;
+    const int grid = (int)((N + per_block - 1) / per_block);
+    xm::classify_kernel<int32_t, false, NT, BLOCK><<<grid, BLOCK>>>(A1, X1, A2, X2, BITS, INT32_MIN, CODE, N);
+}
+
+template <bool NT> static void run_copy(int grid)
+{
+    copy_like<NT><<<grid, 256>>>((const xm::v4i32 *)A1, (const xm::v4i32 *)X1, (const xm::v4i32 *)A2, (const xm::v4i32 *)X2, (uint32_t *)CODE, N / 4);
+}
+
+// ---- K2 variants: chunk geometry K (wave tiles per wave) ----
+static uint32_t *CHUNK_COUNTS, *CHUNK_OFF, *IDX; static unsigned long long *BINOFF, *BINTOT, *COUNTS, *COUNTS_REP;
+struct Plan { uint32_t n_chunks, stride; };
+template <int K> static Plan plan_k() { Plan p; uint64_t ch = (uint64_t)K * 4096; p.n_chunks = (uint32_t)((N + ch - 1) / ch); p.stride = (p.n_chunks + 63u) & ~63u; return p; }
+template <int K> static void run_hist(int) { Plan p = plan_k<K>(); xm::hist_kernel<K><<<p.n_chunks, 256>>>(CODE, N, 1, p.stride, CHUNK_COUNTS, COUNTS_REP); }
+template <int K> static void run_scan(int) { Plan p = plan_k<K>(); xm::scan_kernel<<<8, XM_SCAN_THREADS>>>(CHUNK_COUNTS, p.n_chunks, p.stride, CHUNK_OFF, BINTOT, COUNTS_REP, COUNTS); }
+template <int K> static void run_scatter(int) { Plan p = plan_k<K>(); xm::scatter_kernel<1, K><<<p.n_chunks, 256>>>(CODE, N, p.stride, CHUNK_OFF, BINTOT, BINOFF, IDX); }
+
+int main(int argc, char **argv)
+{
+    N = argc > 1 ? strtoull(argv[1], 0, 10) : 100000000ull;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 15;
+    CK(hipMalloc(&A1, N * 4)); CK(hipMalloc(&X1, N * 4)); CK(hipMalloc(&A2, N * 4)); CK(hipMalloc(&X2, N * 4));
+    CK(hipMalloc(&BITS, N / 8 + 64)); CK(hipMalloc(&CODE, N + 64));
+    CK(hipMalloc(&CHUNK_COUNTS, 8 * (N / 4096 + 128) * 4)); CK(hipMalloc(&CHUNK_OFF, 8 * (N / 4096 + 128) * 4));
+    CK(hipMalloc(&IDX, N * 4)); CK(hipMalloc(&BINOFF, 64)); CK(hipMalloc(&BINTOT, 64)); CK(hipMalloc(&COUNTS, 512)); CK(hipMalloc(&COUNTS_REP, 64 * 512));
+    CK(hipMemset(COUNTS_REP, 0, 64 * 512));
+    {   // pair-structured scores: ~86 % primary, 9 % secondary, 3 % both, 2 % neither, mates share the origin
+        std::vector<int32_t> a1(N), x1(N), a2(N), x2(N);
+        uint64_t s = 88172645463325252ull;
+        auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 32); };
+        for (uint64_t p = 0; p < N / 2; ++p) {
+            uint32_t o = rnd() % 100; int origin = o < 86 ? 0 : o < 95 ? 1 : o < 98 ? 2 : 3;
+            for (int mte = 0; mte < 2; ++mte) {
+                uint64_t i = 2 * p + mte;
+                int32_t ha = (rnd() % 100 < 98) ? (int32_t)(300 - 2 * (rnd() % 40)) : INT32_MIN;
+                int32_t hx = (ha != INT32_MIN && rnd() % 100 < 35) ? ((rnd() % 4 == 0) ? ha : (int32_t)(61 + rnd() % (ha - 60))) : INT32_MIN;
+                int32_t oa = (rnd() % 100 < 15) ? (int32_t)(61 + rnd() % 160) : INT32_MIN;
+                int32_t ox = (oa != INT32_MIN && rnd() % 100 < 40) ? (int32_t)(61 + rnd() % (oa - 60)) : INT32_MIN;
+                if (origin == 0) { a1[i] = ha; x1[i] = hx; a2[i] = oa; x2[i] = ox; }
+                else if (origin == 1) { a1[i] = oa; x1[i] = ox; a2[i] = ha; x2[i] = hx; }
+                else if (origin == 2) { a1[i] = ha; x1[i] = hx; a2[i] = ha; x2[i] = INT32_MIN; }
+                else { a1[i] = x1[i] = a2[i] = x2[i] = INT32_MIN; }
+            }
+        }
+        CK(hipMemcpy(A1, a1.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X1, x1.data(), N * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(A2, a2.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X2, x2.data(), N * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipMemset(BITS, 0xAA, N / 8 + 64));
+    run_cls<true, 512>(0);
+    CK(hipDeviceSynchronize());
+
+    struct Cfg { const char *name; void (*fn)(int); int grid; double bytes; };
+    const double cls_alg = 16.5 * (double)N, k2_alg = 2.5 * (double)N;
+    std::vector<Cfg> cfgs = {
+        {"copy_like NT   g97657", run_copy<true>, 97657, cls_alg},
+        {"classify NT b256", run_cls<true, 256>, 0, cls_alg}, {"classify NT b512", run_cls<true, 512>, 0, cls_alg},
+        {"hist K1", run_hist<1>, 0, (double)N}, {"scan K1", run_scan<1>, 0, 0}, {"scatter K1", run_scatter<1>, 0, 3.0 * N},
+        {"hist K2", run_hist<2>, 0, (double)N}, {"scan K2", run_scan<2>, 0, 0}, {"scatter K2", run_scatter<2>, 0, 3.0 * N},
+        {"hist K4", run_hist<4>, 0, (double)N}, {"scan K4", run_scan<4>, 0, 0}, {"scatter K4", run_scatter<4>, 0, 3.0 * N},
+        {"hist K8", run_hist<8>, 0, (double)N}, {"scan K8", run_scan<8>, 0, 0}, {"scatter K8", run_scatter<8>, 0, 3.0 * N},
+    };
+    (void)k2_alg;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> t(cfgs.size());
+    for (int r = 0; r < rounds + 2; ++r)
+        for (size_t k = 0; k < cfgs.size(); ++k) {
+            if (cfgs[k].name[0] == 'h') CK(hipMemsetAsync(COUNTS_REP, 0, 64 * 512));
+            CK(hipEventRecord(e0)); cfgs[k].fn(cfgs[k].grid); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) t[k].push_back(ms);
+        }
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    unsigned long long off[8]; CK(hipMemcpy(off, BINOFF, 64, hipMemcpyDeviceToHost));
+    printf("N=%llu records; bin_offsets:", (unsigned long long)N);
+    for (int b = 0; b < 8; ++b) printf(" %llu", off[b]);
+    printf("\n");
+    for (size_t k = 0; k < cfgs.size(); ++k) {
+        std::sort(t[k].begin(), t[k].end());
+        float med = t[k][t[k].size() / 2], mn = t[k][0];
+        printf("%-24s median %7.1f us  min %7.1f us   %6.0f GB/s\n", cfgs[k].name, med * 1e3, mn * 1e3,
+               cfgs[k].bytes / (med * 1e-3) / 1e9);
+    }
+    return 0;
+}

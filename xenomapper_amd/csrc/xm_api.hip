@@ -24,6 +24,7 @@ struct xm_ctx {
     // K2 workspace (fixed size, allocated once)
     uint32_t *d_chunk_counts;
     uint32_t *d_chunk_off;
+    uint64_t *d_counts_rep;         // XM_COUNT_REPLICAS x 64 partial category_counts, then 8 bin totals
     // scratch of the host-buffer entry points (grown on demand, never inside *_dev calls)
     void *d_scratch[8];
     size_t scratch_bytes[8];
@@ -166,14 +167,17 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     ctx->max_blocks = (uint32_t)ctx->n_cu * 8u;
     ctx->d_chunk_counts = nullptr;
     ctx->d_chunk_off = nullptr;
+    ctx->d_counts_rep = nullptr;
     for (int i = 0; i < 8; ++i) { ctx->d_scratch[i] = nullptr; ctx->scratch_bytes[i] = 0; }
     ctx->timing = false;
     for (int k = 0; k < XM_K_COUNT; ++k) { ctx->acc_ms[k] = 0.0; ctx->acc_launches[k] = 0; }
-    const size_t ws = (size_t)XM_MAX_CHUNKS * 8 * sizeof(uint32_t);
+    const size_t ws = ((size_t)XM_MAX_CHUNKS + 64) * 8 * sizeof(uint32_t);    // [8 bins][chunk pitch], largest input
     hipError_t e = hipMalloc((void **)&ctx->d_chunk_counts, ws);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_chunk_off, ws);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counts_rep, (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t));
     if (e != hipSuccess) {
         if (ctx->d_chunk_counts) (void)hipFree(ctx->d_chunk_counts);
+        if (ctx->d_chunk_off) (void)hipFree(ctx->d_chunk_off);
         delete ctx;
         return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
     }
@@ -192,6 +196,7 @@ int xm_ctx_destroy(xm_ctx *ctx)
         if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
     (void)hipFree(ctx->d_chunk_counts);
     (void)hipFree(ctx->d_chunk_off);
+    (void)hipFree(ctx->d_counts_rep);
     delete ctx;
     return XM_OK;
 }
@@ -218,7 +223,7 @@ int xm_classify_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     hipStream_t st = (hipStream_t)stream;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_i32(st, ctx->max_blocks, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out);
+        xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out);
     }
     return check_launch(ctx, "classify_kernel<int32>");
 }
@@ -235,7 +240,7 @@ int xm_classify_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     hipStream_t st = (hipStream_t)stream;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_f64(st, ctx->max_blocks, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out);
+        xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out);
     }
     return check_launch(ctx, "classify_kernel<f64>");
 }
@@ -261,27 +266,30 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_
     if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
     if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    XM_HIP(ctx, hipMemsetAsync(counts, 0, 64 * sizeof(uint64_t), st));
     if (n == 0) {
+        XM_HIP(ctx, hipMemsetAsync(counts, 0, 64 * sizeof(uint64_t), st));
         XM_HIP(ctx, hipMemsetAsync(bin_offsets, 0, 8 * sizeof(uint64_t), st));
         return XM_OK;
     }
+    XM_HIP(ctx, hipMemsetAsync(ctx->d_counts_rep, 0, XM_COUNT_REPLICAS * 64 * sizeof(uint64_t), st));
     if (!code || !idx_out || ((uintptr_t)code & 15u)) return XM_ERR_INVALID_ARG;
-    const xm::ChunkPlan plan = xm::plan_chunks(n, XM_MAX_CHUNKS);
+    const xm::ChunkPlan plan = xm::plan_chunks(n);
     int rc;
     {
         Span span(ctx, st, XM_K_HIST);
-        xm::launch_hist(st, plan, mode, n, code, ctx->d_chunk_counts, counts);
+        xm::launch_hist(st, plan, mode, n, code, ctx->d_chunk_counts, ctx->d_counts_rep);
     }
     if ((rc = check_launch(ctx, "hist_kernel")) != XM_OK) return rc;
     {
         Span span(ctx, st, XM_K_SCAN);
-        xm::launch_scan(st, plan, ctx->d_chunk_counts, ctx->d_chunk_off, bin_offsets);
+        xm::launch_scan(st, plan, ctx->d_chunk_counts, ctx->d_chunk_off, ctx->d_counts_rep + XM_COUNT_REPLICAS * 64,
+                        ctx->d_counts_rep, counts);
     }
     if ((rc = check_launch(ctx, "scan_kernel")) != XM_OK) return rc;
     {
         Span span(ctx, st, XM_K_SCATTER);
-        xm::launch_scatter(st, plan, mode, n, code, ctx->d_chunk_off, idx_out);
+        xm::launch_scatter(st, plan, mode, n, code, ctx->d_chunk_off, ctx->d_counts_rep + XM_COUNT_REPLICAS * 64,
+                           bin_offsets, idx_out);
     }
     return check_launch(ctx, "scatter_kernel");
 }

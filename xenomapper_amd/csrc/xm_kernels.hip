@@ -5,7 +5,7 @@
 //   K2 compact    category bytes -> category_counts + a stable split of unit indices by bin
 //                 K2a histogram (LDS, 64 slots x 32 replicas) -> per-chunk bin counts + counts[64]
 //                 K2b scan of the per-chunk counts (one workgroup)
-//                 K2c scatter through an LDS-staged, bin-sorted tile -> coalesced index stores
+//                 K2c scatter: per-wave DPP scans, wave-private LDS slab -> contiguous index runs
 //   K3 cigar      NM + packed CIGAR (CSR) -> synthesised AS column
 //
 // Reference semantics restated (file:line into /root/reference/xenomapper/xenomapper.py):
@@ -62,19 +62,22 @@ __device__ __forceinline__ uint32_t bin_of_code(int mode, uint32_t c)
 // K1: classify
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct Vec4;
-template <> struct Vec4<int32_t> { typedef int4 type; };
-template <> struct Vec4<double>  { typedef double4 type; };
+typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
+typedef double  v4f64 __attribute__((ext_vector_type(4)));
+template <> struct Vec4<int32_t> { typedef v4i32 type; };
+template <> struct Vec4<double>  { typedef v4f64 type; };
 
 template <typename T> __device__ __forceinline__ T absent_value();
 template <> __device__ __forceinline__ int32_t absent_value<int32_t>() { return INT32_MIN; }
 template <> __device__ __forceinline__ double  absent_value<double>()  { return -__builtin_huge_val(); }
 
-template <typename T>
+template <typename T, bool NT>
 __device__ __forceinline__ void load4(const T *__restrict__ col, uint64_t r0, uint64_t n, T out[4])
 {
     typedef typename Vec4<T>::type V;
     if (r0 + 4 <= n) {
-        const V v = *reinterpret_cast<const V *>(col + r0);
+        const V *p = reinterpret_cast<const V *>(col + r0);
+        const V v = NT ? __builtin_nontemporal_load(p) : *p;
         out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
     } else {
 #pragma unroll
@@ -83,125 +86,159 @@ __device__ __forceinline__ void load4(const T *__restrict__ col, uint64_t r0, ui
 }
 
 // One lane owns 4 consecutive records, so each column is read with one 16-byte (int32) load per
-// lane, 1 KiB contiguous per wave instruction.  The forward mate's state of a lane's first record
-// comes from lane-1 (shuffle); lane 0 takes it from the record just before the wave's tile, whose
-// four scores are fetched with wave-uniform (scalar) loads.
-template <typename T, bool PAIRED>
-__global__ void __launch_bounds__(XM_BLOCK)
+// lane, 1 KiB contiguous per wave instruction; a wave covers a 256-record tile, a workgroup BLOCK*4
+// consecutive records, and the grid covers the whole input once (no grid-stride loop: on MI355X the
+// one-tile-per-wave launch measured 20-25 % faster than a persistent 2048-workgroup loop, see
+// profiles/r01_tune_classify.txt).  The forward mate's state of a lane's first record comes from
+// lane-1 (shuffle); lane 0 takes it from the previous wave of the workgroup through LDS, and the
+// first wave of a workgroup from the one record in front of the workgroup's range.
+// NT: the score columns are read once and never again, so they are loaded non-temporally; the
+// category bytes are stored with the default policy because K2 reads them next (100 MB at the
+// 50 M-pair configuration, which fits the 256 MiB Infinity Cache).
+template <typename T, bool PAIRED, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
                 const T *__restrict__ as2, const T *__restrict__ xs2,
                 const uint8_t *__restrict__ unit_bits8, T m,
                 uint8_t *__restrict__ code, uint64_t n)
 {
+    __shared__ uint32_t last_state[BLOCK / 64];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_groups = (n + 3) >> 2;
-    const uint64_t n_wtiles = (n_groups + 63) >> 6;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (XM_BLOCK / 64);
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
+    const uint64_t r0 = g * 4;
 
-    for (uint64_t wt = (uint64_t)blockIdx.x * (XM_BLOCK / 64) + wave_in_block; wt < n_wtiles; wt += n_waves) {
-        const uint64_t g = wt * 64 + lane;
-        const uint64_t r0 = g * 4;
+    T a1[4], x1[4], a2[4], x2[4];
+    load4<T, NT>(as1, r0, n, a1);
+    load4<T, NT>(xs1, r0, n, x1);
+    load4<T, NT>(as2, r0, n, a2);
+    load4<T, NT>(xs2, r0, n, x2);
+    uint32_t mb = 0;
+    if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+    if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
 
-        T a1[4], x1[4], a2[4], x2[4];
-        load4(as1, r0, n, a1);
-        load4(xs1, r0, n, x1);
-        load4(as2, r0, n, a2);
-        load4(xs2, r0, n, x2);
-        uint32_t mb = 0;
-        if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
-        if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
-
-        uint32_t s[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = mapping_state<T>(a1[j], x1[j], a2[j], x2[j], m);
-
-        uint32_t c[4];
-        if (PAIRED) {
-            uint32_t prev = (uint32_t)__shfl_up((int)s[3], 1, 64);
-            const uint64_t tile_first = wt * 256;              // wave-uniform
-            if (tile_first > 0) {
-                const uint64_t h = tile_first - 1;             // exists: h < n because wt < n_wtiles
-                const uint32_t hs = mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m);
-                prev = (lane == 0) ? hs : prev;
-            } else {
-                mb &= (lane == 0) ? ~1u : ~0u;                 // record 0 has no predecessor (:402)
-            }
-            c[0] = (mb & 1u) ? ((prev << 3) | s[0]) : XM_NO_UNIT;
-            c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
-            c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
-            c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
+    // the record in front of the workgroup's range (thread 0 only)
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 > 0) {
+            const uint64_t h = r0 - 1;                         // r0 <= n here, so h < n
+            halo = (r0 <= n) ? mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m) : 0u;
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = ((mb >> j) & 1u) ? s[j] : XM_NO_UNIT;
+            mb &= ~1u;                                         // record 0 has no predecessor (:402)
         }
+    }
 
-        if (r0 + 4 <= n) {
-            *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
-        } else {
+    uint32_t s[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (r0 + j < n) code[r0 + j] = (uint8_t)c[j];
-        }
+    for (int j = 0; j < 4; ++j) s[j] = mapping_state<T>(a1[j], x1[j], a2[j], x2[j], m);
+
+    uint32_t c[4];
+    if (PAIRED) {
+        uint32_t prev = (uint32_t)__shfl_up((int)s[3], 1, 64);
+        if (lane == 63) last_state[wave] = s[3];
+        __syncthreads();
+        if (lane == 0) prev = (wave == 0) ? halo : last_state[wave - 1];
+        c[0] = (mb & 1u) ? ((prev << 3) | s[0]) : XM_NO_UNIT;
+        c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
+        c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
+        c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = ((mb >> j) & 1u) ? s[j] : XM_NO_UNIT;
+    }
+
+    if (r0 + 4 <= n) {
+        *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r0 + j < n) code[r0 + j] = (uint8_t)c[j];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // K2 shared: load one thread's 16 category bytes of a 4096-record tile
 // ---------------------------------------------------------------------------------------------
+__device__ __attribute__((noinline)) uint4 load_codes16_tail(const uint8_t *__restrict__ code, uint64_t base, uint64_t n)
+{
+    uint32_t w[4];
+    for (int k = 0; k < 4; ++k) {
+        uint32_t acc = 0;
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = base + 4 * k + j;
+            const uint32_t c = (i < n) ? (uint32_t)code[i] : XM_NO_UNIT;
+            acc |= c << (8 * j);
+        }
+        w[k] = acc;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __device__ __forceinline__ void load_codes16(const uint8_t *__restrict__ code, uint64_t base, uint64_t n,
                                              uint32_t w[4])
 {
-    if (base + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(code + base);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t i = base + 4 * k + j;
-                const uint32_t c = (i < n) ? (uint32_t)code[i] : XM_NO_UNIT;
-                acc |= c << (8 * j);
-            }
-            w[k] = acc;
-        }
-    }
+    uint4 v;
+    if (base + 16 <= n) v = *reinterpret_cast<const uint4 *>(code + base);
+    else v = load_codes16_tail(code, base, n);          // last, partial tile only
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2a: histogram.  Workgroup `chunk` owns tiles [chunk*tpc, (chunk+1)*tpc).  LDS holds 64 category
-// slots x 32 replicas (replica = lane & 31, so a wave's 64 atomics spread over all 32 banks).
+// K2 geometry.  A wave owns XM_K consecutive wave tiles of XM_WTILE records (16 category bytes per
+// lane, lane l holds records 16l..16l+15 of the tile, so lane order == input order); a workgroup
+// (chunk) owns 4 consecutive wave spans = XM_CHUNK records.  All of a wave's category bytes stay in
+// registers between counting and scattering, so the bytes are read from memory once per kernel.
 // ---------------------------------------------------------------------------------------------
+
+// wave64 inclusive prefix sum with DPP (row_shr 1,2,4,8, row_bcast15, row_bcast31): no LDS traffic
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a: histogram.  LDS holds 64 category slots x 32 replicas (replica = lane & 31, so the 64 atomics
+// of a wave instruction spread over all 32 banks).  A byte position at which no lane of the wave
+// holds a unit (every other position of interleaved paired input) is skipped wave-uniformly.
+// Outputs: counts_rep[replica][64] (partial category_counts) and chunk_counts[bin][chunk] for the scan.
+// ---------------------------------------------------------------------------------------------
+template <int K>
 __global__ void __launch_bounds__(XM_BLOCK)
-hist_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t tiles_per_chunk,
-            uint32_t *__restrict__ chunk_counts, unsigned long long *__restrict__ counts)
+hist_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t chunk_stride,
+            uint32_t *__restrict__ chunk_counts, unsigned long long *__restrict__ counts_rep)
 {
     __shared__ uint32_t hist[64 * 32];
     __shared__ uint32_t binc[8];
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     for (uint32_t k = t; k < 64 * 32; k += XM_BLOCK) hist[k] = 0;
     if (t < 8) binc[t] = 0;
     __syncthreads();
 
-    const uint64_t n_tiles = (n + XM_TILE - 1) / XM_TILE;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_chunk;
-    uint64_t tile1 = tile0 + tiles_per_chunk;
-    if (tile1 > n_tiles) tile1 = n_tiles;
-    const uint32_t rep = t & 31u;
+    const uint64_t span0 = ((uint64_t)blockIdx.x * (XM_BLOCK / 64) + wave) * (uint64_t)(K * XM_WTILE);
+    uint32_t w[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) load_codes16(code, span0 + (uint64_t)k * XM_WTILE + lane * 16u, n, w[k]);
 
-    for (uint64_t tile = tile0; tile < tile1; ++tile) {
-        uint32_t w[4];
-        load_codes16(code, tile * XM_TILE + (uint64_t)t * 16, n, w);
+    const uint32_t rep = t & 31u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < K; ++k) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = (w[k] >> (8 * j)) & 0xFFu;
-                const uint32_t slot = (c == XM_NO_UNIT) ? 63u : (c & 63u);
-                atomicAdd(&hist[slot * 32 + rep], 1u);
-            }
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = (w[k][j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const bool unit = c != XM_NO_UNIT;
+            if (__ballot(unit) == 0ull) continue;                     // wave-uniform
+            if (unit) atomicAdd(&hist[(c & 63u) * 32 + rep], 1u);
         }
     }
     __syncthreads();
@@ -213,175 +250,245 @@ hist_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t til
     for (int r = 0; r < 8; ++r) s += hist[slot * 32 + q * 8 + r];
     s += (uint32_t)__shfl_xor((int)s, 1, 64);
     s += (uint32_t)__shfl_xor((int)s, 2, 64);
-    if (q == 0 && slot != 63u && s != 0u) {
-        atomicAdd(&counts[slot], (unsigned long long)s);
+    if (q == 0 && s != 0u) {
+        // XM_COUNT_REPLICAS copies of counts[64] keep same-address atomics rare; K2b adds them up
+        atomicAdd(&counts_rep[(blockIdx.x % XM_COUNT_REPLICAS) * 64u + slot], (unsigned long long)s);
         atomicAdd(&binc[bin_of_code(mode, slot)], s);
     }
     __syncthreads();
-    if (t < 8) chunk_counts[(uint64_t)blockIdx.x * 8 + t] = binc[t];
+    if (t < 8) chunk_counts[(uint64_t)t * chunk_stride + blockIdx.x] = binc[t];
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2b: exclusive scan of the per-chunk bin counts (one workgroup, wave b scans bin b).
-// chunk_off[k][b] = start of chunk k's units of bin b inside idx_out; bin_offsets[0..7].
+// K2b: exclusive scan of the per-chunk bin counts.  Workgroup b (1024 threads) scans bin b: each of its
+// 16 waves owns a contiguous range of chunks, sums it, and after one barrier rescans it with the
+// carry of the ranges before.  chunk_off[b][k] = units of bin b in chunks < k; bin_totals[b] = units of
+// bin b.  The workgroups also add up the replicas of category_counts (8 slots each).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512)
-scan_kernel(const uint32_t *__restrict__ chunk_counts, uint32_t n_chunks,
-            uint32_t *__restrict__ chunk_off, unsigned long long *__restrict__ bin_offsets)
+#define XM_SCAN_THREADS 1024
+__global__ void __launch_bounds__(XM_SCAN_THREADS)
+scan_kernel(const uint32_t *__restrict__ chunk_counts, uint32_t n_chunks, uint32_t chunk_stride,
+            uint32_t *__restrict__ chunk_off, unsigned long long *__restrict__ bin_totals,
+            const unsigned long long *__restrict__ counts_rep, unsigned long long *__restrict__ counts)
 {
-    __shared__ uint32_t tot[8];
-    const uint32_t b = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t per = (n_chunks + 63u) / 64u;
-    uint32_t k0 = lane * per, k1 = k0 + per;
-    if (k0 > n_chunks) k0 = n_chunks;
-    if (k1 > n_chunks) k1 = n_chunks;
-    uint32_t sum = 0;
-    for (uint32_t k = k0; k < k1; ++k) sum += chunk_counts[(uint64_t)k * 8 + b];
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-        incl += (lane >= (uint32_t)d) ? up : 0u;
+    __shared__ unsigned long long wsum[XM_SCAN_THREADS / 64];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {   // category_counts slots 8b..8b+7: 8 lanes per slot, 8 replicas each
+        const uint32_t slot = b * 8u + (threadIdx.x >> 3), part = threadIdx.x & 7u;
+        unsigned long long acc = 0;
+        for (uint32_t r = part; r < XM_COUNT_REPLICAS; r += 8u) acc += counts_rep[r * 64u + slot];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (part == 0) counts[slot] = acc;
     }
-    if (lane == 63) tot[b] = incl;
+    const uint32_t *src = chunk_counts + (uint64_t)b * chunk_stride;
+    uint32_t *dst = chunk_off + (uint64_t)b * chunk_stride;
+    const uint32_t n_waves = XM_SCAN_THREADS / 64;
+    const uint32_t seg = (((n_chunks + n_waves - 1) / n_waves) + 63u) & ~63u;     // chunks per wave, multiple of 64
+    const uint32_t k_begin = wave * seg;
+    const uint32_t k_end = (k_begin + seg < n_chunks) ? k_begin + seg : n_chunks;
+
+    // pass 1: sum of the wave's range (8 coalesced loads in flight per lane)
+    unsigned long long sum = 0;
+    for (uint32_t j0 = k_begin; j0 < k_end; j0 += 64u * 8u) {
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = j0 + (uint32_t)u * 64u + lane;
+            x[u] = (k < k_end) ? src[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += x[u];
+    }
+    sum += __shfl_xor(sum, 1, 64);  sum += __shfl_xor(sum, 2, 64);  sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 8, 64);  sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    if (lane == 0) wsum[wave] = sum;
     __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t bb = 0; bb < b; ++bb) base += tot[bb];
-    uint32_t run = base + incl - sum;
-    for (uint32_t k = k0; k < k1; ++k) {
-        chunk_off[(uint64_t)k * 8 + b] = run;
-        run += chunk_counts[(uint64_t)k * 8 + b];
+    unsigned long long carry = 0, total = 0;
+    for (uint32_t wv = 0; wv < n_waves; ++wv) {
+        const unsigned long long v = wsum[wv];
+        carry += (wv < wave) ? v : 0ull;
+        total += v;
     }
-    if (lane == 0) {
-        // bins 0..6 are real; slot 7 of the counts is unused (always 0) so bin_offsets[7] = #units
-        bin_offsets[b] = base;
+    if (threadIdx.x == 0) bin_totals[b] = total;
+
+    // pass 2: rescan the range (now cache-resident) with the carry
+    for (uint32_t j0 = k_begin; j0 < k_end; j0 += 64u * 8u) {
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = j0 + (uint32_t)u * 64u + lane;
+            x[u] = (k < k_end) ? src[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = j0 + (uint32_t)u * 64u + lane;
+            const uint32_t incl = wave_scan_incl(x[u]);
+            if (k < k_end) dst[k] = (uint32_t)carry + incl - x[u];
+            carry += lane_value(incl, 63);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2c: scatter.  Per 4096-record tile: per-lane bin counts -> wave scan -> tile-local sorted
-// position of every unit -> record indices staged in LDS in (bin, input order) -> written out as
-// contiguous runs, one run per bin.  Eight 16-bit counters live in two 64-bit registers.
+// K2c: scatter.  Per wave tile: per-lane bin counts (three 10-bit counters per 32-bit word) ->
+// DPP wave scan -> position of every unit in the tile's (bin, input order) sorted order -> record
+// indices staged in the wave's private LDS slab -> each bin's run written out contiguously.
+// One workgroup barrier per chunk (to order the four waves' bases); everything else is per wave.
+// Units holding state 6 (NaN input only) take a slow path that writes straight to slot 6.
 // ---------------------------------------------------------------------------------------------
-struct Packed8 {
-    uint64_t lo, hi;      // lo: bins 0..3, hi: bins 4..7 (7 = "not a unit"), 16 bits each
-};
-
-__device__ __forceinline__ void packed_add(Packed8 &p, uint32_t bin)
+__device__ __forceinline__ void bin_fields(uint32_t b, bool &valid, bool &in_x, uint32_t &shift)
 {
-    const uint64_t one = 1ull << ((bin & 3u) * 16u);
-    p.lo += (bin < 4u) ? one : 0ull;
-    p.hi += (bin < 4u) ? 0ull : one;
+    valid = b < 6u;
+    in_x = b < 3u;
+    const uint32_t f = in_x ? b : b - 3u;
+    shift = (f << 3) + (f << 1);
 }
 
-__device__ __forceinline__ uint32_t packed_get(const Packed8 &p, uint32_t bin)
-{
-    const uint64_t w = (bin < 4u) ? p.lo : p.hi;
-    return (uint32_t)(w >> ((bin & 3u) * 16u)) & 0xFFFFu;
-}
-
-__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d)
-{
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
-    const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-
+template <int MODE, int K>
 __global__ void __launch_bounds__(XM_BLOCK)
-scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t tiles_per_chunk,
-               const uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ idx_out)
+scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stride,
+               const uint32_t *__restrict__ chunk_off, const unsigned long long *__restrict__ bin_totals,
+               unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out)
 {
-    __shared__ uint32_t stage[XM_TILE];
+    __shared__ uint4 tile_state[K][XM_BLOCK];         // per lane and tile: {bins lo, bins hi, counts x, counts y}
+    __shared__ uint32_t stage[XM_BLOCK / 64][XM_WTILE];
     __shared__ uint32_t wave_tot[XM_BLOCK / 64][8];
-    __shared__ uint32_t wave_base[XM_BLOCK / 64][8];
-    __shared__ uint32_t tile_start[8];      // start of bins 0..6 in the sorted tile; [7] = units in tile
-    __shared__ uint32_t tile_cnt[8];
-    __shared__ uint32_t run[8];
 
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    if (t < 8) run[t] = chunk_off[(uint64_t)blockIdx.x * 8 + t];
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint64_t span0 = ((uint64_t)blockIdx.x * (XM_BLOCK / 64) + wave) * (uint64_t)(K * XM_WTILE);
 
-    const uint64_t n_tiles = (n + XM_TILE - 1) / XM_TILE;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_chunk;
-    uint64_t tile1 = tile0 + tiles_per_chunk;
-    if (tile1 > n_tiles) tile1 = n_tiles;
+    // lane b < 8: where bin b starts in idx_out (exclusive prefix of the bin totals) plus this chunk's
+    // offset inside the bin; fetched first so that the latency hides behind phase 1
+    uint32_t bin_start, lane_base;
+    {
+        const uint32_t tot = (lane < 8u) ? (uint32_t)bin_totals[lane] : 0u;
+        const uint32_t off = (lane < 7u) ? chunk_off[(uint64_t)lane * chunk_stride + blockIdx.x] : 0u;
+        bin_start = wave_scan_incl(tot) - tot;
+        lane_base = bin_start + off;
+    }
+    if (blockIdx.x == 0 && t < 8) bin_offsets[t] = bin_start;       // lanes 0..7 of wave 0
 
-    for (uint64_t tile = tile0; tile < tile1; ++tile) {
-        const uint64_t base = tile * XM_TILE + (uint64_t)t * 16;
-        uint32_t w[4];
-        load_codes16(code, base, n, w);
-
-        // A: per-lane counts
-        uint32_t bins[16];
-        Packed8 cnt = {0ull, 0ull};
+    // ---- phase 1: bytes -> bins (4 bits each) and per-lane counters, all tiles of the span
+    // per tile: bin of record j in bits 4j..4j+2 of two words (7 = not a unit); per-lane counts of
+    // bins 0..2 / 3..5 as 10-bit fields of two words.  Parked in LDS so that phase 2 can be a rolled loop.
+    uint32_t lane_tot[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t err_tiles = 0;          // bit k: this lane holds a state-6 unit in tile k
+    {
+        uint32_t w[4], wn[4] = {0, 0, 0, 0};
+        load_codes16(code, span0 + lane * 16u, n, w);
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            if (k + 1 < K) load_codes16(code, span0 + (uint64_t)(k + 1) * XM_WTILE + lane * 16u, n, wn);   // prefetch
+            uint32_t x = 0, y = 0, n0 = 0, n1 = 0, c6 = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            bins[j] = bin_of_code(mode, (w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-            packed_add(cnt, bins[j]);
-        }
-        // B: inclusive scan over the wave
-        Packed8 incl = cnt;
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                if (__ballot(c != XM_NO_UNIT) == 0ull) {              // wave-uniform: nobody has a unit here
+                    if (j < 8) n0 |= 7u << (4 * j); else n1 |= 7u << (4 * (j - 8));
+                    continue;
+                }
+                const uint32_t b = bin_of_code(MODE, c);
+                if (j < 8) n0 |= b << (4 * j); else n1 |= b << (4 * (j - 8));
+                bool valid, in_x; uint32_t sh;
+                bin_fields(b, valid, in_x, sh);
+                const uint32_t inc = valid ? (1u << sh) : 0u;
+                x += in_x ? inc : 0u;
+                y += in_x ? 0u : inc;
+                c6 += (b == 6u) ? 1u : 0u;
+            }
+            tile_state[k][t] = make_uint4(n0, n1, x, y);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t ulo = shfl_up64(incl.lo, d), uhi = shfl_up64(incl.hi, d);
-            if (lane >= (uint32_t)d) { incl.lo += ulo; incl.hi += uhi; }
+            for (int bb = 0; bb < 3; ++bb) {
+                lane_tot[bb] += (x >> (10 * bb)) & 0x3FFu;
+                lane_tot[3 + bb] += (y >> (10 * bb)) & 0x3FFu;
+            }
+            lane_tot[6] += c6;
+            err_tiles |= (c6 != 0u) ? (1u << k) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = wn[q];
         }
-        // C: wave totals
+    }
+    // wave totals of the span (two 16-bit fields per word: at most 8192 per bin)
+    {
+        const uint32_t p01 = wave_scan_incl(lane_tot[0] | (lane_tot[1] << 16));
+        const uint32_t p23 = wave_scan_incl(lane_tot[2] | (lane_tot[3] << 16));
+        const uint32_t p45 = wave_scan_incl(lane_tot[4] | (lane_tot[5] << 16));
+        const uint32_t p6 = wave_scan_incl(lane_tot[6]);
         if (lane == 63) {
-#pragma unroll
-            for (uint32_t b = 0; b < 8; ++b) wave_tot[wave][b] = packed_get(incl, b);
+            wave_tot[wave][0] = p01 & 0xFFFFu; wave_tot[wave][1] = p01 >> 16;
+            wave_tot[wave][2] = p23 & 0xFFFFu; wave_tot[wave][3] = p23 >> 16;
+            wave_tot[wave][4] = p45 & 0xFFFFu; wave_tot[wave][5] = p45 >> 16;
+            wave_tot[wave][6] = p6; wave_tot[wave][7] = 0;
         }
-        __syncthreads();
-        // D: tile layout (lanes 0..7 of wave 0, lane b owns bin b)
-        if (t < 8) {
-            uint32_t tot = 0, pre[XM_BLOCK / 64];
+    }
+    __syncthreads();
+    // where this wave's units of each bin start in idx_out (wave-uniform)
+    uint32_t gbase[7];
 #pragma unroll
-            for (int wv = 0; wv < XM_BLOCK / 64; ++wv) { pre[wv] = tot; tot += wave_tot[wv][t]; }
-            const uint32_t real = (t < 7) ? tot : 0u;          // bin 7 = not-a-unit, takes no room
-            uint32_t incl8 = real;
+    for (int b = 0; b < 7; ++b) {
+        uint32_t g = lane_value(lane_base, b);
+        for (uint32_t wv = 0; wv < wave; ++wv) g += wave_tot[wv][b];
+        gbase[b] = __builtin_amdgcn_readfirstlane(g);
+    }
+
+    // ---- phase 2: tile by tile, no workgroup synchronisation
+    uint32_t *slab = stage[wave];
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const uint4 ts = tile_state[k][t];
+        const uint32_t nib0 = ts.x, nib1 = ts.y, cxk = ts.z, cyk = ts.w;
+        const uint32_t ix = wave_scan_incl(cxk), iy = wave_scan_incl(cyk);
+        const uint32_t ex = ix - cxk, ey = iy - cyk;
+        // tile totals per bin = lane 63's exclusive prefix + own count (added per field: a field may reach 1024)
+        const uint32_t ex63 = lane_value(ex, 63), ey63 = lane_value(ey, 63);
+        const uint32_t cx63 = lane_value(cxk, 63), cy63 = lane_value(cyk, 63);
+        uint32_t cnt[6], lstart[6];
+        uint32_t acc = 0;
 #pragma unroll
-            for (int d = 1; d < 8; d <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl8, d, 64);
-                incl8 += (t >= (uint32_t)d) ? up : 0u;
-            }
-            const uint32_t start = incl8 - real;               // for t == 7 this is the unit total
-            tile_start[t] = start;
-            tile_cnt[t] = real;
-#pragma unroll
-            for (int wv = 0; wv < XM_BLOCK / 64; ++wv) wave_base[wv][t] = start + pre[wv];
+        for (int b = 0; b < 6; ++b) {
+            const uint32_t e = (b < 3) ? ex63 : ey63, c = (b < 3) ? cx63 : cy63;
+            const int f = 10 * (b % 3);
+            cnt[b] = ((e >> f) & 0x3FFu) + ((c >> f) & 0x3FFu);
+            lstart[b] = acc;
+            acc += cnt[b];
         }
-        __syncthreads();
-        // E: ranks -> LDS stage
-        Packed8 pos;
-        {
-            uint64_t blo = 0, bhi = 0;
-#pragma unroll
-            for (uint32_t b = 0; b < 4; ++b) {
-                blo |= (uint64_t)wave_base[wave][b] << (16 * b);
-                bhi |= (uint64_t)(wave_base[wave][b + 4] & 0xFFFFu) << (16 * b);
-            }
-            pos.lo = blo + (incl.lo - cnt.lo);
-            pos.hi = bhi + (incl.hi - cnt.hi);
-        }
+        // running positions, packed like the counters
+        uint32_t px = ex + (lstart[0] | (lstart[1] << 10) | (lstart[2] << 20));
+        uint32_t py = ey + (lstart[3] | (lstart[4] << 10) | (lstart[5] << 20));
+        const uint32_t rec0 = (uint32_t)(span0 + (uint64_t)k * XM_WTILE) + lane * 16u;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t b = bins[j];
-            const uint32_t p = packed_get(pos, b);
-            if (b < 7u) stage[p] = (uint32_t)(base + j);
-            packed_add(pos, b);
+            const uint32_t b = ((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u;
+            bool valid, in_x; uint32_t sh;
+            bin_fields(b, valid, in_x, sh);
+            if (__ballot(valid) == 0ull) continue;                    // wave-uniform
+            const uint32_t pos = ((in_x ? px : py) >> sh) & 0x3FFu;
+            if (valid) slab[pos] = rec0 + (uint32_t)j;
+            const uint32_t inc = valid ? (1u << sh) : 0u;
+            px += in_x ? inc : 0u;
+            py += in_x ? 0u : inc;
         }
-        __syncthreads();
-        // F: coalesced write-out, one contiguous run per bin
-        const uint32_t total = tile_start[7];
-        for (uint32_t e = t; e < total; e += XM_BLOCK) {
-            uint32_t b = 0;
+        // each bin's run, contiguous in LDS and contiguous in idx_out
 #pragma unroll
-            for (uint32_t k = 1; k < 7; ++k) b += (e >= tile_start[k]) ? 1u : 0u;
-            idx_out[run[b] + (e - tile_start[b])] = stage[e];
+        for (int b = 0; b < 6; ++b) {
+            for (uint32_t e = lane; e < cnt[b]; e += 64u) idx_out[gbase[b] + e] = slab[lstart[b] + e];
+            gbase[b] += cnt[b];
         }
-        __syncthreads();
-        // G: advance the chunk's running offsets
-        if (t < 7) run[t] += tile_cnt[t];
+        // state-6 units (rare)
+        if (__ballot((err_tiles >> k) & 1u) != 0ull) {
+            uint32_t c6 = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) c6 += ((((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u) == 6u) ? 1u : 0u;
+            const uint32_t i6 = wave_scan_incl(c6);
+            uint32_t run6 = gbase[6] + i6 - c6;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u) == 6u) idx_out[run6++] = rec0 + (uint32_t)j;
+            gbase[6] += lane_value(i6, 63);
+        }
     }
 }
 
@@ -420,73 +527,71 @@ cigar_kernel(uint64_t n, const int32_t *__restrict__ nm, const uint32_t *__restr
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static inline uint32_t classify_grid(uint64_t n, uint32_t max_blocks)
-{
-    const uint64_t n_wtiles = (((n + 3) >> 2) + 63) >> 6;
-    uint64_t blocks = (n_wtiles + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
-    if (blocks > max_blocks) blocks = max_blocks;
-    if (blocks == 0) blocks = 1;
-    return (uint32_t)blocks;
-}
-
 template <typename T>
-static void launch_classify_t(hipStream_t st, uint32_t max_blocks, int mode, uint64_t n,
+static void launch_classify_t(hipStream_t st, int mode, uint64_t n,
                               const T *as1, const T *xs1, const T *as2, const T *xs2,
                               const uint64_t *unit_bits, T m, uint8_t *code)
 {
-    const uint32_t grid = classify_grid(n, max_blocks);
+    const uint64_t per_block = (uint64_t)XM_CLASSIFY_BLOCK * 4;
+    const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
     if (mode == XM_MODE_SE)
-        classify_kernel<T, false><<<grid, XM_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n);
+        classify_kernel<T, false, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n);
     else
-        classify_kernel<T, true><<<grid, XM_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n);
+        classify_kernel<T, true, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n);
 }
 
-void launch_classify_i32(hipStream_t st, uint32_t max_blocks, int mode, uint64_t n,
+void launch_classify_i32(hipStream_t st, int mode, uint64_t n,
                          const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
                          const uint64_t *unit_bits, int32_t m, uint8_t *code)
 {
-    launch_classify_t<int32_t>(st, max_blocks, mode, n, as1, xs1, as2, xs2, unit_bits, m, code);
+    launch_classify_t<int32_t>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code);
 }
 
-void launch_classify_f64(hipStream_t st, uint32_t max_blocks, int mode, uint64_t n,
+void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
                          const double *as1, const double *xs1, const double *as2, const double *xs2,
                          const uint64_t *unit_bits, double m, uint8_t *code)
 {
-    launch_classify_t<double>(st, max_blocks, mode, n, as1, xs1, as2, xs2, unit_bits, m, code);
+    launch_classify_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code);
 }
 
-ChunkPlan plan_chunks(uint64_t n, uint32_t max_chunks)
+ChunkPlan plan_chunks(uint64_t n)
 {
     ChunkPlan p;
-    const uint64_t n_tiles = (n + XM_TILE - 1) / XM_TILE;
-    uint64_t chunks = n_tiles < max_chunks ? n_tiles : max_chunks;
+    uint64_t chunks = (n + XM_CHUNK - 1) / XM_CHUNK;
     if (chunks == 0) chunks = 1;
-    p.tiles_per_chunk = (uint32_t)((n_tiles + chunks - 1) / chunks);
-    if (p.tiles_per_chunk == 0) p.tiles_per_chunk = 1;
-    p.n_chunks = (uint32_t)((n_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk);
-    if (p.n_chunks == 0) p.n_chunks = 1;
+    p.n_chunks = (uint32_t)chunks;
+    p.chunk_stride = (p.n_chunks + 63u) & ~63u;
     return p;
 }
 
 void launch_hist(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
-                 uint32_t *chunk_counts, uint64_t *counts)
+                 uint32_t *chunk_counts, uint64_t *counts_rep)
 {
-    hist_kernel<<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, mode, p.tiles_per_chunk, chunk_counts,
-                                                  reinterpret_cast<unsigned long long *>(counts));
+    hist_kernel<XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, mode, p.chunk_stride, chunk_counts,
+                                                        reinterpret_cast<unsigned long long *>(counts_rep));
 }
 
 void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_counts, uint32_t *chunk_off,
-                 uint64_t *bin_offsets)
+                 uint64_t *bin_totals, const uint64_t *counts_rep, uint64_t *counts)
 {
-    scan_kernel<<<1, 512, 0, st>>>(chunk_counts, p.n_chunks, chunk_off,
-                                   reinterpret_cast<unsigned long long *>(bin_offsets));
+    scan_kernel<<<8, XM_SCAN_THREADS, 0, st>>>(chunk_counts, p.n_chunks, p.chunk_stride, chunk_off,
+                                   reinterpret_cast<unsigned long long *>(bin_totals),
+                                   reinterpret_cast<const unsigned long long *>(counts_rep),
+                                   reinterpret_cast<unsigned long long *>(counts));
 }
 
 void launch_scatter(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
-                    const uint32_t *chunk_off, uint32_t *idx_out)
+                    const uint32_t *chunk_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out)
 {
-    scatter_kernel<<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, mode, p.tiles_per_chunk, chunk_off, idx_out);
+    const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
+    unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
+    if (mode == XM_MODE_SE)
+        scatter_kernel<XM_MODE_SE, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
+    else if (mode == XM_MODE_PE_LIBERAL)
+        scatter_kernel<XM_MODE_PE_LIBERAL, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
+    else
+        scatter_kernel<XM_MODE_PE_CONSERVATIVE, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
 }
 
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,
