@@ -474,7 +474,10 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
         // each bin's run, contiguous in LDS and contiguous in idx_out
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            for (uint32_t e = lane; e < cnt[b]; e += 64u) idx_out[gbase[b] + e] = slab[lstart[b] + e];
+            // streamed out once and read by the host only: non-temporal, so the 200 MB of indices do not push
+            // the category bytes (re-read by K2, rewritten by the next K1) out of the Infinity Cache
+            for (uint32_t e = lane; e < cnt[b]; e += 64u)
+                __builtin_nontemporal_store(slab[lstart[b] + e], idx_out + gbase[b] + e);
             gbase[b] += cnt[b];
         }
         // state-6 units (rare)
