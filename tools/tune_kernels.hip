@@ -53,6 +53,7 @@ struct Plan { uint32_t n_chunks, stride; };
 template <int K> static Plan plan_k() { Plan p; uint64_t ch = (uint64_t)K * 4096; p.n_chunks = (uint32_t)((N + ch - 1) / ch); p.stride = (p.n_chunks + 63u) & ~63u; return p; }
 template <int K> static void run_hist(int) { Plan p = plan_k<K>(); xm::hist_kernel<K><<<p.n_chunks, 256>>>(CODE, N, 1, p.stride, CHUNK_COUNTS, COUNTS_REP); }
 template <int K> static void run_scan(int) { Plan p = plan_k<K>(); xm::scan_kernel<<<8, XM_SCAN_THREADS>>>(CHUNK_COUNTS, p.n_chunks, p.stride, CHUNK_OFF, BINTOT, COUNTS_REP, COUNTS); }
+template <int K, int ABL> static void run_scatter_abl(int) { Plan p = plan_k<K>(); xm::scatter_kernel<1, K, ABL><<<p.n_chunks, 256>>>(CODE, N, p.stride, CHUNK_OFF, BINTOT, BINOFF, IDX); }
 template <int K> static void run_scatter(int) { Plan p = plan_k<K>(); xm::scatter_kernel<1, K><<<p.n_chunks, 256>>>(CODE, N, p.stride, CHUNK_OFF, BINTOT, BINOFF, IDX); }
 
 int main(int argc, char **argv)
@@ -96,6 +97,8 @@ int main(int argc, char **argv)
         {"classify NT b256", run_cls<true, 256>, 0, cls_alg}, {"classify NT b512", run_cls<true, 512>, 0, cls_alg},
         {"hist K1", run_hist<1>, 0, (double)N}, {"scan K1", run_scan<1>, 0, 0}, {"scatter K1", run_scatter<1>, 0, 3.0 * N},
         {"hist K2", run_hist<2>, 0, (double)N}, {"scan K2", run_scan<2>, 0, 0}, {"scatter K2", run_scatter<2>, 0, 3.0 * N},
+        {"scatter K2 no-store", run_scatter_abl<2, 1>, 0, 3.0 * N}, {"scatter K2 no-stage", run_scatter_abl<2, 2>, 0, 3.0 * N},
+        {"scatter K2 plain-store", run_scatter_abl<2, 3>, 0, 3.0 * N},
         {"hist K4", run_hist<4>, 0, (double)N}, {"scan K4", run_scan<4>, 0, 0}, {"scatter K4", run_scatter<4>, 0, 3.0 * N},
         {"hist K8", run_hist<8>, 0, (double)N}, {"scan K8", run_scan<8>, 0, 0}, {"scatter K8", run_scatter<8>, 0, 3.0 * N},
     };

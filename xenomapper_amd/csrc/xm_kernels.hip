@@ -332,28 +332,62 @@ scan_kernel(const uint32_t *__restrict__ chunk_counts, uint32_t n_chunks, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2c: scatter.  Per wave tile: per-lane bin counts (three 10-bit counters per 32-bit word) ->
-// DPP wave scan -> position of every unit in the tile's (bin, input order) sorted order -> record
+// K2c: scatter.  Per wave tile: per-lane bin counters packed in one 64-bit register (bins 0..2 as
+// 10-bit fields of the low word, 3..5 of the high word, everything else into a 2-bit sink at bit 62)
+// -> DPP wave scan -> position of every unit in the tile's (bin, input order) sorted order -> record
 // indices staged in the wave's private LDS slab -> each bin's run written out contiguously.
 // One workgroup barrier per chunk (to order the four waves' bases); everything else is per wave.
 // Units holding state 6 (NaN input only) take a slow path that writes straight to slot 6.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bin_fields(uint32_t b, bool &valid, bool &in_x, uint32_t &shift)
+
+// shift of bin b's counter inside the packed 64-bit word: byte LUT {0,10,20,32,42,52,62,62} read with
+// v_perm_b32 (selector byte = b picks byte b of {hi,lo}); only bits [5:0] of the result are used.
+__device__ __forceinline__ uint32_t bin_shift(uint32_t b)
 {
-    valid = b < 6u;
-    in_x = b < 3u;
-    const uint32_t f = in_x ? b : b - 3u;
-    shift = (f << 3) + (f << 1);
+    return __builtin_amdgcn_perm(0x3E3E342Au, 0x20140A00u, b);
 }
 
-template <int MODE, int K>
+// bin (0..5), 6 = unit holding a state 6, 7 = not a unit, from a category byte; MODE is a template constant
+template <int MODE>
+__device__ __forceinline__ uint32_t bin_of_byte(uint32_t c)
+{
+    const uint32_t r = c & 7u;
+    if (MODE == XM_MODE_SE) return r;                                  // 0xFF -> 7, state 6 -> 6
+    const uint32_t f = (c >> 3) & 7u;
+    const uint32_t lo = f < r ? f : r, hi = f < r ? r : f;            // 0xFF -> lo = hi = 7
+    uint32_t b = lo;
+    if (MODE == XM_MODE_PE_CONSERVATIVE) {
+        b = (((f ^ r) & 1u) != 0u || hi == 4u) ? 4u : b;              // :525-529
+        b = (hi == 5u) ? 5u : b;                                       // :521
+        b = (hi == 7u) ? 7u : b;
+    }
+    return (hi == 6u) ? 6u : b;
+}
+
+// number of 4-bit fields of w equal to 6
+__device__ __forceinline__ uint32_t count_nibbles_eq6(uint32_t w)
+{
+    const uint32_t t = w ^ 0x66666666u;                                // zero nibble <=> field was 6
+    const uint32_t z = ~(((t & 0x77777777u) + 0x77777777u) | t) & 0x88888888u;
+    return (uint32_t)__builtin_popcount(z);
+}
+
+__device__ __forceinline__ uint64_t wave_scan_incl64(uint64_t v)
+{
+    // fields never carry across bit 32 (each word holds three 10-bit fields + spare bits), so the two
+    // halves scan independently
+    const uint32_t lo = wave_scan_incl((uint32_t)v), hi = wave_scan_incl((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int MODE, int K, int ABL = 0>      // ABL: ablation switches for tools/tune_kernels.hip only (0 = product)
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stride,
                const uint32_t *__restrict__ chunk_off, const unsigned long long *__restrict__ bin_totals,
                unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out)
 {
-    __shared__ uint4 tile_state[K][XM_BLOCK];         // per lane and tile: {bins lo, bins hi, counts x, counts y}
-    __shared__ uint32_t stage[XM_BLOCK / 64][XM_WTILE];
+    __shared__ uint4 tile_state[K][XM_BLOCK];            // per lane and tile: {bins lo, bins hi, counters lo, hi}
+    __shared__ uint16_t stage[XM_BLOCK / 64][XM_WTILE];   // record offsets inside the wave tile (0..1023)
     __shared__ uint32_t wave_tot[XM_BLOCK / 64][8];
 
     const uint32_t t = threadIdx.x, lane = t & 63u;
@@ -371,9 +405,8 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
     }
     if (blockIdx.x == 0 && t < 8) bin_offsets[t] = bin_start;       // lanes 0..7 of wave 0
 
-    // ---- phase 1: bytes -> bins (4 bits each) and per-lane counters, all tiles of the span
-    // per tile: bin of record j in bits 4j..4j+2 of two words (7 = not a unit); per-lane counts of
-    // bins 0..2 / 3..5 as 10-bit fields of two words.  Parked in LDS so that phase 2 can be a rolled loop.
+    // ---- phase 1: bytes -> bins (4 bits each, 7 = not a unit) and per-lane counters, every tile of the span;
+    //      parked in LDS so that phase 2 can be a rolled loop
     uint32_t lane_tot[7] = {0, 0, 0, 0, 0, 0, 0};
     uint32_t err_tiles = 0;          // bit k: this lane holds a state-6 unit in tile k
     {
@@ -382,7 +415,8 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
 #pragma unroll 1
         for (int k = 0; k < K; ++k) {
             if (k + 1 < K) load_codes16(code, span0 + (uint64_t)(k + 1) * XM_WTILE + lane * 16u, n, wn);   // prefetch
-            uint32_t x = 0, y = 0, n0 = 0, n1 = 0, c6 = 0;
+            uint64_t cnt = 0;
+            uint32_t n0 = 0, n1 = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
@@ -390,28 +424,24 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
                     if (j < 8) n0 |= 7u << (4 * j); else n1 |= 7u << (4 * (j - 8));
                     continue;
                 }
-                const uint32_t b = bin_of_code(MODE, c);
+                const uint32_t b = bin_of_byte<MODE>(c);
                 if (j < 8) n0 |= b << (4 * j); else n1 |= b << (4 * (j - 8));
-                bool valid, in_x; uint32_t sh;
-                bin_fields(b, valid, in_x, sh);
-                const uint32_t inc = valid ? (1u << sh) : 0u;
-                x += in_x ? inc : 0u;
-                y += in_x ? 0u : inc;
-                c6 += (b == 6u) ? 1u : 0u;
+                cnt += 1ull << bin_shift(b);
             }
-            tile_state[k][t] = make_uint4(n0, n1, x, y);
+            tile_state[k][t] = make_uint4(n0, n1, (uint32_t)cnt, (uint32_t)(cnt >> 32));
 #pragma unroll
             for (int bb = 0; bb < 3; ++bb) {
-                lane_tot[bb] += (x >> (10 * bb)) & 0x3FFu;
-                lane_tot[3 + bb] += (y >> (10 * bb)) & 0x3FFu;
+                lane_tot[bb] += ((uint32_t)cnt >> (10 * bb)) & 0x3FFu;
+                lane_tot[3 + bb] += ((uint32_t)(cnt >> 32) >> (10 * bb)) & 0x3FFu;
             }
+            const uint32_t c6 = count_nibbles_eq6(n0) + count_nibbles_eq6(n1);
             lane_tot[6] += c6;
             err_tiles |= (c6 != 0u) ? (1u << k) : 0u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] = wn[q];
         }
     }
-    // wave totals of the span (two 16-bit fields per word: at most 8192 per bin)
+    // wave totals of the span (two 16-bit fields per word: at most K*1024 per bin)
     {
         const uint32_t p01 = wave_scan_incl(lane_tot[0] | (lane_tot[1] << 16));
         const uint32_t p23 = wave_scan_incl(lane_tot[2] | (lane_tot[3] << 16));
@@ -435,56 +465,60 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
     }
 
     // ---- phase 2: tile by tile, no workgroup synchronisation
-    uint32_t *slab = stage[wave];
+    uint16_t *slab = stage[wave];
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
         const uint4 ts = tile_state[k][t];
-        const uint32_t nib0 = ts.x, nib1 = ts.y, cxk = ts.z, cyk = ts.w;
-        const uint32_t ix = wave_scan_incl(cxk), iy = wave_scan_incl(cyk);
-        const uint32_t ex = ix - cxk, ey = iy - cyk;
+        const uint32_t nib0 = ts.x, nib1 = ts.y;
+        const uint64_t cnt = ((uint64_t)ts.w << 32) | ts.z;
+        const uint64_t excl = wave_scan_incl64(cnt) - cnt;
         // tile totals per bin = lane 63's exclusive prefix + own count (added per field: a field may reach 1024)
-        const uint32_t ex63 = lane_value(ex, 63), ey63 = lane_value(ey, 63);
-        const uint32_t cx63 = lane_value(cxk, 63), cy63 = lane_value(cyk, 63);
-        uint32_t cnt[6], lstart[6];
+        const uint32_t ex63 = lane_value((uint32_t)excl, 63), ey63 = lane_value((uint32_t)(excl >> 32), 63);
+        const uint32_t cx63 = lane_value((uint32_t)cnt, 63), cy63 = lane_value((uint32_t)(cnt >> 32), 63);
+        uint32_t tcnt[6], lstart[6];
         uint32_t acc = 0;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const uint32_t e = (b < 3) ? ex63 : ey63, c = (b < 3) ? cx63 : cy63;
             const int f = 10 * (b % 3);
-            cnt[b] = ((e >> f) & 0x3FFu) + ((c >> f) & 0x3FFu);
+            tcnt[b] = ((e >> f) & 0x3FFu) + ((c >> f) & 0x3FFu);
             lstart[b] = acc;
-            acc += cnt[b];
+            acc += tcnt[b];
         }
         // running positions, packed like the counters
-        uint32_t px = ex + (lstart[0] | (lstart[1] << 10) | (lstart[2] << 20));
-        uint32_t py = ey + (lstart[3] | (lstart[4] << 10) | (lstart[5] << 20));
-        const uint32_t rec0 = (uint32_t)(span0 + (uint64_t)k * XM_WTILE) + lane * 16u;
+        uint64_t pos = excl + (((uint64_t)(lstart[3] | (lstart[4] << 10) | (lstart[5] << 20)) << 32)
+                               | (uint64_t)(lstart[0] | (lstart[1] << 10) | (lstart[2] << 20)));
+        const uint32_t tile0 = (uint32_t)(span0 + (uint64_t)k * XM_WTILE);
+        const uint32_t rec0 = tile0 + lane * 16u;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t b = ((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u;
-            bool valid, in_x; uint32_t sh;
-            bin_fields(b, valid, in_x, sh);
+            const bool valid = b < 6u;
             if (__ballot(valid) == 0ull) continue;                    // wave-uniform
-            const uint32_t pos = ((in_x ? px : py) >> sh) & 0x3FFu;
-            if (valid) slab[pos] = rec0 + (uint32_t)j;
-            const uint32_t inc = valid ? (1u << sh) : 0u;
-            px += in_x ? inc : 0u;
-            py += in_x ? 0u : inc;
+            const uint32_t sh = bin_shift(b);
+            const uint32_t p = (uint32_t)(pos >> sh) & 0x3FFu;
+            if (ABL < 2) { if (valid) slab[p] = (uint16_t)(lane * 16u + (uint32_t)j); }
+            else asm volatile("" :: "v"(p));
+            pos += 1ull << sh;                                        // bins 6, 7 land in the sink
         }
         // each bin's run, contiguous in LDS and contiguous in idx_out
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             // streamed out once and read by the host only: non-temporal, so the 200 MB of indices do not push
             // the category bytes (re-read by K2, rewritten by the next K1) out of the Infinity Cache
-            for (uint32_t e = lane; e < cnt[b]; e += 64u)
-                __builtin_nontemporal_store(slab[lstart[b] + e], idx_out + gbase[b] + e);
-            gbase[b] += cnt[b];
+            if (ABL == 0) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u)
+                    __builtin_nontemporal_store(tile0 + (uint32_t)slab[lstart[b] + e], idx_out + gbase[b] + e);
+            } else if (ABL == 1) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u) asm volatile("" :: "v"((uint32_t)slab[lstart[b] + e]));
+            } else if (ABL == 3) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u) idx_out[gbase[b] + e] = tile0 + (uint32_t)slab[lstart[b] + e];
+            }
+            gbase[b] += tcnt[b];
         }
         // state-6 units (rare)
         if (__ballot((err_tiles >> k) & 1u) != 0ull) {
-            uint32_t c6 = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) c6 += ((((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u) == 6u) ? 1u : 0u;
+            const uint32_t c6 = count_nibbles_eq6(nib0) + count_nibbles_eq6(nib1);
             const uint32_t i6 = wave_scan_incl(c6);
             uint32_t run6 = gbase[6] + i6 - c6;
 #pragma unroll
