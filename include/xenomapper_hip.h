@@ -104,6 +104,18 @@ int xm_cigar_scores(xm_ctx *ctx, uint64_t n_records, const int32_t *nm,
                     const uint32_t *cig_off, const uint32_t *cig_oplen, int32_t *as_out);
 
 /*
+ * The --cigar_scores path in one call (main loop + tag_func = get_cigarbased_AS_tag, xenomapper.py:684-685,
+ * :228-256): AS of both species is synthesised from NM + CIGAR inside the classify kernel (never stored),
+ * XS comes from the xs1/xs2 columns (the real XS tag when present, :245-246).  Same outputs as xm_classify.
+ * XM_ERR_RANGE if a synthesised score leaves int32.
+ */
+int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n_records,
+                      const int32_t *nm1, const uint32_t *cig_off1, const uint32_t *cig_oplen1, const int32_t *xs1,
+                      const int32_t *nm2, const uint32_t *cig_off2, const uint32_t *cig_oplen2, const int32_t *xs2,
+                      const uint64_t *unit_bits, int32_t min_score_floor,
+                      uint8_t *code_out, uint64_t counts[64]);
+
+/*
  * Replaces the bin routing of the main loops (the if/elif chains xenomapper.py:332-350,
  * :423-448, :521-550) and category_counts: a stable split of the unit indices by output bin.
  * idx_out (capacity >= number of units, n_records always suffices) receives, bin after bin,
@@ -132,6 +144,12 @@ int xm_classify_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
 int xm_classify_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
                         const double *as1, const double *xs1, const double *as2, const double *xs2,
                         const uint64_t *unit_bits, double min_score, uint8_t *code_out);
+
+int xm_classify_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                          const int32_t *nm1, const uint32_t *cig_off1, const uint32_t *cig_oplen1, const int32_t *xs1,
+                          const int32_t *nm2, const uint32_t *cig_off2, const uint32_t *cig_oplen2, const int32_t *xs2,
+                          const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                          uint32_t *range_flag);
 
 /* range_flag: one device uint32, set non-zero when a score left int32 (may be NULL). */
 int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n_records, const int32_t *nm,

@@ -193,6 +193,49 @@ def test_cigar_scores(ctx):
         ctx.cigar_scores(np.array([0], np.int32), np.array([0, 8], np.uint32), big)
 
 
+def _oracle_cigar_classify(mode, c1, xs1, c2, xs2, bits, mi):
+    a1, bad1 = H.c_cigar_scores(c1["nm"], c1["cig_off"], c1["cig_oplen"])
+    a2, bad2 = H.c_cigar_scores(c2["nm"], c2["cig_off"], c2["cig_oplen"])
+    assert bad1 == 0 and bad2 == 0
+    return H.c_classify(mode, a1, xs1, a2, xs2, bits, mi)
+
+
+def _random_cigar(rng, n, max_ops=12):
+    n_ops = rng.integers(0, max_ops + 1, n).astype(np.uint32)
+    n_ops[rng.random(n) < 0.5] = 1
+    off = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum(n_ops, out=off[1:])
+    total = int(off[-1])
+    ops = (rng.integers(1, 60, total).astype(np.uint32) << 4) | rng.integers(0, 9, total).astype(np.uint32)
+    nm = np.where(rng.random(n) < 0.15, ABSENT, rng.integers(0, 6, n)).astype(np.int32)
+    return {"nm": nm, "cig_off": off, "cig_oplen": ops}
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 257, 2047, 2048, 2049, 4097, 100_003])
+def test_classify_cigar_fused(ctx, n):
+    """K3 fused into K1 (the --cigar_scores path) against oracle CIGAR scores + oracle classify."""
+    rng = np.random.default_rng(100 + n)
+    c1, c2 = _random_cigar(rng, n), _random_cigar(rng, n)
+    xs = [np.where(rng.random(n) < 0.8, ABSENT, -rng.integers(0, 200, n)).astype(np.int32) for _ in range(2)]
+    for mode, m in itertools.product((0, 1, 2), (NEG, -40.5)):
+        flags = rng.random(n) < (0.55 if mode else 0.9)
+        bits = H.synth.pack_unit_bits(flags) if n else np.zeros(1, dtype=np.uint64)
+        mi = H.floor_min_score(m)
+        code, counts = ctx.classify_cigar(mode, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs[0],
+                                          c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, mi)
+        want, want_counts = _oracle_cigar_classify(mode, c1, xs[0], c2, xs[1], bits, mi)
+        assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+
+
+def test_classify_cigar_range_error(ctx):
+    big = np.array([((2**28 - 1) << 4) | 1] * 8, dtype=np.uint32)
+    one = {"nm": np.array([0], np.int32), "off": np.array([0, 8], np.uint32)}
+    none = np.array([ABSENT], np.int32)
+    with pytest.raises(OverflowError):
+        ctx.classify_cigar(0, one["nm"], one["off"], big, none, one["nm"], one["off"], big, none,
+                           np.array([1], np.uint64), ABSENT)
+
+
 @pytest.mark.parametrize("case", [c for c in H.golden("g3_end_to_end.json")["cases"]],
                          ids=lambda c: c["name"])
 def test_g3_units_on_gpu(ctx, case):
@@ -279,3 +322,71 @@ def test_device_entry_points_and_full_size(ctx):
         for b in range(6):
             seg = h_idx[int(h_off[b]):int(h_off[b + 1])]
             assert (np.diff(seg.astype(np.int64)) > 0).all()                              # stable within a bin
+
+
+def test_full_size_cfg3_cigar(ctx):
+    """BASELINE.json configs[2]: 50 M paired-end pairs on the --cigar_scores path (no AS tag; NM + CIGAR),
+    device-resident, fused K3+K1 then K2; exact against the C oracle."""
+    import torch
+    from xenomapper_amd import _ffi
+    n_pairs = 50_000_000
+    n = 2 * n_pairs
+    c1 = H.synth.cigar_columns(n, seed=3003)
+    c2 = H.synth.cigar_columns(n, seed=3004, mapped_p=0.3)
+    rng = np.random.default_rng(3005)
+    xs1 = np.where(rng.random(n) < 0.95, ABSENT, -rng.integers(0, 40, n)).astype(np.int32)
+    xs2 = np.full(n, ABSENT, dtype=np.int32)
+    bits = H.synth.interleaved_unit_bits(n)
+    dev = torch.device("cuda:0")
+
+    def up(a):
+        return torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else (a.view(np.int64) if a.dtype == np.uint64 else a)).to(dev)
+    d = [up(x) for x in (c1["nm"], c1["cig_off"], c1["cig_oplen"], xs1, c2["nm"], c2["cig_off"], c2["cig_oplen"], xs2, bits)]
+    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    flag = torch.zeros(4, dtype=torch.int32, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    mode = _ffi.MODE_PE_LIBERAL
+    ctx.classify_cigar_dev(mode, *d, ABSENT, code, range_flag=flag)
+    ctx.compact_dev(mode, code[:n], idx, off, counts)
+    torch.cuda.synchronize()
+    assert int(flag[0].item()) == 0
+    want, want_counts = _oracle_cigar_classify(mode, c1, xs1, c2, xs2, bits, ABSENT)
+    assert np.array_equal(code[:n].cpu().numpy(), want)
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+    want_idx, want_off = H.c_compact(mode, want)
+    h_off = off.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(h_off, want_off)
+    assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)
+    k_bar = (c1["cig_oplen"].shape[0] + c2["cig_oplen"].shape[0]) / (2.0 * n)
+    print("cfg3 mean CIGAR ops per record: %.3f -> algorithmic %.1f B/pair" % (k_bar, 4 * (12 + 4 * k_bar) + 6))
+
+
+def test_full_size_cfg5_zs_conservative(ctx):
+    """BASELINE.json configs[4]: 50 M pairs, HISAT-style scores (AS in [-90, 0], second-best from ZS incl. the
+    AS = 0 / ZS = 0 records that exercise the `not XS` quirk), --conservative; exact against the C oracle."""
+    import torch
+    from xenomapper_amd import _ffi
+    n_pairs = 50_000_000
+    n = 2 * n_pairs
+    dev = torch.device("cuda:0")
+    cols = H.synth.score_columns_torch(n_pairs, seed=5005, device=dev, profile="hisat")
+    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    host = {k: v.cpu().numpy() for k, v in cols.items()}
+    host["unit_bits"] = host["unit_bits"].view(np.uint64)
+    assert int(((host["as1"] == 0) & (host["xs1"] == 0)).sum()) > 1000          # the quirk is exercised
+    for mode, m in ((_ffi.MODE_PE_CONSERVATIVE, ABSENT), (_ffi.MODE_PE_CONSERVATIVE, -30)):
+        ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], m, code)
+        ctx.compact_dev(mode, code[:n], idx, off, counts)
+        torch.cuda.synchronize()
+        want, want_counts = H.c_classify(mode, host["as1"], host["xs1"], host["as2"], host["xs2"], host["unit_bits"], m)
+        want_idx, want_off = H.c_compact(mode, want)
+        assert np.array_equal(code[:n].cpu().numpy(), want)
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+        h_off = off.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(h_off, want_off)
+        assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)

@@ -75,6 +75,8 @@ def lib():
         "xm_classify": ([P, I, U64, P, P, P, P, P, I32, P, P], I),
         "xm_classify_f64": ([P, I, U64, P, P, P, P, P, F64, P, P], I),
         "xm_cigar_scores": ([P, U64, P, P, P, P], I),
+        "xm_classify_cigar": ([P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P], I),
+        "xm_classify_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P], I),
         "xm_compact": ([P, I, U64, P, P, P, P], I),
         "xm_classify_dev": ([P, P, I, U64, P, P, P, P, P, I32, P], I),
         "xm_classify_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P], I),
@@ -93,8 +95,9 @@ def lib():
 
 
 EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create", "xm_ctx_destroy",
-            "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_compact",
-            "xm_classify_dev", "xm_classify_f64_dev", "xm_cigar_scores_dev", "xm_compact_dev",
+            "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_classify_cigar",
+            "xm_compact", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
+            "xm_compact_dev",
             "xm_timing_enable", "xm_timing_reset", "xm_timing_read")
 
 
@@ -191,6 +194,23 @@ class Context(object):
         self._check(rc, "xm_cigar_scores")
         return out
 
+    def classify_cigar(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor):
+        """The --cigar_scores path: AS from NM + CIGAR inside the classify kernel."""
+        a = [_as(nm1, np.int32), _as(off1, np.uint32), _as(ops1, np.uint32), _as(xs1, np.int32),
+             _as(nm2, np.int32), _as(off2, np.uint32), _as(ops2, np.uint32), _as(xs2, np.int32)]
+        n = a[0].shape[0]
+        for k in (2, 6):
+            if a[k].shape[0] == 0:
+                a[k] = np.zeros(1, dtype=np.uint32)
+        assert a[1].shape[0] == n + 1 and a[5].shape[0] == n + 1
+        bits = _as(unit_bits, np.uint64)
+        code = np.empty(n, dtype=np.uint8)
+        counts = np.zeros(64, dtype=np.uint64)
+        rc = self._L.xm_classify_cigar(self._h, mode, n, *[_np_ptr(x) for x in a], _np_ptr(bits),
+                                       int(min_score_floor), _np_ptr(code), _np_ptr(counts))
+        self._check(rc, "xm_classify_cigar")
+        return code, counts
+
     def compact(self, mode, code):
         code = _as(code, np.uint8)
         n = code.shape[0]
@@ -221,6 +241,15 @@ class Context(object):
             rc = self._L.xm_classify_f64_dev(self._h, st, mode, n, *ptrs, float(min_score),
                                              ctypes.c_void_p(code_out.data_ptr()))
         self._check(rc, "xm_classify_dev")
+
+    def classify_cigar_dev(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
+                           code_out, range_flag=None, stream=None):
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits)]
+        rc = self._L.xm_classify_cigar_dev(
+            self._h, self._stream_handle(stream), mode, nm1.numel(), *ptrs, int(min_score_floor),
+            ctypes.c_void_p(code_out.data_ptr()),
+            ctypes.c_void_p(range_flag.data_ptr()) if range_flag is not None else None)
+        self._check(rc, "xm_classify_cigar_dev")
 
     def cigar_scores_dev(self, nm, cig_off, cig_oplen, as_out, range_flag=None, stream=None):
         rc = self._L.xm_cigar_scores_dev(

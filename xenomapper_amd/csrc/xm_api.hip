@@ -245,6 +245,27 @@ int xm_classify_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     return check_launch(ctx, "classify_kernel<f64>");
 }
 
+int xm_classify_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                          const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                          const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                          const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint32_t *range_flag)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!nm1 || !off1 || !ops1 || !xs1 || !nm2 || !off2 || !ops2 || !xs2 || !unit_bits || !code_out)
+        return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)nm1 | (uintptr_t)off1 | (uintptr_t)xs1 | (uintptr_t)nm2 | (uintptr_t)off2 | (uintptr_t)xs2) & 15u) ||
+        ((uintptr_t)code_out & 3u))
+        return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_cigar(st, mode, n, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
+                                  code_out, range_flag);
+    }
+    return check_launch(ctx, "classify_cigar_kernel");
+}
+
 int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n, const int32_t *nm,
                         const uint32_t *cig_off, const uint32_t *cig_oplen, int32_t *as_out,
                         uint32_t *range_flag)
@@ -376,6 +397,58 @@ int xm_cigar_scores(xm_ctx *ctx, uint64_t n, const int32_t *nm, const uint32_t *
     XM_HIP(ctx, hipMemcpy(as_out, ctx->d_scratch[3], n * 4, hipMemcpyDeviceToHost));
     XM_HIP(ctx, hipMemcpy(&flag, ctx->d_scratch[6], 4, hipMemcpyDeviceToHost));
     return flag ? XM_ERR_RANGE : XM_OK;
+}
+
+int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n,
+                      const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                      const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                      const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint64_t counts[64])
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (counts) memset(counts, 0, 64 * sizeof(uint64_t));
+    if (n == 0) return XM_OK;
+    if (!nm1 || !off1 || !xs1 || !nm2 || !off2 || !xs2 || !unit_bits || !code_out) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_ops1 = off1[n], n_ops2 = off2[n];
+    if ((n_ops1 && !ops1) || (n_ops2 && !ops2)) return XM_ERR_INVALID_ARG;
+    // one scratch slab: [nm1 | off1 | xs1 | nm2 | off2 | xs2 | bits | flag | ops1 | ops2], every piece 16-byte aligned
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sz_col = up(n * 4), sz_off = up((n + 1) * 4), sz_bits = up(((n + 63) / 64) * 8);
+    const size_t total = 4 * sz_col + 2 * sz_off + sz_bits + 256 + up(n_ops1 * 4 + 4) + up(n_ops2 * 4 + 4);
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, total)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    uint8_t *base = (uint8_t *)ctx->d_scratch[0];
+    size_t o = 0;
+    auto put = [&](const void *src, size_t bytes, size_t reserve) -> void * {
+        void *d = base + o;
+        o += reserve;
+        if (bytes && src && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    };
+    void *d_nm1 = put(nm1, n * 4, sz_col), *d_off1 = put(off1, (n + 1) * 4, sz_off), *d_xs1 = put(xs1, n * 4, sz_col);
+    void *d_nm2 = put(nm2, n * 4, sz_col), *d_off2 = put(off2, (n + 1) * 4, sz_off), *d_xs2 = put(xs2, n * 4, sz_col);
+    void *d_bits = put(unit_bits, ((n + 63) / 64) * 8, sz_bits);
+    void *d_flag = put(nullptr, 0, 256);
+    void *d_ops1 = put(ops1, n_ops1 * 4, up(n_ops1 * 4 + 4)), *d_ops2 = put(ops2, n_ops2 * 4, up(n_ops2 * 4 + 4));
+    if (!d_nm1 || !d_off1 || !d_xs1 || !d_nm2 || !d_off2 || !d_xs2 || !d_bits || !d_ops1 || !d_ops2)
+        return fail_hip(ctx, hipGetLastError(), "hipMemcpy(cigar columns)");
+    XM_HIP(ctx, hipMemset(d_flag, 0, 16));
+    uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
+    rc = xm_classify_cigar_dev(ctx, nullptr, mode, n, (const int32_t *)d_nm1, (const uint32_t *)d_off1,
+                               (const uint32_t *)d_ops1, (const int32_t *)d_xs1, (const int32_t *)d_nm2,
+                               (const uint32_t *)d_off2, (const uint32_t *)d_ops2, (const int32_t *)d_xs2,
+                               (const uint64_t *)d_bits, min_score_floor, d_code, (uint32_t *)d_flag);
+    if (rc != XM_OK) return rc;
+    uint32_t flag = 0;
+    XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
+    XM_HIP(ctx, hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
+    if (flag) return XM_ERR_RANGE;
+    if (counts) {
+        for (uint64_t i = 0; i < n; ++i)
+            if (code_out[i] != XM_NO_UNIT) counts[code_out[i] & 63u]++;
+    }
+    return XM_OK;
 }
 
 int xm_compact(xm_ctx *ctx, int mode, uint64_t n, const uint8_t *code, uint32_t *idx_out,

@@ -31,6 +31,10 @@ void launch_classify_i32(hipStream_t st, int mode, uint64_t n,
 void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
                          const double *as1, const double *xs1, const double *as2, const double *xs2,
                          const uint64_t *unit_bits, double m, uint8_t *code);
+void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
+                           const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                           const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag);
 void launch_hist(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
                  uint32_t *chunk_counts, uint64_t *counts_rep);
 void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_counts, uint32_t *chunk_off,

@@ -85,49 +85,15 @@ __device__ __forceinline__ void load4(const T *__restrict__ col, uint64_t r0, ui
     }
 }
 
-// One lane owns 4 consecutive records, so each column is read with one 16-byte (int32) load per
-// lane, 1 KiB contiguous per wave instruction; a wave covers a 256-record tile, a workgroup BLOCK*4
-// consecutive records, and the grid covers the whole input once (no grid-stride loop: on MI355X the
-// one-tile-per-wave launch measured 20-25 % faster than a persistent 2048-workgroup loop, see
-// profiles/r01_tune_classify.txt).  The forward mate's state of a lane's first record comes from
-// lane-1 (shuffle); lane 0 takes it from the previous wave of the workgroup through LDS, and the
-// first wave of a workgroup from the one record in front of the workgroup's range.
-// NT: the score columns are read once and never again, so they are loaded non-temporally; the
-// category bytes are stored with the default policy because K2 reads them next (100 MB at the
-// 50 M-pair configuration, which fits the 256 MiB Infinity Cache).
-template <typename T, bool PAIRED, bool NT, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
-classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
-                const T *__restrict__ as2, const T *__restrict__ xs2,
-                const uint8_t *__restrict__ unit_bits8, T m,
-                uint8_t *__restrict__ code, uint64_t n)
+// Shared K1 epilogue: 4 states per lane -> forward mate's state (lane-1 / previous wave via LDS / halo) ->
+// 4 category bytes -> one 4-byte store.
+template <typename T, bool PAIRED, int BLOCK>
+__device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], const T a2[4], const T x2[4], T m,
+                                                uint32_t mb, uint32_t halo, uint32_t *last_state,
+                                                uint8_t *__restrict__ code, uint64_t r0, uint64_t n)
 {
-    __shared__ uint32_t last_state[BLOCK / 64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
-    const uint64_t r0 = g * 4;
-
-    T a1[4], x1[4], a2[4], x2[4];
-    load4<T, NT>(as1, r0, n, a1);
-    load4<T, NT>(xs1, r0, n, x1);
-    load4<T, NT>(as2, r0, n, a2);
-    load4<T, NT>(xs2, r0, n, x2);
-    uint32_t mb = 0;
-    if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
-    if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
-
-    // the record in front of the workgroup's range (thread 0 only)
-    uint32_t halo = 0;
-    if (PAIRED && threadIdx.x == 0) {
-        if (r0 > 0) {
-            const uint64_t h = r0 - 1;                         // r0 <= n here, so h < n
-            halo = (r0 <= n) ? mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m) : 0u;
-        } else {
-            mb &= ~1u;                                         // record 0 has no predecessor (:402)
-        }
-    }
-
     uint32_t s[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = mapping_state<T>(a1[j], x1[j], a2[j], x2[j], m);
@@ -154,6 +120,50 @@ classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
         for (int j = 0; j < 4; ++j)
             if (r0 + j < n) code[r0 + j] = (uint8_t)c[j];
     }
+}
+
+// One lane owns 4 consecutive records, so each column is read with one 16-byte (int32) load per
+// lane, 1 KiB contiguous per wave instruction; a wave covers a 256-record tile, a workgroup BLOCK*4
+// consecutive records, and the grid covers the whole input once (no grid-stride loop: on MI355X the
+// one-tile-per-wave launch measured 20-25 % faster than a persistent 2048-workgroup loop, see
+// profiles/r01_tune_classify.txt).  The forward mate's state of a lane's first record comes from
+// lane-1 (shuffle); lane 0 takes it from the previous wave of the workgroup through LDS, and the
+// first wave of a workgroup from the one record in front of the workgroup's range.
+// NT: the score columns are read once and never again, so they are loaded non-temporally; the
+// category bytes are stored with the default policy because K2 reads them next (100 MB at the
+// 50 M-pair configuration, which fits the 256 MiB Infinity Cache).
+template <typename T, bool PAIRED, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
+                const T *__restrict__ as2, const T *__restrict__ xs2,
+                const uint8_t *__restrict__ unit_bits8, T m,
+                uint8_t *__restrict__ code, uint64_t n)
+{
+    __shared__ uint32_t last_state[BLOCK / 64];
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
+    const uint64_t r0 = g * 4;
+
+    T a1[4], x1[4], a2[4], x2[4];
+    load4<T, NT>(as1, r0, n, a1);
+    load4<T, NT>(xs1, r0, n, x1);
+    load4<T, NT>(as2, r0, n, a2);
+    load4<T, NT>(xs2, r0, n, x2);
+    uint32_t mb = 0;
+    if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+    if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+
+    // the record in front of the workgroup's range (thread 0 only)
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 > 0) {
+            const uint64_t h = r0 - 1;                         // r0 <= n here, so h < n
+            halo = (r0 <= n) ? mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m) : 0u;
+        } else {
+            mb &= ~1u;                                         // record 0 has no predecessor (:402)
+        }
+    }
+
+    classify_finish<T, PAIRED, BLOCK>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -562,6 +572,120 @@ cigar_kernel(uint64_t n, const int32_t *__restrict__ nm, const uint32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1c: classify with AS synthesised from CIGAR + NM on the fly (the --cigar_scores path, ref :684-685):
+// K3 fused into K1, so the AS columns are never written to or read from memory.  Per species a lane
+// loads NM x4, XS x4, five CSR offsets, and the first XM_CIG_SPEC packed ops of each of its 4 records
+// speculatively (all loads issued together; adjacent lanes read adjacent ops); records with more ops
+// finish in a short loop.
+// ---------------------------------------------------------------------------------------------
+#define XM_CIG_SPEC 3
+
+__device__ __forceinline__ long long cigar_term(uint32_t v)
+{
+    const uint32_t op = v & 15u;
+    const long long len = (long long)(v >> 4);
+    long long t = (op == 1u || op == 2u) ? (5ll + 3ll * len) : 0ll;       // I, D: open + extend (:252-255)
+    t += (op == 4u) ? 2ll * len : 0ll;                                     // S
+    return t;
+}
+
+__device__ __forceinline__ int32_t cigar_clamp(long long s, uint32_t *range_flag)
+{
+    if (s <= (long long)INT32_MIN || s > (long long)INT32_MAX) {
+        if (range_flag) atomicOr(range_flag, 1u);
+        s = s < 0 ? (long long)INT32_MIN + 1 : (long long)INT32_MAX;
+    }
+    return (int32_t)s;
+}
+
+__device__ __forceinline__ int32_t cigar_score_one(const int32_t *__restrict__ nm, const uint32_t *__restrict__ off,
+                                                   const uint32_t *__restrict__ ops, uint64_t i, uint32_t *range_flag)
+{
+    const int32_t nmv = nm[i];
+    if (nmv == INT32_MIN) return INT32_MIN;
+    long long s = -6ll * (long long)nmv;
+    const uint32_t k1 = off[i + 1];
+    for (uint32_t k = off[i]; k < k1; ++k) s -= cigar_term(ops[k]);
+    return cigar_clamp(s, range_flag);
+}
+
+// AS of the lane's 4 records of one species
+__device__ __forceinline__ void cigar_scores4(const int32_t *__restrict__ nm, const uint32_t *__restrict__ off,
+                                              const uint32_t *__restrict__ ops, uint64_t r0, uint64_t n,
+                                              uint32_t *range_flag, int32_t as_out[4])
+{
+    int32_t nmv[4];
+    load4<int32_t, true>(nm, r0, n, nmv);
+    uint32_t o[5];
+    if (r0 + 4 <= n) {
+        const v4i32 q = __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(off + r0));
+        o[0] = (uint32_t)q.x; o[1] = (uint32_t)q.y; o[2] = (uint32_t)q.z; o[3] = (uint32_t)q.w;
+        o[4] = off[r0 + 4];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = (r0 + j <= n) ? off[r0 + j] : 0u;
+#pragma unroll
+        for (int j = 1; j < 5; ++j) o[j] = (r0 + j <= n) ? o[j] : o[j - 1];
+    }
+    uint32_t v[4][XM_CIG_SPEC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t k = o[j + 1] - o[j];
+#pragma unroll
+        for (int q = 0; q < XM_CIG_SPEC; ++q) v[j][q] = ((uint32_t)q < k) ? ops[o[j] + q] : 0u;   // op 0 (M) adds nothing
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long s = -6ll * (long long)nmv[j];
+#pragma unroll
+        for (int q = 0; q < XM_CIG_SPEC; ++q) s -= cigar_term(v[j][q]);
+        for (uint32_t k = o[j] + XM_CIG_SPEC; k < o[j + 1]; ++k) s -= cigar_term(ops[k]);
+        as_out[j] = (nmv[j] == INT32_MIN) ? INT32_MIN : cigar_clamp(s, range_flag);
+    }
+}
+
+template <bool PAIRED, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ ops1,
+                      const int32_t *__restrict__ xs1,
+                      const int32_t *__restrict__ nm2, const uint32_t *__restrict__ off2, const uint32_t *__restrict__ ops2,
+                      const int32_t *__restrict__ xs2,
+                      const uint8_t *__restrict__ unit_bits8, int32_t m, uint8_t *__restrict__ code, uint64_t n,
+                      uint32_t *__restrict__ range_flag)
+{
+    __shared__ uint32_t last_state[BLOCK / 64];
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t r0 = g * 4;
+
+    int32_t a1[4], x1[4], a2[4], x2[4];
+    load4<int32_t, true>(xs1, r0, n, x1);
+    load4<int32_t, true>(xs2, r0, n, x2);
+    uint32_t mb = 0;
+    if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+    if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+    if (r0 < n) {
+        cigar_scores4(nm1, off1, ops1, r0, n, range_flag, a1);
+        cigar_scores4(nm2, off2, ops2, r0, n, range_flag, a2);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a1[j] = a2[j] = INT32_MIN;
+    }
+
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 > 0) {
+            const uint64_t h = r0 - 1;
+            if (r0 <= n)
+                halo = mapping_state<int32_t>(cigar_score_one(nm1, off1, ops1, h, range_flag), xs1[h],
+                                              cigar_score_one(nm2, off2, ops2, h, range_flag), xs2[h], m);
+        } else {
+            mb &= ~1u;
+        }
+    }
+    classify_finish<int32_t, PAIRED, BLOCK>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -590,6 +714,22 @@ void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
                          const uint64_t *unit_bits, double m, uint8_t *code)
 {
     launch_classify_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code);
+}
+
+void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
+                           const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                           const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag)
+{
+    const uint64_t per_block = (uint64_t)XM_CLASSIFY_BLOCK * 4;
+    const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
+    const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
+    if (mode == XM_MODE_SE)
+        classify_cigar_kernel<false, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(
+            nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
+    else
+        classify_cigar_kernel<true, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(
+            nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
 }
 
 ChunkPlan plan_chunks(uint64_t n)

@@ -335,36 +335,42 @@ def _score_block(block, needed, tag_func, cigar_mode):
     return vals, nm, ops, scored, err
 
 
-def _cigar_as_column(ctx, nm, ops, n):
+def _cigar_csr(nm, ops, n):
     counts = np.fromiter((len(o) for o in ops[:n]), dtype=np.uint32, count=n)
     off = np.zeros(n + 1, dtype=np.uint32)
     np.cumsum(counts, out=off[1:])
     flat = np.fromiter((v for o in ops[:n] for v in o), dtype=np.uint32, count=int(off[-1]))
     nm_col = np.fromiter((_ABSENT if v is None else v for v in nm[:n]), dtype=np.int32, count=n)
-    return ctx.cigar_scores(nm_col, off, flat)
+    return nm_col, off, flat
 
 
 def _classify_block(ctx, mode, block, n, vals, nm, ops, cigar_mode, min_score):
     """-> (code u8[n], idx u32[units], bin_offsets u64[8], counts u64[64])"""
     flags = np.asarray(block.flags[:n], dtype=np.uint8)
     bits = np.packbits(np.concatenate([flags, np.zeros((-n) % 64, dtype=np.uint8)]), bitorder="little").view(np.uint64)
-    int_cols = []
-    for c in range(4):
-        if cigar_mode and c in (0, 2):
-            int_cols.append(_cigar_as_column(ctx, nm[c // 2], ops[c // 2], n))
+    integral = min_score == min_score
+    if cigar_mode:
+        csr = [_cigar_csr(nm[f], ops[f], n) for f in (0, 1)]
+        xs = [_to_int_column(vals[c][:n]) for c in (1, 3)]
+        if integral and xs[0] is not None and xs[1] is not None:
+            # AS is synthesised inside the classify kernel (fused K3 + K1)
+            code, counts = ctx.classify_cigar(mode, csr[0][0], csr[0][1], csr[0][2], xs[0],
+                                              csr[1][0], csr[1][1], csr[1][2], xs[1], bits, _floor_min_score(min_score))
         else:
-            int_cols.append(_to_int_column(vals[c][:n]))
-    if all(col is not None for col in int_cols) and min_score == min_score:
-        code, counts = ctx.classify(mode, *int_cols, bits, _floor_min_score(min_score))
+            # a non-integral XS or a NaN threshold: CIGAR kernel, then the binary64 classify kernel
+            fcols = []
+            for f in (0, 1):
+                a = ctx.cigar_scores(*csr[f])
+                fcols.append(np.where(a == _ABSENT, _NEG_INF, a.astype(np.float64)))
+                fcols.append(np.asarray(vals[2 * f + 1][:n], dtype=np.float64))
+            code, counts = ctx.classify_f64(mode, *fcols, bits, float(min_score))
     else:
-        fcols = []
-        for c in range(4):
-            if cigar_mode and c in (0, 2):
-                col = int_cols[c]
-                fcols.append(np.where(col == _ABSENT, _NEG_INF, col.astype(np.float64)))
-            else:
-                fcols.append(np.asarray(vals[c][:n], dtype=np.float64))
-        code, counts = ctx.classify_f64(mode, *fcols, bits, float(min_score))
+        int_cols = [_to_int_column(vals[c][:n]) for c in range(4)]
+        if integral and all(col is not None for col in int_cols):
+            code, counts = ctx.classify(mode, *int_cols, bits, _floor_min_score(min_score))
+        else:
+            fcols = [np.asarray(vals[c][:n], dtype=np.float64) for c in range(4)]
+            code, counts = ctx.classify_f64(mode, *fcols, bits, float(min_score))
     idx, off, _ = ctx.compact(mode, code)
     return code, idx, off, counts
 
