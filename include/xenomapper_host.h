@@ -1,0 +1,115 @@
+/*
+ * xenomapper_host.h -- C ABI of the host-side SAM column stripper and line writer
+ * (libxenomapper_host.so, plain C++17 + threads; no GPU code).
+ *
+ * These are the data formats either side of the classification path:
+ *   xmh_parse  replaces the lock-step reader getReadPairs (xenomapper.py:95-118) and the *text* half of the
+ *              tag_func plugins -- finding the AS / XS / ZS / NM fields by substring (xenomapper.py:186-190,
+ *              :247) and the CIGAR operations (xenomapper.py:251) -- and hands the device structure-of-arrays
+ *              columns instead of Python lists.  Arithmetic (scores, states, bins) stays on the GPU.
+ *   xmh_emit   replaces the '\t'.join(fields) + print() of the main loops (xenomapper.py:332-350, :423-448,
+ *              :521-550): gathers the lines of the units of one output bin, whitespace-normalised, in order.
+ *
+ * Exactness contract: anything this parser cannot reproduce bit-for-bit is *reported*, never guessed --
+ * values that are not plain int32 integers (floats, "inf", digits with '_', 64-bit values ...), duplicate tag
+ * matches and short lines come back as exceptions (record, column, kind) which the Python host resolves with
+ * the reference-equivalent text functions; input containing non-ASCII bytes is refused (XMH_ERR_NON_ASCII) and
+ * the host uses its Python reader for that input.
+ */
+#ifndef XENOMAPPER_HOST_H
+#define XENOMAPPER_HOST_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMH_ABI_VERSION 1
+
+#define XMH_OK              0
+#define XMH_ERR_INVALID_ARG (-1)
+#define XMH_ERR_OOM         (-2)
+#define XMH_ERR_NON_ASCII   (-3)   /* a byte >= 0x80 in the window: Python's str.split() rules would apply */
+
+/* which optional fields feed the score columns (the three tag_func plugins) */
+#define XMH_SCORE_AS_XS 0   /* get_tag                 xenomapper.py:176-191 */
+#define XMH_SCORE_AS_ZS 1   /* get_tag_with_ZS_as_XS   xenomapper.py:193-206 */
+#define XMH_SCORE_CIGAR 2   /* get_cigarbased_AS_tag   xenomapper.py:228-256 (NM + CIGAR -> CSR; XS by get_tag) */
+
+/* exception kinds (see xmh_block.exc_*) */
+#define XMH_EX_NONINT   1   /* value is not a plain integer in [-(2^31-1), 2^31-1]: re-parse in Python        */
+#define XMH_EX_DUP      2   /* more than one optional field contains the tag: ValueError (xenomapper.py:189)   */
+#define XMH_EX_SHORT    3   /* CIGAR mode, NM present but the line has fewer than 6 fields: IndexError         */
+#define XMH_EX_BIGLEN   4   /* a CIGAR operation length >= 2^28: does not fit the packed op column             */
+
+/* exception columns */
+#define XMH_COL_AS1 0
+#define XMH_COL_XS1 1
+#define XMH_COL_AS2 2
+#define XMH_COL_XS2 3
+
+/* line flags */
+#define XMH_LINE_NORMAL 1   /* the line already equals '\t'.join(fields) */
+
+typedef struct xmh_parser xmh_parser;
+
+/* Result of one xmh_parse call; every pointer addresses memory owned by the parser, valid until the next
+ * xmh_parse / xmh_parser_destroy on it. */
+typedef struct {
+    uint64_t n_records;        /* records yielded by the lock-step walk in this window                      */
+    uint64_t consumed1;        /* bytes of each window the walk is finished with (the next window starts      */
+    uint64_t consumed2;        /*   here).  With keep_halo the last yielded record is NOT consumed.           */
+    int32_t  ended;            /* 1: a blank line or EOF of either file ended the walk (xenomapper.py:105)    */
+    int32_t  starved;          /* 1: window exhausted before max_records, more input needed (not ended)       */
+    int64_t  mismatch_at;      /* first record whose names disagree (AssertionError, :106) or -1; records    */
+                               /*   at and after it are not reported                                           */
+    /* score columns, n_records each (XM_ABSENT = INT32_MIN when the tag is absent) */
+    const int32_t *as1, *xs1, *as2, *xs2;
+    /* CIGAR mode: nm (INT32_MIN = no NM field), CSR offsets (n_records + 1) and packed ops len<<4|op */
+    const int32_t *nm1, *nm2;
+    const uint32_t *cig_off1, *cig_off2, *cig_ops1, *cig_ops2;
+    /* packed unit mask, ceil(n/64) words: paired -> name[i] == name[i-1]; else every record */
+    const uint64_t *unit_bits;
+    /* the line of every record in each window (offset of first byte, length without terminator, flags,
+     * length after whitespace normalisation) */
+    const uint64_t *line_off1, *line_off2;
+    const uint32_t *line_len1, *line_len2, *norm_len1, *norm_len2;
+    const uint8_t  *line_flags1, *line_flags2;
+    /* exceptions, ordered by (record, column) */
+    uint64_t n_exc;
+    const uint32_t *exc_record;
+    const uint8_t  *exc_col, *exc_kind;
+} xmh_block;
+
+int xmh_abi_version(void);
+const char *xmh_strerror(int status);
+int xmh_parser_create(int n_threads, xmh_parser **out);
+int xmh_parser_destroy(xmh_parser *p);
+
+/*
+ * Walk two SAM record windows in lock-step.  buf*: the bytes after the header (or after what earlier calls
+ * consumed); eof*: the window reaches the end of the file.  paired: compute the unit mask from adjacent equal
+ * names (else every record is a unit).  skip_repeated: after each yielded pair advance each file past further
+ * lines carrying the same name (xenomapper.py:110-114).  keep_halo: leave the last yielded record unconsumed
+ * so that the next window starts with it -- as record 0 it closes no unit (its unit was emitted with this
+ * window), but it is the forward mate the next record is compared with.  At most max_records are yielded.
+ */
+int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const char *buf2, uint64_t len2, int eof2,
+              int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out);
+
+/*
+ * Text of one output bin for the block parsed last: for every unit index in idx[0..n_idx) (ascending, as
+ * xm_compact returns them) the lines the reference prints -- bins 0, 2, 5: file-1 lines; 1, 3: file-2 lines;
+ * 4: file-1 lines then file-2 lines; a paired unit covers records idx-1 and idx -- each as '\t'.join(fields)
+ * + '\n'.  Two-call protocol: with out == NULL only *out_len is computed.  buf1/buf2 must be the windows given
+ * to the xmh_parse call that produced the block.
+ */
+int xmh_emit(xmh_parser *p, const char *buf1, const char *buf2, int paired, int bin,
+             const uint32_t *idx, uint64_t n_idx, char *out, uint64_t out_cap, uint64_t *out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XENOMAPPER_HOST_H */

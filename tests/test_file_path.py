@@ -1,0 +1,157 @@
+"""File-to-file fast path (C++ stripper -> HIP kernels -> C++ writer) against the golden end-to-end
+outputs of the reference: six bin texts byte-identical, category_counts, summary; small windows, error
+handling, exceptional values, CLI."""
+import hashlib
+import io
+
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+G3 = H.golden("g3_end_to_end.json")["cases"]
+
+
+def run_files(xm, case, tmp_path, window=None, string_sinks=False):
+    t1, t2 = H.case_texts(case)
+    p1, p2 = tmp_path / "one.sam", tmp_path / "two.sam"
+    p1.write_text(t1, newline="")
+    p2.write_text(t2, newline="")
+    if string_sinks:
+        outs = {name: io.StringIO() for name in H.STATES}
+    else:
+        outs = {name: open(tmp_path / (name + ".sam"), "wt") for name in H.STATES}
+    hdr = outs if case["options"]["header_sinks"] == "all" else \
+        {k: outs[k] for k in ("primary_specific", "secondary_specific")}
+    with open(p1, "rt") as f1, open(p2, "rt") as f2:
+        xm.process_headers(f1, f2, **hdr)
+    old = xm.FILE_WINDOW_BYTES
+    if window:
+        xm.FILE_WINDOW_BYTES = window
+    try:
+        counts = xm.classify_sam_files(
+            str(p1), str(p2), paired=case["mode"] != "se", conservative=case["mode"] == "pe_conservative",
+            min_score=H.unnum(case["options"]["min_score"]), tag_func=getattr(xm, case["options"]["tag_func"]),
+            skip_repeated_reads=case["options"]["skip_repeated"], **outs)
+    finally:
+        xm.FILE_WINDOW_BYTES = old
+    texts = {}
+    for name, sink in outs.items():
+        if string_sinks:
+            texts[name] = sink.getvalue()
+        else:
+            sink.close()
+            texts[name] = (tmp_path / (name + ".sam")).read_text()
+    return counts, texts
+
+
+def check(xm, case, tmp_path, **kw):
+    counts, texts = run_files(xm, case, tmp_path, **kw)
+    exp = case["expect"]
+    flat = {("|".join(k) if isinstance(k, tuple) else k): v for k, v in counts.items()}
+    assert flat == exp["counts"]
+    for name in H.STATES:
+        assert len(texts[name]) == exp["bins"][name]["len"], name
+        assert hashlib.sha224(texts[name].encode("latin-1")).hexdigest() == exp["bins"][name]["sha224"], name
+    buf = io.StringIO()
+    xm.output_summary(counts, outfile=buf)
+    assert buf.getvalue() == exp["summary"]
+
+
+@pytest.mark.parametrize("case", G3, ids=[c["name"] for c in G3])
+def test_golden_files(case, tmp_path):
+    from xenomapper_amd import xenomapper as xm
+    check(xm, case, tmp_path)
+
+
+@pytest.mark.parametrize("name", ["ref_pe_liberal", "ref_se_skip_repeated", "all36_conservative", "all36_se_skip",
+                                   "cfg1_se_cli", "cfg2_pe_liberal", "cfg3_pe_cigar", "cfg5_pe_zs_conservative"])
+@pytest.mark.parametrize("window", [700, 4096, 65536])
+def test_small_windows(name, window, tmp_path):
+    from xenomapper_amd import xenomapper as xm
+    check(xm, {c["name"]: c for c in G3}[name], tmp_path, window=window)
+
+
+def test_string_sinks(tmp_path):
+    from xenomapper_amd import xenomapper as xm
+    check(xm, {c["name"]: c for c in G3}["all36_liberal"], tmp_path, string_sinks=True)
+
+
+def _rec(name, *opts):
+    return "\t".join([name, "0", "chr1", "1", "30", "10M", "*", "0", "0", "ACGT", "IIII"] + list(opts))
+
+
+def _files(tmp_path, lines1, lines2):
+    p1, p2 = tmp_path / "a.sam", tmp_path / "b.sam"
+    p1.write_text("@HD\tVN:1.0\n" + "\n".join(lines1) + "\n")
+    p2.write_text("@HD\tVN:1.0\n" + "\n".join(lines2) + "\n")
+    return str(p1), str(p2)
+
+
+def test_exceptional_values_and_errors(tmp_path):
+    from xenomapper_amd import xenomapper as xm
+    # floats / 64-bit values go through binary64 and agree with the Python-reader path
+    l1 = [_rec("a", "AS:f:12.5", "XS:f:12.25"), _rec("b", "AS:i:3000000000"), _rec("c", "AS:i:5", "XS:i:5"), _rec("d", "AS:i:1_0")]
+    l2 = [_rec("a", "AS:f:12.25"), _rec("b", "AS:i:3000000001"), _rec("c", "AS:f:4.999"), _rec("d", "AS:i:9")]
+    p1, p2 = _files(tmp_path, l1, l2)
+    out = io.StringIO()
+    counts = xm.classify_sam_files(p1, p2, primary_specific=out, min_score=4.5, skip_repeated_reads=False)
+    with open(p1) as f1, open(p2) as f2:
+        xm.get_sam_header(f1), xm.get_sam_header(f2)
+        ref_out = io.StringIO()
+        want = xm.main_single_end(xm.getReadPairs(f1, f2), primary_specific=ref_out, min_score=4.5)
+    assert counts == want and out.getvalue() == ref_out.getvalue()
+    # duplicate tag match -> ValueError after the records before it were written
+    l1 = [_rec("a", "AS:i:9"), _rec("b", "AS:i:9"), _rec("c", "AS:i:5", "RG:Z:BASS"), _rec("d", "AS:i:9")]
+    l2 = [_rec("a"), _rec("b"), _rec("c"), _rec("d")]
+    p1, p2 = _files(tmp_path, l1, l2)
+    out = io.StringIO()
+    with pytest.raises(ValueError):
+        xm.classify_sam_files(p1, p2, primary_specific=out, skip_repeated_reads=False)
+    assert out.getvalue().count("\n") == 2
+    # name mismatch -> AssertionError, earlier records written
+    p1, p2 = _files(tmp_path, [_rec("a", "AS:i:9"), _rec("b", "AS:i:9")], [_rec("a"), _rec("x")])
+    out = io.StringIO()
+    with pytest.raises(AssertionError):
+        xm.classify_sam_files(p1, p2, primary_specific=out, skip_repeated_reads=False)
+    assert out.getvalue().count("\n") == 1
+    # paired: the malformed tag of an unpaired record is never evaluated
+    l1 = [_rec("p", "AS:i:9"), _rec("p", "AS:i:9"), _rec("lonely", "AS:i:1", "RG:Z:BASS"), _rec("q", "AS:i:9"), _rec("q", "AS:i:9")]
+    l2 = [_rec("p"), _rec("p"), _rec("lonely"), _rec("q"), _rec("q")]
+    p1, p2 = _files(tmp_path, l1, l2)
+    out = io.StringIO()
+    counts = xm.classify_sam_files(p1, p2, primary_specific=out, paired=True)
+    assert counts == {("primary_specific", "primary_specific"): 2} and out.getvalue().count("\n") == 4
+    # NaN -> RuntimeError (ref :289)
+    p1, p2 = _files(tmp_path, [_rec("a", "AS:i:9"), _rec("n", "AS:f:nan")], [_rec("a"), _rec("n", "AS:i:2")])
+    out = io.StringIO()
+    with pytest.raises(RuntimeError):
+        xm.classify_sam_files(p1, p2, primary_specific=out, skip_repeated_reads=False)
+    assert out.getvalue().count("\n") == 1
+    # non-ASCII input falls back to the Python reader and still classifies
+    p1, p2 = _files(tmp_path, [_rec("a", "AS:i:9"), _rec("bé", "AS:i:9")], [_rec("a"), _rec("bé")])
+    out = io.StringIO()
+    counts = xm.classify_sam_files(p1, p2, primary_specific=out, skip_repeated_reads=False)
+    assert counts == {"primary_specific": 2}
+
+
+def test_cli_uses_fast_path(tmp_path, capsys, monkeypatch):
+    from xenomapper_amd import xenomapper as xm
+    case = {c["name"]: c for c in G3}["cfg5_pe_zs_conservative"]
+    t1, t2 = H.case_texts(case)
+    (tmp_path / "h.sam").write_text(t1)
+    (tmp_path / "m.sam").write_text(t2)
+    called = {}
+    real = xm.classify_sam_files
+    monkeypatch.setattr(xm, "classify_sam_files", lambda *a, **k: called.setdefault("yes", True) and real(*a, **k))
+    args = ["--primary_sam", str(tmp_path / "h.sam"), "--secondary_sam", str(tmp_path / "m.sam"),
+            "--paired", "--conservative", "--use_zs"]
+    for name in H.STATES:
+        args += ["--" + name, str(tmp_path / (name + ".sam"))]
+    xm.main(args)
+    assert called.get("yes")
+    assert capsys.readouterr().err == case["expect"]["summary"]
+    for name in H.STATES:
+        text = (tmp_path / (name + ".sam")).read_text()
+        assert hashlib.sha224(text.encode("latin-1")).hexdigest() == case["expect"]["bins"][name]["sha224"]

@@ -1,0 +1,230 @@
+"""The C++ SAM column stripper / line writer (libxenomapper_host.so) against the oracle's text-level
+restatement, on every golden end-to-end input plus newline / whitespace / error edge cases.  CPU only."""
+import io
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tests.helpers import ORACLE, NEG
+
+G3 = H.golden("g3_end_to_end.json")["cases"]
+ABSENT = -2**31
+SCORERS = {"get_tag": (0, ORACLE.tag_score), "get_tag_with_ZS_as_XS": (1, ORACLE.tag_score_zs),
+           "get_cigarbased_AS_tag": (2, ORACLE.cigar_score)}
+
+
+@pytest.fixture(scope="module")
+def parser():
+    from xenomapper_amd import _host, build
+    build.build_host()
+    p = _host.Parser(3)
+    yield p
+    p.close()
+
+
+def body_of(text):
+    """Bytes of a SAM text after its header lines."""
+    from xenomapper_amd import xenomapper as xm
+    raw = np.frombuffer(text.encode("ascii"), dtype=np.uint8)
+    return raw, xm._record_start(raw)
+
+
+def parse_all(parser, t1, t2, score_mode, paired, skip, keep_halo=False, max_records=1 << 22):
+    r1, p1 = body_of(t1)
+    r2, p2 = body_of(t2)
+    return parser.parse(r1, p1, len(r1) - p1, True, r2, p2, len(r2) - p2, True, score_mode, paired, skip, keep_halo,
+                        max_records), (r1, p1), (r2, p2)
+
+
+def oracle_pairs(t1, t2, skip):
+    s1, s2 = io.StringIO(t1), io.StringIO(t2)
+    ORACLE.read_header(s1), ORACLE.read_header(s2)
+    return list(ORACLE.read_pairs(s1, s2, skip))
+
+
+@pytest.mark.parametrize("case", G3, ids=[c["name"] for c in G3])
+def test_columns_and_lines_match_oracle(parser, case):
+    t1, t2 = H.case_texts(case)
+    score_mode, scorer = SCORERS[case["options"]["tag_func"]]
+    paired = case["mode"] != "se"
+    skip = case["options"]["skip_repeated"]
+    block, (r1, p1), (r2, p2) = parse_all(parser, t1, t2, score_mode, paired, skip)
+    pairs = oracle_pairs(t1, t2, skip)
+    assert block.n == len(pairs) == case["expect"]["n_records"]
+    assert block.ended and block.mismatch_at == -1
+    names = [p[0][0] for p in pairs]
+    flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:block.n]
+    want_flags = [1] * len(pairs) if not paired else [0] + [int(names[i] == names[i - 1]) for i in range(1, len(names))]
+    assert flags.tolist() == want_flags
+    exc = {(k, c) for k, c, _ in block.exc}
+    for k, (f1, f2) in enumerate(pairs):
+        for c, (fields, tag) in enumerate(((f1, "AS"), (f1, "XS"), (f2, "AS"), (f2, "XS"))):
+            if (k, c) in exc:
+                continue
+            if score_mode == 2 and tag == "AS":
+                nm_col, off, ops = block.csr[c // 2]
+                ops_k = ops[int(off[k]):int(off[k + 1])]
+                score = ABSENT if nm_col[k] == ABSENT else -6 * int(nm_col[k]) - sum(
+                    (5 + 3 * (int(v) >> 4)) if (int(v) & 15) in (1, 2) else (2 * (int(v) >> 4) if (int(v) & 15) == 4 else 0)
+                    for v in ops_k)
+                want = scorer(fields, tag="AS")
+                assert (score == ABSENT and want == NEG) or score == want, (k, fields)
+            else:
+                want = scorer(fields, tag=tag)
+                got = int(block.cols[c][k])
+                assert (got == ABSENT and want == NEG) or got == want, (k, c, fields)
+        # the line table addresses the record's text
+        for f, (raw, pos, fields) in enumerate(((r1, p1, f1), (r2, p2, f2))):
+            start = pos + int(block.line_off[f][k])
+            assert bytes(raw[start:start + int(block.line_len[f][k])]).decode().split() == fields
+
+
+@pytest.mark.parametrize("name", ["ref_se", "ref_pe_liberal", "ref_pe_conservative", "all36_liberal", "all36_se",
+                                   "cfg1_se", "cfg5_pe_zs_conservative"])
+def test_emit_reproduces_reference_bins(parser, name):
+    """xmh_emit output for the golden units equals the reference's bin texts (hash of header + body)."""
+    import hashlib
+    case = {c["name"]: c for c in G3}[name]
+    t1, t2 = H.case_texts(case)
+    score_mode, _ = SCORERS[case["options"]["tag_func"]]
+    paired = case["mode"] != "se"
+    block, _, _ = parse_all(parser, t1, t2, score_mode, paired, case["options"]["skip_repeated"])
+    exp = case["expect"]
+    mode = H.MODES[case["mode"]]
+    bins = [ORACLE.bin_of(mode, int(f), int(r)) for f, r in zip(exp["unit_fwd"], exp["unit_rev"])]
+    heads = [io.StringIO() for _ in range(6)]
+    ORACLE.write_headers(io.StringIO(t1), io.StringIO(t2), heads)
+    for b, state in enumerate(H.STATES):
+        idx = np.array([i for i, bb in zip(exp["unit_index"], bins) if bb == b], dtype=np.uint32)
+        body = bytes(parser.emit(paired, b, idx)).decode("ascii")
+        text = heads[b].getvalue() + body
+        assert hashlib.sha224(text.encode("latin-1")).hexdigest() == exp["bins"][state]["sha224"], state
+
+
+def sam(lines, nl="\n", tail=True):
+    return nl.join(lines) + (nl if tail else "")
+
+
+def rec(name, *opts, sep="\t"):
+    return sep.join([name, "0", "chr1", "1", "30", "10M", "*", "0", "0", "ACGT", "IIII"] + list(opts))
+
+
+def parse_text(parser, t1, t2, score_mode=0, paired=False, skip=False):
+    r1 = np.frombuffer(t1.encode("latin-1"), dtype=np.uint8)
+    r2 = np.frombuffer(t2.encode("latin-1"), dtype=np.uint8)
+    return parser.parse(r1, 0, len(r1), True, r2, 0, len(r2), True, score_mode, paired, skip, False, 1 << 20)
+
+
+@pytest.mark.parametrize("nl,tail", [("\n", True), ("\n", False), ("\r\n", True), ("\r\n", False), ("\r", True)])
+def test_newline_conventions(parser, nl, tail):
+    lines = [rec("a", "AS:i:5"), rec("b", "AS:i:7", "XS:i:3"), rec("c")]
+    t = sam(lines, nl, tail)
+    block = parse_text(parser, t, t)
+    want = list(ORACLE.read_pairs(io.StringIO(t, newline=None), io.StringIO(t, newline=None)))
+    assert block.n == len(want) == 3
+    assert block.cols[0].tolist() == [5, 7, ABSENT] and block.cols[1].tolist() == [ABSENT, 3, ABSENT]
+
+
+def test_blank_line_and_shorter_file_end_the_walk(parser):
+    a = sam([rec("a"), rec("b"), "", rec("c")])
+    b = sam([rec("a"), rec("b"), rec("c"), rec("d")])
+    assert parse_text(parser, a, b).n == 2
+    assert parse_text(parser, b, a).n == 2
+    assert parse_text(parser, sam([rec("a"), "   \t "]), b).n == 1          # whitespace-only line splits to []
+    assert parse_text(parser, sam([rec("a")]), b).n == 1                      # EOF of the shorter file
+    assert parse_text(parser, "", b).n == 0
+
+
+def test_name_mismatch_reported(parser):
+    a = sam([rec("a"), rec("b"), rec("c")])
+    b = sam([rec("a"), rec("x"), rec("c")])
+    block = parse_text(parser, a, b)
+    assert block.mismatch_at == 1 and block.n == 1
+
+
+def test_skip_repeated_matches_oracle(parser):
+    a = sam([rec("a"), rec("a"), rec("a"), rec("b"), rec("c"), rec("c")])
+    b = sam([rec("a"), rec("b"), rec("b"), rec("c")])
+    block = parse_text(parser, a, b, skip=True)
+    want = list(ORACLE.read_pairs(io.StringIO(a), io.StringIO(b), True))
+    assert block.n == len(want) == 3
+
+
+def test_mixed_whitespace_and_normalisation(parser):
+    messy = rec("a", "AS:i:5", sep=" ") + "  "
+    t = sam([messy, rec("b", "AS:i:9")])
+    block = parse_text(parser, t, t)
+    assert block.cols[0].tolist() == [5, 9]
+    out = bytes(parser.emit(False, 0, np.array([0, 1], dtype=np.uint32))).decode()
+    assert out == "\t".join(messy.split()) + "\n" + rec("b", "AS:i:9") + "\n"
+
+
+def test_exceptions_are_reported_not_guessed(parser):
+    from xenomapper_amd import _host
+    lines = [rec("a", "AS:f:12.5"), rec("b", "AS:i:7", "RG:Z:BASS"), rec("c", "AS:i:3000000000"),
+             rec("d", "AS:i:1_0"), rec("e", "AS:i:", "XS:A:+"), rec("f", "AS:i:-2147483647"), rec("g", "xAS:i:44")]
+    t = sam(lines)
+    block = parse_text(parser, t, t)
+    kinds = {(k, c): kind for k, c, kind in block.exc}
+    assert kinds[(0, 0)] == _host.EX_NONINT and kinds[(1, 0)] == _host.EX_DUP and kinds[(2, 0)] == _host.EX_NONINT
+    assert kinds[(3, 0)] == _host.EX_NONINT and kinds[(4, 0)] == _host.EX_NONINT and kinds[(4, 1)] == _host.EX_NONINT
+    assert (5, 0) not in kinds and block.cols[0][5] == -2147483647
+    assert (6, 0) not in kinds and block.cols[0][6] == 44           # substring match, like the reference
+    # CIGAR mode
+    lines = [rec("a", "NM:i:1"), "b 0 chr1 1 30 NM:i:2 x x x x x NM:i:2", rec("c", "NM:i:x"), rec("d", "NM:i:2", "NM:i:3")]
+    t = sam(lines)
+    block = parse_text(parser, t, t, score_mode=2)
+    kinds = {(k, c): kind for k, c, kind in block.exc}
+    assert kinds.get((2, 0)) == _host.EX_NONINT and (3, 0) not in kinds and block.csr[0][0][3] == 2
+    assert (0, 0) not in kinds and block.csr[0][0][0] == 1
+
+
+def test_non_ascii_is_refused(parser):
+    from xenomapper_amd import _host
+    t = sam([rec("a", "AS:i:5"), rec("b c", "AS:i:5")])
+    with pytest.raises(_host.NonAsciiInput):
+        parse_text(parser, t, t)
+
+
+def test_windowed_walk_equals_whole_file(parser):
+    """Drive the parser the way _run_files does, with tiny windows (halo kept for paired input)."""
+    case = {c["name"]: c for c in G3}["cfg2_pe_liberal"]
+    t1, t2 = H.case_texts(case)
+    r1, p1 = body_of(t1)
+    r2, p2 = body_of(t2)
+    whole = parser.parse(r1, p1, len(r1) - p1, True, r2, p2, len(r2) - p2, True, 0, True, False, False, 1 << 22)
+    whole_as1 = whole.cols[0].copy()
+    whole_flags = np.unpackbits(whole.unit_bits.view(np.uint8), bitorder="little")[:whole.n].copy()
+    pos = [p1, p2]
+    got_as1, got_flags = [], []
+    window = 4096
+    for _ in range(100000):
+        lens = [min(window, len(r1) - pos[0]), min(window, len(r2) - pos[1])]
+        eofs = [pos[0] + lens[0] >= len(r1), pos[1] + lens[1] >= len(r2)]
+        b = parser.parse(r1, pos[0], lens[0], eofs[0], r2, pos[1], lens[1], eofs[1], 0, True, False, True, 1 << 22)
+        flags = np.unpackbits(b.unit_bits.view(np.uint8), bitorder="little")[:b.n]
+        first = 1 if got_as1 else 0                       # record 0 of later windows is the halo
+        got_as1 += b.cols[0][first:].tolist()
+        got_flags += flags[first:].tolist()
+        if first:
+            assert flags[0] == 0
+        if b.ended:
+            break
+        assert b.consumed[0] > 0 and b.consumed[1] > 0
+        pos = [pos[0] + b.consumed[0], pos[1] + b.consumed[1]]
+    assert got_as1 == whole_as1.tolist()
+    assert got_flags == whole_flags.tolist()
+
+
+def test_library_exports_header_symbols():
+    import ctypes, os, re
+    from xenomapper_amd import _host, build
+    build.build_host()
+    text = open(os.path.join(H.REPO, "include", "xenomapper_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(xmh_[a-z0-9_]+)\s*\(", text)))
+    L = ctypes.CDLL(_host.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(_host.EXPORTED) == names

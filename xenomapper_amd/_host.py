@@ -1,0 +1,142 @@
+"""ctypes binding of include/xenomapper_host.h (libxenomapper_host.so): the multi-threaded C++ SAM column
+stripper and line writer used by the file-to-file fast path of xenomapper_amd.xenomapper.main()."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libxenomapper_host.so")
+
+SCORE_AS_XS, SCORE_AS_ZS, SCORE_CIGAR = 0, 1, 2
+EX_NONINT, EX_DUP, EX_SHORT, EX_BIGLEN = 1, 2, 3, 4
+ERR_NON_ASCII = -3
+
+EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit")
+
+_P = ctypes.c_void_p
+
+
+class _Block(ctypes.Structure):
+    _fields_ = [("n_records", ctypes.c_uint64), ("consumed1", ctypes.c_uint64), ("consumed2", ctypes.c_uint64),
+                ("ended", ctypes.c_int32), ("starved", ctypes.c_int32), ("mismatch_at", ctypes.c_int64),
+                ("as1", _P), ("xs1", _P), ("as2", _P), ("xs2", _P), ("nm1", _P), ("nm2", _P),
+                ("cig_off1", _P), ("cig_off2", _P), ("cig_ops1", _P), ("cig_ops2", _P), ("unit_bits", _P),
+                ("line_off1", _P), ("line_off2", _P), ("line_len1", _P), ("line_len2", _P),
+                ("norm_len1", _P), ("norm_len2", _P), ("line_flags1", _P), ("line_flags2", _P),
+                ("n_exc", ctypes.c_uint64), ("exc_record", _P), ("exc_col", _P), ("exc_kind", _P)]
+
+
+class NonAsciiInput(Exception):
+    """The window holds bytes >= 0x80; Python's own str.split() must read this input."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `python -m xenomapper_amd.build`" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.xmh_abi_version.restype = ctypes.c_int
+        L.xmh_strerror.argtypes = [ctypes.c_int]
+        L.xmh_strerror.restype = ctypes.c_char_p
+        L.xmh_parser_create.argtypes = [ctypes.c_int, ctypes.POINTER(_P)]
+        L.xmh_parser_destroy.argtypes = [_P]
+        L.xmh_parse.argtypes = [_P, _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                ctypes.POINTER(_Block)]
+        L.xmh_emit.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_uint64,
+                               ctypes.POINTER(ctypes.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def _view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class Block(object):
+    """NumPy views of one parsed window (valid until the parser parses again)."""
+
+    def __init__(self, raw, cigar):
+        n = self.n = int(raw.n_records)
+        self.consumed = (int(raw.consumed1), int(raw.consumed2))
+        self.ended, self.starved, self.mismatch_at = bool(raw.ended), bool(raw.starved), int(raw.mismatch_at)
+        self.cols = [_view(p, n, np.int32) for p in (raw.as1, raw.xs1, raw.as2, raw.xs2)]
+        self.unit_bits = _view(raw.unit_bits, (n + 63) // 64, np.uint64)
+        if cigar:
+            off = [_view(p, n + 1, np.uint32) for p in (raw.cig_off1, raw.cig_off2)]
+            self.csr = [(_view(raw.nm1, n, np.int32), off[0], _view(raw.cig_ops1, int(off[0][-1]) if n else 0, np.uint32)),
+                        (_view(raw.nm2, n, np.int32), off[1], _view(raw.cig_ops2, int(off[1][-1]) if n else 0, np.uint32))]
+        else:
+            self.csr = None
+        self.line_off = [_view(raw.line_off1, n, np.uint64), _view(raw.line_off2, n, np.uint64)]
+        self.line_len = [_view(raw.line_len1, n, np.uint32), _view(raw.line_len2, n, np.uint32)]
+        k = int(raw.n_exc)
+        self.exc = list(zip(_view(raw.exc_record, k, np.uint32).tolist(), _view(raw.exc_col, k, np.uint8).tolist(),
+                            _view(raw.exc_kind, k, np.uint8).tolist()))
+
+
+class Parser(object):
+    def __init__(self, n_threads=0):
+        self._L = lib()
+        h = _P()
+        rc = self._L.xmh_parser_create(int(n_threads), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("xmh_parser_create: " + self._L.xmh_strerror(rc).decode())
+        self._h = h
+        self._win = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.xmh_parser_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def parse(self, arr1, pos1, len1, eof1, arr2, pos2, len2, eof2, score_mode, paired, skip_repeated, keep_halo,
+              max_records):
+        """arr*: uint8 NumPy arrays over the whole files (memmap); the windows are [pos, pos+len)."""
+        raw = _Block()
+        p1 = arr1.ctypes.data + pos1 if len1 else None
+        p2 = arr2.ctypes.data + pos2 if len2 else None
+        rc = self._L.xmh_parse(self._h, p1, len1, int(eof1), p2, len2, int(eof2), score_mode, int(paired),
+                               int(skip_repeated), int(keep_halo), int(max_records), ctypes.byref(raw))
+        if rc == ERR_NON_ASCII:
+            raise NonAsciiInput()
+        if rc != 0:
+            raise RuntimeError("xmh_parse: " + self._L.xmh_strerror(rc).decode())
+        self._win = (p1, p2)
+        self._keep = (arr1, arr2)            # the windows must outlive emit()
+        return Block(raw, score_mode == SCORE_CIGAR)
+
+    def emit(self, paired, bin_index, idx):
+        """Text (bytes) of one output bin for the last parsed block; idx: ascending uint32 unit indices."""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        n = idx.shape[0]
+        if n == 0:
+            return b""
+        need = ctypes.c_uint64()
+        ip = idx.ctypes.data_as(_P)
+        rc = self._L.xmh_emit(self._h, self._win[0], self._win[1], int(paired), bin_index, ip, n, None, 0,
+                              ctypes.byref(need))
+        if rc != 0:
+            raise RuntimeError("xmh_emit: " + self._L.xmh_strerror(rc).decode())
+        out = np.empty(need.value, dtype=np.uint8)
+        rc = self._L.xmh_emit(self._h, self._win[0], self._win[1], int(paired), bin_index, ip, n,
+                              out.ctypes.data_as(_P), need.value, ctypes.byref(need))
+        if rc != 0:
+            raise RuntimeError("xmh_emit: " + self._L.xmh_strerror(rc).decode())
+        return out

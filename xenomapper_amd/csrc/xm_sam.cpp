@@ -1,0 +1,498 @@
+// xm_sam.cpp -- host-side SAM column stripper and line writer (C ABI in include/xenomapper_host.h).
+//
+// Restates, on raw bytes and in parallel, the text half of the reference's hot loop:
+//   getReadPairs                 /root/reference/xenomapper/xenomapper.py:95-118
+//   get_tag (field search)       :186-190        get_tag_with_ZS_as_XS :204-206
+//   get_cigarbased_AS_tag (NM field + CIGAR operations)   :247-251
+//   '\t'.join(fields) + print    :332-350, :423-448, :521-550
+// It never evaluates a score, a state or a bin: those are the GPU's (csrc/xm_kernels.hip).
+// Anything it cannot reproduce bit-for-bit is reported as an exception for the Python host to resolve.
+#include "../../include/xenomapper_host.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+const int32_t ABSENT = INT32_MIN;
+
+// Python's str.split() separators in the ASCII range (str.isspace): \t \n \v \f \r FS GS RS US and space
+inline bool is_ws(unsigned char c)
+{
+    return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31);
+}
+
+struct Line {
+    uint64_t off;
+    uint32_t len;
+};
+
+struct Rec {                  // what the parser learnt about one line
+    uint32_t name_off, name_len;      // first token, relative to the line
+    uint32_t norm_len;                // length of '\t'.join(fields)
+    uint32_t n_tok;
+    int32_t a, x, nm;                 // AS (or unused), XS/ZS, NM
+    uint8_t ex_a, ex_x;               // exception kind of the AS / XS column
+    uint8_t normal;                   // already '\t'.join(fields)
+    uint32_t ops_begin, ops_count;    // CIGAR ops in the worker's local vector
+    uint32_t worker;
+};
+
+struct FileParse {
+    std::vector<Line> lines;
+    std::vector<Rec> recs;
+    std::vector<std::vector<uint32_t>> ops;   // per worker
+    uint64_t complete_end = 0;                // offset just past the last complete line
+    bool non_ascii = false;
+};
+
+template <typename F>
+void parallel_for(int n_threads, uint64_t n, F fn)
+{
+    if (n_threads <= 1 || n < 4096) {
+        fn(0, 0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const uint64_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        const uint64_t b = std::min<uint64_t>(n, (uint64_t)t * per), e = std::min<uint64_t>(n, b + per);
+        if (b >= e) break;
+        pool.emplace_back([=]() { fn(t, b, e); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+// ---- line index: universal newlines ('\n', '\r\n', '\r'), as Python text mode reads them --------------
+void index_lines(const char *buf, uint64_t len, bool eof, int n_threads, FileParse &fp)
+{
+    // a trailing '\r' might be the first half of "\r\n" continuing in the next window
+    uint64_t usable = len;
+    if (!eof && len > 0 && buf[len - 1] == '\r') usable = len - 1;
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> found(std::max(1, n_threads));   // (end, next start)
+    std::vector<char> bad(std::max(1, n_threads), 0);
+    parallel_for(n_threads, usable, [&](int t, uint64_t b, uint64_t e) {
+        auto &v = found[t];
+        bool hi = false;
+        for (uint64_t p = b; p < e; ++p) {
+            const unsigned char c = (unsigned char)buf[p];
+            hi |= (c & 0x80) != 0;
+            if (c == '\n') {
+                if (p > 0 && buf[p - 1] == '\r') continue;          // second half of "\r\n"
+                v.emplace_back(p, p + 1);
+            } else if (c == '\r') {
+                const bool crlf = (p + 1 < len) && buf[p + 1] == '\n';
+                v.emplace_back(p, p + (crlf ? 2 : 1));
+            }
+        }
+        bad[t] = hi;
+    });
+    fp.non_ascii = false;
+    for (char b : bad) fp.non_ascii |= (b != 0);
+    fp.lines.clear();
+    uint64_t start = 0;
+    for (auto &v : found)
+        for (auto &pr : v) {
+            fp.lines.push_back(Line{start, (uint32_t)(pr.first - start)});
+            start = pr.second;
+        }
+    fp.complete_end = start;
+    if (eof && start < len) {                                        // last line without a terminator
+        fp.lines.push_back(Line{start, (uint32_t)(len - start)});
+        fp.complete_end = len;
+        for (uint64_t p = start; p < len; ++p) fp.non_ascii |= ((unsigned char)buf[p] & 0x80) != 0;
+    }
+}
+
+// ---- one line ---------------------------------------------------------------------------------------------
+inline bool contains2(const char *s, uint32_t n, char c0, char c1)
+{
+    for (uint32_t i = 0; i + 1 < n; ++i)
+        if (s[i] == c0 && s[i + 1] == c1) return true;
+    return false;
+}
+
+// text after the last ':' as a plain integer in [-(2^31-1), 2^31-1]; false -> let Python's float()/int() decide
+inline bool plain_int(const char *s, uint32_t n, int32_t &out)
+{
+    uint32_t b = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (s[i] == ':') b = i + 1;
+    const char *p = s + b;
+    uint32_t m = n - b, i = 0;
+    bool neg = false;
+    if (m && (p[0] == '-' || p[0] == '+')) { neg = p[0] == '-'; i = 1; }
+    if (i >= m || m - i > 10) return false;
+    uint64_t v = 0;
+    for (; i < m; ++i) {
+        if (p[i] < '0' || p[i] > '9') return false;
+        v = v * 10 + (uint64_t)(p[i] - '0');
+    }
+    if (v > 2147483647ull) return false;
+    out = neg ? -(int32_t)v : (int32_t)v;
+    return true;
+}
+
+inline int cigar_op(char c)
+{
+    switch (c) {
+    case 'M': return 0; case 'I': return 1; case 'D': return 2; case 'N': return 3; case 'S': return 4;
+    case 'H': return 5; case 'P': return 6; case '=': return 7; case 'X': return 8; default: return -1;
+    }
+}
+
+void parse_line(const char *s, uint32_t n, int score_mode, uint32_t worker, std::vector<uint32_t> &ops, Rec &r)
+{
+    r.name_off = r.name_len = 0;
+    r.norm_len = 0;
+    r.n_tok = 0;
+    r.a = r.x = r.nm = ABSENT;
+    r.ex_a = r.ex_x = 0;
+    r.ops_begin = (uint32_t)ops.size();
+    r.ops_count = 0;
+    r.worker = worker;
+    const char xtag0 = (score_mode == XMH_SCORE_AS_ZS) ? 'Z' : 'X';
+    uint32_t n_a = 0, n_x = 0;
+    bool have_nm = false;
+    const char *cig = nullptr;
+    uint32_t cig_len = 0;
+    bool normal = true;
+    uint32_t i = 0, total = 0;
+    while (i < n) {
+        if (is_ws((unsigned char)s[i])) {
+            // separators must be exactly one '\t' between tokens, none leading / trailing
+            if (s[i] != '\t' || r.n_tok == 0 || i + 1 >= n || is_ws((unsigned char)s[i + 1])) normal = false;
+            ++i;
+            continue;
+        }
+        uint32_t b = i;
+        while (i < n && !is_ws((unsigned char)s[i])) ++i;
+        const char *tok = s + b;
+        const uint32_t tl = i - b;
+        const uint32_t k = r.n_tok++;
+        total += tl;
+        if (k == 0) { r.name_off = b; r.name_len = tl; }
+        else if (k == 5) { cig = tok; cig_len = tl; }
+        else if (k >= 11) {
+            if (score_mode != XMH_SCORE_CIGAR && contains2(tok, tl, 'A', 'S')) {
+                if (++n_a == 1 && !plain_int(tok, tl, r.a)) r.ex_a = XMH_EX_NONINT;
+            }
+            if (contains2(tok, tl, xtag0, 'S')) {
+                if (++n_x == 1 && !plain_int(tok, tl, r.x)) r.ex_x = XMH_EX_NONINT;
+            }
+            if (score_mode == XMH_SCORE_CIGAR && !have_nm && contains2(tok, tl, 'N', 'M')) {
+                have_nm = true;                                      // NM[0]: the first match, no duplicate check (:247-250)
+                if (!plain_int(tok, tl, r.nm)) r.ex_a = XMH_EX_NONINT;
+            }
+        }
+    }
+    if (n_a > 1) r.ex_a = XMH_EX_DUP;
+    if (n_x > 1) r.ex_x = XMH_EX_DUP;
+    r.norm_len = r.n_tok ? total + (r.n_tok - 1) : 0;
+    r.normal = (normal && r.n_tok > 0) ? 1 : 0;
+    if (score_mode == XMH_SCORE_CIGAR && have_nm) {
+        if (r.n_tok < 6) {
+            r.ex_a = XMH_EX_SHORT;
+        } else {
+            // re.findall(r'([0-9]+)([MIDNSHPX=])', cigar): a run of ASCII digits directly followed by an op letter
+            uint64_t run = 0;
+            uint32_t digits = 0;
+            bool big = false;
+            for (uint32_t p = 0; p < cig_len; ++p) {
+                const char c = cig[p];
+                if (c >= '0' && c <= '9') {
+                    ++digits;
+                    if (run < (1ull << 40)) run = run * 10 + (uint64_t)(c - '0');
+                    continue;
+                }
+                const int op = cigar_op(c);
+                if (op >= 0 && digits > 0) {
+                    if (run >= (1ull << 28)) big = true;
+                    else ops.push_back(((uint32_t)run << 4) | (uint32_t)op);
+                }
+                run = 0;
+                digits = 0;
+            }
+            if (big && r.ex_a == 0) r.ex_a = XMH_EX_BIGLEN;
+            r.ops_count = (uint32_t)ops.size() - r.ops_begin;
+        }
+    }
+}
+
+void parse_file(const char *buf, int score_mode, int n_threads, FileParse &fp)
+{
+    const uint64_t n = fp.lines.size();
+    fp.recs.resize(n);
+    fp.ops.assign(std::max(1, n_threads), std::vector<uint32_t>());
+    parallel_for(n_threads, n, [&](int t, uint64_t b, uint64_t e) {
+        auto &ops = fp.ops[t];
+        for (uint64_t i = b; i < e; ++i)
+            parse_line(buf + fp.lines[i].off, fp.lines[i].len, score_mode, (uint32_t)t, ops, fp.recs[i]);
+    });
+}
+
+inline bool same_name(const char *b1, const FileParse &f1, uint64_t i, const char *b2, const FileParse &f2, uint64_t j)
+{
+    const Rec &a = f1.recs[i], &b = f2.recs[j];
+    return a.name_len == b.name_len &&
+           memcmp(b1 + f1.lines[i].off + a.name_off, b2 + f2.lines[j].off + b.name_off, a.name_len) == 0;
+}
+
+}  // namespace
+
+struct xmh_parser {
+    int n_threads;
+    FileParse f[2];
+    std::vector<uint64_t> sel[2];                 // line index of every yielded record, per file
+    // output storage
+    std::vector<int32_t> as1, xs1, as2, xs2, nm1, nm2;
+    std::vector<uint32_t> off1, off2, ops1, ops2, llen1, llen2, nlen1, nlen2, exc_record;
+    std::vector<uint64_t> loff1, loff2, bits;
+    std::vector<uint8_t> lflag1, lflag2, exc_col, exc_kind;
+};
+
+extern "C" {
+
+int xmh_abi_version(void) { return XMH_ABI_VERSION; }
+
+const char *xmh_strerror(int status)
+{
+    switch (status) {
+    case XMH_OK: return "ok";
+    case XMH_ERR_INVALID_ARG: return "invalid argument";
+    case XMH_ERR_OOM: return "out of memory";
+    case XMH_ERR_NON_ASCII: return "non-ASCII byte in SAM input";
+    default: return "unknown status";
+    }
+}
+
+int xmh_parser_create(int n_threads, xmh_parser **out)
+{
+    if (!out) return XMH_ERR_INVALID_ARG;
+    xmh_parser *p = new (std::nothrow) xmh_parser();
+    if (!p) return XMH_ERR_OOM;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    p->n_threads = std::max(1, std::min(n_threads, 64));
+    *out = p;
+    return XMH_OK;
+}
+
+int xmh_parser_destroy(xmh_parser *p)
+{
+    if (!p) return XMH_ERR_INVALID_ARG;
+    delete p;
+    return XMH_OK;
+}
+
+int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const char *buf2, uint64_t len2, int eof2,
+              int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out)
+{
+    if (!p || !out || (!buf1 && len1) || (!buf2 && len2) || score_mode < 0 || score_mode > 2)
+        return XMH_ERR_INVALID_ARG;
+    try {
+        const char *buf[2] = {buf1, buf2};
+        const uint64_t len[2] = {len1, len2};
+        const int eof[2] = {eof1, eof2};
+        for (int f = 0; f < 2; ++f) {
+            index_lines(buf[f], len[f], eof[f] != 0, p->n_threads, p->f[f]);
+            if (p->f[f].non_ascii) return XMH_ERR_NON_ASCII;
+        }
+        for (int f = 0; f < 2; ++f) parse_file(buf[f], score_mode, p->n_threads, p->f[f]);
+
+        // ---- the lock-step walk (xenomapper.py:103-117) ------------------------------------------------
+        const uint64_t L[2] = {p->f[0].lines.size(), p->f[1].lines.size()};
+        // all lines of the file are in the window (then running out of lines is EOF, i.e. a blank readline)
+        const bool whole[2] = {eof1 && p->f[0].complete_end == len1, eof2 && p->f[1].complete_end == len2};
+        auto blank = [&](int f, uint64_t i) { return p->f[f].recs[i].n_tok == 0; };
+        p->sel[0].clear();
+        p->sel[1].clear();
+        uint64_t i1 = 0, i2 = 0;
+        int ended = 0, starved = 0;
+        int64_t mismatch = -1;
+        while (p->sel[0].size() < max_records) {
+            if (i1 >= L[0] || i2 >= L[1]) {
+                const bool end1 = i1 >= L[0] && whole[0], end2 = i2 >= L[1] && whole[1];
+                if (end1 || end2) ended = 1; else starved = 1;
+                break;
+            }
+            if (blank(0, i1) || blank(1, i2)) { ended = 1; break; }
+            if (!same_name(buf1, p->f[0], i1, buf2, p->f[1], i2)) { mismatch = (int64_t)p->sel[0].size(); break; }
+            uint64_t j1 = i1 + 1, j2 = i2 + 1;
+            if (skip_repeated) {
+                // each file moves past further lines with the name just yielded; a blank line stops the skipping
+                while (j1 < L[0] && !blank(0, j1) && same_name(buf1, p->f[0], j1, buf1, p->f[0], i1)) ++j1;
+                while (j2 < L[1] && !blank(1, j2) && same_name(buf2, p->f[1], j2, buf2, p->f[1], i2)) ++j2;
+                // the run must be seen to end inside the window, or the pair waits for the next window
+                if ((j1 >= L[0] && !whole[0]) || (j2 >= L[1] && !whole[1])) { starved = 1; break; }
+            }
+            p->sel[0].push_back(i1);
+            p->sel[1].push_back(i2);
+            i1 = j1;
+            i2 = j2;
+        }
+        const uint64_t n = p->sel[0].size();
+
+        // ---- consumed bytes: where the next window starts ----------------------------------------------
+        auto start_of = [&](int f, uint64_t line) -> uint64_t {
+            return line < p->f[f].lines.size() ? p->f[f].lines[line].off : p->f[f].complete_end;
+        };
+        if (keep_halo && n > 0 && !ended && mismatch < 0) {
+            out->consumed1 = start_of(0, p->sel[0][n - 1]);
+            out->consumed2 = start_of(1, p->sel[1][n - 1]);
+        } else {
+            out->consumed1 = start_of(0, i1);
+            out->consumed2 = start_of(1, i2);
+        }
+
+        // ---- gather columns for the yielded records -------------------------------------------------
+        const bool cigar = score_mode == XMH_SCORE_CIGAR;
+        std::vector<int32_t> *cols[2][3] = {{&p->as1, &p->xs1, &p->nm1}, {&p->as2, &p->xs2, &p->nm2}};
+        std::vector<uint32_t> *offs[2] = {&p->off1, &p->off2}, *opsv[2] = {&p->ops1, &p->ops2};
+        std::vector<uint64_t> *loff[2] = {&p->loff1, &p->loff2};
+        std::vector<uint32_t> *llen[2] = {&p->llen1, &p->llen2}, *nlen[2] = {&p->nlen1, &p->nlen2};
+        std::vector<uint8_t> *lflag[2] = {&p->lflag1, &p->lflag2};
+        for (int f = 0; f < 2; ++f) {
+            cols[f][0]->resize(n + 4); cols[f][1]->resize(n + 4); cols[f][2]->resize(cigar ? n + 4 : 4);
+            loff[f]->resize(n + 1); llen[f]->resize(n + 1); nlen[f]->resize(n + 1); lflag[f]->resize(n + 1);
+            offs[f]->assign(cigar ? n + 1 : 1, 0);
+            const FileParse &fp = p->f[f];
+            const auto &sel = p->sel[f];
+            parallel_for(p->n_threads, n, [&](int, uint64_t b, uint64_t e) {
+                for (uint64_t k = b; k < e; ++k) {
+                    const Rec &r = fp.recs[sel[k]];
+                    (*cols[f][0])[k] = r.a;
+                    (*cols[f][1])[k] = r.x;
+                    if (cigar) (*cols[f][2])[k] = r.nm;
+                    (*loff[f])[k] = fp.lines[sel[k]].off;
+                    (*llen[f])[k] = fp.lines[sel[k]].len;
+                    (*nlen[f])[k] = r.norm_len;
+                    (*lflag[f])[k] = r.normal ? XMH_LINE_NORMAL : 0;
+                }
+            });
+            if (cigar) {
+                uint32_t acc = 0;
+                for (uint64_t k = 0; k < n; ++k) { (*offs[f])[k] = acc; acc += fp.recs[sel[k]].ops_count; }
+                (*offs[f])[n] = acc;
+                opsv[f]->resize((size_t)acc + 4);
+                parallel_for(p->n_threads, n, [&](int, uint64_t b, uint64_t e) {
+                    for (uint64_t k = b; k < e; ++k) {
+                        const Rec &r = fp.recs[sel[k]];
+                        if (r.ops_count)
+                            memcpy(opsv[f]->data() + (*offs[f])[k], fp.ops[r.worker].data() + r.ops_begin,
+                                   (size_t)r.ops_count * 4);
+                    }
+                });
+            } else {
+                opsv[f]->assign(4, 0);
+            }
+        }
+        // ---- unit mask (xenomapper.py:402: name equals the previous record's name) -------------------
+        p->bits.assign((n + 63) / 64 + 1, 0);
+        if (paired) {
+            for (uint64_t k = 1; k < n; ++k)
+                if (same_name(buf1, p->f[0], p->sel[0][k], buf1, p->f[0], p->sel[0][k - 1]))
+                    p->bits[k >> 6] |= 1ull << (k & 63);
+        } else {
+            for (uint64_t k = 0; k < n; ++k) p->bits[k >> 6] |= 1ull << (k & 63);
+        }
+        // ---- exceptions ---------------------------------------------------------------------------------
+        p->exc_record.clear(); p->exc_col.clear(); p->exc_kind.clear();
+        for (uint64_t k = 0; k < n; ++k) {
+            for (int f = 0; f < 2; ++f) {
+                const Rec &r = p->f[f].recs[p->sel[f][k]];
+                if (r.ex_a) { p->exc_record.push_back((uint32_t)k); p->exc_col.push_back((uint8_t)(2 * f)); p->exc_kind.push_back(r.ex_a); }
+                if (r.ex_x) { p->exc_record.push_back((uint32_t)k); p->exc_col.push_back((uint8_t)(2 * f + 1)); p->exc_kind.push_back(r.ex_x); }
+            }
+        }
+        out->n_records = n;
+        out->ended = ended;
+        out->starved = starved;
+        out->mismatch_at = mismatch;
+        out->as1 = p->as1.data(); out->xs1 = p->xs1.data(); out->as2 = p->as2.data(); out->xs2 = p->xs2.data();
+        out->nm1 = p->nm1.data(); out->nm2 = p->nm2.data();
+        out->cig_off1 = p->off1.data(); out->cig_off2 = p->off2.data();
+        out->cig_ops1 = p->ops1.data(); out->cig_ops2 = p->ops2.data();
+        out->unit_bits = p->bits.data();
+        out->line_off1 = p->loff1.data(); out->line_off2 = p->loff2.data();
+        out->line_len1 = p->llen1.data(); out->line_len2 = p->llen2.data();
+        out->norm_len1 = p->nlen1.data(); out->norm_len2 = p->nlen2.data();
+        out->line_flags1 = p->lflag1.data(); out->line_flags2 = p->lflag2.data();
+        out->n_exc = p->exc_record.size();
+        out->exc_record = p->exc_record.data(); out->exc_col = p->exc_col.data(); out->exc_kind = p->exc_kind.data();
+        return XMH_OK;
+    } catch (const std::bad_alloc &) {
+        return XMH_ERR_OOM;
+    }
+}
+
+static inline char *put_line(char *dst, const char *src, uint32_t len, uint8_t flags)
+{
+    if (flags & XMH_LINE_NORMAL) {
+        memcpy(dst, src, len);
+        dst += len;
+    } else {                                                          // '\t'.join(line.split())
+        bool first = true;
+        uint32_t i = 0;
+        while (i < len) {
+            if (is_ws((unsigned char)src[i])) { ++i; continue; }
+            uint32_t b = i;
+            while (i < len && !is_ws((unsigned char)src[i])) ++i;
+            if (!first) *dst++ = '\t';
+            memcpy(dst, src + b, i - b);
+            dst += i - b;
+            first = false;
+        }
+    }
+    *dst++ = '\n';
+    return dst;
+}
+
+int xmh_emit(xmh_parser *p, const char *buf1, const char *buf2, int paired, int bin,
+             const uint32_t *idx, uint64_t n_idx, char *out, uint64_t out_cap, uint64_t *out_len)
+{
+    if (!p || !out_len || bin < 0 || bin > 5 || (n_idx && !idx)) return XMH_ERR_INVALID_ARG;
+    const uint64_t n = p->sel[0].size();
+    const bool use1 = (bin == 0 || bin == 2 || bin == 5 || bin == 4), use2 = (bin == 1 || bin == 3 || bin == 4);
+    const uint32_t *nl1 = p->nlen1.data(), *nl2 = p->nlen2.data();
+    auto unit_bytes = [&](uint32_t i) -> uint64_t {
+        uint64_t b = 0;
+        if (use1) b += (uint64_t)nl1[i] + 1 + (paired ? (uint64_t)nl1[i - 1] + 1 : 0);
+        if (use2) b += (uint64_t)nl2[i] + 1 + (paired ? (uint64_t)nl2[i - 1] + 1 : 0);
+        return b;
+    };
+    for (uint64_t u = 0; u < n_idx; ++u)
+        if (idx[u] >= n || (paired && idx[u] == 0)) return XMH_ERR_INVALID_ARG;
+    try {
+        std::vector<uint64_t> start(n_idx + 1);
+        uint64_t acc = 0;
+        for (uint64_t u = 0; u < n_idx; ++u) { start[u] = acc; acc += unit_bytes(idx[u]); }
+        start[n_idx] = acc;
+        *out_len = acc;
+        if (!out) return XMH_OK;
+        if (out_cap < acc) return XMH_ERR_INVALID_ARG;
+        const char *b[2] = {buf1, buf2};
+        const uint64_t *lo[2] = {p->loff1.data(), p->loff2.data()};
+        const uint32_t *ll[2] = {p->llen1.data(), p->llen2.data()};
+        const uint8_t *lf[2] = {p->lflag1.data(), p->lflag2.data()};
+        parallel_for(p->n_threads, n_idx, [&](int, uint64_t ub, uint64_t ue) {
+            for (uint64_t u = ub; u < ue; ++u) {
+                char *d = out + start[u];
+                const uint32_t i = idx[u];
+                for (int f = 0; f < 2; ++f) {                          // file-1 lines, then file-2 lines (:439-444)
+                    if (!(f == 0 ? use1 : use2)) continue;
+                    if (paired) d = put_line(d, b[f] + lo[f][i - 1], ll[f][i - 1], lf[f][i - 1]);
+                    d = put_line(d, b[f] + lo[f][i], ll[f][i], lf[f][i]);
+                }
+            }
+        });
+        return XMH_OK;
+    } catch (const std::bad_alloc &) {
+        return XMH_ERR_OOM;
+    }
+}
+
+}  // extern "C"

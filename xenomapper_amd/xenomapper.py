@@ -504,6 +504,251 @@ def _run(mode, readpairs, sinks, min_score, tag_func):
     return ordered
 
 
+# --------------------------------------------------------------------------------------------
+# file-to-file fast path: C++ column stripper -> GPU -> C++ line writer
+# --------------------------------------------------------------------------------------------
+FILE_WINDOW_BYTES = 48 << 20          # bytes of each SAM file parsed per block
+FILE_MAX_RECORDS = 1 << 22
+
+
+def _record_start(raw):
+    """Byte offset of the first record of a SAM file held in `raw` (uint8 array): the first line that does
+    not start with '@' (what get_sam_header leaves the stream at, ref :36-46)."""
+    pos, size = 0, raw.shape[0]
+    while pos < size and raw[pos] == 0x40:
+        window = raw[pos:pos + (1 << 16)]
+        while True:
+            hits = np.flatnonzero((window == 10) | (window == 13))
+            if hits.shape[0] or pos + window.shape[0] >= size:
+                break
+            window = raw[pos:pos + 4 * window.shape[0]]
+        if hits.shape[0] == 0:
+            return size
+        end = pos + int(hits[0])
+        pos = end + 1
+        if raw[end] == 13 and pos < size and raw[pos] == 10:
+            pos += 1
+    return pos
+
+
+def _write_bytes(sink, data):
+    """Append ASCII bytes to a text sink (through its binary buffer when it has one)."""
+    if data is None or len(data) == 0:
+        return
+    raw = getattr(sink, "buffer", None)
+    if raw is not None:
+        sink.flush()
+        raw.write(memoryview(data))
+    else:
+        sink.write(bytes(data).decode("ascii"))
+
+
+def _fields_of(raw, block, f, k, pos):
+    start = pos + int(block.line_off[f][k])
+    return bytes(raw[start:start + int(block.line_len[f][k])]).decode("ascii").split()
+
+
+def _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode):
+    """Values the C++ stripper would not vouch for (non-integers, duplicate tags, short lines ...) are
+    re-evaluated with the text-level plugin on the original line, in record order.  Returns
+    (patches {record: [AS1, XS1, AS2, XS2 as Python numbers]}, first_bad_record or None, error or None)."""
+    patches, seen = {}, set()
+    for k, _col, _kind in block.exc:
+        if k in seen or not needed[k]:
+            continue
+        seen.add(k)
+        try:
+            vals = []
+            for f in (0, 1):
+                fields = _fields_of(raws[f], block, f, k, pos[f])
+                if cigar_mode:
+                    nm, ops = _cigar_columns(fields)              # may raise like the reference would
+                    vals.append(("cigar", nm, ops))
+                    vals.append(get_tag(fields, "XS"))
+                else:
+                    vals.append(tag_func(fields, tag="AS"))
+                    vals.append(tag_func(fields, tag="XS"))
+            patches[k] = vals
+        except Exception as exc:
+            return patches, k, exc
+    return patches, None, None
+
+
+def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_threads=0):
+    """The three main loops on two SAM *files*: same results as _run(mode, getReadPairs(...)), with the text
+    work done by the C++ stripper / writer.  Falls back to the Python reader when the input is not ASCII."""
+    from . import _host
+    ctx = default_context()
+    paired = mode != _ffi.MODE_SE
+    cigar_mode = tag_func is get_cigarbased_AS_tag
+    score_mode = _host.SCORE_CIGAR if cigar_mode else (_host.SCORE_AS_ZS if tag_func is get_tag_with_ZS_as_XS
+                                                       else _host.SCORE_AS_XS)
+    raws = [np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
+            for path in (path1, path2)]
+    sizes = [r.shape[0] for r in raws]
+    pos = [_record_start(r) for r in raws]
+    parser = _host.Parser(n_threads)
+    totals, key_order = Counter(), []
+    window = FILE_WINDOW_BYTES
+    active = [s for s in sinks if s]
+    distinct = len(set(id(s) for s in active)) == len(active)
+    try:
+        while True:
+            lens = [min(window, sizes[f] - pos[f]) for f in (0, 1)]
+            eofs = [pos[f] + lens[f] >= sizes[f] for f in (0, 1)]
+            try:
+                block = parser.parse(raws[0], pos[0], lens[0], eofs[0], raws[1], pos[1], lens[1], eofs[1], score_mode,
+                                     paired, skip_repeated, paired, FILE_MAX_RECORDS)
+            except _host.NonAsciiInput:
+                return _finish_in_python(mode, path1, path2, pos, sinks, min_score, tag_func, skip_repeated,
+                                         totals, key_order)
+            n = block.n
+            progressed = block.consumed[0] > 0 or block.consumed[1] > 0
+            if block.starved and not progressed and not (eofs[0] and eofs[1]):
+                window *= 2                                      # a line (or run of equal names) longer than the window
+                continue
+            pending = AssertionError() if block.mismatch_at >= 0 else None
+            flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:n].astype(bool)
+            if paired:
+                needed = flags.copy()
+                needed[:-1] |= flags[1:]
+            else:
+                needed = np.ones(n, dtype=bool)
+            patches, bad, err = _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode) if block.exc \
+                else ({}, None, None)
+            if err is not None:
+                n, pending = bad, err                                # units closing at index >= bad are not reached
+            if n:
+                code, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
+                idx, off, _ = ctx.compact(mode, code)
+                limit, state_error = None, None
+                if int(off[7]) != int(off[6]):
+                    limit = int(idx[int(off[6]):int(off[7])].min())
+                    state_error = RuntimeError("Error in processing logic with values {0} ".format(
+                        tuple(int(block.cols[c][limit]) for c in range(4))))
+                for b in (range(6) if distinct else ()):
+                    if sinks[b]:
+                        seg = idx[int(off[b]):int(off[b + 1])]
+                        if limit is not None:
+                            seg = seg[seg < limit]
+                        _write_bytes(sinks[b], parser.emit(paired, b, seg))
+                if not distinct:
+                    _emit_shared(parser, paired, code, idx, off, sinks, limit)
+                if state_error is not None:
+                    raise state_error
+                unit_codes = code[code != _ffi.NO_UNIT]
+                uniq, first_at = np.unique(unit_codes, return_index=True)
+                for c in uniq[np.argsort(first_at)].tolist():
+                    key = STATE_NAMES[c] if not paired else (STATE_NAMES[c >> 3], STATE_NAMES[c & 7])
+                    if key not in totals:
+                        key_order.append(key)
+                    totals[key] += int(counts[c])
+            if pending is not None:
+                raise pending
+            if block.ended or (eofs[0] and eofs[1] and not progressed):
+                break
+            pos = [pos[0] + block.consumed[0], pos[1] + block.consumed[1]]
+    finally:
+        parser.close()
+    ordered = Counter()
+    for key in key_order:
+        ordered[key] = totals[key]
+    return ordered
+
+
+def _emit_shared(parser, paired, code, idx, off, sinks, limit):
+    """Two bins share a sink: write unit by unit so that the interleaving matches the reference."""
+    bins = np.full(code.shape[0], 7, dtype=np.uint8)
+    for b in range(6):
+        bins[idx[int(off[b]):int(off[b + 1])]] = b
+    for i in np.flatnonzero(bins < 6).tolist():
+        if limit is not None and i >= limit:
+            break
+        b = int(bins[i])
+        if sinks[b]:
+            _write_bytes(sinks[b], parser.emit(paired, b, np.array([i], dtype=np.uint32)))
+
+
+def _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score):
+    """Category bytes + counts of the first n records of a parsed block (patched values merged in)."""
+    bits = block.unit_bits
+    if n < block.n:                                                # truncated at an input error
+        flags = np.unpackbits(bits.view(np.uint8), bitorder="little")[:n]
+        bits = np.packbits(np.concatenate([flags, np.zeros((-n) % 64, dtype=np.uint8)]), bitorder="little").view(np.uint64)
+    cols = [np.array(c[:n]) for c in block.cols]
+    fvals = {}                                                     # (record, column) -> value that needs binary64
+    csr = None
+    if cigar_mode:
+        csr = [[np.array(block.csr[f][0][:n]), np.array(block.csr[f][1][:n + 1]), block.csr[f][2]] for f in (0, 1)]
+    for k, vals in patches.items():
+        if k >= n:
+            continue
+        for c, v in enumerate(vals):
+            if isinstance(v, tuple):                                # ("cigar", nm, ops) of a record the stripper flagged
+                _, nm, ops = v
+                f = c // 2
+                want = list(ops)
+                have = csr[f][2][int(csr[f][1][k]):int(csr[f][1][k + 1])].tolist()
+                if want != have:                                    # cannot happen: the op scan is deterministic
+                    raise RuntimeError("CIGAR operations of record %d differ between parsers" % k)
+                csr[f][0][k] = _ABSENT if nm is None else nm
+            elif v == _NEG_INF:
+                cols[c][k] = _ABSENT
+            elif v == v and abs(v) <= _I32_MAX and float(v).is_integer():
+                cols[c][k] = int(v)
+            else:
+                fvals[(k, c)] = float(v)
+    integral = (min_score == min_score) and not fvals
+    if cigar_mode:
+        if integral:
+            return ctx.classify_cigar(mode, csr[0][0], csr[0][1], csr[0][2], cols[1],
+                                      csr[1][0], csr[1][1], csr[1][2], cols[3], bits, _floor_min_score(min_score))
+        fcols = []
+        for f in (0, 1):
+            a = ctx.cigar_scores(csr[f][0], csr[f][1], csr[f][2])
+            fcols.append(np.where(a == _ABSENT, _NEG_INF, a.astype(np.float64)))
+            fcols.append(np.where(cols[2 * f + 1] == _ABSENT, _NEG_INF, cols[2 * f + 1].astype(np.float64)))
+    else:
+        if integral:
+            return ctx.classify(mode, *cols, bits, _floor_min_score(min_score))
+        fcols = [np.where(c == _ABSENT, _NEG_INF, c.astype(np.float64)) for c in cols]
+    for (k, c), v in fvals.items():
+        fcols[c][k] = v
+    return ctx.classify_f64(mode, *fcols, bits, float(min_score))
+
+
+def _finish_in_python(mode, path1, path2, pos, sinks, min_score, tag_func, skip_repeated, totals, key_order):
+    """Non-ASCII input: continue from byte offsets `pos` with the Python reader (str.split() semantics)."""
+    with open(path1, "rt") as f1, open(path2, "rt") as f2:
+        f1.seek(pos[0])
+        f2.seek(pos[1])
+        rest = _run(mode, getReadPairs(f1, f2, skip_repeated_reads=skip_repeated), sinks, min_score, tag_func)
+    ordered = Counter()
+    for key in key_order:
+        ordered[key] = totals[key]
+    for key, val in rest.items():
+        ordered[key] += val
+    return ordered
+
+
+def classify_sam_files(primary_sam, secondary_sam, primary_specific=sys.stdout, secondary_specific=None,
+                       primary_multi=None, secondary_multi=None, unassigned=None, unresolved=None, paired=False,
+                       conservative=False, min_score=float("-inf"), tag_func=get_tag, skip_repeated_reads=None,
+                       n_threads=0):
+    """File-level entry point: classify two SAM files (paths) whose headers the caller has already dealt with
+    (process_headers).  Equivalent to main_*(getReadPairs(open(primary_sam), open(secondary_sam), ...)) after the
+    header lines, but parses and writes through the C++ stripper.  tag_func must be one of the three built-in
+    plugins.  skip_repeated_reads defaults to `not paired`, as the command line does (ref :691)."""
+    if tag_func not in (get_tag, get_tag_with_ZS_as_XS, get_cigarbased_AS_tag):
+        raise ValueError("classify_sam_files needs a built-in tag_func; use main_* for custom plugins")
+    if skip_repeated_reads is None:
+        skip_repeated_reads = not paired
+    mode = _ffi.MODE_SE if not paired else (_ffi.MODE_PE_CONSERVATIVE if conservative else _ffi.MODE_PE_LIBERAL)
+    return _run_files(mode, primary_sam, secondary_sam,
+                      _sinks(primary_specific, secondary_specific, primary_multi, secondary_multi, unassigned, unresolved),
+                      min_score, tag_func, skip_repeated_reads, n_threads)
+
+
 def _sinks(primary_specific, secondary_specific, primary_multi, secondary_multi, unassigned, unresolved):
     # indexed by state: 0 PS, 1 SS, 2 PM, 3 SM, 4 unresolved, 5 unassigned
     return [primary_specific, secondary_specific, primary_multi, secondary_multi, unresolved, unassigned]
@@ -615,6 +860,17 @@ def main(argv=None):
     skip_repeated = not args.paired
     if args.primary_sam:
         process_headers(args.primary_sam, args.secondary_sam, **sinks)
+        names = [getattr(f, "name", None) for f in (args.primary_sam, args.secondary_sam)]
+        if all(isinstance(nm, str) and os.path.isfile(nm) for nm in names) and not os.environ.get("XENOMAPPER_PYTHON_READER"):
+            # regular files: C++ column stripper -> GPU -> C++ writer
+            category_counts = classify_sam_files(names[0], names[1], paired=args.paired, conservative=args.conservative,
+                                                 min_score=args.min_score, tag_func=tag_func,
+                                                 skip_repeated_reads=skip_repeated, **sinks)
+            output_summary(category_counts=category_counts, outfile=sys.stderr)
+            for sink in sinks.values():
+                if sink and sink not in (sys.stdout, sys.stderr):
+                    sink.flush()
+            return
         readpairs = getReadPairs(args.primary_sam, args.secondary_sam, skip_repeated_reads=skip_repeated)
     else:  # pragma: no cover - needs samtools
         process_headers(args.primary_bam, args.secondary_bam, bam=True, **sinks)
