@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""End-to-end SAM -> six SAM files throughput of the file fast path (C++ stripper -> GPU -> C++ writer).
+
+    python tools/bench_e2e.py --pairs 2000000 --threads 0
+
+Input: a synthetic 2x150 bp paired SAM text twin (50 k pairs, seed 2002) tiled to the requested size in
+/dev/shm.  Reports read-pairs/s including parsing, H2D/D2H through the host-buffer C ABI and writing all six
+bins (to /dev/null).  This is the PCIe- and parser-inclusive number; bench.py's `value` is the HBM-resident one.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=2_000_000)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--mode", default="liberal", choices=("liberal", "conservative", "se"))
+    ap.add_argument("--dir", default="/dev/shm")
+    a = ap.parse_args()
+    from xenomapper_amd import synth, xenomapper as xm
+    base = 50_000
+    t1, t2, _ = synth.sam_text_pair(n_pairs=base, seed=2002, profile="bowtie2", paired=a.mode != "se", read_len=150)
+    reps = max(1, a.pairs // base)
+    paths = []
+    for tag, text in (("p", t1), ("s", t2)):
+        head_end = 0
+        while text[head_end] == "@":
+            head_end = text.index("\n", head_end) + 1
+        path = os.path.join(a.dir, "xm_e2e_%s_%d.sam" % (tag, os.getpid()))
+        with open(path, "wt") as fh:
+            fh.write(text[:head_end])
+            body = text[head_end:]
+            for _ in range(reps):
+                fh.write(body)
+        paths.append(path)
+    size = sum(os.path.getsize(p) for p in paths)
+    sinks = {k: open(os.devnull, "wt") for k in ("primary_specific", "secondary_specific", "primary_multi",
+                                                  "secondary_multi", "unassigned", "unresolved")}
+    try:
+        xm.default_context()
+        for warm in (True, False):
+            t0 = time.perf_counter()
+            counts = xm.classify_sam_files(paths[0], paths[1], paired=a.mode != "se", conservative=a.mode == "conservative",
+                                           n_threads=a.threads, **sinks)
+            el = time.perf_counter() - t0
+        units = sum(counts.values())
+        print(json.dumps({"metric": "end-to-end read-pairs/s (SAM text in, six SAM files out)", "value": units / el,
+                          "units": units, "seconds": el, "input_bytes": size, "input_GBps": size / el / 1e9,
+                          "threads": a.threads or os.cpu_count(), "mode": a.mode}))
+    finally:
+        for p in paths:
+            os.unlink(p)
+
+
+if __name__ == "__main__":
+    main()
