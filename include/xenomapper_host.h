@@ -32,6 +32,7 @@ extern "C" {
 #define XMH_ERR_INVALID_ARG (-1)
 #define XMH_ERR_OOM         (-2)
 #define XMH_ERR_NON_ASCII   (-3)   /* a byte >= 0x80 in the window: Python's str.split() rules would apply */
+#define XMH_ERR_BAD_BAM     (-4)   /* not a BGZF/BAM image, or a truncated / corrupt one */
 
 /* which optional fields feed the score columns (the three tag_func plugins) */
 #define XMH_SCORE_AS_XS 0   /* get_tag                 xenomapper.py:176-191 */
@@ -108,6 +109,20 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
  */
 int xmh_emit(xmh_parser *p, const char *buf1, const char *buf2, int paired, int bin,
              const uint32_t *idx, uint64_t n_idx, char *out, uint64_t out_cap, uint64_t *out_len);
+
+/* ---- BAM input ------------------------------------------------------------------------
+ * The reference reads BAM by piping it through `samtools view` (get_bam_header, bam_lines, getBamReadPairs,
+ * xenomapper.py:48-93) and then handles the text as SAM.  xmh_bam_* is that pipe, natively: BGZF blocks are
+ * inflated in parallel and every alignment is printed as the SAM line `samtools view` prints, so the SAM path
+ * (xmh_parse / kernels / xmh_emit) applies unchanged.  `data` must stay valid while the reader is open. */
+typedef struct xmh_bam xmh_bam;
+int xmh_bam_open(const uint8_t *data, uint64_t len, int n_threads, xmh_bam **out);
+int xmh_bam_close(xmh_bam *b);
+/* The header as `samtools view -H` prints it (text owned by the reader, not NUL-terminated). */
+int xmh_bam_header(xmh_bam *b, const char **text, uint64_t *len);
+/* Append the SAM lines of the next alignments to dst (whole lines only, at most cap bytes; cap must hold at
+ * least one line).  *eof = 1 once every alignment has been returned. */
+int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof);
 
 #ifdef __cplusplus
 }

@@ -155,3 +155,64 @@ def test_cli_uses_fast_path(tmp_path, capsys, monkeypatch):
     for name in H.STATES:
         text = (tmp_path / (name + ".sam")).read_text()
         assert hashlib.sha224(text.encode("latin-1")).hexdigest() == case["expect"]["bins"][name]["sha224"]
+
+
+# ---------------------------------------------------------------------------------------------- BAM input
+def _bam_case_outputs(xm, mode_case, tmp_path, via):
+    import os
+    import shutil
+    case = {c["name"]: c for c in G3}[mode_case]
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_%s.bam")
+    b1, b2 = str(tmp_path / "h.bam"), str(tmp_path / "m.bam")
+    shutil.copyfile(base % "human", b1)
+    shutil.copyfile(base % "mouse", b2)
+    outs = {name: open(tmp_path / (name + ".sam"), "wt") for name in H.STATES}
+    paired, cons = case["mode"] != "se", case["mode"] == "pe_conservative"
+    tag_func = getattr(xm, case["options"]["tag_func"])
+    m = H.unnum(case["options"]["min_score"])
+    with open(b1, "rb") as f1, open(b2, "rb") as f2:
+        xm.process_headers(f1, f2, bam=True, **outs)
+        if via == "files":
+            counts = xm.classify_sam_files(b1, b2, paired=paired, conservative=cons, min_score=m, tag_func=tag_func,
+                                           bam=True, **outs)
+        else:
+            loop = xm.conservative_main_paired_end if cons else xm.main_paired_end
+            counts = loop(xm.getBamReadPairs(f1, f2), min_score=m, tag_func=tag_func, **outs)
+    texts = {}
+    for name, sink in outs.items():
+        sink.close()
+        texts[name] = (tmp_path / (name + ".sam")).read_text()
+    return case, counts, texts
+
+
+@pytest.mark.parametrize("via", ["files", "iterator"])
+@pytest.mark.parametrize("mode_case", ["ref_pe_liberal", "ref_pe_conservative", "ref_pe_liberal_cigar",
+                                       "ref_pe_conservative_min99_5"])
+def test_bam_input_equals_sam_input(mode_case, via, tmp_path):
+    """The reference's BAM fixtures carry the same alignments as its SAM fixtures, so BAM input must give the
+    golden outputs recorded for SAM input (the reference would get there through `samtools view`)."""
+    from xenomapper_amd import xenomapper as xm
+    case, counts, texts = _bam_case_outputs(xm, mode_case, tmp_path, via)
+    exp = case["expect"]
+    flat = {("|".join(k) if isinstance(k, tuple) else k): v for k, v in counts.items()}
+    assert flat == exp["counts"]
+    for name in H.STATES:
+        assert hashlib.sha224(texts[name].encode("latin-1")).hexdigest() == exp["bins"][name]["sha224"], name
+
+
+def test_cli_bam(tmp_path, capsys):
+    import os
+    import shutil
+    from xenomapper_amd import xenomapper as xm
+    case = {c["name"]: c for c in G3}["ref_pe_conservative"]
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_%s.bam")
+    shutil.copyfile(base % "human", tmp_path / "h.bam")
+    shutil.copyfile(base % "mouse", tmp_path / "m.bam")
+    args = ["--primary_bam", str(tmp_path / "h.bam"), "--secondary_bam", str(tmp_path / "m.bam"), "--paired", "--conservative"]
+    for name in H.STATES:
+        args += ["--" + name, str(tmp_path / (name + ".sam"))]
+    xm.main(args)
+    assert capsys.readouterr().err == case["expect"]["summary"]
+    for name in H.STATES:
+        text = (tmp_path / (name + ".sam")).read_text()
+        assert hashlib.sha224(text.encode("latin-1")).hexdigest() == case["expect"]["bins"][name]["sha224"]

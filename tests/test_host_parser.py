@@ -228,3 +228,84 @@ def test_library_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_host.EXPORTED) == names
+
+
+# ---------------------------------------------------------------------------------------------- BAM input
+def _decode_bam(path, chunk=1 << 20):
+    from xenomapper_amd import _host
+    data = np.fromfile(path, dtype=np.uint8)
+    r = _host.BamReader(data, 3)
+    hdr = r.header()
+    buf = np.empty(chunk, dtype=np.uint8)
+    parts = []
+    while not r.eof:
+        n = r.read_into(buf, 0)
+        parts.append(bytes(buf[:n]).decode("ascii"))
+        assert n > 0 or r.eof
+    r.close()
+    return hdr, "".join(parts)
+
+
+@pytest.mark.parametrize("species", ["human", "mouse"])
+@pytest.mark.parametrize("chunk", [1 << 20, 700])
+def test_bam_decoder_reproduces_the_sam_fixture(species, chunk):
+    """The reference's BAM fixtures hold the same alignments as its SAM fixtures; the native decoder must print
+    them exactly as the SAM text (which is what `samtools view -h` gives the reference, ref :48-64)."""
+    import os
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_%s" % species)
+    hdr, body = _decode_bam(base + ".bam", chunk)
+    with open(base + ".sam") as fh:
+        sam = fh.read()
+    assert hdr + body == sam + "\n"                      # the SAM fixture has no trailing newline
+
+
+def test_bam_decoder_rejects_garbage():
+    from xenomapper_amd import _host
+    with pytest.raises(ValueError):
+        _host.BamReader(np.frombuffer(b"this is not a BAM file at all, not even gzip....", dtype=np.uint8))
+    import os
+    data = np.fromfile(os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_human.bam"), dtype=np.uint8)
+    with pytest.raises(ValueError):
+        r = _host.BamReader(data[:20000].copy())
+        buf = np.empty(1 << 20, dtype=np.uint8)
+        while not r.eof:
+            r.read_into(buf, 0)
+
+
+def test_bam_optional_field_formats():
+    """Hand-assembled BAM record covering every optional-field type."""
+    import struct, zlib
+    from xenomapper_amd import _host
+
+    def bgzf(payload):
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = comp.compress(payload) + comp.flush()
+        bsize = len(cdata) + 25
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + cdata +
+                struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+    text = b"@HD\tVN:1.0\n@SQ\tSN:chrA\tLN:1000\n@SQ\tSN:chrB\tLN:2000\n"
+    head = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 2)
+    for name, ln in ((b"chrA\x00", 1000), (b"chrB\x00", 2000)):
+        head += struct.pack("<i", len(name)) + name + struct.pack("<i", ln)
+    tags = (b"XAAq" + b"XBc" + struct.pack("<b", -5) + b"XCC" + struct.pack("<B", 200) + b"XDs" + struct.pack("<h", -300) +
+            b"XES" + struct.pack("<H", 60000) + b"ASi" + struct.pack("<i", -70000) + b"XFI" + struct.pack("<I", 4000000000) +
+            b"XGf" + struct.pack("<f", 1.5) + b"XHZhello world\x00" + b"XIH1AE3\x00" +
+            b"XJBs" + struct.pack("<i", 3) + struct.pack("<hhh", 1, -2, 3) + b"XKBf" + struct.pack("<i", 2) + struct.pack("<ff", 0.25, 1e10))
+    seq = bytes([0x12, 0x48, 0x10])                         # A C G T A (5 bases)
+    qual = bytes([30, 31, 32, 33, 34])
+    cigar = struct.pack("<II", (3 << 4) | 0, (2 << 4) | 4)  # 3M2S
+    rname = b"read/1\x00"
+    core = struct.pack("<iiBBHHHIiii", 0, 99, len(rname), 42, 4680, 2, 99, 5, 1, 199, -250)
+    rec = core + rname + cigar + seq + qual + tags
+    unm = struct.pack("<iiBBHHHIiii", -1, -1, 2, 0, 4680, 0, 4, 0, -1, -1, 0) + b"u\x00"
+    payload = head + struct.pack("<i", len(rec)) + rec + struct.pack("<i", len(unm)) + unm
+    image = bgzf(payload[:150]) + bgzf(payload[150:]) + bgzf(b"")
+    r = _host.BamReader(np.frombuffer(image, dtype=np.uint8), 2)
+    assert r.header() == text.decode()
+    buf = np.empty(4096, dtype=np.uint8)
+    n = r.read_into(buf, 0)
+    lines = bytes(buf[:n]).decode().split("\n")
+    assert lines[0] == ("read/1\t99\tchrA\t100\t42\t3M2S\tchrB\t200\t-250\tACGTA\t?@ABC\tXA:A:q\tXB:i:-5\tXC:i:200\tXD:i:-300"
+                        "\tXE:i:60000\tAS:i:-70000\tXF:i:4000000000\tXG:f:1.5\tXH:Z:hello world\tXI:H:1AE3\tXJ:B:s,1,-2,3"
+                        "\tXK:B:f,0.25,1e+10")
+    assert lines[1] == "u\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*" and r.eof

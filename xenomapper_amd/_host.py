@@ -14,7 +14,8 @@ SCORE_AS_XS, SCORE_AS_ZS, SCORE_CIGAR = 0, 1, 2
 EX_NONINT, EX_DUP, EX_SHORT, EX_BIGLEN = 1, 2, 3, 4
 ERR_NON_ASCII = -3
 
-EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit")
+EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
+            "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read")
 
 _P = ctypes.c_void_p
 
@@ -52,6 +53,10 @@ def lib():
                                 ctypes.POINTER(_Block)]
         L.xmh_emit.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_uint64,
                                ctypes.POINTER(ctypes.c_uint64)]
+        L.xmh_bam_open.argtypes = [_P, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(_P)]
+        L.xmh_bam_close.argtypes = [_P]
+        L.xmh_bam_header.argtypes = [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]
+        L.xmh_bam_read.argtypes = [_P, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
         _lib = L
     return _lib
 
@@ -140,3 +145,43 @@ class Parser(object):
         if rc != 0:
             raise RuntimeError("xmh_emit: " + self._L.xmh_strerror(rc).decode())
         return out
+
+
+class BamReader(object):
+    """BAM file image -> SAM text, like `samtools view` (header via .header(), lines via .read_into())."""
+
+    def __init__(self, data, n_threads=0):
+        self._L = lib()
+        self._data = np.ascontiguousarray(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        h = _P()
+        rc = self._L.xmh_bam_open(self._data.ctypes.data if self._data.shape[0] else None, self._data.shape[0],
+                                  int(n_threads), ctypes.byref(h))
+        if rc != 0:
+            raise ValueError("xmh_bam_open: " + self._L.xmh_strerror(rc).decode())
+        self._h = h
+        self.eof = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.xmh_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def header(self):
+        text, n = _P(), ctypes.c_uint64()
+        self._L.xmh_bam_header(self._h, ctypes.byref(text), ctypes.byref(n))
+        return ctypes.string_at(text, n.value).decode("ascii") if n.value else ""
+
+    def read_into(self, out, start):
+        """Append whole SAM lines to the uint8 array `out` from offset `start`; returns bytes written."""
+        w, eof = ctypes.c_uint64(), ctypes.c_int()
+        rc = self._L.xmh_bam_read(self._h, out.ctypes.data + start, out.shape[0] - start, ctypes.byref(w), ctypes.byref(eof))
+        if rc != 0:
+            raise ValueError("xmh_bam_read: " + self._L.xmh_strerror(rc).decode())
+        self.eof = bool(eof.value)
+        return int(w.value)

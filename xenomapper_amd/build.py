@@ -16,7 +16,7 @@ HIP_LIB = os.path.join(PKG, "libxenomapper_hip.so")
 HOST_LIB = os.path.join(PKG, "libxenomapper_host.so")
 
 HIP_SOURCES = ["xm_kernels.hip", "xm_api.hip"]
-HOST_SOURCES = ["xm_sam.cpp"]
+HOST_SOURCES = ["xm_sam.cpp", "xm_bam.cpp"]
 
 
 def _hipcc():
@@ -54,7 +54,7 @@ def build_host(force=False, verbose=False):
     if not force and not _stale(HOST_LIB, deps):
         return HOST_LIB
     cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra",
-           "-I", os.path.join(REPO, "include")] + srcs + ["-o", HOST_LIB]
+           "-I", os.path.join(REPO, "include")] + srcs + ["-o", HOST_LIB, "-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

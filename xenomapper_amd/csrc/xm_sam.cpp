@@ -266,6 +266,7 @@ const char *xmh_strerror(int status)
     case XMH_ERR_INVALID_ARG: return "invalid argument";
     case XMH_ERR_OOM: return "out of memory";
     case XMH_ERR_NON_ASCII: return "non-ASCII byte in SAM input";
+    case XMH_ERR_BAD_BAM: return "not a valid BGZF/BAM file";
     default: return "unknown status";
     }
 }

@@ -25,7 +25,6 @@ import argparse
 import math
 import os
 import re
-import subprocess
 import sys
 import textwrap
 from collections import Counter
@@ -81,23 +80,34 @@ def get_sam_header(samfile):
     return header
 
 
-def _samtools_lines(handle, args):  # pragma: no cover - needs samtools
-    proc = subprocess.Popen("samtools view %s -" % args, stdin=handle, stdout=subprocess.PIPE,
-                            stderr=subprocess.PIPE, shell=True)
-    for raw in proc.stdout:
-        yield raw.decode("ascii")
-
-
-def get_bam_header(bamfile):  # pragma: no cover - needs samtools
-    """Header of a BAM file via `samtools view -H` (ref :48-54)."""
-    lines = [text.strip("\n") for text in _samtools_lines(bamfile, "-H")]
+def _bam_reader(bamfile):
+    """Native BGZF/BAM decoder over a binary file object (no samtools needed)."""
+    from . import _host
+    data = np.frombuffer(bamfile.read(), dtype=np.uint8)
     bamfile.seek(0)
-    return lines
+    return _host.BamReader(data)
 
 
-def bam_lines(f):  # pragma: no cover - needs samtools
-    """SAM text lines of a BAM file via `samtools view` (ref :56-64)."""
-    return _samtools_lines(f, "")
+def get_bam_header(bamfile):
+    """Header lines of a BAM file, as `samtools view -H` prints them (ref :48-54)."""
+    reader = _bam_reader(bamfile)
+    try:
+        return [line for line in reader.header().split("\n") if line]
+    finally:
+        reader.close()
+
+
+def bam_lines(f):
+    """SAM text lines of the alignments of a BAM file, as `samtools view` prints them (ref :56-64)."""
+    reader = _bam_reader(f)
+    try:
+        buf = np.empty(8 << 20, dtype=np.uint8)
+        while not reader.eof:
+            n = reader.read_into(buf, 0)
+            for line in bytes(buf[:n]).decode("ascii").splitlines(True):
+                yield line
+    finally:
+        reader.close()
 
 
 def _lockstep(next1, next2, skip_repeated_reads):
@@ -125,8 +135,8 @@ def getReadPairs(sam1, sam2, skip_repeated_reads=False):
                      lambda: sam2.readline().strip("\n").split(), skip_repeated_reads)
 
 
-def getBamReadPairs(bamfile1, bamfile2, skip_repeated_reads=False):  # pragma: no cover - needs samtools
-    """As getReadPairs for BAM input read through samtools (ref :66-93)."""
+def getBamReadPairs(bamfile1, bamfile2, skip_repeated_reads=False):
+    """As getReadPairs for BAM input (ref :66-93); decoded natively instead of through samtools."""
     it1, it2 = bam_lines(bamfile1), bam_lines(bamfile2)
 
     class _Done(Exception):
@@ -574,19 +584,71 @@ def _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode):
     return patches, None, None
 
 
-def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_threads=0):
-    """The three main loops on two SAM *files*: same results as _run(mode, getReadPairs(...)), with the text
-    work done by the C++ stripper / writer.  Falls back to the Python reader when the input is not ASCII."""
+class _SamSource(object):
+    """Record text of a SAM file: windows of a read-only memory map."""
+
+    def __init__(self, path):
+        self.path = path
+        self.raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
+        self.pos = _record_start(self.raw)
+
+    def window(self, want):
+        n = min(want, self.raw.shape[0] - self.pos)
+        return self.raw, self.pos, n, self.pos + n >= self.raw.shape[0]
+
+    def advance(self, consumed):
+        self.pos += consumed
+
+    def close(self):
+        pass
+
+
+class _BamSource(object):
+    """Record text of a BAM file: SAM lines decoded on demand into a sliding buffer."""
+
+    def __init__(self, path, n_threads=0):
+        from . import _host
+        self.path = path
+        self.data = np.memmap(path, dtype=np.uint8, mode="r")
+        self.reader = _host.BamReader(self.data, n_threads)
+        self.buf = np.empty(FILE_WINDOW_BYTES + (1 << 20), dtype=np.uint8)
+        self.start = self.end = 0
+
+    def window(self, want):
+        if self.end - self.start < want and not self.reader.eof:
+            live = self.end - self.start
+            if want + (1 << 20) > self.buf.shape[0]:
+                grown = np.empty(2 * want + (1 << 20), dtype=np.uint8)
+                grown[:live] = self.buf[self.start:self.end]
+                self.buf = grown
+            elif self.start:
+                self.buf[:live] = self.buf[self.start:self.end].copy()
+            self.start, self.end = 0, live
+            while self.end - self.start < want and not self.reader.eof:
+                got = self.reader.read_into(self.buf, self.end)
+                if got == 0 and not self.reader.eof:
+                    break                                          # the next line needs a bigger buffer
+                self.end += got
+        n = min(want, self.end - self.start)
+        return self.buf, self.start, n, self.reader.eof and n == self.end - self.start
+
+    def advance(self, consumed):
+        self.start += consumed
+
+    def close(self):
+        self.reader.close()
+
+
+def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_threads=0, bam=False):
+    """The three main loops on two SAM (or BAM) *files*: same results as _run(mode, getReadPairs(...)), with the
+    text work done by the C++ stripper / writer.  Falls back to the Python reader when the input is not ASCII."""
     from . import _host
     ctx = default_context()
     paired = mode != _ffi.MODE_SE
     cigar_mode = tag_func is get_cigarbased_AS_tag
     score_mode = _host.SCORE_CIGAR if cigar_mode else (_host.SCORE_AS_ZS if tag_func is get_tag_with_ZS_as_XS
                                                        else _host.SCORE_AS_XS)
-    raws = [np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
-            for path in (path1, path2)]
-    sizes = [r.shape[0] for r in raws]
-    pos = [_record_start(r) for r in raws]
+    sources = [(_BamSource(path, n_threads) if bam else _SamSource(path)) for path in (path1, path2)]
     parser = _host.Parser(n_threads)
     totals, key_order = Counter(), []
     window = FILE_WINDOW_BYTES
@@ -594,12 +656,17 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     distinct = len(set(id(s) for s in active)) == len(active)
     try:
         while True:
-            lens = [min(window, sizes[f] - pos[f]) for f in (0, 1)]
-            eofs = [pos[f] + lens[f] >= sizes[f] for f in (0, 1)]
+            wins = [src.window(window) for src in sources]
+            raws = [w[0] for w in wins]
+            pos = [w[1] for w in wins]
+            lens = [w[2] for w in wins]
+            eofs = [w[3] for w in wins]
             try:
                 block = parser.parse(raws[0], pos[0], lens[0], eofs[0], raws[1], pos[1], lens[1], eofs[1], score_mode,
                                      paired, skip_repeated, paired, FILE_MAX_RECORDS)
             except _host.NonAsciiInput:
+                if bam:
+                    raise ValueError("non-ASCII bytes in BAM text fields are not supported")
                 return _finish_in_python(mode, path1, path2, pos, sinks, min_score, tag_func, skip_repeated,
                                          totals, key_order)
             n = block.n
@@ -647,9 +714,12 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 raise pending
             if block.ended or (eofs[0] and eofs[1] and not progressed):
                 break
-            pos = [pos[0] + block.consumed[0], pos[1] + block.consumed[1]]
+            for f in (0, 1):
+                sources[f].advance(block.consumed[f])
     finally:
         parser.close()
+        for src in sources:
+            src.close()
     ordered = Counter()
     for key in key_order:
         ordered[key] = totals[key]
@@ -734,11 +804,12 @@ def _finish_in_python(mode, path1, path2, pos, sinks, min_score, tag_func, skip_
 def classify_sam_files(primary_sam, secondary_sam, primary_specific=sys.stdout, secondary_specific=None,
                        primary_multi=None, secondary_multi=None, unassigned=None, unresolved=None, paired=False,
                        conservative=False, min_score=float("-inf"), tag_func=get_tag, skip_repeated_reads=None,
-                       n_threads=0):
+                       n_threads=0, bam=False):
     """File-level entry point: classify two SAM files (paths) whose headers the caller has already dealt with
     (process_headers).  Equivalent to main_*(getReadPairs(open(primary_sam), open(secondary_sam), ...)) after the
     header lines, but parses and writes through the C++ stripper.  tag_func must be one of the three built-in
-    plugins.  skip_repeated_reads defaults to `not paired`, as the command line does (ref :691)."""
+    plugins.  skip_repeated_reads defaults to `not paired`, as the command line does (ref :691).  bam=True: the
+    inputs are BAM files, decoded natively to the text `samtools view` would print."""
     if tag_func not in (get_tag, get_tag_with_ZS_as_XS, get_cigarbased_AS_tag):
         raise ValueError("classify_sam_files needs a built-in tag_func; use main_* for custom plugins")
     if skip_repeated_reads is None:
@@ -746,7 +817,7 @@ def classify_sam_files(primary_sam, secondary_sam, primary_specific=sys.stdout, 
     mode = _ffi.MODE_SE if not paired else (_ffi.MODE_PE_CONSERVATIVE if conservative else _ffi.MODE_PE_LIBERAL)
     return _run_files(mode, primary_sam, secondary_sam,
                       _sinks(primary_specific, secondary_specific, primary_multi, secondary_multi, unassigned, unresolved),
-                      min_score, tag_func, skip_repeated_reads, n_threads)
+                      min_score, tag_func, skip_repeated_reads, n_threads, bam)
 
 
 def _sinks(primary_specific, secondary_specific, primary_multi, secondary_multi, unassigned, unresolved):
@@ -872,8 +943,18 @@ def main(argv=None):
                     sink.flush()
             return
         readpairs = getReadPairs(args.primary_sam, args.secondary_sam, skip_repeated_reads=skip_repeated)
-    else:  # pragma: no cover - needs samtools
+    else:
         process_headers(args.primary_bam, args.secondary_bam, bam=True, **sinks)
+        names = [getattr(f, "name", None) for f in (args.primary_bam, args.secondary_bam)]
+        if all(isinstance(nm, str) and os.path.isfile(nm) for nm in names) and not os.environ.get("XENOMAPPER_PYTHON_READER"):
+            category_counts = classify_sam_files(names[0], names[1], paired=args.paired, conservative=args.conservative,
+                                                 min_score=args.min_score, tag_func=tag_func,
+                                                 skip_repeated_reads=skip_repeated, bam=True, **sinks)
+            output_summary(category_counts=category_counts, outfile=sys.stderr)
+            for sink in sinks.values():
+                if sink and sink not in (sys.stdout, sys.stderr):
+                    sink.flush()
+            return
         readpairs = getBamReadPairs(args.primary_bam, args.secondary_bam, skip_repeated_reads=skip_repeated)
     if args.paired:
         loop = conservative_main_paired_end if args.conservative else main_paired_end
