@@ -148,6 +148,7 @@ def main():
     fence()
     job_counts.zero_()
     fence()
+    ctx.timing_select(["classify"])          # the timed region brackets only the kernel the roofline is about
     ctx.timing_enable(True)
     ctx.timing_reset()
     t0 = time.perf_counter()
@@ -157,6 +158,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timing = ctx.timing_read()
+    job_total = int(job_counts.sum().item())
+    # diagnostic pass outside the timed region: every kernel bracketed (the event pairs cost stream time)
+    ctx.timing_select(None)
+    ctx.timing_reset()
+    for _ in range(min(args.steps, 20)):
+        step()
+    fence()
+    timing_all = ctx.timing_read()
     ctx.timing_enable(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -178,7 +187,7 @@ def main():
         ok &= bool((off.cpu().numpy().astype(np.uint64) == want_off).all())
         ok &= bool((idx[:int(want_off[7])].cpu().numpy().view(np.uint32) == want_idx).all())
         ok &= bool((counts.cpu().numpy().astype(np.uint64) == want_counts).all())
-        ok &= int(job_counts.sum().item()) == world * n_pairs * args.steps
+        ok &= job_total == world * n_pairs * args.steps
         verified = ok
         flag = torch.tensor([1 if ok else 0], device=dev)
         if world > 1:
@@ -189,7 +198,7 @@ def main():
         k_cls = timing["classify"]
         cls_ms = k_cls["ms"] / max(1, k_cls["launches"])
         achieved = BYTES_PER_PAIR_CLASSIFY * n_pairs / (cls_ms * 1e-3) / 1e9
-        kernels = {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in timing.items() if v["launches"]}
+        kernels = {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in timing_all.items() if v["launches"]}
         traffic = None
         pmc_file = os.path.join(REPO, "profiles", "pmc_classify.json")
         if os.path.exists(pmc_file):
@@ -213,7 +222,7 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_pair": BYTES_PER_PAIR_CLASSIFY,
                          "kernel_ms": cls_ms},
-            "kernel_ms": kernels,
+            "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region",
             "verified_vs_oracle": verified,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -133,7 +133,8 @@ int xm_compact(xm_ctx *ctx, int mode, uint64_t n_records, const uint8_t *code,
  * All pointers are device memory of the context's device; `stream` is a hipStream_t passed
  * as void* (NULL = the default stream).  Nothing is synchronised or allocated: the calls
  * only enqueue work (graph-capturable).  Column base pointers must be 16-byte aligned and
- * code 4-byte aligned (any hipMalloc / torch allocation is).  n_records <= XM_MAX_RECORDS.
+ * code 4-byte aligned (any hipMalloc / torch allocation is).  n_records <= XM_MAX_RECORDS.  The calling
+ * thread's current HIP device must be the context's device (XM_ERR_INVALID_ARG otherwise).
  */
 #define XM_MAX_RECORDS 0xFFFFF000ull
 
@@ -171,6 +172,9 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, cons
  * launch stream.  xm_timing_read() synchronises the recorded events and adds their elapsed
  * times: ms[k] = total milliseconds, launches[k] = number of launches since the last reset. */
 int xm_timing_enable(xm_ctx *ctx, int on);
+/* Restrict the bracketing to the kernels whose bit (1 << XM_K_*) is set (default: all).  An event pair costs a
+ * few microseconds of stream time per launch, so a throughput run times only the kernel it reports on. */
+int xm_timing_select(xm_ctx *ctx, uint32_t kernel_mask);
 int xm_timing_reset(xm_ctx *ctx);
 int xm_timing_read(xm_ctx *ctx, double ms[XM_K_COUNT], uint64_t launches[XM_K_COUNT]);
 

@@ -107,7 +107,6 @@ int main(int argc, char **argv)
     std::vector<std::vector<float>> t(cfgs.size());
     for (int r = 0; r < rounds + 2; ++r)
         for (size_t k = 0; k < cfgs.size(); ++k) {
-            if (cfgs[k].name[0] == 'h') CK(hipMemsetAsync(COUNTS_REP, 0, 64 * 512));
             CK(hipEventRecord(e0)); cfgs[k].fn(cfgs[k].grid); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 2) t[k].push_back(ms);

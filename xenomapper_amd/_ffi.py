@@ -83,6 +83,7 @@ def lib():
         "xm_cigar_scores_dev": ([P, P, U64, P, P, P, P, P], I),
         "xm_compact_dev": ([P, P, I, U64, P, P, P, P], I),
         "xm_timing_enable": ([P, I], I),
+        "xm_timing_select": ([P, ctypes.c_uint32], I),
         "xm_timing_reset": ([P], I),
         "xm_timing_read": ([P, P, P], I),
     }
@@ -97,8 +98,7 @@ def lib():
 EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create", "xm_ctx_destroy",
             "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_classify_cigar",
             "xm_compact", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
-            "xm_compact_dev",
-            "xm_timing_enable", "xm_timing_reset", "xm_timing_read")
+            "xm_compact_dev", "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
 
 def _np_ptr(a):
@@ -269,6 +269,11 @@ class Context(object):
     # ---- timing --------------------------------------------------------------------------
     def timing_enable(self, on=True):
         self._check(self._L.xm_timing_enable(self._h, 1 if on else 0), "xm_timing_enable")
+
+    def timing_select(self, kernels=None):
+        """Time only the named kernels (None = all)."""
+        mask = 0xFFFFFFFF if kernels is None else sum(1 << KERNELS.index(k) for k in kernels)
+        self._check(self._L.xm_timing_select(self._h, mask), "xm_timing_select")
 
     def timing_reset(self):
         self._check(self._L.xm_timing_reset(self._h), "xm_timing_reset")

@@ -30,6 +30,7 @@ struct xm_ctx {
     size_t scratch_bytes[8];
     // timing
     bool timing;
+    uint32_t timing_mask;           // bit k: kernel k is bracketed with events while timing is on
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> free_events;
     double acc_ms[XM_K_COUNT];
@@ -96,7 +97,7 @@ struct Span {
     hipStream_t st;
     TimedSpan sp;
     bool on;
-    Span(xm_ctx *c, hipStream_t s, int kernel) : ctx(c), st(s), on(c->timing)
+    Span(xm_ctx *c, hipStream_t s, int kernel) : ctx(c), st(s), on(c->timing && ((c->timing_mask >> kernel) & 1u))
     {
         if (!on) return;
         sp.kernel = kernel;
@@ -121,6 +122,13 @@ int check_launch(xm_ctx *ctx, const char *what)
 }
 
 bool bad_mode(int mode) { return mode < XM_MODE_SE || mode > XM_MODE_PE_CONSERVATIVE; }
+
+// the *_dev entry points launch on the calling thread's current device, which must be the context's
+bool wrong_device(const xm_ctx *ctx)
+{
+    int cur = -1;
+    return hipGetDevice(&cur) != hipSuccess || cur != ctx->device;
+}
 
 }  // namespace
 
@@ -170,11 +178,13 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     ctx->d_counts_rep = nullptr;
     for (int i = 0; i < 8; ++i) { ctx->d_scratch[i] = nullptr; ctx->scratch_bytes[i] = 0; }
     ctx->timing = false;
+    ctx->timing_mask = ~0u;
     for (int k = 0; k < XM_K_COUNT; ++k) { ctx->acc_ms[k] = 0.0; ctx->acc_launches[k] = 0; }
     const size_t ws = ((size_t)XM_MAX_CHUNKS + 64) * 8 * sizeof(uint32_t);    // [8 bins][chunk pitch], largest input
     hipError_t e = hipMalloc((void **)&ctx->d_chunk_counts, ws);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_chunk_off, ws);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counts_rep, (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counts_rep, 0, (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t));
     if (e != hipSuccess) {
         if (ctx->d_chunk_counts) (void)hipFree(ctx->d_chunk_counts);
         if (ctx->d_chunk_off) (void)hipFree(ctx->d_chunk_off);
@@ -215,7 +225,7 @@ int xm_classify_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                     const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
                     const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out)
 {
-    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (n == 0) return XM_OK;
     if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out) return XM_ERR_INVALID_ARG;
     if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 15u) || ((uintptr_t)code_out & 3u))
@@ -232,7 +242,7 @@ int xm_classify_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                         const double *as1, const double *xs1, const double *as2, const double *xs2,
                         const uint64_t *unit_bits, double min_score, uint8_t *code_out)
 {
-    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (n == 0) return XM_OK;
     if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out) return XM_ERR_INVALID_ARG;
     if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || ((uintptr_t)code_out & 3u))
@@ -250,7 +260,7 @@ int xm_classify_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                           const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
                           const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint32_t *range_flag)
 {
-    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (n == 0) return XM_OK;
     if (!nm1 || !off1 || !ops1 || !xs1 || !nm2 || !off2 || !ops2 || !xs2 || !unit_bits || !code_out)
         return XM_ERR_INVALID_ARG;
@@ -270,7 +280,7 @@ int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n, const int32_t *nm
                         const uint32_t *cig_off, const uint32_t *cig_oplen, int32_t *as_out,
                         uint32_t *range_flag)
 {
-    if (!ctx || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (!ctx || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (n == 0) return XM_OK;
     if (!nm || !cig_off || !cig_oplen || !as_out) return XM_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -284,7 +294,7 @@ int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n, const int32_t *nm
 int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_t *code,
                    uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
 {
-    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
@@ -292,7 +302,7 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_
         XM_HIP(ctx, hipMemsetAsync(bin_offsets, 0, 8 * sizeof(uint64_t), st));
         return XM_OK;
     }
-    XM_HIP(ctx, hipMemsetAsync(ctx->d_counts_rep, 0, XM_COUNT_REPLICAS * 64 * sizeof(uint64_t), st));
+    // d_counts_rep is all zero here: zeroed at context creation and by every K2b after it has summed it
     if (!code || !idx_out || ((uintptr_t)code & 15u)) return XM_ERR_INVALID_ARG;
     const xm::ChunkPlan plan = xm::plan_chunks(n);
     int rc;
@@ -484,6 +494,13 @@ int xm_timing_enable(xm_ctx *ctx, int on)
 {
     if (!ctx) return XM_ERR_INVALID_ARG;
     ctx->timing = on != 0;
+    return XM_OK;
+}
+
+int xm_timing_select(xm_ctx *ctx, uint32_t kernel_mask)
+{
+    if (!ctx) return XM_ERR_INVALID_ARG;
+    ctx->timing_mask = kernel_mask;
     return XM_OK;
 }
 

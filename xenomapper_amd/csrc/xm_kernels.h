@@ -38,7 +38,7 @@ void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
 void launch_hist(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
                  uint32_t *chunk_counts, uint64_t *counts_rep);
 void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_counts, uint32_t *chunk_off,
-                 uint64_t *bin_totals, const uint64_t *counts_rep, uint64_t *counts);
+                 uint64_t *bin_totals, uint64_t *counts_rep, uint64_t *counts);
 void launch_scatter(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
                     const uint32_t *chunk_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out);
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,

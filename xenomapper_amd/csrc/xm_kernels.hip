@@ -273,20 +273,23 @@ hist_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t chu
 // K2b: exclusive scan of the per-chunk bin counts.  Workgroup b (1024 threads) scans bin b: each of its
 // 16 waves owns a contiguous range of chunks, sums it, and after one barrier rescans it with the
 // carry of the ranges before.  chunk_off[b][k] = units of bin b in chunks < k; bin_totals[b] = units of
-// bin b.  The workgroups also add up the replicas of category_counts (8 slots each).
+// bin b.  The workgroups also add up the replicas of category_counts (8 slots each) and zero them again.
 // ---------------------------------------------------------------------------------------------
 #define XM_SCAN_THREADS 1024
 __global__ void __launch_bounds__(XM_SCAN_THREADS)
 scan_kernel(const uint32_t *__restrict__ chunk_counts, uint32_t n_chunks, uint32_t chunk_stride,
             uint32_t *__restrict__ chunk_off, unsigned long long *__restrict__ bin_totals,
-            const unsigned long long *__restrict__ counts_rep, unsigned long long *__restrict__ counts)
+            unsigned long long *__restrict__ counts_rep, unsigned long long *__restrict__ counts)
 {
     __shared__ unsigned long long wsum[XM_SCAN_THREADS / 64];
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x < 64) {   // category_counts slots 8b..8b+7: 8 lanes per slot, 8 replicas each
         const uint32_t slot = b * 8u + (threadIdx.x >> 3), part = threadIdx.x & 7u;
         unsigned long long acc = 0;
-        for (uint32_t r = part; r < XM_COUNT_REPLICAS; r += 8u) acc += counts_rep[r * 64u + slot];
+        for (uint32_t r = part; r < XM_COUNT_REPLICAS; r += 8u) {
+            acc += counts_rep[r * 64u + slot];
+            counts_rep[r * 64u + slot] = 0;               // consumed: leave the replicas zeroed for the next K2a
+        }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
@@ -750,11 +753,11 @@ void launch_hist(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const
 }
 
 void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_counts, uint32_t *chunk_off,
-                 uint64_t *bin_totals, const uint64_t *counts_rep, uint64_t *counts)
+                 uint64_t *bin_totals, uint64_t *counts_rep, uint64_t *counts)
 {
     scan_kernel<<<8, XM_SCAN_THREADS, 0, st>>>(chunk_counts, p.n_chunks, p.chunk_stride, chunk_off,
                                    reinterpret_cast<unsigned long long *>(bin_totals),
-                                   reinterpret_cast<const unsigned long long *>(counts_rep),
+                                   reinterpret_cast<unsigned long long *>(counts_rep),
                                    reinterpret_cast<unsigned long long *>(counts));
 }
 
