@@ -56,6 +56,16 @@ template <int K> static void run_scan(int) { Plan p = plan_k<K>(); xm::scan_kern
 template <int K, int ABL> static void run_scatter_abl(int) { Plan p = plan_k<K>(); xm::scatter_kernel<1, K, ABL><<<p.n_chunks, 256>>>(CODE, N, p.stride, CHUNK_OFF, BINTOT, BINOFF, IDX); }
 template <int K> static void run_scatter(int) { Plan p = plan_k<K>(); xm::scatter_kernel<1, K><<<p.n_chunks, 256>>>(CODE, N, p.stride, CHUNK_OFF, BINTOT, BINOFF, IDX); }
 
+template <int ABL> static void run_pipeline(int)     // 4 back-to-back steps: steady-state cache contents
+{
+    for (int r = 0; r < 4; ++r) {
+        run_cls<true, 512>(0);
+        run_hist<2>(0);
+        run_scan<2>(0);
+        run_scatter_abl<2, ABL>(0);
+    }
+}
+
 int main(int argc, char **argv)
 {
     N = argc > 1 ? strtoull(argv[1], 0, 10) : 100000000ull;
@@ -99,6 +109,10 @@ int main(int argc, char **argv)
         {"hist K2", run_hist<2>, 0, (double)N}, {"scan K2", run_scan<2>, 0, 0}, {"scatter K2", run_scatter<2>, 0, 3.0 * N},
         {"scatter K2 no-store", run_scatter_abl<2, 1>, 0, 3.0 * N}, {"scatter K2 no-stage", run_scatter_abl<2, 2>, 0, 3.0 * N},
         {"scatter K2 plain-store", run_scatter_abl<2, 3>, 0, 3.0 * N},
+        {"scatter K2 sc1-store", run_scatter_abl<2, 4>, 0, 3.0 * N},
+        {"pipeline x4 nt", run_pipeline<0>, 0, 4 * 19.0 * N}, {"pipeline x4 plain", run_pipeline<3>, 0, 4 * 19.0 * N},
+        {"pipeline x4 sc1", run_pipeline<4>, 0, 4 * 19.0 * N}, {"pipeline x4 hybrid", run_pipeline<5>, 0, 4 * 19.0 * N},
+        {"scatter K2 hybrid", run_scatter_abl<2, 5>, 0, 3.0 * N},
         {"hist K4", run_hist<4>, 0, (double)N}, {"scan K4", run_scan<4>, 0, 0}, {"scatter K4", run_scatter<4>, 0, 3.0 * N},
         {"hist K8", run_hist<8>, 0, (double)N}, {"scan K8", run_scan<8>, 0, 0}, {"scatter K8", run_scatter<8>, 0, 3.0 * N},
     };

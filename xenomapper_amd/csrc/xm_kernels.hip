@@ -430,16 +430,29 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
             if (k + 1 < K) load_codes16(code, span0 + (uint64_t)(k + 1) * XM_WTILE + lane * 16u, n, wn);   // prefetch
             uint64_t cnt = 0;
             uint32_t n0 = 0, n1 = 0;
+            // strictly interleaved mates (the usual paired input): units only at odd positions in every lane of
+            // the wave -> a branch-free pass over the 8 odd bytes; anything else takes the general pass
+            const bool even_free = ((w[0] & w[1] & w[2] & w[3]) & 0x00FF00FFu) == 0x00FF00FFu;
+            if (__ballot(!even_free) == 0ull) {
+                n0 = n1 = 0x07070707u;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                if (__ballot(c != XM_NO_UNIT) == 0ull) {              // wave-uniform: nobody has a unit here
-                    if (j < 8) n0 |= 7u << (4 * j); else n1 |= 7u << (4 * (j - 8));
-                    continue;
+                for (int j = 1; j < 16; j += 2) {
+                    const uint32_t b = bin_of_byte<MODE>((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                    if (j < 8) n0 |= b << (4 * j); else n1 |= b << (4 * (j - 8));
+                    cnt += 1ull << bin_shift(b);
                 }
-                const uint32_t b = bin_of_byte<MODE>(c);
-                if (j < 8) n0 |= b << (4 * j); else n1 |= b << (4 * (j - 8));
-                cnt += 1ull << bin_shift(b);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                    if (__ballot(c != XM_NO_UNIT) == 0ull) {          // wave-uniform: nobody has a unit here
+                        if (j < 8) n0 |= 7u << (4 * j); else n1 |= 7u << (4 * (j - 8));
+                        continue;
+                    }
+                    const uint32_t b = bin_of_byte<MODE>(c);
+                    if (j < 8) n0 |= b << (4 * j); else n1 |= b << (4 * (j - 8));
+                    cnt += 1ull << bin_shift(b);
+                }
             }
             tile_state[k][t] = make_uint4(n0, n1, (uint32_t)cnt, (uint32_t)(cnt >> 32));
 #pragma unroll
@@ -503,16 +516,29 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
                                | (uint64_t)(lstart[0] | (lstart[1] << 10) | (lstart[2] << 20)));
         const uint32_t tile0 = (uint32_t)(span0 + (uint64_t)k * XM_WTILE);
         const uint32_t rec0 = tile0 + lane * 16u;
+        const bool even_free2 = ((nib0 & nib1) & 0x0F0F0F0Fu) == 0x07070707u;
+        if (__ballot(!even_free2) == 0ull) {                          // interleaved mates: odd positions only
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t b = ((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u;
-            const bool valid = b < 6u;
-            if (__ballot(valid) == 0ull) continue;                    // wave-uniform
-            const uint32_t sh = bin_shift(b);
-            const uint32_t p = (uint32_t)(pos >> sh) & 0x3FFu;
-            if (ABL < 2) { if (valid) slab[p] = (uint16_t)(lane * 16u + (uint32_t)j); }
-            else asm volatile("" :: "v"(p));
-            pos += 1ull << sh;                                        // bins 6, 7 land in the sink
+            for (int j = 1; j < 16; j += 2) {
+                const uint32_t b = ((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u;
+                const uint32_t sh = bin_shift(b);
+                const uint32_t p = (uint32_t)(pos >> sh) & 0x3FFu;
+                if (ABL < 2) { if (b < 6u) slab[p] = (uint16_t)(lane * 16u + (uint32_t)j); }
+                else asm volatile("" :: "v"(p));
+                pos += 1ull << sh;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t b = ((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u;
+                const bool valid = b < 6u;
+                if (__ballot(valid) == 0ull) continue;                // wave-uniform
+                const uint32_t sh = bin_shift(b);
+                const uint32_t p = (uint32_t)(pos >> sh) & 0x3FFu;
+                if (ABL < 2) { if (valid) slab[p] = (uint16_t)(lane * 16u + (uint32_t)j); }
+                else asm volatile("" :: "v"(p));
+                pos += 1ull << sh;                                    // bins 6, 7 land in the sink
+            }
         }
         // each bin's run, contiguous in LDS and contiguous in idx_out
 #pragma unroll
@@ -526,6 +552,20 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stri
                 for (uint32_t e = lane; e < tcnt[b]; e += 64u) asm volatile("" :: "v"((uint32_t)slab[lstart[b] + e]));
             } else if (ABL == 3) {
                 for (uint32_t e = lane; e < tcnt[b]; e += 64u) idx_out[gbase[b] + e] = tile0 + (uint32_t)slab[lstart[b] + e];
+            } else if (ABL == 5) {
+                // whole 128-byte lines of the run stream out non-temporally; the ragged head and tail (which a
+                // neighbouring run completes later) go through the cache so that the halves can merge there
+                const uint32_t g0 = gbase[b], g1 = g0 + tcnt[b];
+                const uint32_t a0 = (g0 + 31u) & ~31u, a1 = g1 & ~31u;
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u) {
+                    const uint32_t g = g0 + e, v = tile0 + (uint32_t)slab[lstart[b] + e];
+                    if (g >= a0 && g < a1) __builtin_nontemporal_store(v, idx_out + g);
+                    else idx_out[g] = v;
+                }
+            } else if (ABL == 4) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u)
+                    __hip_atomic_store(idx_out + gbase[b] + e, tile0 + (uint32_t)slab[lstart[b] + e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
             gbase[b] += tcnt[b];
         }
