@@ -93,13 +93,36 @@ void index_lines(const char *buf, uint64_t len, bool eof, int n_threads, FilePar
     });
     fp.non_ascii = false;
     for (char b : bad) fp.non_ascii |= (b != 0);
-    fp.lines.clear();
-    uint64_t start = 0;
-    for (auto &v : found)
-        for (auto &pr : v) {
-            fp.lines.push_back(Line{start, (uint32_t)(pr.first - start)});
-            start = pr.second;
+    // line k starts where terminator k-1 ends: per-chunk prefix of the terminator counts, then a parallel fill
+    std::vector<uint64_t> base(found.size() + 1, 0);
+    for (size_t t = 0; t < found.size(); ++t) base[t + 1] = base[t] + found[t].size();
+    fp.lines.resize((size_t)base.back());
+    std::vector<uint64_t> first_start(found.size(), 0);               // start of the first line ending in chunk t
+    {
+        uint64_t start = 0;
+        for (size_t t = 0; t < found.size(); ++t) {
+            first_start[t] = start;
+            if (!found[t].empty()) start = found[t].back().second;
         }
+    }
+    {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < found.size(); ++t) {
+            if (found[t].empty()) continue;
+            pool.emplace_back([&, t]() {
+                uint64_t start = first_start[t];
+                Line *dst = fp.lines.data() + base[t];
+                for (auto &pr : found[t]) {
+                    *dst++ = Line{start, (uint32_t)(pr.first - start)};
+                    start = pr.second;
+                }
+            });
+        }
+        for (auto &th : pool) th.join();
+    }
+    uint64_t start = 0;
+    for (size_t t = found.size(); t-- > 0;)
+        if (!found[t].empty()) { start = found[t].back().second; break; }
     fp.complete_end = start;
     if (eof && start < len) {                                        // last line without a terminator
         fp.lines.push_back(Line{start, (uint32_t)(len - start)});
@@ -314,7 +337,31 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
         uint64_t i1 = 0, i2 = 0;
         int ended = 0, starved = 0;
         int64_t mismatch = -1;
-        while (p->sel[0].size() < max_records) {
+        if (!skip_repeated) {
+            // record k is line k of both files: the walk stops at the first k that is blank in either file or
+            // whose names differ -- found in parallel
+            const uint64_t lim = std::min<uint64_t>(std::min(L[0], L[1]), max_records);
+            std::vector<uint64_t> stop((size_t)std::max(1, p->n_threads), lim);
+            parallel_for(p->n_threads, lim, [&](int t, uint64_t b, uint64_t e) {
+                for (uint64_t k = b; k < e; ++k)
+                    if (blank(0, k) || blank(1, k) || !same_name(buf1, p->f[0], k, buf2, p->f[1], k)) { stop[(size_t)t] = k; break; }
+            });
+            uint64_t k_stop = lim;
+            for (uint64_t v : stop) k_stop = std::min(k_stop, v);
+            p->sel[0].resize((size_t)k_stop);
+            p->sel[1].resize((size_t)k_stop);
+            parallel_for(p->n_threads, k_stop, [&](int, uint64_t b, uint64_t e) {
+                for (uint64_t k = b; k < e; ++k) p->sel[0][(size_t)k] = p->sel[1][(size_t)k] = k;
+            });
+            i1 = i2 = k_stop;
+            if (k_stop < lim) {
+                if (blank(0, k_stop) || blank(1, k_stop)) ended = 1; else mismatch = (int64_t)k_stop;
+            } else if (k_stop < max_records) {
+                const bool end1 = i1 >= L[0] && whole[0], end2 = i2 >= L[1] && whole[1];
+                if (end1 || end2) ended = 1; else starved = 1;
+            }
+        }
+        while (skip_repeated && p->sel[0].size() < max_records) {
             if (i1 >= L[0] || i2 >= L[1]) {
                 const bool end1 = i1 >= L[0] && whole[0], end2 = i2 >= L[1] && whole[1];
                 if (end1 || end2) ended = 1; else starved = 1;
@@ -393,21 +440,32 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
         }
         // ---- unit mask (xenomapper.py:402: name equals the previous record's name) -------------------
         p->bits.assign((n + 63) / 64 + 1, 0);
-        if (paired) {
-            for (uint64_t k = 1; k < n; ++k)
-                if (same_name(buf1, p->f[0], p->sel[0][k], buf1, p->f[0], p->sel[0][k - 1]))
-                    p->bits[k >> 6] |= 1ull << (k & 63);
-        } else {
-            for (uint64_t k = 0; k < n; ++k) p->bits[k >> 6] |= 1ull << (k & 63);
-        }
+        parallel_for(p->n_threads, (n + 63) / 64, [&](int, uint64_t wb, uint64_t we) {
+            for (uint64_t w = wb; w < we; ++w) {
+                uint64_t word = 0;
+                const uint64_t k0 = w * 64, k1 = std::min<uint64_t>(n, k0 + 64);
+                for (uint64_t k = k0; k < k1; ++k) {
+                    const bool unit = !paired || (k > 0 && same_name(buf1, p->f[0], p->sel[0][k], buf1, p->f[0], p->sel[0][k - 1]));
+                    word |= (uint64_t)unit << (k & 63);
+                }
+                p->bits[w] = word;
+            }
+        });
         // ---- exceptions ---------------------------------------------------------------------------------
         p->exc_record.clear(); p->exc_col.clear(); p->exc_kind.clear();
-        for (uint64_t k = 0; k < n; ++k) {
-            for (int f = 0; f < 2; ++f) {
-                const Rec &r = p->f[f].recs[p->sel[f][k]];
-                if (r.ex_a) { p->exc_record.push_back((uint32_t)k); p->exc_col.push_back((uint8_t)(2 * f)); p->exc_kind.push_back(r.ex_a); }
-                if (r.ex_x) { p->exc_record.push_back((uint32_t)k); p->exc_col.push_back((uint8_t)(2 * f + 1)); p->exc_kind.push_back(r.ex_x); }
-            }
+        {
+            struct Exc { uint32_t rec; uint8_t col, kind; };
+            std::vector<std::vector<Exc>> part((size_t)std::max(1, p->n_threads));
+            parallel_for(p->n_threads, n, [&](int t, uint64_t b, uint64_t e) {
+                for (uint64_t k = b; k < e; ++k)
+                    for (int f = 0; f < 2; ++f) {
+                        const Rec &r = p->f[f].recs[p->sel[f][k]];
+                        if (r.ex_a) part[(size_t)t].push_back(Exc{(uint32_t)k, (uint8_t)(2 * f), r.ex_a});
+                        if (r.ex_x) part[(size_t)t].push_back(Exc{(uint32_t)k, (uint8_t)(2 * f + 1), r.ex_x});
+                    }
+            });
+            for (auto &v : part)
+                for (auto &x : v) { p->exc_record.push_back(x.rec); p->exc_col.push_back(x.col); p->exc_kind.push_back(x.kind); }
         }
         out->n_records = n;
         out->ended = ended;

@@ -517,7 +517,7 @@ def _run(mode, readpairs, sinks, min_score, tag_func):
 # --------------------------------------------------------------------------------------------
 # file-to-file fast path: C++ column stripper -> GPU -> C++ line writer
 # --------------------------------------------------------------------------------------------
-FILE_WINDOW_BYTES = 48 << 20          # bytes of each SAM file parsed per block
+FILE_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_WINDOW_MB", "128")) << 20     # bytes of each file parsed per block
 FILE_MAX_RECORDS = 1 << 22
 
 
@@ -650,20 +650,27 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                                                        else _host.SCORE_AS_XS)
     sources = [(_BamSource(path, n_threads) if bam else _SamSource(path)) for path in (path1, path2)]
     parser = _host.Parser(n_threads)
+    import time as _time
+    prof = {"window": 0.0, "parse": 0.0, "classify": 0.0, "compact": 0.0, "emit": 0.0, "write": 0.0, "other": 0.0}
+    t_all = _time.perf_counter()
     totals, key_order = Counter(), []
     window = FILE_WINDOW_BYTES
     active = [s for s in sinks if s]
     distinct = len(set(id(s) for s in active)) == len(active)
     try:
         while True:
+            _t = _time.perf_counter()
             wins = [src.window(window) for src in sources]
+            prof["window"] += _time.perf_counter() - _t
             raws = [w[0] for w in wins]
             pos = [w[1] for w in wins]
             lens = [w[2] for w in wins]
             eofs = [w[3] for w in wins]
             try:
+                _t = _time.perf_counter()
                 block = parser.parse(raws[0], pos[0], lens[0], eofs[0], raws[1], pos[1], lens[1], eofs[1], score_mode,
                                      paired, skip_repeated, paired, FILE_MAX_RECORDS)
+                prof["parse"] += _time.perf_counter() - _t
             except _host.NonAsciiInput:
                 if bam:
                     raise ValueError("non-ASCII bytes in BAM text fields are not supported")
@@ -686,8 +693,12 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             if err is not None:
                 n, pending = bad, err                                # units closing at index >= bad are not reached
             if n:
+                _t = _time.perf_counter()
                 code, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
+                prof["classify"] += _time.perf_counter() - _t
+                _t = _time.perf_counter()
                 idx, off, _ = ctx.compact(mode, code)
+                prof["compact"] += _time.perf_counter() - _t
                 limit, state_error = None, None
                 if int(off[7]) != int(off[6]):
                     limit = int(idx[int(off[6]):int(off[7])].min())
@@ -698,7 +709,12 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         seg = idx[int(off[b]):int(off[b + 1])]
                         if limit is not None:
                             seg = seg[seg < limit]
-                        _write_bytes(sinks[b], parser.emit(paired, b, seg))
+                        _t = _time.perf_counter()
+                        text = parser.emit(paired, b, seg)
+                        prof["emit"] += _time.perf_counter() - _t
+                        _t = _time.perf_counter()
+                        _write_bytes(sinks[b], text)
+                        prof["write"] += _time.perf_counter() - _t
                 if not distinct:
                     _emit_shared(parser, paired, code, idx, off, sinks, limit)
                 if state_error is not None:
@@ -720,6 +736,10 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         parser.close()
         for src in sources:
             src.close()
+        if os.environ.get("XENOMAPPER_PROFILE"):
+            total = _time.perf_counter() - t_all
+            prof["other"] = total - sum(prof.values())
+            print("xenomapper file path: %.3f s  " % total + "  ".join("%s %.3f" % kv for kv in prof.items()), file=sys.stderr)
     ordered = Counter()
     for key in key_order:
         ordered[key] = totals[key]
