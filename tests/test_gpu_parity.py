@@ -390,3 +390,35 @@ def test_full_size_cfg5_zs_conservative(ctx):
         h_off = off.cpu().numpy().astype(np.uint64)
         assert np.array_equal(h_off, want_off)
         assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)
+
+
+def test_large_batch_64bit_offsets(ctx):
+    """300 M records per species (column byte offsets beyond 2^32, record indices beyond 2^28), ragged tail;
+    exact against the C oracle."""
+    import torch
+    from xenomapper_amd import _ffi
+    n_pairs = 150_000_001
+    n = 2 * n_pairs
+    dev = torch.device("cuda:0")
+    cols = H.synth.score_columns_torch(n_pairs, seed=77, device=dev)
+    # break the strict interleave in a few places, also far beyond 2^31 bytes into the columns
+    bits = cols["unit_bits"].clone()
+    for word in (5, 1_000_003, (n // 64) - 2):
+        bits[word] = 0x0F0F00FF00FF0F0F
+    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    mode = _ffi.MODE_PE_CONSERVATIVE
+    ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], bits, 100, code)
+    ctx.compact_dev(mode, code[:n], idx, off, counts)
+    torch.cuda.synchronize()
+    host = {k: v.cpu().numpy() for k, v in cols.items()}
+    h_bits = bits.cpu().numpy().view(np.uint64)
+    want, want_counts = H.c_classify(mode, host["as1"], host["xs1"], host["as2"], host["xs2"], h_bits, 100)
+    assert np.array_equal(code[:n].cpu().numpy(), want)
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+    want_idx, want_off = H.c_compact(mode, want)
+    h_off = off.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(h_off, want_off)
+    assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)

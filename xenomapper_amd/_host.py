@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libxenomapper_host.so")
+LIB_PATH = os.environ.get("XENOMAPPER_HOST_LIB") or os.path.join(PKG, "libxenomapper_host.so")   # override: sanitizer builds
 
 SCORE_AS_XS, SCORE_AS_ZS, SCORE_CIGAR = 0, 1, 2
 EX_NONINT, EX_DUP, EX_SHORT, EX_BIGLEN = 1, 2, 3, 4

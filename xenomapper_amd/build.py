@@ -61,6 +61,17 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+def build_host_sanitized(out_path, verbose=False):
+    """ASan + UBSan build of the host library, for CPU-side test runs (GPU ASan is not available on the pool)."""
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fsanitize=address,undefined",
+           "-fno-omit-frame-pointer", "-I", os.path.join(REPO, "include")] + srcs + ["-o", out_path, "-lz"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out_path
+
+
 def build_oracle(verbose=False):
     """The C oracle is test infrastructure; building it here is not using it."""
     subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s"])
