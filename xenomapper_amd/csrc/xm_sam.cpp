@@ -10,6 +10,9 @@
 #include "../../include/xenomapper_host.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -42,10 +45,18 @@ struct Rec {                  // what the parser learnt about one line
     uint32_t worker;
 };
 
+// per-worker scratch, kept across calls (fresh multi-megabyte vectors would be re-mapped and page-faulted on every
+// window) and padded to its own cache lines (neighbouring vector headers would false-share on every push_back)
+struct alignas(128) WorkerSlot {
+    std::vector<std::pair<uint64_t, uint64_t>> ends;   // (terminator offset, next line start)
+    std::vector<uint32_t> ops;                         // packed CIGAR operations
+    bool non_ascii = false;
+};
+
 struct FileParse {
     std::vector<Line> lines;
     std::vector<Rec> recs;
-    std::vector<std::vector<uint32_t>> ops;   // per worker
+    std::vector<WorkerSlot> slots;            // one per worker
     uint64_t complete_end = 0;                // offset just past the last complete line
     bool non_ascii = false;
 };
@@ -73,10 +84,10 @@ void index_lines(const char *buf, uint64_t len, bool eof, int n_threads, FilePar
     // a trailing '\r' might be the first half of "\r\n" continuing in the next window
     uint64_t usable = len;
     if (!eof && len > 0 && buf[len - 1] == '\r') usable = len - 1;
-    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> found(std::max(1, n_threads));   // (end, next start)
-    std::vector<char> bad(std::max(1, n_threads), 0);
+    if (fp.slots.size() < (size_t)std::max(1, n_threads)) fp.slots.resize((size_t)std::max(1, n_threads));
+    for (auto &sl : fp.slots) { sl.ends.clear(); sl.non_ascii = false; }
     parallel_for(n_threads, usable, [&](int t, uint64_t b, uint64_t e) {
-        auto &v = found[t];
+        auto &v = fp.slots[(size_t)t].ends;
         bool hi = false;
         for (uint64_t p = b; p < e; ++p) {
             const unsigned char c = (unsigned char)buf[p];
@@ -89,40 +100,36 @@ void index_lines(const char *buf, uint64_t len, bool eof, int n_threads, FilePar
                 v.emplace_back(p, p + (crlf ? 2 : 1));
             }
         }
-        bad[t] = hi;
+        fp.slots[(size_t)t].non_ascii = hi;
     });
     fp.non_ascii = false;
-    for (char b : bad) fp.non_ascii |= (b != 0);
+    for (auto &sl : fp.slots) fp.non_ascii |= sl.non_ascii;
     // line k starts where terminator k-1 ends: per-chunk prefix of the terminator counts, then a parallel fill
-    std::vector<uint64_t> base(found.size() + 1, 0);
-    for (size_t t = 0; t < found.size(); ++t) base[t + 1] = base[t] + found[t].size();
+    const size_t n_slots = fp.slots.size();
+    std::vector<uint64_t> base(n_slots + 1, 0);
+    for (size_t t = 0; t < n_slots; ++t) base[t + 1] = base[t] + fp.slots[t].ends.size();
     fp.lines.resize((size_t)base.back());
-    std::vector<uint64_t> first_start(found.size(), 0);               // start of the first line ending in chunk t
-    {
-        uint64_t start = 0;
-        for (size_t t = 0; t < found.size(); ++t) {
-            first_start[t] = start;
-            if (!found[t].empty()) start = found[t].back().second;
-        }
+    std::vector<uint64_t> first_start(n_slots, 0);                    // start of the first line ending in chunk t
+    uint64_t start = 0;
+    for (size_t t = 0; t < n_slots; ++t) {
+        first_start[t] = start;
+        if (!fp.slots[t].ends.empty()) start = fp.slots[t].ends.back().second;
     }
     {
         std::vector<std::thread> pool;
-        for (size_t t = 0; t < found.size(); ++t) {
-            if (found[t].empty()) continue;
+        for (size_t t = 0; t < n_slots; ++t) {
+            if (fp.slots[t].ends.empty()) continue;
             pool.emplace_back([&, t]() {
-                uint64_t start = first_start[t];
+                uint64_t st = first_start[t];
                 Line *dst = fp.lines.data() + base[t];
-                for (auto &pr : found[t]) {
-                    *dst++ = Line{start, (uint32_t)(pr.first - start)};
-                    start = pr.second;
+                for (auto &pr : fp.slots[t].ends) {
+                    *dst++ = Line{st, (uint32_t)(pr.first - st)};
+                    st = pr.second;
                 }
             });
         }
         for (auto &th : pool) th.join();
     }
-    uint64_t start = 0;
-    for (size_t t = found.size(); t-- > 0;)
-        if (!found[t].empty()) { start = found[t].back().second; break; }
     fp.complete_end = start;
     if (eof && start < len) {                                        // last line without a terminator
         fp.lines.push_back(Line{start, (uint32_t)(len - start)});
@@ -250,9 +257,10 @@ void parse_file(const char *buf, int score_mode, int n_threads, FileParse &fp)
 {
     const uint64_t n = fp.lines.size();
     fp.recs.resize(n);
-    fp.ops.assign(std::max(1, n_threads), std::vector<uint32_t>());
+    if (fp.slots.size() < (size_t)std::max(1, n_threads)) fp.slots.resize((size_t)std::max(1, n_threads));
+    for (auto &sl : fp.slots) sl.ops.clear();
     parallel_for(n_threads, n, [&](int t, uint64_t b, uint64_t e) {
-        auto &ops = fp.ops[t];
+        auto &ops = fp.slots[(size_t)t].ops;
         for (uint64_t i = b; i < e; ++i)
             parse_line(buf + fp.lines[i].off, fp.lines[i].len, score_mode, (uint32_t)t, ops, fp.recs[i]);
     });
@@ -318,6 +326,12 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
     if (!p || !out || (!buf1 && len1) || (!buf2 && len2) || score_mode < 0 || score_mode > 2)
         return XMH_ERR_INVALID_ARG;
     try {
+        static const bool profile = getenv("XMH_PROFILE") != nullptr;
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        const auto t0 = now();
         const char *buf[2] = {buf1, buf2};
         const uint64_t len[2] = {len1, len2};
         const int eof[2] = {eof1, eof2};
@@ -325,7 +339,9 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
             index_lines(buf[f], len[f], eof[f] != 0, p->n_threads, p->f[f]);
             if (p->f[f].non_ascii) return XMH_ERR_NON_ASCII;
         }
+        const auto t1 = now();
         for (int f = 0; f < 2; ++f) parse_file(buf[f], score_mode, p->n_threads, p->f[f]);
+        const auto t2 = now();
 
         // ---- the lock-step walk (xenomapper.py:103-117) ------------------------------------------------
         const uint64_t L[2] = {p->f[0].lines.size(), p->f[1].lines.size()};
@@ -430,7 +446,7 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
                     for (uint64_t k = b; k < e; ++k) {
                         const Rec &r = fp.recs[sel[k]];
                         if (r.ops_count)
-                            memcpy(opsv[f]->data() + (*offs[f])[k], fp.ops[r.worker].data() + r.ops_begin,
+                            memcpy(opsv[f]->data() + (*offs[f])[k], fp.slots[r.worker].ops.data() + r.ops_begin,
                                    (size_t)r.ops_count * 4);
                     }
                 });
@@ -467,6 +483,9 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
             for (auto &v : part)
                 for (auto &x : v) { p->exc_record.push_back(x.rec); p->exc_col.push_back(x.col); p->exc_kind.push_back(x.kind); }
         }
+        if (profile)
+            fprintf(stderr, "xmh_parse: %.1f MB  index %.1f ms  parse %.1f ms  walk+gather %.1f ms\n",
+                    (double)(len1 + len2) / 1e6, ms(t0, t1), ms(t1, t2), ms(t2, now()));
         out->n_records = n;
         out->ended = ended;
         out->starved = starved;

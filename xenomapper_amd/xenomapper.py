@@ -649,39 +649,58 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     score_mode = _host.SCORE_CIGAR if cigar_mode else (_host.SCORE_AS_ZS if tag_func is get_tag_with_ZS_as_XS
                                                        else _host.SCORE_AS_XS)
     sources = [(_BamSource(path, n_threads) if bam else _SamSource(path)) for path in (path1, path2)]
-    parser = _host.Parser(n_threads)
+    # SAM input: two parsers alternate so that the next window is parsed (in a helper thread; the C++ code runs
+    # without the GIL) while the GPU classifies and the writer emits the current one.  BAM input decodes into a
+    # sliding buffer that the next window() call may move, so it stays sequential.
+    parsers = [_host.Parser(n_threads)] if bam else [_host.Parser(n_threads), _host.Parser(n_threads)]
     import time as _time
+    from concurrent.futures import ThreadPoolExecutor
+    pool = None if bam else ThreadPoolExecutor(max_workers=1)
     prof = {"window": 0.0, "parse": 0.0, "classify": 0.0, "compact": 0.0, "emit": 0.0, "write": 0.0, "other": 0.0}
     t_all = _time.perf_counter()
     totals, key_order = Counter(), []
     window = FILE_WINDOW_BYTES
     active = [s for s in sinks if s]
     distinct = len(set(id(s) for s in active)) == len(active)
+
+    def parse_next(which, want):
+        _t = _time.perf_counter()
+        wins = [src.window(want) for src in sources]
+        prof["window"] += _time.perf_counter() - _t
+        _t = _time.perf_counter()
+        blk = parsers[which].parse(wins[0][0], wins[0][1], wins[0][2], wins[0][3], wins[1][0], wins[1][1], wins[1][2],
+                                   wins[1][3], score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
+        prof["parse"] += _time.perf_counter() - _t
+        return blk, [w[0] for w in wins], [w[1] for w in wins], [w[3] for w in wins]
+
+    which = 0
+    future = None
     try:
         while True:
-            _t = _time.perf_counter()
-            wins = [src.window(window) for src in sources]
-            prof["window"] += _time.perf_counter() - _t
-            raws = [w[0] for w in wins]
-            pos = [w[1] for w in wins]
-            lens = [w[2] for w in wins]
-            eofs = [w[3] for w in wins]
             try:
-                _t = _time.perf_counter()
-                block = parser.parse(raws[0], pos[0], lens[0], eofs[0], raws[1], pos[1], lens[1], eofs[1], score_mode,
-                                     paired, skip_repeated, paired, FILE_MAX_RECORDS)
-                prof["parse"] += _time.perf_counter() - _t
+                if future is not None:
+                    parsed, future = future.result(), None
+                else:
+                    parsed = parse_next(which, window)
             except _host.NonAsciiInput:
                 if bam:
                     raise ValueError("non-ASCII bytes in BAM text fields are not supported")
-                return _finish_in_python(mode, path1, path2, pos, sinks, min_score, tag_func, skip_repeated,
-                                         totals, key_order)
+                return _finish_in_python(mode, path1, path2, [src.pos for src in sources], sinks, min_score, tag_func,
+                                         skip_repeated, totals, key_order)
+            block, raws, pos, eofs = parsed
+            parser = parsers[which]
             n = block.n
             progressed = block.consumed[0] > 0 or block.consumed[1] > 0
             if block.starved and not progressed and not (eofs[0] and eofs[1]):
                 window *= 2                                      # a line (or run of equal names) longer than the window
                 continue
             pending = AssertionError() if block.mismatch_at >= 0 else None
+            last = block.ended or pending is not None or (eofs[0] and eofs[1] and not progressed)
+            if not last:
+                for f in (0, 1):
+                    sources[f].advance(block.consumed[f])
+                if pool is not None:                             # parse the next window while this one is classified
+                    future = pool.submit(parse_next, which ^ 1, window)
             flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:n].astype(bool)
             if paired:
                 needed = flags.copy()
@@ -728,12 +747,20 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     totals[key] += int(counts[c])
             if pending is not None:
                 raise pending
-            if block.ended or (eofs[0] and eofs[1] and not progressed):
+            if last:
                 break
-            for f in (0, 1):
-                sources[f].advance(block.consumed[f])
+            if pool is not None:
+                which ^= 1
     finally:
-        parser.close()
+        if future is not None:
+            try:
+                future.result()
+            except Exception:
+                pass
+        if pool is not None:
+            pool.shutdown(wait=True)
+        for prs in parsers:
+            prs.close()
         for src in sources:
             src.close()
         if os.environ.get("XENOMAPPER_PROFILE"):
