@@ -79,7 +79,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=50_000_000, help="read pairs per GPU")
-    ap.add_argument("--mode", choices=("liberal", "conservative"), default="liberal")
+    ap.add_argument("--mode", choices=("liberal", "conservative"), default=None)
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
+                    help="BASELINE.json configs[1] (default, the quoted metric), [2] --cigar_scores path, [4] HISAT ZS + conservative")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -116,9 +118,28 @@ def main():
 
     n_pairs = args.pairs
     n = 2 * n_pairs
+    if args.mode is None:
+        args.mode = "conservative" if args.workload == "cfg5" else "liberal"
     mode = _ffi.MODE_PE_LIBERAL if args.mode == "liberal" else _ffi.MODE_PE_CONSERVATIVE
     ctx = _ffi.Context(local_rank)
-    cols = synth.score_columns_torch(n_pairs, seed=2002 + rank, device=dev)       # each rank: its own read block
+    bytes_per_pair = BYTES_PER_PAIR_CLASSIFY
+    cig = None
+    if args.workload == "cfg3":
+        # no AS tag: AS is synthesised in-kernel from NM + CIGAR (CSR); XS mostly absent
+        cig = [synth.cigar_columns_torch(n, seed=3003 + 2 * rank, device=dev),
+               synth.cigar_columns_torch(n, seed=3004 + 2 * rank, device=dev, mapped_p=0.3)]
+        g = torch.Generator(device=dev)
+        g.manual_seed(3005 + rank)
+        xs1 = torch.where(torch.rand(n, generator=g, device=dev) < 0.95, torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
+                          -torch.randint(0, 40, (n,), generator=g, device=dev, dtype=torch.int32))
+        cols = {"xs1": xs1, "xs2": torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
+                "unit_bits": torch.from_numpy(synth.interleaved_unit_bits(n).view(np.int64)).to(dev)}
+        k_bar = (cig[0]["cig_oplen"].numel() + cig[1]["cig_oplen"].numel()) / (2.0 * n)
+        bytes_per_pair = 4 * (12 + 4 * k_bar) + 1            # per record and species NM + XS + offset + ops
+        range_flag = torch.zeros(4, dtype=torch.int32, device=dev)
+    else:
+        cols = synth.score_columns_torch(n_pairs, seed=(2002 if args.workload == "cfg2" else 5005) + rank, device=dev,
+                                         profile="hisat" if args.workload == "cfg5" else "bowtie2")   # own read block per rank
     code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     off = torch.zeros(8, dtype=torch.int64, device=dev)
@@ -127,8 +148,13 @@ def main():
     floor_min = _ffi.ABSENT                                                       # min_score = -inf
 
     def step():
-        ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"],
-                         floor_min, code)
+        if cig is not None:
+            ctx.classify_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
+                                   cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"], cols["unit_bits"],
+                                   floor_min, code, range_flag=range_flag)
+        else:
+            ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"],
+                             floor_min, code)
         ctx.compact_dev(mode, code[:n], idx, off, counts)
         job_counts.add_(counts)                                  # category_counts of the job so far
 
@@ -180,6 +206,11 @@ def main():
         from tests import helpers as H
         host_cols = {k: v.cpu().numpy() for k, v in cols.items()}
         host_cols["unit_bits"] = host_cols["unit_bits"].view(np.uint64)
+        if cig is not None:
+            for f, key in ((0, "as1"), (1, "as2")):
+                hc = {k: v.cpu().numpy() for k, v in cig[f].items()}
+                host_cols[key], bad = H.c_cigar_scores(hc["nm"], hc["cig_off"].view(np.uint32), hc["cig_oplen"].view(np.uint32))
+                assert bad == 0
         want_code, want_counts = H.c_classify(mode, host_cols["as1"], host_cols["xs1"], host_cols["as2"],
                                               host_cols["xs2"], host_cols["unit_bits"], floor_min)
         want_idx, want_off = H.c_compact(mode, want_code)
@@ -197,11 +228,11 @@ def main():
     if rank == 0:
         k_cls = timing["classify"]
         cls_ms = k_cls["ms"] / max(1, k_cls["launches"])
-        achieved = BYTES_PER_PAIR_CLASSIFY * n_pairs / (cls_ms * 1e-3) / 1e9
+        achieved = bytes_per_pair * n_pairs / (cls_ms * 1e-3) / 1e9
         kernels = {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in timing_all.items() if v["launches"]}
         traffic = None
         pmc_file = os.path.join(REPO, "profiles", "pmc_classify.json")
-        if os.path.exists(pmc_file):
+        if os.path.exists(pmc_file) and args.workload == "cfg2" and n_pairs == 50_000_000:
             try:
                 traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
             except Exception:
@@ -214,20 +245,25 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
-            "config": {"workload": "configs[1]: %d paired-end 2x150 bp read pairs per GPU, AS/XS present, %s "
-                                   "pair rule, min_score=-inf, score columns resident in HBM" % (n_pairs, args.mode),
+            "config": {"workload": {"cfg2": "configs[1]: %d paired-end 2x150 bp read pairs per GPU, AS/XS present, %s "
+                                           "pair rule, min_score=-inf, score columns resident in HBM",
+                                    "cfg3": "configs[2]: %d paired-end pairs per GPU on the --cigar_scores path (no AS/XS; NM + "
+                                            "CIGAR as CSR, AS synthesised in the classify kernel), %s pair rule, columns resident in HBM",
+                                    "cfg5": "configs[4]: %d paired-end pairs per GPU, HISAT-style scores with ZS as second-best "
+                                            "(AS=0/ZS=0 present), %s pair rule, columns resident in HBM"}[args.workload]
+                                   % (n_pairs, args.mode),
                        "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": n,
                        "sharding": "read-block per GPU, no halo exchange" + (", one RCCL all-reduce of the final category_counts" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "classify_kernel<int32, paired>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "algorithmic_bytes_per_pair": BYTES_PER_PAIR_CLASSIFY,
-                         "kernel_ms": cls_ms},
+            "roofline": {"bound": "hbm",
+                         "kernel": "classify_cigar_kernel<paired>" if cig is not None else "classify_kernel<int32, paired>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "algorithmic_bytes_per_pair": bytes_per_pair, "kernel_ms": cls_ms},
             "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region",
             "verified_vs_oracle": verified,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_python()
-            if host_cols is not None:
+            if host_cols is not None and cig is None:
                 m = min(n_pairs, 5_000_000)
                 sub = {k: np.ascontiguousarray(v[:2 * m]) for k, v in host_cols.items() if k != "unit_bits"}
                 sub["unit_bits"] = np.ascontiguousarray(host_cols["unit_bits"][:(2 * m + 63) // 64])

@@ -71,11 +71,12 @@ template <typename T> __device__ __forceinline__ T absent_value();
 template <> __device__ __forceinline__ int32_t absent_value<int32_t>() { return INT32_MIN; }
 template <> __device__ __forceinline__ double  absent_value<double>()  { return -__builtin_huge_val(); }
 
-template <typename T, bool NT>
+// FULL: the caller knows (workgroup-uniformly) that all 4 records exist, so no bounds test is compiled in
+template <typename T, bool NT, bool FULL = false>
 __device__ __forceinline__ void load4(const T *__restrict__ col, uint64_t r0, uint64_t n, T out[4])
 {
     typedef typename Vec4<T>::type V;
-    if (r0 + 4 <= n) {
+    if (FULL || r0 + 4 <= n) {
         const V *p = reinterpret_cast<const V *>(col + r0);
         const V v = NT ? __builtin_nontemporal_load(p) : *p;
         out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
@@ -87,7 +88,7 @@ __device__ __forceinline__ void load4(const T *__restrict__ col, uint64_t r0, ui
 
 // Shared K1 epilogue: 4 states per lane -> forward mate's state (lane-1 / previous wave via LDS / halo) ->
 // 4 category bytes -> one 4-byte store.
-template <typename T, bool PAIRED, int BLOCK>
+template <typename T, bool PAIRED, int BLOCK, bool FULL>
 __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], const T a2[4], const T x2[4], T m,
                                                 uint32_t mb, uint32_t halo, uint32_t *last_state,
                                                 uint8_t *__restrict__ code, uint64_t r0, uint64_t n)
@@ -113,7 +114,7 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
         for (int j = 0; j < 4; ++j) c[j] = ((mb >> j) & 1u) ? s[j] : XM_NO_UNIT;
     }
 
-    if (r0 + 4 <= n) {
+    if (FULL || r0 + 4 <= n) {
         *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
     } else {
 #pragma unroll
@@ -132,6 +133,37 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
 // NT: the score columns are read once and never again, so they are loaded non-temporally; the
 // category bytes are stored with the default policy because K2 reads them next (100 MB at the
 // 50 M-pair configuration, which fits the 256 MiB Infinity Cache).
+template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL>
+__device__ __forceinline__ void classify_body(const T *__restrict__ as1, const T *__restrict__ xs1,
+                                              const T *__restrict__ as2, const T *__restrict__ xs2,
+                                              const uint8_t *__restrict__ unit_bits8, T m,
+                                              uint8_t *__restrict__ code, uint64_t n, uint32_t *last_state)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
+    const uint64_t r0 = g * 4;
+
+    T a1[4], x1[4], a2[4], x2[4];
+    load4<T, NT, FULL>(as1, r0, n, a1);
+    load4<T, NT, FULL>(xs1, r0, n, x1);
+    load4<T, NT, FULL>(as2, r0, n, a2);
+    load4<T, NT, FULL>(xs2, r0, n, x2);
+    uint32_t mb = 0;
+    if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+    if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+
+    // the record in front of the workgroup's range (thread 0 only)
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 > 0) {
+            const uint64_t h = r0 - 1;                         // thread 0's r0 < n (grid sizing), so h < n
+            halo = mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m);
+        } else {
+            mb &= ~1u;                                         // record 0 has no predecessor (:402)
+        }
+    }
+    classify_finish<T, PAIRED, BLOCK, FULL>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
+}
+
 template <typename T, bool PAIRED, bool NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
@@ -140,30 +172,11 @@ classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
                 uint8_t *__restrict__ code, uint64_t n)
 {
     __shared__ uint32_t last_state[BLOCK / 64];
-    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
-    const uint64_t r0 = g * 4;
-
-    T a1[4], x1[4], a2[4], x2[4];
-    load4<T, NT>(as1, r0, n, a1);
-    load4<T, NT>(xs1, r0, n, x1);
-    load4<T, NT>(as2, r0, n, a2);
-    load4<T, NT>(xs2, r0, n, x2);
-    uint32_t mb = 0;
-    if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
-    if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
-
-    // the record in front of the workgroup's range (thread 0 only)
-    uint32_t halo = 0;
-    if (PAIRED && threadIdx.x == 0) {
-        if (r0 > 0) {
-            const uint64_t h = r0 - 1;                         // r0 <= n here, so h < n
-            halo = (r0 <= n) ? mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m) : 0u;
-        } else {
-            mb &= ~1u;                                         // record 0 has no predecessor (:402)
-        }
-    }
-
-    classify_finish<T, PAIRED, BLOCK>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
+    // every workgroup but possibly the last covers BLOCK*4 existing records: no bounds tests on that path
+    if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
+        classify_body<T, PAIRED, NT, BLOCK, true>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state);
+    else
+        classify_body<T, PAIRED, NT, BLOCK, false>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,6 +645,15 @@ __device__ __forceinline__ long long cigar_term(uint32_t v)
     return t;
 }
 
+// the same in 32 bits: a packed op carries len < 2^28, so one term is < 2^30 and three of them fit a uint32
+__device__ __forceinline__ uint32_t cigar_term32(uint32_t v)
+{
+    const uint32_t op = v & 15u, len = v >> 4;
+    uint32_t t = (op == 1u || op == 2u) ? (5u + 3u * len) : 0u;
+    t += (op == 4u) ? 2u * len : 0u;
+    return t;
+}
+
 __device__ __forceinline__ int32_t cigar_clamp(long long s, uint32_t *range_flag)
 {
     if (s <= (long long)INT32_MIN || s > (long long)INT32_MAX) {
@@ -652,15 +674,21 @@ __device__ __forceinline__ int32_t cigar_score_one(const int32_t *__restrict__ n
     return cigar_clamp(s, range_flag);
 }
 
-// AS of the lane's 4 records of one species
-__device__ __forceinline__ void cigar_scores4(const int32_t *__restrict__ nm, const uint32_t *__restrict__ off,
-                                              const uint32_t *__restrict__ ops, uint64_t r0, uint64_t n,
-                                              uint32_t *range_flag, int32_t as_out[4])
+struct __attribute__((packed, aligned(4))) Ops3 {
+    uint32_t v[XM_CIG_SPEC];
+};
+
+// AS of the lane's 4 records of one species.  Hot path without divergent branches: the first XM_CIG_SPEC ops of
+// every record come with ONE 12-byte load (reading into the next record's ops is harmless, the surplus is masked)
+// whenever the whole wave stays XM_CIG_SPEC entries clear of the end of the op array (n_ops = cig_off[n]); longer
+// CIGARs and out-of-range scores are handled after wave-uniform tests.  Returns true when a score left int32.
+// Phase A of a species: NM x4 and the five CSR offsets of the lane's 4 records (independent loads).
+template <bool FULL>
+__device__ __forceinline__ void cigar_fetch_offsets(const int32_t *__restrict__ nm, const uint32_t *__restrict__ off,
+                                                    uint64_t r0, uint64_t n, int32_t nmv[4], uint32_t o[5])
 {
-    int32_t nmv[4];
-    load4<int32_t, true>(nm, r0, n, nmv);
-    uint32_t o[5];
-    if (r0 + 4 <= n) {
+    load4<int32_t, true, FULL>(nm, r0, n, nmv);
+    if (FULL || r0 + 4 <= n) {
         const v4i32 q = __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(off + r0));
         o[0] = (uint32_t)q.x; o[1] = (uint32_t)q.y; o[2] = (uint32_t)q.z; o[3] = (uint32_t)q.w;
         o[4] = off[r0 + 4];
@@ -670,21 +698,109 @@ __device__ __forceinline__ void cigar_scores4(const int32_t *__restrict__ nm, co
 #pragma unroll
         for (int j = 1; j < 5; ++j) o[j] = (r0 + j <= n) ? o[j] : o[j - 1];
     }
-    uint32_t v[4][XM_CIG_SPEC];
+}
+
+// Phase B, part 1: the first XM_CIG_SPEC ops of every record with ONE 12-byte load (reading into the next record's
+// ops is harmless, the surplus is masked later) whenever the whole wave stays XM_CIG_SPEC entries clear of the end of
+// the op array (n_ops = cig_off[n]); a wave-uniform test, so the hot path has no divergent branch.
+__device__ __forceinline__ void cigar_fetch_ops(const uint32_t *__restrict__ ops, uint32_t n_ops, const uint32_t o[5],
+                                                uint32_t v[4][XM_CIG_SPEC])
+{
+    if (__ballot(o[3] + XM_CIG_SPEC > n_ops) == 0ull) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const Ops3 t = *reinterpret_cast<const Ops3 *>(ops + o[j]);
+#pragma unroll
+            for (int q = 0; q < XM_CIG_SPEC; ++q) v[j][q] = t.v[q];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < XM_CIG_SPEC; ++q) v[j][q] = (o[j] + (uint32_t)q < o[j + 1]) ? ops[o[j] + q] : 0u;
+    }
+}
+
+// Phase B, part 2: scores.  Longer CIGARs and out-of-range scores are handled after wave-uniform tests.
+// Returns true when a score left int32.
+__device__ __forceinline__ bool cigar_finish_scores(const uint32_t *__restrict__ ops, const int32_t nmv[4], const uint32_t o[5],
+                                                    const uint32_t v[4][XM_CIG_SPEC], int32_t as_out[4])
+{
+    long long s[4];
+    bool longer = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t k = o[j + 1] - o[j];
+        uint32_t acc = 0;
 #pragma unroll
-        for (int q = 0; q < XM_CIG_SPEC; ++q) v[j][q] = ((uint32_t)q < k) ? ops[o[j] + q] : 0u;   // op 0 (M) adds nothing
+        for (int q = 0; q < XM_CIG_SPEC; ++q) acc += ((uint32_t)q < k) ? cigar_term32(v[j][q]) : 0u;
+        s[j] = -6ll * (long long)nmv[j] - (long long)acc;
+        longer |= k > (uint32_t)XM_CIG_SPEC;
     }
+    if (__ballot(longer) != 0ull) {                                    // some record of the wave has more ops
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (uint32_t k = o[j] + XM_CIG_SPEC; k < o[j + 1]; ++k) s[j] -= cigar_term(ops[k]);
+    }
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        long long s = -6ll * (long long)nmv[j];
-#pragma unroll
-        for (int q = 0; q < XM_CIG_SPEC; ++q) s -= cigar_term(v[j][q]);
-        for (uint32_t k = o[j] + XM_CIG_SPEC; k < o[j + 1]; ++k) s -= cigar_term(ops[k]);
-        as_out[j] = (nmv[j] == INT32_MIN) ? INT32_MIN : cigar_clamp(s, range_flag);
+        const bool present = nmv[j] != INT32_MIN;
+        const bool out = present && (s[j] <= (long long)INT32_MIN || s[j] > (long long)INT32_MAX);
+        bad |= out;
+        const long long c = out ? (s[j] < 0 ? (long long)INT32_MIN + 1 : (long long)INT32_MAX) : s[j];
+        as_out[j] = present ? (int32_t)c : INT32_MIN;
     }
+    return bad;
+}
+
+template <bool PAIRED, int BLOCK, bool FULL>
+__device__ __forceinline__ void classify_cigar_body(
+    const int32_t *__restrict__ nm1, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ ops1,
+    const int32_t *__restrict__ xs1,
+    const int32_t *__restrict__ nm2, const uint32_t *__restrict__ off2, const uint32_t *__restrict__ ops2,
+    const int32_t *__restrict__ xs2,
+    const uint8_t *__restrict__ unit_bits8, int32_t m, uint8_t *__restrict__ code, uint64_t n,
+    uint32_t *__restrict__ range_flag, uint32_t *last_state)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t r0 = g * 4;
+
+    int32_t a1[4], x1[4], a2[4], x2[4];
+    load4<int32_t, true, FULL>(xs1, r0, n, x1);
+    load4<int32_t, true, FULL>(xs2, r0, n, x2);
+    uint32_t mb = 0;
+    if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+    if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+    bool bad = false;
+    if (FULL || r0 < n) {
+        // two dependent memory latencies in total: offsets of both species first, then the ops of both
+        int32_t nmv1[4], nmv2[4];
+        uint32_t o1[5], o2[5], v1[4][XM_CIG_SPEC], v2[4][XM_CIG_SPEC];
+        const uint32_t n_ops1 = off1[n], n_ops2 = off2[n];
+        cigar_fetch_offsets<FULL>(nm1, off1, r0, n, nmv1, o1);
+        cigar_fetch_offsets<FULL>(nm2, off2, r0, n, nmv2, o2);
+        cigar_fetch_ops(ops1, n_ops1, o1, v1);
+        cigar_fetch_ops(ops2, n_ops2, o2, v2);
+        bad |= cigar_finish_scores(ops1, nmv1, o1, v1, a1);
+        bad |= cigar_finish_scores(ops2, nmv2, o2, v2, a2);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a1[j] = a2[j] = INT32_MIN;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u && range_flag) atomicOr(range_flag, 1u);
+
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 > 0) {
+            const uint64_t h = r0 - 1;
+            halo = mapping_state<int32_t>(cigar_score_one(nm1, off1, ops1, h, range_flag), xs1[h],
+                                          cigar_score_one(nm2, off2, ops2, h, range_flag), xs2[h], m);
+        } else {
+            mb &= ~1u;
+        }
+    }
+    classify_finish<int32_t, PAIRED, BLOCK, FULL>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
 }
 
 template <bool PAIRED, int BLOCK>
@@ -697,35 +813,12 @@ classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restric
                       uint32_t *__restrict__ range_flag)
 {
     __shared__ uint32_t last_state[BLOCK / 64];
-    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const uint64_t r0 = g * 4;
-
-    int32_t a1[4], x1[4], a2[4], x2[4];
-    load4<int32_t, true>(xs1, r0, n, x1);
-    load4<int32_t, true>(xs2, r0, n, x2);
-    uint32_t mb = 0;
-    if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
-    if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
-    if (r0 < n) {
-        cigar_scores4(nm1, off1, ops1, r0, n, range_flag, a1);
-        cigar_scores4(nm2, off2, ops2, r0, n, range_flag, a2);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a1[j] = a2[j] = INT32_MIN;
-    }
-
-    uint32_t halo = 0;
-    if (PAIRED && threadIdx.x == 0) {
-        if (r0 > 0) {
-            const uint64_t h = r0 - 1;
-            if (r0 <= n)
-                halo = mapping_state<int32_t>(cigar_score_one(nm1, off1, ops1, h, range_flag), xs1[h],
-                                              cigar_score_one(nm2, off2, ops2, h, range_flag), xs2[h], m);
-        } else {
-            mb &= ~1u;
-        }
-    }
-    classify_finish<int32_t, PAIRED, BLOCK>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
+    if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
+        classify_cigar_body<PAIRED, BLOCK, true>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
+                                                 range_flag, last_state);
+    else
+        classify_cigar_body<PAIRED, BLOCK, false>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
+                                                  range_flag, last_state);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -384,3 +384,56 @@ def score_columns_torch(n_pairs, seed, device, profile="bowtie2", chunk_pairs=1 
     bits = torch.from_numpy(interleaved_unit_bits(n).view(np.int64)).to(device)
     out["unit_bits"] = bits
     return out
+
+
+def cigar_columns_torch(n_records, seed, device, read_len=150, mapped_p=0.9):
+    """cigar_columns() drawn with torch on `device` (same shape model, different random stream).
+    Returns torch tensors nm int32[n], cig_off int32[n+1] (bit pattern of uint32), cig_oplen int32[]."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    n = n_records
+
+    def rand():
+        return torch.rand(n, generator=gen, device=device)
+
+    def randint(lo, hi):
+        return torch.randint(lo, hi, (n,), generator=gen, device=device, dtype=torch.int32)
+
+    mapped = rand() < mapped_p
+    nm = torch.poisson(torch.full((n,), 1.2, device=device), generator=gen).to(torch.int32)
+    u = rand()
+    shape = (u >= 0.80).to(torch.int32) + (u >= 0.92).to(torch.int32) + (u >= 0.95).to(torch.int32) + (u >= 0.99).to(torch.int32)
+    a, b, c = randint(1, 40), randint(1, 4), randint(1, 30)
+    is_del = rand() < 0.5
+    clip_left = rand() < 0.5
+    L = read_len
+
+    def op(length, code):
+        return (length << 4) | code
+
+    zero = torch.zeros(n, dtype=torch.int32, device=device)
+    indel = torch.where(is_del, torch.full_like(zero, OP_D), torch.full_like(zero, OP_I))
+    dense = torch.zeros((n, 5), dtype=torch.int32, device=device)
+    count = torch.zeros(n, dtype=torch.int32, device=device)
+    rows = {
+        0: ([op(torch.full_like(zero, L), OP_M)], shape == 0),
+        1: ([op(a, OP_S), op(L - a, OP_M)], (shape == 1) & clip_left),
+        2: ([op(L - a, OP_M), op(a, OP_S)], (shape == 1) & ~clip_left),
+        3: ([op(a, OP_S), op(L - a - c, OP_M), op(c, OP_S)], shape == 2),
+        4: ([op(a + 10, OP_M), (b << 4) | indel, op(L - a - 10 - torch.where(is_del, zero, b), OP_M)], shape == 3),
+        5: ([op(a + 5, OP_M), op(b, OP_I), op(c + 5, OP_M), op(b, OP_D), op(L - a - c - 10 - b, OP_M)], shape == 4),
+    }
+    for ops_list, sel in rows.values():
+        sel = sel & mapped
+        for k, v in enumerate(ops_list):
+            dense[:, k] = torch.where(sel, v, dense[:, k])
+        count = torch.where(sel, torch.full_like(count, len(ops_list)), count)
+    valid = torch.arange(5, device=device, dtype=torch.int32).unsqueeze(0) < count.unsqueeze(1)
+    ops = dense[valid]
+    off = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    off[1:] = torch.cumsum(count.to(torch.int64), 0)
+    nm = torch.where(mapped, nm, torch.full_like(nm, int(ABSENT)))
+    if ops.numel() == 0:
+        ops = torch.zeros(1, dtype=torch.int32, device=device)
+    return {"nm": nm.contiguous(), "cig_off": off.to(torch.int32).contiguous(), "cig_oplen": ops.contiguous()}
