@@ -35,7 +35,7 @@ def oracle_run(t1, t2, mode, scorer, m, skip):
     return [o.getvalue() for o in outs], counts, err
 
 
-@settings(max_examples=250, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get('XM_FUZZ_EXAMPLES', '250')), deadline=None, suppress_health_check=list(HealthCheck))
 @given(texts=sam_pair(), mode=st.sampled_from(["se", "pe", "pe_conservative"]),
        func=st.sampled_from(sorted(SCORERS)), m=st.sampled_from([NEG, 0.0, -12.5, 3.0]), skip=st.booleans(),
        via_files=st.booleans())

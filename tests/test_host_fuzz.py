@@ -2,6 +2,7 @@
 mismatching names) through the C++ stripper must agree with the oracle's text-level restatement -- record
 count, names, unit mask, every score the stripper vouches for, and an exception wherever it does not.  CPU only."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -73,7 +74,7 @@ def oracle_walk(t1, t2, skip):
     return pairs, err
 
 
-@settings(max_examples=400, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get('XM_FUZZ_EXAMPLES', '400')), deadline=None, suppress_health_check=list(HealthCheck))
 @given(texts=sam_pair(), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans(), skip=st.booleans())
 def test_stripper_agrees_with_oracle(parser, texts, score_mode, paired, skip):
     t1, t2 = texts
