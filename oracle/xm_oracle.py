@@ -314,10 +314,12 @@ def run_paired_end(readpairs, outs, min_score=NEG_INF, scorer=tag_score, conserv
         if not prev1 or prev1[0] != rec1[0]:
             prev1, prev2 = rec1, rec2
             continue
-        fwd = mapping_state(scorer(prev1, tag="AS"), scorer(prev1, tag="XS"),
-                            scorer(prev2, tag="AS"), scorer(prev2, tag="XS"), min_score)
-        rev = mapping_state(scorer(rec1, tag="AS"), scorer(rec1, tag="XS"),
-                            scorer(rec2, tag="AS"), scorer(rec2, tag="XS"), min_score)
+        # all eight tags are read before either state is evaluated (:408-415, then :417-418), so a malformed
+        # tag of the second mate raises before a NaN of the first one can
+        p_scores = (scorer(prev1, tag="AS"), scorer(prev1, tag="XS"), scorer(prev2, tag="AS"), scorer(prev2, tag="XS"))
+        c_scores = (scorer(rec1, tag="AS"), scorer(rec1, tag="XS"), scorer(rec2, tag="AS"), scorer(rec2, tag="XS"))
+        fwd = mapping_state(*p_scores, min_score)
+        rev = mapping_state(*c_scores, min_score)
         res.counts[(fwd, rev)] += 1
         b = bin_conservative(fwd, rev) if conservative else bin_liberal(fwd, rev)
         res.units.append((i, fwd, rev, b))

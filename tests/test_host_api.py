@@ -217,3 +217,35 @@ def test_cli_main(tmp_path, capsys):
     for name in H.STATES:
         text = (tmp_path / (name + ".sam")).read_text()
         assert hashlib.sha224(text.encode("latin-1")).hexdigest() == case["expect"]["bins"][name]["sha224"]
+
+
+G5 = H.golden("g5_errors.json")["cases"]
+
+
+@pytest.mark.parametrize("via_files", [False, True])
+@pytest.mark.parametrize("case", G5, ids=[c["name"] for c in G5])
+def test_g5_errors_like_the_reference(case, via_files, tmp_path):
+    """Malformed input: the reference's exception type after the reference's partial output, through the iterator
+    loops and through the file fast path."""
+    from xenomapper_amd import xenomapper as xm
+    t1, t2 = case["text"]
+    outs = {name: io.StringIO() for name in H.STATES}
+    m = H.unnum(case["min_score"])
+    tag_func = getattr(xm, case["tag_func"])
+    err = None
+    try:
+        if via_files:
+            (tmp_path / "a.sam").write_text(t1)
+            (tmp_path / "b.sam").write_text(t2)
+            xm.classify_sam_files(str(tmp_path / "a.sam"), str(tmp_path / "b.sam"), paired=case["mode"] != "se",
+                                  conservative=case["mode"] == "pe_conservative", min_score=m, tag_func=tag_func,
+                                  skip_repeated_reads=False, **outs)
+        else:
+            loop = {"se": xm.main_single_end, "pe": xm.main_paired_end,
+                    "pe_conservative": xm.conservative_main_paired_end}[case["mode"]]
+            loop(xm.getReadPairs(io.StringIO(t1), io.StringIO(t2)), min_score=m, tag_func=tag_func, **outs)
+    except Exception as exc:
+        err = type(exc).__name__
+    assert err == case["error"]
+    for name in H.STATES:
+        assert outs[name].getvalue() == case["outputs"][name], name

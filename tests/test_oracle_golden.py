@@ -242,3 +242,29 @@ def test_c_cigar_matches_python():
             fields.append("NM:i:%d" % cols["nm"][i])
         want = ORACLE.cigar_score(fields)
         assert (got[i] == H.synth.ABSENT and want == NEG) or got[i] == want
+
+
+# ---------------------------------------------------------------- G5: malformed input
+G5 = H.golden("g5_errors.json")["cases"]
+
+
+@pytest.mark.parametrize("case", G5, ids=[c["name"] for c in G5])
+def test_g5_error_type_and_partial_output(case):
+    """Exception type and what was written before it, as recorded from the reference -- including the order in
+    which the eight tags of a pair are read (all before either state, xenomapper.py:408-418)."""
+    t1, t2 = case["text"]
+    outs = [io.StringIO() for _ in range(6)]
+    scorer = FUNCS[case["tag_func"]]
+    m = H.unnum(case["min_score"])
+    err = None
+    try:
+        pairs = ORACLE.read_pairs(io.StringIO(t1), io.StringIO(t2))
+        if case["mode"] == "se":
+            ORACLE.run_single_end(pairs, outs, m, scorer)
+        else:
+            ORACLE.run_paired_end(pairs, outs, m, scorer, conservative=case["mode"] == "pe_conservative")
+    except Exception as exc:
+        err = type(exc).__name__
+    assert err == case["error"]
+    for b, name in enumerate(H.STATES):
+        assert outs[b].getvalue() == case["outputs"][name], name

@@ -317,6 +317,52 @@ def g3():
     return {"cases": cases}
 
 
+def g5():
+    """Malformed inputs: the exception type the reference raises and what it had written by then."""
+    def rec(name, *opts):
+        return "\t".join([name, "0", "chr1", "1", "30", "10M", "*", "0", "0", "ACGT", "IIII"] + list(opts))
+
+    def sam(lines):
+        return "\n".join(lines) + "\n"
+    cases = []
+
+    def add(name, l1, l2, mode, tag_func_name="get_tag", min_score=NEG):
+        t1, t2 = sam(l1), sam(l2)
+        outs = {k: io.StringIO() for k in BIN_ARGS}
+        loop = {"se": ref.main_single_end, "pe": ref.main_paired_end,
+                "pe_conservative": ref.conservative_main_paired_end}[mode]
+        err = None
+        try:
+            loop(ref.getReadPairs(io.StringIO(t1), io.StringIO(t2)), min_score=min_score,
+                 tag_func=getattr(ref, tag_func_name), **outs)
+        except Exception as exc:
+            err = type(exc).__name__
+        cases.append({"name": name, "text": [t1, t2], "mode": mode, "tag_func": tag_func_name, "min_score": num(min_score),
+                      "error": err, "outputs": {k: outs[k].getvalue() for k in BIN_ARGS}})
+
+    good = [rec("a", "AS:i:9"), rec("b", "AS:i:2")]
+    add("se_duplicate_tag", good + [rec("c", "AS:i:5", "RG:Z:BASS"), rec("d", "AS:i:9")], good + [rec("c"), rec("d")], "se")
+    add("se_name_mismatch", good + [rec("x", "AS:i:1")], good + [rec("y", "AS:i:1")], "se")
+    add("se_non_numeric", good + [rec("c", "AS:i:7", "XS:A:+")], good + [rec("c")], "se")
+    add("se_nan_falls_through", good + [rec("n", "AS:f:nan")], good + [rec("n", "AS:i:2")], "se")
+    add("pe_unpaired_malformed_is_never_read",
+        [rec("p", "AS:i:9"), rec("p", "AS:i:9"), rec("lonely", "AS:i:1", "RG:Z:BASS"), rec("q", "AS:i:9"), rec("q", "AS:i:9")],
+        [rec("p"), rec("p"), rec("lonely"), rec("q"), rec("q")], "pe")
+    # all eight tags are read before either state is evaluated: the duplicate of the second mate wins over the first's NaN
+    add("pe_second_mate_error_before_first_mate_nan",
+        [rec("p", "AS:i:9"), rec("p", "AS:i:9"), rec("r", "AS:i:nan"), rec("r", "AS:i:3")],
+        [rec("p"), rec("p"), rec("r"), rec("r", "AS:i:0", "RG:Z:BASS")], "pe")
+    add("pe_nan_first_mate", [rec("p", "AS:i:9"), rec("p", "AS:i:9"), rec("r", "AS:i:nan"), rec("r", "AS:i:3")],
+        [rec("p"), rec("p"), rec("r"), rec("r", "AS:i:0")], "pe_conservative")
+    add("pe_cigar_bad_nm", [rec("p", "NM:i:1"), rec("p", "NM:i:x")], [rec("p", "NM:i:0"), rec("p", "NM:i:0")], "pe",
+        tag_func_name="get_cigarbased_AS_tag")
+    add("pe_cigar_short_line", [rec("p", "NM:i:1"), "p 0 chr1 1 30 NM:i:2 x x x x x NM:i:2"],
+        [rec("p", "NM:i:0"), rec("p", "NM:i:0")], "pe", tag_func_name="get_cigarbased_AS_tag")
+    add("se_zs_duplicate", good + [rec("c", "AS:i:5", "ZS:i:1", "ZS:i:1")], good + [rec("c")], "se",
+        tag_func_name="get_tag_with_ZS_as_XS")
+    return {"cases": cases}
+
+
 def header_golden():
     """process_headers on the PE fixtures (tests/test_xenomapper.py:29-54): full texts."""
     data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
@@ -330,7 +376,7 @@ def header_golden():
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     payload = {"g1_mapping_state.json": g1(), "g2_tag_parsers.json": g2(), "g3_end_to_end.json": g3(),
-               "g4_headers.json": header_golden()}
+               "g4_headers.json": header_golden(), "g5_errors.json": g5()}
     for name, obj in payload.items():
         with open(os.path.join(GOLDEN, name), "wt") as fh:
             json.dump(obj, fh, indent=None, separators=(",", ":"), sort_keys=True)
