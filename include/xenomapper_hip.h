@@ -128,6 +128,14 @@ int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n_records,
 int xm_compact(xm_ctx *ctx, int mode, uint64_t n_records, const uint8_t *code,
                uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
 
+/*
+ * xenomappability (the reference's experimental companion tool): replaces the inner loop of
+ * Mappability.single_end_to_paired (/root/reference/xenomapper/mappability.py:94-124) for one chromosome:
+ * out[i] = 1.0 where track[i] == 1, else sum_j track[i+j] * density[j], j < min(m, n - i), accumulated left to right
+ * in binary64 with separately rounded multiply and add (bit-identical to the Python loop).
+ */
+int xm_mate_correlate(xm_ctx *ctx, uint64_t n, const double *track, uint64_t m, const double *density, double *out);
+
 /* ---- device-resident entry points (asynchronous on `stream`) -------------------------- */
 /*
  * All pointers are device memory of the context's device; `stream` is a hipStream_t passed
@@ -157,6 +165,9 @@ int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n_records, const int
                         const uint32_t *cig_off, const uint32_t *cig_oplen, int32_t *as_out,
                         uint32_t *range_flag);
 
+int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,
+                          const double *density, double *out);
+
 /* bin_offsets: 8 device uint64; counts: 64 device uint64 (both overwritten). */
 int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, const uint8_t *code,
                    uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
@@ -167,7 +178,8 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, cons
 #define XM_K_SCAN     2
 #define XM_K_SCATTER  3
 #define XM_K_CIGAR    4
-#define XM_K_COUNT    5
+#define XM_K_CORRELATE 5
+#define XM_K_COUNT    6
 /* When enabled, every *_dev call brackets each kernel it launches with hipEventRecord on the
  * launch stream.  xm_timing_read() synchronises the recorded events and adds their elapsed
  * times: ms[k] = total milliseconds, launches[k] = number of launches since the last reset. */

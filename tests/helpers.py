@@ -55,6 +55,8 @@ def c_oracle():
     lib.xmo_compact.restype = None
     lib.xmo_cigar_scores.argtypes = [u64, P, P, P, P]
     lib.xmo_cigar_scores.restype = u64
+    lib.xmo_mate_correlate.argtypes = [u64, P, u64, P, P]
+    lib.xmo_mate_correlate.restype = None
     _C = lib
     return lib
 
@@ -124,3 +126,14 @@ def floor_min_score(m):
     if m == -NEG:
         return 2**31 - 1
     return int(max(-2**31, min(2**31 - 1, math.floor(m))))
+
+
+def c_mate_correlate(track, density):
+    lib = c_oracle()
+    track = np.ascontiguousarray(track, dtype=np.float64)
+    density = np.ascontiguousarray(density, dtype=np.float64)
+    out = np.empty(track.shape[0], dtype=np.float64)
+    t = track if track.shape[0] else np.zeros(1)
+    d = density if density.shape[0] else np.zeros(1)
+    lib.xmo_mate_correlate(track.shape[0], ptr(t), density.shape[0], ptr(d), ptr(out if out.shape[0] else np.zeros(1)))
+    return out

@@ -363,6 +363,60 @@ def g5():
     return {"cases": cases}
 
 
+def g6():
+    """xenomappability: outputs of the reference's mappability module on its own fixtures and on
+    random tracks.  Floats are recorded as hex so that they compare bit for bit."""
+    import random
+    from xenomapper import mappability as refm
+    data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
+    out_dir = os.path.join(GOLDEN, "ref_data")
+    for name in ("test_from_EcoliK12DH10B.fasta", "test_from_EcoliK12DH10B_150reads.sam"):
+        shutil.copyfile(os.path.join(data_dir, name), os.path.join(out_dir, name))
+        os.chmod(os.path.join(out_dir, name), 0o644)
+    out = {}
+    buf = io.StringIO()
+    refm.simulate_reads(open(os.path.join(data_dir, "test_from_EcoliK12DH10B.fasta")), readlength=150, outfile=buf)
+    out["simulate_reads_150_sha224"] = hashlib.sha224(buf.getvalue().encode("latin-1")).hexdigest()
+    buf = io.StringIO()
+    with open(os.path.join(data_dir, "test_from_EcoliK12DH10B_150reads.sam")) as fh:
+        refm.single_end_mappability_from_sam(fh, outfile=buf, chromosome_sizes={"Chromosome": 2752, "A_Repeat": 991})
+    out["single_end_wiggle_sha224"] = hashlib.sha224(buf.getvalue().encode("latin-1")).hexdigest()
+    out["single_end_wiggle_text"] = buf.getvalue()
+    with open(os.path.join(data_dir, "paired_end_testdata_human.sam")) as fh:
+        out["mate_density_sample3"] = [v.hex() for v in refm.mate_distribution_from_sam(samfile=fh, sample_size=3)]
+    with open(os.path.join(data_dir, "paired_end_testdata_human.sam")) as fh:
+        dens = refm.mate_distribution_from_sam(samfile=fh)
+        out["mate_density_default"] = [v.hex() for v in dens]
+    # paired-end mappability of the E. coli single-end track with the fixture's mate density
+    buf2 = io.StringIO()
+    refm.paired_end_mappability(io.StringIO(out["single_end_wiggle_text"]), dens, outfile=buf2,
+                                chromosome_sizes={"Chromosome": 2752, "A_Repeat": 991})
+    out["paired_wiggle_sha224"] = hashlib.sha224(buf2.getvalue().encode("latin-1")).hexdigest()
+    out["paired_wiggle_len"] = len(buf2.getvalue())
+    # random tracks: 0/1 tracks (what the tool produces) and fractional tracks (what from_wiggle accepts)
+    rnd = random.Random(60606)
+    cases = []
+    for n, m, kind in ((0, 3, "bits"), (1, 1, "bits"), (7, 3, "bits"), (64, 5, "bits"), (300, 17, "bits"), (1000, 451, "bits"),
+                       (257, 300, "frac"), (2000, 64, "frac"), (513, 1, "frac"), (100, 7, "ints")):
+        if kind == "bits":
+            track = [float(rnd.random() < 0.6) for _ in range(n)]
+        elif kind == "ints":
+            track = [rnd.choice([0, 1, 1, 2]) for _ in range(n)]
+        else:
+            track = [rnd.choice([0.0, 1.0, rnd.random(), 0.25, 1e-3]) for _ in range(n)]
+        raw = [rnd.random() for _ in range(m)]
+        tot = sum(raw)
+        density = [x / tot for x in raw]
+        mp = refm.Mappability(chromosome_sizes={"c": n})
+        mp["c"] = list(track)
+        res = mp.single_end_to_paired(mate_density=density)["c"]
+        cases.append({"track": [float(v).hex() for v in track], "track_is_int": kind == "ints",
+                      "density": [v.hex() for v in density], "expect": [float(v).hex() for v in res]})
+    out["single_end_to_paired"] = cases
+    out["smoothed_list"] = [repr(v) for v in refm.smoothed_list([1, 2, 3] * 10 + [100] + [1, 2, 3] * 10)]   # ints and floats
+    return out
+
+
 def header_golden():
     """process_headers on the PE fixtures (tests/test_xenomapper.py:29-54): full texts."""
     data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
@@ -376,7 +430,7 @@ def header_golden():
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     payload = {"g1_mapping_state.json": g1(), "g2_tag_parsers.json": g2(), "g3_end_to_end.json": g3(),
-               "g4_headers.json": header_golden(), "g5_errors.json": g5()}
+               "g4_headers.json": header_golden(), "g5_errors.json": g5(), "g6_mappability.json": g6()}
     for name, obj in payload.items():
         with open(os.path.join(GOLDEN, name), "wt") as fh:
             json.dump(obj, fh, indent=None, separators=(",", ":"), sort_keys=True)

@@ -20,7 +20,7 @@ MODE_SE, MODE_PE_LIBERAL, MODE_PE_CONSERVATIVE = 0, 1, 2
 NO_UNIT = 0xFF
 ABSENT = -2**31
 MAX_RECORDS = 0xFFFFF000
-KERNELS = ("classify", "hist", "scan", "scatter", "cigar")
+KERNELS = ("classify", "hist", "scan", "scatter", "cigar", "correlate")
 
 XM_OK = 0
 _ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, -5: OverflowError}
@@ -78,6 +78,8 @@ def lib():
         "xm_classify_cigar": ([P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P], I),
         "xm_classify_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P], I),
         "xm_compact": ([P, I, U64, P, P, P, P], I),
+        "xm_mate_correlate": ([P, U64, P, U64, P, P], I),
+        "xm_mate_correlate_dev": ([P, P, U64, P, U64, P, P], I),
         "xm_classify_dev": ([P, P, I, U64, P, P, P, P, P, I32, P], I),
         "xm_classify_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P], I),
         "xm_cigar_scores_dev": ([P, P, U64, P, P, P, P, P], I),
@@ -97,7 +99,7 @@ def lib():
 
 EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create", "xm_ctx_destroy",
             "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_classify_cigar",
-            "xm_compact", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
+            "xm_compact", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
             "xm_compact_dev", "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
 
@@ -220,6 +222,24 @@ class Context(object):
         rc = self._L.xm_compact(self._h, mode, n, _np_ptr(code), _np_ptr(idx), _np_ptr(off), _np_ptr(counts))
         self._check(rc, "xm_compact")
         return idx[:int(off[7])], off, counts
+
+    def mate_correlate(self, track, density):
+        """Paired-end mappability of one chromosome track (float64 in, float64 out)."""
+        track = _as(track, np.float64)
+        density = _as(density, np.float64)
+        out = np.empty(track.shape[0], dtype=np.float64)
+        d = density if density.shape[0] else np.zeros(1)
+        t = track if track.shape[0] else np.zeros(1)
+        rc = self._L.xm_mate_correlate(self._h, track.shape[0], _np_ptr(t), density.shape[0], _np_ptr(d),
+                                       _np_ptr(out if out.shape[0] else np.zeros(1)))
+        self._check(rc, "xm_mate_correlate")
+        return out
+
+    def mate_correlate_dev(self, track, density, out, stream=None):
+        rc = self._L.xm_mate_correlate_dev(self._h, self._stream_handle(stream), track.numel(),
+                                           ctypes.c_void_p(track.data_ptr()), density.numel(),
+                                           ctypes.c_void_p(density.data_ptr()), ctypes.c_void_p(out.data_ptr()))
+        self._check(rc, "xm_mate_correlate_dev")
 
     # ---- device-resident entry points (torch tensors on this context's GPU) --------------
     @staticmethod

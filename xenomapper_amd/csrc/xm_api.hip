@@ -325,6 +325,20 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_
     return check_launch(ctx, "scatter_kernel");
 }
 
+int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,
+                          const double *density, double *out)
+{
+    if (!ctx || wrong_device(ctx) || m > 0xFFFFFFFFull || n > (1ull << 40)) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!track || !out || (m && !density)) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Span span(ctx, st, XM_K_CORRELATE);
+        xm::launch_mate_correlate(st, n, track, (uint32_t)m, density, out);
+    }
+    return check_launch(ctx, "mate_correlate_kernel");
+}
+
 /* ---- host-buffer entry points ------------------------------------------------------------ */
 
 static int classify_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const void *as1, const void *xs1,
@@ -458,6 +472,25 @@ int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n,
         for (uint64_t i = 0; i < n; ++i)
             if (code_out[i] != XM_NO_UNIT) counts[code_out[i] & 63u]++;
     }
+    return XM_OK;
+}
+
+int xm_mate_correlate(xm_ctx *ctx, uint64_t n, const double *track, uint64_t m, const double *density, double *out)
+{
+    if (!ctx || m > 0xFFFFFFFFull) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!track || !out || (m && !density)) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, n * 8)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 1, (m ? m : 1) * 8)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 2, n * 8)) != XM_OK) return rc;
+    XM_HIP(ctx, hipMemcpy(ctx->d_scratch[0], track, n * 8, hipMemcpyHostToDevice));
+    if (m) XM_HIP(ctx, hipMemcpy(ctx->d_scratch[1], density, m * 8, hipMemcpyHostToDevice));
+    rc = xm_mate_correlate_dev(ctx, nullptr, n, (const double *)ctx->d_scratch[0], m, (const double *)ctx->d_scratch[1],
+                               (double *)ctx->d_scratch[2]);
+    if (rc != XM_OK) return rc;
+    XM_HIP(ctx, hipMemcpy(out, ctx->d_scratch[2], n * 8, hipMemcpyDeviceToHost));
     return XM_OK;
 }
 

@@ -41,6 +41,7 @@ void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_count
                  uint64_t *bin_totals, uint64_t *counts_rep, uint64_t *counts);
 void launch_scatter(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
                     const uint32_t *chunk_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out);
+void launch_mate_correlate(hipStream_t st, uint64_t n, const double *track, uint32_t m, const double *density, double *out);
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,
                   const uint32_t *cig_oplen, int32_t *as_out, uint32_t *range_flag);
 

@@ -822,6 +822,52 @@ classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// K4: mate-density correlation of a single-end mappability track (xenomappability, SURVEY 8f-4;
+// Mappability.single_end_to_paired, /root/reference/xenomapper/mappability.py:94-124).
+// out[i] = 1.0 where track[i] == 1, else sum_j track[i+j] * density[j] for j < min(m, n - i), accumulated left to
+// right in binary64 with a separately rounded multiply and add (fp contraction switched off: never an FMA),
+// which is what Python's `result += a * b` does -- bit-exact, not just close.  f64-VALU bound (2 flops per tap,
+// m taps per output); the track window of a workgroup is staged in LDS (conflict-free ds_read_b64, one tap per
+// step), the taps are wave-uniform loads.
+// ---------------------------------------------------------------------------------------------
+#define XM_CORR_T 256       // outputs per workgroup
+#define XM_CORR_M 2048      // taps per pass (LDS: (256 + 2048) * 8 bytes)
+__global__ void __launch_bounds__(XM_CORR_T)
+mate_correlate_kernel(const double *__restrict__ track, uint64_t n, const double *__restrict__ density, uint32_t m,
+                      double *__restrict__ out)
+{
+#pragma clang fp contract(off)          // hipcc contracts a * b + c into v_fma_f64 by default: one rounding instead of two
+    __shared__ double tile[XM_CORR_T + XM_CORR_M];
+    const uint32_t t = threadIdx.x;
+    const uint64_t i0 = (uint64_t)blockIdx.x * XM_CORR_T, i = i0 + t;
+    const uint64_t left = (i < n) ? n - i : 0;                         // taps that still have a track position
+    double acc = 0.0;
+    for (uint32_t j0 = 0; j0 < m; j0 += XM_CORR_M) {
+        const uint32_t mm = (m - j0 < XM_CORR_M) ? m - j0 : XM_CORR_M;
+        __syncthreads();
+        for (uint32_t k = t; k < XM_CORR_T + mm; k += XM_CORR_T) {
+            const uint64_t p = i0 + j0 + k;
+            tile[k] = (p < n) ? track[p] : 0.0;
+        }
+        __syncthreads();
+        const uint32_t lim = (left > j0) ? (uint32_t)((left - j0 < mm) ? left - j0 : mm) : 0u;
+        if (__ballot(lim != mm) == 0ull) {                             // wave-uniform: nobody is near the track's end
+            for (uint32_t j = 0; j < mm; ++j) {
+                const double prod = tile[t + j] * density[j0 + j];      // rounded
+                acc = acc + prod;                                       // rounded again (contraction is off above)
+            }
+        } else {
+            for (uint32_t j = 0; j < mm; ++j) {
+                const double prod = tile[t + j] * density[j0 + j];
+                const double s = acc + prod;
+                acc = (j < lim) ? s : acc;
+            }
+        }
+    }
+    if (i < n) out[i] = (track[i] == 1.0) ? 1.0 : acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -905,6 +951,12 @@ void launch_scatter(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, co
         scatter_kernel<XM_MODE_PE_LIBERAL, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
     else
         scatter_kernel<XM_MODE_PE_CONSERVATIVE, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
+}
+
+void launch_mate_correlate(hipStream_t st, uint64_t n, const double *track, uint32_t m, const double *density, double *out)
+{
+    const uint32_t grid = (uint32_t)((n + XM_CORR_T - 1) / XM_CORR_T);
+    mate_correlate_kernel<<<grid, XM_CORR_T, 0, st>>>(track, n, density, m, out);
 }
 
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,
