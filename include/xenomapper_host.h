@@ -86,6 +86,8 @@ typedef struct {
 
 int xmh_abi_version(void);
 const char *xmh_strerror(int status);
+/* workers used when n_threads <= 0: CPUs in the affinity mask, cut to the cgroup CPU quota if one is set, at most 64 */
+int xmh_default_threads(void);
 int xmh_parser_create(int n_threads, xmh_parser **out);
 int xmh_parser_destroy(xmh_parser *p);
 

@@ -217,6 +217,32 @@ def test_windowed_walk_equals_whole_file(parser):
     assert got_flags == whole_flags.tolist()
 
 
+def test_worker_count_does_not_change_the_result():
+    """Enough lines for every parallel phase to split (> 4096), parsed and written with 1, 3 and 7 workers."""
+    import os
+    from xenomapper_amd import _host, synth
+    t1, t2, _ = synth.sam_text_pair(n_pairs=5000, seed=77, profile="bowtie2", paired=True, read_len=50)
+    want = None
+    for threads in (1, 3, 7):
+        prs = _host.Parser(threads)
+        block, _, _ = parse_all(prs, t1, t2, 2, True, False)
+        flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:block.n]
+        idx = np.flatnonzero(flags).astype(np.uint32)
+        fresh = bytes(prs.emit(True, 4, idx))
+        assert bytes(prs.emit(True, 4, idx, reuse=True)) == fresh
+        assert bytes(prs.emit(True, 4, idx[:10], reuse=True)) == bytes(prs.emit(True, 4, idx[:10]))
+        got = ([c.tolist() for c in block.cols], [[a.tolist() for a in f] for f in block.csr], flags.tolist(),
+               [o.tolist() for o in block.line_off], [l.tolist() for l in block.line_len], block.exc, fresh)
+        prs.close()
+        if want is None:
+            want = got
+            assert block.n == 10000 and len(fresh) > 0
+        else:
+            assert got == want
+    n = _host.lib().xmh_default_threads()
+    assert 1 <= n <= min(64, len(os.sched_getaffinity(0)))
+
+
 def test_library_exports_header_symbols():
     import ctypes, os, re
     from xenomapper_amd import _host, build

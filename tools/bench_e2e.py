@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--mode", default="liberal", choices=("liberal", "conservative", "se"))
     ap.add_argument("--dir", default="/dev/shm")
     a = ap.parse_args()
-    from xenomapper_amd import synth, xenomapper as xm
+    from xenomapper_amd import _host, synth, xenomapper as xm
     base = 50_000
     t1, t2, _ = synth.sam_text_pair(n_pairs=base, seed=2002, profile="bowtie2", paired=a.mode != "se", read_len=150)
     reps = max(1, a.pairs // base)
@@ -53,7 +53,7 @@ def main():
         units = sum(counts.values())
         print(json.dumps({"metric": "end-to-end read-pairs/s (SAM text in, six SAM files out)", "value": units / el,
                           "units": units, "seconds": el, "input_bytes": size, "input_GBps": size / el / 1e9,
-                          "threads": a.threads or os.cpu_count(), "mode": a.mode}))
+                          "threads": a.threads or _host.lib().xmh_default_threads(), "mode": a.mode}))
     finally:
         for p in paths:
             os.unlink(p)

@@ -14,7 +14,7 @@ SCORE_AS_XS, SCORE_AS_ZS, SCORE_CIGAR = 0, 1, 2
 EX_NONINT, EX_DUP, EX_SHORT, EX_BIGLEN = 1, 2, 3, 4
 ERR_NON_ASCII = -3
 
-EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
+EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_default_threads", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
             "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read")
 
 _P = ctypes.c_void_p
@@ -46,6 +46,7 @@ def lib():
         L.xmh_abi_version.restype = ctypes.c_int
         L.xmh_strerror.argtypes = [ctypes.c_int]
         L.xmh_strerror.restype = ctypes.c_char_p
+        L.xmh_default_threads.restype = ctypes.c_int
         L.xmh_parser_create.argtypes = [ctypes.c_int, ctypes.POINTER(_P)]
         L.xmh_parser_destroy.argtypes = [_P]
         L.xmh_parse.argtypes = [_P, _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, ctypes.c_int,
@@ -99,6 +100,7 @@ class Parser(object):
             raise RuntimeError("xmh_parser_create: " + self._L.xmh_strerror(rc).decode())
         self._h = h
         self._win = None
+        self._out = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -127,8 +129,10 @@ class Parser(object):
         self._keep = (arr1, arr2)            # the windows must outlive emit()
         return Block(raw, score_mode == SCORE_CIGAR)
 
-    def emit(self, paired, bin_index, idx):
-        """Text (bytes) of one output bin for the last parsed block; idx: ascending uint32 unit indices."""
+    def emit(self, paired, bin_index, idx, reuse=False):
+        """Text (bytes) of one output bin for the last parsed block; idx: ascending uint32 unit indices.
+        reuse=True returns a view of a buffer the parser keeps (valid until the next emit): a fresh multi-megabyte
+        array per call is mapped, page-faulted and unmapped every time."""
         idx = np.ascontiguousarray(idx, dtype=np.uint32)
         n = idx.shape[0]
         if n == 0:
@@ -139,7 +143,12 @@ class Parser(object):
                               ctypes.byref(need))
         if rc != 0:
             raise RuntimeError("xmh_emit: " + self._L.xmh_strerror(rc).decode())
-        out = np.empty(need.value, dtype=np.uint8)
+        if reuse:
+            if self._out is None or self._out.shape[0] < need.value:
+                self._out = np.empty(max(int(need.value * 1.25), 1 << 20), dtype=np.uint8)
+            out = self._out[:need.value]
+        else:
+            out = np.empty(need.value, dtype=np.uint8)
         rc = self._L.xmh_emit(self._h, self._win[0], self._win[1], int(paired), bin_index, ip, n,
                               out.ctypes.data_as(_P), need.value, ctypes.byref(need))
         if rc != 0:

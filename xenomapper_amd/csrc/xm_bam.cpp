@@ -272,7 +272,7 @@ int xmh_bam_open(const uint8_t *data, uint64_t len, int n_threads, xmh_bam **out
         xmh_bam *b = new xmh_bam();
         b->data = data;
         b->len = len;
-        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads <= 0) n_threads = xmh_default_threads();
         b->n_threads = std::max(1, std::min(n_threads, 64));
         if (!index_blocks(data, len, b->blocks) || !read_header(b)) { delete b; return XMH_ERR_BAD_BAM; }
         *out = b;

@@ -11,10 +11,17 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <sched.h>
+#include <sys/mman.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +34,21 @@ const int32_t ABSENT = INT32_MIN;
 inline bool is_ws(unsigned char c)
 {
     return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31);
+}
+
+// first index >= i (i < n) of a separator in s[0..n), or n.  Every separator is below 0x21 and the input is ASCII
+// (the index pass has rejected anything else), so a word without a byte below 0x21 is skipped whole.
+inline uint32_t token_end(const char *s, uint32_t i, uint32_t n)
+{
+    const uint64_t ones = 0x0101010101010101ull, tops = 0x8080808080808080ull;
+    while (i + 8 <= n) {
+        uint64_t w;
+        std::memcpy(&w, s + i, 8);
+        if ((w - ones * 0x21u) & ~w & tops) break;
+        i += 8;
+    }
+    while (i < n && !is_ws((unsigned char)s[i])) ++i;
+    return i;
 }
 
 struct Line {
@@ -61,46 +83,187 @@ struct FileParse {
     bool non_ascii = false;
 };
 
-template <typename F>
-void parallel_for(int n_threads, uint64_t n, F fn)
+}  // namespace
+
+// Worker count when the caller passes 0: the CPUs this process may actually use -- the affinity mask, cut down to a
+// cgroup CPU quota when one is set (a container with 16 CPUs' worth of quota on a 256-thread host) -- at most 64.
+extern "C" int xmh_default_threads(void)
 {
-    if (n_threads <= 1 || n < 4096) {
-        fn(0, 0, n);
+    long n = (long)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<long>(n > 0 ? n : 1 << 20, (long)CPU_COUNT(&set));
+    long quota = -1, period = -1;
+    if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0};
+        if (std::fscanf(fh, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+        std::fclose(fh);
+    } else {                                                                             // cgroup v1
+        if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (std::fscanf(fq, "%ld", &quota) != 1) quota = -1;
+            std::fclose(fq);
+        }
+        if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(fp, "%ld", &period) != 1) period = -1;
+            std::fclose(fp);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (quota + period - 1) / period);
+    return (int)std::max<long>(1, std::min<long>(n, 64));
+}
+
+namespace {
+
+// Workers that live as long as the parser: a window needs about fifteen short parallel phases, and starting sixteen
+// threads for each of them costs more than several of the phases themselves.
+class Pool {
+public:
+    explicit Pool(int n) : n_(std::max(1, n))
+    {
+        for (int t = 1; t < n_; ++t) workers_.emplace_back([this, t]() { loop(t); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        wake_.notify_all();
+        for (auto &th : workers_) th.join();
+    }
+    Pool(const Pool &) = delete;
+    Pool &operator=(const Pool &) = delete;
+    int size() const { return n_; }
+
+    // fn(t) for t in [0, n_tasks), n_tasks <= size(); task 0 runs on the calling thread.  The first exception thrown
+    // by a task is rethrown here once every task has finished.
+    void run(int n_tasks, const std::function<void(int)> &fn)
+    {
+        n_tasks = std::min(n_tasks, n_);
+        if (n_tasks <= 1) {
+            fn(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            tasks_ = n_tasks;
+            pending_ = n_tasks - 1;
+            error_ = nullptr;
+            ++gen_;
+        }
+        wake_.notify_all();
+        std::exception_ptr mine;
+        try { fn(0); } catch (...) { mine = std::current_exception(); }
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this]() { return pending_ == 0; });
+        job_ = nullptr;
+        tasks_ = 0;
+        std::exception_ptr err = mine ? mine : error_;
+        error_ = nullptr;
+        lk.unlock();
+        if (err) std::rethrow_exception(err);
+    }
+
+private:
+    void loop(int t)
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            wake_.wait(lk, [&]() { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            if (t >= tasks_ || !job_) continue;
+            const std::function<void(int)> *job = job_;
+            lk.unlock();
+            std::exception_ptr err;
+            try { (*job)(t); } catch (...) { err = std::current_exception(); }
+            lk.lock();
+            if (err && !error_) error_ = err;
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+
+    const int n_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    int tasks_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+    std::exception_ptr error_;
+};
+
+// fn(worker, begin, end) over [0, n) in one contiguous slice per worker
+template <typename F>
+void parallel_for(Pool &pool, uint64_t n, F fn, int max_workers = 1 << 30)
+{
+    const int workers = std::min(pool.size(), max_workers);
+    if (workers <= 1 || n < 4096) {
+        fn(0, (uint64_t)0, n);
         return;
     }
-    std::vector<std::thread> pool;
-    const uint64_t per = (n + n_threads - 1) / n_threads;
-    for (int t = 0; t < n_threads; ++t) {
+    const uint64_t per = (n + (uint64_t)workers - 1) / (uint64_t)workers;
+    const int used = (int)((n + per - 1) / per);
+    pool.run(used, [&](int t) {
         const uint64_t b = std::min<uint64_t>(n, (uint64_t)t * per), e = std::min<uint64_t>(n, b + per);
-        if (b >= e) break;
-        pool.emplace_back([=]() { fn(t, b, e); });
-    }
-    for (auto &th : pool) th.join();
+        if (b < e) fn(t, b, e);
+    });
+}
+
+// Map the pages of a window before the workers touch them.  A window of a memory-mapped file is first touched here;
+// left to demand faults, sixteen workers take ~65 k minor faults per 256 MB through one address-space lock and the
+// index pass runs at a fraction of its speed.  MADV_POPULATE_READ (Linux >= 5.14) maps the range in bulk; older
+// kernels return EINVAL and the faults happen as before.  Harmless on memory that is already resident.
+void prefault(const char *buf, uint64_t len, Pool &pool)
+{
+    if (!buf || len < (1u << 20)) return;
+    const uintptr_t page = 4096, lo = (uintptr_t)buf & ~(page - 1), hi = ((uintptr_t)buf + len + page - 1) & ~(page - 1);
+    const uint64_t pages = (hi - lo) / page;
+    parallel_for(pool, pages, [&](int, uint64_t b, uint64_t e) {
+        (void)madvise((void *)(lo + b * page), (size_t)((e - b) * page), MADV_POPULATE_READ);
+    }, 8);
 }
 
 // ---- line index: universal newlines ('\n', '\r\n', '\r'), as Python text mode reads them --------------
-void index_lines(const char *buf, uint64_t len, bool eof, int n_threads, FileParse &fp)
+void index_lines(const char *buf, uint64_t len, bool eof, Pool &pool, FileParse &fp)
 {
     // a trailing '\r' might be the first half of "\r\n" continuing in the next window
     uint64_t usable = len;
     if (!eof && len > 0 && buf[len - 1] == '\r') usable = len - 1;
-    if (fp.slots.size() < (size_t)std::max(1, n_threads)) fp.slots.resize((size_t)std::max(1, n_threads));
+    if (fp.slots.size() < (size_t)pool.size()) fp.slots.resize((size_t)pool.size());
     for (auto &sl : fp.slots) { sl.ends.clear(); sl.non_ascii = false; }
-    parallel_for(n_threads, usable, [&](int t, uint64_t b, uint64_t e) {
+    parallel_for(pool, usable, [&](int t, uint64_t b, uint64_t e) {
         auto &v = fp.slots[(size_t)t].ends;
-        bool hi = false;
-        for (uint64_t p = b; p < e; ++p) {
+        uint64_t hi = 0;
+        auto one = [&](uint64_t p) {
             const unsigned char c = (unsigned char)buf[p];
-            hi |= (c & 0x80) != 0;
             if (c == '\n') {
-                if (p > 0 && buf[p - 1] == '\r') continue;          // second half of "\r\n"
+                if (p > 0 && buf[p - 1] == '\r') return;             // second half of "\r\n"
                 v.emplace_back(p, p + 1);
             } else if (c == '\r') {
                 const bool crlf = (p + 1 < len) && buf[p + 1] == '\n';
                 v.emplace_back(p, p + (crlf ? 2 : 1));
             }
+        };
+        // eight bytes at a time: a word is looked at byte by byte only when it holds a '\n' or '\r'
+        const uint64_t ones = 0x0101010101010101ull, tops = 0x8080808080808080ull;
+        uint64_t p = b;
+        for (; p + 8 <= e; p += 8) {
+            uint64_t w;
+            std::memcpy(&w, buf + p, 8);
+            hi |= w;
+            const uint64_t xn = w ^ (ones * (uint64_t)'\n'), xr = w ^ (ones * (uint64_t)'\r');
+            if ((((xn - ones) & ~xn) | ((xr - ones) & ~xr)) & tops)
+                for (uint64_t q = p; q < p + 8; ++q) one(q);
         }
-        fp.slots[(size_t)t].non_ascii = hi;
+        for (; p < e; ++p) {
+            hi |= (uint64_t)(unsigned char)buf[p];
+            one(p);
+        }
+        fp.slots[(size_t)t].non_ascii = (hi & tops) != 0;
     });
     fp.non_ascii = false;
     for (auto &sl : fp.slots) fp.non_ascii |= sl.non_ascii;
@@ -115,21 +278,16 @@ void index_lines(const char *buf, uint64_t len, bool eof, int n_threads, FilePar
         first_start[t] = start;
         if (!fp.slots[t].ends.empty()) start = fp.slots[t].ends.back().second;
     }
-    {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < n_slots; ++t) {
-            if (fp.slots[t].ends.empty()) continue;
-            pool.emplace_back([&, t]() {
-                uint64_t st = first_start[t];
-                Line *dst = fp.lines.data() + base[t];
-                for (auto &pr : fp.slots[t].ends) {
-                    *dst++ = Line{st, (uint32_t)(pr.first - st)};
-                    st = pr.second;
-                }
-            });
+    pool.run((int)std::min<size_t>(n_slots, (size_t)pool.size()), [&](int w) {
+        for (size_t t = (size_t)w; t < n_slots; t += (size_t)pool.size()) {
+            uint64_t st = first_start[t];
+            Line *dst = fp.lines.data() + base[t];
+            for (auto &pr : fp.slots[t].ends) {
+                *dst++ = Line{st, (uint32_t)(pr.first - st)};
+                st = pr.second;
+            }
         }
-        for (auto &th : pool) th.join();
-    }
+    });
     fp.complete_end = start;
     if (eof && start < len) {                                        // last line without a terminator
         fp.lines.push_back(Line{start, (uint32_t)(len - start)});
@@ -200,7 +358,7 @@ void parse_line(const char *s, uint32_t n, int score_mode, uint32_t worker, std:
             continue;
         }
         uint32_t b = i;
-        while (i < n && !is_ws((unsigned char)s[i])) ++i;
+        i = token_end(s, i, n);
         const char *tok = s + b;
         const uint32_t tl = i - b;
         const uint32_t k = r.n_tok++;
@@ -253,13 +411,13 @@ void parse_line(const char *s, uint32_t n, int score_mode, uint32_t worker, std:
     }
 }
 
-void parse_file(const char *buf, int score_mode, int n_threads, FileParse &fp)
+void parse_file(const char *buf, int score_mode, Pool &pool, FileParse &fp)
 {
     const uint64_t n = fp.lines.size();
     fp.recs.resize(n);
-    if (fp.slots.size() < (size_t)std::max(1, n_threads)) fp.slots.resize((size_t)std::max(1, n_threads));
+    if (fp.slots.size() < (size_t)pool.size()) fp.slots.resize((size_t)pool.size());
     for (auto &sl : fp.slots) sl.ops.clear();
-    parallel_for(n_threads, n, [&](int t, uint64_t b, uint64_t e) {
+    parallel_for(pool, n, [&](int t, uint64_t b, uint64_t e) {
         auto &ops = fp.slots[(size_t)t].ops;
         for (uint64_t i = b; i < e; ++i)
             parse_line(buf + fp.lines[i].off, fp.lines[i].len, score_mode, (uint32_t)t, ops, fp.recs[i]);
@@ -276,6 +434,7 @@ inline bool same_name(const char *b1, const FileParse &f1, uint64_t i, const cha
 }  // namespace
 
 struct xmh_parser {
+    std::unique_ptr<Pool> pool;
     int n_threads;
     FileParse f[2];
     std::vector<uint64_t> sel[2];                 // line index of every yielded record, per file
@@ -307,8 +466,14 @@ int xmh_parser_create(int n_threads, xmh_parser **out)
     if (!out) return XMH_ERR_INVALID_ARG;
     xmh_parser *p = new (std::nothrow) xmh_parser();
     if (!p) return XMH_ERR_OOM;
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = xmh_default_threads();
     p->n_threads = std::max(1, std::min(n_threads, 64));
+    try {
+        p->pool.reset(new Pool(p->n_threads));
+    } catch (...) {                                                   // bad_alloc, or no more threads (system_error)
+        delete p;
+        return XMH_ERR_OOM;
+    }
     *out = p;
     return XMH_OK;
 }
@@ -335,12 +500,14 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
         const char *buf[2] = {buf1, buf2};
         const uint64_t len[2] = {len1, len2};
         const int eof[2] = {eof1, eof2};
+        for (int f = 0; f < 2; ++f) prefault(buf[f], len[f], *p->pool);
+        const auto t0b = now();
         for (int f = 0; f < 2; ++f) {
-            index_lines(buf[f], len[f], eof[f] != 0, p->n_threads, p->f[f]);
+            index_lines(buf[f], len[f], eof[f] != 0, *p->pool, p->f[f]);
             if (p->f[f].non_ascii) return XMH_ERR_NON_ASCII;
         }
         const auto t1 = now();
-        for (int f = 0; f < 2; ++f) parse_file(buf[f], score_mode, p->n_threads, p->f[f]);
+        for (int f = 0; f < 2; ++f) parse_file(buf[f], score_mode, *p->pool, p->f[f]);
         const auto t2 = now();
 
         // ---- the lock-step walk (xenomapper.py:103-117) ------------------------------------------------
@@ -358,7 +525,7 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
             // whose names differ -- found in parallel
             const uint64_t lim = std::min<uint64_t>(std::min(L[0], L[1]), max_records);
             std::vector<uint64_t> stop((size_t)std::max(1, p->n_threads), lim);
-            parallel_for(p->n_threads, lim, [&](int t, uint64_t b, uint64_t e) {
+            parallel_for(*p->pool, lim, [&](int t, uint64_t b, uint64_t e) {
                 for (uint64_t k = b; k < e; ++k)
                     if (blank(0, k) || blank(1, k) || !same_name(buf1, p->f[0], k, buf2, p->f[1], k)) { stop[(size_t)t] = k; break; }
             });
@@ -366,7 +533,7 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
             for (uint64_t v : stop) k_stop = std::min(k_stop, v);
             p->sel[0].resize((size_t)k_stop);
             p->sel[1].resize((size_t)k_stop);
-            parallel_for(p->n_threads, k_stop, [&](int, uint64_t b, uint64_t e) {
+            parallel_for(*p->pool, k_stop, [&](int, uint64_t b, uint64_t e) {
                 for (uint64_t k = b; k < e; ++k) p->sel[0][(size_t)k] = p->sel[1][(size_t)k] = k;
             });
             i1 = i2 = k_stop;
@@ -425,7 +592,7 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
             offs[f]->assign(cigar ? n + 1 : 1, 0);
             const FileParse &fp = p->f[f];
             const auto &sel = p->sel[f];
-            parallel_for(p->n_threads, n, [&](int, uint64_t b, uint64_t e) {
+            parallel_for(*p->pool, n, [&](int, uint64_t b, uint64_t e) {
                 for (uint64_t k = b; k < e; ++k) {
                     const Rec &r = fp.recs[sel[k]];
                     (*cols[f][0])[k] = r.a;
@@ -442,7 +609,7 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
                 for (uint64_t k = 0; k < n; ++k) { (*offs[f])[k] = acc; acc += fp.recs[sel[k]].ops_count; }
                 (*offs[f])[n] = acc;
                 opsv[f]->resize((size_t)acc + 4);
-                parallel_for(p->n_threads, n, [&](int, uint64_t b, uint64_t e) {
+                parallel_for(*p->pool, n, [&](int, uint64_t b, uint64_t e) {
                     for (uint64_t k = b; k < e; ++k) {
                         const Rec &r = fp.recs[sel[k]];
                         if (r.ops_count)
@@ -456,7 +623,7 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
         }
         // ---- unit mask (xenomapper.py:402: name equals the previous record's name) -------------------
         p->bits.assign((n + 63) / 64 + 1, 0);
-        parallel_for(p->n_threads, (n + 63) / 64, [&](int, uint64_t wb, uint64_t we) {
+        parallel_for(*p->pool, (n + 63) / 64, [&](int, uint64_t wb, uint64_t we) {
             for (uint64_t w = wb; w < we; ++w) {
                 uint64_t word = 0;
                 const uint64_t k0 = w * 64, k1 = std::min<uint64_t>(n, k0 + 64);
@@ -472,7 +639,7 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
         {
             struct Exc { uint32_t rec; uint8_t col, kind; };
             std::vector<std::vector<Exc>> part((size_t)std::max(1, p->n_threads));
-            parallel_for(p->n_threads, n, [&](int t, uint64_t b, uint64_t e) {
+            parallel_for(*p->pool, n, [&](int t, uint64_t b, uint64_t e) {
                 for (uint64_t k = b; k < e; ++k)
                     for (int f = 0; f < 2; ++f) {
                         const Rec &r = p->f[f].recs[p->sel[f][k]];
@@ -484,8 +651,8 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
                 for (auto &x : v) { p->exc_record.push_back(x.rec); p->exc_col.push_back(x.col); p->exc_kind.push_back(x.kind); }
         }
         if (profile)
-            fprintf(stderr, "xmh_parse: %.1f MB  index %.1f ms  parse %.1f ms  walk+gather %.1f ms\n",
-                    (double)(len1 + len2) / 1e6, ms(t0, t1), ms(t1, t2), ms(t2, now()));
+            fprintf(stderr, "xmh_parse: %.1f MB  prefault %.1f ms  index %.1f ms  parse %.1f ms  walk+gather %.1f ms\n",
+                    (double)(len1 + len2) / 1e6, ms(t0, t0b), ms(t0b, t1), ms(t1, t2), ms(t2, now()));
         out->n_records = n;
         out->ended = ended;
         out->starved = starved;
@@ -556,7 +723,7 @@ int xmh_emit(xmh_parser *p, const char *buf1, const char *buf2, int paired, int 
         const uint64_t *lo[2] = {p->loff1.data(), p->loff2.data()};
         const uint32_t *ll[2] = {p->llen1.data(), p->llen2.data()};
         const uint8_t *lf[2] = {p->lflag1.data(), p->lflag2.data()};
-        parallel_for(p->n_threads, n_idx, [&](int, uint64_t ub, uint64_t ue) {
+        parallel_for(*p->pool, n_idx, [&](int, uint64_t ub, uint64_t ue) {
             for (uint64_t u = ub; u < ue; ++u) {
                 char *d = out + start[u];
                 const uint32_t i = idx[u];

@@ -648,16 +648,18 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     cigar_mode = tag_func is get_cigarbased_AS_tag
     score_mode = _host.SCORE_CIGAR if cigar_mode else (_host.SCORE_AS_ZS if tag_func is get_tag_with_ZS_as_XS
                                                        else _host.SCORE_AS_XS)
+    import time as _time
+    t_all = _time.perf_counter()
     sources = [(_BamSource(path, n_threads) if bam else _SamSource(path)) for path in (path1, path2)]
     # SAM input: two parsers alternate so that the next window is parsed (in a helper thread; the C++ code runs
     # without the GIL) while the GPU classifies and the writer emits the current one.  BAM input decodes into a
     # sliding buffer that the next window() call may move, so it stays sequential.
     parsers = [_host.Parser(n_threads)] if bam else [_host.Parser(n_threads), _host.Parser(n_threads)]
-    import time as _time
     from concurrent.futures import ThreadPoolExecutor
     pool = None if bam else ThreadPoolExecutor(max_workers=1)
-    prof = {"window": 0.0, "parse": 0.0, "classify": 0.0, "compact": 0.0, "emit": 0.0, "write": 0.0, "other": 0.0}
-    t_all = _time.perf_counter()
+    prof = {"open": 0.0, "window": 0.0, "parse": 0.0, "classify": 0.0, "compact": 0.0, "emit": 0.0, "write": 0.0,
+            "close": 0.0, "other": 0.0}
+    prof["open"] = _time.perf_counter() - t_all
     totals, key_order = Counter(), []
     window = FILE_WINDOW_BYTES
     active = [s for s in sinks if s]
@@ -729,7 +731,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         if limit is not None:
                             seg = seg[seg < limit]
                         _t = _time.perf_counter()
-                        text = parser.emit(paired, b, seg)
+                        text = parser.emit(paired, b, seg, reuse=True)
                         prof["emit"] += _time.perf_counter() - _t
                         _t = _time.perf_counter()
                         _write_bytes(sinks[b], text)
@@ -757,12 +759,14 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 future.result()
             except Exception:
                 pass
+        _t = _time.perf_counter()
         if pool is not None:
             pool.shutdown(wait=True)
         for prs in parsers:
             prs.close()
         for src in sources:
             src.close()
+        prof["close"] = _time.perf_counter() - _t
         if os.environ.get("XENOMAPPER_PROFILE"):
             total = _time.perf_counter() - t_all
             prof["other"] = total - sum(prof.values())
