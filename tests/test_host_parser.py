@@ -285,6 +285,98 @@ def test_bam_decoder_reproduces_the_sam_fixture(species, chunk):
     assert hdr + body == sam + "\n"                      # the SAM fixture has no trailing newline
 
 
+def _reblocked_bam(path, chunk, copies):
+    """The alignments of a BAM file, `copies` times over, in BGZF blocks of `chunk` uncompressed bytes (records then
+    straddle blocks, worker ranges and batches at arbitrary places)."""
+    import gzip, struct, zlib
+    raw = gzip.decompress(open(path, "rb").read())
+    l_text, = struct.unpack_from("<i", raw, 4)
+    at = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, at)
+    at += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, at)
+        at += 4 + l_name + 4
+    payload = raw[:at] + raw[at:] * copies
+    out = []
+    for lo in range(0, len(payload), chunk):
+        part = payload[lo:lo + chunk]
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = comp.compress(part) + comp.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" +
+                   struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(part), len(part)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return np.frombuffer(b"".join(out), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("chunk,copies,threads,cap", [(37, 1, 5, 1 << 20), (300, 3, 16, 5000), (4096, 40, 7, 1 << 22),
+                                                      (65280, 40, 16, 1 << 20), (65280, 3, 1, 1 << 16)])
+def test_bam_decoder_with_records_across_blocks_and_workers(chunk, copies, threads, cap):
+    import os
+    from xenomapper_amd import _host
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_human")
+    data = _reblocked_bam(base + ".bam", chunk, copies)
+    r = _host.BamReader(data, threads)
+    buf = np.empty(cap, dtype=np.uint8)
+    parts = []
+    while not r.eof:
+        n = r.read_into(buf, 0)
+        assert n > 0 or r.eof
+        parts.append(bytes(buf[:n]))
+    r.close()
+    with open(base + ".sam") as fh:
+        lines = [l for l in (fh.read() + "\n").splitlines(True) if not l.startswith("@")]
+    assert b"".join(parts).decode("ascii") == "".join(lines) * copies
+
+
+def test_bam_decoder_reports_a_file_that_ends_inside_a_record():
+    import os
+    from xenomapper_amd import _host
+    data = _reblocked_bam(os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_human.bam"), 1000, 1)
+    raw = data.tobytes()
+    cut = raw.rfind(b"\x1f\x8b\x08\x04", 0, len(raw) - 28)       # drop the last data block and the end marker
+    r = _host.BamReader(np.frombuffer(raw[:cut], dtype=np.uint8), 3)
+    buf = np.empty(1 << 20, dtype=np.uint8)
+    with pytest.raises(ValueError):
+        while not r.eof:
+            r.read_into(buf, 0)
+
+
+def test_bam_decoder_zlib_and_libdeflate_agree():
+    """The decoder prefers libdeflate when the shared library is installed; XMH_NO_LIBDEFLATE=1 forces zlib.
+    Both must print the fixture identically (the switch is read once per process, hence the child process)."""
+    import os, subprocess, sys
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_mouse")
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from tests.test_host_parser import _decode_bam\n"
+            "hdr, body = _decode_bam(%r, 1 << 16)\n"
+            "print(hashlib.md5((hdr + body).encode()).hexdigest())" % (H.REPO, base + ".bam"))
+    digests = []
+    for force_zlib in (False, True):
+        env = dict(os.environ)
+        env.pop("XMH_NO_LIBDEFLATE", None)
+        if force_zlib:
+            env["XMH_NO_LIBDEFLATE"] = "1"
+        digests.append(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip())
+    import hashlib
+    with open(base + ".sam") as fh:
+        want = hashlib.md5((fh.read() + "\n").encode()).hexdigest()
+    assert digests == [want, want]
+
+
+def test_bam_decoder_checks_the_block_crc():
+    import os
+    from xenomapper_amd import _host
+    data = np.fromfile(os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_human.bam"), dtype=np.uint8).copy()
+    bsize = int(data[16]) | (int(data[17]) << 8)                  # first block: flip one bit of its CRC-32 trailer
+    data[bsize + 1 - 8] ^= 1
+    with pytest.raises(ValueError):
+        r = _host.BamReader(data)
+        buf = np.empty(1 << 20, dtype=np.uint8)
+        while not r.eof:
+            r.read_into(buf, 0)
+
+
 def test_bam_decoder_rejects_garbage():
     from xenomapper_amd import _host
     with pytest.raises(ValueError):

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""End-to-end BAM -> six SAM files throughput of the file fast path (native BGZF/BAM decoder -> stripper -> GPU -> writer).
+
+    python tools/bench_bam.py --copies 4000
+
+Input: the reference's two paired-end BAM fixtures (tests/golden/ref_data/), their alignment records repeated
+`--copies` times.  The record section is deflated once into BGZF blocks and the same blocks are written again for every
+copy, so building a multi-gigabyte input takes seconds.  Reports read-pairs/s and GB/s of BAM and of decoded SAM text.
+"""
+import argparse
+import gzip
+import json
+import os
+import struct
+import sys
+import time
+import zlib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+DATA = os.path.join(REPO, "tests", "golden", "ref_data")
+
+
+def bgzf_blocks(payload, level=6, chunk=0xff00):
+    out = []
+    for at in range(0, len(payload), chunk):
+        part = payload[at:at + chunk]
+        comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = comp.compress(part) + comp.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" +
+                   struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(part), len(part)))
+    return b"".join(out)
+
+
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def tiled_bam(src, dst, copies):
+    raw = gzip.decompress(open(src, "rb").read())
+    assert raw[:4] == b"BAM\x01"
+    l_text, = struct.unpack_from("<i", raw, 4)
+    at = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, at)
+    at += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, at)
+        at += 4 + l_name + 4
+    head, records = bgzf_blocks(raw[:at]), bgzf_blocks(raw[at:])
+    with open(dst, "wb") as fh:
+        fh.write(head)
+        for _ in range(copies):
+            fh.write(records)
+        fh.write(BGZF_EOF)
+    return len(raw) - at
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--copies", type=int, default=4000)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--dir", default="/dev/shm")
+    a = ap.parse_args()
+    from xenomapper_amd import _host, xenomapper as xm
+    paths = []
+    for tag in ("human", "mouse"):
+        path = os.path.join(a.dir, "xm_bam_%s_%d.bam" % (tag, os.getpid()))
+        tiled_bam(os.path.join(DATA, "paired_end_testdata_%s.bam" % tag), path, a.copies)
+        paths.append(path)
+    size = sum(os.path.getsize(p) for p in paths)
+    sinks = {k: open(os.devnull, "wt") for k in ("primary_specific", "secondary_specific", "primary_multi",
+                                                  "secondary_multi", "unassigned", "unresolved")}
+    try:
+        xm.default_context()
+        for _warm in (True, False):
+            t0 = time.perf_counter()
+            counts = xm.classify_sam_files(paths[0], paths[1], paired=True, n_threads=a.threads, bam=True, **sinks)
+            el = time.perf_counter() - t0
+        units = sum(counts.values())
+        print(json.dumps({"metric": "end-to-end read-pairs/s (BAM in, six SAM files out)", "value": units / el,
+                          "units": units, "seconds": el, "bam_bytes": size, "bam_GBps": size / el / 1e9,
+                          "threads": a.threads or _host.lib().xmh_default_threads()}))
+    finally:
+        for p in paths:
+            os.unlink(p)
+
+
+if __name__ == "__main__":
+    main()

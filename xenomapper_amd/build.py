@@ -50,11 +50,11 @@ def build_host(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
     if not all(os.path.exists(s) for s in srcs):
         return None
-    deps = srcs + [os.path.join(REPO, "include", "xenomapper_host.h")]
+    deps = srcs + [os.path.join(REPO, "include", "xenomapper_host.h"), os.path.join(CSRC, "xm_pool.h")]
     if not force and not _stale(HOST_LIB, deps):
         return HOST_LIB
     cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra",
-           "-I", os.path.join(REPO, "include")] + srcs + ["-o", HOST_LIB, "-lz"]
+           "-I", os.path.join(REPO, "include")] + srcs + ["-o", HOST_LIB, "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -65,7 +65,7 @@ def build_host_sanitized(out_path, verbose=False):
     """ASan + UBSan build of the host library, for CPU-side test runs (GPU ASan is not available on the pool)."""
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fsanitize=address,undefined",
-           "-fno-omit-frame-pointer", "-I", os.path.join(REPO, "include")] + srcs + ["-o", out_path, "-lz"]
+           "-fno-omit-frame-pointer", "-I", os.path.join(REPO, "include")] + srcs + ["-o", out_path, "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -5,15 +5,22 @@
 // the layout `samtools view` prints -- so that everything downstream (column stripper, kernels, writer) is the
 // SAM path unchanged and inherits its parity pins.  BGZF blocks are inflated in parallel (zlib, raw deflate).
 #include "../../include/xenomapper_host.h"
+#include "xm_pool.h"
 
+#include <dlfcn.h>
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
 namespace {
@@ -22,6 +29,7 @@ struct BgzfBlock {
     uint64_t cdata_off;      // offset of the deflate stream in the file image
     uint32_t cdata_len;
     uint32_t isize;          // uncompressed size
+    uint32_t crc;            // CRC-32 of the uncompressed bytes
 };
 
 inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -49,89 +57,206 @@ bool index_blocks(const uint8_t *d, uint64_t len, std::vector<BgzfBlock> &out)
         b.cdata_off = p + 12 + xlen;
         b.cdata_len = (uint32_t)(total - 12 - xlen - 8);
         b.isize = le32(d + p + total - 4);
+        b.crc = le32(d + p + total - 8);
         out.push_back(b);
         p += total;
     }
     return true;
 }
 
-bool inflate_block(const uint8_t *src, uint32_t slen, uint8_t *dst, uint32_t dlen)
+// libdeflate (raw-deflate decoder and CRC-32 two to three times faster than zlib's) is used when the shared library
+// is installed -- looked up at run time, its four entry points declared here because the image ships no header --
+// and zlib otherwise.  XMH_NO_LIBDEFLATE=1 forces zlib.
+struct LibDeflate {
+    void *(*alloc)(void) = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+    void (*release)(void *) = nullptr;
+    bool ok = false;
+    LibDeflate()
+    {
+        if (getenv("XMH_NO_LIBDEFLATE")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        ok = alloc && decompress && crc && release;
+    }
+};
+const LibDeflate &libdeflate()
 {
-    if (dlen == 0) return true;
+    static const LibDeflate lib;
+    return lib;
+}
+
+// one decoder per worker, reused from block to block; the BGZF trailer's CRC-32 is checked like htslib does
+struct Inflater {
     z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) return false;
-    zs.next_in = const_cast<Bytef *>(src);
-    zs.avail_in = slen;
-    zs.next_out = dst;
-    zs.avail_out = dlen;
-    const int rc = inflate(&zs, Z_FINISH);
-    const bool ok = (rc == Z_STREAM_END) && zs.total_out == dlen;
-    inflateEnd(&zs);
-    return ok;
+    bool ready = false;
+    void *fast = nullptr;
+    Inflater() { memset(&zs, 0, sizeof zs); }
+    ~Inflater()
+    {
+        if (ready) inflateEnd(&zs);
+        if (fast) libdeflate().release(fast);
+    }
+    Inflater(const Inflater &) = delete;
+    Inflater &operator=(const Inflater &) = delete;
+
+    bool block(const uint8_t *src, uint32_t slen, uint8_t *dst, uint32_t dlen, uint32_t crc)
+    {
+        if (dlen == 0) return true;                                  // e.g. the end-of-file marker block
+        const LibDeflate &ld = libdeflate();
+        if (ld.ok) {
+            if (!fast && !(fast = ld.alloc())) return false;
+            size_t got = 0;
+            if (ld.decompress(fast, src, slen, dst, dlen, &got) != 0 || got != dlen) return false;
+            return ld.crc(0, dst, dlen) == crc;
+        }
+        if (!ready) {
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            ready = true;
+        } else if (inflateReset(&zs) != Z_OK) {
+            return false;
+        }
+        zs.next_in = const_cast<Bytef *>(src);
+        zs.avail_in = slen;
+        zs.next_out = dst;
+        zs.avail_out = dlen;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.total_out != dlen) return false;
+        return (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, dlen) == crc;
+    }
+};
+
+inline char *put_uint(char *o, uint64_t v)
+{
+    char tmp[20];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *o++ = tmp[--n];
+    return o;
 }
 
-inline void put_int(std::string &s, long long v)
+inline char *put_int(char *o, int64_t v)
 {
-    char buf[24];
-    const int n = snprintf(buf, sizeof buf, "%lld", v);
-    s.append(buf, (size_t)n);
+    if (v < 0) { *o++ = '-'; return put_uint(o, (uint64_t)(-(v + 1)) + 1); }
+    return put_uint(o, (uint64_t)v);
 }
 
-inline void put_real(std::string &s, double v)
+inline char *put_real(char *o, double v) { return o + snprintf(o, 40, "%g", v); }
+
+inline char *put_str(char *o, const std::string &s)
 {
-    char buf[40];
-    const int n = snprintf(buf, sizeof buf, "%g", v);
-    s.append(buf, (size_t)n);
+    memcpy(o, s.data(), s.size());
+    return o + s.size();
 }
+
+struct SeqTable {                      // one packed byte -> its two bases
+    char pair[256][2];
+    SeqTable()
+    {
+        for (int b = 0; b < 256; ++b) { pair[b][0] = "=ACMGRSVTWYHKDBN"[b >> 4]; pair[b][1] = "=ACMGRSVTWYHKDBN"[b & 15]; }
+    }
+};
+const SeqTable SEQ;
+
+// text bytes one alignment record of `size` binary bytes can grow to: the worst ratios are a B:c array element
+// (1 byte -> "-128,"), a CIGAR operation (4 -> 11) and a packed base pair (1 -> 2); the fixed fields add < 128
+inline size_t text_bound(uint32_t size) { return 5 * (size_t)size + 128; }
 
 }  // namespace
+
+// inflated bytes not yet consumed: [pos, end) of one reused, never zero-filled buffer (a std::vector would memset --
+// and page-fault -- every 64 MB batch on one thread before the workers get to write it)
+struct ByteStream {
+    std::unique_ptr<uint8_t[]> buf;
+    size_t cap = 0, pos = 0, end = 0;
+    uint8_t *data() { return buf.get(); }
+    const uint8_t *data() const { return buf.get(); }
+    size_t size() const { return end; }
+    void compact()                       // drop what has been consumed; offsets into the stream change
+    {
+        if (pos == 0) return;
+        memmove(buf.get(), buf.get() + pos, end - pos);
+        end -= pos;
+        pos = 0;
+    }
+    void grow_to(size_t new_end)         // room for [0, new_end); offsets stay valid
+    {
+        if (new_end <= cap) return;
+        const size_t nc = std::max(new_end, cap + cap / 2);
+        std::unique_ptr<uint8_t[]> nb(new uint8_t[nc]);
+        if (end) memcpy(nb.get(), buf.get(), end);
+        buf.swap(nb);
+        cap = nc;
+    }
+};
+
+struct BamWorker {
+    Inflater inf;
+    std::unique_ptr<char[]> text;       // formatted lines of this worker's records (uninitialised storage, reused)
+    size_t text_cap = 0, text_len = 0, n_rec = 0;
+    std::vector<uint64_t> rec;          // stream offsets of this worker's records in the current batch
+    bool ok = true;
+};
 
 struct xmh_bam {
     const uint8_t *data;
     uint64_t len;
     int n_threads;
+    std::unique_ptr<xmh::Pool> pool;
+    std::vector<BamWorker> workers;
     std::vector<BgzfBlock> blocks;
     size_t next_block = 0;              // first block not yet inflated
-    std::vector<uint8_t> stream;        // inflated bytes not yet consumed, starting at stream_pos
-    size_t stream_pos = 0;
+    ByteStream stream;
+    double text_per_byte = 2.0;         // text bytes per binary byte seen so far (sizes the next batch)
     std::string header;                 // SAM header text
     std::vector<std::string> ref_names;
     bool header_done = false;
-    std::string pending;                // formatted text that did not fit the caller's buffer
+    std::vector<char> pending;          // formatted lines that did not fit the caller's buffer, from pending_pos
+    size_t pending_pos = 0;
 
-    bool fill(size_t want)              // make at least `want` bytes available after stream_pos (or reach the end)
+    // make at least `want` bytes available after stream.pos (or reach the end of the file): one parallel pass
+    // over as many blocks as that takes
+    bool fill(size_t want)
     {
-        while (stream.size() - stream_pos < want && next_block < blocks.size()) {
-            if (stream_pos > (64u << 20)) {                      // drop what has been consumed
-                stream.erase(stream.begin(), stream.begin() + (ptrdiff_t)stream_pos);
-                stream_pos = 0;
-            }
-            const size_t batch = std::min<size_t>(blocks.size() - next_block, (size_t)std::max(64, n_threads * 16));
-            std::vector<uint64_t> off(batch + 1);
-            uint64_t acc = stream.size();
-            for (size_t i = 0; i < batch; ++i) { off[i] = acc; acc += blocks[next_block + i].isize; }
-            off[batch] = acc;
-            stream.resize((size_t)acc);
-            std::vector<char> ok((size_t)std::max(1, n_threads), 1);
-            const int nt = (int)std::min<size_t>((size_t)n_threads, batch);
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nt; ++t)
-                pool.emplace_back([&, t]() {
-                    for (size_t i = (size_t)t; i < batch; i += (size_t)nt) {
-                        const BgzfBlock &b = blocks[next_block + i];
-                        if (!inflate_block(data + b.cdata_off, b.cdata_len, stream.data() + off[i], b.isize)) ok[(size_t)t] = 0;
-                    }
-                });
-            for (auto &th : pool) th.join();
-            for (char o : ok)
-                if (!o) return false;
-            next_block += batch;
+        if (stream.size() - stream.pos >= want || next_block >= blocks.size()) return true;
+        std::vector<uint64_t> off;
+        uint64_t acc = stream.size();
+        size_t nb = 0;
+        const size_t least = (size_t)n_threads * 4;              // enough blocks to keep every worker busy
+        while (next_block + nb < blocks.size() && (acc - stream.pos < want || nb < least)) {
+            off.push_back(acc);
+            acc += blocks[next_block + nb].isize;
+            ++nb;
         }
+        stream.grow_to((size_t)acc);
+        stream.end = (size_t)acc;
+        {                                                        // map the compressed bytes of these blocks in bulk
+            const uintptr_t page = 4096, lo = (uintptr_t)(data + blocks[next_block].cdata_off) & ~(page - 1);
+            const BgzfBlock &last = blocks[next_block + nb - 1];
+            const uintptr_t hi = ((uintptr_t)(data + last.cdata_off + last.cdata_len) + page - 1) & ~(page - 1);
+            (void)madvise((void *)lo, (size_t)(hi - lo), MADV_POPULATE_READ);
+        }
+        for (auto &w : workers) w.ok = true;
+        const int nt = (int)std::min<size_t>((size_t)pool->size(), nb);
+        pool->run(nt, [&](int t) {
+            BamWorker &w = workers[(size_t)t];
+            for (size_t i = (size_t)t; i < nb; i += (size_t)nt) {
+                const BgzfBlock &b = blocks[next_block + i];
+                if (!w.inf.block(data + b.cdata_off, b.cdata_len, stream.data() + off[i], b.isize, b.crc)) w.ok = false;
+            }
+        });
+        for (auto &w : workers)
+            if (!w.ok) return false;
+        next_block += nb;
         return true;
     }
-    size_t avail() const { return stream.size() - stream_pos; }
-    const uint8_t *cur() const { return stream.data() + stream_pos; }
+    size_t avail() const { return stream.size() - stream.pos; }
+    const uint8_t *cur() const { return stream.data() + stream.pos; }
 };
 
 namespace {
@@ -144,7 +269,7 @@ bool read_header(xmh_bam *b)
     b->header.assign((const char *)b->cur() + 8, l_text);
     while (!b->header.empty() && b->header.back() == '\0') b->header.pop_back();
     const uint32_t n_ref = le32(b->cur() + 8 + l_text);
-    b->stream_pos += 12 + l_text;
+    b->stream.pos += 12 + l_text;
     for (uint32_t r = 0; r < n_ref; ++r) {
         if (!b->fill(4) || b->avail() < 4) return false;
         const uint32_t l_name = le32(b->cur());
@@ -152,76 +277,81 @@ bool read_header(xmh_bam *b)
         std::string name((const char *)b->cur() + 4, l_name);
         while (!name.empty() && name.back() == '\0') name.pop_back();
         b->ref_names.push_back(name);
-        b->stream_pos += 8 + l_name;
+        b->stream.pos += 8 + l_name;
     }
     b->header_done = true;
     return true;
 }
 
-// one alignment record (without its block_size word) -> one SAM line, the way `samtools view` prints it
-bool format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, std::string &s)
+// one alignment record (without its block_size word) -> one SAM line at o, the way `samtools view` prints it.
+// Returns the end of the line, or nullptr for a malformed record.  o has text_bound(size) bytes of room, plus the
+// longest reference name twice (checked by the caller).
+char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
 {
-    if (size < 32) return false;
+    if (size < 32) return nullptr;
     const int32_t ref_id = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
     const uint32_t l_read_name = r[8], mapq = r[9], n_cigar = le16(r + 12), flag = le16(r + 14);
     const uint32_t l_seq = le32(r + 16);
     const int32_t next_ref = (int32_t)le32(r + 20), next_pos = (int32_t)le32(r + 24), tlen = (int32_t)le32(r + 28);
     uint64_t p = 32;
-    const uint64_t need = p + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq;
-    if (need > size || l_read_name == 0) return false;
-    s.append((const char *)r + p, strnlen((const char *)r + p, l_read_name));
+    const uint64_t need = p + l_read_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+    if (need > size || l_read_name == 0) return nullptr;
+    const size_t nl = strnlen((const char *)r + p, l_read_name);
+    memcpy(o, r + p, nl);
+    o += nl;
     p += l_read_name;
-    s.push_back('\t'); put_int(s, flag);
-    s.push_back('\t');
-    if (ref_id < 0 || (size_t)ref_id >= b->ref_names.size()) s.push_back('*'); else s += b->ref_names[(size_t)ref_id];
-    s.push_back('\t'); put_int(s, (long long)pos + 1);
-    s.push_back('\t'); put_int(s, mapq);
-    s.push_back('\t');
-    if (n_cigar == 0) s.push_back('*');
+    *o++ = '\t'; o = put_uint(o, flag);
+    *o++ = '\t';
+    if (ref_id < 0 || (size_t)ref_id >= b->ref_names.size()) *o++ = '*'; else o = put_str(o, b->ref_names[(size_t)ref_id]);
+    *o++ = '\t'; o = put_int(o, (int64_t)pos + 1);
+    *o++ = '\t'; o = put_uint(o, mapq);
+    *o++ = '\t';
+    if (n_cigar == 0) *o++ = '*';
     for (uint32_t k = 0; k < n_cigar; ++k) {
         const uint32_t v = le32(r + p + 4ull * k);
-        put_int(s, v >> 4);
-        s.push_back("MIDNSHP=XB??????"[v & 15]);
+        o = put_uint(o, v >> 4);
+        *o++ = "MIDNSHP=XB??????"[v & 15];
     }
     p += 4ull * n_cigar;
-    s.push_back('\t');
-    if (next_ref < 0 || (size_t)next_ref >= b->ref_names.size()) s.push_back('*');
-    else if (next_ref == ref_id) s.push_back('=');
-    else s += b->ref_names[(size_t)next_ref];
-    s.push_back('\t'); put_int(s, (long long)next_pos + 1);
-    s.push_back('\t'); put_int(s, tlen);
-    s.push_back('\t');
-    if (l_seq == 0) s.push_back('*');
-    for (uint32_t k = 0; k < l_seq; ++k) {
-        const uint8_t byte = r[p + k / 2];
-        s.push_back("=ACMGRSVTWYHKDBN"[(k & 1) ? (byte & 15) : (byte >> 4)]);
+    *o++ = '\t';
+    if (next_ref < 0 || (size_t)next_ref >= b->ref_names.size()) *o++ = '*';
+    else if (next_ref == ref_id) *o++ = '=';
+    else o = put_str(o, b->ref_names[(size_t)next_ref]);
+    *o++ = '\t'; o = put_int(o, (int64_t)next_pos + 1);
+    *o++ = '\t'; o = put_int(o, tlen);
+    *o++ = '\t';
+    if (l_seq == 0) *o++ = '*';
+    for (uint32_t k = 0; k + 1 < l_seq; k += 2) { memcpy(o, SEQ.pair[r[p + k / 2]], 2); o += 2; }
+    if (l_seq & 1) *o++ = SEQ.pair[r[p + l_seq / 2]][0];
+    p += ((uint64_t)l_seq + 1) / 2;
+    *o++ = '\t';
+    if (l_seq == 0 || r[p] == 0xFF) *o++ = '*';
+    else {
+        for (uint32_t k = 0; k < l_seq; ++k) o[k] = (char)(r[p + k] + 33);
+        o += l_seq;
     }
-    p += (l_seq + 1) / 2;
-    s.push_back('\t');
-    if (l_seq == 0 || r[p] == 0xFF) s.push_back('*');
-    else for (uint32_t k = 0; k < l_seq; ++k) s.push_back((char)(r[p + k] + 33));
     p += l_seq;
     // optional fields
     while (p + 3 <= size) {
-        s.push_back('\t');
-        s.push_back((char)r[p]); s.push_back((char)r[p + 1]); s.push_back(':');
+        *o++ = '\t';
+        *o++ = (char)r[p]; *o++ = (char)r[p + 1]; *o++ = ':';
         const char type = (char)r[p + 2];
         p += 3;
-        auto scalar = [&](char t, bool emit) -> bool {              // advances p; appends the value when emit
+        auto scalar = [&](char t) -> bool {                          // appends one value of type t, advances p
             switch (t) {
-            case 'A': if (p + 1 > size) return false; if (emit) s.push_back((char)r[p]); p += 1; return true;
-            case 'c': if (p + 1 > size) return false; if (emit) put_int(s, (int8_t)r[p]); p += 1; return true;
-            case 'C': if (p + 1 > size) return false; if (emit) put_int(s, r[p]); p += 1; return true;
-            case 's': if (p + 2 > size) return false; if (emit) put_int(s, (int16_t)le16(r + p)); p += 2; return true;
-            case 'S': if (p + 2 > size) return false; if (emit) put_int(s, le16(r + p)); p += 2; return true;
-            case 'i': if (p + 4 > size) return false; if (emit) put_int(s, (int32_t)le32(r + p)); p += 4; return true;
-            case 'I': if (p + 4 > size) return false; if (emit) put_int(s, le32(r + p)); p += 4; return true;
+            case 'A': if (p + 1 > size) return false; *o++ = (char)r[p]; p += 1; return true;
+            case 'c': if (p + 1 > size) return false; o = put_int(o, (int8_t)r[p]); p += 1; return true;
+            case 'C': if (p + 1 > size) return false; o = put_uint(o, r[p]); p += 1; return true;
+            case 's': if (p + 2 > size) return false; o = put_int(o, (int16_t)le16(r + p)); p += 2; return true;
+            case 'S': if (p + 2 > size) return false; o = put_uint(o, le16(r + p)); p += 2; return true;
+            case 'i': if (p + 4 > size) return false; o = put_int(o, (int32_t)le32(r + p)); p += 4; return true;
+            case 'I': if (p + 4 > size) return false; o = put_uint(o, le32(r + p)); p += 4; return true;
             case 'f': {
                 if (p + 4 > size) return false;
                 float f;
                 const uint32_t u = le32(r + p);
                 memcpy(&f, &u, 4);
-                if (emit) put_real(s, f);
+                o = put_real(o, f);
                 p += 4;
                 return true;
             }
@@ -230,34 +360,164 @@ bool format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, std::strin
                 double dv;
                 const uint64_t u = (uint64_t)le32(r + p) | ((uint64_t)le32(r + p + 4) << 32);
                 memcpy(&dv, &u, 8);
-                if (emit) put_real(s, dv);
+                o = put_real(o, dv);
                 p += 8;
                 return true;
             }
             default: return false;
             }
         };
-        if (type == 'A') { s += "A:"; if (!scalar('A', true)) return false; }
-        else if (type == 'c' || type == 'C' || type == 's' || type == 'S' || type == 'i' || type == 'I') { s += "i:"; if (!scalar(type, true)) return false; }
-        else if (type == 'f') { s += "f:"; if (!scalar('f', true)) return false; }
-        else if (type == 'd') { s += "d:"; if (!scalar('d', true)) return false; }
+        if (type == 'A') { *o++ = 'A'; *o++ = ':'; if (!scalar('A')) return nullptr; }
+        else if (type == 'c' || type == 'C' || type == 's' || type == 'S' || type == 'i' || type == 'I') {
+            *o++ = 'i'; *o++ = ':';
+            if (!scalar(type)) return nullptr;
+        }
+        else if (type == 'f') { *o++ = 'f'; *o++ = ':'; if (!scalar('f')) return nullptr; }
+        else if (type == 'd') { *o++ = 'd'; *o++ = ':'; if (!scalar('d')) return nullptr; }
         else if (type == 'Z' || type == 'H') {
-            s.push_back(type); s.push_back(':');
+            *o++ = type; *o++ = ':';
             const size_t l = strnlen((const char *)r + p, (size_t)(size - p));
-            if (p + l >= size) return false;
-            s.append((const char *)r + p, l);
+            if (p + l >= size) return nullptr;
+            memcpy(o, r + p, l);
+            o += l;
             p += l + 1;
         } else if (type == 'B') {
-            if (p + 5 > size) return false;
+            if (p + 5 > size) return nullptr;
             const char sub = (char)r[p];
             const uint32_t cnt = le32(r + p + 1);
             p += 5;
-            s += "B:"; s.push_back(sub);
-            for (uint32_t k = 0; k < cnt; ++k) { s.push_back(','); if (!scalar(sub, true)) return false; }
-        } else return false;
+            *o++ = 'B'; *o++ = ':'; *o++ = sub;
+            for (uint32_t k = 0; k < cnt; ++k) { *o++ = ','; if (!scalar(sub)) return nullptr; }
+        } else return nullptr;
     }
-    s.push_back('\n');
-    return p == size;
+    *o++ = '\n';
+    return p == size ? o : nullptr;
+}
+
+// hand out pending text in whole lines; returns bytes copied (0 when the first pending line does not fit)
+uint64_t take_pending(xmh_bam *b, char *dst, uint64_t cap)
+{
+    const size_t have = b->pending.size() - b->pending_pos;
+    if (have == 0) return 0;
+    size_t take = have;
+    if (take > cap) {
+        const char *base = b->pending.data() + b->pending_pos;
+        const void *nl = cap ? memrchr(base, '\n', (size_t)cap) : nullptr;
+        take = nl ? (size_t)((const char *)nl - base) + 1 : 0;
+    }
+    memcpy(dst, b->pending.data() + b->pending_pos, take);
+    b->pending_pos += take;
+    if (b->pending_pos == b->pending.size()) { b->pending.clear(); b->pending_pos = 0; }
+    return take;
+}
+
+
+// One batch: inflate the next blocks (about `budget` bytes), find the record boundaries and print the records.
+// Worker t owns a contiguous run of blocks.  Record boundaries form a chain (each record's length word gives the
+// next record), which one thread following it through 100 MB written by fifteen other cores pays ~100 ns a hop for;
+// here every worker follows the chain only through the bytes it has just inflated itself, starting where its
+// left-hand neighbour's last record ends (handed over through `chain`), and then prints the records it found.
+// A record belongs to the worker its first byte lies with, even when it runs on into later ranges.
+// On return: text of worker t in workers[t].text (length text_len), stream.pos at the first record not printed,
+// *n_records = records printed, *n_workers = workers used.  false = corrupt input.
+bool produce_batch(xmh_bam *b, size_t budget, size_t *n_records, int *n_workers)
+{
+    ByteStream &st = b->stream;
+    st.compact();                                                  // leftover (a partial record) moves to the front
+    *n_records = 0;
+    *n_workers = 0;
+    std::vector<uint64_t> off;
+    uint64_t acc = st.end;
+    size_t nb = 0;
+    while (b->next_block + nb < b->blocks.size() && acc - st.end < budget) {
+        off.push_back(acc);
+        acc += b->blocks[b->next_block + nb].isize;
+        ++nb;
+    }
+    if (nb == 0 && st.end == 0) return true;                       // nothing left at all
+    const size_t old_end = st.end;
+    st.grow_to((size_t)acc);
+    st.end = (size_t)acc;
+    if (nb) {                                                      // map the compressed bytes of these blocks in bulk
+        const uintptr_t page = 4096, lo = (uintptr_t)(b->data + b->blocks[b->next_block].cdata_off) & ~(page - 1);
+        const BgzfBlock &last = b->blocks[b->next_block + nb - 1];
+        const uintptr_t hi = ((uintptr_t)(b->data + last.cdata_off + last.cdata_len) + page - 1) & ~(page - 1);
+        (void)madvise((void *)lo, (size_t)(hi - lo), MADV_POPULATE_READ);
+    }
+    // contiguous block runs of about equal inflated size; worker 0 also owns the leftover bytes
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)b->pool->size(), nb));
+    std::vector<size_t> first_block((size_t)nt + 1, nb);
+    std::vector<uint64_t> range((size_t)nt + 1, acc);              // worker t scans stream offsets [range[t], range[t+1])
+    first_block[0] = 0;
+    range[0] = 0;
+    {
+        const uint64_t per = (acc - old_end + (uint64_t)nt - 1) / (uint64_t)nt;
+        size_t i = 0;
+        for (int t = 1; t < nt; ++t) {
+            while (i < nb && off[i] - old_end < (uint64_t)t * per) ++i;
+            first_block[(size_t)t] = i;
+            range[(size_t)t] = i < nb ? off[i] : acc;
+        }
+    }
+    for (auto &w : b->workers) { w.ok = true; w.text_len = 0; w.n_rec = 0; }
+    uint8_t *sp = st.data();
+    b->pool->run(nt, [&](int t) {
+        BamWorker &w = b->workers[(size_t)t];
+        for (size_t i = first_block[(size_t)t]; i < first_block[(size_t)t + 1]; ++i) {
+            const BgzfBlock &blk = b->blocks[b->next_block + i];
+            if (!w.inf.block(b->data + blk.cdata_off, blk.cdata_len, sp + off[i], blk.isize, blk.crc)) w.ok = false;
+        }
+    });
+    for (int t = 0; t < nt; ++t)
+        if (!b->workers[(size_t)t].ok) return false;
+    b->next_block += nb;
+
+    size_t longest_ref = 0;
+    for (auto &name : b->ref_names) longest_ref = std::max(longest_ref, name.size());
+    const uint64_t unset = ~(uint64_t)0;
+    std::vector<std::atomic<uint64_t>> chain((size_t)nt + 1);
+    for (auto &c : chain) c.store(unset, std::memory_order_relaxed);
+    chain[0].store(0, std::memory_order_release);
+    const uint64_t end = st.end;
+    b->pool->run(nt, [&](int t) {
+        BamWorker &w = b->workers[(size_t)t];
+        uint64_t p;
+        while ((p = chain[(size_t)t].load(std::memory_order_acquire)) == unset) std::this_thread::yield();
+        const uint64_t first = p, stop = range[(size_t)t + 1];
+        w.rec.clear();
+        while (p < stop && end - p >= 4) {
+            const uint64_t next = p + 4 + (uint64_t)le32(sp + p);
+            if (next > end) break;                                   // the record continues in a later batch
+            w.rec.push_back(p);
+            p = next;
+        }
+        chain[(size_t)t + 1].store(p, std::memory_order_release);
+        if (w.rec.empty()) return;
+        const size_t room = 5 * (size_t)(p - first) + w.rec.size() * (128 + 2 * longest_ref);
+        if (w.text_cap < room) {
+            w.text.reset(new char[room]);
+            w.text_cap = room;
+        }
+        char *o = w.text.get();
+        for (uint64_t at : w.rec) {
+            o = format_record(b, sp + at + 4, le32(sp + at), o);
+            if (!o) { w.ok = false; return; }
+        }
+        w.text_len = (size_t)(o - w.text.get());
+        w.n_rec = w.rec.size();
+    });
+    size_t n = 0, text = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (!b->workers[(size_t)t].ok) return false;
+        n += b->workers[(size_t)t].n_rec;
+        text += b->workers[(size_t)t].text_len;
+    }
+    const uint64_t done = chain[(size_t)nt].load(std::memory_order_acquire);
+    if (n) b->text_per_byte = std::max(1.0, (double)text / (double)done);
+    st.pos = (size_t)done;
+    *n_records = n;
+    *n_workers = nt;
+    return true;
 }
 
 }  // namespace
@@ -268,16 +528,20 @@ int xmh_bam_open(const uint8_t *data, uint64_t len, int n_threads, xmh_bam **out
 {
     if (!data || !out) return XMH_ERR_INVALID_ARG;
     *out = nullptr;
+    xmh_bam *b = nullptr;
     try {
-        xmh_bam *b = new xmh_bam();
+        b = new xmh_bam();
         b->data = data;
         b->len = len;
         if (n_threads <= 0) n_threads = xmh_default_threads();
         b->n_threads = std::max(1, std::min(n_threads, 64));
+        b->pool.reset(new xmh::Pool(b->n_threads));
+        b->workers = std::vector<BamWorker>((size_t)b->n_threads);
         if (!index_blocks(data, len, b->blocks) || !read_header(b)) { delete b; return XMH_ERR_BAD_BAM; }
         *out = b;
         return XMH_OK;
-    } catch (const std::bad_alloc &) {
+    } catch (...) {                                                   // bad_alloc, or no more threads
+        delete b;
         return XMH_ERR_OOM;
     }
 }
@@ -301,29 +565,52 @@ int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eo
 {
     if (!b || !dst || !written || !eof) return XMH_ERR_INVALID_ARG;
     try {
-        uint64_t w = 0;
+        static const bool profile = getenv("XMH_PROFILE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         *eof = 0;
-        if (!b->pending.empty()) {
-            if (b->pending.size() > cap) return XMH_ERR_INVALID_ARG;      // buffer smaller than one line
-            memcpy(dst, b->pending.data(), b->pending.size());
-            w = b->pending.size();
-            b->pending.clear();
-        }
-        std::string line;
-        while (true) {
-            if (!b->fill(4)) return XMH_ERR_BAD_BAM;
-            if (b->avail() < 4) { *eof = (b->avail() == 0); if (!*eof) return XMH_ERR_BAD_BAM; break; }
-            const uint32_t size = le32(b->cur());
-            if (!b->fill(4 + (size_t)size)) return XMH_ERR_BAD_BAM;
-            if (b->avail() < 4 + (size_t)size) return XMH_ERR_BAD_BAM;
-            line.clear();
-            if (!format_record(b, b->cur() + 4, size, line)) return XMH_ERR_BAD_BAM;
-            b->stream_pos += 4 + (size_t)size;
-            if (w + line.size() > cap) { b->pending.swap(line); break; }
-            memcpy(dst + w, line.data(), line.size());
-            w += line.size();
+        uint64_t w = take_pending(b, dst, cap);
+        *written = w;
+        // batches small enough for a worker's share to stay in its cache between inflating, scanning and printing
+        const size_t batch_max = (size_t)b->pool->size() << 21;
+        size_t budget = 0, batches = 0;
+        while (b->pending.empty()) {
+            if (b->next_block >= b->blocks.size() && b->avail() == 0) break;
+            const uint64_t room = cap - w;
+            if (w > 0 && room < (64u << 10)) break;                  // close enough to full
+            const size_t fit = (size_t)((double)room / (b->text_per_byte * 1.02));
+            budget = std::max(budget, std::min(batch_max, std::max<size_t>((size_t)64 << 10, fit)));
+            size_t n_rec = 0;
+            int nt = 0;
+            if (!produce_batch(b, budget, &n_rec, &nt)) return XMH_ERR_BAD_BAM;
+            ++batches;
+            if (n_rec == 0) {
+                if (b->next_block >= b->blocks.size()) {
+                    if (b->avail() == 0) break;                      // only empty blocks (the end-of-file marker) were left
+                    return XMH_ERR_BAD_BAM;                          // the file ends inside a record
+                }
+                budget = b->avail() >= 4 ? std::max(2 * budget, (size_t)le32(b->cur()) + 8) : 2 * budget;
+                continue;                                            // a record longer than the batch: take more blocks
+            }
+            budget = 0;
+            // whole worker buffers while they fit (copied in parallel), the rest becomes pending
+            std::vector<uint64_t> at((size_t)nt + 1, w);
+            int whole = 0;
+            for (; whole < nt && at[(size_t)whole] + b->workers[(size_t)whole].text_len <= cap; ++whole)
+                at[(size_t)whole + 1] = at[(size_t)whole] + b->workers[(size_t)whole].text_len;
+            b->pool->run(whole, [&](int t) {
+                memcpy(dst + at[(size_t)t], b->workers[(size_t)t].text.get(), b->workers[(size_t)t].text_len);
+            });
+            w = at[(size_t)whole];
+            for (int t = whole; t < nt; ++t)
+                b->pending.insert(b->pending.end(), b->workers[(size_t)t].text.get(),
+                                  b->workers[(size_t)t].text.get() + b->workers[(size_t)t].text_len);
+            w += take_pending(b, dst + w, cap - w);
         }
         *written = w;
+        *eof = (b->pending.empty() && b->avail() == 0 && b->next_block >= b->blocks.size()) ? 1 : 0;
+        if (profile)
+            fprintf(stderr, "xmh_bam_read: %.1f MB text in %zu batches, %.1f ms\n", (double)w / 1e6, batches,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         return XMH_OK;
     } catch (const std::bad_alloc &) {
         return XMH_ERR_OOM;

@@ -604,36 +604,50 @@ class _SamSource(object):
 
 
 class _BamSource(object):
-    """Record text of a BAM file: SAM lines decoded on demand into a sliding buffer."""
+    """Record text of a BAM file: SAM lines decoded on demand into one of two buffers.  A refill after advance()
+    moves the unread tail to the *other* buffer and decodes behind it, so the window handed out before stays
+    readable (the writer is still gathering lines from it) while the next one is decoded and parsed."""
+
+    SLACK = 1 << 20
 
     def __init__(self, path, n_threads=0):
         from . import _host
         self.path = path
         self.data = np.memmap(path, dtype=np.uint8, mode="r")
         self.reader = _host.BamReader(self.data, n_threads)
-        self.buf = np.empty(FILE_WINDOW_BYTES + (1 << 20), dtype=np.uint8)
+        self.bufs = [np.empty(FILE_WINDOW_BYTES + self.SLACK, dtype=np.uint8), None]
+        self.cur = 0
         self.start = self.end = 0
+        self.advanced = False
 
     def window(self, want):
+        buf = self.bufs[self.cur]
         if self.end - self.start < want and not self.reader.eof:
             live = self.end - self.start
-            if want + (1 << 20) > self.buf.shape[0]:
-                grown = np.empty(2 * want + (1 << 20), dtype=np.uint8)
-                grown[:live] = self.buf[self.start:self.end]
-                self.buf = grown
-            elif self.start:
-                self.buf[:live] = self.buf[self.start:self.end].copy()
-            self.start, self.end = 0, live
+            if self.advanced:
+                other = self.bufs[self.cur ^ 1]
+                if other is None or other.shape[0] < want + self.SLACK:
+                    other = np.empty(want + self.SLACK, dtype=np.uint8)
+                other[:live] = buf[self.start:self.end]
+                self.cur ^= 1
+                self.bufs[self.cur] = buf = other
+                self.start, self.end, self.advanced = 0, live, False
+            elif want + self.SLACK > buf.shape[0]:                 # a line longer than the window: grow in place
+                grown = np.empty(2 * want + self.SLACK, dtype=np.uint8)
+                grown[:live] = buf[self.start:self.end]
+                self.bufs[self.cur] = buf = grown
+                self.start, self.end = 0, live
             while self.end - self.start < want and not self.reader.eof:
-                got = self.reader.read_into(self.buf, self.end)
+                got = self.reader.read_into(buf, self.end)
                 if got == 0 and not self.reader.eof:
                     break                                          # the next line needs a bigger buffer
                 self.end += got
         n = min(want, self.end - self.start)
-        return self.buf, self.start, n, self.reader.eof and n == self.end - self.start
+        return buf, self.start, n, self.reader.eof and n == self.end - self.start
 
     def advance(self, consumed):
         self.start += consumed
+        self.advanced = self.advanced or consumed > 0
 
     def close(self):
         self.reader.close()
@@ -651,12 +665,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     import time as _time
     t_all = _time.perf_counter()
     sources = [(_BamSource(path, n_threads) if bam else _SamSource(path)) for path in (path1, path2)]
-    # SAM input: two parsers alternate so that the next window is parsed (in a helper thread; the C++ code runs
-    # without the GIL) while the GPU classifies and the writer emits the current one.  BAM input decodes into a
-    # sliding buffer that the next window() call may move, so it stays sequential.
-    parsers = [_host.Parser(n_threads)] if bam else [_host.Parser(n_threads), _host.Parser(n_threads)]
+    # Two parsers alternate so that the next window is decoded (BAM) and parsed in a helper thread -- the C++ code
+    # runs without the GIL -- while the GPU classifies and the writer emits the current one.
+    parsers = [_host.Parser(n_threads), _host.Parser(n_threads)]
     from concurrent.futures import ThreadPoolExecutor
-    pool = None if bam else ThreadPoolExecutor(max_workers=1)
+    pool = ThreadPoolExecutor(max_workers=1)
     prof = {"open": 0.0, "window": 0.0, "parse": 0.0, "classify": 0.0, "compact": 0.0, "emit": 0.0, "write": 0.0,
             "close": 0.0, "other": 0.0}
     prof["open"] = _time.perf_counter() - t_all
@@ -701,8 +714,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             if not last:
                 for f in (0, 1):
                     sources[f].advance(block.consumed[f])
-                if pool is not None:                             # parse the next window while this one is classified
-                    future = pool.submit(parse_next, which ^ 1, window)
+                future = pool.submit(parse_next, which ^ 1, window)   # parse the next window while this one is classified
             flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:n].astype(bool)
             if paired:
                 needed = flags.copy()
@@ -751,8 +763,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 raise pending
             if last:
                 break
-            if pool is not None:
-                which ^= 1
+            which ^= 1
     finally:
         if future is not None:
             try:
@@ -760,8 +771,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             except Exception:
                 pass
         _t = _time.perf_counter()
-        if pool is not None:
-            pool.shutdown(wait=True)
+        pool.shutdown(wait=True)
         for prs in parsers:
             prs.close()
         for src in sources:
