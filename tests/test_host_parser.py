@@ -217,6 +217,58 @@ def test_windowed_walk_equals_whole_file(parser):
     assert got_flags == whole_flags.tolist()
 
 
+def _repeated_name_texts(n_names, seed):
+    """Two single-end SAM bodies over the same names, each name repeated 1-4 times independently per file."""
+    rng = np.random.default_rng(seed)
+    texts = []
+    for f in range(2):
+        reps = rng.integers(1, 5, size=n_names)
+        lines = []
+        for k in range(n_names):
+            for j in range(int(reps[k])):
+                lines.append("r%d\t0\tchr1\t%d\t30\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\tAS:i:%d\tXS:i:%d\n"
+                             % (k, 100 + k, -(k % 50) - 10 * j - f, -(k % 7) - 60))
+        texts.append("".join(lines))
+    return texts
+
+
+@pytest.mark.parametrize("threads", [1, 7])
+def test_skip_repeated_in_parallel_and_in_windows(threads):
+    """skip_repeated_reads on > 4096 lines (every parallel slice boundary falls somewhere inside a run of equal
+    names), whole file and in 3000-byte windows, against the oracle's lock-step reader."""
+    from xenomapper_amd import _host
+    t1, t2 = _repeated_name_texts(6000, 5)
+    want = [int(ORACLE.tag_score(p[0], "AS")) for p in oracle_pairs(t1, t2, True)]
+    assert len(want) == 6000
+    prs = _host.Parser(threads)
+    r1, r2 = (np.frombuffer(t.encode("ascii"), dtype=np.uint8) for t in (t1, t2))
+    whole = prs.parse(r1, 0, len(r1), True, r2, 0, len(r2), True, 0, False, True, False, 1 << 22)
+    assert whole.n == 6000 and whole.ended and whole.mismatch_at == -1
+    assert whole.cols[0].tolist() == want
+    pos, got = [0, 0], []
+    for _ in range(100000):
+        lens = [min(3000, len(r1) - pos[0]), min(3000, len(r2) - pos[1])]
+        eofs = [pos[0] + lens[0] >= len(r1), pos[1] + lens[1] >= len(r2)]
+        b = prs.parse(r1, pos[0], lens[0], eofs[0], r2, pos[1], lens[1], eofs[1], 0, False, True, False, 1 << 22)
+        got += b.cols[0].tolist()
+        if b.ended:
+            break
+        assert b.starved and (b.consumed[0] > 0 or b.consumed[1] > 0)
+        pos = [pos[0] + b.consumed[0], pos[1] + b.consumed[1]]
+    assert got == want
+    # a mismatch and a blank line are found at the right pair, also behind a slice boundary
+    bad = t2.replace("r5000\t", "rX\t")
+    rb = np.frombuffer(bad.encode("ascii"), dtype=np.uint8)
+    blk = prs.parse(r1, 0, len(r1), True, rb, 0, len(rb), True, 0, False, True, False, 1 << 22)
+    assert blk.mismatch_at == 5000 and blk.n == 5000
+    cut = t1.index("r4500\t")
+    blank = t1[:cut] + "\n" + t1[cut:]
+    rc = np.frombuffer(blank.encode("ascii"), dtype=np.uint8)
+    blk = prs.parse(rc, 0, len(rc), True, r2, 0, len(r2), True, 0, False, True, False, 1 << 22)
+    assert blk.ended and blk.n == 4500 and blk.mismatch_at == -1
+    prs.close()
+
+
 def test_worker_count_does_not_change_the_result():
     """Enough lines for every parallel phase to split (> 4096), parsed and written with 1, 3 and 7 workers."""
     import os

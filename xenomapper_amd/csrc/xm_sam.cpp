@@ -448,26 +448,58 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
                 if (end1 || end2) ended = 1; else starved = 1;
             }
         }
-        while (skip_repeated && p->sel[0].size() < max_records) {
-            if (i1 >= L[0] || i2 >= L[1]) {
-                const bool end1 = i1 >= L[0] && whole[0], end2 = i2 >= L[1] && whole[1];
+        if (skip_repeated) {
+            // Each file is cut into runs of adjacent lines with one name (a blank line is a run of its own: it stops the
+            // skipping, :110-117); pair k is the first line of run k of both files.  Run starts are collected in
+            // parallel; the walk then stops at the first k that is blank, mismatched, or whose run reaches the end of
+            // a window that is not the end of the file (the run may continue in the next window) -- in that order.
+            const char *bufs[2] = {buf1, buf2};
+            for (int f = 0; f < 2; ++f) {
+                const FileParse &fp = p->f[f];
+                const char *bf = bufs[f];
+                auto is_start = [&](uint64_t i) {
+                    return i == 0 || blank(f, i) || blank(f, i - 1) || !same_name(bf, fp, i, bf, fp, i - 1);
+                };
+                std::vector<uint64_t> cnt((size_t)p->pool->size() + 1, 0);
+                parallel_for(*p->pool, L[f], [&](int t, uint64_t b, uint64_t e) {
+                    uint64_t c = 0;
+                    for (uint64_t i = b; i < e; ++i) c += is_start(i) ? 1 : 0;
+                    cnt[(size_t)t + 1] = c;
+                });
+                for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+                p->sel[f].resize((size_t)cnt.back());
+                parallel_for(*p->pool, L[f], [&](int t, uint64_t b, uint64_t e) {     // same slices as the counting pass
+                    uint64_t w = cnt[(size_t)t];
+                    for (uint64_t i = b; i < e; ++i)
+                        if (is_start(i)) p->sel[f][(size_t)w++] = i;
+                });
+            }
+            const uint64_t R[2] = {p->sel[0].size(), p->sel[1].size()};
+            const uint64_t lim = std::min<uint64_t>(std::min(R[0], R[1]), max_records);
+            const auto &s0 = p->sel[0], &s1 = p->sel[1];
+            auto open_run = [&](uint64_t k) { return (k + 1 == R[0] && !whole[0]) || (k + 1 == R[1] && !whole[1]); };
+            std::vector<uint64_t> stop((size_t)p->pool->size(), lim);
+            parallel_for(*p->pool, lim, [&](int t, uint64_t b, uint64_t e) {
+                for (uint64_t k = b; k < e; ++k)
+                    if (blank(0, s0[k]) || blank(1, s1[k]) || !same_name(buf1, p->f[0], s0[k], buf2, p->f[1], s1[k]) || open_run(k)) {
+                        stop[(size_t)t] = k;
+                        break;
+                    }
+            });
+            uint64_t k_stop = lim;
+            for (uint64_t v : stop) k_stop = std::min(k_stop, v);
+            if (k_stop < lim) {
+                if (blank(0, s0[k_stop]) || blank(1, s1[k_stop])) ended = 1;
+                else if (!same_name(buf1, p->f[0], s0[k_stop], buf2, p->f[1], s1[k_stop])) mismatch = (int64_t)k_stop;
+                else starved = 1;
+            } else if (k_stop < max_records) {
+                const bool end1 = R[0] == lim && whole[0], end2 = R[1] == lim && whole[1];
                 if (end1 || end2) ended = 1; else starved = 1;
-                break;
             }
-            if (blank(0, i1) || blank(1, i2)) { ended = 1; break; }
-            if (!same_name(buf1, p->f[0], i1, buf2, p->f[1], i2)) { mismatch = (int64_t)p->sel[0].size(); break; }
-            uint64_t j1 = i1 + 1, j2 = i2 + 1;
-            if (skip_repeated) {
-                // each file moves past further lines with the name just yielded; a blank line stops the skipping
-                while (j1 < L[0] && !blank(0, j1) && same_name(buf1, p->f[0], j1, buf1, p->f[0], i1)) ++j1;
-                while (j2 < L[1] && !blank(1, j2) && same_name(buf2, p->f[1], j2, buf2, p->f[1], i2)) ++j2;
-                // the run must be seen to end inside the window, or the pair waits for the next window
-                if ((j1 >= L[0] && !whole[0]) || (j2 >= L[1] && !whole[1])) { starved = 1; break; }
-            }
-            p->sel[0].push_back(i1);
-            p->sel[1].push_back(i2);
-            i1 = j1;
-            i2 = j2;
+            i1 = k_stop < R[0] ? s0[k_stop] : L[0];
+            i2 = k_stop < R[1] ? s1[k_stop] : L[1];
+            p->sel[0].resize((size_t)k_stop);
+            p->sel[1].resize((size_t)k_stop);
         }
         const uint64_t n = p->sel[0].size();
 
