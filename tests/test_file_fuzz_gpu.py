@@ -38,8 +38,8 @@ def oracle_run(t1, t2, mode, scorer, m, skip):
 @settings(max_examples=int(os.environ.get('XM_FUZZ_EXAMPLES', '250')), deadline=None, suppress_health_check=list(HealthCheck))
 @given(texts=sam_pair(), mode=st.sampled_from(["se", "pe", "pe_conservative"]),
        func=st.sampled_from(sorted(SCORERS)), m=st.sampled_from([NEG, 0.0, -12.5, 3.0]), skip=st.booleans(),
-       via_files=st.booleans())
-def test_random_inputs_behave_like_the_oracle(texts, mode, func, m, skip, via_files):
+       via=st.sampled_from(["files", "api", "python"]))
+def test_random_inputs_behave_like_the_oracle(texts, mode, func, m, skip, via):
     from xenomapper_amd import xenomapper as xm
     t1, t2 = texts
     want_texts, want_counts, want_err = oracle_run(t1, t2, mode, SCORERS[func], m, skip)
@@ -54,15 +54,17 @@ def test_random_inputs_behave_like_the_oracle(texts, mode, func, m, skip, via_fi
         with open(p2, "w", newline="") as f:
             f.write(t2)
         try:
-            if via_files:
+            if via == "files":
                 counts = xm.classify_sam_files(p1, p2, paired=mode != "se", conservative=mode == "pe_conservative",
                                                min_score=m, tag_func=getattr(xm, func), skip_repeated_reads=skip, **outs)
             else:
                 loop = {"se": xm.main_single_end, "pe": xm.main_paired_end,
                         "pe_conservative": xm.conservative_main_paired_end}[mode]
                 with open(p1) as f1, open(p2) as f2:
-                    counts = loop(xm.getReadPairs(f1, f2, skip_repeated_reads=skip), min_score=m,
-                                  tag_func=getattr(xm, func), **outs)
+                    pairs = xm.getReadPairs(f1, f2, skip_repeated_reads=skip)    # regular files: the C++ text path
+                    if via == "python":
+                        pairs = (pr for pr in pairs)                             # any other iterable: split in Python
+                    counts = loop(pairs, min_score=m, tag_func=getattr(xm, func), **outs)
         except OverflowError:
             return                       # a CIGAR length / NM beyond the packed columns: documented limit
         except Exception as exc:

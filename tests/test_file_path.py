@@ -73,6 +73,67 @@ def test_small_windows(name, window, tmp_path):
     check(xm, {c["name"]: c for c in G3}[name], tmp_path, window=window)
 
 
+@pytest.mark.parametrize("name", ["ref_pe_liberal", "ref_se_skip_repeated", "all36_conservative", "cfg3_pe_cigar",
+                                   "cfg5_pe_zs_conservative", "all36_se_skip"])
+def test_reference_style_calls_on_regular_files_take_the_file_path(name, tmp_path, monkeypatch):
+    """process_headers + main_*(getReadPairs(f1, f2)) on open files, the way the reference's main() drives them,
+    must reach the C++ stripper (not the line-by-line Python loop) and still give the golden outputs."""
+    from xenomapper_amd import xenomapper as xm
+    case = {c["name"]: c for c in G3}[name]
+    t1, t2 = H.case_texts(case)
+    p1, p2 = tmp_path / "a.sam", tmp_path / "b.sam"
+    p1.write_text(t1, newline="")
+    p2.write_text(t2, newline="")
+    calls = []
+    real = xm._run_files
+    monkeypatch.setattr(xm, "_run_files", lambda *a, **k: (calls.append(k.get("starts")), real(*a, **k))[1])
+    outs = {n: open(tmp_path / (n + ".sam"), "wt") for n in H.STATES}
+    hdr = outs if case["options"]["header_sinks"] == "all" else {k: outs[k] for k in ("primary_specific", "secondary_specific")}
+    loop = {"se": xm.main_single_end, "pe": xm.main_paired_end, "pe_conservative": xm.conservative_main_paired_end}[case["mode"]]
+    with open(p1, "rt") as f1, open(p2, "rt") as f2:
+        xm.process_headers(f1, f2, **hdr)
+        universal = f1.newlines in (None, "\n") and f2.newlines in (None, "\n")
+        counts = loop(xm.getReadPairs(f1, f2, skip_repeated_reads=case["options"]["skip_repeated"]),
+                      min_score=H.unnum(case["options"]["min_score"]), tag_func=getattr(xm, case["options"]["tag_func"]), **outs)
+        assert f1.read() == "" or not universal
+    assert len(calls) == (1 if universal else 0)
+    for sink in outs.values():
+        sink.close()
+    flat = {("|".join(k) if isinstance(k, tuple) else k): v for k, v in counts.items()}
+    assert flat == case["expect"]["counts"]
+    for n in H.STATES:
+        text = (tmp_path / (n + ".sam")).read_text()
+        assert hashlib.sha224(text.encode("latin-1")).hexdigest() == case["expect"]["bins"][n]["sha224"], n
+
+
+def test_reference_style_calls_keep_to_python_when_the_offset_cannot_be_trusted(tmp_path, monkeypatch):
+    """CRLF files (the header lines already showed a '\\r'), StringIO sources and custom plugins stay on the generic
+    loop; the results are the same as for the LF files."""
+    from xenomapper_amd import xenomapper as xm
+    case = {c["name"]: c for c in G3}["ref_pe_liberal"]
+    t1, t2 = H.case_texts(case)
+    monkeypatch.setattr(xm, "_run_files", lambda *a, **k: pytest.fail("file path taken"))
+    want = None
+    for variant in ("crlf", "stringio", "plugin"):
+        out = io.StringIO()
+        if variant == "stringio":
+            f1, f2 = io.StringIO(t1), io.StringIO(t2)
+        else:
+            nl = "\r\n" if variant == "crlf" else "\n"
+            (tmp_path / "a.sam").write_text(t1.replace("\n", nl), newline="")
+            (tmp_path / "b.sam").write_text(t2.replace("\n", nl), newline="")
+            f1, f2 = open(tmp_path / "a.sam", "rt"), open(tmp_path / "b.sam", "rt")
+        with f1, f2:
+            xm.get_sam_header(f1), xm.get_sam_header(f2)
+            tag_func = (lambda line, tag="AS": xm.get_tag(line, tag)) if variant == "plugin" else xm.get_tag
+            counts = xm.main_paired_end(xm.getReadPairs(f1, f2), primary_specific=out, tag_func=tag_func)
+        got = (dict(counts), out.getvalue())
+        want = want or got
+        assert got == want
+    flat = {"|".join(k): v for k, v in want[0].items()}
+    assert flat == case["expect"]["counts"]
+
+
 def test_string_sinks(tmp_path):
     from xenomapper_amd import xenomapper as xm
     check(xm, {c["name"]: c for c in G3}["all36_liberal"], tmp_path, string_sinks=True)
@@ -100,7 +161,7 @@ def test_exceptional_values_and_errors(tmp_path):
     with open(p1) as f1, open(p2) as f2:
         xm.get_sam_header(f1), xm.get_sam_header(f2)
         ref_out = io.StringIO()
-        want = xm.main_single_end(xm.getReadPairs(f1, f2), primary_specific=ref_out, min_score=4.5)
+        want = xm.main_single_end((pr for pr in xm.getReadPairs(f1, f2)), primary_specific=ref_out, min_score=4.5)
     assert counts == want and out.getvalue() == ref_out.getvalue()
     # duplicate tag match -> ValueError after the records before it were written
     l1 = [_rec("a", "AS:i:9"), _rec("b", "AS:i:9"), _rec("c", "AS:i:5", "RG:Z:BASS"), _rec("d", "AS:i:9")]

@@ -22,6 +22,7 @@ written before the exception propagates, as with the reference.
 from __future__ import annotations
 
 import argparse
+import io
 import math
 import os
 import re
@@ -125,18 +126,74 @@ def _lockstep(next1, next2, skip_repeated_reads):
             rec1, rec2 = next1(), next2()
 
 
+class _ReadPairs(object):
+    """What getReadPairs / getBamReadPairs return: the reference's generator, which also remembers its sources.
+    Handed untouched to main_single_end / main_paired_end / conservative_main_paired_end with a built-in tag_func,
+    two regular files go through the C++ stripper and writer (_run_files) instead of being split line by line in
+    Python -- same outputs, same exceptions."""
+
+    def __init__(self, make, sources, skip_repeated_reads, bam):
+        self._make = make
+        self._it = None
+        self.sources = sources
+        self.skip_repeated_reads = skip_repeated_reads
+        self.bam = bam
+
+    @property
+    def started(self):
+        return self._it is not None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._it is None:
+            self._it = self._make()
+        return next(self._it)
+
+    def file_backed(self):
+        """(path1, path2, start offsets) when both sources are distinct regular files positioned at a byte offset
+        this module can trust, else None."""
+        if self.started or os.environ.get("XENOMAPPER_PYTHON_READER") or self.sources[0] is self.sources[1]:
+            return None
+        paths, starts = [], []
+        for f in self.sources:
+            name = getattr(f, "name", None)
+            if not isinstance(name, str) or not os.path.isfile(name):
+                return None
+            try:
+                pos = f.tell()
+            except (OSError, ValueError):
+                return None
+            if self.bam:
+                if not isinstance(f, (io.BufferedReader, io.FileIO)) or pos != 0:
+                    return None
+            else:
+                # a text-mode tell() is the byte offset only while the decoder holds no state (then it is < size);
+                # universal newlines is the mode the stripper implements, so a '\r' seen so far rules the file out
+                if not isinstance(f, io.TextIOWrapper) or f.newlines not in (None, "\n"):
+                    return None
+                if (f.encoding or "").lower().replace("-", "").replace("_", "") not in ("utf8", "ascii", "usascii", "latin1", "iso88591"):
+                    return None
+                if not 0 <= pos <= os.path.getsize(name):
+                    return None
+            paths.append(name)
+            starts.append(pos)
+        return paths[0], paths[1], starts
+
+
 def getReadPairs(sam1, sam2, skip_repeated_reads=False):
     """Yield (fields1, fields2) for the same read from two SAM streams (ref :95-118).
 
     Fields are split on any whitespace; iteration ends at the first blank line or EOF of either
     stream; names must agree (AssertionError); with skip_repeated_reads each stream skips further
     lines that carry the name just yielded."""
-    return _lockstep(lambda: sam1.readline().strip("\n").split(),
-                     lambda: sam2.readline().strip("\n").split(), skip_repeated_reads)
+    return _ReadPairs(lambda: _lockstep(lambda: sam1.readline().strip("\n").split(),
+                                        lambda: sam2.readline().strip("\n").split(), skip_repeated_reads),
+                      (sam1, sam2), skip_repeated_reads, False)
 
 
-def getBamReadPairs(bamfile1, bamfile2, skip_repeated_reads=False):
-    """As getReadPairs for BAM input (ref :66-93); decoded natively instead of through samtools."""
+def _bam_lockstep(bamfile1, bamfile2, skip_repeated_reads):
     it1, it2 = bam_lines(bamfile1), bam_lines(bamfile2)
 
     class _Done(Exception):
@@ -154,6 +211,12 @@ def getBamReadPairs(bamfile1, bamfile2, skip_repeated_reads=False):
             yield pair
     except _Done:
         return
+
+
+def getBamReadPairs(bamfile1, bamfile2, skip_repeated_reads=False):
+    """As getReadPairs for BAM input (ref :66-93); decoded natively instead of through samtools."""
+    return _ReadPairs(lambda: _bam_lockstep(bamfile1, bamfile2, skip_repeated_reads), (bamfile1, bamfile2),
+                      skip_repeated_reads, True)
 
 
 def add_pg_tag(sam_header_list, comment=None):
@@ -433,6 +496,15 @@ def _emit_block(block, mode, code, idx, off, sinks, limit):
 
 
 def _run(mode, readpairs, sinks, min_score, tag_func):
+    if isinstance(readpairs, _ReadPairs) and tag_func in (get_tag, get_tag_with_ZS_as_XS, get_cigarbased_AS_tag):
+        backed = readpairs.file_backed()
+        if backed is not None:
+            try:
+                return _run_files(mode, backed[0], backed[1], sinks, min_score, tag_func, readpairs.skip_repeated_reads,
+                                  bam=readpairs.bam, starts=None if readpairs.bam else backed[2])
+            finally:
+                for f in readpairs.sources:                       # the records have been consumed
+                    f.seek(0, 2)
     ctx = default_context()
     paired = mode != _ffi.MODE_SE
     cigar_mode = tag_func is get_cigarbased_AS_tag
@@ -587,10 +659,10 @@ def _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode):
 class _SamSource(object):
     """Record text of a SAM file: windows of a read-only memory map."""
 
-    def __init__(self, path):
+    def __init__(self, path, start=None):
         self.path = path
         self.raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
-        self.pos = _record_start(self.raw)
+        self.pos = _record_start(self.raw) if start is None else int(start)
 
     def window(self, want):
         n = min(want, self.raw.shape[0] - self.pos)
@@ -653,7 +725,7 @@ class _BamSource(object):
         self.reader.close()
 
 
-def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_threads=0, bam=False):
+def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_threads=0, bam=False, starts=None):
     """The three main loops on two SAM (or BAM) *files*: same results as _run(mode, getReadPairs(...)), with the
     text work done by the C++ stripper / writer.  Falls back to the Python reader when the input is not ASCII."""
     from . import _host
@@ -664,7 +736,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                                                        else _host.SCORE_AS_XS)
     import time as _time
     t_all = _time.perf_counter()
-    sources = [(_BamSource(path, n_threads) if bam else _SamSource(path)) for path in (path1, path2)]
+    sources = [(_BamSource(path, n_threads) if bam else _SamSource(path, None if starts is None else starts[k]))
+               for k, path in enumerate((path1, path2))]
     # Two parsers alternate so that the next window is decoded (BAM) and parsed in a helper thread -- the C++ code
     # runs without the GIL -- while the GPU classifies and the writer emits the current one.
     parsers = [_host.Parser(n_threads), _host.Parser(n_threads)]
@@ -853,7 +926,9 @@ def _finish_in_python(mode, path1, path2, pos, sinks, min_score, tag_func, skip_
     with open(path1, "rt") as f1, open(path2, "rt") as f2:
         f1.seek(pos[0])
         f2.seek(pos[1])
-        rest = _run(mode, getReadPairs(f1, f2, skip_repeated_reads=skip_repeated), sinks, min_score, tag_func)
+        pairs = _lockstep(lambda: f1.readline().strip("\n").split(), lambda: f2.readline().strip("\n").split(),
+                          skip_repeated)                          # a plain generator: _run must not come back here
+        rest = _run(mode, pairs, sinks, min_score, tag_func)
     ordered = Counter()
     for key in key_order:
         ordered[key] = totals[key]
