@@ -143,3 +143,31 @@ def test_headers_summary_and_reader():
         list(xm.getReadPairs(a, b))
     with pytest.raises(IndexError):
         xm.get_sam_header(io.StringIO("@HD\tVN:1.0\n"))
+
+
+def test_write_bytes_reaches_every_kind_of_sink(tmp_path):
+    """Bin texts reach text files (through the binary buffer, in order with text written around them), sinks whose
+    encoding is not an ASCII superset, and StringIO unchanged."""
+    import io
+    import numpy as np
+    from xenomapper_amd import xenomapper as xm
+    data = np.random.default_rng(3).integers(32, 127, size=100_003, dtype=np.uint8)
+    body = data.tobytes()
+    path = tmp_path / "out.sam"
+    with open(path, "wt") as f:
+        f.write("@HD\tVN:1.0\n")
+        xm._write_bytes(f, data)
+        f.write("between\n")
+        xm._write_bytes(f, data[:100])
+        xm._write_bytes(f, data[:0])
+        f.write("end\n")
+    assert path.read_bytes() == b"@HD\tVN:1.0\n" + body + b"between\n" + body[:100] + b"end\n"
+    with open(path, "at") as f:
+        xm._write_bytes(f, data)
+    assert path.read_bytes().endswith(b"end\n" + body)
+    with open(path, "wt", encoding="utf-16") as f:
+        xm._write_bytes(f, data[:50])
+    assert path.read_text(encoding="utf-16") == body[:50].decode("ascii")
+    s = io.StringIO()
+    xm._write_bytes(s, data[:77])
+    assert s.getvalue() == body[:77].decode("ascii")

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--mode", default="liberal", choices=("liberal", "conservative", "se"))
     ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--out-dir", default=None, help="write the six outputs to real files here (default: /dev/null)")
     a = ap.parse_args()
     from xenomapper_amd import _host, synth, xenomapper as xm
     base = 50_000
@@ -41,21 +42,32 @@ def main():
                 fh.write(body)
         paths.append(path)
     size = sum(os.path.getsize(p) for p in paths)
-    sinks = {k: open(os.devnull, "wt") for k in ("primary_specific", "secondary_specific", "primary_multi",
-                                                  "secondary_multi", "unassigned", "unresolved")}
+    names = ("primary_specific", "secondary_specific", "primary_multi", "secondary_multi", "unassigned", "unresolved")
+    out_paths = [os.path.join(a.out_dir, "xm_e2e_out_%s_%d.sam" % (k, os.getpid())) for k in names] if a.out_dir else []
+    sinks = {k: open(out_paths[i] if a.out_dir else os.devnull, "wt") for i, k in enumerate(names)}
     try:
         xm.default_context()
         for warm in (True, False):
+            for sink in sinks.values():
+                if a.out_dir:
+                    sink.seek(0)
+                    sink.truncate()
             t0 = time.perf_counter()
             counts = xm.classify_sam_files(paths[0], paths[1], paired=a.mode != "se", conservative=a.mode == "conservative",
                                            n_threads=a.threads, **sinks)
+            for sink in sinks.values():
+                sink.flush()
             el = time.perf_counter() - t0
         units = sum(counts.values())
         print(json.dumps({"metric": "end-to-end read-pairs/s (SAM text in, six SAM files out)", "value": units / el,
                           "units": units, "seconds": el, "input_bytes": size, "input_GBps": size / el / 1e9,
-                          "threads": a.threads or _host.lib().xmh_default_threads(), "mode": a.mode}))
+                          "threads": a.threads or _host.lib().xmh_default_threads(), "mode": a.mode,
+                          "outputs": "files" if a.out_dir else "/dev/null",
+                          "output_bytes": sum(os.path.getsize(p) for p in out_paths)}))
     finally:
-        for p in paths:
+        for sink in sinks.values():
+            sink.close()
+        for p in paths + out_paths:
             os.unlink(p)
 
 

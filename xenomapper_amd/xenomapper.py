@@ -613,12 +613,19 @@ def _record_start(raw):
     return pos
 
 
+_ASCII_SUPERSETS = ("utf8", "ascii", "usascii", "latin1", "iso88591", "cp1252", "ansix3.41968")
+
+
 def _write_bytes(sink, data):
-    """Append ASCII bytes to a text sink (through its binary buffer when it has one)."""
+    """Append ASCII bytes to a text sink: through its binary buffer when it has one and its encoding leaves ASCII
+    alone, else as decoded text.  (Writing one bin's text with several positional writes, or from a writer thread,
+    was tried and bought nothing: buffered writes to one file serialise on its inode lock, ~5 GB/s on tmpfs, and the
+    host threads are already at the CPU quota.)"""
     if data is None or len(data) == 0:
         return
     raw = getattr(sink, "buffer", None)
-    if raw is not None:
+    enc = (getattr(sink, "encoding", None) or "").lower().replace("-", "").replace("_", "")
+    if raw is not None and enc in _ASCII_SUPERSETS:
         sink.flush()
         raw.write(memoryview(data))
     else:
