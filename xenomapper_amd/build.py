@@ -38,8 +38,9 @@ def build_hip(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, "xm_kernels.h"), os.path.join(REPO, "include", "xenomapper_hip.h")]
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB
+    # XENOMAPPER_HIPCC_FLAGS: extra flags for tuning builds (e.g. -DXM_CIGAR_BLOCK=256); not used by the tests
     cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-           "-I", os.path.join(REPO, "include")] + srcs + ["-o", HIP_LIB]
+           "-I", os.path.join(REPO, "include")] + os.environ.get("XENOMAPPER_HIPCC_FLAGS", "").split() + srcs + ["-o", HIP_LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

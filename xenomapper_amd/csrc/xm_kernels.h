@@ -14,6 +14,9 @@
 #define XM_MAX_CHUNKS ((uint32_t)((0xFFFFF000ull + XM_CHUNK - 1) / XM_CHUNK))
 #define XM_COUNT_REPLICAS 64u // K2a adds category_counts into one of 64 copies; K2b sums them
 #define XM_CLASSIFY_BLOCK 512  // classify workgroup (tuned on the box with tools/tune_kernels.hip)
+#ifndef XM_CIGAR_BLOCK
+#define XM_CIGAR_BLOCK 256     // classify_cigar workgroup (128: 0.650, 256: 0.626, 512: 0.649, 1024: 0.754 ms per 50 M pairs)
+#endif
 #define XM_CLASSIFY_NT true    // non-temporal loads of the score columns in classify
 
 namespace xm {

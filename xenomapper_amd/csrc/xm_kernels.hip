@@ -63,6 +63,7 @@ __device__ __forceinline__ uint32_t bin_of_code(int mode, uint32_t c)
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct Vec4;
 typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
+typedef int32_t v4i32_a4 __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
 typedef double  v4f64 __attribute__((ext_vector_type(4)));
 template <> struct Vec4<int32_t> { typedef v4i32 type; };
 template <> struct Vec4<double>  { typedef v4f64 type; };
@@ -754,6 +755,62 @@ __device__ __forceinline__ bool cigar_finish_scores(const uint32_t *__restrict__
     return bad;
 }
 
+// The usual case, op-parallel: the wave's records own one contiguous stretch of the op array, [o[0] of lane 0,
+// o[4] of lane 63).  Every lane loads four consecutive ops of it with one 16-byte load (coalesced, instead of one
+// 12-byte gather per record), turns them into penalty terms, and a wave prefix sum of the terms goes to LDS as table
+// T; a record's penalty is then T[end] - T[begin].  Exact while a record's terms sum below 2^32: guaranteed by the
+// wave-uniform guards (no op longer than 2^20, no record with more than 512 ops); a wave that trips one of them, or
+// whose stretch has XM_CIG_WAVE_OPS ops or more, returns false and takes the per-record path above.
+#define XM_CIG_WAVE_OPS 1024
+__device__ __forceinline__ bool cigar_scores_by_prefix(const uint32_t *__restrict__ ops, uint32_t n_ops, const int32_t nmv[4],
+                                                       const uint32_t o[5], uint32_t *T, int32_t as_out[4], bool &bad)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t base = __builtin_amdgcn_readfirstlane(o[0]);
+    const uint32_t W = lane_value(o[4], 63) - base;
+    bool odd = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) odd |= (o[j + 1] - o[j]) > 512u;
+    if (W >= (uint32_t)XM_CIG_WAVE_OPS || __ballot(odd) != 0ull) return false;
+    uint32_t carry = 0;
+    const uint32_t chunks = W / 256u + 1u;                              // slot W (the grand total) is written too
+    for (uint32_t c = 0; c < chunks; ++c) {
+        const uint32_t s0 = c * 256u + 4u * lane;
+        uint32_t v[4];
+        if (base + (c + 1u) * 256u <= n_ops) {                          // wave-uniform: the chunk lies inside the array
+            const v4i32 q = *reinterpret_cast<const v4i32_a4 *>(ops + base + s0);
+            v[0] = (uint32_t)q.x; v[1] = (uint32_t)q.y; v[2] = (uint32_t)q.z; v[3] = (uint32_t)q.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (base + s0 + (uint32_t)q < n_ops) ? ops[base + s0 + (uint32_t)q] : 0u;
+        }
+        uint32_t t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = s0 + (uint32_t)q < W;
+            odd |= in && (v[q] >> 4) >= (1u << 20);
+            t[q] = in ? cigar_term32(v[q]) : 0u;
+        }
+        const uint32_t p1 = t[0], p2 = p1 + t[1], p3 = p2 + t[2], tot = p3 + t[3];
+        const uint32_t incl = wave_scan_incl(tot);
+        const uint32_t ex = incl - tot + carry;
+        *reinterpret_cast<uint4 *>(T + s0) = make_uint4(ex, ex + p1, ex + p2, ex + p3);
+        carry += lane_value(incl, 63);
+    }
+    if (__ballot(odd) != 0ull) return false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t d = T[o[j + 1] - base] - T[o[j] - base];
+        const long long sc = -6ll * (long long)nmv[j] - (long long)d;
+        const bool present = nmv[j] != INT32_MIN;
+        const bool out = present && (sc <= (long long)INT32_MIN || sc > (long long)INT32_MAX);
+        bad |= out;
+        const long long cl = out ? (sc < 0 ? (long long)INT32_MIN + 1 : (long long)INT32_MAX) : sc;
+        as_out[j] = present ? (int32_t)cl : INT32_MIN;
+    }
+    return true;
+}
+
 template <bool PAIRED, int BLOCK, bool FULL>
 __device__ __forceinline__ void classify_cigar_body(
     const int32_t *__restrict__ nm1, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ ops1,
@@ -761,7 +818,7 @@ __device__ __forceinline__ void classify_cigar_body(
     const int32_t *__restrict__ nm2, const uint32_t *__restrict__ off2, const uint32_t *__restrict__ ops2,
     const int32_t *__restrict__ xs2,
     const uint8_t *__restrict__ unit_bits8, int32_t m, uint8_t *__restrict__ code, uint64_t n,
-    uint32_t *__restrict__ range_flag, uint32_t *last_state)
+    uint32_t *__restrict__ range_flag, uint32_t *last_state, uint32_t *cig_T)
 {
     const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t r0 = g * 4;
@@ -780,10 +837,17 @@ __device__ __forceinline__ void classify_cigar_body(
         const uint32_t n_ops1 = off1[n], n_ops2 = off2[n];
         cigar_fetch_offsets<FULL>(nm1, off1, r0, n, nmv1, o1);
         cigar_fetch_offsets<FULL>(nm2, off2, r0, n, nmv2, o2);
-        cigar_fetch_ops(ops1, n_ops1, o1, v1);
-        cigar_fetch_ops(ops2, n_ops2, o2, v2);
-        bad |= cigar_finish_scores(ops1, nmv1, o1, v1, a1);
-        bad |= cigar_finish_scores(ops2, nmv2, o2, v2, a2);
+        // FULL: every lane of the wave is here, so the wave can work on its op stretch together
+        const bool done1 = FULL && cigar_scores_by_prefix(ops1, n_ops1, nmv1, o1, cig_T, a1, bad);
+        const bool done2 = FULL && cigar_scores_by_prefix(ops2, n_ops2, nmv2, o2, cig_T, a2, bad);
+        if (!done1) {                                                   // wave-uniform when FULL
+            cigar_fetch_ops(ops1, n_ops1, o1, v1);
+            bad |= cigar_finish_scores(ops1, nmv1, o1, v1, a1);
+        }
+        if (!done2) {
+            cigar_fetch_ops(ops2, n_ops2, o2, v2);
+            bad |= cigar_finish_scores(ops2, nmv2, o2, v2, a2);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) a1[j] = a2[j] = INT32_MIN;
@@ -813,12 +877,14 @@ classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restric
                       uint32_t *__restrict__ range_flag)
 {
     __shared__ uint32_t last_state[BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t cig_table[BLOCK / 64][XM_CIG_WAVE_OPS + 4];
+    uint32_t *cig_T = cig_table[threadIdx.x >> 6];
     if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
         classify_cigar_body<PAIRED, BLOCK, true>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
-                                                 range_flag, last_state);
+                                                 range_flag, last_state, cig_T);
     else
         classify_cigar_body<PAIRED, BLOCK, false>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
-                                                  range_flag, last_state);
+                                                  range_flag, last_state, cig_T);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -903,14 +969,14 @@ void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
                            const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
                            const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag)
 {
-    const uint64_t per_block = (uint64_t)XM_CLASSIFY_BLOCK * 4;
+    const uint64_t per_block = (uint64_t)XM_CIGAR_BLOCK * 4;
     const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
     if (mode == XM_MODE_SE)
-        classify_cigar_kernel<false, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(
+        classify_cigar_kernel<false, XM_CIGAR_BLOCK><<<grid, XM_CIGAR_BLOCK, 0, st>>>(
             nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
     else
-        classify_cigar_kernel<true, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(
+        classify_cigar_kernel<true, XM_CIGAR_BLOCK><<<grid, XM_CIGAR_BLOCK, 0, st>>>(
             nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
 }
 
