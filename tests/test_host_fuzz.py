@@ -121,3 +121,106 @@ def test_stripper_agrees_with_oracle(parser, texts, score_mode, paired, skip):
         assert out == "".join("\t".join(p[0]) + "\n" for p in pairs)
         out2 = bytes(parser.emit(False, 4, idx)).decode()
         assert out2 == "".join("\t".join(p[0]) + "\n" + "\t".join(p[1]) + "\n" for p in pairs)
+
+
+# ---------------------------------------------------------------------------------------------- BAM decoder
+import struct
+import zlib
+
+from oracle import bam_oracle
+
+_INT_TYPES = {"c": (-128, 127), "C": (0, 255), "s": (-32768, 32767), "S": (0, 65535), "i": (-2**31, 2**31 - 1),
+              "I": (0, 2**32 - 1)}
+_FLOATS = st.sampled_from([0.0, 1.5, -2.25, 1e10, 3.0e-5, 123456.0, 1234567.0, -0.1, float("inf")])
+_TAGNAME = st.text(alphabet="ABCXYZabc019", min_size=2, max_size=2)
+
+
+@st.composite
+def bam_tag(draw):
+    tag = draw(_TAGNAME).encode()
+    kind = draw(st.sampled_from(list("AcCsSiIfZHB")))
+    if kind == "A":
+        return tag + b"A" + draw(st.sampled_from(list("+-!~aZ"))).encode()
+    if kind in _INT_TYPES:
+        lo, hi = _INT_TYPES[kind]
+        v = draw(st.one_of(st.integers(lo, hi), st.sampled_from([lo, hi, 0])))
+        return tag + kind.encode() + struct.pack(bam_oracle._SCALAR[kind], v)
+    if kind == "f":
+        return tag + b"f" + struct.pack("<f", draw(_FLOATS))
+    if kind == "Z":
+        return tag + b"Z" + draw(st.text(alphabet="abcXYZ09 :;,*", max_size=12)).encode() + b"\0"
+    if kind == "H":
+        return tag + b"H" + draw(st.text(alphabet="0123456789ABCDEF", max_size=8)).encode() + b"\0"
+    sub = draw(st.sampled_from(list("cCsSiIf")))
+    if sub == "f":
+        vals = draw(st.lists(_FLOATS, max_size=5))
+    else:
+        lo, hi = _INT_TYPES[sub]
+        vals = draw(st.lists(st.one_of(st.integers(lo, hi), st.sampled_from([lo, hi])), max_size=40))
+    return tag + b"B" + sub.encode() + struct.pack("<I", len(vals)) + b"".join(struct.pack(bam_oracle._SCALAR[sub], v) for v in vals)
+
+
+@st.composite
+def bam_record(draw, n_ref):
+    name = draw(st.text(alphabet="abcXYZ019:/._", min_size=1, max_size=30)).encode() + b"\0"
+    cigar = draw(st.lists(st.tuples(st.integers(0, 2**28 - 1), st.integers(0, 9)), max_size=6))
+    l_seq = draw(st.sampled_from([0, 1, 2, 7, 50, 151]))
+    seq = bytes(draw(st.lists(st.integers(0, 255), min_size=(l_seq + 1) // 2, max_size=(l_seq + 1) // 2)))
+    if l_seq and draw(st.booleans()):
+        qual = bytes([0xFF] * l_seq)
+    else:
+        qual = bytes(draw(st.lists(st.integers(0, 93), min_size=l_seq, max_size=l_seq)))
+    tags = b"".join(draw(st.lists(bam_tag(), max_size=6)))
+    core = struct.pack("<iiBBHHHIiii", draw(st.integers(-1, n_ref)), draw(st.integers(-1, 2**31 - 2)), len(name),
+                       draw(st.integers(0, 255)), 4680, len(cigar), draw(st.integers(0, 65535)), l_seq,
+                       draw(st.integers(-1, n_ref)), draw(st.integers(-1, 2**31 - 2)), draw(st.integers(-2**31, 2**31 - 1)))
+    body = core + name + b"".join(struct.pack("<I", (ln << 4) | op) for ln, op in cigar) + seq + qual + tags
+    return struct.pack("<I", len(body)) + body
+
+
+@st.composite
+def bam_image(draw):
+    refs = draw(st.lists(st.text(alphabet="chrXY0123_", min_size=1, max_size=12), max_size=3))
+    text = draw(st.sampled_from(["", "@HD\tVN:1.0\n", "@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:10\n@PG\tID:x\n"])).encode()
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for r in refs:
+        rn = r.encode() + b"\0"
+        head += struct.pack("<i", len(rn)) + rn + struct.pack("<i", 1000)
+    recs = draw(st.lists(bam_record(len(refs)), max_size=25))
+    payload = head + b"".join(recs) * draw(st.sampled_from([1, 1, 7]))
+    out, at = [], 0
+    while at < len(payload):
+        step = draw(st.sampled_from([1, 5, 33, 200, 3000, 65280]))
+        part = payload[at:at + step]
+        comp = zlib.compressobj(draw(st.sampled_from([0, 1, 6])), zlib.DEFLATED, -15)
+        body = comp.compress(part) + comp.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                   struct.pack("<II", zlib.crc32(part), len(part)))
+        at += step
+    if draw(st.booleans()):
+        out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+@settings(max_examples=int(os.environ.get('XM_FUZZ_EXAMPLES', '300')), deadline=None, suppress_health_check=list(HealthCheck))
+@given(image=bam_image(), threads=st.sampled_from([1, 3, 8]), cap=st.sampled_from([1 << 10, 1 << 14, 1 << 20]))
+def test_bam_decoder_agrees_with_the_spec_restatement(image, threads, cap):
+    """Random alignment records (every optional-field type, extreme integers, empty and odd-length sequences) in BGZF
+    blocks of random sizes: the native decoder must print what the oracle's restatement of the BAM layout prints."""
+    from xenomapper_amd import _host
+    want_header, want_lines = bam_oracle.bam_to_sam(image)
+    r = _host.BamReader(np.frombuffer(image, dtype=np.uint8), threads)
+    buf = np.empty(cap, dtype=np.uint8)
+    parts = []
+    grown = 0
+    while not r.eof:
+        n = r.read_into(buf, 0)
+        if n == 0 and not r.eof:                                   # a line longer than the buffer: the caller grows it
+            buf = np.empty(2 * buf.shape[0], dtype=np.uint8)
+            grown += 1
+            assert grown < 20
+        parts.append(bytes(buf[:n]))
+    got_header = r.header()
+    r.close()
+    assert got_header == want_header
+    assert b"".join(parts).decode("latin-1") == "".join(l + "\n" for l in want_lines)

@@ -268,3 +268,16 @@ def test_g5_error_type_and_partial_output(case):
     assert err == case["error"]
     for b, name in enumerate(H.STATES):
         assert outs[b].getvalue() == case["outputs"][name], name
+
+
+@pytest.mark.parametrize("species", ["human", "mouse"])
+def test_bam_oracle_reproduces_the_reference_sam_fixture(species):
+    """Pin of oracle/bam_oracle.py: the reference's BAM fixture, decoded by the plain-Python restatement of the BAM
+    layout, is the reference's SAM fixture (what `samtools view -h` gave the reference's authors)."""
+    import os
+    from oracle import bam_oracle
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_%s" % species)
+    with open(base + ".bam", "rb") as fh:
+        header, lines = bam_oracle.bam_to_sam(fh.read())
+    with open(base + ".sam") as fh:
+        assert header + "\n".join(lines) == fh.read()

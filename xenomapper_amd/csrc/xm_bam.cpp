@@ -163,10 +163,6 @@ struct SeqTable {                      // one packed byte -> its two bases
 };
 const SeqTable SEQ;
 
-// text bytes one alignment record of `size` binary bytes can grow to: the worst ratios are a B:c array element
-// (1 byte -> "-128,"), a CIGAR operation (4 -> 11) and a packed base pair (1 -> 2); the fixed fields add < 128
-inline size_t text_bound(uint32_t size) { return 5 * (size_t)size + 128; }
-
 }  // namespace
 
 // inflated bytes not yet consumed: [pos, end) of one reused, never zero-filled buffer (a std::vector would memset --
@@ -284,8 +280,8 @@ bool read_header(xmh_bam *b)
 }
 
 // one alignment record (without its block_size word) -> one SAM line at o, the way `samtools view` prints it.
-// Returns the end of the line, or nullptr for a malformed record.  o has text_bound(size) bytes of room, plus the
-// longest reference name twice (checked by the caller).
+// Returns the end of the line, or nullptr for a malformed record.  The caller guarantees room for 5 * size + 128
+// bytes plus the longest reference name twice.
 char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
 {
     if (size < 32) return nullptr;
@@ -493,6 +489,8 @@ bool produce_batch(xmh_bam *b, size_t budget, size_t *n_records, int *n_workers)
         }
         chain[(size_t)t + 1].store(p, std::memory_order_release);
         if (w.rec.empty()) return;
+        // text a record can grow to: the worst ratios are a B:c array element (1 byte -> "-128,"), a CIGAR operation
+        // (4 -> 11) and a packed base pair (1 -> 2), so 5x; the fixed fields add < 128 and two reference names
         const size_t room = 5 * (size_t)(p - first) + w.rec.size() * (128 + 2 * longest_ref);
         if (w.text_cap < room) {
             w.text.reset(new char[room]);
