@@ -596,12 +596,14 @@ int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eo
             for (; whole < nt && at[(size_t)whole] + b->workers[(size_t)whole].text_len <= cap; ++whole)
                 at[(size_t)whole + 1] = at[(size_t)whole] + b->workers[(size_t)whole].text_len;
             b->pool->run(whole, [&](int t) {
-                memcpy(dst + at[(size_t)t], b->workers[(size_t)t].text.get(), b->workers[(size_t)t].text_len);
+                const BamWorker &wk = b->workers[(size_t)t];
+                if (wk.text_len) memcpy(dst + at[(size_t)t], wk.text.get(), wk.text_len);
             });
             w = at[(size_t)whole];
-            for (int t = whole; t < nt; ++t)
-                b->pending.insert(b->pending.end(), b->workers[(size_t)t].text.get(),
-                                  b->workers[(size_t)t].text.get() + b->workers[(size_t)t].text_len);
+            for (int t = whole; t < nt; ++t) {
+                const BamWorker &wk = b->workers[(size_t)t];
+                if (wk.text_len) b->pending.insert(b->pending.end(), wk.text.get(), wk.text.get() + wk.text_len);
+            }
             w += take_pending(b, dst + w, cap - w);
         }
         *written = w;
