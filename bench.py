@@ -231,8 +231,9 @@ def main():
         achieved = bytes_per_pair * n_pairs / (cls_ms * 1e-3) / 1e9
         kernels = {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in timing_all.items() if v["launches"]}
         traffic = None
-        pmc_file = os.path.join(REPO, "profiles", "pmc_classify.json")
-        if os.path.exists(pmc_file) and args.workload == "cfg2" and n_pairs == 50_000_000:
+        pmc_file = os.path.join(REPO, "profiles", {"cfg2": "pmc_classify.json", "cfg3": "pmc_classify_cigar.json"}.get(
+            args.workload, "none"))
+        if os.path.exists(pmc_file) and n_pairs == 50_000_000:
             try:
                 traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
             except Exception:

@@ -778,8 +778,11 @@ __device__ __forceinline__ bool cigar_scores_by_prefix(const uint32_t *__restric
         const uint32_t s0 = c * 256u + 4u * lane;
         uint32_t v[4];
         if (base + (c + 1u) * 256u <= n_ops) {                          // wave-uniform: the chunk lies inside the array
-            const v4i32 q = *reinterpret_cast<const v4i32_a4 *>(ops + base + s0);
-            v[0] = (uint32_t)q.x; v[1] = (uint32_t)q.y; v[2] = (uint32_t)q.z; v[3] = (uint32_t)q.w;
+            v[0] = v[1] = v[2] = v[3] = 0u;
+            if (s0 < W) {                                               // lanes past the stretch fetch nothing
+                const v4i32 q = *reinterpret_cast<const v4i32_a4 *>(ops + base + s0);
+                v[0] = (uint32_t)q.x; v[1] = (uint32_t)q.y; v[2] = (uint32_t)q.z; v[3] = (uint32_t)q.w;
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = (base + s0 + (uint32_t)q < n_ops) ? ops[base + s0 + (uint32_t)q] : 0u;
