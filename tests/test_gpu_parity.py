@@ -227,6 +227,48 @@ def test_classify_cigar_fused(ctx, n):
         assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
 
 
+@pytest.mark.parametrize("flavour", ["huge_op", "many_ops", "long_stretch", "huge_nm"])
+def test_classify_cigar_guards_of_the_op_parallel_path(ctx, flavour):
+    """Full workgroups (so the op-parallel path runs) with the inputs its wave-uniform guards are there for: an
+    operation longer than 2^20, a record with more than 512 operations, a wave whose records own 1024 operations
+    or more, and an NM that takes the score out of int32 (reported, not wrapped)."""
+    n = 8192
+    rng = np.random.default_rng(7)
+    c1, c2 = _random_cigar(rng, n), _random_cigar(rng, n)
+    xs = [np.where(rng.random(n) < 0.8, ABSENT, -rng.integers(0, 200, n)).astype(np.int32) for _ in range(2)]
+
+    def splice(c, at, new_ops):
+        off, ops = c["cig_off"].astype(np.int64), c["cig_oplen"]
+        a, b = int(off[at]), int(off[at + 1])
+        c["cig_oplen"] = np.concatenate([ops[:a], np.asarray(new_ops, dtype=np.uint32), ops[b:]])
+        off[at + 1:] += len(new_ops) - (b - a)
+        c["cig_off"] = off.astype(np.uint32)
+        c["nm"][at] = 1
+    if flavour == "huge_op":
+        for at in (5, 700, 4099, 8191):
+            splice(c1, at, [(10 << 4) | 0, ((2**27) << 4) | 4, ((2**20) << 4) | 2])   # 134217728S, 1048576D
+            splice(c2, at + (0 if at == 8191 else 1), [((2**26) << 4) | 1])
+    elif flavour == "many_ops":
+        splice(c1, 1000, [(3 << 4) | (k % 9) for k in range(600)])
+        splice(c2, 6000, [(2 << 4) | 1] * 513)
+    elif flavour == "long_stretch":
+        for at in range(2048, 2304):                                   # one wave's 256 records, 5 ops each
+            splice(c1, at, [(7 << 4) | 4, (20 << 4) | 0, (1 << 4) | 1, (30 << 4) | 0, (2 << 4) | 2])
+    else:
+        c1["nm"][4321] = 2**30
+    bits = H.synth.pack_unit_bits(rng.random(n) < 0.6)
+    if flavour == "huge_nm":
+        with pytest.raises(OverflowError):
+            ctx.classify_cigar(1, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs[0],
+                               c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, ABSENT)
+        return
+    for mode in (0, 1, 2):
+        code, counts = ctx.classify_cigar(mode, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs[0],
+                                          c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, ABSENT)
+        want, want_counts = _oracle_cigar_classify(mode, c1, xs[0], c2, xs[1], bits, ABSENT)
+        assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+
+
 def test_classify_cigar_range_error(ctx):
     big = np.array([((2**28 - 1) << 4) | 1] * 8, dtype=np.uint32)
     one = {"nm": np.array([0], np.int32), "off": np.array([0, 8], np.uint32)}
