@@ -145,9 +145,10 @@ uint64_t xmo_cigar_scores(uint64_t n, const int32_t *nm, const uint32_t *cig_off
 /*
  * xenomappability: Mappability.single_end_to_paired for one chromosome, mappability.py:94-124.
  * out[i] = 1.0 where track[i] == 1, else sum_j track[i+j] * density[j] for j < min(m, n - i), accumulated left to
- * right with a separately rounded multiply and add (Python's `result += a * b`).  Compile without contraction.
+ * right with a separately rounded multiply and add (Python's `result += a * b`).  The Makefile compiles with
+ * -ffp-contract=off (gcc ignores the STDC FP_CONTRACT pragma), and the volatile temporaries keep the two roundings
+ * apart under any flags.
  */
-#pragma STDC FP_CONTRACT OFF
 void xmo_mate_correlate(uint64_t n, const double *track, uint64_t m, const double *density, double *out)
 {
     for (uint64_t i = 0; i < n; ++i) {
