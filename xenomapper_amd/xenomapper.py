@@ -22,13 +22,16 @@ written before the exception propagates, as with the reference.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import io
 import math
 import os
 import re
 import sys
 import textwrap
+import time
 from collections import Counter
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -663,6 +666,18 @@ def _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode):
     return patches, None, None
 
 
+class _PhaseClock(dict):
+    """Wall time per phase of the file path (printed when XENOMAPPER_PROFILE is set)."""
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        start = time.perf_counter()
+        try:
+            yield
+        finally:
+            self[name] = self.get(name, 0.0) + time.perf_counter() - start
+
+
 class _SamSource(object):
     """Record text of a SAM file: windows of a read-only memory map."""
 
@@ -741,31 +756,26 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     cigar_mode = tag_func is get_cigarbased_AS_tag
     score_mode = _host.SCORE_CIGAR if cigar_mode else (_host.SCORE_AS_ZS if tag_func is get_tag_with_ZS_as_XS
                                                        else _host.SCORE_AS_XS)
-    import time as _time
-    t_all = _time.perf_counter()
-    sources = [(_BamSource(path, n_threads) if bam else _SamSource(path, None if starts is None else starts[k]))
-               for k, path in enumerate((path1, path2))]
-    # Two parsers alternate so that the next window is decoded (BAM) and parsed in a helper thread -- the C++ code
-    # runs without the GIL -- while the GPU classifies and the writer emits the current one.
-    parsers = [_host.Parser(n_threads), _host.Parser(n_threads)]
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=1)
-    prof = {"open": 0.0, "window": 0.0, "parse": 0.0, "classify": 0.0, "compact": 0.0, "emit": 0.0, "write": 0.0,
-            "close": 0.0, "other": 0.0}
-    prof["open"] = _time.perf_counter() - t_all
+    prof = _PhaseClock()
+    t_all = time.perf_counter()
+    with prof("open"):
+        sources = [(_BamSource(path, n_threads) if bam else _SamSource(path, None if starts is None else starts[k]))
+                   for k, path in enumerate((path1, path2))]
+        # Two parsers alternate so that the next window is decoded (BAM) and parsed in a helper thread -- the C++
+        # code runs without the GIL -- while the GPU classifies and the writer emits the current one.
+        parsers = [_host.Parser(n_threads), _host.Parser(n_threads)]
+        pool = ThreadPoolExecutor(max_workers=1)
     totals, key_order = Counter(), []
     window = FILE_WINDOW_BYTES
     active = [s for s in sinks if s]
     distinct = len(set(id(s) for s in active)) == len(active)
 
     def parse_next(which, want):
-        _t = _time.perf_counter()
-        wins = [src.window(want) for src in sources]
-        prof["window"] += _time.perf_counter() - _t
-        _t = _time.perf_counter()
-        blk = parsers[which].parse(wins[0][0], wins[0][1], wins[0][2], wins[0][3], wins[1][0], wins[1][1], wins[1][2],
-                                   wins[1][3], score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
-        prof["parse"] += _time.perf_counter() - _t
+        with prof("window"):
+            wins = [src.window(want) for src in sources]
+        with prof("parse"):
+            blk = parsers[which].parse(wins[0][0], wins[0][1], wins[0][2], wins[0][3], wins[1][0], wins[1][1], wins[1][2],
+                                       wins[1][3], score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
         return blk, [w[0] for w in wins], [w[1] for w in wins], [w[3] for w in wins]
 
     which = 0
@@ -806,12 +816,10 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             if err is not None:
                 n, pending = bad, err                                # units closing at index >= bad are not reached
             if n:
-                _t = _time.perf_counter()
-                code, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
-                prof["classify"] += _time.perf_counter() - _t
-                _t = _time.perf_counter()
-                idx, off, _ = ctx.compact(mode, code)
-                prof["compact"] += _time.perf_counter() - _t
+                with prof("classify"):
+                    code, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
+                with prof("compact"):
+                    idx, off, _ = ctx.compact(mode, code)
                 limit, state_error = None, None
                 if int(off[7]) != int(off[6]):
                     limit = int(idx[int(off[6]):int(off[7])].min())
@@ -822,12 +830,10 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         seg = idx[int(off[b]):int(off[b + 1])]
                         if limit is not None:
                             seg = seg[seg < limit]
-                        _t = _time.perf_counter()
-                        text = parser.emit(paired, b, seg, reuse=True)
-                        prof["emit"] += _time.perf_counter() - _t
-                        _t = _time.perf_counter()
-                        _write_bytes(sinks[b], text)
-                        prof["write"] += _time.perf_counter() - _t
+                        with prof("emit"):
+                            text = parser.emit(paired, b, seg, reuse=True)
+                        with prof("write"):
+                            _write_bytes(sinks[b], text)
                 if not distinct:
                     _emit_shared(parser, paired, code, idx, off, sinks, limit)
                 if state_error is not None:
@@ -850,16 +856,15 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 future.result()
             except Exception:
                 pass
-        _t = _time.perf_counter()
-        pool.shutdown(wait=True)
-        for prs in parsers:
-            prs.close()
-        for src in sources:
-            src.close()
-        prof["close"] = _time.perf_counter() - _t
+        with prof("close"):
+            pool.shutdown(wait=True)
+            for prs in parsers:
+                prs.close()
+            for src in sources:
+                src.close()
         if os.environ.get("XENOMAPPER_PROFILE"):
-            total = _time.perf_counter() - t_all
-            prof["other"] = total - sum(prof.values())
+            total = time.perf_counter() - t_all
+            prof["other"] = total - sum(prof.values())           # negative: helper-thread phases overlap the rest
             print("xenomapper file path: %.3f s  " % total + "  ".join("%s %.3f" % kv for kv in prof.items()), file=sys.stderr)
     ordered = Counter()
     for key in key_order:
