@@ -756,6 +756,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     cigar_mode = tag_func is get_cigarbased_AS_tag
     score_mode = _host.SCORE_CIGAR if cigar_mode else (_host.SCORE_AS_ZS if tag_func is get_tag_with_ZS_as_XS
                                                        else _host.SCORE_AS_XS)
+    if not n_threads:                                                # 0: the CPUs this process may use (cgroup-aware)
+        n_threads = int(os.environ.get("XENOMAPPER_THREADS", "0"))
     prof = _PhaseClock()
     t_all = time.perf_counter()
     with prof("open"):
