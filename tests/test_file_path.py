@@ -264,11 +264,12 @@ def test_bam_input_equals_sam_input(mode_case, via, tmp_path):
 @pytest.mark.parametrize("window", [1500, 20000])
 @pytest.mark.parametrize("mode_case", ["ref_pe_liberal", "ref_pe_conservative_min99_5"])
 def test_bam_input_in_small_windows(mode_case, window, tmp_path, monkeypatch):
-    """Many windows per file: every refill moves the unread tail to the other decode buffer while the lines of
-    the previous window are still being written (1500 bytes is a handful of lines, some windows must grow)."""
+    """Many windows per file: every refill moves the unread tail in front of the text the decoder thread has produced
+    meanwhile, while the lines of the previous window are still being written (1500 bytes is a handful of lines: some
+    windows must grow, and a 64-byte head room never holds the tail)."""
     from xenomapper_amd import xenomapper as xm
     monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", window)
-    monkeypatch.setattr(xm._BamSource, "SLACK", 64)
+    monkeypatch.setattr(xm._BamSource, "HEAD", 64 if window == 1500 else 4096)
     case, counts, texts = _bam_case_outputs(xm, mode_case, tmp_path, "files")
     exp = case["expect"]
     flat = {("|".join(k) if isinstance(k, tuple) else k): v for k, v in counts.items()}

@@ -394,6 +394,40 @@ def test_bam_decoder_reports_a_file_that_ends_inside_a_record():
             r.read_into(buf, 0)
 
 
+@pytest.mark.parametrize("window,head", [(1500, 64), (1500, 4096), (50_000, 1 << 20), (1 << 22, 1 << 20)])
+def test_bam_source_windows_reassemble_the_text(window, head, monkeypatch):
+    """The file path's BAM source (three buffers, decoder thread running ahead) driven the way _run_files drives it:
+    take a window, consume its whole lines, ask again; a window without a complete line is asked for again, larger."""
+    import os
+    from xenomapper_amd import xenomapper as xm
+    monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", window)
+    monkeypatch.setattr(xm._BamSource, "HEAD", head)
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_mouse")
+    src = xm._BamSource(base + ".bam", 3)
+    out, want, prev = [], window, None
+    for _ in range(1_000_000):
+        buf, start, n, eof = src.window(want)
+        if prev is not None:            # the writer gathers window k's lines while window k+1 is decoded and parsed
+            assert bytes(prev[0][prev[1]:prev[1] + len(prev[2])]) == prev[2]
+        view = bytes(buf[start:start + n])
+        if eof:
+            out.append(view)
+            break
+        cut = view.rfind(b"\n") + 1
+        if cut == 0:
+            want *= 2
+            continue
+        held = bytes(buf[start:start + cut])
+        out.append(held)
+        src.advance(cut)
+        want = window
+        prev = (buf, start, held)
+    src.close()
+    with open(base + ".sam") as fh:
+        lines = [l for l in (fh.read() + "\n").splitlines(True) if not l.startswith("@")]
+    assert b"".join(out).decode("ascii") == "".join(lines)
+
+
 def test_bam_decoder_zlib_and_libdeflate_agree():
     """The decoder prefers libdeflate when the shared library is installed; XMH_NO_LIBDEFLATE=1 forces zlib.
     Both must print the fixture identically (the switch is read once per process, hence the child process)."""

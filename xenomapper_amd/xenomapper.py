@@ -698,52 +698,103 @@ class _SamSource(object):
 
 
 class _BamSource(object):
-    """Record text of a BAM file: SAM lines decoded on demand into one of two buffers.  A refill after advance()
-    moves the unread tail to the *other* buffer and decodes behind it, so the window handed out before stays
-    readable (the writer is still gathering lines from it) while the next one is decoded and parsed."""
+    """Record text of a BAM file: SAM lines decoded into three buffers in rotation -- one holds the window whose
+    lines the writer is still gathering, one the window being parsed, and a decoder thread fills the third with
+    the text that follows.  Every buffer keeps HEAD bytes free in front of its decoded text: the unread tail of the
+    previous window is copied there, so moving on to the next window costs no large copy."""
 
-    SLACK = 1 << 20
+    HEAD = 1 << 20
 
     def __init__(self, path, n_threads=0):
         from . import _host
         self.path = path
         self.data = np.memmap(path, dtype=np.uint8, mode="r")
         self.reader = _host.BamReader(self.data, n_threads)
-        self.bufs = [np.empty(FILE_WINDOW_BYTES + self.SLACK, dtype=np.uint8), None]
+        self.bufs = [None, None, None]
         self.cur = 0
-        self.start = self.end = 0
+        self.start = self.end = self.HEAD
         self.advanced = False
+        self.decoder = ThreadPoolExecutor(max_workers=1)
+        self.ahead = None                     # Future of (buffer index, bytes decoded at [HEAD, HEAD + n))
+
+    def _buffer(self, k, room):
+        if self.bufs[k] is None or self.bufs[k].shape[0] < self.HEAD + room:
+            self.bufs[k] = np.empty(self.HEAD + room, dtype=np.uint8)
+        return self.bufs[k]
+
+    def _decode(self, buf, at):
+        """Decode behind buf[:at] until the buffer is full or the file ends; returns the new end."""
+        while not self.reader.eof:
+            got = self.reader.read_into(buf, at)
+            if got == 0:
+                break                                              # the next line does not fit what is left
+            at += got
+        return at
+
+    def _decode_ahead(self, k):
+        return k, self._decode(self.bufs[k], self.HEAD) - self.HEAD
+
+    def _take_ahead(self):
+        k, n = self.ahead.result()
+        self.ahead = None
+        return self.bufs[k], n
 
     def window(self, want):
         buf = self.bufs[self.cur]
-        if self.end - self.start < want and not self.reader.eof:
+        if self.end - self.start < want and not (self.reader.eof and self.ahead is None):
             live = self.end - self.start
-            if self.advanced:
-                other = self.bufs[self.cur ^ 1]
-                if other is None or other.shape[0] < want + self.SLACK:
-                    other = np.empty(want + self.SLACK, dtype=np.uint8)
-                other[:live] = buf[self.start:self.end]
-                self.cur ^= 1
-                self.bufs[self.cur] = buf = other
-                self.start, self.end, self.advanced = 0, live, False
-            elif want + self.SLACK > buf.shape[0]:                 # a line longer than the window: grow in place
-                grown = np.empty(2 * want + self.SLACK, dtype=np.uint8)
-                grown[:live] = buf[self.start:self.end]
-                self.bufs[self.cur] = buf = grown
-                self.start, self.end = 0, live
-            while self.end - self.start < want and not self.reader.eof:
-                got = self.reader.read_into(buf, self.end)
-                if got == 0 and not self.reader.eof:
-                    break                                          # the next line needs a bigger buffer
-                self.end += got
+            if self.advanced:                                      # move on: tail of this window + the text decoded ahead
+                nxt = (self.cur + 1) % 3
+                if self.ahead is not None:
+                    nb, n = self._take_ahead()
+                else:
+                    nb, n = self._buffer(nxt, max(FILE_WINDOW_BYTES, want)), 0
+                if live <= self.HEAD and nb.shape[0] - self.HEAD >= want:
+                    nb[self.HEAD - live:self.HEAD] = buf[self.start:self.end]
+                    self.start, self.end = self.HEAD - live, self.HEAD + n
+                else:                                              # a tail longer than the head room, or a larger window
+                    grown = np.empty(self.HEAD + live + max(n, want) + (1 << 16), dtype=np.uint8)
+                    grown[self.HEAD:self.HEAD + live] = buf[self.start:self.end]
+                    grown[self.HEAD + live:self.HEAD + live + n] = nb[self.HEAD:self.HEAD + n]
+                    self.start, self.end = self.HEAD, self.HEAD + live + n
+                    nb = grown
+                self.cur = nxt
+                self.bufs[nxt] = buf = nb
+                self.advanced = False
+            else:                                                  # the same window again, larger (or the very first one)
+                extra = None
+                if self.ahead is not None:                         # text already decoded ahead belongs behind this window
+                    extra = self._take_ahead()
+                need = live + (extra[1] if extra else 0) + want + (1 << 16)
+                if buf is None or self.start + need > buf.shape[0]:
+                    grown = np.empty(self.HEAD + 2 * need, dtype=np.uint8)
+                    if live:
+                        grown[self.HEAD:self.HEAD + live] = buf[self.start:self.end]
+                    self.bufs[self.cur] = buf = grown
+                    self.start, self.end = self.HEAD, self.HEAD + live
+                if extra:
+                    buf[self.end:self.end + extra[1]] = extra[0][self.HEAD:self.HEAD + extra[1]]
+                    self.end += extra[1]
+            if self.end - self.start < want:
+                self.end = self._decode(buf, self.end)
+            if not self.reader.eof:                                # decode what follows while this window is parsed
+                k = (self.cur + 1) % 3
+                self._buffer(k, max(FILE_WINDOW_BYTES, want))
+                self.ahead = self.decoder.submit(self._decode_ahead, k)
         n = min(want, self.end - self.start)
-        return buf, self.start, n, self.reader.eof and n == self.end - self.start
+        return buf, self.start, n, self.reader.eof and self.ahead is None and n == self.end - self.start
 
     def advance(self, consumed):
         self.start += consumed
         self.advanced = self.advanced or consumed > 0
 
     def close(self):
+        if self.ahead is not None:
+            try:
+                self.ahead.result()
+            except Exception:
+                pass
+        self.decoder.shutdown(wait=True)
         self.reader.close()
 
 
