@@ -255,6 +255,14 @@ hist_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t chu
     for (int k = 0; k < K; ++k) load_codes16(code, span0 + (uint64_t)k * XM_WTILE + lane * 16u, n, w[k]);
 
     const uint32_t rep = t & 31u;
+    // One category usually dominates (both mates primary-specific in a xenograft).  The wave takes the first unit of
+    // its first lane as its guess `common`; units of that category are counted in a register and reach LDS with one
+    // atomic per lane at the end, so the per-position atomics carry only the other lanes -- fewer of the lane pairs
+    // (l, l + 32) that share a bank are both active, and the instruction mostly takes one pass instead of two.
+    uint32_t common = w[0][0] & 0xFFu;
+    if (common == XM_NO_UNIT) common = (w[0][0] >> 8) & 0xFFu;
+    common = (uint32_t)__builtin_amdgcn_readfirstlane((int)common);
+    uint32_t n_common = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
 #pragma unroll
@@ -262,9 +270,12 @@ hist_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t chu
             const uint32_t c = (w[k][j >> 2] >> (8 * (j & 3))) & 0xFFu;
             const bool unit = c != XM_NO_UNIT;
             if (__ballot(unit) == 0ull) continue;                     // wave-uniform
-            if (unit) atomicAdd(&hist[(c & 63u) * 32 + rep], 1u);
+            const bool same = unit && c == common;
+            n_common += same ? 1u : 0u;
+            if (unit && !same) atomicAdd(&hist[(c & 63u) * 32 + rep], 1u);
         }
     }
+    if (n_common) atomicAdd(&hist[(common & 63u) * 32 + rep], n_common);
     __syncthreads();
 
     // 4 threads per slot, 8 replicas each
