@@ -3,6 +3,7 @@ reference's own test-suite drives the reference (tests/test_xenomapper.py), plus
 end-to-end case: six bin texts byte-identical (SHA-224), category_counts, summary text."""
 import hashlib
 import io
+import os
 
 import pytest
 
@@ -249,3 +250,43 @@ def test_g5_errors_like_the_reference(case, via_files, tmp_path):
     assert err == case["error"]
     for name in H.STATES:
         assert outs[name].getvalue() == case["outputs"][name], name
+
+
+@pytest.mark.parametrize("name", ["all36_liberal", "all36_conservative", "ref_se", "cfg2_pe_liberal"])
+def test_the_ctypes_stub_of_integration_md(name):
+    """INTEGRATION.md section B shows the binding a maintainer of the reference would add.  The code block is taken
+    from the document as it stands and run: its category counts and bin lists must be the golden ones."""
+    import io
+    import math
+    import re
+    from xenomapper_amd import _ffi, xenomapper as xm
+    case = {c["name"]: c for c in H.golden("g3_end_to_end.json")["cases"]}[name]
+    text = open(os.path.join(H.REPO, "INTEGRATION.md")).read()
+    section = text[text.index("## B."):text.index("## C.")]
+    code = re.search(r"```python\n(.*?)```", section, flags=re.S).group(1)
+    assert '"libxenomapper_hip.so"' in code
+    _ffi.lib()                                                       # one HIP runtime per process (see _ffi)
+    code = code.replace('"libxenomapper_hip.so"', repr(_ffi.LIB_PATH))
+    ns = {"get_tag": xm.get_tag,
+          "_to_i32": lambda v: -2**31 if v == float("-inf") else int(v),
+          "_floor_i32": lambda m: -2**31 if m == float("-inf") else max(-2**31, min(2**31 - 1, math.floor(m)))}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    t1, t2 = H.case_texts(case)
+    s1, s2 = io.StringIO(t1), io.StringIO(t2)
+    xm.get_sam_header(s1), xm.get_sam_header(s2)
+    pairs = list(xm.getReadPairs(s1, s2, skip_repeated_reads=case["options"]["skip_repeated"]))
+    mode = {"se": 0, "pe": 1, "pe_conservative": 2}[case["mode"]]
+    counts, lists = ns["classify_block"]([p[0] for p in pairs], [p[1] for p in pairs], mode,
+                                         H.unnum(case["options"]["min_score"]))
+    exp = case["expect"]
+    names = ["primary_specific", "secondary_specific", "primary_multi", "secondary_multi", "unresolved", "unassigned"]
+    got = {}
+    for c in range(64):
+        if counts[c]:
+            key = names[c] if mode == 0 else "|".join((names[c >> 3], names[c & 7]))
+            got[key] = int(counts[c])
+    assert got == exp["counts"]
+    want = [[] for _ in range(6)]
+    for f, r, i in zip(exp["unit_fwd"], exp["unit_rev"], exp["unit_index"]):
+        want[H.ORACLE.bin_of(mode, int(f), int(r))].append(i)
+    assert [l.tolist() for l in lists] == want
