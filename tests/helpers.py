@@ -1,6 +1,5 @@
 """Shared test plumbing: golden vectors, the oracle (Python + C), SAM inputs of golden cases."""
 import ctypes
-import io
 import json
 import os
 import subprocess

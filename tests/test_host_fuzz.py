@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
-from tests import helpers as H
 from tests.helpers import ORACLE, NEG
 
 ABSENT = -2**31

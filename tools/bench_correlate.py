@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the mate-density correlation kernel (xenomappability, 8f-4) on a chromosome-sized track."""
-import json, sys, time
+import json, sys
 sys.path.insert(0, '.')
 import torch
 from xenomapper_amd import _ffi

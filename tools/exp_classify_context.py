@@ -1,4 +1,4 @@
-import sys, time, torch, numpy as np
+import sys, time, torch
 sys.path.insert(0, '.')
 from xenomapper_amd import _ffi, synth
 dev = torch.device('cuda:0')

@@ -1,5 +1,5 @@
 """Experiment: pipeline K2 of batch i under K1 of batch i+1 on two HIP streams (double-buffered category bytes)."""
-import sys, time, torch, numpy as np
+import sys, time, torch
 sys.path.insert(0, '.')
 from xenomapper_amd import _ffi, synth
 dev = torch.device('cuda:0')
