@@ -394,7 +394,8 @@ def test_bam_decoder_reports_a_file_that_ends_inside_a_record():
             r.read_into(buf, 0)
 
 
-@pytest.mark.parametrize("window,head", [(1500, 64), (1500, 4096), (50_000, 1 << 20), (1 << 22, 1 << 20)])
+@pytest.mark.parametrize("window,head", [(1500, 64), (1500, 4096), (50_000, 1 << 20), (1 << 22, 1 << 20), (333, 0),
+                                         (9_999, 17), (70_000, 300)])
 def test_bam_source_windows_reassemble_the_text(window, head, monkeypatch):
     """The file path's BAM source (three buffers, decoder thread running ahead) driven the way _run_files drives it:
     take a window, consume its whole lines, ask again; a window without a complete line is asked for again, larger."""
