@@ -28,13 +28,38 @@ def _scalar(raw, p, t):
     return (_real(v) if t in "fd" else str(v)), p + struct.calcsize(fmt)
 
 
+def _value_bytes(rec, p, t):
+    if t in "ZH":
+        return rec.index(b"\0", p) + 1 - p
+    if t == "B":
+        count, = struct.unpack_from("<I", rec, p + 1)
+        return 5 + count * struct.calcsize(_SCALAR[chr(rec[p])])
+    return 1 if t == "A" else struct.calcsize(_SCALAR[t])
+
+
+def _real_cigar_field(rec, aux0, n_cigar, cigar_ops, l_seq, ref_id, pos):
+    """Offset of the CG:B:I field holding the real CIGAR, or None (conditions of htslib's bam_tag2cigar)."""
+    if n_cigar == 0 or ref_id < 0 or pos < 0 or (cigar_ops[0] & 15) != 4 or (cigar_ops[0] >> 4) != l_seq:
+        return None
+    p = aux0
+    while p + 3 <= len(rec):
+        t = chr(rec[p + 2])
+        if rec[p:p + 2] == b"CG":
+            if t != "B" or chr(rec[p + 3]) != "I":
+                return None
+            count, = struct.unpack_from("<I", rec, p + 4)
+            return p if n_cigar <= count < (1 << 29) else None
+        p += 3 + _value_bytes(rec, p + 3, t)
+    return None
+
+
 def record_to_line(rec, ref_names):
     """One alignment record (bytes after its block_size word) -> one SAM line without the newline."""
     ref_id, pos, l_name, mapq, _bin, n_cigar, flag, l_seq, next_ref, next_pos, tlen = struct.unpack_from("<iiBBHHHIiii", rec, 0)
     p = 32
     name = rec[p:p + l_name].split(b"\0")[0].decode("latin-1")
     p += l_name
-    cigar = "".join("%d%s" % (v >> 4, CIGAR_CODE[v & 15]) for v in struct.unpack_from("<%dI" % n_cigar, rec, p)) or "*"
+    cigar_ops = struct.unpack_from("<%dI" % n_cigar, rec, p)
     p += 4 * n_cigar
     seq = "".join(SEQ_CODE[(rec[p + k // 2] >> (0 if k & 1 else 4)) & 15] for k in range(l_seq)) or "*"
     p += (l_seq + 1) // 2
@@ -44,8 +69,19 @@ def record_to_line(rec, ref_names):
     def ref(i):
         return ref_names[i] if 0 <= i < len(ref_names) else "*"
     rnext = "=" if (0 <= next_ref < len(ref_names) and next_ref == ref_id) else ref(next_ref)
+    # A CIGAR of more than 65535 operations is stored as the placeholder "<l_seq>S<ref_len>N" plus a CG:B:I field; htslib
+    # moves the real operations back when it reads the record (sam.c, bam_tag2cigar), so `samtools view` prints them
+    # as the CIGAR and prints no CG field.
+    real_at = _real_cigar_field(rec, p, n_cigar, cigar_ops, l_seq, ref_id, pos)
+    if real_at is not None:
+        count, = struct.unpack_from("<I", rec, real_at + 4)
+        cigar_ops = struct.unpack_from("<%dI" % count, rec, real_at + 8)
+    cigar = "".join("%d%s" % (v >> 4, CIGAR_CODE[v & 15]) for v in cigar_ops) or "*"
     fields = [name, str(flag), ref(ref_id), str(pos + 1), str(mapq), cigar, rnext, str(next_pos + 1), str(tlen), seq, qual]
     while p < len(rec):
+        if real_at is not None and p == real_at:
+            p += 8 + 4 * len(cigar_ops)
+            continue
         tag, t = rec[p:p + 2].decode("latin-1"), chr(rec[p + 2])
         p += 3
         if t in "cCsSiI":

@@ -169,7 +169,14 @@ def bam_record(draw, n_ref):
         qual = bytes([0xFF] * l_seq)
     else:
         qual = bytes(draw(st.lists(st.integers(0, 93), min_size=l_seq, max_size=l_seq)))
-    tags = b"".join(draw(st.lists(bam_tag(), max_size=6)))
+    tag_list = draw(st.lists(bam_tag(), max_size=6))
+    if draw(st.integers(0, 5)) == 0:                                  # the long-CIGAR convention: placeholder + CG:B:I
+        cigar = [(l_seq if draw(st.integers(0, 3)) else l_seq + 1, 4), (draw(st.integers(0, 5000)), 3)][:draw(st.integers(1, 2))]
+        real = draw(st.lists(st.tuples(st.integers(0, 2**28 - 1), st.integers(0, 8)), max_size=9))
+        sub = draw(st.sampled_from(["I", "I", "I", "i"]))
+        cg = b"CGB" + sub.encode() + struct.pack("<I", len(real)) + b"".join(struct.pack("<I", (ln << 4) | op) for ln, op in real)
+        tag_list.insert(draw(st.integers(0, len(tag_list))), cg)
+    tags = b"".join(tag_list)
     core = struct.pack("<iiBBHHHIiii", draw(st.integers(-1, n_ref)), draw(st.integers(-1, 2**31 - 2)), len(name),
                        draw(st.integers(0, 255)), 4680, len(cigar), draw(st.integers(0, 65535)), l_seq,
                        draw(st.integers(-1, n_ref)), draw(st.integers(-1, 2**31 - 2)), draw(st.integers(-2**31, 2**31 - 1)))

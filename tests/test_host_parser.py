@@ -514,3 +514,45 @@ def test_bam_optional_field_formats():
                         "\tXE:i:60000\tAS:i:-70000\tXF:i:4000000000\tXG:f:1.5\tXH:Z:hello world\tXI:H:1AE3\tXJ:B:s,1,-2,3"
                         "\tXK:B:f,0.25,1e+10")
     assert lines[1] == "u\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*" and r.eof
+
+
+def test_bam_long_cigar_convention():
+    """A CIGAR of more than 65535 operations is stored as "<l_seq>S<ref_len>N" plus a CG:B:I field; htslib (sam.c,
+    bam_tag2cigar) moves it back on reading, so `samtools view` prints the real operations and no CG field -- only for
+    a mapped record whose first operation soft-clips the whole read and whose CG field is of type B,I."""
+    import struct, zlib
+    from xenomapper_amd import _host
+
+    def record(ref_id, pos, cigar, cg_sub=b"I", l_seq=5, extra_before=b"", extra_after=b"NMC\x02"):
+        real = struct.pack("<III", (3 << 4) | 0, (1 << 4) | 1, (1 << 4) | 0)                  # 3M1I1M
+        cg = b"CGB" + cg_sub + struct.pack("<I", 3) + real
+        name = b"r\x00"
+        core = struct.pack("<iiBBHHHIiii", ref_id, pos, len(name), 7, 4680, len(cigar), 0, l_seq, -1, -1, 0)
+        body = (core + name + b"".join(struct.pack("<I", (ln << 4) | op) for ln, op in cigar) + bytes([0x12, 0x48, 0x10]) +
+                bytes([30] * 5) + extra_before + cg + extra_after)
+        return struct.pack("<I", len(body)) + body
+    head = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chrA\x00" + struct.pack("<i", 9)
+    recs = [record(0, 9, [(5, 4), (4, 3)]),                                  # the convention: rewritten
+            record(0, 9, [(5, 4), (4, 3)], extra_before=b"XXZhi\x00"),       # CG behind another field
+            record(-1, 9, [(5, 4), (4, 3)]),                                 # unmapped: left alone
+            record(0, 9, [(4, 4), (4, 3)]),                                  # the clip is not the whole read
+            record(0, 9, [(5, 4), (4, 3)], cg_sub=b"i"),                     # CG is not B,I
+            record(0, -1, [(5, 4), (4, 3)])]                                 # no position
+    payload = head + b"".join(recs)
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = comp.compress(payload) + comp.flush()
+    image = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata +
+             struct.pack("<II", zlib.crc32(payload), len(payload)))
+    r = _host.BamReader(np.frombuffer(image, dtype=np.uint8), 2)
+    buf = np.empty(4096, dtype=np.uint8)
+    lines = bytes(buf[:r.read_into(buf, 0)]).decode().split("\n")
+    tail = "\t*\t0\t0\tACGTA\t?????"
+    assert lines[0] == "r\t0\tchrA\t10\t7\t3M1I1M" + tail + "\tNM:i:2"
+    assert lines[1] == "r\t0\tchrA\t10\t7\t3M1I1M" + tail + "\tXX:Z:hi\tNM:i:2"
+    assert lines[2] == "r\t0\t*\t10\t7\t5S4N" + tail + "\tCG:B:I,48,17,16\tNM:i:2"
+    assert lines[3] == "r\t0\tchrA\t10\t7\t4S4N" + tail + "\tCG:B:I,48,17,16\tNM:i:2"
+    assert lines[4] == "r\t0\tchrA\t10\t7\t5S4N" + tail + "\tCG:B:i,48,17,16\tNM:i:2"
+    assert lines[5] == "r\t0\tchrA\t0\t7\t5S4N" + tail + "\tCG:B:I,48,17,16\tNM:i:2"
+    # and the plain-Python restatement says the same
+    from oracle import bam_oracle
+    assert bam_oracle.bam_to_sam(image)[1] == lines[:6]

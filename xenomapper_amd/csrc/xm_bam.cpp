@@ -279,6 +279,58 @@ bool read_header(xmh_bam *b)
     return true;
 }
 
+// bytes of one optional-field value of type t starting at r[p] (the tag and type bytes already passed), or 0 when the
+// record ends inside it
+inline uint64_t aux_value_bytes(const uint8_t *r, uint64_t p, uint32_t size, char t)
+{
+    auto elem = [](char e) -> uint64_t {
+        switch (e) {
+        case 'A': case 'c': case 'C': return 1;
+        case 's': case 'S': return 2;
+        case 'i': case 'I': case 'f': return 4;
+        case 'd': return 8;
+        default: return 0;
+        }
+    };
+    if (t == 'Z' || t == 'H') {
+        const size_t l = strnlen((const char *)r + p, (size_t)(size - p));
+        return p + l < size ? l + 1 : 0;
+    }
+    if (t == 'B') {
+        if (p + 5 > size) return 0;
+        const uint64_t e = elem((char)r[p]), n = le32(r + p + 1);
+        return (e && p + 5 + e * n <= size) ? 5 + e * n : 0;
+    }
+    const uint64_t e = elem(t);
+    return (e && p + e <= size) ? e : 0;
+}
+
+// A CIGAR of more than 65 535 operations does not fit the 16-bit count of a BAM record: writers store the placeholder
+// "<l_seq>S<ref_len>N" and the real operations in a CG:B:I field, and htslib moves them back when it reads the record
+// (sam.c, bam_tag2cigar: mapped record, first operation a soft clip of the whole read, CG of type B,I with at least
+// n_cigar and fewer than 2^29 values), so `samtools view` prints the real CIGAR and no CG field.  Returns the offset
+// of the CG field's tag bytes (and its value count) when that applies, else 0.
+inline uint64_t real_cigar_field(const uint8_t *r, uint32_t size, uint64_t aux0, uint32_t n_cigar, uint32_t first_op,
+                                 uint32_t l_seq, int32_t ref_id, int32_t pos, uint32_t *count)
+{
+    if (n_cigar == 0 || ref_id < 0 || pos < 0 || (first_op & 15u) != 4u || (first_op >> 4) != l_seq) return 0;
+    uint64_t p = aux0;
+    while (p + 3 <= size) {
+        const char t = (char)r[p + 2];
+        const uint64_t len = aux_value_bytes(r, p + 3, size, t);
+        if (!len) return 0;
+        if (r[p] == 'C' && r[p + 1] == 'G') {                             // the first CG field decides, as bam_aux_get does
+            if (t != 'B' || r[p + 3] != 'I') return 0;
+            const uint32_t n = le32(r + p + 4);
+            if (n < n_cigar || n >= (1u << 29)) return 0;
+            *count = n;
+            return p;
+        }
+        p += 3 + len;
+    }
+    return 0;
+}
+
 // one alignment record (without its block_size word) -> one SAM line at o, the way `samtools view` prints it.
 // Returns the end of the line, or nullptr for a malformed record.  The caller guarantees room for 5 * size + 128
 // bytes plus the longest reference name twice.
@@ -302,9 +354,13 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
     *o++ = '\t'; o = put_int(o, (int64_t)pos + 1);
     *o++ = '\t'; o = put_uint(o, mapq);
     *o++ = '\t';
-    if (n_cigar == 0) *o++ = '*';
-    for (uint32_t k = 0; k < n_cigar; ++k) {
-        const uint32_t v = le32(r + p + 4ull * k);
+    uint32_t cg_count = 0;
+    const uint64_t cg_at = n_cigar ? real_cigar_field(r, size, need, n_cigar, le32(r + p), l_seq, ref_id, pos, &cg_count) : 0;
+    const uint8_t *ops = cg_at ? r + cg_at + 8 : r + p;
+    const uint32_t n_ops = cg_at ? cg_count : n_cigar;
+    if (n_ops == 0) *o++ = '*';
+    for (uint32_t k = 0; k < n_ops; ++k) {
+        const uint32_t v = le32(ops + 4ull * k);
         o = put_uint(o, v >> 4);
         *o++ = "MIDNSHP=XB??????"[v & 15];
     }
@@ -329,6 +385,10 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
     p += l_seq;
     // optional fields
     while (p + 3 <= size) {
+        if (cg_at && p == cg_at) {                                      // its operations were printed as the CIGAR
+            p += 8 + 4ull * cg_count;
+            continue;
+        }
         *o++ = '\t';
         *o++ = (char)r[p]; *o++ = (char)r[p + 1]; *o++ = ':';
         const char type = (char)r[p + 2];
