@@ -294,3 +294,42 @@ def test_cli_bam(tmp_path, capsys):
     for name in H.STATES:
         text = (tmp_path / (name + ".sam")).read_text()
         assert hashlib.sha224(text.encode("latin-1")).hexdigest() == case["expect"]["bins"][name]["sha224"]
+
+
+@pytest.mark.parametrize("via", ["files", "python"])
+def test_g7_random_corpus_like_the_reference(via, tmp_path):
+    """1000 small adversarial text pairs recorded from the reference (G7): same exception type, same six texts written
+    by then, same counts -- through the C++ text path on files and through the line-by-line Python path."""
+    from xenomapper_amd import xenomapper as xm
+    cases = H.golden("g7_random_corpus.json")["cases"]
+    p1, p2 = str(tmp_path / "a.sam"), str(tmp_path / "b.sam")
+    skipped = 0
+    for k, case in enumerate(cases):
+        t1, t2 = case["text"]
+        outs = {name: io.StringIO() for name in H.STATES}
+        mode, func, m = case["mode"], getattr(xm, case["tag_func"]), H.unnum(case["min_score"])
+        err, counts = None, None
+        try:
+            if via == "files":
+                with open(p1, "w", newline="") as f:
+                    f.write(t1)
+                with open(p2, "w", newline="") as f:
+                    f.write(t2)
+                got = xm.classify_sam_files(p1, p2, paired=mode != "se", conservative=mode == "pe_conservative", min_score=m,
+                                            tag_func=func, skip_repeated_reads=case["skip_repeated"], **outs)
+            else:
+                loop = {"se": xm.main_single_end, "pe": xm.main_paired_end, "pe_conservative": xm.conservative_main_paired_end}[mode]
+                got = loop(xm.getReadPairs(io.StringIO(t1, newline=None), io.StringIO(t2, newline=None),
+                                           skip_repeated_reads=case["skip_repeated"]), min_score=m, tag_func=func, **outs)
+            counts = {("|".join(key) if isinstance(key, tuple) else key): v for key, v in got.items()}
+        except OverflowError:
+            skipped += 1                   # a CIGAR length / NM beyond the packed columns: documented limit
+            continue
+        except Exception as exc:
+            err = type(exc).__name__
+        assert err == case["error"], k
+        for name in H.STATES:
+            assert outs[name].getvalue() == case["outputs"][name], (k, name)
+        if err is None:
+            assert counts == case["counts"], k
+    assert skipped < 20

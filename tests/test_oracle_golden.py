@@ -270,6 +270,34 @@ def test_g5_error_type_and_partial_output(case):
         assert outs[b].getvalue() == case["outputs"][name], name
 
 
+def test_g7_random_corpus():
+    """1000 small adversarial text pairs run through the reference (tools/make_golden.py, G7): the oracle must raise
+    the same exception type, have written the same six texts by then, and return the same counts."""
+    cases = H.golden("g7_random_corpus.json")["cases"]
+    assert len(cases) == 1000
+    for k, case in enumerate(cases):
+        t1, t2 = case["text"]
+        outs = [io.StringIO() for _ in range(6)]
+        scorer = FUNCS[case["tag_func"]]
+        m = H.unnum(case["min_score"])
+        err, counts = None, None
+        try:
+            pairs = ORACLE.read_pairs(io.StringIO(t1, newline=None), io.StringIO(t2, newline=None), case["skip_repeated"])
+            if case["mode"] == "se":
+                res = ORACLE.run_single_end(pairs, outs, m, scorer)
+            else:
+                res = ORACLE.run_paired_end(pairs, outs, m, scorer, conservative=case["mode"] == "pe_conservative")
+            counts = {("|".join(key) if isinstance(key, tuple) else key): v
+                      for key, v in res.named_counts(case["mode"] != "se").items()}
+        except Exception as exc:
+            err = type(exc).__name__
+        assert err == case["error"], k
+        for b, name in enumerate(H.STATES):
+            assert outs[b].getvalue() == case["outputs"][name], (k, name)
+        if err is None:
+            assert counts == case["counts"], k
+
+
 @pytest.mark.parametrize("species", ["human", "mouse"])
 def test_bam_oracle_reproduces_the_reference_sam_fixture(species):
     """Pin of oracle/bam_oracle.py: the reference's BAM fixture, decoded by the plain-Python restatement of the BAM

@@ -15,6 +15,9 @@ Vectors:
   G3  end-to-end runs of the three main loops on the reference's four SAM fixtures and on
       build-generated synthetic SAM text: per-unit (index, fwd, rev, bin), category_counts,
       SHA-224 + length of each of the six bin texts, the stderr summary text
+  G5  malformed inputs: exception type and the partial outputs
+  G6  the xenomappability companion tool
+  G7  a random corpus of small adversarial text pairs: error type, outputs and counts of the reference
 """
 import hashlib
 import io
@@ -417,6 +420,86 @@ def g6():
     return out
 
 
+# ------------------------------------------------------------------ G7
+def g7(n_cases=1000, seed=7007):
+    """Random corpus: small adversarial SAM-like text pairs (odd whitespace, every newline style, colliding and
+    malformed tags, odd CIGARs, repeated / mismatching names, blank lines) through the reference's three loops with
+    every plugin -- what it raised, what it had written by then, and the counts it returned."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def pick(seq):
+        return seq[int(rng.integers(0, len(seq)))]
+    ws = ["\t", "\t", "\t", " ", "\t\t", "  ", " \t", "\x0b", "\x0c", "\x1c", "\x1f"]
+    names = ["r1", "r2", "r2", "read/3", "q", "AS", "x:1"]
+    nums = [str(int(rng.integers(-300, 301))) for _ in range(40)] + ["0", "-0", "+7", "007", "2147483647", "2147483648",
+                                                                    "-2147483648", "1.5", "1e2", "inf", "nan", "", "1_0", "x"]
+    tagn = ["AS", "XS", "ZS", "NM", "YS", "XN", "MD", "RG", "xAS", "ASx"]
+    fixed_tags = ["RG:Z:BASS", "XS:A:+", "AS", "NM", "YT:Z:UU", "ZS:i:4:5"]
+    cigars = ["*", "50M", "10M2I3M1D4M6S", "5H10M", "0010S40M", "10Q5S", "5S10", "M5S", "3=2X1P4N5M", "268435455S", "1I1D1S"]
+
+    def tag():
+        u = rng.random()
+        if u < 0.10:
+            return pick(fixed_tags)
+        if u < 0.35:
+            return "%s:%s:%s" % (pick(tagn), pick("ifZA"), pick(nums))
+        return "%s:i:%d" % (pick(["AS", "XS", "ZS", "NM", "YS"]), int(rng.integers(-60, 61)) if rng.random() < 0.8 else 0)
+
+    def cigar():
+        if rng.random() < 0.5:
+            return pick(cigars)
+        return "".join("%d%s" % (int(rng.integers(0, 401)), pick("MIDNSHP=XQ")) for _ in range(int(rng.integers(0, 7))))
+
+    def line(name):
+        n_fixed = pick([11, 11, 11, 11, 3, 6, 1])
+        fields = [name] + ["0", "chr1", "7", "30", cigar(), "*", "0", "0", "ACGT", "IIII"][:n_fixed - 1]
+        if n_fixed == 11:
+            good = ["%s:i:%d" % (t, int(rng.integers(-60, 61)) if rng.random() < 0.85 else 0)
+                    for t in ("AS", "XS", "ZS", "NM", "YS") if rng.random() < 0.6]
+            if good and "NM" in good[-1]:
+                good[-1] = "NM:i:%d" % int(rng.integers(0, 9))
+            if rng.random() < 0.2:
+                good += [tag() for _ in range(int(rng.integers(1, 3)))]
+            fields += [good[i] for i in rng.permutation(len(good))]
+        text = fields[0] + "".join(pick(ws) + f for f in fields[1:])
+        if rng.random() < 0.1:
+            text = pick(ws) + text + pick(ws)
+        return text
+
+    cases = []
+    for k in range(n_cases):
+        n = int(rng.integers(0, 13))
+        nm = []
+        while len(nm) < n:                                            # runs of equal names: mates and repeats
+            nm += [pick(names)] * int(pick([1, 1, 2, 2, 2, 3]))
+        nm = nm[:n]
+        l1, l2 = [line(x) for x in nm], [line(x) for x in nm]
+        if n and rng.random() < 0.125:
+            l2[int(rng.integers(0, n))] = line("other")
+        if rng.random() < 0.17:
+            (l1 if rng.random() < 0.5 else l2).insert(int(rng.integers(0, n + 1)), pick(["", " ", "\t"]))
+        nl = pick(["\n", "\n", "\r\n", "\r"])
+        t1 = nl.join(l1) + (nl if l1 and rng.random() < 0.5 else "")
+        t2 = nl.join(l2) + (nl if l2 and rng.random() < 0.5 else "")
+        mode = pick(["se", "pe", "pe_conservative"])
+        func = pick(["get_tag", "get_tag_with_ZS_as_XS", "get_cigarbased_AS_tag"])
+        m = pick([NEG, 0.0, -12.5, 3.0])
+        skip = bool(rng.random() < 0.5)
+        outs = {name: io.StringIO() for name in BIN_ARGS}
+        loop = {"se": ref.main_single_end, "pe": ref.main_paired_end, "pe_conservative": ref.conservative_main_paired_end}[mode]
+        err, counts = None, None
+        try:
+            got = loop(ref.getReadPairs(io.StringIO(t1, newline=None), io.StringIO(t2, newline=None), skip_repeated_reads=skip),
+                       min_score=m, tag_func=getattr(ref, func), **outs)
+            counts = {("|".join(key) if isinstance(key, tuple) else key): v for key, v in sorted(got.items())}
+        except Exception as exc:
+            err = type(exc).__name__
+        cases.append({"text": [t1, t2], "mode": mode, "tag_func": func, "min_score": num(m), "skip_repeated": skip,
+                      "error": err, "counts": counts, "outputs": {name: outs[name].getvalue() for name in BIN_ARGS}})
+    return {"cases": cases}
+
+
 def header_golden():
     """process_headers on the PE fixtures (tests/test_xenomapper.py:29-54): full texts."""
     data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
@@ -430,7 +513,8 @@ def header_golden():
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     payload = {"g1_mapping_state.json": g1(), "g2_tag_parsers.json": g2(), "g3_end_to_end.json": g3(),
-               "g4_headers.json": header_golden(), "g5_errors.json": g5(), "g6_mappability.json": g6()}
+               "g4_headers.json": header_golden(), "g5_errors.json": g5(), "g6_mappability.json": g6(),
+               "g7_random_corpus.json": g7()}
     for name, obj in payload.items():
         with open(os.path.join(GOLDEN, name), "wt") as fh:
             json.dump(obj, fh, indent=None, separators=(",", ":"), sort_keys=True)
