@@ -333,3 +333,14 @@ def test_g7_random_corpus_like_the_reference(via, tmp_path):
         if err is None:
             assert counts == case["counts"], k
     assert skipped < 20
+
+
+G8 = H.golden("g8_large_runs.json")["cases"]
+
+
+@pytest.mark.parametrize("case", G8, ids=[c["name"] for c in G8])
+def test_g8_large_runs_like_the_reference(case, tmp_path):
+    """100 k-pair text twins of configs 1, 2, 3 and 5, classified by the reference (G8): the file path (a dozen
+    stripper windows, hundreds of kernel tiles) must give its counts, its six output texts and its summary."""
+    from xenomapper_amd import xenomapper as xm
+    check(xm, case, tmp_path, window=8 << 20)

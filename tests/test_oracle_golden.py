@@ -298,6 +298,22 @@ def test_g7_random_corpus():
             assert counts == case["counts"], k
 
 
+G8 = H.golden("g8_large_runs.json")["cases"]
+
+
+@pytest.mark.parametrize("case", G8, ids=[c["name"] for c in G8])
+def test_g8_large_runs(case):
+    """100 k-pair text twins of configs 1, 2, 3 and 5 as the reference classified them: counts, digests and line
+    counts of the six outputs, summary."""
+    res, outs = run_oracle_case(case)
+    exp = case["expect"]
+    counts = {("|".join(k) if isinstance(k, tuple) else k): v for k, v in res.named_counts(case["mode"] != "se").items()}
+    assert counts == exp["counts"]
+    for b, name in enumerate(H.STATES):
+        text = outs[b].getvalue()
+        assert (hashlib.sha224(text.encode("latin-1")).hexdigest(), len(text)) == (exp["bins"][name]["sha224"], exp["bins"][name]["len"]), name
+
+
 @pytest.mark.parametrize("species", ["human", "mouse"])
 def test_bam_oracle_reproduces_the_reference_sam_fixture(species):
     """Pin of oracle/bam_oracle.py: the reference's BAM fixture, decoded by the plain-Python restatement of the BAM

@@ -18,6 +18,7 @@ Vectors:
   G5  malformed inputs: exception type and the partial outputs
   G6  the xenomappability companion tool
   G7  a random corpus of small adversarial text pairs: error type, outputs and counts of the reference
+  G8  100 k-pair text twins of configs 1, 2, 3, 5: counts, digests of the six outputs, summary
 """
 import hashlib
 import io
@@ -500,6 +501,33 @@ def g7(n_cases=1000, seed=7007):
     return {"cases": cases}
 
 
+# ------------------------------------------------------------------ G8
+def g8():
+    """The reference on synthetic text twins of configs 1, 2, 3 and 5 at 100 k pairs (200 k SAM lines per file): large
+    enough for many kernel tiles, chunks and several stripper windows.  Only counts, digests and the summary are kept."""
+    cases = []
+
+    def add(name, args, mode, **kw):
+        t1, t2, _ = synth.sam_text_pair(**args)
+        res = run_reference(t1, t2, mode, **kw)
+        for key in ("unit_index", "unit_fwd", "unit_rev"):
+            res.pop(key)
+        opts = {"tag_func": kw.get("tag_func_name", "get_tag"), "min_score": num(kw.get("min_score", NEG)),
+                "skip_repeated": kw.get("skip_repeated", False), "header_sinks": "all"}
+        cases.append({"name": name, "mode": mode, "options": opts, "expect": res,
+                      "source": {"kind": "synth", "args": args,
+                                 "sha224": [hashlib.sha224(t.encode()).hexdigest() for t in (t1, t2)]}})
+    add("cfg1_se_cli_200k", dict(n_pairs=200000, seed=1101, profile="bowtie2", paired=False, read_len=50, mixed_ws=0.02,
+                                 irregular=0.01), "se", skip_repeated=True)
+    add("cfg2_pe_liberal_100k", dict(n_pairs=100000, seed=2102, profile="bowtie2", paired=True, read_len=150, irregular=0.005), "pe")
+    add("cfg3_pe_cigar_100k", dict(n_pairs=100000, seed=3103, profile="cigar", paired=True, read_len=150, irregular=0.005), "pe",
+        tag_func_name="get_cigarbased_AS_tag")
+    add("cfg5_pe_zs_conservative_100k", dict(n_pairs=100000, seed=5105, profile="hisat", paired=True, read_len=150,
+                                             irregular=0.005, mixed_ws=0.01), "pe_conservative",
+        tag_func_name="get_tag_with_ZS_as_XS", min_score=-40.0)
+    return {"cases": cases}
+
+
 def header_golden():
     """process_headers on the PE fixtures (tests/test_xenomapper.py:29-54): full texts."""
     data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
@@ -514,7 +542,7 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     payload = {"g1_mapping_state.json": g1(), "g2_tag_parsers.json": g2(), "g3_end_to_end.json": g3(),
                "g4_headers.json": header_golden(), "g5_errors.json": g5(), "g6_mappability.json": g6(),
-               "g7_random_corpus.json": g7()}
+               "g7_random_corpus.json": g7(), "g8_large_runs.json": g8()}
     for name, obj in payload.items():
         with open(os.path.join(GOLDEN, name), "wt") as fh:
             json.dump(obj, fh, indent=None, separators=(",", ":"), sort_keys=True)
