@@ -19,6 +19,7 @@ Vectors:
   G6  the xenomappability companion tool
   G7  a random corpus of small adversarial text pairs: error type, outputs and counts of the reference
   G8  100 k-pair text twins of configs 1, 2, 3, 5: counts, digests of the six outputs, summary
+  G9  the command line as a child process: stdout, stderr, exit code, output files
 """
 import hashlib
 import io
@@ -528,6 +529,68 @@ def g8():
     return {"cases": cases}
 
 
+# ------------------------------------------------------------------ G9
+def g9():
+    """The reference's command line (xenomapper.py:568-743) run as a child process on its own SAM fixtures and on a
+    HISAT-style text twin: stdout, stderr, exit code and the output files for a spread of flag combinations.  {P} and
+    {S} stand for the two input paths, {O}/<bin>.sam for an output path."""
+    import subprocess
+    import tempfile
+    data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
+    se = ("test_human_in.sam", "test_mouse_in.sam")
+    pe = ("paired_end_testdata_human.sam", "paired_end_testdata_mouse.sam")
+    zs_args = dict(n_pairs=300, seed=5905, profile="hisat", paired=True, read_len=100, irregular=0.02)
+    runner = ("import sys; sys.dont_write_bytecode = True; sys.path.insert(0, %r); "
+              "from xenomapper import xenomapper as x; x.main()" % REF_ROOT)
+    cases = []
+
+    def add(name, inputs, flags, outputs):
+        with tempfile.TemporaryDirectory() as d:
+            if inputs[0] == "ref":
+                paths = [os.path.join(data_dir, inputs[1]), os.path.join(data_dir, inputs[2])]
+                src = {"kind": "ref_data", "files": [inputs[1], inputs[2]]}
+            elif inputs[0] == "synth":
+                t1, t2, _ = synth.sam_text_pair(**inputs[1])
+                paths = [os.path.join(d, "p.sam"), os.path.join(d, "s.sam")]
+                for path, text in zip(paths, (t1, t2)):
+                    with open(path, "w") as fh:
+                        fh.write(text)
+                src = {"kind": "synth", "args": inputs[1], "sha224": [hashlib.sha224(t.encode()).hexdigest() for t in (t1, t2)]}
+            else:
+                paths, src = [], {"kind": "none"}
+            argv = []
+            if paths:
+                argv += ["--primary_sam", paths[0], "--secondary_sam", paths[1]]
+            argv += flags
+            for b in outputs:
+                argv += ["--" + b, os.path.join(d, b + ".sam")]
+            proc = subprocess.run([sys.executable, "-c", runner] + argv, capture_output=True, text=True, cwd=d)
+            files = {}
+            for b in outputs:
+                with open(os.path.join(d, b + ".sam")) as fh:
+                    text = fh.read()
+                files[b] = {"sha224": hashlib.sha224(text.encode("latin-1")).hexdigest(), "len": len(text)}
+            cases.append({"name": name, "source": src, "flags": flags, "outputs": outputs, "returncode": proc.returncode,
+                          "stdout": {"sha224": hashlib.sha224(proc.stdout.encode("latin-1")).hexdigest(), "len": len(proc.stdout)},
+                          # a traceback quotes source lines: only its last line (exception type and message) is kept
+                          "stderr": (None if inputs[0] == "none" else
+                                     proc.stderr if "Traceback" not in proc.stderr else None),
+                          "exception": (proc.stderr.strip().splitlines()[-1] if "Traceback" in proc.stderr else None),
+                          "files": files})
+    add("se_default_stdout", ("ref",) + se, [], [])
+    add("se_all_outputs", ("ref",) + se, [], list(BIN_ARGS))
+    add("se_min60_two_outputs", ("ref",) + se, ["--min_score", "60"], ["unresolved", "unassigned"])
+    add("pe_liberal_two_outputs", ("ref",) + pe, ["--paired"], ["primary_specific", "secondary_specific"])
+    add("pe_conservative_min_all", ("ref",) + pe, ["--paired", "--conservative", "--min_score", "99.5"], list(BIN_ARGS))
+    add("pe_cigar_scores", ("ref",) + pe, ["--paired", "--cigar_scores"], ["primary_specific", "primary_multi"])
+    add("pe_conservative_without_paired_is_single_end", ("ref",) + pe, ["--conservative"], ["primary_specific", "unresolved"])
+    add("pe_use_zs_conservative", ("synth", zs_args), ["--paired", "--conservative", "--use_zs"], list(BIN_ARGS))
+    add("pe_use_zs_and_cigar_scores", ("synth", zs_args), ["--paired", "--use_zs", "--cigar_scores"], ["primary_specific"])
+    add("version", ("none",), ["--version"], [])
+    add("no_inputs_is_a_usage_error", ("none",), [], [])
+    return {"cases": cases}
+
+
 def header_golden():
     """process_headers on the PE fixtures (tests/test_xenomapper.py:29-54): full texts."""
     data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
@@ -542,7 +605,8 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     payload = {"g1_mapping_state.json": g1(), "g2_tag_parsers.json": g2(), "g3_end_to_end.json": g3(),
                "g4_headers.json": header_golden(), "g5_errors.json": g5(), "g6_mappability.json": g6(),
-               "g7_random_corpus.json": g7(), "g8_large_runs.json": g8()}
+               "g7_random_corpus.json": g7(), "g8_large_runs.json": g8(),
+               "g9_cli.json": g9()}
     for name, obj in payload.items():
         with open(os.path.join(GOLDEN, name), "wt") as fh:
             json.dump(obj, fh, indent=None, separators=(",", ":"), sort_keys=True)

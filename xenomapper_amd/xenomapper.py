@@ -1130,32 +1130,13 @@ def main(argv=None):
                  primary_multi=args.primary_multi, secondary_multi=args.secondary_multi,
                  unassigned=args.unassigned, unresolved=args.unresolved)
     skip_repeated = not args.paired
+    # regular files reach the C++ stripper / writer through the readpairs objects (see _ReadPairs); anything else is
+    # split line by line in Python
     if args.primary_sam:
         process_headers(args.primary_sam, args.secondary_sam, **sinks)
-        names = [getattr(f, "name", None) for f in (args.primary_sam, args.secondary_sam)]
-        if all(isinstance(nm, str) and os.path.isfile(nm) for nm in names) and not os.environ.get("XENOMAPPER_PYTHON_READER"):
-            # regular files: C++ column stripper -> GPU -> C++ writer
-            category_counts = classify_sam_files(names[0], names[1], paired=args.paired, conservative=args.conservative,
-                                                 min_score=args.min_score, tag_func=tag_func,
-                                                 skip_repeated_reads=skip_repeated, **sinks)
-            output_summary(category_counts=category_counts, outfile=sys.stderr)
-            for sink in sinks.values():
-                if sink and sink not in (sys.stdout, sys.stderr):
-                    sink.flush()
-            return
         readpairs = getReadPairs(args.primary_sam, args.secondary_sam, skip_repeated_reads=skip_repeated)
     else:
         process_headers(args.primary_bam, args.secondary_bam, bam=True, **sinks)
-        names = [getattr(f, "name", None) for f in (args.primary_bam, args.secondary_bam)]
-        if all(isinstance(nm, str) and os.path.isfile(nm) for nm in names) and not os.environ.get("XENOMAPPER_PYTHON_READER"):
-            category_counts = classify_sam_files(names[0], names[1], paired=args.paired, conservative=args.conservative,
-                                                 min_score=args.min_score, tag_func=tag_func,
-                                                 skip_repeated_reads=skip_repeated, bam=True, **sinks)
-            output_summary(category_counts=category_counts, outfile=sys.stderr)
-            for sink in sinks.values():
-                if sink and sink not in (sys.stdout, sys.stderr):
-                    sink.flush()
-            return
         readpairs = getBamReadPairs(args.primary_bam, args.secondary_bam, skip_repeated_reads=skip_repeated)
     if args.paired:
         loop = conservative_main_paired_end if args.conservative else main_paired_end
