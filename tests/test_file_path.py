@@ -349,12 +349,15 @@ def test_g8_large_runs_like_the_reference(case, tmp_path):
 G9 = H.golden("g9_cli.json")["cases"]
 
 
+@pytest.mark.parametrize("reader", ["stripper", "python"])
 @pytest.mark.parametrize("case", G9, ids=[c["name"] for c in G9])
-def test_g9_command_line_like_the_reference(case, tmp_path, capsys):
+def test_g9_command_line_like_the_reference(case, reader, tmp_path, capsys, monkeypatch):
     """The reference's command line, run as a child process on these inputs and flags (G9): same exit status, same
     bytes on stdout, same summary on stderr, same output files; a crash is the same exception type and message."""
     import os
     from xenomapper_amd import xenomapper as xm
+    if reader == "python":
+        monkeypatch.setenv("XENOMAPPER_PYTHON_READER", "1")        # the line-by-line path instead of the C++ stripper
     argv = []
     src = case["source"]
     if src["kind"] == "ref_data":
