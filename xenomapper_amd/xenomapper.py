@@ -831,6 +831,52 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                                        wins[1][3], score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
         return blk, [w[0] for w in wins], [w[1] for w in wins], [w[3] for w in wins]
 
+    def settle(block, raws, pos, parser, pending):
+        """Classify one parsed block and hand its units to the sinks.  Returns the input error to raise once the
+        units in front of it have been written (one found while resolving the stripper's exceptions comes first)."""
+        n = block.n
+        flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:n].astype(bool)
+        if paired:
+            needed = flags.copy()
+            needed[:-1] |= flags[1:]
+        else:
+            needed = np.ones(n, dtype=bool)
+        patches, bad, err = _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode) if block.exc \
+            else ({}, None, None)
+        if err is not None:
+            n, pending = bad, err                                # units closing at index >= bad are not reached
+        if n:
+            with prof("classify"):
+                code, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
+            with prof("compact"):
+                idx, off, _ = ctx.compact(mode, code)
+            limit, state_error = None, None
+            if int(off[7]) != int(off[6]):
+                limit = int(idx[int(off[6]):int(off[7])].min())
+                state_error = RuntimeError("Error in processing logic with values {0} ".format(
+                    tuple(int(block.cols[c][limit]) for c in range(4))))
+            for b in (range(6) if distinct else ()):
+                if sinks[b]:
+                    seg = idx[int(off[b]):int(off[b + 1])]
+                    if limit is not None:
+                        seg = seg[seg < limit]
+                    with prof("emit"):
+                        text = parser.emit(paired, b, seg, reuse=True)
+                    with prof("write"):
+                        _write_bytes(sinks[b], text)
+            if not distinct:
+                _emit_shared(parser, paired, code, idx, off, sinks, limit)
+            if state_error is not None:
+                raise state_error
+            unit_codes = code[code != _ffi.NO_UNIT]
+            uniq, first_at = np.unique(unit_codes, return_index=True)
+            for c in uniq[np.argsort(first_at)].tolist():
+                key = STATE_NAMES[c] if not paired else (STATE_NAMES[c >> 3], STATE_NAMES[c & 7])
+                if key not in totals:
+                    key_order.append(key)
+                totals[key] += int(counts[c])
+        return pending
+
     which = 0
     future = None
     try:
@@ -846,8 +892,6 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 return _finish_in_python(mode, path1, path2, [src.pos for src in sources], sinks, min_score, tag_func,
                                          skip_repeated, totals, key_order)
             block, raws, pos, eofs = parsed
-            parser = parsers[which]
-            n = block.n
             progressed = block.consumed[0] > 0 or block.consumed[1] > 0
             if block.starved and not progressed and not (eofs[0] and eofs[1]):
                 window *= 2                                      # a line (or run of equal names) longer than the window
@@ -858,46 +902,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 for f in (0, 1):
                     sources[f].advance(block.consumed[f])
                 future = pool.submit(parse_next, which ^ 1, window)   # parse the next window while this one is classified
-            flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:n].astype(bool)
-            if paired:
-                needed = flags.copy()
-                needed[:-1] |= flags[1:]
-            else:
-                needed = np.ones(n, dtype=bool)
-            patches, bad, err = _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode) if block.exc \
-                else ({}, None, None)
-            if err is not None:
-                n, pending = bad, err                                # units closing at index >= bad are not reached
-            if n:
-                with prof("classify"):
-                    code, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
-                with prof("compact"):
-                    idx, off, _ = ctx.compact(mode, code)
-                limit, state_error = None, None
-                if int(off[7]) != int(off[6]):
-                    limit = int(idx[int(off[6]):int(off[7])].min())
-                    state_error = RuntimeError("Error in processing logic with values {0} ".format(
-                        tuple(int(block.cols[c][limit]) for c in range(4))))
-                for b in (range(6) if distinct else ()):
-                    if sinks[b]:
-                        seg = idx[int(off[b]):int(off[b + 1])]
-                        if limit is not None:
-                            seg = seg[seg < limit]
-                        with prof("emit"):
-                            text = parser.emit(paired, b, seg, reuse=True)
-                        with prof("write"):
-                            _write_bytes(sinks[b], text)
-                if not distinct:
-                    _emit_shared(parser, paired, code, idx, off, sinks, limit)
-                if state_error is not None:
-                    raise state_error
-                unit_codes = code[code != _ffi.NO_UNIT]
-                uniq, first_at = np.unique(unit_codes, return_index=True)
-                for c in uniq[np.argsort(first_at)].tolist():
-                    key = STATE_NAMES[c] if not paired else (STATE_NAMES[c >> 3], STATE_NAMES[c & 7])
-                    if key not in totals:
-                        key_order.append(key)
-                    totals[key] += int(counts[c])
+            pending = settle(block, raws, pos, parsers[which], pending)
             if pending is not None:
                 raise pending
             if last:
