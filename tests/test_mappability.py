@@ -107,3 +107,40 @@ def test_correlate_golden_and_large_bit_exact():
         got = ctx.mate_correlate(track, density)
         want = H.c_mate_correlate(track, density)
         assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+G10 = H.golden("g10_mappability_cli.json")["cases"]
+
+
+def _run_mappability_cli(case, tmp_path, monkeypatch, capsys):
+    import hashlib
+    import os
+    from xenomapper_amd import mappability as mp
+    data = os.path.join(H.GOLDEN, "ref_data")
+    by = {c["name"]: c for c in G10}
+    (tmp_path / "single.wig").write_text(by["single_end_wiggle"]["stdout"]["text"])
+    argv = ["xenomappability"] + [a.replace("{D}", data).replace("{T}", str(tmp_path)) for a in case["argv"]]
+    monkeypatch.setattr("sys.argv", argv)
+    code, raised = 0, None
+    try:
+        mp.main()
+    except SystemExit as exc:
+        code = exc.code or 0
+    except Exception as exc:
+        code, raised = 1, "%s: %s" % (type(exc).__name__, exc)
+    out = capsys.readouterr().out
+    assert (code, raised) == (case["returncode"], case["exception"])
+    if case["name"] != "no_arguments":                           # its stdout is the help text, which is this build's own
+        assert (hashlib.sha224(out.encode("latin-1")).hexdigest(), len(out)) == (case["stdout"]["sha224"], case["stdout"]["len"])
+
+
+@pytest.mark.parametrize("case", [c for c in G10 if c["name"] != "paired_end_wiggle"], ids=lambda c: c["name"])
+def test_g10_command_line_host_steps(case, tmp_path, monkeypatch, capsys):
+    """The companion tool's command line as the reference ran it (G10): the steps that are host text work."""
+    _run_mappability_cli(case, tmp_path, monkeypatch, capsys)
+
+
+@pytest.mark.gpu
+def test_g10_command_line_paired_step(tmp_path, monkeypatch, capsys):
+    """... and the step whose inner loop is the GPU correlation kernel."""
+    _run_mappability_cli({c["name"]: c for c in G10}["paired_end_wiggle"], tmp_path, monkeypatch, capsys)

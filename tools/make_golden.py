@@ -20,6 +20,7 @@ Vectors:
   G7  a random corpus of small adversarial text pairs: error type, outputs and counts of the reference
   G8  100 k-pair text twins of configs 1, 2, 3, 5: counts, digests of the six outputs, summary
   G9  the command line as a child process: stdout, stderr, exit code, output files
+  G10 the companion tool's command line as a child process
 """
 import hashlib
 import io
@@ -591,6 +592,40 @@ def g9():
     return {"cases": cases}
 
 
+# ------------------------------------------------------------------ G10
+def g10():
+    """The companion tool's command line (mappability.py:275-331) as a child process on the reference's E. coli
+    fixtures: exit status and stdout of each of its three steps (the wiggle of step 3 is the input of step 4), the
+    version flag, the usage error and the missing --sam_for_sizes error.  {D} stands for tests/golden/ref_data."""
+    import subprocess
+    import tempfile
+    data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
+    runner = ("import sys; sys.dont_write_bytecode = True; sys.path.insert(0, %r); "
+              "from xenomapper import mappability as m; m.main()" % REF_ROOT)
+    cases = []
+    with tempfile.TemporaryDirectory() as d:
+        def run(name, argv_template, keep_stdout=False):
+            argv = [a.replace("{D}", data_dir).replace("{T}", d) for a in argv_template]
+            proc = subprocess.run([sys.executable, "-c", runner] + argv, capture_output=True, text=True, cwd=d)
+            case = {"name": name, "argv": argv_template, "returncode": proc.returncode,
+                    "stdout": {"sha224": hashlib.sha224(proc.stdout.encode("latin-1")).hexdigest(), "len": len(proc.stdout)},
+                    "exception": (proc.stderr.strip().splitlines()[-1] if "Traceback" in proc.stderr else None)}
+            if keep_stdout:
+                case["stdout"]["text"] = proc.stdout
+            cases.append(case)
+            return proc.stdout
+        run("simulate_reads_150", ["--fasta", "{D}/test_from_EcoliK12DH10B.fasta", "--readlength", "150"])
+        run("simulate_reads_default_length", ["--fasta", "{D}/test_from_EcoliK12DH10B.fasta"])
+        wig = run("single_end_wiggle", ["--mapped_test_data", "{D}/test_from_EcoliK12DH10B_150reads.sam"], keep_stdout=True)
+        with open(os.path.join(d, "single.wig"), "w") as fh:
+            fh.write(wig)
+        run("paired_end_wiggle", ["--single_end_wiggle", "{T}/single.wig", "--sam_for_sizes", "{D}/paired_end_testdata_human.sam"])
+        run("paired_needs_sam_for_sizes", ["--single_end_wiggle", "{T}/single.wig"])
+        run("version", ["--version"])
+        run("no_arguments", [])
+    return {"cases": cases}
+
+
 def header_golden():
     """process_headers on the PE fixtures (tests/test_xenomapper.py:29-54): full texts."""
     data_dir = os.path.join(REF_ROOT, "xenomapper", "tests", "data")
@@ -606,7 +641,7 @@ def main():
     payload = {"g1_mapping_state.json": g1(), "g2_tag_parsers.json": g2(), "g3_end_to_end.json": g3(),
                "g4_headers.json": header_golden(), "g5_errors.json": g5(), "g6_mappability.json": g6(),
                "g7_random_corpus.json": g7(), "g8_large_runs.json": g8(),
-               "g9_cli.json": g9()}
+               "g9_cli.json": g9(), "g10_mappability_cli.json": g10()}
     for name, obj in payload.items():
         with open(os.path.join(GOLDEN, name), "wt") as fh:
             json.dump(obj, fh, indent=None, separators=(",", ":"), sort_keys=True)

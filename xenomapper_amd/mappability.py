@@ -199,14 +199,16 @@ def command_line_interface():
 def main(args=None):
     if not args:
         args = command_line_interface()
+    out = sys.stdout                       # looked up now: the functions' defaults were bound when the module was imported
     if args.fasta:
-        simulate_reads(fastafile=args.fasta, readlength=args.readlength)
+        simulate_reads(fastafile=args.fasta, readlength=args.readlength, outfile=out)
     elif args.mapped_test_data:
-        single_end_mappability_from_sam(samfile=args.mapped_test_data)
+        single_end_mappability_from_sam(samfile=args.mapped_test_data, outfile=out)
     elif args.single_end_wiggle:
         if not args.sam_for_sizes:
             raise RuntimeError("You must provide a sam file to estimate the mate pair distance distribution")
-        paired_end_mappability(wiggle=args.single_end_wiggle, mate_density=mate_distribution_from_sam(args.sam_for_sizes))
+        paired_end_mappability(wiggle=args.single_end_wiggle, mate_density=mate_distribution_from_sam(args.sam_for_sizes),
+                               outfile=out)
 
 
 if __name__ == "__main__":  # pragma: no cover
