@@ -395,3 +395,22 @@ def test_g9_command_line_like_the_reference(case, reader, tmp_path, capsys, monk
         with open(tmp_path / (b + ".sam")) as fh:
             text = fh.read()
         assert (hashlib.sha224(text.encode("latin-1")).hexdigest(), len(text)) == (want["sha224"], want["len"]), b
+
+
+@pytest.mark.parametrize("name", ["cfg2_pe_liberal_100k", "cfg3_pe_cigar_100k"])
+def test_g8_large_runs_through_the_python_reader(name):
+    """The same 100 k-pair runs through the line-by-line Python path (blocks of BLOCK_RECORDS records)."""
+    from xenomapper_amd import xenomapper as xm
+    case = {c["name"]: c for c in G8}[name]
+    t1, t2 = H.case_texts(case)
+    s1, s2 = io.StringIO(t1), io.StringIO(t2)
+    outs = {n: io.StringIO() for n in H.STATES}
+    xm.process_headers(s1, s2, **outs)
+    loop = {"se": xm.main_single_end, "pe": xm.main_paired_end, "pe_conservative": xm.conservative_main_paired_end}[case["mode"]]
+    counts = loop(xm.getReadPairs(s1, s2, skip_repeated_reads=case["options"]["skip_repeated"]),
+                  min_score=H.unnum(case["options"]["min_score"]), tag_func=getattr(xm, case["options"]["tag_func"]), **outs)
+    exp = case["expect"]
+    assert {("|".join(k) if isinstance(k, tuple) else k): v for k, v in counts.items()} == exp["counts"]
+    for n in H.STATES:
+        text = outs[n].getvalue()
+        assert (hashlib.sha224(text.encode("latin-1")).hexdigest(), len(text)) == (exp["bins"][n]["sha224"], exp["bins"][n]["len"]), n
