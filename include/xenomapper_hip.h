@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XM_ABI_VERSION 1
+#define XM_ABI_VERSION 2
 
 #define XM_ABSENT   INT32_MIN
 #define XM_NO_UNIT  0xFFu
@@ -58,6 +58,7 @@ extern "C" {
 #define XM_ERR_HIP         (-3)   /* a HIP call failed; xm_last_hip_error() has details */
 #define XM_ERR_OOM         (-4)
 #define XM_ERR_RANGE       (-5)   /* a CIGAR-derived score does not fit the int32 column */
+#define XM_ERR_RCCL        (-6)   /* librccl missing or an RCCL call failed; xm_last_hip_error() has details */
 
 typedef struct xm_ctx xm_ctx;
 
@@ -129,6 +130,28 @@ int xm_compact(xm_ctx *ctx, int mode, uint64_t n_records, const uint8_t *code,
                uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
 
 /*
+ * One whole main loop per call (xenomapper.py:321-350, :398-452, :498-554): what xm_classify + xm_compact give, from
+ * one fused pass -- the category bytes stay on the device between the two stages and category_counts come from the
+ * kernels.  code_out may be NULL when the caller only needs the bins (the emission rule needs nothing else);
+ * idx_out, bin_offsets and counts as for xm_compact.
+ */
+int xm_classify_compact(xm_ctx *ctx, int mode, uint64_t n_records,
+                        const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                        const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                        uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
+
+int xm_classify_compact_f64(xm_ctx *ctx, int mode, uint64_t n_records,
+                            const double *as1, const double *xs1, const double *as2, const double *xs2,
+                            const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                            uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
+
+int xm_classify_compact_cigar(xm_ctx *ctx, int mode, uint64_t n_records,
+                              const int32_t *nm1, const uint32_t *cig_off1, const uint32_t *cig_oplen1, const int32_t *xs1,
+                              const int32_t *nm2, const uint32_t *cig_off2, const uint32_t *cig_oplen2, const int32_t *xs2,
+                              const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                              uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
+
+/*
  * xenomappability (the reference's experimental companion tool): replaces the inner loop of
  * Mappability.single_end_to_paired (/root/reference/xenomapper/mappability.py:94-124) for one chromosome:
  * out[i] = 1.0 where track[i] == 1, else sum_j track[i+j] * density[j], j < min(m, n - i), accumulated left to right
@@ -168,9 +191,53 @@ int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n_records, const int
 int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,
                           const double *density, double *out);
 
-/* bin_offsets: 8 device uint64; counts: 64 device uint64 (both overwritten). */
+/* bin_offsets: 8 device uint64; counts: 64 device uint64 (both overwritten).
+ * The compaction workspace (per-granule counts and offsets, the count replicas) belongs to the context: ONE
+ * xm_compact_dev / xm_classify_compact*_dev call may be in flight per context at a time -- issue them on one stream,
+ * or order them with events; use one context per concurrent stream. */
 int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, const uint8_t *code,
                    uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
+
+/*
+ * One whole main loop (xenomapper.py:321-350, :398-452, :498-554) on device-resident columns: xm_classify_dev
+ * followed by xm_compact_dev, fused -- the classify kernel counts its units per category and per output bin while
+ * the category bytes are still in registers, so they are written once (code_out, n_records bytes, 16-byte aligned,
+ * required) and read once (by the scatter).  Outputs as xm_classify_dev + xm_compact_dev.  Same one-in-flight rule.
+ */
+int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                            const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                            const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                            uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
+
+int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                                const double *as1, const double *xs1, const double *as2, const double *xs2,
+                                const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                                uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
+
+int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                                  const int32_t *nm1, const uint32_t *cig_off1, const uint32_t *cig_oplen1, const int32_t *xs1,
+                                  const int32_t *nm2, const uint32_t *cig_off2, const uint32_t *cig_oplen2, const int32_t *xs2,
+                                  const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                                  uint32_t *range_flag, uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
+
+/* ---- multi-GPU: the one collective of the path ------------------------------------------ */
+/*
+ * The path shards by read block, one process (or thread) and one context per GPU; the only exchange is the sum of
+ * category_counts at the end of a run (the Counter the main loops return, xenomapper.py:420 / :520 / :330; printed
+ * once by output_summary :558-566).  RCCL over xGMI, 64 x uint64 = 512 bytes, latency-bound.  Bin index lists are
+ * never exchanged: shard order is input order.
+ * Rank 0 calls xm_comm_unique_id() and hands the XM_UNIQUE_ID_BYTES bytes to every rank out of band (a file, a
+ * socket, MPI, torch.distributed ...); every rank then calls xm_comm_init() (collective: returns when all n_ranks
+ * have joined).  librccl is looked up at run time -- a copy already mapped into the process (PyTorch's) is reused --
+ * so single-GPU users need none.
+ */
+#define XM_UNIQUE_ID_BYTES 128
+int xm_comm_unique_id(void *id_out /* XM_UNIQUE_ID_BYTES */);
+int xm_comm_init(xm_ctx *ctx, int n_ranks, int rank, const void *unique_id);
+int xm_comm_destroy(xm_ctx *ctx);                 /* also done by xm_ctx_destroy */
+int xm_comm_size(const xm_ctx *ctx);              /* ranks of the communicator, 0 = none */
+/* In-place sum over all ranks of 64 device uint64 (category_counts), asynchronous on `stream`. */
+int xm_allreduce_counts(xm_ctx *ctx, void *stream, uint64_t *counts_dev);
 
 /* ---- per-kernel timing (HIP events on the launch stream) ------------------------------ */
 #define XM_K_CLASSIFY 0

@@ -42,11 +42,18 @@ def check_all(ctx, mode, cols, bits, m_float):
     assert np.array_equal(off, want_off)
     assert np.array_equal(idx, want_idx)
     assert np.array_equal(counts2, want_counts)
+    # the fused pass (classify + count in one kernel, scan, scatter) gives the same four results
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, mi)
+    assert np.array_equal(fcode, want_code) and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
     # the binary64 path must agree with the integer path on integral input
     fcols = [np.where(c == ABSENT, NEG, c.astype(np.float64)) for c in cols]
     codef, countsf = ctx.classify_f64(mode, *fcols, bits, m_float)
     assert np.array_equal(codef, want_code)
     assert np.array_equal(countsf, want_counts)
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *fcols, bits, m_float, want_code=False)
+    assert fcode is None and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
 
 
 SIZES = [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12289,
@@ -225,6 +232,88 @@ def test_classify_cigar_fused(ctx, n):
                                           c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, mi)
         want, want_counts = _oracle_cigar_classify(mode, c1, xs[0], c2, xs[1], bits, mi)
         assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+        # the same through the fused pass (1024-record granules: the classify_cigar workgroup)
+        want_idx, want_off = H.c_compact(mode, want)
+        fcode, fidx, foff, fcounts = ctx.classify_compact_cigar(mode, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs[0],
+                                                                c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, mi)
+        assert np.array_equal(fcode, want) and np.array_equal(fcounts, want_counts)
+        assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
+
+
+# one realisation of every state (AS1, XS1, AS2, XS2); state 6 needs a NaN (binary64 path only)
+_REAL = {0: (0, 0, -5, ABSENT), 1: (-5, ABSENT, 0, 0), 2: (7, 7, 3, ABSENT), 3: (3, ABSENT, 7, 9),
+         4: (4, 0, 4, 0), 5: (ABSENT, 1, ABSENT, 1)}
+
+
+def _columns_of_states(states):
+    table = np.array([_REAL[k] for k in range(6)], dtype=np.int64)
+    return [np.ascontiguousarray(table[states, j]).astype(np.int32) for j in range(4)]
+
+
+_EDGE_N = 5 * 2048 + 77          # > one K2 workgroup (4 granules of 2048), ragged tail
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_split_edges_single_bin(ctx, mode):
+    """Whole granules / 256-record groups in ONE bin, for every bin: the rank of a unit is then its index, every
+    ballot mask is full, and every other bin is empty (the wave-uniform skips)."""
+    n = _EDGE_N
+    for b in range(6):
+        cols = _columns_of_states(np.full(n, b))
+        flags = np.ones(n, dtype=np.uint8)
+        if mode:
+            flags[0::2] = 0
+        check_all(ctx, mode, cols, H.synth.pack_unit_bits(flags), NEG)
+        if mode == 0:
+            code, idx, off, counts = ctx.classify_compact(0, *cols, H.synth.pack_unit_bits(flags), ABSENT)
+            assert int(off[b + 1] - off[b]) == n and np.array_equal(idx, np.arange(n, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("k", [1, 2, 127, 128, 255, 512, 1023])
+def test_split_edges_two_bins(ctx, mode, k):
+    """Every 1024 records: the first k in bin a, the rest in bin b, for every ordered pair (a, b) -- counts of
+    k / 1024-k (512-unit groups in the paired modes) meeting at every possible lane of a 256-record group."""
+    n = _EDGE_N
+    pos = np.arange(n) % 1024
+    for a, b in itertools.permutations(range(6), 2):
+        states = np.where(pos < k, a, b)
+        if mode:
+            states[0::2] = states[1::2][: len(states[0::2])] if n % 2 == 0 else np.append(states[1::2], states[-1])[: len(states[0::2])]
+        cols = _columns_of_states(states)
+        flags = np.ones(n, dtype=np.uint8)
+        if mode:
+            flags[0::2] = 0
+        check_all(ctx, mode, cols, H.synth.pack_unit_bits(flags), NEG)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_split_edges_with_state6_units(ctx, mode):
+    """State-6 units (NaN scores, binary64 path) inside otherwise single-bin granules: they go to slot 6 and leave
+    the ranks of the units around them intact."""
+    n = _EDGE_N
+    rng = np.random.default_rng(66)
+    for b in (0, 3, 5):
+        cols = [c.astype(np.float64) for c in _columns_of_states(np.full(n, b))]
+        cols = [np.where(c == ABSENT, NEG, c) for c in cols]
+        hit = rng.choice(n, 40, replace=False)
+        hit = np.concatenate([hit, [0, 1, 255, 256, 1023, 1024, 2047, 2048, n - 1]])
+        cols[0][hit] = float("nan")
+        cols[2][hit] = float("nan")
+        flags = np.ones(n, dtype=np.uint8)
+        if mode:
+            flags[0::2] = 0
+        bits = H.synth.pack_unit_bits(flags)
+        want, want_counts = H.c_classify(mode, *cols, bits, NEG)
+        want_idx, want_off = H.c_compact(mode, want)
+        assert int(want_off[7] - want_off[6]) > 0
+        code, counts = ctx.classify_f64(mode, *cols, bits, NEG)
+        assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+        idx, off, _ = ctx.compact(mode, code)
+        assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx)
+        fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, NEG)
+        assert np.array_equal(fcode, want) and np.array_equal(fcounts, want_counts)
+        assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
 
 
 @pytest.mark.parametrize("flavour", ["huge_op", "many_ops", "long_stretch", "huge_nm"])

@@ -63,6 +63,9 @@ def test_int_path(ctx, n, seed, mode, kind, mkind, m):
     idx, off, counts2 = ctx.compact(mode, code)
     want_idx, want_off = H.c_compact(mode, want)
     assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx) and np.array_equal(counts2, want_counts)
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m)
+    assert np.array_equal(fcode, want) and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
 
 
 @settings(max_examples=N_EX, deadline=None, suppress_health_check=list(HealthCheck))
@@ -79,6 +82,9 @@ def test_f64_path(ctx, n, seed, mode, m):
     idx, off, _ = ctx.compact(mode, code)
     want_idx, want_off = H.c_compact(mode, want)
     assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx)
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m)
+    assert np.array_equal(fcode, want) and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
 
 
 @settings(max_examples=N_EX, deadline=None, suppress_health_check=list(HealthCheck))
@@ -107,3 +113,8 @@ def test_cigar_path(ctx, n, seed, mode, max_ops, m):
                                       c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, m)
     want, want_counts = H.c_classify(mode, a1, xs[0], a2, xs[1], bits, m)
     assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+    want_idx, want_off = H.c_compact(mode, want)
+    fcode, fidx, foff, fcounts = ctx.classify_compact_cigar(mode, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs[0],
+                                                            c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, m)
+    assert np.array_equal(fcode, want) and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)

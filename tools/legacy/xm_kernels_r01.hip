@@ -1,12 +1,13 @@
+// FROZEN COPY of the round-1 kernels (git f617191), kept only so that tools/tune_kernels.hip can time old against new
+// on the same box in one process.  Not built into any product library.  Compile with -Dxm=xm_r01.
 // xm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the xenograft read classifier.
 //
 // Three stages, all HBM-bound integer/byte work (no MFMA):
 //   K1 classify   score columns -> one category byte per record     (16 B in, 1 B out / record)
-//                 fused form: K1 also counts its units per category and per bin (LDS histogram, last wave flushes)
 //   K2 compact    category bytes -> category_counts + a stable split of unit indices by bin
-//                 K2a histogram (only when the bytes come from memory: wave-private LDS) -> per-granule bin counts
-//                 K2b scan of the per-granule counts (one workgroup per bin)
-//                 K2c scatter: ballot + mbcnt ranks, scalar per-bin bases -> dense index runs, no LDS staging
+//                 K2a histogram (LDS, 64 slots x 32 replicas) -> per-chunk bin counts + counts[64]
+//                 K2b scan of the per-chunk counts (one workgroup)
+//                 K2c scatter: per-wave DPP scans, wave-private LDS slab -> contiguous index runs
 //   K3 cigar      NM + packed CIGAR (CSR) -> synthesised AS column
 //
 // Reference semantics restated (file:line into /root/reference/xenomapper/xenomapper.py):
@@ -88,96 +89,12 @@ __device__ __forceinline__ void load4(const T *__restrict__ col, uint64_t r0, ui
     }
 }
 
-// wave64 inclusive prefix sum with DPP (row_shr 1,2,4,8, row_bcast15, row_bcast31): no LDS traffic
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane)
-{
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
-}
-
-// This wave's LDS operations so far have been performed (LDS executes a wave's operations in issue order), and the
-// compiler moves no memory access across this point.
-__device__ __forceinline__ void lds_settle()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-// ---------------------------------------------------------------------------------------------
-// Counting (category_counts + the per-granule bin counts the stable split needs), shared by K1 (fused: the
-// category bytes are still in registers) and K2a (stand-alone compaction of category bytes from memory).
-//
-// A *granule* is the stretch of records one counting group owns: a K1 workgroup (BLOCK*4 records) or a K2a
-// wave (XM_GRAN_K2 records).  Per granule: bin counts -> gran_counts[bin][granule]; the 64 category slots ->
-// one of XM_COUNT_REPLICAS global copies of counts[64] (K2b adds the copies up).
-//
-// LDS layout of one counting group: hist[64 slots][XM_HREP replicas] (replica = lane & 7: a wave instruction's
-// atomics on one slot spread over 8 banks), then 16 words: [0] arrival counter, [8..15] bin counts.
-// ---------------------------------------------------------------------------------------------
-#define XM_HREP 8
-#define XM_COUNT_LDS_WORDS (64 * XM_HREP + 16)
-
-struct CountSink {
-    uint32_t *gran_counts;               // [8][gran_stride]
-    unsigned long long *counts_rep;      // [XM_COUNT_REPLICAS][64]
-    uint32_t gran_stride;
-    int mode;                            // bin rule of the flush
-};
-
-// one wave adds up the group's histogram (lane = category slot) and publishes it
-__device__ __forceinline__ void count_flush(uint32_t *lds, uint32_t granule, const CountSink &sink)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t *misc = lds + 64 * XM_HREP;
-    const uint4 h0 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP);
-    const uint4 h1 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP + 4);
-    const uint32_t s = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
-    if (s != 0u) {
-        atomicAdd(&sink.counts_rep[(granule % XM_COUNT_REPLICAS) * 64u + lane], (unsigned long long)s);
-        atomicAdd(&misc[8u + bin_of_code(sink.mode, lane)], s);          // a counted slot is never 0xFF: bin <= 6
-    }
-    lds_settle();
-    if (lane < 8u) sink.gran_counts[(uint64_t)lane * sink.gran_stride + granule] = misc[8u + lane];
-}
-
-// K1 side: every wave adds its (up to 4 per lane) category bytes; the last wave to arrive flushes.  `lds` must have
-// been zeroed by the workgroup before a barrier that precedes this call.  No barrier of its own.
-template <int BLOCK>
-__device__ __forceinline__ void count_units(const uint32_t c[4], uint32_t *lds, const CountSink &sink)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rep = lane & (XM_HREP - 1u);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool unit = c[j] != XM_NO_UNIT;
-        if (__ballot(unit) == 0ull) continue;                             // wave-uniform (interleaved mates: j = 0, 2)
-        if (unit) atomicAdd(&lds[(c[j] & 63u) * XM_HREP + rep], 1u);
-    }
-    lds_settle();                                                         // this wave's counts are in
-    uint32_t arrived = 0;
-    if (lane == 0u) arrived = atomicAdd(&lds[64 * XM_HREP], 1u);
-    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-    if (arrived != (uint32_t)(BLOCK / 64 - 1)) return;
-    lds_settle();
-    count_flush(lds, blockIdx.x, sink);
-}
-
 // Shared K1 epilogue: 4 states per lane -> forward mate's state (lane-1 / previous wave via LDS / halo) ->
-// 4 category bytes -> one 4-byte store (-> counts, when fused).
-template <typename T, bool PAIRED, int BLOCK, bool FULL, bool COUNTS>
+// 4 category bytes -> one 4-byte store.
+template <typename T, bool PAIRED, int BLOCK, bool FULL>
 __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], const T a2[4], const T x2[4], T m,
                                                 uint32_t mb, uint32_t halo, uint32_t *last_state,
-                                                uint8_t *__restrict__ code, uint64_t r0, uint64_t n,
-                                                uint32_t *count_lds, const CountSink &sink)
+                                                uint8_t *__restrict__ code, uint64_t r0, uint64_t n)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -196,7 +113,6 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
         c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
         c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
     } else {
-        if (COUNTS) __syncthreads();                  // the zeroed count_lds is visible (paired: the barrier above)
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[j] = ((mb >> j) & 1u) ? s[j] : XM_NO_UNIT;
     }
@@ -208,7 +124,6 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
         for (int j = 0; j < 4; ++j)
             if (r0 + j < n) code[r0 + j] = (uint8_t)c[j];
     }
-    if (COUNTS) count_units<BLOCK>(c, count_lds, sink);
 }
 
 // One lane owns 4 consecutive records, so each column is read with one 16-byte (int32) load per
@@ -221,12 +136,11 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
 // NT: the score columns are read once and never again, so they are loaded non-temporally; the
 // category bytes are stored with the default policy because K2 reads them next (100 MB at the
 // 50 M-pair configuration, which fits the 256 MiB Infinity Cache).
-template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL, bool COUNTS>
+template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL>
 __device__ __forceinline__ void classify_body(const T *__restrict__ as1, const T *__restrict__ xs1,
                                               const T *__restrict__ as2, const T *__restrict__ xs2,
                                               const uint8_t *__restrict__ unit_bits8, T m,
-                                              uint8_t *__restrict__ code, uint64_t n, uint32_t *last_state,
-                                              uint32_t *count_lds, const CountSink &sink)
+                                              uint8_t *__restrict__ code, uint64_t n, uint32_t *last_state)
 {
     const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
     const uint64_t r0 = g * 4;
@@ -250,42 +164,27 @@ __device__ __forceinline__ void classify_body(const T *__restrict__ as1, const T
             mb &= ~1u;                                         // record 0 has no predecessor (:402)
         }
     }
-    classify_finish<T, PAIRED, BLOCK, FULL, COUNTS>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, count_lds, sink);
+    classify_finish<T, PAIRED, BLOCK, FULL>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
 }
 
-template <int BLOCK>
-__device__ __forceinline__ void count_lds_clear(uint32_t *count_lds)
-{
-    for (uint32_t k = threadIdx.x; k < (uint32_t)XM_COUNT_LDS_WORDS; k += BLOCK) count_lds[k] = 0;
-}
-
-// COUNTS: the fused form (xm_classify_compact*): the workgroup also counts its units per category and per bin, so
-// the category bytes are not read again for a histogram; a granule = this workgroup's BLOCK*4 records.
-template <typename T, bool PAIRED, bool NT, int BLOCK, bool COUNTS>
+template <typename T, bool PAIRED, bool NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
                 const T *__restrict__ as2, const T *__restrict__ xs2,
                 const uint8_t *__restrict__ unit_bits8, T m,
-                uint8_t *__restrict__ code, uint64_t n, CountSink sink)
+                uint8_t *__restrict__ code, uint64_t n)
 {
     __shared__ uint32_t last_state[BLOCK / 64];
-    __shared__ __attribute__((aligned(16))) uint32_t count_lds[COUNTS ? XM_COUNT_LDS_WORDS : 4];
-    if (COUNTS) count_lds_clear<BLOCK>(count_lds);
     // every workgroup but possibly the last covers BLOCK*4 existing records: no bounds tests on that path
     if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
-        classify_body<T, PAIRED, NT, BLOCK, true, COUNTS>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
+        classify_body<T, PAIRED, NT, BLOCK, true>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state);
     else
-        classify_body<T, PAIRED, NT, BLOCK, false, COUNTS>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
+        classify_body<T, PAIRED, NT, BLOCK, false>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 geometry.  Counting and splitting work granule by granule; a wave owns one granule and nothing is shared between
-// waves, so K2a and K2c have no workgroup barrier.  Lane order == record order everywhere, which is what makes the
-// split stable.  Stand-alone compaction uses XM_GRAN_K2-record granules; after a fused K1 the granule is K1's
-// workgroup (2048 records for classify_kernel, 1024 for classify_cigar_kernel).
+// K2 shared: load one thread's 16 category bytes of a 4096-record tile
 // ---------------------------------------------------------------------------------------------
-
-// 16 category bytes of one lane; past the end of the input: XM_NO_UNIT
 __device__ __attribute__((noinline)) uint4 load_codes16_tail(const uint8_t *__restrict__ code, uint64_t base, uint64_t n)
 {
     uint32_t w[4];
@@ -306,252 +205,407 @@ __device__ __forceinline__ void load_codes16(const uint8_t *__restrict__ code, u
 {
     uint4 v;
     if (base + 16 <= n) v = *reinterpret_cast<const uint4 *>(code + base);
-    else v = load_codes16_tail(code, base, n);          // last, partial granule only
+    else v = load_codes16_tail(code, base, n);          // last, partial tile only
     w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 
-__device__ __attribute__((noinline)) uint32_t load_codes4_tail(const uint8_t *__restrict__ code, uint64_t base, uint64_t n)
+// ---------------------------------------------------------------------------------------------
+// K2 geometry.  A wave owns XM_K consecutive wave tiles of XM_WTILE records (16 category bytes per
+// lane, lane l holds records 16l..16l+15 of the tile, so lane order == input order); a workgroup
+// (chunk) owns 4 consecutive wave spans = XM_CHUNK records.  All of a wave's category bytes stay in
+// registers between counting and scattering, so the bytes are read from memory once per kernel.
+// ---------------------------------------------------------------------------------------------
+
+// wave64 inclusive prefix sum with DPP (row_shr 1,2,4,8, row_bcast15, row_bcast31): no LDS traffic
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 {
-    uint32_t acc = 0;
-    for (int j = 0; j < 4; ++j) {
-        const uint64_t i = base + j;
-        const uint32_t c = (i < n) ? (uint32_t)code[i] : XM_NO_UNIT;
-        acc |= c << (8 * j);
-    }
-    return acc;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2a: histogram of category bytes in memory (stand-alone xm_compact*; the fused path counts in K1).  One wave =
-// one granule of XM_GRAN_K2 records (32 bytes per lane), wave-private LDS histogram.  A byte position at which no
-// lane of the wave holds a unit (every other position of interleaved paired input) is skipped wave-uniformly; units
-// of the wave's presumably dominant category (the first unit of its first lane) are counted in a register and reach
-// LDS with one atomic per lane.
+// K2a: histogram.  LDS holds 64 category slots x 32 replicas (replica = lane & 31, so the 64 atomics
+// of a wave instruction spread over all 32 banks).  A byte position at which no lane of the wave
+// holds a unit (every other position of interleaved paired input) is skipped wave-uniformly.
+// Outputs: counts_rep[replica][64] (partial category_counts) and chunk_counts[bin][chunk] for the scan.
 // ---------------------------------------------------------------------------------------------
+template <int K>
 __global__ void __launch_bounds__(XM_BLOCK)
-hist_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t n_gran, CountSink sink)
+hist_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t chunk_stride,
+            uint32_t *__restrict__ chunk_counts, unsigned long long *__restrict__ counts_rep)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[XM_BLOCK / 64][XM_COUNT_LDS_WORDS];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *lds = lds_all[wave];
-    const uint32_t g = blockIdx.x * (XM_BLOCK / 64) + wave;
-    if (g >= n_gran) return;                                              // wave-uniform; no barrier in this kernel
-    for (uint32_t k = lane; k < (uint32_t)XM_COUNT_LDS_WORDS; k += 64u) lds[k] = 0;
+    __shared__ uint32_t hist[64 * 32];
+    __shared__ uint32_t binc[8];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    for (uint32_t k = t; k < 64 * 32; k += XM_BLOCK) hist[k] = 0;
+    if (t < 8) binc[t] = 0;
+    __syncthreads();
 
-    constexpr int TILES = XM_GRAN_K2 / 1024;
-    const uint64_t rec0 = (uint64_t)g * XM_GRAN_K2;
-    uint32_t w[TILES][4];
+    const uint64_t span0 = ((uint64_t)blockIdx.x * (XM_BLOCK / 64) + wave) * (uint64_t)(K * XM_WTILE);
+    uint32_t w[K][4];
 #pragma unroll
-    for (int k = 0; k < TILES; ++k) load_codes16(code, rec0 + (uint64_t)k * 1024u + lane * 16u, n, w[k]);
-    lds_settle();
+    for (int k = 0; k < K; ++k) load_codes16(code, span0 + (uint64_t)k * XM_WTILE + lane * 16u, n, w[k]);
 
-    const uint32_t rep = lane & (XM_HREP - 1u);
+    const uint32_t rep = t & 31u;
+    // One category usually dominates (both mates primary-specific in a xenograft).  The wave takes the first unit of
+    // its first lane as its guess `common`; units of that category are counted in a register and reach LDS with one
+    // atomic per lane at the end, so the per-position atomics carry only the other lanes -- fewer of the lane pairs
+    // (l, l + 32) that share a bank are both active, and the instruction mostly takes one pass instead of two.
     uint32_t common = w[0][0] & 0xFFu;
     if (common == XM_NO_UNIT) common = (w[0][0] >> 8) & 0xFFu;
     common = (uint32_t)__builtin_amdgcn_readfirstlane((int)common);
     uint32_t n_common = 0;
 #pragma unroll
-    for (int k = 0; k < TILES; ++k) {
+    for (int k = 0; k < K; ++k) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t c = (w[k][j >> 2] >> (8 * (j & 3))) & 0xFFu;
             const bool unit = c != XM_NO_UNIT;
-            if (__ballot(unit) == 0ull) continue;                         // wave-uniform
+            if (__ballot(unit) == 0ull) continue;                     // wave-uniform
             const bool same = unit && c == common;
             n_common += same ? 1u : 0u;
-            if (unit && !same) atomicAdd(&lds[(c & 63u) * XM_HREP + rep], 1u);
+            if (unit && !same) atomicAdd(&hist[(c & 63u) * 32 + rep], 1u);
         }
     }
-    if (n_common) atomicAdd(&lds[(common & 63u) * XM_HREP + rep], n_common);
-    lds_settle();
-    count_flush(lds, g, sink);
+    if (n_common) atomicAdd(&hist[(common & 63u) * 32 + rep], n_common);
+    __syncthreads();
+
+    // 4 threads per slot, 8 replicas each
+    const uint32_t slot = t >> 2, q = t & 3u;
+    uint32_t s = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += hist[slot * 32 + q * 8 + r];
+    s += (uint32_t)__shfl_xor((int)s, 1, 64);
+    s += (uint32_t)__shfl_xor((int)s, 2, 64);
+    if (q == 0 && s != 0u) {
+        // XM_COUNT_REPLICAS copies of counts[64] keep same-address atomics rare; K2b adds them up
+        atomicAdd(&counts_rep[(blockIdx.x % XM_COUNT_REPLICAS) * 64u + slot], (unsigned long long)s);
+        atomicAdd(&binc[bin_of_code(mode, slot)], s);
+    }
+    __syncthreads();
+    if (t < 8) chunk_counts[(uint64_t)t * chunk_stride + blockIdx.x] = binc[t];
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2b: exclusive scan of the per-granule bin counts, two levels, two small launches.  A part = XM_PART_GRAN = 1024
-// consecutive granules.  part_sum_kernel: workgroup (part p, bin b) adds up its 1024 granule counts.  scan_kernel:
-// workgroup (p, b) takes its carry from the part totals before p and scans its own 1024 counts once -- nobody passes
-// over all counts, nothing depends on another workgroup of the same launch.  gran_off[b][g] = units of bin b in
-// granules < g; bin_totals[b] = units of bin b.  Workgroups of part 0 also add up the replicas of category_counts (8
-// slots per bin row) and zero them again.  (Adding the part totals up from the counting kernels with atomics
-// instead was tried: ~14 hot addresses at a time, K1 282 -> 506 us.)
+// K2b: exclusive scan of the per-chunk bin counts.  Workgroup b (1024 threads) scans bin b: each of its
+// 16 waves owns a contiguous range of chunks, sums it, and after one barrier rescans it with the
+// carry of the ranges before.  chunk_off[b][k] = units of bin b in chunks < k; bin_totals[b] = units of
+// bin b.  The workgroups also add up the replicas of category_counts (8 slots each) and zero them again.
 // ---------------------------------------------------------------------------------------------
 #define XM_SCAN_THREADS 1024
-__device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long v, unsigned long long *wsum)
-{
-    v += __shfl_xor(v, 1, 64);  v += __shfl_xor(v, 2, 64);  v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-    if ((threadIdx.x & 63u) == 0u) wsum[threadIdx.x >> 6] = v;
-    __syncthreads();
-    unsigned long long total = 0;
-#pragma unroll
-    for (int w = 0; w < XM_SCAN_THREADS / 64; ++w) total += wsum[w];
-    return total;
-}
-
 __global__ void __launch_bounds__(XM_SCAN_THREADS)
-part_sum_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t gran_stride, uint32_t *__restrict__ part_tot)
-{
-    __shared__ unsigned long long wsum[XM_SCAN_THREADS / 64];
-    const uint32_t p = blockIdx.x, b = blockIdx.y;
-    const uint32_t g = p * XM_PART_GRAN + threadIdx.x;
-    const unsigned long long x = (g < n_gran) ? gran_counts[(uint64_t)b * gran_stride + g] : 0u;
-    const unsigned long long total = block_sum_1024(x, wsum);
-    if (threadIdx.x == 0u) part_tot[b * XM_PART_STRIDE + p] = (uint32_t)total;        // <= 1024 granules x 2048 units
-}
-
-__global__ void __launch_bounds__(XM_SCAN_THREADS)
-scan_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t gran_stride,
-            const uint32_t *__restrict__ part_tot, uint32_t *__restrict__ gran_off,
-            unsigned long long *__restrict__ bin_totals,
+scan_kernel(const uint32_t *__restrict__ chunk_counts, uint32_t n_chunks, uint32_t chunk_stride,
+            uint32_t *__restrict__ chunk_off, unsigned long long *__restrict__ bin_totals,
             unsigned long long *__restrict__ counts_rep, unsigned long long *__restrict__ counts)
 {
     __shared__ unsigned long long wsum[XM_SCAN_THREADS / 64];
-    __shared__ uint32_t wtot[XM_SCAN_THREADS / 64];
-    const uint32_t p = blockIdx.x, b = blockIdx.y, n_parts = gridDim.x;
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    if (p == 0u && t < 64u) {   // category_counts slots 8b..8b+7: 8 lanes per slot, 8 replicas each
-        const uint32_t slot = b * 8u + (t >> 3), part = t & 7u;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {   // category_counts slots 8b..8b+7: 8 lanes per slot, 8 replicas each
+        const uint32_t slot = b * 8u + (threadIdx.x >> 3), part = threadIdx.x & 7u;
         unsigned long long acc = 0;
         for (uint32_t r = part; r < XM_COUNT_REPLICAS; r += 8u) {
             acc += counts_rep[r * 64u + slot];
-            counts_rep[r * 64u + slot] = 0;               // consumed: leave the replicas zeroed for the next count
+            counts_rep[r * 64u + slot] = 0;               // consumed: leave the replicas zeroed for the next K2a
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
         if (part == 0) counts[slot] = acc;
     }
-    // carry: units of bin b in the parts before this one
-    const uint32_t *tot_row = part_tot + b * XM_PART_STRIDE;
-    unsigned long long part_sum = 0;
-    for (uint32_t q = t; q < p; q += XM_SCAN_THREADS) part_sum += tot_row[q];
-    const unsigned long long carry = block_sum_1024(part_sum, wsum);
-    if (p + 1u == n_parts && t == 0u) bin_totals[b] = carry + tot_row[p];
+    const uint32_t *src = chunk_counts + (uint64_t)b * chunk_stride;
+    uint32_t *dst = chunk_off + (uint64_t)b * chunk_stride;
+    const uint32_t n_waves = XM_SCAN_THREADS / 64;
+    const uint32_t seg = (((n_chunks + n_waves - 1) / n_waves) + 63u) & ~63u;     // chunks per wave, multiple of 64
+    const uint32_t k_begin = wave * seg;
+    const uint32_t k_end = (k_begin + seg < n_chunks) ? k_begin + seg : n_chunks;
 
-    // this part's granules: one per thread
-    const uint32_t g = p * XM_PART_GRAN + t;
-    const uint32_t x = (g < n_gran) ? gran_counts[(uint64_t)b * gran_stride + g] : 0u;
-    const uint32_t incl = wave_scan_incl(x);
-    if (lane == 63u) wtot[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wave; ++w) before += wtot[w];
-    if (g < n_gran) gran_off[(uint64_t)b * gran_stride + g] = (uint32_t)carry + before + incl - x;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2c: scatter.  One wave = one granule, taken 256 records (one dword of category bytes per lane) at a time.
-// A unit's place in its bin is   (bin start) + (bin's units in earlier granules: K2b) + (rank inside the granule),
-// and the rank comes from ballots: for every bin that occurs in the 256 records, the lanes holding it form a 64-bit
-// mask per byte position, v_mbcnt counts the mask bits below the lane, and the running per-bin base lives in scalar
-// registers.  Lanes of one bin therefore write one dense run of idx_out per store instruction -- no LDS staging, no
-// barrier.  The byte -> bin rule (mode dependent) is a 64-entry wave-private LDS table, read conflict-free.
-// SLOTS: which of a lane's 4 byte positions can hold units -- 0b1010 for strictly interleaved mates (a wave-uniform
-// test per 256 records), else 0b1111.  WIDE: byte offsets into idx_out need more than 32 bits.
-// ---------------------------------------------------------------------------------------------
-// XM_SCATTER_GUARD: no index is stored past the number of units (what K2b reported), whatever the category bytes hold
-#ifndef XM_SCATTER_GUARD
-#define XM_SCATTER_GUARD 1
-#endif
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask, uint32_t add)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, add));
-}
-
-template <bool WIDE>
-__device__ __forceinline__ void store_index(uint32_t *__restrict__ idx_out, uint32_t pos, uint32_t rec)
-{
-    if (WIDE) idx_out[pos] = rec;
-    else *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(idx_out) + (pos << 2)) = rec;   // SGPR base + 32-bit offset
-}
-
-template <int SLOTS, bool WIDE>
-__device__ __forceinline__ void scatter_256(uint32_t w, const uint8_t *lut, uint32_t rec0, uint32_t base[7],
-                                            uint32_t *__restrict__ idx_out, uint32_t n_units)
-{
-    uint32_t bin[4], pos[4] = {0, 0, 0, 0};
+    // pass 1: sum of the wave's range (8 coalesced loads in flight per lane)
+    unsigned long long sum = 0;
+    for (uint32_t j0 = k_begin; j0 < k_end; j0 += 64u * 8u) {
+        uint32_t x[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bin[j] = ((SLOTS >> j) & 1) ? (uint32_t)lut[(w >> (8 * j)) & 63u] : 7u;
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        uint64_t m[4], any = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            m[j] = ((SLOTS >> j) & 1) ? __ballot(bin[j] == (uint32_t)b) : 0ull;
-            any |= m[j];
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = j0 + (uint32_t)u * 64u + lane;
+            x[u] = (k < k_end) ? src[k] : 0u;
         }
-        if (any == 0ull) continue;              // wave-uniform: bin b does not occur here (inside the pipeline 1-2 % faster)
-        uint32_t t = base[b];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) t = mbcnt64(m[j], t);                    // + units of bin b in lower lanes
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) pos[j] = (bin[j] == (uint32_t)b) ? t : pos[j];
-        uint32_t total = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) total += (uint32_t)__builtin_popcountll(m[j]);
-        base[b] += total;
+        for (int u = 0; u < 8; ++u) sum += x[u];
     }
-    // units of the same bin earlier in this lane
+    sum += __shfl_xor(sum, 1, 64);  sum += __shfl_xor(sum, 2, 64);  sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 8, 64);  sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    if (lane == 0) wsum[wave] = sum;
+    __syncthreads();
+    unsigned long long carry = 0, total = 0;
+    for (uint32_t wv = 0; wv < n_waves; ++wv) {
+        const unsigned long long v = wsum[wv];
+        carry += (wv < wave) ? v : 0ull;
+        total += v;
+    }
+    if (threadIdx.x == 0) bin_totals[b] = total;
+
+    // pass 2: rescan the range (now cache-resident) with the carry
+    for (uint32_t j0 = k_begin; j0 < k_end; j0 += 64u * 8u) {
+        uint32_t x[8];
 #pragma unroll
-    for (int j = 1; j < 4; ++j)
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = j0 + (uint32_t)u * 64u + lane;
+            x[u] = (k < k_end) ? src[k] : 0u;
+        }
 #pragma unroll
-        for (int i = 0; i < j; ++i)
-            if (((SLOTS >> j) & 1) && ((SLOTS >> i) & 1)) pos[j] += (bin[i] == bin[j]) ? 1u : 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (((SLOTS >> j) & 1) && bin[j] < 7u && (!XM_SCATTER_GUARD || pos[j] < n_units))
-            store_index<WIDE>(idx_out, pos[j], rec0 + (uint32_t)j);
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = j0 + (uint32_t)u * 64u + lane;
+            const uint32_t incl = wave_scan_incl(x[u]);
+            if (k < k_end) dst[k] = (uint32_t)carry + incl - x[u];
+            carry += lane_value(incl, 63);
+        }
+    }
 }
 
-template <int NSUB, bool WIDE>
+// ---------------------------------------------------------------------------------------------
+// K2c: scatter.  Per wave tile: per-lane bin counters packed in one 64-bit register (bins 0..2 as
+// 10-bit fields of the low word, 3..5 of the high word, everything else into a 2-bit sink at bit 62)
+// -> DPP wave scan -> position of every unit in the tile's (bin, input order) sorted order -> record
+// indices staged in the wave's private LDS slab -> each bin's run written out contiguously.
+// One workgroup barrier per chunk (to order the four waves' bases); everything else is per wave.
+// Units holding state 6 (NaN input only) take a slow path that writes straight to slot 6.
+// ---------------------------------------------------------------------------------------------
+
+// shift of bin b's counter inside the packed 64-bit word: byte LUT {0,10,20,32,42,52,62,62} read with
+// v_perm_b32 (selector byte = b picks byte b of {hi,lo}); only bits [5:0] of the result are used.
+__device__ __forceinline__ uint32_t bin_shift(uint32_t b)
+{
+    return __builtin_amdgcn_perm(0x3E3E342Au, 0x20140A00u, b);
+}
+
+// bin (0..5), 6 = unit holding a state 6, 7 = not a unit, from a category byte; MODE is a template constant
+template <int MODE>
+__device__ __forceinline__ uint32_t bin_of_byte(uint32_t c)
+{
+    const uint32_t r = c & 7u;
+    if (MODE == XM_MODE_SE) return r;                                  // 0xFF -> 7, state 6 -> 6
+    const uint32_t f = (c >> 3) & 7u;
+    const uint32_t lo = f < r ? f : r, hi = f < r ? r : f;            // 0xFF -> lo = hi = 7
+    uint32_t b = lo;
+    if (MODE == XM_MODE_PE_CONSERVATIVE) {
+        b = (((f ^ r) & 1u) != 0u || hi == 4u) ? 4u : b;              // :525-529
+        b = (hi == 5u) ? 5u : b;                                       // :521
+        b = (hi == 7u) ? 7u : b;
+    }
+    return (hi == 6u) ? 6u : b;
+}
+
+// number of 4-bit fields of w equal to 6
+__device__ __forceinline__ uint32_t count_nibbles_eq6(uint32_t w)
+{
+    const uint32_t t = w ^ 0x66666666u;                                // zero nibble <=> field was 6
+    const uint32_t z = ~(((t & 0x77777777u) + 0x77777777u) | t) & 0x88888888u;
+    return (uint32_t)__builtin_popcount(z);
+}
+
+__device__ __forceinline__ uint64_t wave_scan_incl64(uint64_t v)
+{
+    // fields never carry across bit 32 (each word holds three 10-bit fields + spare bits), so the two
+    // halves scan independently
+    const uint32_t lo = wave_scan_incl((uint32_t)v), hi = wave_scan_incl((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int MODE, int K, int ABL = 0>      // ABL: ablation switches for tools/tune_kernels.hip only (0 = product)
 __global__ void __launch_bounds__(XM_BLOCK)
-scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
-               const uint32_t *__restrict__ gran_off, const unsigned long long *__restrict__ bin_totals,
+scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t chunk_stride,
+               const uint32_t *__restrict__ chunk_off, const unsigned long long *__restrict__ bin_totals,
                unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out)
 {
-    __shared__ uint8_t lut_all[XM_BLOCK / 64][64];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t g = blockIdx.x * (XM_BLOCK / 64) + wave;
-    if (g >= n_gran) return;                                              // wave-uniform; no barrier in this kernel
-    uint8_t *lut = lut_all[wave];
-    lut[lane] = (uint8_t)bin_of_code(mode, lane == 63u ? XM_NO_UNIT : lane);
+    __shared__ uint4 tile_state[K][XM_BLOCK];            // per lane and tile: {bins lo, bins hi, counters lo, hi}
+    __shared__ uint16_t stage[XM_BLOCK / 64][XM_WTILE];   // record offsets inside the wave tile (0..1023)
+    __shared__ uint32_t wave_tot[XM_BLOCK / 64][8];
 
-    // lane b < 8: where bin b starts in idx_out (exclusive prefix of the bin totals) plus what the granules before
-    // this one hold of it
-    uint32_t lane_base, n_units;
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint64_t span0 = ((uint64_t)blockIdx.x * (XM_BLOCK / 64) + wave) * (uint64_t)(K * XM_WTILE);
+
+    // lane b < 8: where bin b starts in idx_out (exclusive prefix of the bin totals) plus this chunk's
+    // offset inside the bin; fetched first so that the latency hides behind phase 1
+    uint32_t bin_start, lane_base;
     {
         const uint32_t tot = (lane < 8u) ? (uint32_t)bin_totals[lane] : 0u;
-        const uint32_t off = (lane < 7u) ? gran_off[(uint64_t)lane * gran_stride + g] : 0u;
-        const uint32_t bin_start = wave_scan_incl(tot) - tot;
+        const uint32_t off = (lane < 7u) ? chunk_off[(uint64_t)lane * chunk_stride + blockIdx.x] : 0u;
+        bin_start = wave_scan_incl(tot) - tot;
         lane_base = bin_start + off;
-        n_units = lane_value(bin_start, 7);                               // slot 7 counts nothing: the total
-        if (g == 0u && lane < 8u) bin_offsets[lane] = bin_start;
     }
-    uint32_t base[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
+    if (blockIdx.x == 0 && t < 8) bin_offsets[t] = bin_start;       // lanes 0..7 of wave 0
 
-    const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
-    uint32_t w[NSUB];
-    if (rec_g + NSUB * 256u <= n) {
+    // ---- phase 1: bytes -> bins (4 bits each, 7 = not a unit) and per-lane counters, every tile of the span;
+    //      parked in LDS so that phase 2 can be a rolled loop
+    uint32_t lane_tot[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t err_tiles = 0;          // bit k: this lane holds a state-6 unit in tile k
+    {
+        uint32_t w[4], wn[4] = {0, 0, 0, 0};
+        load_codes16(code, span0 + lane * 16u, n, w);
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            if (k + 1 < K) load_codes16(code, span0 + (uint64_t)(k + 1) * XM_WTILE + lane * 16u, n, wn);   // prefetch
+            uint64_t cnt = 0;
+            uint32_t n0 = 0, n1 = 0;
+            // strictly interleaved mates (the usual paired input): units only at odd positions in every lane of
+            // the wave -> a branch-free pass over the 8 odd bytes; anything else takes the general pass
+            const bool even_free = ((w[0] & w[1] & w[2] & w[3]) & 0x00FF00FFu) == 0x00FF00FFu;
+            if (__ballot(!even_free) == 0ull) {
+                n0 = n1 = 0x07070707u;
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) w[s] = *reinterpret_cast<const uint32_t *>(code + rec_g + s * 256u + lane * 4u);
-    } else {
+                for (int j = 1; j < 16; j += 2) {
+                    const uint32_t b = bin_of_byte<MODE>((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                    if (j < 8) n0 |= b << (4 * j); else n1 |= b << (4 * (j - 8));
+                    cnt += 1ull << bin_shift(b);
+                }
+            } else {
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) w[s] = load_codes4_tail(code, rec_g + s * 256u + lane * 4u, n);
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                    if (__ballot(c != XM_NO_UNIT) == 0ull) {          // wave-uniform: nobody has a unit here
+                        if (j < 8) n0 |= 7u << (4 * j); else n1 |= 7u << (4 * (j - 8));
+                        continue;
+                    }
+                    const uint32_t b = bin_of_byte<MODE>(c);
+                    if (j < 8) n0 |= b << (4 * j); else n1 |= b << (4 * (j - 8));
+                    cnt += 1ull << bin_shift(b);
+                }
+            }
+            tile_state[k][t] = make_uint4(n0, n1, (uint32_t)cnt, (uint32_t)(cnt >> 32));
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                lane_tot[bb] += ((uint32_t)cnt >> (10 * bb)) & 0x3FFu;
+                lane_tot[3 + bb] += ((uint32_t)(cnt >> 32) >> (10 * bb)) & 0x3FFu;
+            }
+            const uint32_t c6 = count_nibbles_eq6(n0) + count_nibbles_eq6(n1);
+            lane_tot[6] += c6;
+            err_tiles |= (c6 != 0u) ? (1u << k) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = wn[q];
+        }
     }
-    lds_settle();
+    // wave totals of the span (two 16-bit fields per word: at most K*1024 per bin)
+    {
+        const uint32_t p01 = wave_scan_incl(lane_tot[0] | (lane_tot[1] << 16));
+        const uint32_t p23 = wave_scan_incl(lane_tot[2] | (lane_tot[3] << 16));
+        const uint32_t p45 = wave_scan_incl(lane_tot[4] | (lane_tot[5] << 16));
+        const uint32_t p6 = wave_scan_incl(lane_tot[6]);
+        if (lane == 63) {
+            wave_tot[wave][0] = p01 & 0xFFFFu; wave_tot[wave][1] = p01 >> 16;
+            wave_tot[wave][2] = p23 & 0xFFFFu; wave_tot[wave][3] = p23 >> 16;
+            wave_tot[wave][4] = p45 & 0xFFFFu; wave_tot[wave][5] = p45 >> 16;
+            wave_tot[wave][6] = p6; wave_tot[wave][7] = 0;
+        }
+    }
+    __syncthreads();
+    // where this wave's units of each bin start in idx_out (wave-uniform)
+    uint32_t gbase[7];
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-        const uint32_t rec0 = (uint32_t)rec_g + (uint32_t)s * 256u + lane * 4u;
-        const bool even_free = (w[s] & 0x00FF00FFu) == 0x00FF00FFu;
-        if (__ballot(!even_free) == 0ull) scatter_256<0xA, WIDE>(w[s], lut, rec0, base, idx_out, n_units);
-        else scatter_256<0xF, WIDE>(w[s], lut, rec0, base, idx_out, n_units);
+    for (int b = 0; b < 7; ++b) {
+        uint32_t g = lane_value(lane_base, b);
+        for (uint32_t wv = 0; wv < wave; ++wv) g += wave_tot[wv][b];
+        gbase[b] = __builtin_amdgcn_readfirstlane(g);
+    }
+
+    // ---- phase 2: tile by tile, no workgroup synchronisation
+    uint16_t *slab = stage[wave];
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const uint4 ts = tile_state[k][t];
+        const uint32_t nib0 = ts.x, nib1 = ts.y;
+        const uint64_t cnt = ((uint64_t)ts.w << 32) | ts.z;
+        const uint64_t excl = wave_scan_incl64(cnt) - cnt;
+        // tile totals per bin = lane 63's exclusive prefix + own count (added per field: a field may reach 1024)
+        const uint32_t ex63 = lane_value((uint32_t)excl, 63), ey63 = lane_value((uint32_t)(excl >> 32), 63);
+        const uint32_t cx63 = lane_value((uint32_t)cnt, 63), cy63 = lane_value((uint32_t)(cnt >> 32), 63);
+        uint32_t tcnt[6], lstart[6];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const uint32_t e = (b < 3) ? ex63 : ey63, c = (b < 3) ? cx63 : cy63;
+            const int f = 10 * (b % 3);
+            tcnt[b] = ((e >> f) & 0x3FFu) + ((c >> f) & 0x3FFu);
+            lstart[b] = acc;
+            acc += tcnt[b];
+        }
+        // running positions, packed like the counters
+        uint64_t pos = excl + (((uint64_t)(lstart[3] | (lstart[4] << 10) | (lstart[5] << 20)) << 32)
+                               | (uint64_t)(lstart[0] | (lstart[1] << 10) | (lstart[2] << 20)));
+        const uint32_t tile0 = (uint32_t)(span0 + (uint64_t)k * XM_WTILE);
+        const uint32_t rec0 = tile0 + lane * 16u;
+        const bool even_free2 = ((nib0 & nib1) & 0x0F0F0F0Fu) == 0x07070707u;
+        if (__ballot(!even_free2) == 0ull) {                          // interleaved mates: odd positions only
+#pragma unroll
+            for (int j = 1; j < 16; j += 2) {
+                const uint32_t b = ((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u;
+                const uint32_t sh = bin_shift(b);
+                const uint32_t p = (uint32_t)(pos >> sh) & 0x3FFu;
+                if (ABL < 2) { if (b < 6u) slab[p] = (uint16_t)(lane * 16u + (uint32_t)j); }
+                else asm volatile("" :: "v"(p));
+                pos += 1ull << sh;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t b = ((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u;
+                const bool valid = b < 6u;
+                if (__ballot(valid) == 0ull) continue;                // wave-uniform
+                const uint32_t sh = bin_shift(b);
+                const uint32_t p = (uint32_t)(pos >> sh) & 0x3FFu;
+                if (ABL < 2) { if (valid) slab[p] = (uint16_t)(lane * 16u + (uint32_t)j); }
+                else asm volatile("" :: "v"(p));
+                pos += 1ull << sh;                                    // bins 6, 7 land in the sink
+            }
+        }
+        // each bin's run, contiguous in LDS and contiguous in idx_out
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            // streamed out once and read by the host only: non-temporal, so the 200 MB of indices do not push
+            // the category bytes (re-read by K2, rewritten by the next K1) out of the Infinity Cache
+            if (ABL == 0) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u)
+                    __builtin_nontemporal_store(tile0 + (uint32_t)slab[lstart[b] + e], idx_out + gbase[b] + e);
+            } else if (ABL == 1) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u) asm volatile("" :: "v"((uint32_t)slab[lstart[b] + e]));
+            } else if (ABL == 3) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u) idx_out[gbase[b] + e] = tile0 + (uint32_t)slab[lstart[b] + e];
+            } else if (ABL == 5) {
+                // whole 128-byte lines of the run stream out non-temporally; the ragged head and tail (which a
+                // neighbouring run completes later) go through the cache so that the halves can merge there
+                const uint32_t g0 = gbase[b], g1 = g0 + tcnt[b];
+                const uint32_t a0 = (g0 + 31u) & ~31u, a1 = g1 & ~31u;
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u) {
+                    const uint32_t g = g0 + e, v = tile0 + (uint32_t)slab[lstart[b] + e];
+                    if (g >= a0 && g < a1) __builtin_nontemporal_store(v, idx_out + g);
+                    else idx_out[g] = v;
+                }
+            } else if (ABL == 4) {
+                for (uint32_t e = lane; e < tcnt[b]; e += 64u)
+                    __hip_atomic_store(idx_out + gbase[b] + e, tile0 + (uint32_t)slab[lstart[b] + e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            gbase[b] += tcnt[b];
+        }
+        // state-6 units (rare)
+        if (__ballot((err_tiles >> k) & 1u) != 0ull) {
+            const uint32_t c6 = count_nibbles_eq6(nib0) + count_nibbles_eq6(nib1);
+            const uint32_t i6 = wave_scan_incl(c6);
+            uint32_t run6 = gbase[6] + i6 - c6;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((((j < 8 ? nib0 : nib1) >> (4 * (j & 7))) & 7u) == 6u) idx_out[run6++] = rec0 + (uint32_t)j;
+            gbase[6] += lane_value(i6, 63);
+        }
     }
 }
 
@@ -773,15 +827,14 @@ __device__ __forceinline__ bool cigar_scores_by_prefix(const uint32_t *__restric
     return true;
 }
 
-template <bool PAIRED, int BLOCK, bool FULL, bool COUNTS>
+template <bool PAIRED, int BLOCK, bool FULL>
 __device__ __forceinline__ void classify_cigar_body(
     const int32_t *__restrict__ nm1, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ ops1,
     const int32_t *__restrict__ xs1,
     const int32_t *__restrict__ nm2, const uint32_t *__restrict__ off2, const uint32_t *__restrict__ ops2,
     const int32_t *__restrict__ xs2,
     const uint8_t *__restrict__ unit_bits8, int32_t m, uint8_t *__restrict__ code, uint64_t n,
-    uint32_t *__restrict__ range_flag, uint32_t *last_state, uint32_t *cig_T, uint32_t *count_lds,
-    const CountSink &sink)
+    uint32_t *__restrict__ range_flag, uint32_t *last_state, uint32_t *cig_T)
 {
     const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t r0 = g * 4;
@@ -827,29 +880,27 @@ __device__ __forceinline__ void classify_cigar_body(
             mb &= ~1u;
         }
     }
-    classify_finish<int32_t, PAIRED, BLOCK, FULL, COUNTS>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, count_lds, sink);
+    classify_finish<int32_t, PAIRED, BLOCK, FULL>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n);
 }
 
-template <bool PAIRED, int BLOCK, bool COUNTS>
+template <bool PAIRED, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ ops1,
                       const int32_t *__restrict__ xs1,
                       const int32_t *__restrict__ nm2, const uint32_t *__restrict__ off2, const uint32_t *__restrict__ ops2,
                       const int32_t *__restrict__ xs2,
                       const uint8_t *__restrict__ unit_bits8, int32_t m, uint8_t *__restrict__ code, uint64_t n,
-                      uint32_t *__restrict__ range_flag, CountSink sink)
+                      uint32_t *__restrict__ range_flag)
 {
     __shared__ uint32_t last_state[BLOCK / 64];
     __shared__ __attribute__((aligned(16))) uint32_t cig_table[BLOCK / 64][XM_CIG_WAVE_OPS + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t count_lds[COUNTS ? XM_COUNT_LDS_WORDS : 4];
-    if (COUNTS) count_lds_clear<BLOCK>(count_lds);
     uint32_t *cig_T = cig_table[threadIdx.x >> 6];
     if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
-        classify_cigar_body<PAIRED, BLOCK, true, COUNTS>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
-                                                         range_flag, last_state, cig_T, count_lds, sink);
+        classify_cigar_body<PAIRED, BLOCK, true>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
+                                                 range_flag, last_state, cig_T);
     else
-        classify_cigar_body<PAIRED, BLOCK, false, COUNTS>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
-                                                          range_flag, last_state, cig_T, count_lds, sink);
+        classify_cigar_body<PAIRED, BLOCK, false>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
+                                                  range_flag, last_state, cig_T);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -901,102 +952,87 @@ mate_correlate_kernel(const double *__restrict__ track, uint64_t n, const double
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-GranPlan plan_granules(uint64_t n, uint32_t gran_records)
-{
-    GranPlan p;
-    uint64_t g = (n + gran_records - 1) / gran_records;
-    if (g == 0) g = 1;
-    p.gran_records = gran_records;
-    p.n_gran = (uint32_t)g;
-    p.gran_stride = (p.n_gran + 63u) & ~63u;
-    return p;
-}
-
-static CountSink make_sink(const CountPlan *cp, int mode)
-{
-    CountSink s;
-    s.gran_counts = cp ? cp->gran_counts : nullptr;
-    s.counts_rep = cp ? reinterpret_cast<unsigned long long *>(cp->counts_rep) : nullptr;
-    s.gran_stride = cp ? cp->plan.gran_stride : 0u;
-    s.mode = mode;
-    return s;
-}
-
 template <typename T>
 static void launch_classify_t(hipStream_t st, int mode, uint64_t n,
                               const T *as1, const T *xs1, const T *as2, const T *xs2,
-                              const uint64_t *unit_bits, T m, uint8_t *code, const CountPlan *cp)
+                              const uint64_t *unit_bits, T m, uint8_t *code)
 {
     const uint64_t per_block = (uint64_t)XM_CLASSIFY_BLOCK * 4;
     const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
-    const CountSink sink = make_sink(cp, mode);
-    const bool paired = mode != XM_MODE_SE;
-#define XM_LAUNCH_CLS(P, C) classify_kernel<T, P, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK, C><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n, sink)
-    if (cp) { if (paired) XM_LAUNCH_CLS(true, true); else XM_LAUNCH_CLS(false, true); }
-    else    { if (paired) XM_LAUNCH_CLS(true, false); else XM_LAUNCH_CLS(false, false); }
-#undef XM_LAUNCH_CLS
+    if (mode == XM_MODE_SE)
+        classify_kernel<T, false, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n);
+    else
+        classify_kernel<T, true, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n);
 }
 
 void launch_classify_i32(hipStream_t st, int mode, uint64_t n,
                          const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                         const uint64_t *unit_bits, int32_t m, uint8_t *code, const CountPlan *cp)
+                         const uint64_t *unit_bits, int32_t m, uint8_t *code)
 {
-    launch_classify_t<int32_t>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, cp);
+    launch_classify_t<int32_t>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code);
 }
 
 void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
                          const double *as1, const double *xs1, const double *as2, const double *xs2,
-                         const uint64_t *unit_bits, double m, uint8_t *code, const CountPlan *cp)
+                         const uint64_t *unit_bits, double m, uint8_t *code)
 {
-    launch_classify_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, cp);
+    launch_classify_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code);
 }
 
 void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
                            const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
                            const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
-                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag, const CountPlan *cp)
+                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag)
 {
     const uint64_t per_block = (uint64_t)XM_CIGAR_BLOCK * 4;
     const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
-    const CountSink sink = make_sink(cp, mode);
-    const bool paired = mode != XM_MODE_SE;
-#define XM_LAUNCH_CIG(P, C) classify_cigar_kernel<P, XM_CIGAR_BLOCK, C><<<grid, XM_CIGAR_BLOCK, 0, st>>>( \
-        nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag, sink)
-    if (cp) { if (paired) XM_LAUNCH_CIG(true, true); else XM_LAUNCH_CIG(false, true); }
-    else    { if (paired) XM_LAUNCH_CIG(true, false); else XM_LAUNCH_CIG(false, false); }
-#undef XM_LAUNCH_CIG
+    if (mode == XM_MODE_SE)
+        classify_cigar_kernel<false, XM_CIGAR_BLOCK><<<grid, XM_CIGAR_BLOCK, 0, st>>>(
+            nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
+    else
+        classify_cigar_kernel<true, XM_CIGAR_BLOCK><<<grid, XM_CIGAR_BLOCK, 0, st>>>(
+            nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
 }
 
-void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, const CountPlan &cp)
+ChunkPlan plan_chunks(uint64_t n)
 {
-    const uint32_t grid = (cp.plan.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
-    hist_kernel<<<grid, XM_BLOCK, 0, st>>>(code, n, cp.plan.n_gran, make_sink(&cp, mode));
+    ChunkPlan p;
+    uint64_t chunks = (n + XM_CHUNK - 1) / XM_CHUNK;
+    if (chunks == 0) chunks = 1;
+    p.n_chunks = (uint32_t)chunks;
+    p.chunk_stride = (p.n_chunks + 63u) & ~63u;
+    return p;
 }
 
-void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64_t *bin_totals, uint64_t *counts)
+void launch_hist(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
+                 uint32_t *chunk_counts, uint64_t *counts_rep)
 {
-    const uint32_t n_parts = (cp.plan.n_gran + XM_PART_GRAN - 1) / XM_PART_GRAN;
-    part_sum_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot);
-    scan_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride,
-                                                              cp.part_tot, gran_off,
-                                                              reinterpret_cast<unsigned long long *>(bin_totals),
-                                                              reinterpret_cast<unsigned long long *>(cp.counts_rep),
-                                                              reinterpret_cast<unsigned long long *>(counts));
+    hist_kernel<XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, mode, p.chunk_stride, chunk_counts,
+                                                        reinterpret_cast<unsigned long long *>(counts_rep));
 }
 
-void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code,
-                    const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out)
+void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_counts, uint32_t *chunk_off,
+                 uint64_t *bin_totals, uint64_t *counts_rep, uint64_t *counts)
+{
+    scan_kernel<<<8, XM_SCAN_THREADS, 0, st>>>(chunk_counts, p.n_chunks, p.chunk_stride, chunk_off,
+                                   reinterpret_cast<unsigned long long *>(bin_totals),
+                                   reinterpret_cast<unsigned long long *>(counts_rep),
+                                   reinterpret_cast<unsigned long long *>(counts));
+}
+
+void launch_scatter(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code,
+                    const uint32_t *chunk_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out)
 {
     const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
-    const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
-    const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
-#define XM_LAUNCH_SCT(NSUB, W) scatter_kernel<NSUB, W><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_off, bt, bo, idx_out)
-    if (p.gran_records == 1024u) { if (wide) XM_LAUNCH_SCT(4, true); else XM_LAUNCH_SCT(4, false); }
-    else                         { if (wide) XM_LAUNCH_SCT(8, true); else XM_LAUNCH_SCT(8, false); }
-#undef XM_LAUNCH_SCT
+    if (mode == XM_MODE_SE)
+        scatter_kernel<XM_MODE_SE, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
+    else if (mode == XM_MODE_PE_LIBERAL)
+        scatter_kernel<XM_MODE_PE_LIBERAL, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
+    else
+        scatter_kernel<XM_MODE_PE_CONSERVATIVE, XM_K><<<p.n_chunks, XM_BLOCK, 0, st>>>(code, n, p.chunk_stride, chunk_off, bt, bo, idx_out);
 }
 
 void launch_mate_correlate(hipStream_t st, uint64_t n, const double *track, uint32_t m, const double *density, double *out)

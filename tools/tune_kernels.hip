@@ -1,88 +1,255 @@
-// tune_kernels.hip -- on-box A/B harness for the classify kernel variants (not shipped).
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I include -I xenomapper_amd/csrc tools/tune_kernels.hip -o /tmp/tune && /tmp/tune
-// Variants are interleaved in one process (guide rule 24); prints median/min per variant.
+// tune_kernels.hip -- on-box A/B harness (not shipped): round-1 kernels (frozen copy, tools/legacy) against the
+// current ones, interleaved in one process (guide rule 24); prints median/min per variant and checks that old and
+// new produce identical category bytes, counts, offsets and index lists.
+//   tools/build_tune.sh && /tmp/tune [n_records] [rounds]
 #include "../xenomapper_amd/csrc/xm_kernels.hip"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
+
+// round-1 launchers (tools/legacy/xm_kernels_r01.hip compiled with -Dxm=xm_r01)
+namespace xm_r01 {
+struct ChunkPlan { uint32_t n_chunks; uint32_t chunk_stride; };
+ChunkPlan plan_chunks(uint64_t n);
+void launch_classify_i32(hipStream_t st, int mode, uint64_t n, const int32_t *as1, const int32_t *xs1, const int32_t *as2,
+                         const int32_t *xs2, const uint64_t *unit_bits, int32_t m, uint8_t *code);
+void launch_hist(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code, uint32_t *chunk_counts,
+                 uint64_t *counts_rep);
+void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_counts, uint32_t *chunk_off, uint64_t *bin_totals,
+                 uint64_t *counts_rep, uint64_t *counts);
+void launch_scatter(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code, const uint32_t *chunk_off,
+                    const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out);
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-// streaming ceiling with the same footprint: 4 x 16 B loads + 4 B store per lane, no arithmetic
-template <bool NT>
+// streaming ceiling with K1's footprint: 4 x 16 B loads + 4 B store per lane, no arithmetic
 __global__ void __launch_bounds__(256) copy_like(const xm::v4i32 *a, const xm::v4i32 *b, const xm::v4i32 *c, const xm::v4i32 *d, uint32_t *out, uint64_t ngroups)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += stride) {
-        xm::v4i32 va = NT ? __builtin_nontemporal_load(a + g) : a[g];
-        xm::v4i32 vb = NT ? __builtin_nontemporal_load(b + g) : b[g];
-        xm::v4i32 vc = NT ? __builtin_nontemporal_load(c + g) : c[g];
-        xm::v4i32 vd = NT ? __builtin_nontemporal_load(d + g) : d[g];
-        uint32_t r = (uint32_t)(va.x ^ vb.y ^ vc.z ^ vd.w ^ va.w ^ vb.x ^ vc.y ^ vd.z ^ va.y ^ va.z ^ vb.z ^ vb.w ^ vc.x ^ vc.w ^ vd.x ^ vd.y);
-        if (NT) __builtin_nontemporal_store(r, out + g); else out[g] = r;
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    xm::v4i32 va = __builtin_nontemporal_load(a + g), vb = __builtin_nontemporal_load(b + g);
+    xm::v4i32 vc = __builtin_nontemporal_load(c + g), vd = __builtin_nontemporal_load(d + g);
+    out[g] = (uint32_t)(va.x ^ vb.y ^ vc.z ^ vd.w ^ va.w ^ vb.x ^ vc.y ^ vd.z ^ va.y ^ va.z ^ vb.z ^ vb.w ^ vc.x ^ vc.w ^ vd.x ^ vd.y);
+}
+
+static int32_t *A1, *X1, *A2, *X2; static uint64_t *BITS; static uint8_t *CODE, *CODE_OLD; static uint64_t N;
+static uint32_t *GC, *GO, *IDX, *IDX_OLD, *CC_OLD, *CO_OLD;
+static uint64_t *REP, *REP_OLD, *BINOFF, *BINOFF_OLD, *COUNTS, *COUNTS_OLD;
+static int MODE = XM_MODE_PE_LIBERAL;
+
+static uint32_t *PART;
+static xm::CountPlan cplan(uint32_t gran) { xm::CountPlan cp; cp.plan = xm::plan_granules(N, gran); cp.gran_counts = GC; cp.counts_rep = REP; cp.part_tot = PART; return cp; }
+
+static void old_classify() { xm_r01::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE_OLD); }
+static void old_hist() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_hist(0, p, MODE, N, CODE_OLD, CC_OLD, REP_OLD); }
+static void old_scan() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_scan(0, p, CC_OLD, CO_OLD, REP_OLD + 64 * 64, REP_OLD, COUNTS_OLD); }
+static void old_scatter() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_scatter(0, p, MODE, N, CODE_OLD, CO_OLD, REP_OLD + 64 * 64, BINOFF_OLD, IDX_OLD); }
+static void old_pipeline() { for (int r = 0; r < 4; ++r) { old_classify(); old_hist(); old_scan(); old_scatter(); } }
+
+static void new_classify() { xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, nullptr); }
+static void new_classify_counts() { auto cp = cplan(XM_CLASSIFY_BLOCK * 4); xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, &cp); }
+static void new_hist() { auto cp = cplan(XM_GRAN_K2); xm::launch_hist(0, MODE, N, CODE, cp); }
+static void new_scan() { auto cp = cplan(2048); xm::launch_scan(0, cp, GO, REP + 64 * 64, COUNTS); }
+static void new_scatter() { auto cp = cplan(2048); xm::launch_scatter(0, cp.plan, MODE, N, CODE, GO, REP + 64 * 64, BINOFF, IDX); }
+static void new_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); new_scatter(); } }
+static void new_unfused() { for (int r = 0; r < 4; ++r) { new_classify(); new_hist(); new_scan(); new_scatter(); } }
+// two independent batches in flight on two streams (consecutive windows of a file): K2 of one under K1 of the other
+struct Lane2 { hipStream_t st; uint8_t *code; uint32_t *gc, *go, *idx, *part; uint64_t *rep, *binoff, *counts; };
+static Lane2 L2[2];
+static void fused_on(const Lane2 &l) {
+    xm::CountPlan cp; cp.plan = xm::plan_granules(N, XM_CLASSIFY_BLOCK * 4); cp.gran_counts = l.gc; cp.counts_rep = l.rep; cp.part_tot = l.part;
+    xm::launch_classify_i32(l.st, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, l.code, &cp);
+    xm::launch_scan(l.st, cp, l.go, l.rep + 64 * 64, l.counts);
+    xm::launch_scatter(l.st, cp.plan, MODE, N, l.code, l.go, l.rep + 64 * 64, l.binoff, l.idx);
+}
+static hipEvent_t EV_FORK, EV_JOIN[2];
+static void new_fused_2stream() {        // 4 steps, alternating lanes; fork from / join to the null stream so that the timing events bracket it
+    CK(hipEventRecord(EV_FORK, 0));
+    for (int k = 0; k < 2; ++k) CK(hipStreamWaitEvent(L2[k].st, EV_FORK, 0));
+    for (int r = 0; r < 4; ++r) fused_on(L2[r & 1]);
+    for (int k = 0; k < 2; ++k) { CK(hipEventRecord(EV_JOIN[k], L2[k].st)); CK(hipStreamWaitEvent(0, EV_JOIN[k], 0)); }
+}
+static void run_copy() { copy_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((const xm::v4i32 *)A1, (const xm::v4i32 *)X1, (const xm::v4i32 *)A2, (const xm::v4i32 *)X2, (uint32_t *)CODE, N / 4); }
+
+
+// ---- ablations of the scatter kernel (copies of the product body with switches; harness only) ----
+// ABL 1: no stores; 6: bins that do not occur are skipped (wave-uniform branch); 3: stores go to a coalesced dummy position;
+// 4: arithmetic byte -> bin (liberal rule) instead of the LDS table; 5: no guard compare; 8: XCD-contiguous granules
+namespace abl {
+using namespace xm;
+template <int SLOTS, int ABL>
+__device__ __forceinline__ void scatter_256(uint32_t w, const uint8_t *lut, uint32_t rec0, uint32_t base[7],
+                                            uint32_t *__restrict__ idx_out, uint32_t n_units)
+{
+    uint32_t bin[4], pos[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!((SLOTS >> j) & 1)) { bin[j] = 7u; continue; }
+        if (ABL == 4) {
+            const uint32_t c = (w >> (8 * j)) & 0xFFu, f = (c >> 3) & 7u, r = c & 7u;
+            bin[j] = f < r ? f : r;
+        } else bin[j] = (uint32_t)lut[(w >> (8 * j)) & 63u];
+    }
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        uint64_t m[4], any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m[j] = ((SLOTS >> j) & 1) ? __ballot(bin[j] == (uint32_t)b) : 0ull; any |= m[j]; }
+        if (ABL == 6 && any == 0ull) continue;
+        uint32_t t = base[b];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if ((SLOTS >> j) & 1) t = mbcnt64(m[j], t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if ((SLOTS >> j) & 1) pos[j] = (bin[j] == (uint32_t)b) ? t : pos[j];
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if ((SLOTS >> j) & 1) total += (uint32_t)__builtin_popcountll(m[j]);
+        base[b] += total;
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < j; ++i)
+            if (((SLOTS >> j) & 1) && ((SLOTS >> i) & 1)) pos[j] += (bin[i] == bin[j]) ? 1u : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!((SLOTS >> j) & 1)) continue;
+        if (ABL == 1) { asm volatile("" :: "v"(pos[j])); continue; }
+        if (ABL == 3) { if (bin[j] < 7u) store_index<false>(idx_out, (rec0 + (uint32_t)j) >> 1, pos[j]); continue; }
+        if (ABL == 7) { if (bin[j] < 7u && pos[j] < n_units) __builtin_nontemporal_store(rec0 + (uint32_t)j, idx_out + pos[j]); continue; }
+        if (bin[j] < 7u && (ABL == 5 || pos[j] < n_units)) store_index<false>(idx_out, pos[j], rec0 + (uint32_t)j);
     }
 }
 
-struct Variant { const char *name; void (*run)(int grid); };
-
-static int32_t *A1, *X1, *A2, *X2; static uint8_t *BITS; static uint8_t *CODE; static uint64_t N;
-
-template <bool NT, int BLOCK> static void run_cls(int)
+template <int NSUB, int ABL, int GPW = 1>
+__global__ void __launch_bounds__(XM_BLOCK)
+scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
+               const uint32_t *__restrict__ gran_off, const unsigned long long *__restrict__ bin_totals,
+               unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out)
 {
-    const uint64_t per_block = (uint64_t)BLOCK * 4;
-    const int grid = (int)((N + per_block - 1) / per_block);
-    xm::classify_kernel<int32_t, true, NT, BLOCK><<<grid, BLOCK>>>(A1, X1, A2, X2, BITS, INT32_MIN, CODE, N);
-}
-template <bool NT, int BLOCK> static void run_cls_se(int)
-{
-    const uint64_t per_block = (uint64_t)BLOCK * 4;
-    const int grid = (int)((N + per_block - 1) / per_block);
-    xm::classify_kernel<int32_t, false, NT, BLOCK><<<grid, BLOCK>>>(A1, X1, A2, X2, BITS, INT32_MIN, CODE, N);
-}
-
-template <bool NT> static void run_copy(int grid)
-{
-    copy_like<NT><<<grid, 256>>>((const xm::v4i32 *)A1, (const xm::v4i32 *)X1, (const xm::v4i32 *)A2, (const xm::v4i32 *)X2, (uint32_t *)CODE, N / 4);
-}
-
-// ---- K2 variants: chunk geometry K (wave tiles per wave) ----
-static uint32_t *CHUNK_COUNTS, *CHUNK_OFF, *IDX; static unsigned long long *BINOFF, *BINTOT, *COUNTS, *COUNTS_REP;
-struct Plan { uint32_t n_chunks, stride; };
-template <int K> static Plan plan_k() { Plan p; uint64_t ch = (uint64_t)K * 4096; p.n_chunks = (uint32_t)((N + ch - 1) / ch); p.stride = (p.n_chunks + 63u) & ~63u; return p; }
-template <int K> static void run_hist(int) { Plan p = plan_k<K>(); xm::hist_kernel<K><<<p.n_chunks, 256>>>(CODE, N, 1, p.stride, CHUNK_COUNTS, COUNTS_REP); }
-template <int K> static void run_scan(int) { Plan p = plan_k<K>(); xm::scan_kernel<<<8, XM_SCAN_THREADS>>>(CHUNK_COUNTS, p.n_chunks, p.stride, CHUNK_OFF, BINTOT, COUNTS_REP, COUNTS); }
-template <int K, int ABL> static void run_scatter_abl(int) { Plan p = plan_k<K>(); xm::scatter_kernel<1, K, ABL><<<p.n_chunks, 256>>>(CODE, N, p.stride, CHUNK_OFF, BINTOT, BINOFF, IDX); }
-template <int K> static void run_scatter(int) { Plan p = plan_k<K>(); xm::scatter_kernel<1, K><<<p.n_chunks, 256>>>(CODE, N, p.stride, CHUNK_OFF, BINTOT, BINOFF, IDX); }
-
-template <int ABL> static void run_pipeline(int)     // 4 back-to-back steps: steady-state cache contents
-{
-    for (int r = 0; r < 4; ++r) {
-        run_cls<true, 512>(0);
-        run_hist<2>(0);
-        run_scan<2>(0);
-        run_scatter_abl<2, ABL>(0);
+    __shared__ uint8_t lut_all[XM_BLOCK / 64][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t wg = blockIdx.x;
+    if (ABL == 8) {             // workgroups go round-robin over the 8 XCDs: give every XCD one contiguous stretch of granules
+        const uint32_t per = (gridDim.x + 7u) / 8u;
+        wg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (wg >= gridDim.x) return;
     }
+    const uint32_t g_first = (wg * (XM_BLOCK / 64) + wave) * GPW;
+    if (g_first >= n_gran) return;
+    uint8_t *lut = lut_all[wave];
+    lut[lane] = (uint8_t)bin_of_code(mode, lane == 63u ? XM_NO_UNIT : lane);
+    const uint32_t tot = (lane < 8u) ? (uint32_t)bin_totals[lane] : 0u;
+    const uint32_t bin_start = wave_scan_incl(tot) - tot;
+    const uint32_t n_units = lane_value(bin_start, 7);
+    if (g_first == 0u && lane < 8u) bin_offsets[lane] = bin_start;
+    uint32_t off[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) off[i] = (lane < 7u && g_first + i < n_gran) ? gran_off[(uint64_t)lane * gran_stride + g_first + i] : 0u;
+    uint32_t w[NSUB], wn[NSUB];
+    auto load = [&](uint32_t g, uint32_t dst[NSUB]) {
+        const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) dst[s] = (g < n_gran && rec_g + NSUB * 256u <= n) ? *reinterpret_cast<const uint32_t *>(code + rec_g + s * 256u + lane * 4u) : 0xFFFFFFFFu;
+    };
+    load(g_first, w);
+    lds_settle();
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        const uint32_t g = g_first + i;
+        if (i + 1 < GPW) load(g + 1, wn);
+        const uint32_t lane_base = bin_start + off[i];
+        uint32_t base[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
+        const uint32_t rec_g = g * (NSUB * 256u);
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const uint32_t rec0 = rec_g + (uint32_t)s * 256u + lane * 4u;
+            const bool even_free = (w[s] & 0x00FF00FFu) == 0x00FF00FFu;
+            if (__ballot(!even_free) == 0ull) scatter_256<0xA, ABL>(w[s], lut, rec0, base, idx_out, n_units);
+            else scatter_256<0xF, ABL>(w[s], lut, rec0, base, idx_out, n_units);
+        }
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) w[s] = wn[s];
+    }
+}
+}  // namespace abl
+
+static uint32_t *IDX_SCRATCH;
+template <int ABL> static void ablp_scatter() { auto cp = cplan(2048); const uint32_t grid = (cp.plan.n_gran + 3) / 4;
+    abl::scatter_kernel<8, ABL, 1><<<grid, XM_BLOCK>>>(CODE, N, MODE, cp.plan.n_gran, cp.plan.gran_stride, GO, (const unsigned long long *)(REP + 64 * 64), (unsigned long long *)BINOFF, IDX); }
+template <int ABL> static void ablp_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); ablp_scatter<ABL>(); } }
+template <int GPW> static void gpw_scatter() { auto cp = cplan(2048); const uint32_t grid = (cp.plan.n_gran + 4 * GPW - 1) / (4 * GPW);
+    abl::scatter_kernel<8, 0, GPW><<<grid, XM_BLOCK>>>(CODE, N, MODE, cp.plan.n_gran, cp.plan.gran_stride, GO, (const unsigned long long *)(REP + 64 * 64), (unsigned long long *)BINOFF, IDX); }
+template <int GPW> static void gpw_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); gpw_scatter<GPW>(); } }
+template <int ABL> static void abl_scatter() { auto cp = cplan(2048); const uint32_t grid = ABL == 8 ? ((cp.plan.n_gran + 3) / 4 + 7) / 8 * 8 : (cp.plan.n_gran + 3) / 4;
+    abl::scatter_kernel<8, ABL><<<grid, XM_BLOCK>>>(CODE, N, MODE, cp.plan.n_gran, cp.plan.gran_stride, GO, (const unsigned long long *)(REP + 64 * 64), (unsigned long long *)BINOFF, IDX_SCRATCH); }
+// plain streaming stores with the scatter's output footprint (4 B per unit), and reads with its input footprint
+__global__ void __launch_bounds__(256) stream_write(uint32_t *out, uint64_t n) { const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; if (i < n) out[i] = (uint32_t)i; }
+__global__ void __launch_bounds__(256) stream_write16(uint4 *out, uint64_t n16) { const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; if (i < n16) out[i] = make_uint4((uint32_t)i, 1, 2, 3); }
+__global__ void __launch_bounds__(256) stream_write16_nt(uint4 *out, uint64_t n16) { const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; xm::v4i32 v = {(int)i, 1, 2, 3}; if (i < n16) __builtin_nontemporal_store(v, (xm::v4i32 *)out + i); }
+static void run_stream_write16() { const uint64_t n16 = N / 8; stream_write16<<<(unsigned)((n16 + 255) / 256), 256>>>((uint4 *)IDX_SCRATCH, n16); }
+static void run_stream_write16_nt() { const uint64_t n16 = N / 8; stream_write16_nt<<<(unsigned)((n16 + 255) / 256), 256>>>((uint4 *)IDX_SCRATCH, n16); }
+static void run_stream_write() { const uint64_t units = N / 2; stream_write<<<(unsigned)((units + 255) / 256), 256>>>(IDX_SCRATCH, units); }
+
+template <typename T> static std::vector<T> fetch(const T *d, size_t n) { std::vector<T> h(n); CK(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+
+static bool compare_outputs(const char *what)
+{
+    CK(hipDeviceSynchronize());
+    auto off_new = fetch(BINOFF, 8), off_old = fetch(BINOFF_OLD, 8);
+    auto cnt_new = fetch(COUNTS, 64), cnt_old = fetch(COUNTS_OLD, 64);
+    bool ok = off_new == off_old && cnt_new == cnt_old;
+    auto code_new = fetch(CODE, N), code_old = fetch(CODE_OLD, N);
+    ok &= code_new == code_old;
+    auto idx_new = fetch(IDX, off_old[7]), idx_old = fetch(IDX_OLD, off_old[7]);
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < idx_old.size(); ++i) if (idx_new[i] != idx_old[i]) { if (!bad) first = i; ++bad; }
+    ok &= bad == 0;
+    printf("verify %-28s %s  (units %llu; offsets %s, counts %s, codes %s, idx mismatches %zu first at %zu)\n", what, ok ? "OK" : "MISMATCH",
+           (unsigned long long)off_old[7], off_new == off_old ? "ok" : "BAD", cnt_new == cnt_old ? "ok" : "BAD",
+           code_new == code_old ? "ok" : "BAD", bad, first);
+    return ok;
 }
 
 int main(int argc, char **argv)
 {
     N = argc > 1 ? strtoull(argv[1], 0, 10) : 100000000ull;
     const int rounds = argc > 2 ? atoi(argv[2]) : 15;
-    CK(hipMalloc(&A1, N * 4)); CK(hipMalloc(&X1, N * 4)); CK(hipMalloc(&A2, N * 4)); CK(hipMalloc(&X2, N * 4));
-    CK(hipMalloc(&BITS, N / 8 + 64)); CK(hipMalloc(&CODE, N + 64));
-    CK(hipMalloc(&CHUNK_COUNTS, 8 * (N / 4096 + 128) * 4)); CK(hipMalloc(&CHUNK_OFF, 8 * (N / 4096 + 128) * 4));
-    CK(hipMalloc(&IDX, N * 4)); CK(hipMalloc(&BINOFF, 64)); CK(hipMalloc(&BINTOT, 64)); CK(hipMalloc(&COUNTS, 512)); CK(hipMalloc(&COUNTS_REP, 64 * 512));
-    CK(hipMemset(COUNTS_REP, 0, 64 * 512));
+    MODE = argc > 3 ? atoi(argv[3]) : XM_MODE_PE_LIBERAL;
+    const bool interleaved = !(argc > 4 && atoi(argv[4]) == 0);
+    CK(hipMalloc(&A1, N * 4 + 64)); CK(hipMalloc(&X1, N * 4 + 64)); CK(hipMalloc(&A2, N * 4 + 64)); CK(hipMalloc(&X2, N * 4 + 64));
+    CK(hipMalloc(&BITS, N / 8 + 64)); CK(hipMalloc(&CODE, N + 64)); CK(hipMalloc(&CODE_OLD, N + 64));
+    const size_t ws = 8 * (N / 1024 + 256) * 4;
+    CK(hipMalloc(&GC, ws)); CK(hipMalloc(&GO, ws)); CK(hipMalloc(&CC_OLD, ws)); CK(hipMalloc(&CO_OLD, ws));
+    CK(hipMalloc(&IDX, N * 4 + 64)); CK(hipMalloc(&IDX_OLD, N * 4 + 64)); CK(hipMalloc(&IDX_SCRATCH, N * 4 + 64));
+    CK(hipMalloc(&BINOFF, 64)); CK(hipMalloc(&BINOFF_OLD, 64)); CK(hipMalloc(&COUNTS, 512)); CK(hipMalloc(&COUNTS_OLD, 512));
+    CK(hipMalloc(&REP, (64 * 64 + 8) * 8)); CK(hipMalloc(&REP_OLD, (64 * 64 + 8) * 8));
+    CK(hipMemset(REP, 0, (64 * 64 + 8) * 8)); CK(hipMemset(REP_OLD, 0, (64 * 64 + 8) * 8));
+    CK(hipMalloc(&PART, 8 * XM_PART_STRIDE * 4));
+    CK(hipEventCreate(&EV_FORK)); CK(hipEventCreate(&EV_JOIN[0])); CK(hipEventCreate(&EV_JOIN[1]));
+    for (int k = 0; k < 2; ++k) {
+        Lane2 &l = L2[k];
+        CK(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+        CK(hipMalloc(&l.code, N + 64)); CK(hipMalloc(&l.gc, ws)); CK(hipMalloc(&l.go, ws)); CK(hipMalloc(&l.idx, N * 4 + 64));
+        CK(hipMalloc(&l.part, 8 * XM_PART_STRIDE * 4)); CK(hipMalloc(&l.rep, (64 * 64 + 8) * 8)); CK(hipMemset(l.rep, 0, (64 * 64 + 8) * 8));
+        CK(hipMalloc(&l.binoff, 64)); CK(hipMalloc(&l.counts, 512));
+    }
     {   // pair-structured scores: ~86 % primary, 9 % secondary, 3 % both, 2 % neither, mates share the origin
         std::vector<int32_t> a1(N), x1(N), a2(N), x2(N);
         uint64_t s = 88172645463325252ull;
         auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 32); };
-        for (uint64_t p = 0; p < N / 2; ++p) {
+        for (uint64_t p = 0; p < (N + 1) / 2; ++p) {
             uint32_t o = rnd() % 100; int origin = o < 86 ? 0 : o < 95 ? 1 : o < 98 ? 2 : 3;
             for (int mte = 0; mte < 2; ++mte) {
                 uint64_t i = 2 * p + mte;
+                if (i >= N) break;
                 int32_t ha = (rnd() % 100 < 98) ? (int32_t)(300 - 2 * (rnd() % 40)) : INT32_MIN;
                 int32_t hx = (ha != INT32_MIN && rnd() % 100 < 35) ? ((rnd() % 4 == 0) ? ha : (int32_t)(61 + rnd() % (ha - 60))) : INT32_MIN;
                 int32_t oa = (rnd() % 100 < 15) ? (int32_t)(61 + rnd() % 160) : INT32_MIN;
@@ -96,40 +263,53 @@ int main(int argc, char **argv)
         CK(hipMemcpy(A1, a1.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X1, x1.data(), N * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(A2, a2.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X2, x2.data(), N * 4, hipMemcpyHostToDevice));
     }
-    CK(hipMemset(BITS, 0xAA, N / 8 + 64));
-    run_cls<true, 512>(0);
-    CK(hipDeviceSynchronize());
+    CK(hipMemset(BITS, (MODE == XM_MODE_SE || !interleaved) ? 0xFF : 0xAA, N / 8 + 64));
 
-    struct Cfg { const char *name; void (*fn)(int); int grid; double bytes; };
-    const double cls_alg = 16.5 * (double)N, k2_alg = 2.5 * (double)N;
+    // correctness first: old chain, new fused chain, new unfused chain
+    old_classify(); old_hist(); old_scan(); old_scatter();
+    new_classify_counts(); new_scan(); new_scatter();
+    bool ok = compare_outputs("fused K1+counts/scan/scatter");
+    CK(hipMemset(IDX, 0xEE, N * 4)); CK(hipMemset(COUNTS, 0xEE, 512)); CK(hipMemset(BINOFF, 0xEE, 64)); CK(hipMemset(CODE, 0xEE, N));
+    new_classify(); new_hist(); new_scan(); new_scatter();
+    ok &= compare_outputs("K1, hist/scan/scatter");
+    if (!ok) { printf("STOP: results differ\n"); return 1; }
+
+    struct Cfg { const char *name; void (*fn)(); double bytes; void (*prep)(); };
+
+    const double cls = 16.5 * (double)N, step = 19.0 * (double)N;
     std::vector<Cfg> cfgs = {
-        {"copy_like NT   g97657", run_copy<true>, 97657, cls_alg},
-        {"classify NT b256", run_cls<true, 256>, 0, cls_alg}, {"classify NT b512", run_cls<true, 512>, 0, cls_alg},
-        {"hist K1", run_hist<1>, 0, (double)N}, {"scan K1", run_scan<1>, 0, 0}, {"scatter K1", run_scatter<1>, 0, 3.0 * N},
-        {"hist K2", run_hist<2>, 0, (double)N}, {"scan K2", run_scan<2>, 0, 0}, {"scatter K2", run_scatter<2>, 0, 3.0 * N},
-        {"scatter K2 no-store", run_scatter_abl<2, 1>, 0, 3.0 * N}, {"scatter K2 no-stage", run_scatter_abl<2, 2>, 0, 3.0 * N},
-        {"scatter K2 plain-store", run_scatter_abl<2, 3>, 0, 3.0 * N},
-        {"scatter K2 sc1-store", run_scatter_abl<2, 4>, 0, 3.0 * N},
-        {"pipeline x4 nt", run_pipeline<0>, 0, 4 * 19.0 * N}, {"pipeline x4 plain", run_pipeline<3>, 0, 4 * 19.0 * N},
-        {"pipeline x4 sc1", run_pipeline<4>, 0, 4 * 19.0 * N}, {"pipeline x4 hybrid", run_pipeline<5>, 0, 4 * 19.0 * N},
-        {"scatter K2 hybrid", run_scatter_abl<2, 5>, 0, 3.0 * N},
-        {"hist K4", run_hist<4>, 0, (double)N}, {"scan K4", run_scan<4>, 0, 0}, {"scatter K4", run_scatter<4>, 0, 3.0 * N},
-        {"hist K8", run_hist<8>, 0, (double)N}, {"scan K8", run_scan<8>, 0, 0}, {"scatter K8", run_scatter<8>, 0, 3.0 * N},
+        {"copy_like NT", run_copy, cls},
+        {"r01 classify", old_classify, cls}, {"r01 hist", old_hist, (double)N}, {"r01 scan", old_scan, 0}, {"r01 scatter", old_scatter, 3.0 * N},
+        {"r02 classify", new_classify, cls}, {"r02 classify+counts", new_classify_counts, cls}, {"r02 hist", new_hist, (double)N},
+        {"r02 scan", new_scan, 0}, {"r02 scatter", new_scatter, 3.0 * N},
+        {"abl scatter product", abl_scatter<0>, 3.0 * N}, {"abl scatter no-store", abl_scatter<1>, 3.0 * N},
+        {"abl scatter skip-empty", abl_scatter<6>, 3.0 * N}, {"abl scatter xcd-contig", abl_scatter<8>, 3.0 * N}, {"abl scatter coalesced-st", abl_scatter<3>, 3.0 * N},
+        {"abl scatter arith-decode", abl_scatter<4>, 3.0 * N}, {"abl scatter no-guard", abl_scatter<5>, 3.0 * N},
+        {"stream write 4B/unit", run_stream_write, 2.0 * N}, {"stream write 16B/lane", run_stream_write16, 2.0 * N},
+        {"stream write 16B nt", run_stream_write16_nt, 2.0 * N},
+        {"r01 pipeline x4", old_pipeline, 4 * step}, {"r02 unfused x4", new_unfused, 4 * step}, {"r02 fused x4", new_fused, 4 * step}, {"r02 fused x4 2-stream", new_fused_2stream, 4 * step},
+        {"fused x4 all-bins", ablp_fused<0>, 4 * step}, {"fused x4 skip-empty", ablp_fused<6>, 4 * step},
+        {"fused x4 no-guard", ablp_fused<5>, 4 * step}, {"fused x4 nt-store", ablp_fused<7>, 4 * step},
+        {"fused x4 arith", ablp_fused<4>, 4 * step}, {"fused x4 no-store", ablp_fused<1>, 4 * step},
     };
-    (void)k2_alg;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<std::vector<float>> t(cfgs.size());
     for (int r = 0; r < rounds + 2; ++r)
         for (size_t k = 0; k < cfgs.size(); ++k) {
-            CK(hipEventRecord(e0)); cfgs[k].fn(cfgs[k].grid); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            if (cfgs[k].prep) cfgs[k].prep();
+            CK(hipEventRecord(e0)); cfgs[k].fn(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 2) t[k].push_back(ms);
         }
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
-    unsigned long long off[8]; CK(hipMemcpy(off, BINOFF, 64, hipMemcpyDeviceToHost));
-    printf("N=%llu records; bin_offsets:", (unsigned long long)N);
-    for (int b = 0; b < 8; ++b) printf(" %llu", off[b]);
+    // the timed launches left the buffers in a consistent state again? (run the chains once more and compare)
+    old_classify(); old_hist(); old_scan(); old_scatter();
+    new_classify_counts(); new_scan(); new_scatter();
+    ok = compare_outputs("after timing, fused");
+    auto off = fetch(BINOFF, 8);
+    printf("N=%llu records mode=%d interleaved=%d; bin_offsets:", (unsigned long long)N, MODE, (int)interleaved);
+    for (int b = 0; b < 8; ++b) printf(" %llu", (unsigned long long)off[b]);
     printf("\n");
     for (size_t k = 0; k < cfgs.size(); ++k) {
         std::sort(t[k].begin(), t[k].end());
@@ -137,5 +317,5 @@ int main(int argc, char **argv)
         printf("%-24s median %7.1f us  min %7.1f us   %6.0f GB/s\n", cfgs[k].name, med * 1e3, mn * 1e3,
                cfgs[k].bytes / (med * 1e-3) / 1e9);
     }
-    return 0;
+    return ok ? 0 : 1;
 }

@@ -23,7 +23,8 @@ MAX_RECORDS = 0xFFFFF000
 KERNELS = ("classify", "hist", "scan", "scatter", "cigar", "correlate")
 
 XM_OK = 0
-_ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, -5: OverflowError}
+_ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, -5: OverflowError, -6: RuntimeError}
+UNIQUE_ID_BYTES = 128
 
 
 class HipExtensionMissing(RuntimeError):
@@ -78,12 +79,23 @@ def lib():
         "xm_classify_cigar": ([P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P], I),
         "xm_classify_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P], I),
         "xm_compact": ([P, I, U64, P, P, P, P], I),
+        "xm_classify_compact": ([P, I, U64, P, P, P, P, P, I32, P, P, P, P], I),
+        "xm_classify_compact_f64": ([P, I, U64, P, P, P, P, P, F64, P, P, P, P], I),
+        "xm_classify_compact_cigar": ([P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P, P, P], I),
         "xm_mate_correlate": ([P, U64, P, U64, P, P], I),
         "xm_mate_correlate_dev": ([P, P, U64, P, U64, P, P], I),
         "xm_classify_dev": ([P, P, I, U64, P, P, P, P, P, I32, P], I),
         "xm_classify_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P], I),
         "xm_cigar_scores_dev": ([P, P, U64, P, P, P, P, P], I),
         "xm_compact_dev": ([P, P, I, U64, P, P, P, P], I),
+        "xm_classify_compact_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, P], I),
+        "xm_classify_compact_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P], I),
+        "xm_classify_compact_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P], I),
+        "xm_comm_unique_id": ([P], I),
+        "xm_comm_init": ([P, I, I, P], I),
+        "xm_comm_destroy": ([P], I),
+        "xm_comm_size": ([P], I),
+        "xm_allreduce_counts": ([P, P, P], I),
         "xm_timing_enable": ([P, I], I),
         "xm_timing_select": ([P, ctypes.c_uint32], I),
         "xm_timing_reset": ([P], I),
@@ -99,8 +111,10 @@ def lib():
 
 EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create", "xm_ctx_destroy",
             "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_classify_cigar",
-            "xm_compact", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
-            "xm_compact_dev", "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
+            "xm_compact", "xm_classify_compact", "xm_classify_compact_f64", "xm_classify_compact_cigar", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
+            "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
+            "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
+            "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
 
 def _np_ptr(a):
@@ -110,6 +124,16 @@ def _np_ptr(a):
 def _as(a, dtype):
     a = np.ascontiguousarray(a, dtype=dtype)
     return a
+
+
+def comm_unique_id():
+    """A fresh RCCL unique id (bytes) -- call on rank 0 and hand it to every rank."""
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = lib().xm_comm_unique_id(buf)
+    if rc != XM_OK:
+        raise _ERRORS.get(rc, RuntimeError)("xm_comm_unique_id: %s [%s]" % (lib().xm_strerror(rc).decode(),
+                                                                              lib().xm_last_hip_error(None).decode()))
+    return buf.raw
 
 
 class Context(object):
@@ -148,7 +172,7 @@ class Context(object):
             return
         msg = "%s: %s" % (what, self._L.xm_strerror(rc).decode())
         detail = self._L.xm_last_hip_error(self._h).decode()
-        if detail and rc in (-3, -4):
+        if detail and rc in (-3, -4, -6):
             msg += " [" + detail + "]"
         raise _ERRORS.get(rc, RuntimeError)(msg)
 
@@ -223,6 +247,45 @@ class Context(object):
         self._check(rc, "xm_compact")
         return idx[:int(off[7])], off, counts
 
+    def classify_compact(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, want_code=True):
+        """One fused pass: classify + count + stable split.  Columns int32 (min_score = int floor) or float64
+        (min_score = float).  -> (code or None, idx, bin_offsets[8], counts[64])"""
+        f64 = np.asarray(as1).dtype == np.float64
+        cols = [_as(c, np.float64 if f64 else np.int32) for c in (as1, xs1, as2, xs2)]
+        n = cols[0].shape[0]
+        bits = _as(unit_bits, np.uint64)
+        assert bits.shape[0] >= (n + 63) // 64 and all(c.shape[0] == n for c in cols)
+        code = np.empty(n, dtype=np.uint8) if want_code else None
+        idx = np.empty(max(n, 1), dtype=np.uint32)
+        off = np.zeros(8, dtype=np.uint64)
+        counts = np.zeros(64, dtype=np.uint64)
+        fn = self._L.xm_classify_compact_f64 if f64 else self._L.xm_classify_compact
+        rc = fn(self._h, mode, n, *[_np_ptr(c) for c in cols], _np_ptr(bits),
+                float(min_score) if f64 else int(min_score), _np_ptr(code) if want_code else None,
+                _np_ptr(idx), _np_ptr(off), _np_ptr(counts))
+        self._check(rc, "xm_classify_compact")
+        return code, idx[:int(off[7])], off, counts
+
+    def classify_compact_cigar(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
+                               want_code=True):
+        a = [_as(nm1, np.int32), _as(off1, np.uint32), _as(ops1, np.uint32), _as(xs1, np.int32),
+             _as(nm2, np.int32), _as(off2, np.uint32), _as(ops2, np.uint32), _as(xs2, np.int32)]
+        n = a[0].shape[0]
+        for k in (2, 6):
+            if a[k].shape[0] == 0:
+                a[k] = np.zeros(1, dtype=np.uint32)
+        assert a[1].shape[0] == n + 1 and a[5].shape[0] == n + 1
+        bits = _as(unit_bits, np.uint64)
+        code = np.empty(n, dtype=np.uint8) if want_code else None
+        idx = np.empty(max(n, 1), dtype=np.uint32)
+        off = np.zeros(8, dtype=np.uint64)
+        counts = np.zeros(64, dtype=np.uint64)
+        rc = self._L.xm_classify_compact_cigar(self._h, mode, n, *[_np_ptr(x) for x in a], _np_ptr(bits),
+                                               int(min_score_floor), _np_ptr(code) if want_code else None,
+                                               _np_ptr(idx), _np_ptr(off), _np_ptr(counts))
+        self._check(rc, "xm_classify_compact_cigar")
+        return code, idx[:int(off[7])], off, counts
+
     def mate_correlate(self, track, density):
         """Paired-end mappability of one chromosome track (float64 in, float64 out)."""
         track = _as(track, np.float64)
@@ -285,6 +348,50 @@ class Context(object):
             ctypes.c_void_p(idx_out.data_ptr()), ctypes.c_void_p(bin_offsets.data_ptr()),
             ctypes.c_void_p(counts.data_ptr()))
         self._check(rc, "xm_compact_dev")
+
+    def classify_compact_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, code_out, idx_out, bin_offsets,
+                             counts, stream=None):
+        """The fused main loop on device-resident columns (int32 or float64): classify + count in one kernel, then
+        scan + scatter.  Asynchronous."""
+        n = as1.numel()
+        st = self._stream_handle(stream)
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (as1, xs1, as2, xs2, unit_bits)]
+        outs = [ctypes.c_void_p(t.data_ptr()) for t in (code_out, idx_out, bin_offsets, counts)]
+        if as1.element_size() == 4:
+            rc = self._L.xm_classify_compact_dev(self._h, st, mode, n, *ptrs, int(min_score), *outs)
+        else:
+            rc = self._L.xm_classify_compact_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), *outs)
+        self._check(rc, "xm_classify_compact_dev")
+
+    def classify_compact_cigar_dev(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
+                                   code_out, idx_out, bin_offsets, counts, range_flag=None, stream=None):
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits)]
+        rc = self._L.xm_classify_compact_cigar_dev(
+            self._h, self._stream_handle(stream), mode, nm1.numel(), *ptrs, int(min_score_floor),
+            ctypes.c_void_p(code_out.data_ptr()),
+            ctypes.c_void_p(range_flag.data_ptr()) if range_flag is not None else None,
+            ctypes.c_void_p(idx_out.data_ptr()), ctypes.c_void_p(bin_offsets.data_ptr()),
+            ctypes.c_void_p(counts.data_ptr()))
+        self._check(rc, "xm_classify_compact_cigar_dev")
+
+    # ---- the count all-reduce (RCCL inside the library) -----------------------------------
+    def comm_init(self, n_ranks, rank, unique_id):
+        """Join the communicator of the category_counts all-reduce; `unique_id` = comm_unique_id() of rank 0."""
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        self._check(self._L.xm_comm_init(self._h, int(n_ranks), int(rank), ctypes.c_char_p(bytes(unique_id))),
+                    "xm_comm_init")
+
+    def comm_destroy(self):
+        self._check(self._L.xm_comm_destroy(self._h), "xm_comm_destroy")
+
+    def comm_size(self):
+        return int(self._L.xm_comm_size(self._h))
+
+    def allreduce_counts(self, counts, stream=None):
+        """In-place sum over all ranks of a 64-element int64/uint64 device tensor.  Asynchronous."""
+        assert counts.numel() == 64 and counts.element_size() == 8
+        self._check(self._L.xm_allreduce_counts(self._h, self._stream_handle(stream), ctypes.c_void_p(counts.data_ptr())),
+                    "xm_allreduce_counts")
 
     # ---- timing --------------------------------------------------------------------------
     def timing_enable(self, on=True):

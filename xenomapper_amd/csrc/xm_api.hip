@@ -6,8 +6,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>          // types only: the library is looked up at run time (xm_comm_init), not linked
 
 #include "xm_kernels.h"
 
@@ -21,10 +25,11 @@ struct xm_ctx {
     int n_cu;
     char name[128];
     uint32_t max_blocks;            // grid cap for the streaming kernels: 8 workgroups per CU
-    // K2 workspace (fixed size, allocated once)
-    uint32_t *d_chunk_counts;
-    uint32_t *d_chunk_off;
-    uint64_t *d_counts_rep;         // XM_COUNT_REPLICAS x 64 partial category_counts, then 8 bin totals
+    // K2 workspace (fixed size, allocated once; one compaction in flight per context)
+    uint32_t *d_gran_counts;        // [8 bins][granule]: units per bin and granule (fused K1, or K2a)
+    uint32_t *d_gran_off;           // [8 bins][granule]: K2b's exclusive scan of the above
+    uint64_t *d_counts_rep;         // XM_COUNT_REPLICAS x 64 partial category_counts (all zero between calls), then 8 bin totals
+    uint32_t *d_part_tot;           // [8][XM_PART_STRIDE]: per-part bin totals (K2b's first level)
     // scratch of the host-buffer entry points (grown on demand, never inside *_dev calls)
     void *d_scratch[8];
     size_t scratch_bytes[8];
@@ -36,6 +41,9 @@ struct xm_ctx {
     double acc_ms[XM_K_COUNT];
     uint64_t acc_launches[XM_K_COUNT];
     std::string last_error;
+    // RCCL communicator of the count all-reduce (xm_comm_init); null until then
+    ncclComm_t comm;
+    int comm_ranks;
 };
 
 namespace {
@@ -121,6 +129,13 @@ int check_launch(xm_ctx *ctx, const char *what)
     return XM_OK;
 }
 
+const size_t COUNTS_REP_BYTES = (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t);
+const size_t PART_TOT_BYTES = 8 * XM_PART_STRIDE * sizeof(uint32_t);
+
+// a launch failed between counting and K2b: the count replicas may be non-zero -- clear them, so that the next call
+// starts from zero again
+void reset_count_state(xm_ctx *ctx, hipStream_t st);
+
 bool bad_mode(int mode) { return mode < XM_MODE_SE || mode > XM_MODE_PE_CONSERVATIVE; }
 
 // the *_dev entry points launch on the calling thread's current device, which must be the context's
@@ -128,6 +143,11 @@ bool wrong_device(const xm_ctx *ctx)
 {
     int cur = -1;
     return hipGetDevice(&cur) != hipSuccess || cur != ctx->device;
+}
+
+void reset_count_state(xm_ctx *ctx, hipStream_t st)
+{
+    (void)hipMemsetAsync(ctx->d_counts_rep, 0, COUNTS_REP_BYTES, st);
 }
 
 }  // namespace
@@ -145,6 +165,7 @@ const char *xm_strerror(int status)
     case XM_ERR_HIP: return "HIP runtime error";
     case XM_ERR_OOM: return "out of device memory";
     case XM_ERR_RANGE: return "CIGAR-derived score outside int32";
+    case XM_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
     }
 }
@@ -173,23 +194,31 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     ctx->n_cu = prop.multiProcessorCount;
     snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
     ctx->max_blocks = (uint32_t)ctx->n_cu * 8u;
-    ctx->d_chunk_counts = nullptr;
-    ctx->d_chunk_off = nullptr;
+    ctx->d_gran_counts = nullptr;
+    ctx->d_gran_off = nullptr;
     ctx->d_counts_rep = nullptr;
+    ctx->d_part_tot = nullptr;
     for (int i = 0; i < 8; ++i) { ctx->d_scratch[i] = nullptr; ctx->scratch_bytes[i] = 0; }
     ctx->timing = false;
+    ctx->comm = nullptr;
+    ctx->comm_ranks = 0;
     ctx->timing_mask = ~0u;
     for (int k = 0; k < XM_K_COUNT; ++k) { ctx->acc_ms[k] = 0.0; ctx->acc_launches[k] = 0; }
-    const size_t ws = ((size_t)XM_MAX_CHUNKS + 64) * 8 * sizeof(uint32_t);    // [8 bins][chunk pitch], largest input
-    hipError_t e = hipMalloc((void **)&ctx->d_chunk_counts, ws);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_chunk_off, ws);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counts_rep, (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemset(ctx->d_counts_rep, 0, (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t));
+    // [8 bins][granule pitch] for the largest input at the smallest granule: 2 x 134 MB of the 288 GB
+    const size_t ws = ((size_t)XM_MAX_GRANULES + 64) * 8 * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void **)&ctx->d_gran_counts, ws);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_gran_off, ws);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counts_rep, COUNTS_REP_BYTES);
+    if (e == hipSuccess) e = hipMemset(ctx->d_counts_rep, 0, COUNTS_REP_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_part_tot, PART_TOT_BYTES);
     if (e != hipSuccess) {
-        if (ctx->d_chunk_counts) (void)hipFree(ctx->d_chunk_counts);
-        if (ctx->d_chunk_off) (void)hipFree(ctx->d_chunk_off);
+        const int rc = fail_hip(nullptr, e, "xm_ctx_create: workspace");
+        if (ctx->d_gran_counts) (void)hipFree(ctx->d_gran_counts);
+        if (ctx->d_gran_off) (void)hipFree(ctx->d_gran_off);
+        if (ctx->d_counts_rep) (void)hipFree(ctx->d_counts_rep);
+        if (ctx->d_part_tot) (void)hipFree(ctx->d_part_tot);
         delete ctx;
-        return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
+        return rc;
     }
     *out = ctx;
     return XM_OK;
@@ -200,13 +229,15 @@ int xm_ctx_destroy(xm_ctx *ctx)
     if (!ctx) return XM_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    if (ctx->comm) (void)xm_comm_destroy(ctx);
     for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }
     for (auto &e : ctx->free_events) (void)hipEventDestroy(e);
     for (int i = 0; i < 8; ++i)
         if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
-    (void)hipFree(ctx->d_chunk_counts);
-    (void)hipFree(ctx->d_chunk_off);
+    (void)hipFree(ctx->d_gran_counts);
+    (void)hipFree(ctx->d_gran_off);
     (void)hipFree(ctx->d_counts_rep);
+    (void)hipFree(ctx->d_part_tot);
     delete ctx;
     return XM_OK;
 }
@@ -233,7 +264,7 @@ int xm_classify_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     hipStream_t st = (hipStream_t)stream;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out);
+        xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, nullptr);
     }
     return check_launch(ctx, "classify_kernel<int32>");
 }
@@ -250,7 +281,7 @@ int xm_classify_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     hipStream_t st = (hipStream_t)stream;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out);
+        xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, nullptr);
     }
     return check_launch(ctx, "classify_kernel<f64>");
 }
@@ -271,7 +302,7 @@ int xm_classify_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_cigar(st, mode, n, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
-                                  code_out, range_flag);
+                                  code_out, range_flag, nullptr);
     }
     return check_launch(ctx, "classify_cigar_kernel");
 }
@@ -291,38 +322,134 @@ int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n, const int32_t *nm
     return check_launch(ctx, "cigar_kernel");
 }
 
+/* K2b + K2c after the counting side (fused K1 or K2a) has filled gran_counts / counts_rep.  When a launch fails
+ * with the replicas possibly non-zero, they are cleared again so that the next call starts from zero. */
+static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const uint8_t *code, const xm::CountPlan &cp,
+                        uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
+{
+    uint64_t *bin_totals = ctx->d_counts_rep + XM_COUNT_REPLICAS * 64;
+    int rc;
+    {
+        Span span(ctx, st, XM_K_SCAN);
+        xm::launch_scan(st, cp, ctx->d_gran_off, bin_totals, counts);
+    }
+    if ((rc = check_launch(ctx, "scan_kernel")) != XM_OK) {
+        reset_count_state(ctx, st);
+        return rc;
+    }
+    {
+        Span span(ctx, st, XM_K_SCATTER);
+        xm::launch_scatter(st, cp.plan, mode, n, code, ctx->d_gran_off, bin_totals, bin_offsets, idx_out);
+    }
+    return check_launch(ctx, "scatter_kernel");
+}
+
+static xm::CountPlan count_plan(xm_ctx *ctx, uint64_t n, uint32_t gran_records)
+{
+    xm::CountPlan cp;
+    cp.plan = xm::plan_granules(n, gran_records);
+    cp.gran_counts = ctx->d_gran_counts;
+    cp.counts_rep = ctx->d_counts_rep;
+    cp.part_tot = ctx->d_part_tot;
+    return cp;
+}
+
+static int empty_compact(xm_ctx *ctx, hipStream_t st, uint64_t *bin_offsets, uint64_t *counts)
+{
+    XM_HIP(ctx, hipMemsetAsync(counts, 0, 64 * sizeof(uint64_t), st));
+    XM_HIP(ctx, hipMemsetAsync(bin_offsets, 0, 8 * sizeof(uint64_t), st));
+    return XM_OK;
+}
+
 int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_t *code,
                    uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
 {
     if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (n == 0) {
-        XM_HIP(ctx, hipMemsetAsync(counts, 0, 64 * sizeof(uint64_t), st));
-        XM_HIP(ctx, hipMemsetAsync(bin_offsets, 0, 8 * sizeof(uint64_t), st));
-        return XM_OK;
-    }
+    if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
     // d_counts_rep is all zero here: zeroed at context creation and by every K2b after it has summed it
     if (!code || !idx_out || ((uintptr_t)code & 15u)) return XM_ERR_INVALID_ARG;
-    const xm::ChunkPlan plan = xm::plan_chunks(n);
+    const xm::CountPlan cp = count_plan(ctx, n, XM_GRAN_K2);
     int rc;
     {
         Span span(ctx, st, XM_K_HIST);
-        xm::launch_hist(st, plan, mode, n, code, ctx->d_chunk_counts, ctx->d_counts_rep);
+        xm::launch_hist(st, mode, n, code, cp);
     }
     if ((rc = check_launch(ctx, "hist_kernel")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code, cp, idx_out, bin_offsets, counts);
+}
+
+/* ---- fused: classify + count in one kernel, then scan + scatter ---------------------------------------------- */
+
+int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                            const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                            const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                            uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out || !idx_out) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2 | (uintptr_t)code_out) & 15u))
+        return XM_ERR_INVALID_ARG;
+    const xm::CountPlan cp = count_plan(ctx, n, XM_CLASSIFY_BLOCK * 4);
+    int rc;
     {
-        Span span(ctx, st, XM_K_SCAN);
-        xm::launch_scan(st, plan, ctx->d_chunk_counts, ctx->d_chunk_off, ctx->d_counts_rep + XM_COUNT_REPLICAS * 64,
-                        ctx->d_counts_rep, counts);
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &cp);
     }
-    if ((rc = check_launch(ctx, "scan_kernel")) != XM_OK) return rc;
+    if ((rc = check_launch(ctx, "classify_kernel<int32, counts>")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code_out, cp, idx_out, bin_offsets, counts);
+}
+
+int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                                const double *as1, const double *xs1, const double *as2, const double *xs2,
+                                const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                                uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out || !idx_out) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || ((uintptr_t)code_out & 15u))
+        return XM_ERR_INVALID_ARG;
+    const xm::CountPlan cp = count_plan(ctx, n, XM_CLASSIFY_BLOCK * 4);
+    int rc;
     {
-        Span span(ctx, st, XM_K_SCATTER);
-        xm::launch_scatter(st, plan, mode, n, code, ctx->d_chunk_off, ctx->d_counts_rep + XM_COUNT_REPLICAS * 64,
-                           bin_offsets, idx_out);
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &cp);
     }
-    return check_launch(ctx, "scatter_kernel");
+    if ((rc = check_launch(ctx, "classify_kernel<f64, counts>")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code_out, cp, idx_out, bin_offsets, counts);
+}
+
+int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                                  const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                                  const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                                  const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                                  uint32_t *range_flag, uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
+    if (!nm1 || !off1 || !ops1 || !xs1 || !nm2 || !off2 || !ops2 || !xs2 || !unit_bits || !code_out || !idx_out)
+        return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)nm1 | (uintptr_t)off1 | (uintptr_t)xs1 | (uintptr_t)nm2 | (uintptr_t)off2 | (uintptr_t)xs2 |
+          (uintptr_t)code_out) & 15u))
+        return XM_ERR_INVALID_ARG;
+    const xm::CountPlan cp = count_plan(ctx, n, XM_CIGAR_BLOCK * 4);
+    int rc;
+    {
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_cigar(st, mode, n, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
+                                  code_out, range_flag, &cp);
+    }
+    if ((rc = check_launch(ctx, "classify_cigar_kernel<counts>")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code_out, cp, idx_out, bin_offsets, counts);
 }
 
 int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,
@@ -340,6 +467,18 @@ int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *t
 }
 
 /* ---- host-buffer entry points ------------------------------------------------------------ */
+
+static int fetch_compact_results(xm_ctx *ctx, uint64_t n, const uint8_t *d_code, const uint32_t *d_idx, const uint64_t *d_off,
+                                 uint8_t *code_out, uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
+
+// category_counts of a counting classify launch without a compaction: K2b alone adds the replicas up (and zeroes them)
+static int counts_only_tail(xm_ctx *ctx, const xm::CountPlan &cp, uint64_t *d_counts)
+{
+    xm::launch_scan(nullptr, cp, ctx->d_gran_off, ctx->d_counts_rep + XM_COUNT_REPLICAS * 64, d_counts);
+    const int rc = check_launch(ctx, "scan_kernel");
+    if (rc != XM_OK) reset_count_state(ctx, nullptr);
+    return rc;
+}
 
 static int classify_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const void *as1, const void *xs1,
                          const void *as2, const void *xs2, const uint64_t *unit_bits, int32_t mi, double mf,
@@ -361,21 +500,28 @@ static int classify_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const v
     if ((rc = ensure_scratch(ctx, 4, bits_bytes)) != XM_OK) return rc;
     XM_HIP(ctx, hipMemcpy(ctx->d_scratch[4], unit_bits, bits_bytes, hipMemcpyHostToDevice));
     if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 7, 72 * sizeof(uint64_t))) != XM_OK) return rc;
     uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
-    if (elem == 4)
-        rc = xm_classify_dev(ctx, nullptr, mode, n, (const int32_t *)ctx->d_scratch[0], (const int32_t *)ctx->d_scratch[1],
-                             (const int32_t *)ctx->d_scratch[2], (const int32_t *)ctx->d_scratch[3],
-                             (const uint64_t *)ctx->d_scratch[4], mi, d_code);
-    else
-        rc = xm_classify_f64_dev(ctx, nullptr, mode, n, (const double *)ctx->d_scratch[0], (const double *)ctx->d_scratch[1],
-                                 (const double *)ctx->d_scratch[2], (const double *)ctx->d_scratch[3],
-                                 (const uint64_t *)ctx->d_scratch[4], mf, d_code);
-    if (rc != XM_OK) return rc;
-    XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
-    if (counts) {
-        for (uint64_t i = 0; i < n; ++i)
-            if (code_out[i] != XM_NO_UNIT) counts[code_out[i] & 63u]++;
+    uint64_t *d_counts = (uint64_t *)ctx->d_scratch[7] + 8;
+    // category_counts come from the counting form of the kernel (+ K2b, which adds the replicas up)
+    const xm::CountPlan cp = count_plan(ctx, n, XM_CLASSIFY_BLOCK * 4);
+    {
+        Span span(ctx, nullptr, XM_K_CLASSIFY);
+        if (elem == 4)
+            xm::launch_classify_i32(nullptr, mode, n, (const int32_t *)ctx->d_scratch[0], (const int32_t *)ctx->d_scratch[1],
+                                    (const int32_t *)ctx->d_scratch[2], (const int32_t *)ctx->d_scratch[3],
+                                    (const uint64_t *)ctx->d_scratch[4], mi, d_code, counts ? &cp : nullptr);
+        else
+            xm::launch_classify_f64(nullptr, mode, n, (const double *)ctx->d_scratch[0], (const double *)ctx->d_scratch[1],
+                                    (const double *)ctx->d_scratch[2], (const double *)ctx->d_scratch[3],
+                                    (const uint64_t *)ctx->d_scratch[4], mf, d_code, counts ? &cp : nullptr);
     }
+    if ((rc = check_launch(ctx, "classify_kernel")) != XM_OK) return rc;
+    if (counts) {
+        if ((rc = counts_only_tail(ctx, cp, d_counts)) != XM_OK) return rc;
+        XM_HIP(ctx, hipMemcpy(counts, d_counts, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
     return XM_OK;
 }
 
@@ -423,15 +569,18 @@ int xm_cigar_scores(xm_ctx *ctx, uint64_t n, const int32_t *nm, const uint32_t *
     return flag ? XM_ERR_RANGE : XM_OK;
 }
 
-int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n,
-                      const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
-                      const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
-                      const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint64_t counts[64])
+static int classify_cigar_host(xm_ctx *ctx, int mode, uint64_t n,
+                               const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                               const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                               const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint64_t counts[64],
+                               bool compact, uint32_t *idx_out, uint64_t bin_offsets[8])
 {
-    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS) return XM_ERR_INVALID_ARG;
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || (compact && !bin_offsets)) return XM_ERR_INVALID_ARG;
     if (counts) memset(counts, 0, 64 * sizeof(uint64_t));
+    if (compact) memset(bin_offsets, 0, 8 * sizeof(uint64_t));
     if (n == 0) return XM_OK;
-    if (!nm1 || !off1 || !xs1 || !nm2 || !off2 || !xs2 || !unit_bits || !code_out) return XM_ERR_INVALID_ARG;
+    if (!nm1 || !off1 || !xs1 || !nm2 || !off2 || !xs2 || !unit_bits) return XM_ERR_INVALID_ARG;
+    if (compact ? !idx_out : !code_out) return XM_ERR_INVALID_ARG;
     XM_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n_ops1 = off1[n], n_ops2 = off2[n];
     if ((n_ops1 && !ops1) || (n_ops2 && !ops2)) return XM_ERR_INVALID_ARG;
@@ -442,6 +591,8 @@ int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n,
     int rc;
     if ((rc = ensure_scratch(ctx, 0, total)) != XM_OK) return rc;
     if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 7, 72 * sizeof(uint64_t))) != XM_OK) return rc;
+    if (compact && (rc = ensure_scratch(ctx, 6, (size_t)n * 4)) != XM_OK) return rc;
     uint8_t *base = (uint8_t *)ctx->d_scratch[0];
     size_t o = 0;
     auto put = [&](const void *src, size_t bytes, size_t reserve) -> void * {
@@ -459,20 +610,49 @@ int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n,
         return fail_hip(ctx, hipGetLastError(), "hipMemcpy(cigar columns)");
     XM_HIP(ctx, hipMemset(d_flag, 0, 16));
     uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
-    rc = xm_classify_cigar_dev(ctx, nullptr, mode, n, (const int32_t *)d_nm1, (const uint32_t *)d_off1,
-                               (const uint32_t *)d_ops1, (const int32_t *)d_xs1, (const int32_t *)d_nm2,
-                               (const uint32_t *)d_off2, (const uint32_t *)d_ops2, (const int32_t *)d_xs2,
-                               (const uint64_t *)d_bits, min_score_floor, d_code, (uint32_t *)d_flag);
+    uint64_t *d_off = (uint64_t *)ctx->d_scratch[7];
+    const xm::CountPlan cp = count_plan(ctx, n, XM_CIGAR_BLOCK * 4);
+    const bool counting = compact || counts != nullptr;
+    {
+        Span span(ctx, nullptr, XM_K_CLASSIFY);
+        xm::launch_classify_cigar(nullptr, mode, n, (const int32_t *)d_nm1, (const uint32_t *)d_off1, (const uint32_t *)d_ops1,
+                                  (const int32_t *)d_xs1, (const int32_t *)d_nm2, (const uint32_t *)d_off2,
+                                  (const uint32_t *)d_ops2, (const int32_t *)d_xs2, (const uint64_t *)d_bits,
+                                  min_score_floor, d_code, (uint32_t *)d_flag, counting ? &cp : nullptr);
+    }
+    if ((rc = check_launch(ctx, "classify_cigar_kernel")) != XM_OK) return rc;
+    if (compact)
+        rc = compact_tail(ctx, nullptr, mode, n, d_code, cp, (uint32_t *)ctx->d_scratch[6], d_off, d_off + 8);
+    else if (counting)
+        rc = counts_only_tail(ctx, cp, d_off + 8);
     if (rc != XM_OK) return rc;
     uint32_t flag = 0;
-    XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
     XM_HIP(ctx, hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
     if (flag) return XM_ERR_RANGE;
-    if (counts) {
-        for (uint64_t i = 0; i < n; ++i)
-            if (code_out[i] != XM_NO_UNIT) counts[code_out[i] & 63u]++;
-    }
+    if (compact)
+        return fetch_compact_results(ctx, n, d_code, (const uint32_t *)ctx->d_scratch[6], d_off, code_out, idx_out, bin_offsets, counts);
+    XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
+    if (counts) XM_HIP(ctx, hipMemcpy(counts, d_off + 8, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return XM_OK;
+}
+
+int xm_classify_cigar(xm_ctx *ctx, int mode, uint64_t n,
+                      const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                      const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                      const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint64_t counts[64])
+{
+    return classify_cigar_host(ctx, mode, n, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor, code_out,
+                               counts, false, nullptr, nullptr);
+}
+
+int xm_classify_compact_cigar(xm_ctx *ctx, int mode, uint64_t n,
+                              const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
+                              const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
+                              const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                              uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64])
+{
+    return classify_cigar_host(ctx, mode, n, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor, code_out,
+                               counts, true, idx_out, bin_offsets);
 }
 
 int xm_mate_correlate(xm_ctx *ctx, uint64_t n, const double *track, uint64_t m, const double *density, double *out)
@@ -519,6 +699,189 @@ int xm_compact(xm_ctx *ctx, int mode, uint64_t n, const uint8_t *code, uint32_t 
     if (counts) memcpy(counts, host + 8, 64 * sizeof(uint64_t));
     if (host[7]) XM_HIP(ctx, hipMemcpy(idx_out, ctx->d_scratch[6], (size_t)host[7] * 4, hipMemcpyDeviceToHost));
     return XM_OK;
+}
+
+/* ---- host-buffer fused entry points: columns up, one fused pass, lists (and category bytes) down -------------- */
+
+// results of a fused pass: bin offsets + counts first (they size the index copy), then the lists, then the bytes
+static int fetch_compact_results(xm_ctx *ctx, uint64_t n, const uint8_t *d_code, const uint32_t *d_idx, const uint64_t *d_off,
+                                 uint8_t *code_out, uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64])
+{
+    uint64_t host[72];
+    XM_HIP(ctx, hipMemcpy(host, d_off, sizeof host, hipMemcpyDeviceToHost));
+    memcpy(bin_offsets, host, 8 * sizeof(uint64_t));
+    if (counts) memcpy(counts, host + 8, 64 * sizeof(uint64_t));
+    if (host[7]) XM_HIP(ctx, hipMemcpy(idx_out, d_idx, (size_t)host[7] * 4, hipMemcpyDeviceToHost));
+    if (code_out) XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
+    return XM_OK;
+}
+
+static int classify_compact_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const void *as1, const void *xs1,
+                                 const void *as2, const void *xs2, const uint64_t *unit_bits, int32_t mi, double mf,
+                                 uint8_t *code_out, uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64])
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || !bin_offsets) return XM_ERR_INVALID_ARG;
+    memset(bin_offsets, 0, 8 * sizeof(uint64_t));
+    if (counts) memset(counts, 0, 64 * sizeof(uint64_t));
+    if (n == 0) return XM_OK;
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !idx_out) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t col_bytes = (size_t)n * elem;
+    const size_t bits_bytes = (size_t)((n + 63) / 64) * 8;
+    const void *src[4] = {as1, xs1, as2, xs2};
+    int rc;
+    for (int c = 0; c < 4; ++c) {
+        if ((rc = ensure_scratch(ctx, c, col_bytes)) != XM_OK) return rc;
+        XM_HIP(ctx, hipMemcpy(ctx->d_scratch[c], src[c], col_bytes, hipMemcpyHostToDevice));
+    }
+    if ((rc = ensure_scratch(ctx, 4, bits_bytes)) != XM_OK) return rc;
+    XM_HIP(ctx, hipMemcpy(ctx->d_scratch[4], unit_bits, bits_bytes, hipMemcpyHostToDevice));
+    if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 6, (size_t)n * 4)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 7, 72 * sizeof(uint64_t))) != XM_OK) return rc;
+    uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
+    uint32_t *d_idx = (uint32_t *)ctx->d_scratch[6];
+    uint64_t *d_off = (uint64_t *)ctx->d_scratch[7];
+    if (elem == 4)
+        rc = xm_classify_compact_dev(ctx, nullptr, mode, n, (const int32_t *)ctx->d_scratch[0], (const int32_t *)ctx->d_scratch[1],
+                                     (const int32_t *)ctx->d_scratch[2], (const int32_t *)ctx->d_scratch[3],
+                                     (const uint64_t *)ctx->d_scratch[4], mi, d_code, d_idx, d_off, d_off + 8);
+    else
+        rc = xm_classify_compact_f64_dev(ctx, nullptr, mode, n, (const double *)ctx->d_scratch[0], (const double *)ctx->d_scratch[1],
+                                         (const double *)ctx->d_scratch[2], (const double *)ctx->d_scratch[3],
+                                         (const uint64_t *)ctx->d_scratch[4], mf, d_code, d_idx, d_off, d_off + 8);
+    if (rc != XM_OK) return rc;
+    return fetch_compact_results(ctx, n, d_code, d_idx, d_off, code_out, idx_out, bin_offsets, counts);
+}
+
+int xm_classify_compact(xm_ctx *ctx, int mode, uint64_t n,
+                        const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                        const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                        uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64])
+{
+    return classify_compact_host(ctx, mode, n, sizeof(int32_t), as1, xs1, as2, xs2, unit_bits, min_score_floor, 0.0,
+                                 code_out, idx_out, bin_offsets, counts);
+}
+
+int xm_classify_compact_f64(xm_ctx *ctx, int mode, uint64_t n,
+                            const double *as1, const double *xs1, const double *as2, const double *xs2,
+                            const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                            uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64])
+{
+    return classify_compact_host(ctx, mode, n, sizeof(double), as1, xs1, as2, xs2, unit_bits, 0, min_score,
+                                 code_out, idx_out, bin_offsets, counts);
+}
+
+/* ---- the one collective of the path: category_counts summed over the GPUs (RCCL) ------------------------------ */
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+// One RCCL per process: a copy that is already mapped (PyTorch-ROCm brings its own librccl) is reused, otherwise the
+// ROCm installation's is loaded.
+RcclApi *rccl()
+{
+    static RcclApi api;
+    if (api.handle || !api.error.empty()) return &api;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *nm : names)
+        if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *nm : names)
+        if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (!api.handle) api.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!api.handle) {
+        const char *why = dlerror();
+        api.error = std::string("librccl not found: ") + (why ? why : "dlopen failed");
+        return &api;
+    }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+        api.error = "librccl lacks an expected entry point";
+        api.handle = nullptr;
+    }
+    return &api;
+}
+
+int fail_rccl(xm_ctx *ctx, RcclApi *api, ncclResult_t r, const char *what)
+{
+    std::string msg = std::string(what) + ": " + (api->GetErrorString ? api->GetErrorString(r) : "RCCL error");
+    if (ctx) ctx->last_error = msg;
+    else g_create_error = msg;
+    return XM_ERR_RCCL;
+}
+
+int no_rccl(xm_ctx *ctx, RcclApi *api)
+{
+    if (ctx) ctx->last_error = api->error;
+    else g_create_error = api->error;
+    return XM_ERR_RCCL;
+}
+
+}  // namespace
+
+int xm_comm_unique_id(void *id_out)
+{
+    if (!id_out) return XM_ERR_INVALID_ARG;
+    RcclApi *api = rccl();
+    if (!api->handle) return no_rccl(nullptr, api);
+    ncclUniqueId id;
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail_rccl(nullptr, api, r, "ncclGetUniqueId");
+    static_assert(sizeof id == XM_UNIQUE_ID_BYTES, "RCCL unique id size");
+    memcpy(id_out, &id, sizeof id);
+    return XM_OK;
+}
+
+int xm_comm_init(xm_ctx *ctx, int n_ranks, int rank, const void *unique_id)
+{
+    if (!ctx || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks || ctx->comm) return XM_ERR_INVALID_ARG;
+    RcclApi *api = rccl();
+    if (!api->handle) return no_rccl(ctx, api);
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    const ncclResult_t r = api->CommInitRank(&ctx->comm, n_ranks, id, rank);
+    if (r != ncclSuccess) {
+        ctx->comm = nullptr;
+        return fail_rccl(ctx, api, r, "ncclCommInitRank");
+    }
+    ctx->comm_ranks = n_ranks;
+    return XM_OK;
+}
+
+int xm_comm_destroy(xm_ctx *ctx)
+{
+    if (!ctx) return XM_ERR_INVALID_ARG;
+    if (!ctx->comm) return XM_OK;
+    RcclApi *api = rccl();
+    (void)hipSetDevice(ctx->device);
+    const ncclResult_t r = api->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_ranks = 0;
+    return r == ncclSuccess ? XM_OK : fail_rccl(ctx, api, r, "ncclCommDestroy");
+}
+
+int xm_comm_size(const xm_ctx *ctx) { return ctx ? ctx->comm_ranks : 0; }
+
+int xm_allreduce_counts(xm_ctx *ctx, void *stream, uint64_t *counts)
+{
+    if (!ctx || !counts || !ctx->comm || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    RcclApi *api = rccl();
+    const ncclResult_t r = api->AllReduce(counts, counts, 64, ncclUint64, ncclSum, ctx->comm, (hipStream_t)stream);
+    return r == ncclSuccess ? XM_OK : fail_rccl(ctx, api, r, "ncclAllReduce(category_counts)");
 }
 
 /* ---- timing -------------------------------------------------------------------------------- */
