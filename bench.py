@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the classification hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py                              # 1 GPU, configs[1]
+    python bench.py --gpus N --steps K --warmup W   # N > 1: starts its own N ranks (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W            # ... or is started as a rank
 
-One step = one pass of the hot path over one batch of synthetic input that is already resident
-in HBM: K1 classify (score columns -> category byte per record) + K2 compact (category_counts +
-stable split of the pair indices into the six bins); every step adds its category_counts to the
-job's running total on the device.  On N > 1 GPUs the job ends -- inside the timed region -- with the
-one RCCL all-reduce of the final category_counts (the reference also only reports them at the end of
-a run).  Workload = BASELINE.json configs[1]: 50 M paired-end 2x150 bp read pairs with AS/XS scores
-per GPU (weak scaling: every rank holds its own 50 M-pair read block).
+One step = one pass of the hot path over one batch of synthetic input that is already resident in HBM, through
+ONE C-ABI call (xm_classify_compact_dev): K1 classify + count (score columns -> category byte per record,
+category_counts, per-granule bin counts), K2b scan, K2c scatter (stable split of the pair indices into the six
+bins); every step adds its category_counts to the job's running total on the device.  On N > 1 GPUs the job ends --
+inside the timed region -- with the one RCCL all-reduce of the final category_counts (the reference also only
+reports them at the end of a run).  Workload = BASELINE.json configs[1]: 50 M paired-end 2x150 bp read pairs with
+AS/XS scores per GPU (weak scaling: every rank holds its own 50 M-pair read block).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (classify): algorithmic bytes
-(33 B per pair: 4 int32 scores x 2 mates in, 1 category byte out) / the kernel's mean
-duration, measured with HIP events on the launch stream inside the timed region.  `cpu_baseline`
-is the oracle's Python restatement of the reference's whole CPU path (parse + classify + write) on
-SAM text, timed on one host core at N = 1 on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (classify): algorithmic bytes (33 B per pair:
+4 int32 scores x 2 mates in, 1 category byte out) / the kernel's mean duration, measured with HIP
+events on the launch stream inside the timed region.  `roofline_step` is SURVEY 8d's whole-step figure: 38 B per pair
+/ the sum of the kernels' mean durations.  `cpu_baseline` is the oracle's Python restatement of the reference's whole
+CPU path (parse + classify + write) on SAM text, timed on one host core at N = 1 on a bounded sample.  `e2e` holds
+the two transfer-inclusive rates SURVEY 8d asks for beside it (never `value`): host columns in / bin lists out over
+PCIe, and SAM text in / six SAM files out.
 """
 import argparse
+import contextlib
 import io
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +38,61 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBPS = 8000.0                 # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 BYTES_PER_PAIR_CLASSIFY = 33.0         # algorithmic: 2 mates x 4 int32 scores in + 1 category byte out
 BYTES_PER_PAIR_COMPACT = 5.0           # 1 category byte in + one u32 pair index out
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=50_000_000, help="read pairs per GPU")
+    ap.add_argument("--mode", choices=("liberal", "conservative"), default=None)
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5", "f64", "se"), default="cfg2",
+                    help="BASELINE.json configs[1] (default, the quoted metric), [2] --cigar_scores path, [4] HISAT ZS + "
+                         "conservative; f64 = configs[1] through the binary64 kernel; se = the single-end loop (units = reads)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the transfer-inclusive side measurements")
+    return ap.parse_args()
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on stdout when its first communicator comes up; stdout is for the one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a plain start: N fresh rank processes under torch.distributed.run, before this
+    process has touched the GPU (it never does); rank 0's JSON line comes through on stdout."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline_python(sample_pairs=20000, passes=0, budget_s=12.0):
@@ -54,7 +115,8 @@ def cpu_baseline_python(sample_pairs=20000, passes=0, budget_s=12.0):
         el = time.perf_counter() - t0
         if (passes and n_pass >= passes) or (not passes and el >= budget_s):
             break
-    return {"value": done / el, "unit": "read-pairs/s", "cores": 1, "kind": "port",
+    return {"value": done / el, "unit": "read-pairs/s", "cores": 1, "cpu_model": cpu_model(),
+            "host_cpus_visible": os.cpu_count(), "kind": "port",
             "sample": "%d passes over a %d-pair 2x150 bp SAM text twin (seed 2002): parse + classify + "
                       "write six bins, pure-Python restatement of the reference loop" % (n_pass, sample_pairs),
             "seconds": round(el, 2)}
@@ -68,23 +130,47 @@ def cpu_baseline_c(cols_host, n_pairs):
                            cols_host["unit_bits"], -2**31)
     H.c_compact(1, code)
     el = time.perf_counter() - t0
-    return {"value": n_pairs / el, "unit": "read-pairs/s", "cores": 1, "kind": "port",
+    return {"value": n_pairs / el, "unit": "read-pairs/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
             "sample": "%d pairs of the same columns, scalar C restatement, classify + compact only "
                       "(no SAM parsing, no output)" % n_pairs, "seconds": round(el, 3)}
 
 
+def e2e_h2d_inclusive(ctx, mode, host_cols, pairs, reps=3):
+    """Host columns in, bin lists + counts out, through the host-buffer C ABI (pageable NumPy memory): H2D of the four
+    score columns and the unit mask, the fused pass, D2H of the index lists.  Never `value`."""
+    import numpy as np
+    n = 2 * pairs
+    cols = [np.ascontiguousarray(host_cols[k][:n]) for k in ("as1", "xs1", "as2", "xs2")]
+    bits = np.ascontiguousarray(host_cols["unit_bits"][:(n + 63) // 64])
+    best, units = None, 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        _, idx, off, _ = ctx.classify_compact(mode, *cols, bits, -2**31, want_code=False)
+        el = time.perf_counter() - t0
+        best = el if best is None else min(best, el)
+        units = int(off[7])
+    moved = 16 * n + n // 8 + 4 * units
+    return {"read_pairs_per_s": units / best, "GBps_over_pcie": moved / best / 1e9, "pairs": pairs,
+            "bytes_over_pcie": moved, "seconds": round(best, 4),
+            "what": "xm_classify_compact on pageable host arrays: H2D 32.25 B/pair, fused pass, D2H 4 B/pair (bin lists)"}
+
+
+def e2e_sam_text(pairs=2_000_000):
+    """SAM text in -> six SAM files out through the file fast path (C++ stripper -> GPU -> C++ writer), outputs on
+    tmpfs.  Never `value`."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import bench_e2e
+    out_dir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    r = bench_e2e.run(pairs=pairs, threads=0, mode="liberal", workdir="/dev/shm" if out_dir else "/tmp", out_dir=out_dir)
+    return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"],
+            "seconds": round(r["seconds"], 4), "outputs": r["outputs"], "output_bytes": r["output_bytes"],
+            "what": "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> stripper -> H2D -> fused pass -> D2H -> six SAM files"}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=50_000_000, help="read pairs per GPU")
-    ap.add_argument("--mode", choices=("liberal", "conservative"), default=None)
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
-                    help="BASELINE.json configs[1] (default, the quoted metric), [2] --cigar_scores path, [4] HISAT ZS + conservative")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
@@ -96,8 +182,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the classifier has no CPU fallback", file=sys.stderr)
@@ -109,20 +194,45 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        backend = "gloo" if rehearsal else "nccl"
+        with stdout_to_stderr():
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def allreduce(t, op):
+        if world == 1:
+            return t
+        if backend == "gloo":                      # rehearsal only: gloo reduces host tensors
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.all_reduce(t, op=op)
+        return t
+
+    # how many ranks the collective backend really connected (the driver checks this against --gpus)
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    with stdout_to_stderr():
+        n_ranks_seen = int(allreduce(one, dist.ReduceOp.SUM).item()) if world > 1 else 1
 
     n_pairs = args.pairs
     n = 2 * n_pairs
     if args.mode is None:
         args.mode = "conservative" if args.workload == "cfg5" else "liberal"
-    mode = _ffi.MODE_PE_LIBERAL if args.mode == "liberal" else _ffi.MODE_PE_CONSERVATIVE
+    if args.workload == "se":
+        mode = _ffi.MODE_SE
+    else:
+        mode = _ffi.MODE_PE_LIBERAL if args.mode == "liberal" else _ffi.MODE_PE_CONSERVATIVE
+    units_per_step = n if args.workload == "se" else n_pairs            # se: a unit is a read
     ctx = _ffi.Context(local_rank)
-    bytes_per_pair = BYTES_PER_PAIR_CLASSIFY
+    bytes_per_unit = BYTES_PER_PAIR_CLASSIFY
+    bytes_per_unit_compact = BYTES_PER_PAIR_COMPACT
+    dtype = "int32"
     cig = None
     if args.workload == "cfg3":
         # no AS tag: AS is synthesised in-kernel from NM + CIGAR (CSR); XS mostly absent
@@ -135,32 +245,54 @@ def main():
         cols = {"xs1": xs1, "xs2": torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
                 "unit_bits": torch.from_numpy(synth.interleaved_unit_bits(n).view(np.int64)).to(dev)}
         k_bar = (cig[0]["cig_oplen"].numel() + cig[1]["cig_oplen"].numel()) / (2.0 * n)
-        bytes_per_pair = 4 * (12 + 4 * k_bar) + 1            # per record and species NM + XS + offset + ops
+        bytes_per_unit = 4 * (12 + 4 * k_bar) + 1            # per record and species NM + XS + offset + ops
         range_flag = torch.zeros(4, dtype=torch.int32, device=dev)
     else:
-        cols = synth.score_columns_torch(n_pairs, seed=(2002 if args.workload == "cfg2" else 5005) + rank, device=dev,
+        cols = synth.score_columns_torch(n_pairs, seed=(5005 if args.workload == "cfg5" else 2002) + rank, device=dev,
                                          profile="hisat" if args.workload == "cfg5" else "bowtie2")   # own read block per rank
+        if args.workload == "se":
+            cols["unit_bits"] = torch.full(((n + 63) // 64,), -1, dtype=torch.int64, device=dev)      # every record is a unit
+            bytes_per_unit, bytes_per_unit_compact = 17.0, 5.0                   # 4 int32 in + 1 byte out; 1 byte in + 1 index out
+        if args.workload == "f64":
+            for k in ("as1", "xs1", "as2", "xs2"):
+                c = cols[k]
+                cols[k] = torch.where(c == _ffi.ABSENT, torch.full((), float("-inf"), dtype=torch.float64, device=dev),
+                                      c.to(torch.float64))
+            bytes_per_unit = 65.0                                                # 2 mates x 4 binary64 scores in + 1 byte out
+            dtype = "f64"
     code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     off = torch.zeros(8, dtype=torch.int64, device=dev)
     counts = torch.zeros(64, dtype=torch.int64, device=dev)
     job_counts = torch.zeros(64, dtype=torch.int64, device=dev)
-    floor_min = _ffi.ABSENT                                                       # min_score = -inf
+    floor_min = float("-inf") if args.workload == "f64" else _ffi.ABSENT          # min_score = -inf
 
-    def step():
+    unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"          # A/B only: two C-ABI calls (classify, then compact with its own histogram)
+
+    def step_unfused():
         if cig is not None:
             ctx.classify_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
                                    cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"], cols["unit_bits"],
                                    floor_min, code, range_flag=range_flag)
         else:
-            ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"],
-                             floor_min, code)
+            ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min, code)
         ctx.compact_dev(mode, code[:n], idx, off, counts)
+        job_counts.add_(counts)
+
+    def step():
+        if unfused:
+            return step_unfused()
+        if cig is not None:
+            ctx.classify_compact_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
+                                           cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"],
+                                           cols["unit_bits"], floor_min, code, idx, off, counts, range_flag=range_flag)
+        else:
+            ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"],
+                                     floor_min, code, idx, off, counts)
         job_counts.add_(counts)                                  # category_counts of the job so far
 
     def finish():
-        if world > 1:
-            dist.all_reduce(job_counts, op=dist.ReduceOp.SUM)    # RCCL over xGMI: 64 x int64, once per job
+        allreduce(job_counts, dist.ReduceOp.SUM)                 # RCCL over xGMI: 64 x int64, once per job
 
     def fence():
         torch.cuda.synchronize()
@@ -185,6 +317,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = ctx.timing_read()
     job_total = int(job_counts.sum().item())
+    job_final = job_counts.clone()
     # diagnostic pass outside the timed region: every kernel bracketed (the event pairs cost stream time)
     ctx.timing_select(None)
     ctx.timing_reset()
@@ -195,9 +328,25 @@ def main():
     ctx.timing_enable(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(allreduce(t, dist.ReduceOp.MAX).item()) if world > 1 else elapsed
+
+    # the same reduction through the library's own RCCL communicator (xm_allreduce_counts, the C ABI's collective);
+    # outside the timed region, never fatal: the job total above came from torch.distributed
+    lib_allreduce = None
+    if not rehearsal:
+        try:
+            with stdout_to_stderr():
+                uid = [_ffi.comm_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(world, rank, uid[0])
+                mine = counts * args.steps                       # every step saw the same block: this rank's job total
+                ctx.allreduce_counts(mine)
+                torch.cuda.synchronize()
+                lib_allreduce = {"ranks": ctx.comm_size(), "matches_torch_distributed": bool(torch.equal(mine, job_final))}
+                ctx.comm_destroy()
+        except Exception as e:                                   # noqa: BLE001 -- reported, not raised
+            lib_allreduce = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # parity of what was just timed (rank-local): against the C oracle on the same columns
     verified = None
@@ -218,57 +367,88 @@ def main():
         ok &= bool((off.cpu().numpy().astype(np.uint64) == want_off).all())
         ok &= bool((idx[:int(want_off[7])].cpu().numpy().view(np.uint32) == want_idx).all())
         ok &= bool((counts.cpu().numpy().astype(np.uint64) == want_counts).all())
-        ok &= job_total == world * n_pairs * args.steps
-        verified = ok
-        flag = torch.tensor([1 if ok else 0], device=dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        verified = bool(flag.item())
+        ok &= job_total == world * units_per_step * args.steps
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        verified = bool(allreduce(flag, dist.ReduceOp.MIN).item()) if world > 1 else ok
 
     if rank == 0:
+        unit_name = "read" if args.workload == "se" else "read-pair"
         k_cls = timing["classify"]
         cls_ms = k_cls["ms"] / max(1, k_cls["launches"])
-        achieved = bytes_per_pair * n_pairs / (cls_ms * 1e-3) / 1e9
+        achieved = bytes_per_unit * units_per_step / (cls_ms * 1e-3) / 1e9
         kernels = {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in timing_all.items() if v["launches"]}
-        traffic = None
-        pmc_file = os.path.join(REPO, "profiles", {"cfg2": "pmc_classify.json", "cfg3": "pmc_classify_cigar.json"}.get(
-            args.workload, "none"))
-        if os.path.exists(pmc_file) and n_pairs == 50_000_000:
+        sum_ms = sum(kernels.values())
+        step_bytes = (bytes_per_unit + bytes_per_unit_compact) * units_per_step
+        step_achieved = step_bytes / (sum_ms * 1e-3) / 1e9
+        traffic, traffic_source = None, None
+        pmc_name = {"cfg2": "pmc_classify.json", "cfg3": "pmc_classify_cigar.json"}.get(args.workload)
+        if pmc_name and n_pairs == 50_000_000:
             try:
-                traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+                with open(os.path.join(REPO, "profiles", pmc_name)) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, replayed; not measured in this run)" % pmc_name
             except Exception:
                 traffic = None
+        ms_per_step = 1e3 * elapsed / args.steps
         line = {
-            "metric": "read-pairs/sec classified",
-            "value": world * n_pairs * args.steps / elapsed,
-            "unit": "read-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": "reads/sec classified" if args.workload == "se" else "read-pairs/sec classified",
+            "value": world * units_per_step * args.steps / elapsed,
+            "unit": unit_name + "s/s",
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "collective_backend": backend,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
+            "dtype": dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": {"cfg2": "configs[1]: %d paired-end 2x150 bp read pairs per GPU, AS/XS present, %s "
                                            "pair rule, min_score=-inf, score columns resident in HBM",
                                     "cfg3": "configs[2]: %d paired-end pairs per GPU on the --cigar_scores path (no AS/XS; NM + "
                                             "CIGAR as CSR, AS synthesised in the classify kernel), %s pair rule, columns resident in HBM",
                                     "cfg5": "configs[4]: %d paired-end pairs per GPU, HISAT-style scores with ZS as second-best "
-                                            "(AS=0/ZS=0 present), %s pair rule, columns resident in HBM"}[args.workload]
+                                            "(AS=0/ZS=0 present), %s pair rule, columns resident in HBM",
+                                    "f64": "configs[1] columns as binary64 (the reference's own arithmetic; used for non-integral "
+                                           "scores): %d paired-end pairs per GPU, %s pair rule, columns resident in HBM",
+                                    "se": "configs[0]'s kernel shape at size: single-end loop over 2 x %d reads per GPU, every "
+                                          "record a unit (%s ignored), columns resident in HBM"}[args.workload]
                                    % (n_pairs, args.mode),
                        "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": n,
+                       "step": ("A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)" if unfused else
+                                "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % ("_cigar" if cig is not None else "")),
                        "sharding": "read-block per GPU, no halo exchange" + (", one RCCL all-reduce of the final category_counts" if world > 1 else "")},
             "roofline": {"bound": "hbm",
-                         "kernel": "classify_cigar_kernel<paired>" if cig is not None else "classify_kernel<int32, paired>",
+                         "kernel": "classify_cigar_kernel<paired, counts>" if cig is not None else "classify_kernel<%s, %s, counts>" % (dtype, "single" if args.workload == "se" else "paired"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "algorithmic_bytes_per_pair": bytes_per_pair, "kernel_ms": cls_ms},
-            "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region",
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_unit": bytes_per_unit, "kernel_ms": cls_ms},
+            "roofline_step": {"bound": "hbm", "what": "SURVEY 8d: (classify + compact) algorithmic bytes per %s / sum of the kernels' mean durations" % unit_name,
+                              "algorithmic_bytes_per_unit": bytes_per_unit + bytes_per_unit_compact,
+                              "sum_kernel_ms": round(sum_ms, 5), "achieved": step_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": step_achieved / HBM_PEAK_GBPS,
+                              "frac_by_ms_per_step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region (scan = its two launches)",
             "verified_vs_oracle": verified,
+            "xm_allreduce_counts": lib_allreduce,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_python()
-            if host_cols is not None and cig is None:
+            if host_cols is not None and args.workload in ("cfg2", "cfg5"):
                 m = min(n_pairs, 5_000_000)
                 sub = {k: np.ascontiguousarray(v[:2 * m]) for k, v in host_cols.items() if k != "unit_bits"}
                 sub["unit_bits"] = np.ascontiguousarray(host_cols["unit_bits"][:(2 * m + 63) // 64])
                 line["cpu_baseline_c"] = cpu_baseline_c(sub, m)
+        if world == 1 and not args.no_e2e and args.workload == "cfg2":
+            e2e = {"note": "transfer-inclusive rates beside `value` (which is HBM-resident); measured after the timed region"}
+            try:
+                hc = host_cols if host_cols is not None else {k: v.cpu().numpy() for k, v in cols.items()}
+                if hc["unit_bits"].dtype != np.uint64:
+                    hc["unit_bits"] = hc["unit_bits"].view(np.uint64)
+                e2e["h2d_inclusive"] = e2e_h2d_inclusive(ctx, mode, hc, min(n_pairs, 25_000_000))
+            except Exception as e:                               # noqa: BLE001
+                e2e["h2d_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                e2e["sam_text"] = e2e_sam_text()
+            except Exception as e:                               # noqa: BLE001
+                e2e["sam_text"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["e2e"] = e2e
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

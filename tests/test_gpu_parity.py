@@ -553,3 +553,58 @@ def test_large_batch_64bit_offsets(ctx):
     h_off = off.cpu().numpy().astype(np.uint64)
     assert np.array_equal(h_off, want_off)
     assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_beyond_2_30_records_the_wide_scatter(ctx, mode):
+    """More than 2^30 records per species in one call: byte offsets into the index lists pass 2^32 (single-end: more
+    than 2^30 units), so the scatter runs its 64-bit-addressing instantiation.  The input is periodic -- record i
+    (single-end) / pair k (paired, both mates) holds state i % 6 / k % 6 -- so every bin list is an arithmetic
+    progression and the whole result is checked exactly on the device, chunk by chunk, without a host oracle pass."""
+    import torch
+    from xenomapper_amd import _ffi
+    dev = torch.device("cuda:0")
+    n = 12 * ((1 << 30) // 12 + 4099)                                 # > 2^30, a multiple of 12, not of 2048
+    assert n % 12 == 0 and n > (1 << 30) and n % 2048
+    table = torch.tensor([_REAL[k] for k in range(6)], dtype=torch.int32, device=dev)
+    cols = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)]
+    step = 6 * (1 << 24)
+    for a in range(0, n, step):
+        z = min(n, a + step)
+        i = torch.arange(a, z, device=dev, dtype=torch.int64)
+        s = (i % 6) if mode == 0 else ((i // 2) % 6)
+        for j in range(4):
+            cols[j][a:z] = table[s, j]
+        del i, s
+    words = (n + 63) // 64
+    bits = torch.full((words,), -1 if mode == 0 else -0x5555555555555556, dtype=torch.int64, device=dev)   # all / odd records
+    if n % 64:
+        bits[-1] &= (1 << (n % 64)) - 1
+    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    ctx.classify_compact_dev(mode, *cols, bits, _ffi.ABSENT, code, idx, off, counts)
+    torch.cuda.synchronize()
+    units = n if mode == 0 else n // 2
+    per_bin = units // 6
+    assert off.cpu().tolist() == [b * per_bin for b in range(6)] + [units, units]
+    want_counts = torch.zeros(64, dtype=torch.int64)
+    for b in range(6):
+        want_counts[b if mode == 0 else b * 9] = per_bin
+    assert torch.equal(counts.cpu(), want_counts)
+    stride, first = (6, 0) if mode == 0 else (12, 1)                  # bin b: records b, b+6, ... / 2b+1, 2b+13, ...
+    chunk = 1 << 26
+    for b in range(6):
+        lo = b * per_bin
+        for a in range(0, per_bin, chunk):
+            z = min(per_bin, a + chunk)
+            want = torch.arange(a, z, device=dev, dtype=torch.int64) * stride + (b if mode == 0 else 2 * b + first)
+            got = idx[lo + a:lo + z].to(torch.int64) & 0xFFFFFFFF
+            assert torch.equal(got, want), (b, a)
+            del want, got
+    # the stand-alone compaction of the same category bytes gives the same lists
+    idx2 = torch.empty(n, dtype=torch.int32, device=dev)
+    ctx.compact_dev(mode, code[:n], idx2, off, counts)
+    torch.cuda.synchronize()
+    assert torch.equal(idx2[:units], idx[:units]) and torch.equal(counts.cpu(), want_counts)

@@ -556,3 +556,44 @@ def test_bam_long_cigar_convention():
     # and the plain-Python restatement says the same
     from oracle import bam_oracle
     assert bam_oracle.bam_to_sam(image)[1] == lines[:6]
+
+
+def _one_record_bam(l_seq, name=b"longread\0"):
+    """A minimal BAM image: no references, one unmapped alignment with an l_seq-base sequence, BGZF blocks of 65280 bytes."""
+    import struct
+    import zlib
+    head = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", 0)
+    seq = bytes([0x12]) * ((l_seq + 1) // 2)                     # "AC" repeated
+    qual = bytes([30]) * l_seq
+    core = struct.pack("<iiBBHHHIiii", -1, -1, len(name), 0, 4680, 0, 4, l_seq, -1, -1, 0)
+    body = core + name + seq + qual
+    payload = head + struct.pack("<I", len(body)) + body
+    out = []
+    for at in range(0, len(payload), 65280):
+        part = payload[at:at + 65280]
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+        blk = comp.compress(part) + comp.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(blk) + 25) + blk +
+                   struct.pack("<II", zlib.crc32(part), len(part)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+def test_bam_lines_grows_its_buffer_for_a_line_longer_than_8_mib(tmp_path):
+    """One alignment whose SAM text (SEQ + QUAL of 5 M bases) is longer than bam_lines' first buffer: the generator
+    must deliver it (it used to spin without progress).  Through a real file (memory-mapped) and through BytesIO."""
+    import io
+    from xenomapper_amd import xenomapper as xm
+    l_seq = 5_000_000
+    image = _one_record_bam(l_seq)
+    path = tmp_path / "long.bam"
+    path.write_bytes(image)
+    for source in (open(path, "rb"), io.BytesIO(image)):
+        with source:
+            lines = list(xm.bam_lines(source))
+        assert len(lines) == 1
+        fields = lines[0].rstrip("\n").split("\t")
+        assert fields[0] == "longread" and len(fields[9]) == l_seq and len(fields[10]) == l_seq
+        assert fields[9][:4] == "ACAC" and fields[10][:2] == "??"
+    with open(path, "rb") as fh:
+        assert xm.get_bam_header(fh) == []

@@ -12,7 +12,12 @@ from tests import helpers as H
 
 
 class OracleCtx(object):
-    """Test stand-in with the Context.classify/compact signatures, backed by the C oracle."""
+    """Test stand-in with the Context.classify / compact / classify_compact signatures, backed by the C oracle."""
+
+    def classify_compact(self, mode, as1, xs1, as2, xs2, unit_bits, m, want_code=True):
+        code, counts = H.c_classify(mode, as1, xs1, as2, xs2, unit_bits, m)
+        idx, off = H.c_compact(mode, code)
+        return (code if want_code else None), idx, off, counts
 
     def classify(self, mode, as1, xs1, as2, xs2, unit_bits, m):
         return H.c_classify(mode, as1, xs1, as2, xs2, unit_bits, m)

@@ -17,24 +17,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=2_000_000)
-    ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--mode", default="liberal", choices=("liberal", "conservative", "se"))
-    ap.add_argument("--dir", default="/dev/shm")
-    ap.add_argument("--out-dir", default=None, help="write the six outputs to real files here (default: /dev/null)")
-    a = ap.parse_args()
+def run(pairs=2_000_000, threads=0, mode="liberal", workdir="/dev/shm", out_dir=None):
+    """One warm-up and one timed pass; returns the result record (also used by bench.py's `e2e.sam_text`)."""
     from xenomapper_amd import _host, synth, xenomapper as xm
     base = 50_000
-    t1, t2, _ = synth.sam_text_pair(n_pairs=base, seed=2002, profile="bowtie2", paired=a.mode != "se", read_len=150)
-    reps = max(1, a.pairs // base)
+    t1, t2, _ = synth.sam_text_pair(n_pairs=base, seed=2002, profile="bowtie2", paired=mode != "se", read_len=150)
+    reps = max(1, pairs // base)
     paths = []
     for tag, text in (("p", t1), ("s", t2)):
         head_end = 0
         while text[head_end] == "@":
             head_end = text.index("\n", head_end) + 1
-        path = os.path.join(a.dir, "xm_e2e_%s_%d.sam" % (tag, os.getpid()))
+        path = os.path.join(workdir, "xm_e2e_%s_%d.sam" % (tag, os.getpid()))
         with open(path, "wt") as fh:
             fh.write(text[:head_end])
             body = text[head_end:]
@@ -43,32 +37,44 @@ def main():
         paths.append(path)
     size = sum(os.path.getsize(p) for p in paths)
     names = ("primary_specific", "secondary_specific", "primary_multi", "secondary_multi", "unassigned", "unresolved")
-    out_paths = [os.path.join(a.out_dir, "xm_e2e_out_%s_%d.sam" % (k, os.getpid())) for k in names] if a.out_dir else []
-    sinks = {k: open(out_paths[i] if a.out_dir else os.devnull, "wt") for i, k in enumerate(names)}
+    out_paths = [os.path.join(out_dir, "xm_e2e_out_%s_%d.sam" % (k, os.getpid())) for k in names] if out_dir else []
+    sinks = {k: open(out_paths[i] if out_dir else os.devnull, "wt") for i, k in enumerate(names)}
     try:
         xm.default_context()
         for warm in (True, False):
             for sink in sinks.values():
-                if a.out_dir:
+                if out_dir:
                     sink.seek(0)
                     sink.truncate()
             t0 = time.perf_counter()
-            counts = xm.classify_sam_files(paths[0], paths[1], paired=a.mode != "se", conservative=a.mode == "conservative",
-                                           n_threads=a.threads, **sinks)
+            counts = xm.classify_sam_files(paths[0], paths[1], paired=mode != "se", conservative=mode == "conservative",
+                                           n_threads=threads, **sinks)
             for sink in sinks.values():
                 sink.flush()
             el = time.perf_counter() - t0
         units = sum(counts.values())
-        print(json.dumps({"metric": "end-to-end read-pairs/s (SAM text in, six SAM files out)", "value": units / el,
-                          "units": units, "seconds": el, "input_bytes": size, "input_GBps": size / el / 1e9,
-                          "threads": a.threads or _host.lib().xmh_default_threads(), "mode": a.mode,
-                          "outputs": "files" if a.out_dir else "/dev/null",
-                          "output_bytes": sum(os.path.getsize(p) for p in out_paths)}))
+        return {"metric": "end-to-end read-pairs/s (SAM text in, six SAM files out)", "value": units / el,
+                "units": units, "seconds": el, "input_bytes": size, "input_GBps": size / el / 1e9,
+                "threads": threads or _host.lib().xmh_default_threads(), "mode": mode,
+                "outputs": "files" if out_dir else "/dev/null",
+                "output_bytes": sum(os.path.getsize(p) for p in out_paths)}
     finally:
         for sink in sinks.values():
             sink.close()
         for p in paths + out_paths:
-            os.unlink(p)
+            if os.path.exists(p):
+                os.unlink(p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=2_000_000)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--mode", default="liberal", choices=("liberal", "conservative", "se"))
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--out-dir", default=None, help="write the six outputs to real files here (default: /dev/null)")
+    a = ap.parse_args()
+    print(json.dumps(run(a.pairs, a.threads, a.mode, a.dir, a.out_dir)))
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ static uint64_t *REP, *REP_OLD, *BINOFF, *BINOFF_OLD, *COUNTS, *COUNTS_OLD;
 static int MODE = XM_MODE_PE_LIBERAL;
 
 static uint32_t *PART;
-static xm::CountPlan cplan(uint32_t gran) { xm::CountPlan cp; cp.plan = xm::plan_granules(N, gran); cp.gran_counts = GC; cp.counts_rep = REP; cp.part_tot = PART; return cp; }
+static xm::CountPlan cplan(uint32_t = 0) { xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = GC; cp.counts_rep = REP; cp.part_tot = PART; return cp; }
 
 static void old_classify() { xm_r01::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE_OLD); }
 static void old_hist() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_hist(0, p, MODE, N, CODE_OLD, CC_OLD, REP_OLD); }
@@ -51,17 +51,17 @@ static void old_scatter() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_scat
 static void old_pipeline() { for (int r = 0; r < 4; ++r) { old_classify(); old_hist(); old_scan(); old_scatter(); } }
 
 static void new_classify() { xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, nullptr); }
-static void new_classify_counts() { auto cp = cplan(XM_CLASSIFY_BLOCK * 4); xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, &cp); }
-static void new_hist() { auto cp = cplan(XM_GRAN_K2); xm::launch_hist(0, MODE, N, CODE, cp); }
-static void new_scan() { auto cp = cplan(2048); xm::launch_scan(0, cp, GO, REP + 64 * 64, COUNTS); }
-static void new_scatter() { auto cp = cplan(2048); xm::launch_scatter(0, cp.plan, MODE, N, CODE, GO, REP + 64 * 64, BINOFF, IDX); }
+static void new_classify_counts() { auto cp = cplan(); xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, &cp); }
+static void new_hist() { auto cp = cplan(); xm::launch_hist(0, MODE, N, CODE, cp); }
+static void new_scan() { auto cp = cplan(); xm::launch_scan(0, cp, GO, REP + 64 * 64, COUNTS); }
+static void new_scatter() { auto cp = cplan(); xm::launch_scatter(0, cp.plan, MODE, N, CODE, GO, REP + 64 * 64, BINOFF, IDX); }
 static void new_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); new_scatter(); } }
 static void new_unfused() { for (int r = 0; r < 4; ++r) { new_classify(); new_hist(); new_scan(); new_scatter(); } }
 // two independent batches in flight on two streams (consecutive windows of a file): K2 of one under K1 of the other
 struct Lane2 { hipStream_t st; uint8_t *code; uint32_t *gc, *go, *idx, *part; uint64_t *rep, *binoff, *counts; };
 static Lane2 L2[2];
 static void fused_on(const Lane2 &l) {
-    xm::CountPlan cp; cp.plan = xm::plan_granules(N, XM_CLASSIFY_BLOCK * 4); cp.gran_counts = l.gc; cp.counts_rep = l.rep; cp.part_tot = l.part;
+    xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = l.gc; cp.counts_rep = l.rep; cp.part_tot = l.part;
     xm::launch_classify_i32(l.st, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, l.code, &cp);
     xm::launch_scan(l.st, cp, l.go, l.rep + 64 * 64, l.counts);
     xm::launch_scatter(l.st, cp.plan, MODE, N, l.code, l.go, l.rep + 64 * 64, l.binoff, l.idx);
@@ -182,13 +182,13 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
 }  // namespace abl
 
 static uint32_t *IDX_SCRATCH;
-template <int ABL> static void ablp_scatter() { auto cp = cplan(2048); const uint32_t grid = (cp.plan.n_gran + 3) / 4;
+template <int ABL> static void ablp_scatter() { auto cp = cplan(); const uint32_t grid = (cp.plan.n_gran + 3) / 4;
     abl::scatter_kernel<8, ABL, 1><<<grid, XM_BLOCK>>>(CODE, N, MODE, cp.plan.n_gran, cp.plan.gran_stride, GO, (const unsigned long long *)(REP + 64 * 64), (unsigned long long *)BINOFF, IDX); }
 template <int ABL> static void ablp_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); ablp_scatter<ABL>(); } }
-template <int GPW> static void gpw_scatter() { auto cp = cplan(2048); const uint32_t grid = (cp.plan.n_gran + 4 * GPW - 1) / (4 * GPW);
+template <int GPW> static void gpw_scatter() { auto cp = cplan(); const uint32_t grid = (cp.plan.n_gran + 4 * GPW - 1) / (4 * GPW);
     abl::scatter_kernel<8, 0, GPW><<<grid, XM_BLOCK>>>(CODE, N, MODE, cp.plan.n_gran, cp.plan.gran_stride, GO, (const unsigned long long *)(REP + 64 * 64), (unsigned long long *)BINOFF, IDX); }
 template <int GPW> static void gpw_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); gpw_scatter<GPW>(); } }
-template <int ABL> static void abl_scatter() { auto cp = cplan(2048); const uint32_t grid = ABL == 8 ? ((cp.plan.n_gran + 3) / 4 + 7) / 8 * 8 : (cp.plan.n_gran + 3) / 4;
+template <int ABL> static void abl_scatter() { auto cp = cplan(); const uint32_t grid = ABL == 8 ? ((cp.plan.n_gran + 3) / 4 + 7) / 8 * 8 : (cp.plan.n_gran + 3) / 4;
     abl::scatter_kernel<8, ABL><<<grid, XM_BLOCK>>>(CODE, N, MODE, cp.plan.n_gran, cp.plan.gran_stride, GO, (const unsigned long long *)(REP + 64 * 64), (unsigned long long *)BINOFF, IDX_SCRATCH); }
 // plain streaming stores with the scatter's output footprint (4 B per unit), and reads with its input footprint
 __global__ void __launch_bounds__(256) stream_write(uint32_t *out, uint64_t n) { const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; if (i < n) out[i] = (uint32_t)i; }

@@ -204,7 +204,7 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     ctx->comm_ranks = 0;
     ctx->timing_mask = ~0u;
     for (int k = 0; k < XM_K_COUNT; ++k) { ctx->acc_ms[k] = 0.0; ctx->acc_launches[k] = 0; }
-    // [8 bins][granule pitch] for the largest input at the smallest granule: 2 x 134 MB of the 288 GB
+    // [8 bins][granule pitch] for the largest input: 2 x 67 MB of the 288 GB
     const size_t ws = ((size_t)XM_MAX_GRANULES + 64) * 8 * sizeof(uint32_t);
     hipError_t e = hipMalloc((void **)&ctx->d_gran_counts, ws);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_gran_off, ws);
@@ -302,7 +302,7 @@ int xm_classify_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_cigar(st, mode, n, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
-                                  code_out, range_flag, nullptr);
+                                  code_out, range_flag);
     }
     return check_launch(ctx, "classify_cigar_kernel");
 }
@@ -344,10 +344,10 @@ static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const
     return check_launch(ctx, "scatter_kernel");
 }
 
-static xm::CountPlan count_plan(xm_ctx *ctx, uint64_t n, uint32_t gran_records)
+static xm::CountPlan count_plan(xm_ctx *ctx, uint64_t n)
 {
     xm::CountPlan cp;
-    cp.plan = xm::plan_granules(n, gran_records);
+    cp.plan = xm::plan_granules(n);
     cp.gran_counts = ctx->d_gran_counts;
     cp.counts_rep = ctx->d_counts_rep;
     cp.part_tot = ctx->d_part_tot;
@@ -370,7 +370,7 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_
     if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
     // d_counts_rep is all zero here: zeroed at context creation and by every K2b after it has summed it
     if (!code || !idx_out || ((uintptr_t)code & 15u)) return XM_ERR_INVALID_ARG;
-    const xm::CountPlan cp = count_plan(ctx, n, XM_GRAN_K2);
+    const xm::CountPlan cp = count_plan(ctx, n);
     int rc;
     {
         Span span(ctx, st, XM_K_HIST);
@@ -394,7 +394,7 @@ int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out || !idx_out) return XM_ERR_INVALID_ARG;
     if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2 | (uintptr_t)code_out) & 15u))
         return XM_ERR_INVALID_ARG;
-    const xm::CountPlan cp = count_plan(ctx, n, XM_CLASSIFY_BLOCK * 4);
+    const xm::CountPlan cp = count_plan(ctx, n);
     int rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
@@ -416,7 +416,7 @@ int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out || !idx_out) return XM_ERR_INVALID_ARG;
     if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || ((uintptr_t)code_out & 15u))
         return XM_ERR_INVALID_ARG;
-    const xm::CountPlan cp = count_plan(ctx, n, XM_CLASSIFY_BLOCK * 4);
+    const xm::CountPlan cp = count_plan(ctx, n);
     int rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
@@ -441,15 +441,16 @@ int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t 
     if ((((uintptr_t)nm1 | (uintptr_t)off1 | (uintptr_t)xs1 | (uintptr_t)nm2 | (uintptr_t)off2 | (uintptr_t)xs2 |
           (uintptr_t)code_out) & 15u))
         return XM_ERR_INVALID_ARG;
-    const xm::CountPlan cp = count_plan(ctx, n, XM_CIGAR_BLOCK * 4);
+    // the CIGAR kernel does not count (it measured slower with the counting epilogue than with a separate histogram
+    // pass): classify, then the stand-alone compaction on the category bytes it wrote
     int rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_cigar(st, mode, n, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
-                                  code_out, range_flag, &cp);
+                                  code_out, range_flag);
     }
-    if ((rc = check_launch(ctx, "classify_cigar_kernel<counts>")) != XM_OK) return rc;
-    return compact_tail(ctx, st, mode, n, code_out, cp, idx_out, bin_offsets, counts);
+    if ((rc = check_launch(ctx, "classify_cigar_kernel")) != XM_OK) return rc;
+    return xm_compact_dev(ctx, stream, mode, n, code_out, idx_out, bin_offsets, counts);
 }
 
 int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,
@@ -504,7 +505,7 @@ static int classify_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const v
     uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
     uint64_t *d_counts = (uint64_t *)ctx->d_scratch[7] + 8;
     // category_counts come from the counting form of the kernel (+ K2b, which adds the replicas up)
-    const xm::CountPlan cp = count_plan(ctx, n, XM_CLASSIFY_BLOCK * 4);
+    const xm::CountPlan cp = count_plan(ctx, n);
     {
         Span span(ctx, nullptr, XM_K_CLASSIFY);
         if (elem == 4)
@@ -611,20 +612,22 @@ static int classify_cigar_host(xm_ctx *ctx, int mode, uint64_t n,
     XM_HIP(ctx, hipMemset(d_flag, 0, 16));
     uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
     uint64_t *d_off = (uint64_t *)ctx->d_scratch[7];
-    const xm::CountPlan cp = count_plan(ctx, n, XM_CIGAR_BLOCK * 4);
-    const bool counting = compact || counts != nullptr;
     {
         Span span(ctx, nullptr, XM_K_CLASSIFY);
         xm::launch_classify_cigar(nullptr, mode, n, (const int32_t *)d_nm1, (const uint32_t *)d_off1, (const uint32_t *)d_ops1,
                                   (const int32_t *)d_xs1, (const int32_t *)d_nm2, (const uint32_t *)d_off2,
                                   (const uint32_t *)d_ops2, (const int32_t *)d_xs2, (const uint64_t *)d_bits,
-                                  min_score_floor, d_code, (uint32_t *)d_flag, counting ? &cp : nullptr);
+                                  min_score_floor, d_code, (uint32_t *)d_flag);
     }
     if ((rc = check_launch(ctx, "classify_cigar_kernel")) != XM_OK) return rc;
-    if (compact)
-        rc = compact_tail(ctx, nullptr, mode, n, d_code, cp, (uint32_t *)ctx->d_scratch[6], d_off, d_off + 8);
-    else if (counting)
-        rc = counts_only_tail(ctx, cp, d_off + 8);
+    // the CIGAR kernel does not count: the histogram pass over its category bytes does
+    if (compact) {
+        rc = xm_compact_dev(ctx, nullptr, mode, n, d_code, (uint32_t *)ctx->d_scratch[6], d_off, d_off + 8);
+    } else if (counts) {
+        const xm::CountPlan cp = count_plan(ctx, n);
+        xm::launch_hist(nullptr, mode, n, d_code, cp);
+        if ((rc = check_launch(ctx, "hist_kernel")) == XM_OK) rc = counts_only_tail(ctx, cp, d_off + 8);
+    }
     if (rc != XM_OK) return rc;
     uint32_t flag = 0;
     XM_HIP(ctx, hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));

@@ -6,11 +6,10 @@
 #include "../../include/xenomapper_hip.h"
 
 #define XM_BLOCK 256          // threads per K2 workgroup (4 wavefronts = 4 granules)
-#define XM_GRAN_K2 2048       // K2: records per granule when the category bytes come from memory (stand-alone compact)
-#define XM_GRAN_MIN 1024      // smallest granule any path uses (classify_cigar workgroup); sizes the K2 workspace
-#define XM_MAX_GRANULES ((uint32_t)((0xFFFFF000ull + XM_GRAN_MIN - 1) / XM_GRAN_MIN))
+#define XM_GRAN 2048          // records per granule: what one counting group (a counting K1 workgroup, a K2a wave) and one K2c wave own
+#define XM_MAX_GRANULES ((uint32_t)((0xFFFFF000ull + XM_GRAN - 1) / XM_GRAN))
 #define XM_PART_GRAN 1024u     // K2b: granules per part (first scan level; one K2b workgroup scans one part of one bin)
-#define XM_PART_STRIDE 4160u   // row pitch of part_tot: >= XM_MAX_GRANULES / XM_PART_GRAN (4096) + slack
+#define XM_PART_STRIDE 2112u   // row pitch of part_tot: >= XM_MAX_GRANULES / XM_PART_GRAN (2048) + slack
 #define XM_COUNT_REPLICAS 64u // category_counts is added into one of 64 copies; K2b sums them
 #define XM_CLASSIFY_BLOCK 512  // classify workgroup (tuned on the box with tools/tune_kernels.hip)
 #ifndef XM_CIGAR_BLOCK
@@ -21,8 +20,7 @@
 namespace xm {
 
 struct GranPlan {
-    uint32_t gran_records;      // records per granule
-    uint32_t n_gran;
+    uint32_t n_gran;            // granules of XM_GRAN records
     uint32_t gran_stride;       // row pitch of gran_counts / gran_off ([bin][granule] layout)
 };
 
@@ -34,9 +32,9 @@ struct CountPlan {
     uint64_t *counts_rep;       // [XM_COUNT_REPLICAS][64], all zero between calls
 };
 
-GranPlan plan_granules(uint64_t n, uint32_t gran_records);
+GranPlan plan_granules(uint64_t n);
 
-// cp != nullptr: the fused form, the kernel also counts (granule = its workgroup: *_BLOCK * 4 records)
+// cp != nullptr: the fused form, the kernel also counts (granule = its workgroup)
 void launch_classify_i32(hipStream_t st, int mode, uint64_t n,
                          const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
                          const uint64_t *unit_bits, int32_t m, uint8_t *code, const CountPlan *cp);
@@ -46,7 +44,7 @@ void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
 void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
                            const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
                            const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
-                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag, const CountPlan *cp);
+                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag);
 void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, const CountPlan &cp);
 void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64_t *bin_totals, uint64_t *counts);
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code,

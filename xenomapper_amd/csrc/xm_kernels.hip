@@ -116,8 +116,8 @@ __device__ __forceinline__ void lds_settle()
 // Counting (category_counts + the per-granule bin counts the stable split needs), shared by K1 (fused: the
 // category bytes are still in registers) and K2a (stand-alone compaction of category bytes from memory).
 //
-// A *granule* is the stretch of records one counting group owns: a K1 workgroup (BLOCK*4 records) or a K2a
-// wave (XM_GRAN_K2 records).  Per granule: bin counts -> gran_counts[bin][granule]; the 64 category slots ->
+// A *granule* is the stretch of XM_GRAN = 2048 records one counting group owns: a counting K1 workgroup or a K2a
+// wave.  Per granule: bin counts -> gran_counts[bin][granule]; the 64 category slots ->
 // one of XM_COUNT_REPLICAS global copies of counts[64] (K2b adds the copies up).
 //
 // LDS layout of one counting group: hist[64 slots][XM_HREP replicas] (replica = lane & 7: a wave instruction's
@@ -281,8 +281,7 @@ classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
 // ---------------------------------------------------------------------------------------------
 // K2 geometry.  Counting and splitting work granule by granule; a wave owns one granule and nothing is shared between
 // waves, so K2a and K2c have no workgroup barrier.  Lane order == record order everywhere, which is what makes the
-// split stable.  Stand-alone compaction uses XM_GRAN_K2-record granules; after a fused K1 the granule is K1's
-// workgroup (2048 records for classify_kernel, 1024 for classify_cigar_kernel).
+// split stable.  A granule is XM_GRAN = 2048 records: a wave of K2a / K2c, a workgroup of the counting K1.
 // ---------------------------------------------------------------------------------------------
 
 // 16 category bytes of one lane; past the end of the input: XM_NO_UNIT
@@ -323,7 +322,7 @@ __device__ __attribute__((noinline)) uint32_t load_codes4_tail(const uint8_t *__
 
 // ---------------------------------------------------------------------------------------------
 // K2a: histogram of category bytes in memory (stand-alone xm_compact*; the fused path counts in K1).  One wave =
-// one granule of XM_GRAN_K2 records (32 bytes per lane), wave-private LDS histogram.  A byte position at which no
+// one granule of XM_GRAN records (32 bytes per lane), wave-private LDS histogram.  A byte position at which no
 // lane of the wave holds a unit (every other position of interleaved paired input) is skipped wave-uniformly; units
 // of the wave's presumably dominant category (the first unit of its first lane) are counted in a register and reach
 // LDS with one atomic per lane.
@@ -338,8 +337,8 @@ hist_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t n_gran, Count
     if (g >= n_gran) return;                                              // wave-uniform; no barrier in this kernel
     for (uint32_t k = lane; k < (uint32_t)XM_COUNT_LDS_WORDS; k += 64u) lds[k] = 0;
 
-    constexpr int TILES = XM_GRAN_K2 / 1024;
-    const uint64_t rec0 = (uint64_t)g * XM_GRAN_K2;
+    constexpr int TILES = XM_GRAN / 1024;
+    const uint64_t rec0 = (uint64_t)g * XM_GRAN;
     uint32_t w[TILES][4];
 #pragma unroll
     for (int k = 0; k < TILES; ++k) load_codes16(code, rec0 + (uint64_t)k * 1024u + lane * 16u, n, w[k]);
@@ -773,15 +772,14 @@ __device__ __forceinline__ bool cigar_scores_by_prefix(const uint32_t *__restric
     return true;
 }
 
-template <bool PAIRED, int BLOCK, bool FULL, bool COUNTS>
+template <bool PAIRED, int BLOCK, bool FULL>
 __device__ __forceinline__ void classify_cigar_body(
     const int32_t *__restrict__ nm1, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ ops1,
     const int32_t *__restrict__ xs1,
     const int32_t *__restrict__ nm2, const uint32_t *__restrict__ off2, const uint32_t *__restrict__ ops2,
     const int32_t *__restrict__ xs2,
     const uint8_t *__restrict__ unit_bits8, int32_t m, uint8_t *__restrict__ code, uint64_t n,
-    uint32_t *__restrict__ range_flag, uint32_t *last_state, uint32_t *cig_T, uint32_t *count_lds,
-    const CountSink &sink)
+    uint32_t *__restrict__ range_flag, uint32_t *last_state, uint32_t *cig_T)
 {
     const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t r0 = g * 4;
@@ -827,29 +825,30 @@ __device__ __forceinline__ void classify_cigar_body(
             mb &= ~1u;
         }
     }
-    classify_finish<int32_t, PAIRED, BLOCK, FULL, COUNTS>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, count_lds, sink);
+    // no fused counting here: this kernel runs at the rate its eleven concurrent streams get out of HBM, and the counting
+    // epilogue cost it 36-45 us per 50 M pairs -- more than the separate histogram pass (30 us) it would save
+    const CountSink none = {nullptr, nullptr, 0u, 0};
+    classify_finish<int32_t, PAIRED, BLOCK, FULL, false>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, nullptr, none);
 }
 
-template <bool PAIRED, int BLOCK, bool COUNTS>
+template <bool PAIRED, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ ops1,
                       const int32_t *__restrict__ xs1,
                       const int32_t *__restrict__ nm2, const uint32_t *__restrict__ off2, const uint32_t *__restrict__ ops2,
                       const int32_t *__restrict__ xs2,
                       const uint8_t *__restrict__ unit_bits8, int32_t m, uint8_t *__restrict__ code, uint64_t n,
-                      uint32_t *__restrict__ range_flag, CountSink sink)
+                      uint32_t *__restrict__ range_flag)
 {
     __shared__ uint32_t last_state[BLOCK / 64];
     __shared__ __attribute__((aligned(16))) uint32_t cig_table[BLOCK / 64][XM_CIG_WAVE_OPS + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t count_lds[COUNTS ? XM_COUNT_LDS_WORDS : 4];
-    if (COUNTS) count_lds_clear<BLOCK>(count_lds);
     uint32_t *cig_T = cig_table[threadIdx.x >> 6];
     if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
-        classify_cigar_body<PAIRED, BLOCK, true, COUNTS>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
-                                                         range_flag, last_state, cig_T, count_lds, sink);
+        classify_cigar_body<PAIRED, BLOCK, true>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
+                                                 range_flag, last_state, cig_T);
     else
-        classify_cigar_body<PAIRED, BLOCK, false, COUNTS>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
-                                                          range_flag, last_state, cig_T, count_lds, sink);
+        classify_cigar_body<PAIRED, BLOCK, false>(nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits8, m, code, n,
+                                                  range_flag, last_state, cig_T);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -901,12 +900,13 @@ mate_correlate_kernel(const double *__restrict__ track, uint64_t n, const double
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-GranPlan plan_granules(uint64_t n, uint32_t gran_records)
+static_assert(XM_CLASSIFY_BLOCK * 4 == XM_GRAN, "the counting classify workgroup is one granule");
+
+GranPlan plan_granules(uint64_t n)
 {
     GranPlan p;
-    uint64_t g = (n + gran_records - 1) / gran_records;
+    uint64_t g = (n + XM_GRAN - 1) / XM_GRAN;
     if (g == 0) g = 1;
-    p.gran_records = gran_records;
     p.n_gran = (uint32_t)g;
     p.gran_stride = (p.n_gran + 63u) & ~63u;
     return p;
@@ -955,18 +955,17 @@ void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
 void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
                            const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
                            const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
-                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag, const CountPlan *cp)
+                           const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag)
 {
     const uint64_t per_block = (uint64_t)XM_CIGAR_BLOCK * 4;
     const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
-    const CountSink sink = make_sink(cp, mode);
-    const bool paired = mode != XM_MODE_SE;
-#define XM_LAUNCH_CIG(P, C) classify_cigar_kernel<P, XM_CIGAR_BLOCK, C><<<grid, XM_CIGAR_BLOCK, 0, st>>>( \
-        nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag, sink)
-    if (cp) { if (paired) XM_LAUNCH_CIG(true, true); else XM_LAUNCH_CIG(false, true); }
-    else    { if (paired) XM_LAUNCH_CIG(true, false); else XM_LAUNCH_CIG(false, false); }
-#undef XM_LAUNCH_CIG
+    if (mode == XM_MODE_SE)
+        classify_cigar_kernel<false, XM_CIGAR_BLOCK><<<grid, XM_CIGAR_BLOCK, 0, st>>>(
+            nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
+    else
+        classify_cigar_kernel<true, XM_CIGAR_BLOCK><<<grid, XM_CIGAR_BLOCK, 0, st>>>(
+            nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
 }
 
 void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, const CountPlan &cp)
@@ -994,8 +993,7 @@ void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, con
     const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
 #define XM_LAUNCH_SCT(NSUB, W) scatter_kernel<NSUB, W><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_off, bt, bo, idx_out)
-    if (p.gran_records == 1024u) { if (wide) XM_LAUNCH_SCT(4, true); else XM_LAUNCH_SCT(4, false); }
-    else                         { if (wide) XM_LAUNCH_SCT(8, true); else XM_LAUNCH_SCT(8, false); }
+    if (wide) XM_LAUNCH_SCT(XM_GRAN / 256, true); else XM_LAUNCH_SCT(XM_GRAN / 256, false);
 #undef XM_LAUNCH_SCT
 }
 

@@ -55,9 +55,11 @@ def to_global_index(local_idx, start, halo):
 
 def allreduce_counts(counts):
     """Sum category_counts over all ranks, in place.  `counts`: a torch int64 tensor of 64 elements
-    (device tensor under nccl/RCCL, CPU tensor under gloo).  No-op without an initialised process group."""
+    (device tensor under nccl/RCCL, CPU tensor under gloo).  No-op without an initialised process group.
+    The same reduction without torch.distributed: Context.comm_init + Context.allreduce_counts (xm_allreduce_counts,
+    RCCL inside the library)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
 
@@ -75,9 +77,8 @@ def gather_bin_lists(local_lists, dst=0):
 
 
 def classify_block(ctx, mode, columns, unit_bits, n_records, start, end, min_score_floor):
-    """Run K1 + K2 on one block through the C ABI.  Returns (global bin lists [6 (+1 error slot)], counts u64[64])."""
+    """Run the fused pass (K1 + K2) on one block through the C ABI.  Returns (global bin lists [6 (+1 error slot)], counts u64[64])."""
     local, bits, halo = take_block(columns, unit_bits, n_records, start, end)
-    code, _ = ctx.classify(mode, *local, bits, min_score_floor)
-    idx, off, counts = ctx.compact(mode, code)
+    _, idx, off, counts = ctx.classify_compact(mode, *local, bits, min_score_floor, want_code=False)
     lists = [to_global_index(idx[int(off[b]):int(off[b + 1])], start, halo) for b in range(7)]
     return lists, counts

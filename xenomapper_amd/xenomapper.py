@@ -27,6 +27,7 @@ import io
 import math
 import os
 import re
+import stat
 import sys
 import textwrap
 import time
@@ -85,10 +86,21 @@ def get_sam_header(samfile):
 
 
 def _bam_reader(bamfile):
-    """Native BGZF/BAM decoder over a binary file object (no samtools needed)."""
+    """Native BGZF/BAM decoder over a binary file object (no samtools needed).  A regular file is memory-mapped
+    (nothing is read up front, nothing stays resident); anything else (a pipe, BytesIO) is read whole."""
     from . import _host
-    data = np.frombuffer(bamfile.read(), dtype=np.uint8)
-    bamfile.seek(0)
+    data = None
+    try:
+        fd = bamfile.fileno()
+        st = os.fstat(fd)
+        if stat.S_ISREG(st.st_mode) and st.st_size > 0:
+            data = np.memmap(bamfile.name if isinstance(getattr(bamfile, "name", None), (str, bytes)) else fd,
+                             dtype=np.uint8, mode="r", shape=(st.st_size,))
+    except (AttributeError, OSError, ValueError, io.UnsupportedOperation):
+        data = None
+    if data is None:
+        data = np.frombuffer(bamfile.read(), dtype=np.uint8)
+        bamfile.seek(0)
     return _host.BamReader(data)
 
 
@@ -108,6 +120,11 @@ def bam_lines(f):
         buf = np.empty(8 << 20, dtype=np.uint8)
         while not reader.eof:
             n = reader.read_into(buf, 0)
+            if n == 0 and not reader.eof:                         # the next line alone is longer than the buffer
+                if buf.shape[0] >= BAM_LINE_LIMIT:
+                    raise ValueError("a BAM record prints as a SAM line longer than %d bytes" % BAM_LINE_LIMIT)
+                buf = np.empty(2 * buf.shape[0], dtype=np.uint8)
+                continue
             for line in bytes(buf[:n]).decode("ascii").splitlines(True):
                 yield line
     finally:
@@ -430,25 +447,20 @@ def _classify_block(ctx, mode, block, n, vals, nm, ops, cigar_mode, min_score):
         xs = [_to_int_column(vals[c][:n]) for c in (1, 3)]
         if integral and xs[0] is not None and xs[1] is not None:
             # AS is synthesised inside the classify kernel (fused K3 + K1)
-            code, counts = ctx.classify_cigar(mode, csr[0][0], csr[0][1], csr[0][2], xs[0],
+            return ctx.classify_compact_cigar(mode, csr[0][0], csr[0][1], csr[0][2], xs[0],
                                               csr[1][0], csr[1][1], csr[1][2], xs[1], bits, _floor_min_score(min_score))
-        else:
-            # a non-integral XS or a NaN threshold: CIGAR kernel, then the binary64 classify kernel
-            fcols = []
-            for f in (0, 1):
-                a = ctx.cigar_scores(*csr[f])
-                fcols.append(np.where(a == _ABSENT, _NEG_INF, a.astype(np.float64)))
-                fcols.append(np.asarray(vals[2 * f + 1][:n], dtype=np.float64))
-            code, counts = ctx.classify_f64(mode, *fcols, bits, float(min_score))
-    else:
-        int_cols = [_to_int_column(vals[c][:n]) for c in range(4)]
-        if integral and all(col is not None for col in int_cols):
-            code, counts = ctx.classify(mode, *int_cols, bits, _floor_min_score(min_score))
-        else:
-            fcols = [np.asarray(vals[c][:n], dtype=np.float64) for c in range(4)]
-            code, counts = ctx.classify_f64(mode, *fcols, bits, float(min_score))
-    idx, off, _ = ctx.compact(mode, code)
-    return code, idx, off, counts
+        # a non-integral XS or a NaN threshold: CIGAR kernel, then the binary64 classify kernel
+        fcols = []
+        for f in (0, 1):
+            a = ctx.cigar_scores(*csr[f])
+            fcols.append(np.where(a == _ABSENT, _NEG_INF, a.astype(np.float64)))
+            fcols.append(np.asarray(vals[2 * f + 1][:n], dtype=np.float64))
+        return ctx.classify_compact(mode, *fcols, bits, float(min_score))
+    int_cols = [_to_int_column(vals[c][:n]) for c in range(4)]
+    if integral and all(col is not None for col in int_cols):
+        return ctx.classify_compact(mode, *int_cols, bits, _floor_min_score(min_score))
+    fcols = [np.asarray(vals[c][:n], dtype=np.float64) for c in range(4)]
+    return ctx.classify_compact(mode, *fcols, bits, float(min_score))
 
 
 def _lines_of(block, mode, b, i):
@@ -592,6 +604,7 @@ def _run(mode, readpairs, sinks, min_score, tag_func):
 # --------------------------------------------------------------------------------------------
 # file-to-file fast path: C++ column stripper -> GPU -> C++ line writer
 # --------------------------------------------------------------------------------------------
+BAM_LINE_LIMIT = 1 << 32            # bam_lines gives up on a single SAM line longer than this (the stripper's own limit)
 FILE_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_WINDOW_MB", "128")) << 20     # bytes of each file parsed per block
 FILE_MAX_RECORDS = 1 << 22
 
@@ -846,15 +859,17 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         if err is not None:
             n, pending = bad, err                                # units closing at index >= bad are not reached
         if n:
-            with prof("classify"):
-                code, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
-            with prof("compact"):
-                idx, off, _ = ctx.compact(mode, code)
+            with prof("classify"):          # one fused pass: category bytes, counts and the six bin lists
+                code, idx, off, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
             limit, state_error = None, None
-            if int(off[7]) != int(off[6]):
+            if int(off[7]) != int(off[6]):                       # a unit fell through every branch (ref :289)
                 limit = int(idx[int(off[6]):int(off[7])].min())
-                state_error = RuntimeError("Error in processing logic with values {0} ".format(
-                    tuple(int(block.cols[c][limit]) for c in range(4))))
+                j = limit - 1 if (paired and (int(code[limit]) >> 3) > 5) else limit    # the mate that fell through, as _run()
+                shown = []
+                for f in (0, 1):                                 # the values the reference would print: the plugin's own
+                    fields = _fields_of(raws[f], block, f, j, pos[f])
+                    shown += [tag_func(fields, tag="AS"), tag_func(fields, tag="XS")]
+                state_error = RuntimeError("Error in processing logic with values {0} ".format(tuple(shown)))
             for b in (range(6) if distinct else ()):
                 if sinks[b]:
                     seg = idx[int(off[b]):int(off[b + 1])]
@@ -944,7 +959,8 @@ def _emit_shared(parser, paired, code, idx, off, sinks, limit):
 
 
 def _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score):
-    """Category bytes + counts of the first n records of a parsed block (patched values merged in)."""
+    """One fused pass over the first n records of a parsed block (patched values merged in):
+    -> (code u8[n], idx u32[units], bin_offsets u64[8], counts u64[64])."""
     bits = block.unit_bits
     if n < block.n:                                                # truncated at an input error
         flags = np.unpackbits(bits.view(np.uint8), bitorder="little")[:n]
@@ -975,8 +991,8 @@ def _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score):
     integral = (min_score == min_score) and not fvals
     if cigar_mode:
         if integral:
-            return ctx.classify_cigar(mode, csr[0][0], csr[0][1], csr[0][2], cols[1],
-                                      csr[1][0], csr[1][1], csr[1][2], cols[3], bits, _floor_min_score(min_score))
+            return ctx.classify_compact_cigar(mode, csr[0][0], csr[0][1], csr[0][2], cols[1],
+                                              csr[1][0], csr[1][1], csr[1][2], cols[3], bits, _floor_min_score(min_score))
         fcols = []
         for f in (0, 1):
             a = ctx.cigar_scores(csr[f][0], csr[f][1], csr[f][2])
@@ -984,11 +1000,11 @@ def _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score):
             fcols.append(np.where(cols[2 * f + 1] == _ABSENT, _NEG_INF, cols[2 * f + 1].astype(np.float64)))
     else:
         if integral:
-            return ctx.classify(mode, *cols, bits, _floor_min_score(min_score))
+            return ctx.classify_compact(mode, *cols, bits, _floor_min_score(min_score))
         fcols = [np.where(c == _ABSENT, _NEG_INF, c.astype(np.float64)) for c in cols]
     for (k, c), v in fvals.items():
         fcols[c][k] = v
-    return ctx.classify_f64(mode, *fcols, bits, float(min_score))
+    return ctx.classify_compact(mode, *fcols, bits, float(min_score))
 
 
 def _finish_in_python(mode, path1, path2, pos, sinks, min_score, tag_func, skip_repeated, totals, key_order):
