@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive throughput of the host-buffer C ABI: xm_classify + xm_compact on NumPy arrays in host memory
-(H2D of the four score columns and the unit mask, both kernels, D2H of the category bytes, the index lists and the
-counts).  No SAM parsing, no output text -- that is tools/bench_e2e.py.
+"""PCIe-inclusive throughput of the host-buffer C ABI: xm_classify_compact on NumPy arrays in host memory (H2D of the
+four score columns and the unit mask, the fused pass, D2H of the index lists and the counts; --code adds the category
+bytes, --two-calls is round 1's xm_classify + xm_compact).  No SAM parsing, no output text -- that is tools/bench_e2e.py.
 
     python tools/bench_hostabi.py --pairs 25000000
 """
@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=25_000_000)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--two-calls", action="store_true", help="xm_classify + xm_compact instead of the fused xm_classify_compact")
+    ap.add_argument("--code", action="store_true", help="also bring the category bytes back (1 B per record)")
     a = ap.parse_args()
     from xenomapper_amd import _ffi, synth
     n = 2 * a.pairs
@@ -28,12 +30,16 @@ def main():
     best = None
     for _ in range(a.reps):
         t0 = time.perf_counter()
-        code, counts = ctx.classify(_ffi.MODE_PE_LIBERAL, as1, xs1, as2, xs2, bits, _ffi.ABSENT)
-        idx, off, _ = ctx.compact(_ffi.MODE_PE_LIBERAL, code)
+        if a.two_calls:      # round 1's shape: category bytes down and up again between the two calls
+            code, counts = ctx.classify(_ffi.MODE_PE_LIBERAL, as1, xs1, as2, xs2, bits, _ffi.ABSENT)
+            idx, off, _ = ctx.compact(_ffi.MODE_PE_LIBERAL, code)
+        else:
+            code, idx, off, counts = ctx.classify_compact(_ffi.MODE_PE_LIBERAL, as1, xs1, as2, xs2, bits, _ffi.ABSENT,
+                                                          want_code=a.code)
         el = time.perf_counter() - t0
         best = el if best is None else min(best, el)
     units = int(off[7])
-    moved = 16 * n + n // 8 + n + 4 * units
+    moved = 16 * n + n // 8 + 4 * units + (3 * n if a.two_calls else (n if a.code else 0))
     print(json.dumps({"metric": "read-pairs/s through the host-buffer C ABI (H2D + kernels + D2H)", "value": units / best,
                       "pairs": a.pairs, "records": n, "seconds": best, "bytes_over_pcie": moved,
                       "pcie_GBps": moved / best / 1e9}))

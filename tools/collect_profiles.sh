@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON the GPU box (through gpurun): bench lines + rocprofv3 kernel stats + PMC traffic passes for one round tag.
+#   tools/collect_profiles.sh r02a [workload ...]      (default workloads: cfg2 cfg3)
+# Output under gpurun_out/prof_<tag>/; condense afterwards with tools/summarize_prof.py into profiles/.
+# rocprofv3: --pmc runs are separate from the --kernel-trace --stats run, the program itself follows `--`.
+set -u
+TAG=${1:?round tag}
+shift
+WORKLOADS=${*:-cfg2 cfg3}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for W in $WORKLOADS; do
+  ARGS="--workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-verify"
+  echo "== $W: kernel trace"; date
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_$W" -o "$W" --output-format csv -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace_$W.json" 2> "$OUT/trace_$W.err" || { echo "trace $W failed"; tail -5 "$OUT/trace_$W.err"; exit 1; }
+  for C in FETCH_SIZE WRITE_SIZE; do
+    echo "== $W: pmc $C"; date
+    timeout -k 10 300 rocprofv3 --pmc $C -d "$OUT/pmc_${C}_$W" -o "$W" --output-format csv -- python3 "$ROOT/bench.py" $ARGS --steps 5 > /dev/null 2> "$OUT/pmc_${C}_$W.err" || { echo "pmc $C $W failed"; tail -5 "$OUT/pmc_${C}_$W.err"; exit 1; }
+  done
+done
+find "$OUT" -name "*.csv" | head -40
+echo done

@@ -54,6 +54,12 @@ static void new_classify() { xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2,
 static void new_classify_counts() { auto cp = cplan(); xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, &cp); }
 static void new_hist() { auto cp = cplan(); xm::launch_hist(0, MODE, N, CODE, cp); }
 static void new_scan() { auto cp = cplan(); xm::launch_scan(0, cp, GO, REP + 64 * 64, COUNTS); }
+template <bool DIRECT> static void scan_variant() { auto cp = cplan(); const uint32_t n_parts = (cp.plan.n_gran + XM_PART_GRAN - 1) / XM_PART_GRAN;
+    if (!DIRECT) xm::part_sum_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot);
+    xm::scan_kernel<DIRECT><<<dim3(n_parts, 8), XM_SCAN_THREADS>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot, GO,
+        (unsigned long long *)(REP + 64 * 64), (unsigned long long *)REP, (unsigned long long *)COUNTS); }
+static void new_scatter();
+template <bool DIRECT> static void scanv_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); scan_variant<DIRECT>(); new_scatter(); } }
 static void new_scatter() { auto cp = cplan(); xm::launch_scatter(0, cp.plan, MODE, N, CODE, GO, REP + 64 * 64, BINOFF, IDX); }
 static void new_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); new_scatter(); } }
 static void new_unfused() { for (int r = 0; r < 4; ++r) { new_classify(); new_hist(); new_scan(); new_scatter(); } }
@@ -281,7 +287,8 @@ int main(int argc, char **argv)
         {"copy_like NT", run_copy, cls},
         {"r01 classify", old_classify, cls}, {"r01 hist", old_hist, (double)N}, {"r01 scan", old_scan, 0}, {"r01 scatter", old_scatter, 3.0 * N},
         {"r02 classify", new_classify, cls}, {"r02 classify+counts", new_classify_counts, cls}, {"r02 hist", new_hist, (double)N},
-        {"r02 scan", new_scan, 0}, {"r02 scatter", new_scatter, 3.0 * N},
+        {"r02 scan", new_scan, 0}, {"scan 1 launch", scan_variant<true>, 0}, {"scan 2 launches", scan_variant<false>, 0},
+        {"fused x4 scan1", scanv_fused<true>, 4 * step}, {"fused x4 scan2", scanv_fused<false>, 4 * step}, {"r02 scatter", new_scatter, 3.0 * N},
         {"abl scatter product", abl_scatter<0>, 3.0 * N}, {"abl scatter no-store", abl_scatter<1>, 3.0 * N},
         {"abl scatter skip-empty", abl_scatter<6>, 3.0 * N}, {"abl scatter xcd-contig", abl_scatter<8>, 3.0 * N}, {"abl scatter coalesced-st", abl_scatter<3>, 3.0 * N},
         {"abl scatter arith-decode", abl_scatter<4>, 3.0 * N}, {"abl scatter no-guard", abl_scatter<5>, 3.0 * N},

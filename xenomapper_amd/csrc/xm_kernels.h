@@ -10,6 +10,10 @@
 #define XM_MAX_GRANULES ((uint32_t)((0xFFFFF000ull + XM_GRAN - 1) / XM_GRAN))
 #define XM_PART_GRAN 1024u     // K2b: granules per part (first scan level; one K2b workgroup scans one part of one bin)
 #define XM_PART_STRIDE 2112u   // row pitch of part_tot: >= XM_MAX_GRANULES / XM_PART_GRAN (2048) + slack
+#ifndef XM_SCAN_DIRECT_PARTS
+#define XM_SCAN_DIRECT_PARTS 8u   // up to this many parts (16 M records: the file path's blocks) K2b is one launch, carries summed
+                                  // from the granule counts; at 48 parts the two-launch form measured faster (10.8 vs 12.1 us)
+#endif
 #define XM_COUNT_REPLICAS 64u // category_counts is added into one of 64 copies; K2b sums them
 #define XM_CLASSIFY_BLOCK 512  // classify workgroup (tuned on the box with tools/tune_kernels.hip)
 #ifndef XM_CIGAR_BLOCK

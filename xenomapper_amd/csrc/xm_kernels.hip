@@ -367,7 +367,7 @@ hist_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t n_gran, Count
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2b: exclusive scan of the per-granule bin counts, two levels, two small launches.  A part = XM_PART_GRAN = 1024
+// K2b: exclusive scan of the per-granule bin counts, two levels; two small launches (one for small inputs).  A part = XM_PART_GRAN = 1024
 // consecutive granules.  part_sum_kernel: workgroup (part p, bin b) adds up its 1024 granule counts.  scan_kernel:
 // workgroup (p, b) takes its carry from the part totals before p and scans its own 1024 counts once -- nobody passes
 // over all counts, nothing depends on another workgroup of the same launch.  gran_off[b][g] = units of bin b in
@@ -399,6 +399,10 @@ part_sum_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint3
     if (threadIdx.x == 0u) part_tot[b * XM_PART_STRIDE + p] = (uint32_t)total;        // <= 1024 granules x 2048 units
 }
 
+// DIRECT: no part totals -- the workgroup adds up the granule counts in front of its part itself (8 loads in flight per
+// thread).  One launch less; the redundant reads grow with the square of the number of parts, so only for inputs of up
+// to XM_SCAN_DIRECT_PARTS parts (16 M records).
+template <bool DIRECT>
 __global__ void __launch_bounds__(XM_SCAN_THREADS)
 scan_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t gran_stride,
             const uint32_t *__restrict__ part_tot, uint32_t *__restrict__ gran_off,
@@ -421,22 +425,41 @@ scan_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t 
         acc += __shfl_xor(acc, 4, 64);
         if (part == 0) counts[slot] = acc;
     }
-    // carry: units of bin b in the parts before this one
-    const uint32_t *tot_row = part_tot + b * XM_PART_STRIDE;
-    unsigned long long part_sum = 0;
-    for (uint32_t q = t; q < p; q += XM_SCAN_THREADS) part_sum += tot_row[q];
-    const unsigned long long carry = block_sum_1024(part_sum, wsum);
-    if (p + 1u == n_parts && t == 0u) bin_totals[b] = carry + tot_row[p];
-
-    // this part's granules: one per thread
+    const uint32_t *row = gran_counts + (uint64_t)b * gran_stride;
+    // this part's granules: one per thread (loaded first: the carry loop below hides the latency)
     const uint32_t g = p * XM_PART_GRAN + t;
-    const uint32_t x = (g < n_gran) ? gran_counts[(uint64_t)b * gran_stride + g] : 0u;
+    const uint32_t x = (g < n_gran) ? row[g] : 0u;
+    // carry: units of bin b in front of this part
+    unsigned long long part_sum = 0;
+    if (DIRECT) {
+        const uint32_t before = p * XM_PART_GRAN;            // a multiple of 1024: every thread runs the same trip count
+        for (uint32_t k0 = 0; k0 < before; k0 += XM_SCAN_THREADS * 8u) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t k = k0 + (uint32_t)u * XM_SCAN_THREADS + t;
+                v[u] = (k < before) ? row[k] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part_sum += v[u];
+        }
+    } else {
+        const uint32_t *tot_row = part_tot + b * XM_PART_STRIDE;
+        for (uint32_t q = t; q < p; q += XM_SCAN_THREADS) part_sum += tot_row[q];
+    }
+    const unsigned long long carry = block_sum_1024(part_sum, wsum);
+
     const uint32_t incl = wave_scan_incl(x);
     if (lane == 63u) wtot[wave] = incl;
     __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wave; ++w) before += wtot[w];
-    if (g < n_gran) gran_off[(uint64_t)b * gran_stride + g] = (uint32_t)carry + before + incl - x;
+    uint32_t before_wave = 0, part_total = 0;
+    for (uint32_t w = 0; w < XM_SCAN_THREADS / 64; ++w) {
+        const uint32_t v = wtot[w];
+        before_wave += (w < wave) ? v : 0u;
+        part_total += v;
+    }
+    if (g < n_gran) gran_off[(uint64_t)b * gran_stride + g] = (uint32_t)carry + before_wave + incl - x;
+    if (p + 1u == n_parts && t == 0u) bin_totals[b] = carry + part_total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -977,12 +1000,17 @@ void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, cons
 void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64_t *bin_totals, uint64_t *counts)
 {
     const uint32_t n_parts = (cp.plan.n_gran + XM_PART_GRAN - 1) / XM_PART_GRAN;
-    part_sum_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot);
-    scan_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride,
-                                                              cp.part_tot, gran_off,
-                                                              reinterpret_cast<unsigned long long *>(bin_totals),
-                                                              reinterpret_cast<unsigned long long *>(cp.counts_rep),
-                                                              reinterpret_cast<unsigned long long *>(counts));
+    unsigned long long *bt = reinterpret_cast<unsigned long long *>(bin_totals);
+    unsigned long long *rep = reinterpret_cast<unsigned long long *>(cp.counts_rep);
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(counts);
+    if (n_parts <= XM_SCAN_DIRECT_PARTS) {
+        scan_kernel<true><<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride,
+                                                                        cp.part_tot, gran_off, bt, rep, cnt);
+    } else {
+        part_sum_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot);
+        scan_kernel<false><<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride,
+                                                                         cp.part_tot, gran_off, bt, rep, cnt);
+    }
 }
 
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code,
