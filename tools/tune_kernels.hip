@@ -79,6 +79,27 @@ static void new_fused_2stream() {        // 4 steps, alternating lanes; fork fro
     for (int r = 0; r < 4; ++r) fused_on(L2[r & 1]);
     for (int k = 0; k < 2; ++k) { CK(hipEventRecord(EV_JOIN[k], L2[k].st)); CK(hipStreamWaitEvent(0, EV_JOIN[k], 0)); }
 }
+// software pipeline over consecutive batches: all K1s on one stream, K2 of batch s on a second stream under K1 of batch
+// s + 1; batch s + 2 reuses batch s's buffers, so its K1 waits for that K2
+static hipStream_t ST_A, ST_B; static hipEvent_t EV_K1[8], EV_K2[8];
+template <int STEPS> static void new_fused_pipelined() {
+    CK(hipEventRecord(EV_FORK, 0));
+    CK(hipStreamWaitEvent(ST_A, EV_FORK, 0)); CK(hipStreamWaitEvent(ST_B, EV_FORK, 0));
+    for (int s = 0; s < STEPS; ++s) {
+        const Lane2 &l = L2[s & 1];
+        xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = l.gc; cp.counts_rep = l.rep; cp.part_tot = l.part;
+        if (s >= 2) CK(hipStreamWaitEvent(ST_A, EV_K2[s - 2], 0));
+        xm::launch_classify_i32(ST_A, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, l.code, &cp);
+        CK(hipEventRecord(EV_K1[s], ST_A));
+        CK(hipStreamWaitEvent(ST_B, EV_K1[s], 0));
+        xm::launch_scan(ST_B, cp, l.go, l.rep + 64 * 64, l.counts);
+        xm::launch_scatter(ST_B, cp.plan, MODE, N, l.code, l.go, l.rep + 64 * 64, l.binoff, l.idx);
+        CK(hipEventRecord(EV_K2[s], ST_B));
+    }
+    CK(hipEventRecord(EV_JOIN[0], ST_A)); CK(hipEventRecord(EV_JOIN[1], ST_B));
+    CK(hipStreamWaitEvent(0, EV_JOIN[0], 0)); CK(hipStreamWaitEvent(0, EV_JOIN[1], 0));
+}
+template <int STEPS> static void new_fused_serial() { for (int r = 0; r < STEPS; ++r) { new_classify_counts(); new_scan(); new_scatter(); } }
 static void run_copy() { copy_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((const xm::v4i32 *)A1, (const xm::v4i32 *)X1, (const xm::v4i32 *)A2, (const xm::v4i32 *)X2, (uint32_t *)CODE, N / 4); }
 
 
@@ -240,6 +261,8 @@ int main(int argc, char **argv)
     CK(hipMemset(REP, 0, (64 * 64 + 8) * 8)); CK(hipMemset(REP_OLD, 0, (64 * 64 + 8) * 8));
     CK(hipMalloc(&PART, 8 * XM_PART_STRIDE * 4));
     CK(hipEventCreate(&EV_FORK)); CK(hipEventCreate(&EV_JOIN[0])); CK(hipEventCreate(&EV_JOIN[1]));
+    CK(hipStreamCreateWithFlags(&ST_A, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&ST_B, hipStreamNonBlocking));
+    for (int k = 0; k < 8; ++k) { CK(hipEventCreateWithFlags(&EV_K1[k], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&EV_K2[k], hipEventDisableTiming)); }
     for (int k = 0; k < 2; ++k) {
         Lane2 &l = L2[k];
         CK(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
@@ -295,6 +318,8 @@ int main(int argc, char **argv)
         {"stream write 4B/unit", run_stream_write, 2.0 * N}, {"stream write 16B/lane", run_stream_write16, 2.0 * N},
         {"stream write 16B nt", run_stream_write16_nt, 2.0 * N},
         {"r01 pipeline x4", old_pipeline, 4 * step}, {"r02 unfused x4", new_unfused, 4 * step}, {"r02 fused x4", new_fused, 4 * step}, {"r02 fused x4 2-stream", new_fused_2stream, 4 * step},
+        {"fused x4 pipelined", new_fused_pipelined<4>, 4 * step}, {"fused x8 serial", new_fused_serial<8>, 8 * step},
+        {"fused x8 pipelined", new_fused_pipelined<8>, 8 * step},
         {"fused x4 all-bins", ablp_fused<0>, 4 * step}, {"fused x4 skip-empty", ablp_fused<6>, 4 * step},
         {"fused x4 no-guard", ablp_fused<5>, 4 * step}, {"fused x4 nt-store", ablp_fused<7>, 4 * step},
         {"fused x4 arith", ablp_fused<4>, 4 * step}, {"fused x4 no-store", ablp_fused<1>, 4 * step},
