@@ -9,9 +9,9 @@
 One step = one pass of the hot path over one batch of synthetic input that is already resident in HBM, through
 ONE C-ABI call (xm_classify_compact_dev): K1 classify + count (score columns -> category byte per record,
 category_counts, per-granule bin counts), K2b scan, K2c scatter (stable split of the pair indices into the six
-bins); every step adds its category_counts to the job's running total on the device.  On N > 1 GPUs the job ends --
-inside the timed region -- with the one RCCL all-reduce of the final category_counts (the reference also only
-reports them at the end of a run).  Workload = BASELINE.json configs[1]: 50 M paired-end 2x150 bp read pairs with
+bins); every step leaves its category_counts in its own 64-word slot on the device, and the job ends -- inside the timed
+region -- by summing the slots into the job's category_counts and, on N > 1 GPUs, with the one RCCL all-reduce of them
+(the reference also only reports them at the end of a run).  Workload = BASELINE.json configs[1]: 50 M paired-end 2x150 bp read pairs with
 AS/XS scores per GPU (weak scaling: every rank holds its own 50 M-pair read block).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (classify): algorithmic bytes (33 B per pair:
@@ -263,13 +263,18 @@ def main():
     code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     off = torch.zeros(8, dtype=torch.int64, device=dev)
-    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    n_slots = max(args.steps, args.warmup, 1)
+    step_counts = torch.zeros((n_slots, 64), dtype=torch.int64, device=dev)       # category_counts of every step of the job
+    counts = step_counts[0]
     job_counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    step_no = [0]
     floor_min = float("-inf") if args.workload == "f64" else _ffi.ABSENT          # min_score = -inf
 
     unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"          # A/B only: two C-ABI calls (classify, then compact with its own histogram)
 
     def step_unfused():
+        counts = step_counts[step_no[0] % n_slots]
+        step_no[0] += 1
         if cig is not None:
             ctx.classify_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
                                    cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"], cols["unit_bits"],
@@ -277,11 +282,12 @@ def main():
         else:
             ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min, code)
         ctx.compact_dev(mode, code[:n], idx, off, counts)
-        job_counts.add_(counts)
 
     def step():
         if unfused:
             return step_unfused()
+        counts = step_counts[step_no[0] % n_slots]
+        step_no[0] += 1
         if cig is not None:
             ctx.classify_compact_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
                                            cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"],
@@ -289,9 +295,9 @@ def main():
         else:
             ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"],
                                      floor_min, code, idx, off, counts)
-        job_counts.add_(counts)                                  # category_counts of the job so far
 
-    def finish():
+    def finish(n_steps):
+        torch.sum(step_counts[:n_steps], dim=0, out=job_counts)  # category_counts of the job: the sum over its steps
         allreduce(job_counts, dist.ReduceOp.SUM)                 # RCCL over xGMI: 64 x int64, once per job
 
     def fence():
@@ -302,9 +308,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    finish()                                                      # warms the RCCL communicator up as well
+    with stdout_to_stderr():
+        finish(max(args.warmup, 1))                               # warms the RCCL communicator up as well
     fence()
+    step_counts.zero_()
     job_counts.zero_()
+    step_no[0] = 0
     fence()
     ctx.timing_select(["classify"])          # the timed region brackets only the kernel the roofline is about
     ctx.timing_enable(True)
@@ -312,7 +321,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    finish()
+    finish(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     timing = ctx.timing_read()
@@ -329,24 +338,6 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     elapsed = float(allreduce(t, dist.ReduceOp.MAX).item()) if world > 1 else elapsed
-
-    # the same reduction through the library's own RCCL communicator (xm_allreduce_counts, the C ABI's collective);
-    # outside the timed region, never fatal: the job total above came from torch.distributed
-    lib_allreduce = None
-    if not rehearsal:
-        try:
-            with stdout_to_stderr():
-                uid = [_ffi.comm_unique_id() if rank == 0 else None]
-                if world > 1:
-                    dist.broadcast_object_list(uid, src=0)
-                ctx.comm_init(world, rank, uid[0])
-                mine = counts * args.steps                       # every step saw the same block: this rank's job total
-                ctx.allreduce_counts(mine)
-                torch.cuda.synchronize()
-                lib_allreduce = {"ranks": ctx.comm_size(), "matches_torch_distributed": bool(torch.equal(mine, job_final))}
-                ctx.comm_destroy()
-        except Exception as e:                                   # noqa: BLE001 -- reported, not raised
-            lib_allreduce = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # parity of what was just timed (rank-local): against the C oracle on the same columns
     verified = None
@@ -426,7 +417,7 @@ def main():
                               "frac_by_ms_per_step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region (scan = its two launches)",
             "verified_vs_oracle": verified,
-            "xm_allreduce_counts": lib_allreduce,
+            "xm_allreduce_counts": None,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_python()
@@ -449,6 +440,48 @@ def main():
             except Exception as e:                               # noqa: BLE001
                 e2e["sam_text"] = {"error": "%s: %s" % (type(e).__name__, e)}
             line["e2e"] = e2e
+    # The same reduction through the library's own RCCL communicator (xm_allreduce_counts, the C ABI's collective), on
+    # every rank, after everything else and under a watchdog: the job total above came from torch.distributed, so
+    # whatever happens here the line is printed -- with the outcome (or the error, or "timed out") in it.
+    if rank != 0:
+        line = None
+
+    def give_up():
+        if rank == 0:
+            line["xm_allreduce_counts"] = {"error": "no answer within 120 s"}
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    if not rehearsal:
+        import threading
+        watchdog = threading.Timer(120.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        outcome = None
+        try:
+            with stdout_to_stderr():
+                uid = [None]
+                if rank == 0:
+                    try:
+                        uid = [_ffi.comm_unique_id()]
+                    except Exception as e:                       # noqa: BLE001 -- every rank must still reach the broadcast
+                        uid = ["%s: %s" % (type(e).__name__, e)]
+                if world > 1:
+                    dist.broadcast_object_list(uid, src=0)
+                if not isinstance(uid[0], bytes):
+                    raise RuntimeError("xm_comm_unique_id on rank 0: %s" % uid[0])
+                ctx.comm_init(world, rank, uid[0])
+                mine = counts * args.steps                       # every step saw the same block: this rank's job total
+                ctx.allreduce_counts(mine)
+                torch.cuda.synchronize()
+                outcome = {"ranks": ctx.comm_size(), "matches_torch_distributed": bool(torch.equal(mine, job_final))}
+                ctx.comm_destroy()
+        except Exception as e:                                   # noqa: BLE001 -- reported, not raised
+            outcome = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+        if rank == 0:
+            line["xm_allreduce_counts"] = outcome
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
