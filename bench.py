@@ -261,6 +261,9 @@ def main():
             bytes_per_unit = 65.0                                                # 2 mates x 4 binary64 scores in + 1 byte out
             dtype = "f64"
     code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)      # compact category stream: a nibble per record
+    # XM_BENCH_CATEGORY_BYTES=1 (A/B): the per-record output of the step is the category byte (fwd*8+rev) instead
+    category_bytes = os.environ.get("XM_BENCH_CATEGORY_BYTES") == "1" or args.workload == "cfg3"
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     off = torch.zeros(8, dtype=torch.int64, device=dev)
     n_slots = max(args.steps, args.warmup, 1)
@@ -293,8 +296,9 @@ def main():
                                            cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"],
                                            cols["unit_bits"], floor_min, code, idx, off, counts, range_flag=range_flag)
         else:
-            ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"],
-                                     floor_min, code, idx, off, counts)
+            ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min,
+                                     code if category_bytes else None, idx, off, counts,
+                                     bins4=None if category_bytes else bins4)
 
     def finish(n_steps):
         torch.sum(step_counts[:n_steps], dim=0, out=job_counts)  # category_counts of the job: the sum over its steps
@@ -354,7 +358,19 @@ def main():
         want_code, want_counts = H.c_classify(mode, host_cols["as1"], host_cols["xs1"], host_cols["as2"],
                                               host_cols["xs2"], host_cols["unit_bits"], floor_min)
         want_idx, want_off = H.c_compact(mode, want_code)
-        ok = bool((code[:n].cpu().numpy() == want_code).all())
+        if not category_bytes and not unfused:
+            # the timed step left the compact stream: check it, then ask for the category bytes as well (same kernels,
+            # both outputs) so that they are checked too
+            want_bins = np.full(n, 7, dtype=np.uint8)
+            for b in range(7):
+                want_bins[want_idx[int(want_off[b]):int(want_off[b + 1])]] = b
+            ok_bins = bool((_ffi.unpack_bins4(bins4.cpu().numpy(), n) == want_bins).all())
+            ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min,
+                                     code, idx, off, counts, bins4=bins4)
+            torch.cuda.synchronize()
+        else:
+            ok_bins = True
+        ok = ok_bins and bool((code[:n].cpu().numpy() == want_code).all())
         ok &= bool((off.cpu().numpy().astype(np.uint64) == want_off).all())
         ok &= bool((idx[:int(want_off[7])].cpu().numpy().view(np.uint32) == want_idx).all())
         ok &= bool((counts.cpu().numpy().astype(np.uint64) == want_counts).all())
@@ -404,6 +420,9 @@ def main():
                        "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": n,
                        "step": ("A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)" if unfused else
                                 "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % ("_cigar" if cig is not None else "")),
+                       "category_per_record": ("category byte (fwd*8+rev, 1 B per record)" if category_bytes or unfused else
+                                               "compact stream bins4: the output bin as a nibble per record = 1 B per pair (SURVEY 8d's "
+                                               "algorithmic figure); the category byte is produced on request and checked outside the timed region"),
                        "sharding": "read-block per GPU, no halo exchange" + (", one RCCL all-reduce of the final category_counts" if world > 1 else "")},
             "roofline": {"bound": "hbm",
                          "kernel": "classify_cigar_kernel<paired, counts>" if cig is not None else "classify_kernel<%s, %s, counts>" % (dtype, "single" if args.workload == "se" else "paired"),

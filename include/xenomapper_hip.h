@@ -201,19 +201,29 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, cons
 /*
  * One whole main loop (xenomapper.py:321-350, :398-452, :498-554) on device-resident columns: xm_classify_dev
  * followed by xm_compact_dev, fused -- the classify kernel counts its units per category and per output bin while
- * the category bytes are still in registers, so they are written once (code_out, n_records bytes, 16-byte aligned,
- * required) and read once (by the scatter).  Outputs as xm_classify_dev + xm_compact_dev.  Same one-in-flight rule.
+ * the categories are still in registers.  Outputs as xm_classify_dev + xm_compact_dev.  Same one-in-flight rule.
+ * The per-record output comes in two forms, at least one of which must be given:
+ *   code_out  n_records bytes, the category byte of xm_classify_dev (state, or fwd*8 + rev; 0xFF = closes no unit);
+ *   bins4     XM_BINS4_BYTES(n_records) bytes, the compact category stream: the OUTPUT BIN of every record as a
+ *             nibble (0..5 = the six bins in the priority order above, 6 = a unit holding state 6, 7 = closes no
+ *             unit), record r in bits 4 (r & 1) .. 4 (r & 1) + 3 of byte r >> 1 -- one byte per read pair.  The
+ *             buffer is written in whole 1024-byte blocks (2048 records), hence the rounded-up size.
+ * With bins4 the scatter reads the compact stream (half the bytes, no byte -> bin table) and code_out is an optional
+ * extra; without it the scatter reads code_out.  Both 16-byte aligned.
  */
+#define XM_BINS4_BYTES(n_records) ((((uint64_t)(n_records) + 2047u) / 2048u) * 1024u)
+
 int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
                             const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                            const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                            const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
                             uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
 
 int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
                                 const double *as1, const double *xs1, const double *as2, const double *xs2,
-                                const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                                const uint64_t *unit_bits, double min_score, uint8_t *code_out, uint8_t *bins4,
                                 uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
 
+/* The --cigar_scores form: code_out required (the CIGAR kernel does not count; the compaction reads its bytes). */
 int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
                                   const int32_t *nm1, const uint32_t *cig_off1, const uint32_t *cig_oplen1, const int32_t *xs1,
                                   const int32_t *nm2, const uint32_t *cig_off2, const uint32_t *cig_oplen2, const int32_t *xs2,

@@ -453,6 +453,72 @@ def test_device_entry_points_and_full_size(ctx):
         for b in range(6):
             seg = h_idx[int(h_off[b]):int(h_off[b + 1])]
             assert (np.diff(seg.astype(np.int64)) > 0).all()                              # stable within a bin
+        # the fused call, in its three output forms: category bytes only, compact stream only (what bench.py times), both
+        want_bins = _bins_of_codes(mode, want_code)
+        bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+        for use_code, use_bins4 in ((True, False), (False, True), (True, True)):
+            code.fill_(0x55), idx.fill_(-1), off.zero_(), counts.zero_(), bins4.fill_(0x55)
+            ctx.classify_compact_dev(mode, d["as1"], d["xs1"], d["as2"], d["xs2"], d["unit_bits"], ABSENT,
+                                     code if use_code else None, idx, off, counts, bins4=bins4 if use_bins4 else None)
+            torch.cuda.synchronize()
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+            assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+            assert np.array_equal(idx[:n_pairs].cpu().numpy().view(np.uint32), want_idx)
+            if use_code:
+                assert np.array_equal(code[:n].cpu().numpy(), want_code)
+            if use_bins4:
+                assert np.array_equal(_ffi.unpack_bins4(bins4.cpu().numpy(), n), want_bins)
+
+
+def _bins_of_codes(mode, code):
+    """Output bin per record (6 = unit holding a state 6, 7 = closes no unit) as the oracle's split assigns it: the
+    content of the compact category stream."""
+    idx, off = H.c_compact(mode, code)
+    bins = np.full(code.shape[0], 7, dtype=np.uint8)
+    for b in range(7):
+        bins[idx[int(off[b]):int(off[b + 1])]] = b
+    return bins
+
+
+@pytest.mark.parametrize("n", [1, 5, 2047, 2048, 2049, 8191, 70_001])
+def test_fused_device_forms_small(ctx, n):
+    """xm_classify_compact_dev / _f64_dev with category bytes, with the compact stream, with both -- every mode, ragged
+    sizes around the 2048-record granule, irregular unit masks, and NaN (state 6) on the binary64 side."""
+    import torch
+    from xenomapper_amd import _ffi
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    icols = random_columns(rng, n)
+    fvals = np.array([NEG, NEG, float("nan"), -1.5, 0.0, 0.0, 1.0, 2.5, 3.0])
+    fcols = [fvals[rng.integers(0, len(fvals), n)] for _ in range(4)]
+    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    for mode in (0, 1, 2):
+        flags = rng.random(n) < (0.55 if mode else 0.9)
+        bits = H.synth.pack_unit_bits(flags)
+        d_bits = torch.from_numpy(bits.view(np.int64)).to(dev)
+        for cols, m in ((icols, ABSENT), (fcols, 0.5)):
+            want_code, want_counts = H.c_classify(mode, *cols, bits, m)
+            want_idx, want_off = H.c_compact(mode, want_code)
+            want_bins = _bins_of_codes(mode, want_code)
+            d_cols = [torch.from_numpy(np.ascontiguousarray(c)).to(dev) for c in cols]
+            for use_code, use_bins4 in ((True, False), (False, True), (True, True)):
+                code.fill_(0x55), idx.fill_(-1), off.zero_(), counts.zero_(), bins4.fill_(0x55)
+                ctx.classify_compact_dev(mode, *d_cols, d_bits, m, code if use_code else None, idx, off, counts,
+                                         bins4=bins4 if use_bins4 else None)
+                torch.cuda.synchronize()
+                assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+                assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+                assert np.array_equal(idx[:int(want_off[7])].cpu().numpy().view(np.uint32), want_idx)
+                if use_code:
+                    assert np.array_equal(code[:n].cpu().numpy(), want_code)
+                if use_bins4:
+                    assert np.array_equal(_ffi.unpack_bins4(bins4.cpu().numpy(), n), want_bins)
+    with pytest.raises(ValueError):                       # neither form given
+        ctx.classify_compact_dev(1, *d_cols, d_bits, 0.5, None, idx, off, counts, bins4=None)
 
 
 def test_full_size_cfg3_cigar(ctx):
@@ -584,7 +650,8 @@ def test_beyond_2_30_records_the_wide_scatter(ctx, mode):
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     off = torch.zeros(8, dtype=torch.int64, device=dev)
     counts = torch.zeros(64, dtype=torch.int64, device=dev)
-    ctx.classify_compact_dev(mode, *cols, bits, _ffi.ABSENT, code, idx, off, counts)
+    bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+    ctx.classify_compact_dev(mode, *cols, bits, _ffi.ABSENT, code, idx, off, counts, bins4=bins4)     # K2c reads bins4
     torch.cuda.synchronize()
     units = n if mode == 0 else n // 2
     per_bin = units // 6

@@ -42,7 +42,15 @@ static uint64_t *REP, *REP_OLD, *BINOFF, *BINOFF_OLD, *COUNTS, *COUNTS_OLD;
 static int MODE = XM_MODE_PE_LIBERAL;
 
 static uint32_t *PART;
-static xm::CountPlan cplan(uint32_t = 0) { xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = GC; cp.counts_rep = REP; cp.part_tot = PART; return cp; }
+static uint8_t *BINS4;
+static xm::CountPlan cplan(uint32_t = 0) { xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = GC; cp.counts_rep = REP; cp.part_tot = PART; cp.bins4 = nullptr; return cp; }
+// the compact-stream form of the fused step: K1 writes bins4 (and no category bytes), K2c reads bins4
+static void nib_classify_counts() { auto cp = cplan(); cp.bins4 = BINS4; xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, nullptr, &cp); }
+static void nib_classify_counts_code() { auto cp = cplan(); cp.bins4 = BINS4; xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, &cp); }
+static void new_scan();
+static void nib_scatter() { auto cp = cplan(); xm::launch_scatter(0, cp.plan, MODE, N, BINS4, true, GO, REP + 64 * 64, BINOFF, IDX); }
+static void nib_fused() { for (int r = 0; r < 4; ++r) { nib_classify_counts(); new_scan(); nib_scatter(); } }
+static void nib_fused_code() { for (int r = 0; r < 4; ++r) { nib_classify_counts_code(); new_scan(); nib_scatter(); } }
 
 static void old_classify() { xm_r01::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE_OLD); }
 static void old_hist() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_hist(0, p, MODE, N, CODE_OLD, CC_OLD, REP_OLD); }
@@ -60,17 +68,17 @@ template <bool DIRECT> static void scan_variant() { auto cp = cplan(); const uin
         (unsigned long long *)(REP + 64 * 64), (unsigned long long *)REP, (unsigned long long *)COUNTS); }
 static void new_scatter();
 template <bool DIRECT> static void scanv_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); scan_variant<DIRECT>(); new_scatter(); } }
-static void new_scatter() { auto cp = cplan(); xm::launch_scatter(0, cp.plan, MODE, N, CODE, GO, REP + 64 * 64, BINOFF, IDX); }
+static void new_scatter() { auto cp = cplan(); xm::launch_scatter(0, cp.plan, MODE, N, CODE, false, GO, REP + 64 * 64, BINOFF, IDX); }
 static void new_fused() { for (int r = 0; r < 4; ++r) { new_classify_counts(); new_scan(); new_scatter(); } }
 static void new_unfused() { for (int r = 0; r < 4; ++r) { new_classify(); new_hist(); new_scan(); new_scatter(); } }
 // two independent batches in flight on two streams (consecutive windows of a file): K2 of one under K1 of the other
 struct Lane2 { hipStream_t st; uint8_t *code; uint32_t *gc, *go, *idx, *part; uint64_t *rep, *binoff, *counts; };
 static Lane2 L2[2];
 static void fused_on(const Lane2 &l) {
-    xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = l.gc; cp.counts_rep = l.rep; cp.part_tot = l.part;
+    xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = l.gc; cp.counts_rep = l.rep; cp.part_tot = l.part; cp.bins4 = nullptr;
     xm::launch_classify_i32(l.st, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, l.code, &cp);
     xm::launch_scan(l.st, cp, l.go, l.rep + 64 * 64, l.counts);
-    xm::launch_scatter(l.st, cp.plan, MODE, N, l.code, l.go, l.rep + 64 * 64, l.binoff, l.idx);
+    xm::launch_scatter(l.st, cp.plan, MODE, N, l.code, false, l.go, l.rep + 64 * 64, l.binoff, l.idx);
 }
 static hipEvent_t EV_FORK, EV_JOIN[2];
 static void new_fused_2stream() {        // 4 steps, alternating lanes; fork from / join to the null stream so that the timing events bracket it
@@ -93,13 +101,29 @@ template <int STEPS> static void new_fused_pipelined() {
         CK(hipEventRecord(EV_K1[s], ST_A));
         CK(hipStreamWaitEvent(ST_B, EV_K1[s], 0));
         xm::launch_scan(ST_B, cp, l.go, l.rep + 64 * 64, l.counts);
-        xm::launch_scatter(ST_B, cp.plan, MODE, N, l.code, l.go, l.rep + 64 * 64, l.binoff, l.idx);
+        xm::launch_scatter(ST_B, cp.plan, MODE, N, l.code, false, l.go, l.rep + 64 * 64, l.binoff, l.idx);
         CK(hipEventRecord(EV_K2[s], ST_B));
     }
     CK(hipEventRecord(EV_JOIN[0], ST_A)); CK(hipEventRecord(EV_JOIN[1], ST_B));
     CK(hipStreamWaitEvent(0, EV_JOIN[0], 0)); CK(hipStreamWaitEvent(0, EV_JOIN[1], 0));
 }
 template <int STEPS> static void new_fused_serial() { for (int r = 0; r < STEPS; ++r) { new_classify_counts(); new_scan(); new_scatter(); } }
+// read-only ceiling with K1's input footprint: 4 x 16 B loads per lane, one dword per wave out
+__global__ void __launch_bounds__(256) read_like(const xm::v4i32 *a, const xm::v4i32 *b, const xm::v4i32 *c, const xm::v4i32 *d, uint32_t *out, uint64_t ngroups)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    xm::v4i32 va = __builtin_nontemporal_load(a + g), vb = __builtin_nontemporal_load(b + g);
+    xm::v4i32 vc = __builtin_nontemporal_load(c + g), vd = __builtin_nontemporal_load(d + g);
+    uint32_t r = (uint32_t)(va.x ^ vb.y ^ vc.z ^ vd.w ^ va.w ^ vb.x ^ vc.y ^ vd.z ^ va.y ^ va.z ^ vb.z ^ vb.w ^ vc.x ^ vc.w ^ vd.x ^ vd.y);
+    r ^= (uint32_t)__shfl_xor((int)r, 32, 64);
+    if (r == 0x12345678u && (threadIdx.x & 63u) == 0u) out[g >> 6] = r;           // practically never: no write traffic
+}
+static void run_read() { read_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((const xm::v4i32 *)A1, (const xm::v4i32 *)X1, (const xm::v4i32 *)A2, (const xm::v4i32 *)X2, (uint32_t *)CODE, N / 4); }
+// the same columns at skewed base addresses (copies inside one big buffer): do the four streams collide in the channels?
+static int32_t *SK[4][4];        // [skew variant][column]
+template <int V> static void skew_classify() { xm::launch_classify_i32(0, MODE, N, SK[V][0], SK[V][1], SK[V][2], SK[V][3], BITS, INT32_MIN, CODE, nullptr); }
+template <int V> static void skew_read() { read_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((const xm::v4i32 *)SK[V][0], (const xm::v4i32 *)SK[V][1], (const xm::v4i32 *)SK[V][2], (const xm::v4i32 *)SK[V][3], (uint32_t *)CODE, N / 4); }
 static void run_copy() { copy_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((const xm::v4i32 *)A1, (const xm::v4i32 *)X1, (const xm::v4i32 *)A2, (const xm::v4i32 *)X2, (uint32_t *)CODE, N / 4); }
 
 
@@ -259,7 +283,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&BINOFF, 64)); CK(hipMalloc(&BINOFF_OLD, 64)); CK(hipMalloc(&COUNTS, 512)); CK(hipMalloc(&COUNTS_OLD, 512));
     CK(hipMalloc(&REP, (64 * 64 + 8) * 8)); CK(hipMalloc(&REP_OLD, (64 * 64 + 8) * 8));
     CK(hipMemset(REP, 0, (64 * 64 + 8) * 8)); CK(hipMemset(REP_OLD, 0, (64 * 64 + 8) * 8));
-    CK(hipMalloc(&PART, 8 * XM_PART_STRIDE * 4));
+    CK(hipMalloc(&PART, 8 * XM_PART_STRIDE * 4)); CK(hipMalloc(&BINS4, (N + 2047) / 2048 * 1024 + 64));
     CK(hipEventCreate(&EV_FORK)); CK(hipEventCreate(&EV_JOIN[0])); CK(hipEventCreate(&EV_JOIN[1]));
     CK(hipStreamCreateWithFlags(&ST_A, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&ST_B, hipStreamNonBlocking));
     for (int k = 0; k < 8; ++k) { CK(hipEventCreateWithFlags(&EV_K1[k], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&EV_K2[k], hipEventDisableTiming)); }
@@ -293,6 +317,17 @@ int main(int argc, char **argv)
         CK(hipMemcpy(A2, a2.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X2, x2.data(), N * 4, hipMemcpyHostToDevice));
     }
     CK(hipMemset(BITS, (MODE == XM_MODE_SE || !interleaved) ? 0xFF : 0xAA, N / 8 + 64));
+    {   // skewed copies of the columns: column c starts c * skew bytes past a 2 MiB-aligned slot
+        const size_t skews[4] = {0, 4096, 65536 + 4096, (1u << 20) + 65536 + 4096 + 256};
+        const size_t slot = ((N * 4 + (4u << 20)) + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+        for (int v = 0; v < 4; ++v) {
+            char *big; CK(hipMalloc(&big, 4 * slot + (8u << 20)));
+            char *aligned = (char *)(((uintptr_t)big + (2u << 20) - 1) / (2u << 20) * (2u << 20));
+            const int32_t *src[4] = {A1, X1, A2, X2};
+            for (int c = 0; c < 4; ++c) { SK[v][c] = (int32_t *)(aligned + c * slot + c * skews[v]); CK(hipMemcpy(SK[v][c], src[c], N * 4, hipMemcpyDeviceToDevice)); }
+        }
+        printf("column bases A1 %p X1 %p A2 %p X2 %p\n", (void *)A1, (void *)X1, (void *)A2, (void *)X2);
+    }
 
     // correctness first: old chain, new fused chain, new unfused chain
     old_classify(); old_hist(); old_scan(); old_scatter();
@@ -301,13 +336,20 @@ int main(int argc, char **argv)
     CK(hipMemset(IDX, 0xEE, N * 4)); CK(hipMemset(COUNTS, 0xEE, 512)); CK(hipMemset(BINOFF, 0xEE, 64)); CK(hipMemset(CODE, 0xEE, N));
     new_classify(); new_hist(); new_scan(); new_scatter();
     ok &= compare_outputs("K1, hist/scan/scatter");
+    CK(hipMemset(IDX, 0xEE, N * 4)); CK(hipMemset(COUNTS, 0xEE, 512)); CK(hipMemset(BINOFF, 0xEE, 64));
+    nib_classify_counts(); new_scan(); nib_scatter();              // CODE still holds the previous (correct) bytes: only idx/offsets/counts tell
+    ok &= compare_outputs("fused via bins4 (no category bytes)");
+#ifndef XM_TUNE_NOVERIFY
     if (!ok) { printf("STOP: results differ\n"); return 1; }
+#endif
 
     struct Cfg { const char *name; void (*fn)(); double bytes; void (*prep)(); };
 
     const double cls = 16.5 * (double)N, step = 19.0 * (double)N;
     std::vector<Cfg> cfgs = {
-        {"copy_like NT", run_copy, cls},
+        {"copy_like NT", run_copy, cls}, {"read_like NT", run_read, 16.0 * N},
+        {"read skew 0", skew_read<0>, 16.0 * N}, {"read skew 4K", skew_read<1>, 16.0 * N}, {"read skew 68K", skew_read<2>, 16.0 * N}, {"read skew 1M+", skew_read<3>, 16.0 * N},
+        {"classify skew 0", skew_classify<0>, cls}, {"classify skew 4K", skew_classify<1>, cls}, {"classify skew 68K", skew_classify<2>, cls}, {"classify skew 1M+", skew_classify<3>, cls},
         {"r01 classify", old_classify, cls}, {"r01 hist", old_hist, (double)N}, {"r01 scan", old_scan, 0}, {"r01 scatter", old_scatter, 3.0 * N},
         {"r02 classify", new_classify, cls}, {"r02 classify+counts", new_classify_counts, cls}, {"r02 hist", new_hist, (double)N},
         {"r02 scan", new_scan, 0}, {"scan 1 launch", scan_variant<true>, 0}, {"scan 2 launches", scan_variant<false>, 0},
@@ -317,17 +359,24 @@ int main(int argc, char **argv)
         {"abl scatter arith-decode", abl_scatter<4>, 3.0 * N}, {"abl scatter no-guard", abl_scatter<5>, 3.0 * N},
         {"stream write 4B/unit", run_stream_write, 2.0 * N}, {"stream write 16B/lane", run_stream_write16, 2.0 * N},
         {"stream write 16B nt", run_stream_write16_nt, 2.0 * N},
-        {"r01 pipeline x4", old_pipeline, 4 * step}, {"r02 unfused x4", new_unfused, 4 * step}, {"r02 fused x4", new_fused, 4 * step}, {"r02 fused x4 2-stream", new_fused_2stream, 4 * step},
+        {"r01 pipeline x4", old_pipeline, 4 * step}, {"r02 unfused x4", new_unfused, 4 * step}, {"r02 fused x4", new_fused, 4 * step}, {"bins4 fused x4", nib_fused, 4 * step}, {"bins4+code fused x4", nib_fused_code, 4 * step},
+        {"bins4 classify+counts", nib_classify_counts, cls}, {"bins4 scatter", nib_scatter, 2.5 * N}, {"r02 fused x4 2-stream", new_fused_2stream, 4 * step},
         {"fused x4 pipelined", new_fused_pipelined<4>, 4 * step}, {"fused x8 serial", new_fused_serial<8>, 8 * step},
         {"fused x8 pipelined", new_fused_pipelined<8>, 8 * step},
         {"fused x4 all-bins", ablp_fused<0>, 4 * step}, {"fused x4 skip-empty", ablp_fused<6>, 4 * step},
         {"fused x4 no-guard", ablp_fused<5>, 4 * step}, {"fused x4 nt-store", ablp_fused<7>, 4 * step},
         {"fused x4 arith", ablp_fused<4>, 4 * step}, {"fused x4 no-store", ablp_fused<1>, 4 * step},
     };
+    if (const char *only = getenv("XM_TUNE_ONLY")) {          // comma-free substring filter: time only the matching variants
+        std::vector<Cfg> keep;
+        for (auto &c : cfgs) if (strstr(c.name, only)) keep.push_back(c);
+        cfgs = keep;
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<std::vector<float>> t(cfgs.size());
     for (int r = 0; r < rounds + 2; ++r)
         for (size_t k = 0; k < cfgs.size(); ++k) {
+            if (getenv("XM_TUNE_TRACE")) { printf("run %s\n", cfgs[k].name); fflush(stdout); }
             if (cfgs[k].prep) cfgs[k].prep();
             CK(hipEventRecord(e0)); cfgs[k].fn(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -27,6 +27,21 @@ _ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, 
 UNIQUE_ID_BYTES = 128
 
 
+def bins4_bytes(n_records):
+    """XM_BINS4_BYTES: size of the compact category stream for n_records (whole 1024-byte blocks of 2048 records)."""
+    return ((int(n_records) + 2047) // 2048) * 1024
+
+
+def unpack_bins4(bins4, n_records):
+    """The output bin of every record (uint8: 0..5, 6 = state-6 unit, 7 = closes no unit) from a compact category
+    stream as xm_classify_compact*_dev writes it (host NumPy array): record r = nibble r & 1 of byte r >> 1."""
+    b = np.ascontiguousarray(bins4[:(int(n_records) + 1) // 2])
+    out = np.empty(2 * b.shape[0], dtype=np.uint8)
+    out[0::2] = b & 7
+    out[1::2] = (b >> 4) & 7
+    return out[:n_records]
+
+
 class HipExtensionMissing(RuntimeError):
     pass
 
@@ -88,8 +103,8 @@ def lib():
         "xm_classify_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P], I),
         "xm_cigar_scores_dev": ([P, P, U64, P, P, P, P, P], I),
         "xm_compact_dev": ([P, P, I, U64, P, P, P, P], I),
-        "xm_classify_compact_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, P], I),
-        "xm_classify_compact_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P], I),
+        "xm_classify_compact_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, P, P], I),
+        "xm_classify_compact_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P, P], I),
         "xm_classify_compact_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P], I),
         "xm_comm_unique_id": ([P], I),
         "xm_comm_init": ([P, I, I, P], I),
@@ -350,13 +365,14 @@ class Context(object):
         self._check(rc, "xm_compact_dev")
 
     def classify_compact_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, code_out, idx_out, bin_offsets,
-                             counts, stream=None):
+                             counts, bins4=None, stream=None):
         """The fused main loop on device-resident columns (int32 or float64): classify + count in one kernel, then
-        scan + scatter.  Asynchronous."""
+        scan + scatter.  `code_out` (category bytes) and/or `bins4` (compact category stream, bins4_bytes(n) bytes):
+        at least one; with bins4 the scatter reads the compact stream.  Asynchronous."""
         n = as1.numel()
         st = self._stream_handle(stream)
         ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (as1, xs1, as2, xs2, unit_bits)]
-        outs = [ctypes.c_void_p(t.data_ptr()) for t in (code_out, idx_out, bin_offsets, counts)]
+        outs = [ctypes.c_void_p(t.data_ptr()) if t is not None else None for t in (code_out, bins4, idx_out, bin_offsets, counts)]
         if as1.element_size() == 4:
             rc = self._L.xm_classify_compact_dev(self._h, st, mode, n, *ptrs, int(min_score), *outs)
         else:

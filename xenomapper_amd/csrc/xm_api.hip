@@ -327,6 +327,7 @@ int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n, const int32_t *nm
 static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const uint8_t *code, const xm::CountPlan &cp,
                         uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
 {
+    const bool from_bins4 = cp.bins4 != nullptr;          // a counting classify kernel left the compact stream: K2c reads that
     uint64_t *bin_totals = ctx->d_counts_rep + XM_COUNT_REPLICAS * 64;
     int rc;
     {
@@ -339,7 +340,8 @@ static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const
     }
     {
         Span span(ctx, st, XM_K_SCATTER);
-        xm::launch_scatter(st, cp.plan, mode, n, code, ctx->d_gran_off, bin_totals, bin_offsets, idx_out);
+        xm::launch_scatter(st, cp.plan, mode, n, from_bins4 ? cp.bins4 : code, from_bins4, ctx->d_gran_off, bin_totals,
+                           bin_offsets, idx_out);
     }
     return check_launch(ctx, "scatter_kernel");
 }
@@ -351,6 +353,7 @@ static xm::CountPlan count_plan(xm_ctx *ctx, uint64_t n)
     cp.gran_counts = ctx->d_gran_counts;
     cp.counts_rep = ctx->d_counts_rep;
     cp.part_tot = ctx->d_part_tot;
+    cp.bins4 = nullptr;
     return cp;
 }
 
@@ -384,17 +387,18 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_
 
 int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                             const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                            const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                            const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
                             uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
 {
     if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
-    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out || !idx_out) return XM_ERR_INVALID_ARG;
-    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2 | (uintptr_t)code_out) & 15u))
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || (!code_out && !bins4) || !idx_out) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2 | (uintptr_t)code_out | (uintptr_t)bins4) & 15u))
         return XM_ERR_INVALID_ARG;
-    const xm::CountPlan cp = count_plan(ctx, n);
+    xm::CountPlan cp = count_plan(ctx, n);
+    cp.bins4 = bins4;
     int rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
@@ -406,17 +410,18 @@ int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
 
 int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                                 const double *as1, const double *xs1, const double *as2, const double *xs2,
-                                const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                                const uint64_t *unit_bits, double min_score, uint8_t *code_out, uint8_t *bins4,
                                 uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
 {
     if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
     if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
-    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !code_out || !idx_out) return XM_ERR_INVALID_ARG;
-    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || ((uintptr_t)code_out & 15u))
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || (!code_out && !bins4) || !idx_out) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || (((uintptr_t)code_out | (uintptr_t)bins4) & 15u))
         return XM_ERR_INVALID_ARG;
-    const xm::CountPlan cp = count_plan(ctx, n);
+    xm::CountPlan cp = count_plan(ctx, n);
+    cp.bins4 = bins4;
     int rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
@@ -739,20 +744,23 @@ static int classify_compact_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem,
     }
     if ((rc = ensure_scratch(ctx, 4, bits_bytes)) != XM_OK) return rc;
     XM_HIP(ctx, hipMemcpy(ctx->d_scratch[4], unit_bits, bits_bytes, hipMemcpyHostToDevice));
-    if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    // scratch 5: the category bytes when the caller wants them, else the compact category stream (half the bytes, and
+    // the faster scatter); both at once measured slower than either
+    if ((rc = ensure_scratch(ctx, 5, code_out ? (size_t)n + 16 : (size_t)XM_BINS4_BYTES(n))) != XM_OK) return rc;
     if ((rc = ensure_scratch(ctx, 6, (size_t)n * 4)) != XM_OK) return rc;
     if ((rc = ensure_scratch(ctx, 7, 72 * sizeof(uint64_t))) != XM_OK) return rc;
-    uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
+    uint8_t *d_code = code_out ? (uint8_t *)ctx->d_scratch[5] : nullptr;
+    uint8_t *d_bins4 = code_out ? nullptr : (uint8_t *)ctx->d_scratch[5];
     uint32_t *d_idx = (uint32_t *)ctx->d_scratch[6];
     uint64_t *d_off = (uint64_t *)ctx->d_scratch[7];
     if (elem == 4)
         rc = xm_classify_compact_dev(ctx, nullptr, mode, n, (const int32_t *)ctx->d_scratch[0], (const int32_t *)ctx->d_scratch[1],
                                      (const int32_t *)ctx->d_scratch[2], (const int32_t *)ctx->d_scratch[3],
-                                     (const uint64_t *)ctx->d_scratch[4], mi, d_code, d_idx, d_off, d_off + 8);
+                                     (const uint64_t *)ctx->d_scratch[4], mi, d_code, d_bins4, d_idx, d_off, d_off + 8);
     else
         rc = xm_classify_compact_f64_dev(ctx, nullptr, mode, n, (const double *)ctx->d_scratch[0], (const double *)ctx->d_scratch[1],
                                          (const double *)ctx->d_scratch[2], (const double *)ctx->d_scratch[3],
-                                         (const uint64_t *)ctx->d_scratch[4], mf, d_code, d_idx, d_off, d_off + 8);
+                                         (const uint64_t *)ctx->d_scratch[4], mf, d_code, d_bins4, d_idx, d_off, d_off + 8);
     if (rc != XM_OK) return rc;
     return fetch_compact_results(ctx, n, d_code, d_idx, d_off, code_out, idx_out, bin_offsets, counts);
 }

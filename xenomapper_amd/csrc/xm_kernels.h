@@ -30,10 +30,11 @@ struct GranPlan {
 
 // where the counting side (fused K1, or K2a) leaves its results
 struct CountPlan {
-    GranPlan plan;
-    uint32_t *gran_counts;      // [8][gran_stride]
-    uint32_t *part_tot;         // [8][XM_PART_STRIDE]: K2b's first level (units per bin and part)
-    uint64_t *counts_rep;       // [XM_COUNT_REPLICAS][64], all zero between calls
+    GranPlan plan = {0, 0};
+    uint32_t *gran_counts = nullptr;   // [8][gran_stride]
+    uint32_t *part_tot = nullptr;      // [8][XM_PART_STRIDE]: K2b's first level (units per bin and part)
+    uint8_t *bins4 = nullptr;          // where a counting classify kernel writes the compact category stream, or null
+    uint64_t *counts_rep = nullptr;    // [XM_COUNT_REPLICAS][64], all zero between calls
 };
 
 GranPlan plan_granules(uint64_t n);
@@ -51,7 +52,8 @@ void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
                            const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag);
 void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, const CountPlan &cp);
 void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64_t *bin_totals, uint64_t *counts);
-void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code,
+// code_is_bins4: `code` is the compact category stream of a counting classify kernel, not category bytes
+void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out);
 void launch_mate_correlate(hipStream_t st, uint64_t n, const double *track, uint32_t m, const double *density, double *out);
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,

@@ -129,6 +129,7 @@ __device__ __forceinline__ void lds_settle()
 struct CountSink {
     uint32_t *gran_counts;               // [8][gran_stride]
     unsigned long long *counts_rep;      // [XM_COUNT_REPLICAS][64]
+    uint8_t *bins4;                      // compact category stream (XM_GRAN / 2 bytes per granule) or null
     uint32_t gran_stride;
     int mode;                            // bin rule of the flush
 };
@@ -173,7 +174,24 @@ __device__ __forceinline__ void count_units(const uint32_t c[4], uint32_t *lds, 
 
 // Shared K1 epilogue: 4 states per lane -> forward mate's state (lane-1 / previous wave via LDS / halo) ->
 // 4 category bytes -> one 4-byte store (-> counts, when fused).
-template <typename T, bool PAIRED, int BLOCK, bool FULL, bool COUNTS>
+// output bin of a category byte, rule fixed at compile time.  HAS6: state 6 can occur (binary64 input only).
+// 0..5 bins, 6 = a unit holding a state 6, 7 = not a unit.
+template <int MODE, bool HAS6>
+__device__ __forceinline__ uint32_t unit_bin(uint32_t c)
+{
+    if (MODE == XM_MODE_SE) return c == XM_NO_UNIT ? 7u : (c & 7u);                 // the state itself (6 stays 6)
+    const uint32_t f = (c >> 3) & 7u, r = c & 7u;
+    const uint32_t lo = f < r ? f : r, hi = f < r ? r : f;
+    uint32_t b = lo;
+    if (MODE == XM_MODE_PE_CONSERVATIVE) {
+        b = (((f ^ r) & 1u) != 0u || hi == 4u) ? 4u : b;                           // :525-529
+        b = (hi == 5u) ? 5u : b;                                                    // :521
+    }
+    if (HAS6) b = (hi > 5u) ? 6u : b;
+    return c == XM_NO_UNIT ? 7u : b;
+}
+
+template <typename T, bool PAIRED, int BLOCK, bool FULL, bool COUNTS, int BINMODE>
 __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], const T a2[4], const T x2[4], T m,
                                                 uint32_t mb, uint32_t halo, uint32_t *last_state,
                                                 uint8_t *__restrict__ code, uint64_t r0, uint64_t n,
@@ -202,11 +220,22 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
     }
 
     if (FULL || r0 + 4 <= n) {
-        *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+        if (code != nullptr) *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (r0 + j < n) code[r0 + j] = (uint8_t)c[j];
+            if (code != nullptr && r0 + j < n) code[r0 + j] = (uint8_t)c[j];
+    }
+    if (BINMODE >= 0) {
+        // the compact category stream (xm_classify_compact*_dev with bins4): the output bin of each of the lane's 4 records
+        // as a nibble, record r in nibble r & 1 of byte r >> 1: one full 128-byte line per wave instruction.  (A
+        // [lane][wave] transposition inside the granule, which would let K2c read 16 bytes per lane at once, made this
+        // kernel 20 us slower: eight waves each writing a sliver of every line.)  The last workgroup writes its whole
+        // block, so the buffer is XM_BINS4_BYTES(n) long.
+        uint32_t nib = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nib |= unit_bin<BINMODE, sizeof(T) == 8>(c[j]) << (4 * j);
+        reinterpret_cast<uint16_t *>(sink.bins4)[r0 >> 2] = (uint16_t)nib;
     }
     if (COUNTS) count_units<BLOCK>(c, count_lds, sink);
 }
@@ -221,7 +250,7 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
 // NT: the score columns are read once and never again, so they are loaded non-temporally; the
 // category bytes are stored with the default policy because K2 reads them next (100 MB at the
 // 50 M-pair configuration, which fits the 256 MiB Infinity Cache).
-template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL, bool COUNTS>
+template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL, bool COUNTS, int BINMODE>
 __device__ __forceinline__ void classify_body(const T *__restrict__ as1, const T *__restrict__ xs1,
                                               const T *__restrict__ as2, const T *__restrict__ xs2,
                                               const uint8_t *__restrict__ unit_bits8, T m,
@@ -250,7 +279,7 @@ __device__ __forceinline__ void classify_body(const T *__restrict__ as1, const T
             mb &= ~1u;                                         // record 0 has no predecessor (:402)
         }
     }
-    classify_finish<T, PAIRED, BLOCK, FULL, COUNTS>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, count_lds, sink);
+    classify_finish<T, PAIRED, BLOCK, FULL, COUNTS, BINMODE>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, count_lds, sink);
 }
 
 template <int BLOCK>
@@ -261,7 +290,8 @@ __device__ __forceinline__ void count_lds_clear(uint32_t *count_lds)
 
 // COUNTS: the fused form (xm_classify_compact*): the workgroup also counts its units per category and per bin, so
 // the category bytes are not read again for a histogram; a granule = this workgroup's BLOCK*4 records.
-template <typename T, bool PAIRED, bool NT, int BLOCK, bool COUNTS>
+// BINMODE >= 0 (= the loop's mode): the kernel also writes the compact category stream bins4 and `code` may be null.
+template <typename T, bool PAIRED, bool NT, int BLOCK, bool COUNTS, int BINMODE>
 __global__ void __launch_bounds__(BLOCK)
 classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
                 const T *__restrict__ as2, const T *__restrict__ xs2,
@@ -273,9 +303,9 @@ classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
     if (COUNTS) count_lds_clear<BLOCK>(count_lds);
     // every workgroup but possibly the last covers BLOCK*4 existing records: no bounds tests on that path
     if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
-        classify_body<T, PAIRED, NT, BLOCK, true, COUNTS>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
+        classify_body<T, PAIRED, NT, BLOCK, true, COUNTS, BINMODE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
     else
-        classify_body<T, PAIRED, NT, BLOCK, false, COUNTS>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
+        classify_body<T, PAIRED, NT, BLOCK, false, COUNTS, BINMODE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,12 +519,10 @@ __device__ __forceinline__ void store_index(uint32_t *__restrict__ idx_out, uint
 }
 
 template <int SLOTS, bool WIDE>
-__device__ __forceinline__ void scatter_256(uint32_t w, const uint8_t *lut, uint32_t rec0, uint32_t base[7],
+__device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0, uint32_t base[7],
                                             uint32_t *__restrict__ idx_out, uint32_t n_units)
 {
-    uint32_t bin[4], pos[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bin[j] = ((SLOTS >> j) & 1) ? (uint32_t)lut[(w >> (8 * j)) & 63u] : 7u;
+    uint32_t pos[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
         uint64_t m[4], any = 0;
@@ -529,19 +557,22 @@ __device__ __forceinline__ void scatter_256(uint32_t w, const uint8_t *lut, uint
             store_index<WIDE>(idx_out, pos[j], rec0 + (uint32_t)j);
 }
 
-template <int NSUB, bool WIDE>
+// NIB: the categories come as the compact stream a counting K1 wrote (bins4: the bin itself, a nibble per record, 16 bits
+// per lane and 256 records, no table); otherwise as category bytes (one dword per lane and 256 records, the
+// byte -> bin rule of the mode in a 64-entry wave-private LDS table).
+template <int NSUB, bool WIDE, bool NIB>
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
                const uint32_t *__restrict__ gran_off, const unsigned long long *__restrict__ bin_totals,
                unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out)
 {
-    __shared__ uint8_t lut_all[XM_BLOCK / 64][64];
+    __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t g = blockIdx.x * (XM_BLOCK / 64) + wave;
     if (g >= n_gran) return;                                              // wave-uniform; no barrier in this kernel
-    uint8_t *lut = lut_all[wave];
-    lut[lane] = (uint8_t)bin_of_code(mode, lane == 63u ? XM_NO_UNIT : lane);
+    uint8_t *lut = lut_all[NIB ? 0 : wave];
+    if (!NIB) lut[lane] = (uint8_t)bin_of_code(mode, lane == 63u ? XM_NO_UNIT : lane);
 
     // lane b < 8: where bin b starts in idx_out (exclusive prefix of the bin totals) plus what the granules before
     // this one hold of it
@@ -560,20 +591,41 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
 
     const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
     uint32_t w[NSUB];
-    if (rec_g + NSUB * 256u <= n) {
+    if (NIB) {
+        // 16 bits per lane and 256 records; whole granule blocks exist (records past the end read as 7)
+        const uint16_t *nib = reinterpret_cast<const uint16_t *>(code) + (rec_g >> 2) + lane;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) w[s] = nib[s * 64];
+    } else if (rec_g + NSUB * 256u <= n) {
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) w[s] = *reinterpret_cast<const uint32_t *>(code + rec_g + s * 256u + lane * 4u);
     } else {
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) w[s] = load_codes4_tail(code, rec_g + s * 256u + lane * 4u, n);
     }
-    lds_settle();
+    if (!NIB) lds_settle();
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
         const uint32_t rec0 = (uint32_t)rec_g + (uint32_t)s * 256u + lane * 4u;
-        const bool even_free = (w[s] & 0x00FF00FFu) == 0x00FF00FFu;
-        if (__ballot(!even_free) == 0ull) scatter_256<0xA, WIDE>(w[s], lut, rec0, base, idx_out, n_units);
-        else scatter_256<0xF, WIDE>(w[s], lut, rec0, base, idx_out, n_units);
+        uint32_t bin[4];
+        bool even_free;
+        if (NIB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bin[j] = (w[s] >> (4 * j)) & 7u;
+            even_free = (w[s] & 0x0707u) == 0x0707u;
+        } else {
+            even_free = (w[s] & 0x00FF00FFu) == 0x00FF00FFu;
+        }
+        if (__ballot(!even_free) == 0ull) {                               // strictly interleaved mates: positions 1 and 3 only
+            if (!NIB) { bin[0] = bin[2] = 7u; bin[1] = lut[(w[s] >> 8) & 63u]; bin[3] = lut[(w[s] >> 24) & 63u]; }
+            scatter_256<0xA, WIDE>(bin, rec0, base, idx_out, n_units);
+        } else {
+            if (!NIB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bin[j] = lut[(w[s] >> (8 * j)) & 63u];
+            }
+            scatter_256<0xF, WIDE>(bin, rec0, base, idx_out, n_units);
+        }
     }
 }
 
@@ -850,8 +902,8 @@ __device__ __forceinline__ void classify_cigar_body(
     }
     // no fused counting here: this kernel runs at the rate its eleven concurrent streams get out of HBM, and the counting
     // epilogue cost it 36-45 us per 50 M pairs -- more than the separate histogram pass (30 us) it would save
-    const CountSink none = {nullptr, nullptr, 0u, 0};
-    classify_finish<int32_t, PAIRED, BLOCK, FULL, false>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, nullptr, none);
+    const CountSink none = {nullptr, nullptr, nullptr, 0u, 0};
+    classify_finish<int32_t, PAIRED, BLOCK, FULL, false, -1>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, nullptr, none);
 }
 
 template <bool PAIRED, int BLOCK>
@@ -940,6 +992,7 @@ static CountSink make_sink(const CountPlan *cp, int mode)
     CountSink s;
     s.gran_counts = cp ? cp->gran_counts : nullptr;
     s.counts_rep = cp ? reinterpret_cast<unsigned long long *>(cp->counts_rep) : nullptr;
+    s.bins4 = cp ? cp->bins4 : nullptr;
     s.gran_stride = cp ? cp->plan.gran_stride : 0u;
     s.mode = mode;
     return s;
@@ -955,9 +1008,14 @@ static void launch_classify_t(hipStream_t st, int mode, uint64_t n,
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
     const CountSink sink = make_sink(cp, mode);
     const bool paired = mode != XM_MODE_SE;
-#define XM_LAUNCH_CLS(P, C) classify_kernel<T, P, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK, C><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n, sink)
-    if (cp) { if (paired) XM_LAUNCH_CLS(true, true); else XM_LAUNCH_CLS(false, true); }
-    else    { if (paired) XM_LAUNCH_CLS(true, false); else XM_LAUNCH_CLS(false, false); }
+#define XM_LAUNCH_CLS(P, C, B) classify_kernel<T, P, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK, C, B><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n, sink)
+    if (cp && cp->bins4) {
+        if (mode == XM_MODE_SE) XM_LAUNCH_CLS(false, true, XM_MODE_SE);
+        else if (mode == XM_MODE_PE_LIBERAL) XM_LAUNCH_CLS(true, true, XM_MODE_PE_LIBERAL);
+        else XM_LAUNCH_CLS(true, true, XM_MODE_PE_CONSERVATIVE);
+    }
+    else if (cp) { if (paired) XM_LAUNCH_CLS(true, true, -1); else XM_LAUNCH_CLS(false, true, -1); }
+    else         { if (paired) XM_LAUNCH_CLS(true, false, -1); else XM_LAUNCH_CLS(false, false, -1); }
 #undef XM_LAUNCH_CLS
 }
 
@@ -1013,15 +1071,16 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
     }
 }
 
-void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code,
+void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out)
 {
     const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
     const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
-#define XM_LAUNCH_SCT(NSUB, W) scatter_kernel<NSUB, W><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_off, bt, bo, idx_out)
-    if (wide) XM_LAUNCH_SCT(XM_GRAN / 256, true); else XM_LAUNCH_SCT(XM_GRAN / 256, false);
+#define XM_LAUNCH_SCT(W, NIB) scatter_kernel<XM_GRAN / 256, W, NIB><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_off, bt, bo, idx_out)
+    if (code_is_bins4) { if (wide) XM_LAUNCH_SCT(true, true); else XM_LAUNCH_SCT(false, true); }
+    else               { if (wide) XM_LAUNCH_SCT(true, false); else XM_LAUNCH_SCT(false, false); }
 #undef XM_LAUNCH_SCT
 }
 
