@@ -417,6 +417,9 @@ def main():
                                     "se": "configs[0]'s kernel shape at size: single-end loop over 2 x %d reads per GPU, every "
                                           "record a unit (%s ignored), columns resident in HBM"}[args.workload]
                                    % (n_pairs, args.mode),
+                       "job": ("%d read pairs in all, one %d-pair read block per GPU%s" % (world * n_pairs, n_pairs,
+                               " = BASELINE.json configs[3] (400 M pairs sharded across 8 GPUs, RCCL count all-reduce)"
+                               if world * n_pairs == 400_000_000 and world == 8 and args.workload == "cfg2" else "")),
                        "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": n,
                        "step": ("A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)" if unfused else
                                 "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % ("_cigar" if cig is not None else "")),

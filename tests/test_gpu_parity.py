@@ -675,3 +675,43 @@ def test_beyond_2_30_records_the_wide_scatter(ctx, mode):
     ctx.compact_dev(mode, code[:n], idx2, off, counts)
     torch.cuda.synchronize()
     assert torch.equal(idx2[:units], idx[:units]) and torch.equal(counts.cpu(), want_counts)
+
+
+def test_fused_call_is_graph_capturable(ctx):
+    """The *_dev entry points only enqueue work: one fused call captured into a HIP graph and replayed on fresh inputs
+    gives what the eager call gives (include/xenomapper_hip.h: "graph-capturable")."""
+    import torch
+    from xenomapper_amd import _ffi
+    dev = torch.device("cuda:0")
+    n = 300_001
+    rng = np.random.default_rng(4242)
+    mode = 2
+    bits = H.synth.pack_unit_bits(rng.random(n) < 0.5)
+    d_bits = torch.from_numpy(bits.view(np.int64)).to(dev)
+    d_cols = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4)]
+    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                   # warm-up outside the capture, as torch asks for
+        ctx.classify_compact_dev(mode, *d_cols, d_bits, -3, code, idx, off, counts, bins4=bins4)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        ctx.classify_compact_dev(mode, *d_cols, d_bits, -3, code, idx, off, counts, bins4=bins4)
+    for seed in (1, 2, 3):
+        cols = random_columns(np.random.default_rng(seed), n)
+        for d, c in zip(d_cols, cols):
+            d.copy_(torch.from_numpy(c))
+        graph.replay()
+        torch.cuda.synchronize()
+        want_code, want_counts = H.c_classify(mode, *cols, bits, -3)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        assert np.array_equal(code[:n].cpu().numpy(), want_code)
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+        assert np.array_equal(idx[:int(want_off[7])].cpu().numpy().view(np.uint32), want_idx)
