@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=50_000_000, help="read pairs per GPU")
+    ap.add_argument("--strong-total", type=int, default=0, metavar="PAIRS",
+                    help="strong scaling instead: PAIRS read pairs in all, PAIRS / N per GPU (SURVEY 8d: 400000000)")
     ap.add_argument("--mode", choices=("liberal", "conservative"), default=None)
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5", "f64", "se"), default="cfg2",
                     help="BASELINE.json configs[1] (default, the quoted metric), [2] --cigar_scores path, [4] HISAT ZS + "
@@ -221,6 +223,8 @@ def main():
         n_ranks_seen = int(allreduce(one, dist.ReduceOp.SUM).item()) if world > 1 else 1
 
     n_pairs = args.pairs
+    if args.strong_total:
+        n_pairs = (args.strong_total // world + 3) // 4 * 4          # a read block per GPU, whole 64-record words of the unit mask
     n = 2 * n_pairs
     if args.mode is None:
         args.mode = "conservative" if args.workload == "cfg5" else "liberal"
@@ -404,7 +408,7 @@ def main():
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "collective_backend": backend,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong_total else "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": {"cfg2": "configs[1]: %d paired-end 2x150 bp read pairs per GPU, AS/XS present, %s "
                                            "pair rule, min_score=-inf, score columns resident in HBM",
