@@ -171,3 +171,18 @@ def test_write_bytes_reaches_every_kind_of_sink(tmp_path):
     s = io.StringIO()
     xm._write_bytes(s, data[:77])
     assert s.getvalue() == body[:77].decode("ascii")
+
+
+def test_usage_error_prints_the_reference_help(capsys, monkeypatch):
+    """No inputs: the error line, the help text and exit status 1, byte for byte what the reference's command line
+    prints (G9 `no_inputs_is_a_usage_error`, recorded from the reference run as a child process).  Needs no GPU."""
+    import hashlib
+    from xenomapper_amd import xenomapper as xm
+    case = {c["name"]: c for c in H.golden("g9_cli.json")["cases"]}["no_inputs_is_a_usage_error"]
+    monkeypatch.setenv("COLUMNS", "80")
+    with pytest.raises(SystemExit) as exc:
+        xm.main([])
+    assert exc.value.code == case["returncode"] == 1
+    out = capsys.readouterr().out
+    assert out.startswith("ERROR: You must provide --primary_sam and --secondary_sam")
+    assert (hashlib.sha224(out.encode("latin-1")).hexdigest(), len(out)) == (case["stdout"]["sha224"], case["stdout"]["len"])

@@ -1077,57 +1077,78 @@ def conservative_main_paired_end(readpairs, primary_specific=sys.stdout, seconda
 # command line (same flags as ref :568-678; wiring as ref :681-743)
 # --------------------------------------------------------------------------------------------
 
+# Prose of the command line (`xenomapper --help`, and what the usage error prints): the reference's own wording, kept
+# byte for byte (xenomapper.py:570-668) because scripts and users read it; argparse re-flows the argument help, the
+# description and epilogue are printed raw.
+_CLI_DESCRIPTION = (
+    "A script for parsing pairs of sam files and returning sam files\n"
+    "containing only reads where no better mapping exist in other files.\n"
+    "Used for filtering reads where multiple species may contribute \n"
+    "(eg human tissue xenografted into mouse, pathogen growing on plant).\n"
+    "\n"
+    "Files should contain an AS and XS score and better matches must have\n"
+    "a higher alignment score (but can be negative).\n"
+    "Reads must be in the same order in both species.\n"
+    "\n"
+    "In practice this is best acchieved by using Bowtie2 in --local mode.\n"
+    "If the -p option is used you must also use --reorder.\n"
+    "\n"
+    "Limited support is provided for aligners that do not produce AS and XS\n"
+    "score tags via the --cigar_score option.\n"
+    "\n"
+    "All input files must be seekable\n"
+    "(ie not a FIFO, process substitution or pipe)'\n")
+_CLI_EPILOG = (
+    "To output bam files in a bash shell use process subtitution:\n"
+    "    xenomapper --primary_specific >(samtools view -bS - > outfilename.bam) \n"
+    "\n"
+    "This program is distributed in the hope that it will be useful,\n"
+    "but WITHOUT ANY WARRANTY; without even the implied warranty of\n"
+    "MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE.\n\n"
+    "\n")
+_SAM_IN = "a %s format Bowtie2 mapping output file corresponding to the %s"
+_SAM_OUT = "name for SAM format output file for %s"
+_CLI_ARGUMENTS = (          # (flag, kind, help); kinds: rt / rb / wt file types, flag, float
+    ("primary_sam", "rt", _SAM_IN % ("SAM", "primary species of interest")),
+    ("secondary_sam", "rt", _SAM_IN % ("SAM", "secondary or contaminating species")),
+    ("primary_bam", "rb", _SAM_IN % ("BAM", "primary species of interest")),
+    ("secondary_bam", "rb", _SAM_IN % ("BAM", "secondary or contaminating species")),
+    ("primary_specific", "wt", _SAM_OUT % "reads mapping to a specific location in the primary species"),
+    ("secondary_specific", "wt", _SAM_OUT % "reads mapping to a specific location in the secondary species"),
+    ("primary_multi", "wt", _SAM_OUT % "reads multi mapping in the primary species"),
+    ("secondary_multi", "wt", _SAM_OUT % "reads multi mapping in the secondary species"),
+    ("unassigned", "wt", _SAM_OUT % "unassigned (non-mapping) reads"),
+    ("unresolved", "wt", _SAM_OUT % "unresolved (maps equally well in both species) reads"),
+    ("paired", "flag", "the SAM files consist of paired reads with forward and reverse reads occuring once and interlaced"),
+    ("conservative", "flag", "conservatively allocate paired end reads with discordant category allocations. Only pairs "
+     "that are both specific, or specific and multi will be allocated as specific. Pairs that are discordant for "
+     "species will be deemed unresolved.  Pairs where any read is unassigned will be deemed unassigned."),
+    ("min_score", "float", "the minimum mapping score.  Reads with scores less than or equal to min_score will be "
+     "considered unassigned. Values should be chosen based on the mapping program and read length"),
+    ("cigar_scores", "flag", "Use the cigar line and the NM tag to calculate a score. For aligners that do not support "
+     "the AS tag. No determination of multimapping state will be done.  Reads that are unique in one species and "
+     "multimap in the other species may be misassigned as no score can be calculated in the multimapping species. "
+     "Score is -6 * mismatches + -5 * indel open + -3 * indel extend + -2 * softclip. Treatment of multimappers "
+     "will vary with aligner.  If multimappers are assigned a cigar line they will be treated as species specific, "
+     "otherwise as unassigned."),
+    ("use_zs", "flag", "Use the value of the ZS tag in place of XS for determining the mapping score of the next best "
+     "alignment.  Used with HISAT as the XS:A tag is conventionally used for strand in spliced mappers."),
+    ("version", "flag", "print version information and exit"),
+)
+
+
 def command_line_interface(*args, **kw):
-    parser = argparse.ArgumentParser(
-        prog="xenomapper", formatter_class=argparse.RawDescriptionHelpFormatter,
-        description=textwrap.dedent("""\
-            Sort reads that were aligned to two genomes (e.g. a human xenograft grown in mouse, a
-            pathogen on its host) into species specific, multimapping, unresolved and unassigned
-            SAM files by comparing the alignment scores of each read in both species.
-
-            Both inputs must hold the same reads in the same order with AS and XS score tags where
-            higher is better (Bowtie2 --local; with -p also use --reorder).  Aligners without AS/XS
-            are supported through --cigar_scores.  Inputs must be seekable files.
-
-            This build evaluates the scores on an AMD MI355X GPU."""),
-        epilog=textwrap.dedent("""\
-            To write BAM from a bash shell use process substitution:
-                xenomapper --primary_specific >(samtools view -bS - > outfilename.bam)
-            """))
-    rt, wt = argparse.FileType("rt"), argparse.FileType("wt")
-    parser.add_argument("--primary_sam", type=rt, default=None,
-                        help="SAM file of the reads aligned to the primary species of interest")
-    parser.add_argument("--secondary_sam", type=rt, default=None,
-                        help="SAM file of the same reads aligned to the secondary or contaminating species")
-    parser.add_argument("--primary_bam", type=argparse.FileType("rb"), default=None,
-                        help="BAM file of the reads aligned to the primary species (needs samtools)")
-    parser.add_argument("--secondary_bam", type=argparse.FileType("rb"), default=None,
-                        help="BAM file of the same reads aligned to the secondary species (needs samtools)")
-    parser.add_argument("--primary_specific", type=wt, default=sys.stdout,
-                        help="SAM output: reads mapping to a specific location in the primary species")
-    parser.add_argument("--secondary_specific", type=wt, default=None,
-                        help="SAM output: reads mapping to a specific location in the secondary species")
-    parser.add_argument("--primary_multi", type=wt, default=None,
-                        help="SAM output: reads multi mapping in the primary species")
-    parser.add_argument("--secondary_multi", type=wt, default=None,
-                        help="SAM output: reads multi mapping in the secondary species")
-    parser.add_argument("--unassigned", type=wt, default=None,
-                        help="SAM output: unassigned (non-mapping) reads")
-    parser.add_argument("--unresolved", type=wt, default=None,
-                        help="SAM output: unresolved reads (map equally well in both species)")
-    parser.add_argument("--paired", action="store_true",
-                        help="the SAM files hold paired reads, forward and reverse once each and interlaced")
-    parser.add_argument("--conservative", action="store_true",
-                        help="conservative allocation of pairs whose mates disagree: species-discordant pairs "
-                             "are unresolved and pairs with an unassigned mate are unassigned")
-    parser.add_argument("--min_score", type=float, default=float("-inf"),
-                        help="reads scoring less than or equal to this are considered unassigned")
-    parser.add_argument("--cigar_scores", action="store_true",
-                        help="derive the score from the CIGAR string and the NM tag (-6 per mismatch, -5 per "
-                             "indel open, -3 per indel base, -2 per soft clipped base) for aligners without AS")
-    parser.add_argument("--use_zs", action="store_true",
-                        help="take the next-best score from the ZS tag instead of XS (HISAT)")
-    parser.add_argument("--version", action="store_true", help="print version information and exit")
+    """The reference's command line (xenomapper.py:568-678): same flags, defaults, help and usage-error behaviour."""
+    parser = argparse.ArgumentParser(prog="xenomapper", formatter_class=argparse.RawDescriptionHelpFormatter,
+                                     description=_CLI_DESCRIPTION, epilog=_CLI_EPILOG)
+    for flag, kind, text in _CLI_ARGUMENTS:
+        if kind == "flag":
+            parser.add_argument("--" + flag, action="store_true", help=text)
+        elif kind == "float":
+            parser.add_argument("--" + flag, type=float, default=float("-inf"), help=text)
+        else:
+            parser.add_argument("--" + flag, type=argparse.FileType(kind),
+                                default=sys.stdout if flag == "primary_specific" else None, help=text)
     ns = parser.parse_args(*args, **kw)
     if ns.version:
         print(__version__)
