@@ -157,16 +157,17 @@ def e2e_h2d_inclusive(ctx, mode, host_cols, pairs, reps=3):
             "what": "xm_classify_compact on pageable host arrays: H2D 32.25 B/pair, fused pass, D2H 4 B/pair (bin lists)"}
 
 
-def e2e_sam_text(pairs=2_000_000):
-    """SAM text in -> six SAM files out through the file fast path (C++ stripper -> GPU -> C++ writer), outputs on
-    tmpfs.  Never `value`."""
+def e2e_sam_text(pairs=2_000_000, to_files=True):
+    """SAM text in -> six SAM files out through the file fast path (C++ stripper -> GPU -> C++ writer); outputs on
+    tmpfs (`to_files`) or /dev/null (what is left is parser-bound).  Never `value`."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import bench_e2e
-    out_dir = "/dev/shm" if os.path.isdir("/dev/shm") else None
-    r = bench_e2e.run(pairs=pairs, threads=0, mode="liberal", workdir="/dev/shm" if out_dir else "/tmp", out_dir=out_dir)
+    shm = os.path.isdir("/dev/shm")
+    r = bench_e2e.run(pairs=pairs, threads=0, mode="liberal", workdir="/dev/shm" if shm else "/tmp",
+                      out_dir=("/dev/shm" if shm else "/tmp") if to_files else None)
     return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"],
             "seconds": round(r["seconds"], 4), "outputs": r["outputs"], "output_bytes": r["output_bytes"],
-            "what": "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> stripper -> H2D -> fused pass -> D2H -> six SAM files"}
+            "what": "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> stripper -> H2D -> fused pass -> D2H -> six SAM outputs"}
 
 
 def main():
@@ -461,10 +462,11 @@ def main():
                 e2e["h2d_inclusive"] = e2e_h2d_inclusive(ctx, mode, hc, min(n_pairs, 25_000_000))
             except Exception as e:                               # noqa: BLE001
                 e2e["h2d_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            try:
-                e2e["sam_text"] = e2e_sam_text()
-            except Exception as e:                               # noqa: BLE001
-                e2e["sam_text"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            for key, to_files in (("sam_text", True), ("sam_text_devnull", False)):
+                try:
+                    e2e[key] = e2e_sam_text(to_files=to_files)
+                except Exception as e:                           # noqa: BLE001
+                    e2e[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             line["e2e"] = e2e
     # The same reduction through the library's own RCCL communicator (xm_allreduce_counts, the C ABI's collective), on
     # every rank, after everything else and under a watchdog: the job total above came from torch.distributed, so
