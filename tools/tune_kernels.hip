@@ -1,7 +1,8 @@
-// tune_kernels.hip -- on-box A/B harness (not shipped): round-1 kernels (frozen copy, tools/legacy) against the
-// current ones, interleaved in one process (guide rule 24); prints median/min per variant and checks that old and
-// new produce identical category bytes, counts, offsets and index lists.
-//   tools/build_tune.sh && /tmp/tune [n_records] [rounds]
+// tune_kernels.hip -- on-box A/B harness (not shipped): variants of the kernels interleaved in one process (guide rule
+// 24); prints median/min per variant.  Before timing, the three forms of the pipeline (fused with category bytes,
+// two calls with the stand-alone histogram, fused with the compact category stream) must agree bit for bit.
+// (Round 2 also linked a frozen copy of the round-1 kernels for same-box old-vs-new runs: profiles/r02_tune_*.txt.)
+//   tools/build_tune.sh && /tmp/tune [n_records] [rounds] [mode] [interleaved]     XM_TUNE_ONLY=substr XM_TUNE_TRACE=1
 #include "../xenomapper_amd/csrc/xm_kernels.hip"
 
 #include <algorithm>
@@ -9,20 +10,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-
-// round-1 launchers (tools/legacy/xm_kernels_r01.hip compiled with -Dxm=xm_r01)
-namespace xm_r01 {
-struct ChunkPlan { uint32_t n_chunks; uint32_t chunk_stride; };
-ChunkPlan plan_chunks(uint64_t n);
-void launch_classify_i32(hipStream_t st, int mode, uint64_t n, const int32_t *as1, const int32_t *xs1, const int32_t *as2,
-                         const int32_t *xs2, const uint64_t *unit_bits, int32_t m, uint8_t *code);
-void launch_hist(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code, uint32_t *chunk_counts,
-                 uint64_t *counts_rep);
-void launch_scan(hipStream_t st, const ChunkPlan &p, const uint32_t *chunk_counts, uint32_t *chunk_off, uint64_t *bin_totals,
-                 uint64_t *counts_rep, uint64_t *counts);
-void launch_scatter(hipStream_t st, const ChunkPlan &p, int mode, uint64_t n, const uint8_t *code, const uint32_t *chunk_off,
-                    const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out);
-}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -52,11 +39,6 @@ static void nib_scatter() { auto cp = cplan(); xm::launch_scatter(0, cp.plan, MO
 static void nib_fused() { for (int r = 0; r < 4; ++r) { nib_classify_counts(); new_scan(); nib_scatter(); } }
 static void nib_fused_code() { for (int r = 0; r < 4; ++r) { nib_classify_counts_code(); new_scan(); nib_scatter(); } }
 
-static void old_classify() { xm_r01::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE_OLD); }
-static void old_hist() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_hist(0, p, MODE, N, CODE_OLD, CC_OLD, REP_OLD); }
-static void old_scan() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_scan(0, p, CC_OLD, CO_OLD, REP_OLD + 64 * 64, REP_OLD, COUNTS_OLD); }
-static void old_scatter() { auto p = xm_r01::plan_chunks(N); xm_r01::launch_scatter(0, p, MODE, N, CODE_OLD, CO_OLD, REP_OLD + 64 * 64, BINOFF_OLD, IDX_OLD); }
-static void old_pipeline() { for (int r = 0; r < 4; ++r) { old_classify(); old_hist(); old_scan(); old_scatter(); } }
 
 static void new_classify() { xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, nullptr); }
 static void new_classify_counts() { auto cp = cplan(); xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE, &cp); }
@@ -124,6 +106,14 @@ static void run_read() { read_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((co
 static int32_t *SK[4][4];        // [skew variant][column]
 template <int V> static void skew_classify() { xm::launch_classify_i32(0, MODE, N, SK[V][0], SK[V][1], SK[V][2], SK[V][3], BITS, INT32_MIN, CODE, nullptr); }
 template <int V> static void skew_read() { read_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((const xm::v4i32 *)SK[V][0], (const xm::v4i32 *)SK[V][1], (const xm::v4i32 *)SK[V][2], (const xm::v4i32 *)SK[V][3], (uint32_t *)CODE, N / 4); }
+// the reference the other forms are compared with: classify without counting, stand-alone histogram, scan, scatter
+static void ref_chain() {
+    xm::CountPlan cp; cp.plan = xm::plan_granules(N); cp.gran_counts = CC_OLD; cp.counts_rep = REP_OLD; cp.part_tot = PART;
+    xm::launch_classify_i32(0, MODE, N, A1, X1, A2, X2, BITS, INT32_MIN, CODE_OLD, nullptr);
+    xm::launch_hist(0, MODE, N, CODE_OLD, cp);
+    xm::launch_scan(0, cp, CO_OLD, REP_OLD + 64 * 64, COUNTS_OLD);
+    xm::launch_scatter(0, cp.plan, MODE, N, CODE_OLD, false, CO_OLD, REP_OLD + 64 * 64, BINOFF_OLD, IDX_OLD);
+}
 static void run_copy() { copy_like<<<(unsigned)((N / 4 + 255) / 256), 256>>>((const xm::v4i32 *)A1, (const xm::v4i32 *)X1, (const xm::v4i32 *)A2, (const xm::v4i32 *)X2, (uint32_t *)CODE, N / 4); }
 
 
@@ -329,8 +319,8 @@ int main(int argc, char **argv)
         printf("column bases A1 %p X1 %p A2 %p X2 %p\n", (void *)A1, (void *)X1, (void *)A2, (void *)X2);
     }
 
-    // correctness first: old chain, new fused chain, new unfused chain
-    old_classify(); old_hist(); old_scan(); old_scatter();
+    // correctness first: the two-call chain as the reference, then the fused forms against it
+    ref_chain();
     new_classify_counts(); new_scan(); new_scatter();
     bool ok = compare_outputs("fused K1+counts/scan/scatter");
     CK(hipMemset(IDX, 0xEE, N * 4)); CK(hipMemset(COUNTS, 0xEE, 512)); CK(hipMemset(BINOFF, 0xEE, 64)); CK(hipMemset(CODE, 0xEE, N));
@@ -350,7 +340,6 @@ int main(int argc, char **argv)
         {"copy_like NT", run_copy, cls}, {"read_like NT", run_read, 16.0 * N},
         {"read skew 0", skew_read<0>, 16.0 * N}, {"read skew 4K", skew_read<1>, 16.0 * N}, {"read skew 68K", skew_read<2>, 16.0 * N}, {"read skew 1M+", skew_read<3>, 16.0 * N},
         {"classify skew 0", skew_classify<0>, cls}, {"classify skew 4K", skew_classify<1>, cls}, {"classify skew 68K", skew_classify<2>, cls}, {"classify skew 1M+", skew_classify<3>, cls},
-        {"r01 classify", old_classify, cls}, {"r01 hist", old_hist, (double)N}, {"r01 scan", old_scan, 0}, {"r01 scatter", old_scatter, 3.0 * N},
         {"r02 classify", new_classify, cls}, {"r02 classify+counts", new_classify_counts, cls}, {"r02 hist", new_hist, (double)N},
         {"r02 scan", new_scan, 0}, {"scan 1 launch", scan_variant<true>, 0}, {"scan 2 launches", scan_variant<false>, 0},
         {"fused x4 scan1", scanv_fused<true>, 4 * step}, {"fused x4 scan2", scanv_fused<false>, 4 * step}, {"r02 scatter", new_scatter, 3.0 * N},
@@ -359,7 +348,7 @@ int main(int argc, char **argv)
         {"abl scatter arith-decode", abl_scatter<4>, 3.0 * N}, {"abl scatter no-guard", abl_scatter<5>, 3.0 * N},
         {"stream write 4B/unit", run_stream_write, 2.0 * N}, {"stream write 16B/lane", run_stream_write16, 2.0 * N},
         {"stream write 16B nt", run_stream_write16_nt, 2.0 * N},
-        {"r01 pipeline x4", old_pipeline, 4 * step}, {"r02 unfused x4", new_unfused, 4 * step}, {"r02 fused x4", new_fused, 4 * step}, {"bins4 fused x4", nib_fused, 4 * step}, {"bins4+code fused x4", nib_fused_code, 4 * step},
+ {"r02 unfused x4", new_unfused, 4 * step}, {"r02 fused x4", new_fused, 4 * step}, {"bins4 fused x4", nib_fused, 4 * step}, {"bins4+code fused x4", nib_fused_code, 4 * step},
         {"bins4 classify+counts", nib_classify_counts, cls}, {"bins4 scatter", nib_scatter, 2.5 * N}, {"r02 fused x4 2-stream", new_fused_2stream, 4 * step},
         {"fused x4 pipelined", new_fused_pipelined<4>, 4 * step}, {"fused x8 serial", new_fused_serial<8>, 8 * step},
         {"fused x8 pipelined", new_fused_pipelined<8>, 8 * step},
@@ -385,7 +374,7 @@ int main(int argc, char **argv)
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     // the timed launches left the buffers in a consistent state again? (run the chains once more and compare)
-    old_classify(); old_hist(); old_scan(); old_scatter();
+    ref_chain();
     new_classify_counts(); new_scan(); new_scatter();
     ok = compare_outputs("after timing, fused");
     auto off = fetch(BINOFF, 8);
