@@ -186,3 +186,28 @@ def test_usage_error_prints_the_reference_help(capsys, monkeypatch):
     out = capsys.readouterr().out
     assert out.startswith("ERROR: You must provide --primary_sam and --secondary_sam")
     assert (hashlib.sha224(out.encode("latin-1")).hexdigest(), len(out)) == (case["stdout"]["sha224"], case["stdout"]["len"])
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """include/*.h are the drop-in boundary: they must compile as C99 (no C++-isms outside the extern "C" guards), with
+    warnings as errors, and as C++17; a C program links every declared symbol of the HIP library without a GPU."""
+    import subprocess
+    src = tmp_path / "use_headers.c"
+    names = _declared("xenomapper_hip.h")
+    src.write_text('#include "xenomapper_hip.h"\n#include "xenomapper_host.h"\n'
+                   "typedef void (*fn)(void);\n"
+                   "static const fn table[] = {" + ", ".join("(fn)%s" % n for n in names) + "};\n"
+                   "int main(void) { return (XM_ABI_VERSION == xm_abi_version() && table[0] && "
+                   "XM_BINS4_BYTES(2049) == 2048u && XM_UNIQUE_ID_BYTES == 128) ? 0 : 1; }\n")
+    inc = os.path.join(H.REPO, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src),
+                           "-o", str(tmp_path / "c99.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", str(src),
+                           "-o", str(tmp_path / "cxx.o")])
+    from xenomapper_amd import _ffi, build
+    build.build_hip()
+    exe = tmp_path / "use_headers"
+    libdir = os.path.dirname(_ffi.LIB_PATH)
+    subprocess.check_call(["gcc", str(tmp_path / "c99.o"), "-o", str(exe), "-L", libdir, "-l:libxenomapper_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib"])
+    assert subprocess.call([str(exe)]) == 0

@@ -63,8 +63,11 @@ def test_int_path(ctx, n, seed, mode, kind, mkind, m):
     idx, off, counts2 = ctx.compact(mode, code)
     want_idx, want_off = H.c_compact(mode, want)
     assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx) and np.array_equal(counts2, want_counts)
-    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m)
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m)            # category bytes between K1 and K2c
     assert np.array_equal(fcode, want) and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m, want_code=False)   # the compact stream instead
+    assert fcode is None and np.array_equal(fcounts, want_counts)
     assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
 
 
@@ -82,8 +85,11 @@ def test_f64_path(ctx, n, seed, mode, m):
     idx, off, _ = ctx.compact(mode, code)
     want_idx, want_off = H.c_compact(mode, want)
     assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx)
-    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m)
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m)            # category bytes between K1 and K2c
     assert np.array_equal(fcode, want) and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
+    fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, m, want_code=False)   # the compact stream instead
+    assert fcode is None and np.array_equal(fcounts, want_counts)
     assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
 
 
