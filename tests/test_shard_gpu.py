@@ -132,3 +132,26 @@ def test_config4_eight_blocks_with_halo_full_size(pairs_per_block):
             del local, lf, bits
     assert np.array_equal(total, want_counts)
     assert int(total.sum()) == n // 2 - 1
+
+
+def test_bench_starts_its_own_ranks():
+    """The driver's command shape, `python bench.py --gpus N ...` from a plain start: bench.py must bring up N ranks
+    itself and print exactly one JSON line.  Two ranks sharing this box's GPU over gloo (XM_BENCH_REHEARSAL=1; the
+    RCCL build of the same path needs N GPUs), small batch."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, XM_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                           "--pairs", "1000000", "--no-cpu-baseline", "--no-e2e"], env=env, capture_output=True, text=True,
+                          timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    assert rec["verified_vs_oracle"] is True
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 1_000_000 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+    assert {"roofline", "roofline_step", "kernel_ms", "config"} <= set(rec)
