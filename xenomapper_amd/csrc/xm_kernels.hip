@@ -3,9 +3,10 @@
 // Three stages, all HBM-bound integer/byte work (no MFMA):
 //   K1 classify   score columns -> one category byte per record     (16 B in, 1 B out / record)
 //                 fused form: K1 also counts its units per category and per bin (LDS histogram, last wave flushes)
-//   K2 compact    category bytes -> category_counts + a stable split of unit indices by bin
-//                 K2a histogram (only when the bytes come from memory: wave-private LDS) -> per-granule bin counts
-//                 K2b scan of the per-granule counts (one workgroup per bin)
+//                 and can emit the compact category stream instead (the output bin as a nibble per record)
+//   K2 compact    categories -> category_counts + a stable split of unit indices by bin
+//                 K2a histogram (only when category bytes come from memory: wave-private LDS) -> per-granule bin counts
+//                 K2b scan of the per-granule counts, two levels (part sums, then one workgroup per part and bin)
 //                 K2c scatter: ballot + mbcnt ranks, scalar per-bin bases -> dense index runs, no LDS staging
 //   K3 cigar      NM + packed CIGAR (CSR) -> synthesised AS column
 //
