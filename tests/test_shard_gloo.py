@@ -123,3 +123,9 @@ def test_halo_keeps_overlapping_units():
 def test_sharded_equals_unsharded_gloo(world):
     run_world(world, 50_007, 1)
     run_world(world, 4_100, 2)
+
+
+def test_eight_ranks_like_config_4():
+    """BASELINE.json configs[3]'s shape -- eight read blocks, one per rank, halo at every cut, one all-reduce -- at a
+    size the CPU runs in seconds (the full 400 M pairs: tests/test_shard_gpu.py)."""
+    run_world(8, 80_011, 1)
