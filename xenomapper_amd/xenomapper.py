@@ -463,6 +463,18 @@ def _classify_block(ctx, mode, block, n, vals, nm, ops, cigar_mode, min_score):
     return ctx.classify_compact(mode, *fcols, bits, float(min_score))
 
 
+def _add_counts(totals, key_order, paired, code, counts):
+    """Add a block's category_counts to the run's Counter.  Keys keep the order in which the reference's Counter would
+    have met them (first occurrence in the input): only categories not seen in an earlier block need looking for."""
+    new = []
+    for c in np.flatnonzero(counts).tolist():
+        key = STATE_NAMES[c] if not paired else (STATE_NAMES[c >> 3], STATE_NAMES[c & 7])
+        if key not in totals:
+            new.append((int(np.argmax(code == c)), key))            # first record holding category c
+        totals[key] += int(counts[c])
+    key_order.extend(key for _, key in sorted(new))
+
+
 def _lines_of(block, mode, b, i):
     """Records a unit contributes to bin b (ref :332-350, :423-448, :521-550)."""
     if mode == _ffi.MODE_SE:
@@ -555,13 +567,7 @@ def _run(mode, readpairs, sinks, min_score, tag_func):
                 _emit_block(block, mode, code, idx, off, sinks, limit)
                 if state_error is not None:
                     raise state_error
-                unit_codes = code[code != _ffi.NO_UNIT]
-                uniq, first_at = np.unique(unit_codes, return_index=True)
-                for c in uniq[np.argsort(first_at)].tolist():
-                    key = STATE_NAMES[c] if not paired else (STATE_NAMES[c >> 3], STATE_NAMES[c & 7])
-                    if key not in totals:
-                        key_order.append(key)
-                    totals[key] += int(counts[c])
+                _add_counts(totals, key_order, paired, code, counts)
         if pending_error is not None:
             raise pending_error
 
@@ -883,13 +889,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 _emit_shared(parser, paired, code, idx, off, sinks, limit)
             if state_error is not None:
                 raise state_error
-            unit_codes = code[code != _ffi.NO_UNIT]
-            uniq, first_at = np.unique(unit_codes, return_index=True)
-            for c in uniq[np.argsort(first_at)].tolist():
-                key = STATE_NAMES[c] if not paired else (STATE_NAMES[c >> 3], STATE_NAMES[c & 7])
-                if key not in totals:
-                    key_order.append(key)
-                totals[key] += int(counts[c])
+            _add_counts(totals, key_order, paired, code, counts)
         return pending
 
     which = 0
