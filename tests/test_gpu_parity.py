@@ -715,3 +715,27 @@ def test_fused_call_is_graph_capturable(ctx):
         assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
         assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
         assert np.array_equal(idx[:int(want_off[7])].cpu().numpy().view(np.uint32), want_idx)
+
+
+def test_c_example_through_the_c_abi(tmp_path):
+    """examples/classify_pairs.c (plain C99, no Python, no torch in the process): one xm_classify_compact call on three
+    read pairs; its printout against the oracle's result for the same columns."""
+    import subprocess
+    from tests.test_host_cpu import _build_c_example
+    proc = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stderr
+    as1 = np.array([200, 198, 80, 90, ABSENT, ABSENT], np.int32)
+    xs1 = np.array([150, ABSENT, ABSENT, 70, ABSENT, ABSENT], np.int32)
+    as2 = np.array([120, ABSENT, 190, 188, ABSENT, ABSENT], np.int32)
+    xs2 = np.array([ABSENT, ABSENT, 190, 188, ABSENT, ABSENT], np.int32)
+    code, counts = H.c_classify(1, as1, xs1, as2, xs2, np.array([0x2A], np.uint64), ABSENT)
+    idx, off = H.c_compact(1, code)
+    want = []
+    for c in np.flatnonzero(counts):
+        want.append("count (%s, %s) = %d" % (H.STATES[c >> 3], H.STATES[c & 7], counts[c]))
+    for b in range(6):
+        for i in idx[int(off[b]):int(off[b + 1])]:
+            want.append("bin %s: records %d and %d" % (H.STATES[b], i - 1, i))
+    want += ["code[%d] = 0x%02X" % (i, c) for i, c in enumerate(code)]
+    assert proc.stdout.splitlines() == want
+    assert any("primary_specific" in l for l in want) and any("secondary_multi" in l for l in want)

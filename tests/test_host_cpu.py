@@ -211,3 +211,24 @@ def test_public_headers_are_plain_c(tmp_path):
     subprocess.check_call(["gcc", str(tmp_path / "c99.o"), "-o", str(exe), "-L", libdir, "-l:libxenomapper_hip.so",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib"])
     assert subprocess.call([str(exe)]) == 0
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    from xenomapper_amd import _ffi, build
+    build.build_hip()
+    exe = tmp_path / "classify_pairs"
+    libdir = os.path.dirname(_ffi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(H.REPO, "include"),
+                           os.path.join(H.REPO, "examples", "classify_pairs.c"), "-L", libdir, "-l:libxenomapper_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-o", str(exe)])
+    return str(exe)
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-GPU behaviour")
+def test_c_example_refuses_without_a_device(tmp_path):
+    """examples/classify_pairs.c is plain C99 against include/xenomapper_hip.h; without a gfx950 device xm_ctx_create
+    fails and the program says so -- no CPU fallback behind the C ABI either."""
+    import subprocess
+    proc = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert proc.returncode == 2 and "gfx950" in proc.stderr and proc.stdout == ""
