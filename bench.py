@@ -353,6 +353,10 @@ def main():
     host_cols = None
     if not args.no_verify:
         from tests import helpers as H
+        if rank == 0:
+            H.c_oracle()                       # (re)builds oracle/libxm_oracle.so if stale: once, not in N ranks at a time
+        if world > 1:
+            dist.barrier()
         host_cols = {k: v.cpu().numpy() for k, v in cols.items()}
         host_cols["unit_bits"] = host_cols["unit_bits"].view(np.uint64)
         if cig is not None:
