@@ -39,7 +39,11 @@ def c_oracle():
     so = os.path.join(REPO, "oracle", "libxm_oracle.so")
     src = os.path.join(REPO, "oracle", "xm_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s"])
+        import fcntl
+        with open(os.path.join(REPO, "oracle", ".build.lock"), "w") as lock:       # several ranks may get here at once
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s"])
     lib = ctypes.CDLL(so)
     i32, u64, f64 = ctypes.c_int32, ctypes.c_uint64, ctypes.c_double
     P = ctypes.c_void_p
