@@ -405,6 +405,13 @@ def main():
                 traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, replayed; not measured in this run)" % pmc_name
             except Exception:
                 traffic = None
+        step_traffic = None
+        if args.workload == "cfg2" and n_pairs == 50_000_000 and not unfused and not category_bytes:
+            try:
+                with open(os.path.join(REPO, "profiles", "pmc_step.json")) as fh:
+                    step_traffic = json.load(fh).get("hbm_bytes_per_step")
+            except Exception:
+                step_traffic = None
         ms_per_step = 1e3 * elapsed / args.steps
         line = {
             "metric": "reads/sec classified" if args.workload == "se" else "read-pairs/sec classified",
@@ -445,6 +452,8 @@ def main():
                               "algorithmic_bytes_per_unit": bytes_per_unit + bytes_per_unit_compact,
                               "sum_kernel_ms": round(sum_ms, 5), "achieved": step_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": step_achieved / HBM_PEAK_GBPS,
+                              "traffic": step_traffic,
+                              "traffic_source": "profiles/pmc_step.json (replayed)" if step_traffic else None,
                               "frac_by_ms_per_step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region (scan = its two launches)",
             "verified_vs_oracle": verified,
