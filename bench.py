@@ -157,7 +157,7 @@ def e2e_h2d_inclusive(ctx, mode, host_cols, pairs, reps=3):
             "what": "xm_classify_compact on pageable host arrays: H2D 32.25 B/pair, fused pass, D2H 4 B/pair (bin lists)"}
 
 
-def e2e_sam_text(pairs=2_000_000, to_files=True):
+def e2e_sam_text(pairs=4_000_000, to_files=True):
     """SAM text in -> six SAM files out through the file fast path (C++ stripper -> GPU -> C++ writer); outputs on
     tmpfs (`to_files`) or /dev/null (what is left is parser-bound).  Never `value`."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
