@@ -238,7 +238,8 @@ def main():
     bytes_per_unit = BYTES_PER_PAIR_CLASSIFY
     bytes_per_unit_compact = BYTES_PER_PAIR_COMPACT
     dtype = "int32"
-    cig = None
+    cig = cigp = None
+    cigar_csr = os.environ.get("XM_BENCH_CIGAR_CSR") == "1"     # A/B only: the CSR-column kernel (K1c + stand-alone histogram)
     if args.workload == "cfg3":
         # no AS tag: AS is synthesised in-kernel from NM + CIGAR (CSR); XS mostly absent
         cig = [synth.cigar_columns_torch(n, seed=3003 + 2 * rank, device=dev),
@@ -250,7 +251,12 @@ def main():
         cols = {"xs1": xs1, "xs2": torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
                 "unit_bits": torch.from_numpy(synth.interleaved_unit_bits(n).view(np.int64)).to(dev)}
         k_bar = (cig[0]["cig_oplen"].numel() + cig[1]["cig_oplen"].numel()) / (2.0 * n)
-        bytes_per_unit = 4 * (12 + 4 * k_bar) + 1            # per record and species NM + XS + offset + ops
+        if cigar_csr:
+            bytes_per_unit = 4 * (12 + 4 * k_bar) + 1        # per record and species NM + XS + offset + ops
+        else:
+            # packed CIGAR columns: NM + XS + one count byte per record and species, one tile base per 256 records, the ops
+            cigp = [synth.cigar_pack_torch(c) for c in cig]
+            bytes_per_unit = 4 * (9 + 1.0 / 64 + 4 * k_bar) + 1
         range_flag = torch.zeros(4, dtype=torch.int32, device=dev)
     else:
         cols = synth.score_columns_torch(n_pairs, seed=(5005 if args.workload == "cfg5" else 2002) + rank, device=dev,
@@ -268,7 +274,7 @@ def main():
     code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
     bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)      # compact category stream: a nibble per record
     # XM_BENCH_CATEGORY_BYTES=1 (A/B): the per-record output of the step is the category byte (fwd*8+rev) instead
-    category_bytes = os.environ.get("XM_BENCH_CATEGORY_BYTES") == "1" or args.workload == "cfg3"
+    category_bytes = os.environ.get("XM_BENCH_CATEGORY_BYTES") == "1" or (args.workload == "cfg3" and cigar_csr)
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     off = torch.zeros(8, dtype=torch.int64, device=dev)
     n_slots = max(args.steps, args.warmup, 1)
@@ -296,7 +302,13 @@ def main():
             return step_unfused()
         counts = step_counts[step_no[0] % n_slots]
         step_no[0] += 1
-        if cig is not None:
+        if cigp is not None:
+            ctx.classify_compact_cigar_packed_dev(mode, cigp[0]["nm"], cigp[0]["cig_cnt"], cigp[0]["cig_tile"], cigp[0]["cig_oplen"],
+                                                  cols["xs1"], cigp[1]["nm"], cigp[1]["cig_cnt"], cigp[1]["cig_tile"],
+                                                  cigp[1]["cig_oplen"], cols["xs2"], cols["unit_bits"], floor_min,
+                                                  code if category_bytes else None, idx, off, counts,
+                                                  bins4=None if category_bytes else bins4, range_flag=range_flag)
+        elif cig is not None:
             ctx.classify_compact_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
                                            cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"],
                                            cols["unit_bits"], floor_min, code, idx, off, counts, range_flag=range_flag)
@@ -374,8 +386,14 @@ def main():
             for b in range(7):
                 want_bins[want_idx[int(want_off[b]):int(want_off[b + 1])]] = b
             ok_bins = bool((_ffi.unpack_bins4(bins4.cpu().numpy(), n) == want_bins).all())
-            ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min,
-                                     code, idx, off, counts, bins4=bins4)
+            if cigp is not None:
+                ctx.classify_compact_cigar_packed_dev(mode, cigp[0]["nm"], cigp[0]["cig_cnt"], cigp[0]["cig_tile"], cigp[0]["cig_oplen"],
+                                                      cols["xs1"], cigp[1]["nm"], cigp[1]["cig_cnt"], cigp[1]["cig_tile"],
+                                                      cigp[1]["cig_oplen"], cols["xs2"], cols["unit_bits"], floor_min,
+                                                      code, idx, off, counts, bins4=bins4, range_flag=range_flag)
+            else:
+                ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min,
+                                         code, idx, off, counts, bins4=bins4)
             torch.cuda.synchronize()
         else:
             ok_bins = True
@@ -425,7 +443,7 @@ def main():
             "config": {"workload": {"cfg2": "configs[1]: %d paired-end 2x150 bp read pairs per GPU, AS/XS present, %s "
                                            "pair rule, min_score=-inf, score columns resident in HBM",
                                     "cfg3": "configs[2]: %d paired-end pairs per GPU on the --cigar_scores path (no AS/XS; NM + "
-                                            "CIGAR as CSR, AS synthesised in the classify kernel), %s pair rule, columns resident in HBM",
+                                            "CIGAR ops in " + ("CSR" if cigar_csr else "packed") + " columns, AS synthesised in the classify kernel), %s pair rule, columns resident in HBM",
                                     "cfg5": "configs[4]: %d paired-end pairs per GPU, HISAT-style scores with ZS as second-best "
                                             "(AS=0/ZS=0 present), %s pair rule, columns resident in HBM",
                                     "f64": "configs[1] columns as binary64 (the reference's own arithmetic; used for non-integral "
@@ -438,13 +456,13 @@ def main():
                                if world * n_pairs == 400_000_000 and world == 8 and args.workload == "cfg2" else "")),
                        "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": n,
                        "step": ("A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)" if unfused else
-                                "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % ("_cigar" if cig is not None else "")),
+                                "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % ("_cigar_packed" if cigp is not None else "_cigar" if cig is not None else "")),
                        "category_per_record": ("category byte (fwd*8+rev, 1 B per record)" if category_bytes or unfused else
                                                "compact stream bins4: the output bin as a nibble per record = 1 B per pair (SURVEY 8d's "
                                                "algorithmic figure); the category byte is produced on request and checked outside the timed region"),
                        "sharding": "read-block per GPU, no halo exchange" + (", one RCCL all-reduce of the final category_counts" if world > 1 else "")},
             "roofline": {"bound": "hbm",
-                         "kernel": "classify_cigar_kernel<paired, counts>" if cig is not None else "classify_kernel<%s, %s, counts>" % (dtype, "single" if args.workload == "se" else "paired"),
+                         "kernel": "classify_cigp_kernel<paired, counts, bins4>" if cigp is not None else "classify_cigar_kernel<paired>" if cig is not None else "classify_kernel<%s, %s, counts>" % (dtype, "single" if args.workload == "se" else "paired"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_unit": bytes_per_unit, "kernel_ms": cls_ms},

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XM_ABI_VERSION 2
+#define XM_ABI_VERSION 3
 
 #define XM_ABSENT   INT32_MIN
 #define XM_NO_UNIT  0xFFu
@@ -223,12 +223,54 @@ int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_
                                 const uint64_t *unit_bits, double min_score, uint8_t *code_out, uint8_t *bins4,
                                 uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
 
-/* The --cigar_scores form: code_out required (the CIGAR kernel does not count; the compaction reads its bytes). */
+/* The --cigar_scores form on CSR columns: code_out required (this kernel does not count; the compaction reads its bytes).
+ * The faster form is xm_classify_compact_cigar_packed_dev below. */
 int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
                                   const int32_t *nm1, const uint32_t *cig_off1, const uint32_t *cig_oplen1, const int32_t *xs1,
                                   const int32_t *nm2, const uint32_t *cig_off2, const uint32_t *cig_oplen2, const int32_t *xs2,
                                   const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
                                   uint32_t *range_flag, uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
+
+/*
+ * Packed CIGAR columns -- the layout the --cigar_scores kernel reads fastest (get_cigarbased_AS_tag, xenomapper.py:228-256;
+ * the CIGAR scan of :251 as pre-parsed ops).  Per species:
+ *   nm, xs        as above (int32 per record)
+ *   cig_cnt       one BYTE per record: its number of CIGAR ops; 255 = "255 or more"
+ *   cig_tile      XM_CIG_TILES(n_records) + 1 words: cig_tile[t] = where in cig_oplen the ops of records
+ *                 [256 t, 256 t + 256) begin (records in order, ops of a record contiguous); the last entry = length of
+ *                 cig_oplen in words
+ *   cig_oplen     the packed ops (len << 4 | op); a record with cig_cnt 255 is followed by ONE trailer word
+ *                 n_ops << 4 | 15 (op code 15 scores nothing), so its begin can be found from its end
+ * i.e. 9 + 1/64 bytes per record and species next to the ops, against the 12 of the CSR form (4-byte offsets), and the
+ * position of a tile's ops is known without reading a per-record column.  xm_cigar_pack() converts CSR columns (host
+ * memory, no device needed): it fills cig_cnt[n_records] and cig_tile[XM_CIG_TILES(n_records) + 1], stores the length
+ * of the packed op array in *n_ops_packed and, when ops_packed is not NULL (capacity in words: ops_capacity), writes the
+ * packed op array.  When *n_ops_packed == cig_off[n_records] no record needed a trailer and the packed op array IS
+ * cig_oplen: call with ops_packed = NULL first and skip the copy.  XM_ERR_RANGE: a record with 2^28 ops or more, or more
+ * than 2^32 - 1 packed ops.
+ */
+#define XM_CIG_TILE 256u
+#define XM_CIG_TILES(n_records) (((uint64_t)(n_records) + 255u) / 256u)
+int xm_cigar_pack(uint64_t n_records, const uint32_t *cig_off, const uint32_t *cig_oplen,
+                  uint8_t *cig_cnt, uint32_t *cig_tile, uint32_t *ops_packed, uint64_t ops_capacity,
+                  uint64_t *n_ops_packed);
+
+/*
+ * One whole main loop with tag_func = get_cigarbased_AS_tag (xenomapper.py:684-685, :228-256, and the loop bodies
+ * :321-350, :398-452, :498-554) on device-resident packed CIGAR columns: AS of both species is synthesised inside the
+ * classify kernel, which also counts (category_counts, per-granule bin counts) and writes the per-record output in
+ * either form (code_out and/or bins4, at least one -- as xm_classify_compact_dev); then scan + scatter.  range_flag:
+ * one device uint32, set non-zero when a synthesised score left int32 (may be NULL).  nm/xs 16-byte aligned, the
+ * other columns 4-byte aligned.  No read goes past cig_tile[last] words of cig_oplen whatever the columns hold.
+ * The host-buffer entry points xm_classify_cigar / xm_classify_compact_cigar take CSR columns, pack them and run this.
+ */
+int xm_classify_compact_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                                         const int32_t *nm1, const uint8_t *cig_cnt1, const uint32_t *cig_tile1,
+                                         const uint32_t *cig_oplen1, const int32_t *xs1,
+                                         const int32_t *nm2, const uint8_t *cig_cnt2, const uint32_t *cig_tile2,
+                                         const uint32_t *cig_oplen2, const int32_t *xs2,
+                                         const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
+                                         uint32_t *range_flag, uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
 
 /* ---- multi-GPU: the one collective of the path ------------------------------------------ */
 /*

@@ -140,3 +140,29 @@ def c_mate_correlate(track, density):
     d = density if density.shape[0] else np.zeros(1)
     lib.xmo_mate_correlate(track.shape[0], ptr(t), density.shape[0], ptr(d), ptr(out if out.shape[0] else np.zeros(1)))
     return out
+
+
+def np_cigar_pack(cig_off, cig_oplen):
+    """Independent restatement (plain Python/NumPy) of the packed CIGAR column layout of include/xenomapper_hip.h: a
+    byte of op count per record (255 = 255 or more, the record's ops are then followed by a trailer word
+    n_ops << 4 | 15), the op position of every 256-record tile, the packed op array.  The checker for xm_cigar_pack."""
+    off = np.asarray(cig_off, dtype=np.int64)
+    ops = np.asarray(cig_oplen, dtype=np.uint32)
+    n = off.shape[0] - 1
+    k = np.diff(off)
+    cnt = np.minimum(k, 255).astype(np.uint8)
+    stretch = k + (k >= 255)                                   # ops + trailer
+    begin = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(stretch, out=begin[1:])
+    n_tiles = (n + 255) // 256
+    tile = np.empty(n_tiles + 1, dtype=np.uint32)
+    tile[:n_tiles] = begin[0:n:256]
+    tile[n_tiles] = begin[n]
+    if not (k >= 255).any():
+        return cnt, tile, ops[:int(off[n])].copy()
+    packed = np.empty(int(begin[n]), dtype=np.uint32)
+    for i in range(n):                                          # small inputs only
+        packed[begin[i]:begin[i] + k[i]] = ops[off[i]:off[i + 1]]
+        if k[i] >= 255:
+            packed[begin[i] + k[i]] = (int(k[i]) << 4) | 15
+    return cnt, tile, packed

@@ -358,6 +358,159 @@ def test_classify_cigar_guards_of_the_op_parallel_path(ctx, flavour):
         assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
 
 
+def _packed_on_device(c, xs):
+    import torch
+    from xenomapper_amd import _ffi
+    cnt, tile, ops = _ffi.cigar_pack(c["cig_off"], c["cig_oplen"])
+    wcnt, wtile, wops = H.np_cigar_pack(c["cig_off"], c["cig_oplen"]) if c["nm"].shape[0] <= 200_000 else (cnt, tile, ops)
+    assert np.array_equal(cnt, wcnt) and np.array_equal(tile, wtile) and np.array_equal(ops, wops)
+    dev = torch.device("cuda:0")
+    if ops.shape[0] == 0:
+        ops = np.zeros(1, dtype=np.uint32)
+    if cnt.shape[0] == 0:
+        cnt = np.zeros(4, dtype=np.uint8)
+    return [torch.from_numpy(a).to(dev) for a in (c["nm"], cnt, tile.view(np.int32), ops.view(np.int32), xs)]
+
+
+def _check_packed_dev(ctx, mode, c1, xs1, c2, xs2, bits, mi, forms=("code", "bins4", "both")):
+    """xm_classify_compact_cigar_packed_dev in its output forms against the oracle (CIGAR scores from the CSR
+    columns, classify, compact)."""
+    import torch
+    from xenomapper_amd import _ffi
+    n = c1["nm"].shape[0]
+    dev = torch.device("cuda:0")
+    want, want_counts = _oracle_cigar_classify(mode, c1, xs1, c2, xs2, bits, mi)
+    want_idx, want_off = H.c_compact(mode, want)
+    want_bins = np.full(n, 7, dtype=np.uint8)
+    for b in range(7):
+        want_bins[want_idx[int(want_off[b]):int(want_off[b + 1])]] = b
+    d = _packed_on_device(c1, xs1) + _packed_on_device(c2, xs2) + [torch.from_numpy(bits.view(np.int64)).to(dev)]
+    for form in forms:
+        code = torch.full((n + 16,), 0xAA, dtype=torch.uint8, device=dev) if form != "bins4" else None
+        bins4 = torch.full((_ffi.bins4_bytes(n),), 0xAA, dtype=torch.uint8, device=dev) if form != "code" else None
+        idx = torch.full((max(n, 1),), -1, dtype=torch.int32, device=dev)
+        off = torch.zeros(8, dtype=torch.int64, device=dev)
+        counts = torch.zeros(64, dtype=torch.int64, device=dev)
+        flag = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.classify_compact_cigar_packed_dev(mode, *d, mi, code, idx, off, counts, bins4=bins4, range_flag=flag)
+        torch.cuda.synchronize()
+        assert int(flag[0].item()) == 0
+        if code is not None:
+            assert np.array_equal(code[:n].cpu().numpy(), want), form
+        if bins4 is not None:
+            assert np.array_equal(_ffi.unpack_bins4(bins4.cpu().numpy(), n), want_bins), form
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts), form
+        h_off = off.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(h_off, want_off), form
+        assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx), form
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 256, 257, 2047, 2048, 2049, 4097, 6145, 100_003])
+def test_classify_cigar_packed_dev(ctx, n):
+    """The packed-column kernel (K1p) through its device-resident entry point: all modes, a threshold, irregular
+    unit masks (so that workgroups begin with units: the halo), every output form."""
+    rng = np.random.default_rng(300 + n)
+    c1, c2 = _random_cigar(rng, n), _random_cigar(rng, n)
+    xs = [np.where(rng.random(n) < 0.8, ABSENT, -rng.integers(0, 200, n)).astype(np.int32) for _ in range(2)]
+    for mode, m in itertools.product((0, 1, 2), (NEG, -40.5)):
+        flags = rng.random(n) < (0.55 if mode else 0.9)
+        _check_packed_dev(ctx, mode, c1, xs[0], c2, xs[1], H.synth.pack_unit_bits(flags), H.floor_min_score(m))
+    if n > 1:                                                       # strictly interleaved mates: the fast scatter path
+        _check_packed_dev(ctx, 1, c1, xs[0], c2, xs[1], H.synth.interleaved_unit_bits(n), ABSENT)
+
+
+@pytest.mark.parametrize("flavour", ["escapes", "escape_before_workgroup", "all_escaped_tile", "dense_254", "no_ops"])
+def test_classify_cigar_packed_escapes(ctx, flavour):
+    """Records with 255 operations or more (count byte 255 + trailer word) and the other shapes only the careful path
+    of K1p serves: several escaped records in one tile, an escaped record right in front of a workgroup whose first
+    record closes a unit (the halo reads the trailer), a tile of escaped records, records of 254 operations (the
+    largest plain count; a tile of them is far beyond the 1024-op stretch), and no operations at all."""
+    n = 3 * 2048 + 300
+    rng = np.random.default_rng(11)
+    c1, c2 = _random_cigar(rng, n, max_ops=4), _random_cigar(rng, n, max_ops=4)
+
+    def set_ops(c, lengths):                                        # {record: number of ops}
+        k = np.diff(c["cig_off"].astype(np.int64))
+        for at, length in lengths.items():
+            k[at] = length
+        off = np.zeros(n + 1, dtype=np.uint32)
+        np.cumsum(k, out=off[1:])
+        c["cig_off"] = off
+        c["cig_oplen"] = (rng.integers(1, 9, int(off[-1])).astype(np.uint32) << 4) | rng.integers(0, 9, int(off[-1])).astype(np.uint32)
+        for at in lengths:
+            c["nm"][at] = 2
+    if flavour == "escapes":
+        set_ops(c1, {3: 255, 4: 256, 200: 1000, 255: 300, 256: 255, 2047: 511, 4096: 70000, n - 1: 255})
+        set_ops(c2, {3: 300, 1000: 255, 1001: 255, 1002: 255, n - 2: 400})
+    elif flavour == "escape_before_workgroup":
+        set_ops(c1, {2047: 260, 4095: 255})
+        set_ops(c2, {2047: 3, 4095: 999, 6143: 255})
+    elif flavour == "all_escaped_tile":
+        set_ops(c1, {at: 255 + (at % 3) for at in range(2048, 2048 + 256)})
+        set_ops(c2, {at: 256 for at in range(2048 + 128, 2048 + 384)})
+    elif flavour == "dense_254":
+        set_ops(c1, {at: 254 for at in range(512, 768)})
+        set_ops(c2, {at: 254 for at in range(700, 710)})
+    else:
+        c1["cig_off"][:] = 0
+        c1["cig_oplen"] = np.zeros(0, dtype=np.uint32)
+    xs = [np.where(rng.random(n) < 0.8, ABSENT, -rng.integers(0, 200, n)).astype(np.int32) for _ in range(2)]
+    flags = rng.random(n) < 0.6
+    flags[[2048, 4096, 6144]] = True                                # the first record of every later workgroup closes a unit
+    bits = H.synth.pack_unit_bits(flags)
+    for mode in (0, 1, 2):
+        _check_packed_dev(ctx, mode, c1, xs[0], c2, xs[1], bits, ABSENT, forms=("both",))
+    # and through the host-buffer entry points (CSR in; they pack and run the same kernel)
+    code, counts = ctx.classify_cigar(1, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs[0],
+                                      c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, ABSENT)
+    want, want_counts = _oracle_cigar_classify(1, c1, xs[0], c2, xs[1], bits, ABSENT)
+    assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+    fcode, fidx, foff, fcounts = ctx.classify_compact_cigar(1, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs[0],
+                                                            c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, ABSENT,
+                                                            want_code=False)
+    want_idx, want_off = H.c_compact(1, want)
+    assert fcode is None and np.array_equal(fcounts, want_counts)
+    assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
+
+
+def test_classify_cigar_packed_inconsistent_columns_stay_in_bounds(ctx):
+    """Columns that do not describe each other (random count bytes, a tile table that is not monotone or points past
+    the op array, escape bytes without trailers): the results mean nothing, but the kernel neither faults nor writes
+    outside its outputs -- guard words around every output stay intact and the unit bookkeeping stays consistent."""
+    import torch
+    from xenomapper_amd import _ffi
+    n = 4 * 2048 + 77
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    n_ops = 5000
+    for trial in range(6):
+        sp = []
+        for _ in range(2):
+            cnt = rng.integers(0, 256, n).astype(np.uint8) if trial % 2 == 0 else np.full(n, 255, dtype=np.uint8)
+            tile = rng.integers(0, 2 * n_ops, _ffi.cigar_tiles(n) + 1).astype(np.uint32)
+            if trial >= 3:
+                tile.sort()
+            tile[-1] = n_ops                                             # the length of the op array is honest
+            ops = rng.integers(0, 2**32, n_ops, dtype=np.uint64).astype(np.uint32)
+            nm = rng.integers(0, 5, n).astype(np.int32)
+            xs_ = np.full(n, ABSENT, dtype=np.int32)
+            sp += [torch.from_numpy(a).to(dev) for a in (nm, cnt, tile.view(np.int32), ops.view(np.int32), xs_)]
+        bits = torch.from_numpy(H.synth.pack_unit_bits(rng.random(n) < 0.7).view(np.int64)).to(dev)
+        guard = 64
+        code = torch.full((n + 16 + guard,), 0x5A, dtype=torch.uint8, device=dev)
+        bins4 = torch.full((_ffi.bins4_bytes(n) + guard,), 0x5A, dtype=torch.uint8, device=dev)
+        idx = torch.full((n + guard,), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+        off = torch.zeros(8, dtype=torch.int64, device=dev)
+        counts = torch.zeros(64, dtype=torch.int64, device=dev)
+        flag = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.classify_compact_cigar_packed_dev(1, *sp, bits, ABSENT, code, idx, off, counts, bins4=bins4, range_flag=flag)
+        torch.cuda.synchronize()
+        h_off = off.cpu().numpy()
+        assert int(h_off[7]) == int(counts.sum().item()) <= n and (np.diff(h_off) >= 0).all()
+        assert bool((code[n + 16:] == 0x5A).all()) and bool((bins4[_ffi.bins4_bytes(n):] == 0x5A).all())
+        assert bool((idx[n:] == 0x5A5A5A5A).all())
+
+
 def test_classify_cigar_range_error(ctx):
     big = np.array([((2**28 - 1) << 4) | 1] * 8, dtype=np.uint32)
     one = {"nm": np.array([0], np.int32), "off": np.array([0, 8], np.uint32)}
@@ -558,6 +711,25 @@ def test_full_size_cfg3_cigar(ctx):
     assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)
     k_bar = (c1["cig_oplen"].shape[0] + c2["cig_oplen"].shape[0]) / (2.0 * n)
     print("cfg3 mean CIGAR ops per record: %.3f -> algorithmic %.1f B/pair" % (k_bar, 4 * (12 + 4 * k_bar) + 6))
+
+
+def test_full_size_cfg3_cigar_packed(ctx):
+    """BASELINE.json configs[2] as bench.py --workload cfg3 runs it: 50 M pairs, packed CIGAR columns, ONE
+    xm_classify_compact_cigar_packed_dev call (K1p counts and writes the compact stream); exact against the C oracle."""
+    import torch
+    from xenomapper_amd import _ffi
+    n_pairs = 50_000_000
+    n = 2 * n_pairs
+    c1 = H.synth.cigar_columns(n, seed=3003)
+    c2 = H.synth.cigar_columns(n, seed=3004, mapped_p=0.3)
+    rng = np.random.default_rng(3005)
+    xs1 = np.where(rng.random(n) < 0.95, ABSENT, -rng.integers(0, 40, n)).astype(np.int32)
+    xs2 = np.full(n, ABSENT, dtype=np.int32)
+    bits = H.synth.interleaved_unit_bits(n)
+    _check_packed_dev(ctx, _ffi.MODE_PE_LIBERAL, c1, xs1, c2, xs2, bits, ABSENT, forms=("bins4",))
+    k_bar = (c1["cig_oplen"].shape[0] + c2["cig_oplen"].shape[0]) / (2.0 * n)
+    print("cfg3 mean CIGAR ops per record: %.3f -> algorithmic %.2f B/pair (classify), + 5 (compact)"
+          % (k_bar, 4 * (9 + 1 / 64 + 4 * k_bar) + 1))
 
 
 def test_full_size_cfg5_zs_conservative(ctx):

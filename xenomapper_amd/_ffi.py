@@ -106,6 +106,8 @@ def lib():
         "xm_classify_compact_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, P, P], I),
         "xm_classify_compact_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P, P], I),
         "xm_classify_compact_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P], I),
+        "xm_cigar_pack": ([U64, P, P, P, P, P, U64, ctypes.POINTER(U64)], I),
+        "xm_classify_compact_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P], I),
         "xm_comm_unique_id": ([P], I),
         "xm_comm_init": ([P, I, I, P], I),
         "xm_comm_destroy": ([P], I),
@@ -128,6 +130,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_classify_cigar",
             "xm_compact", "xm_classify_compact", "xm_classify_compact_f64", "xm_classify_compact_cigar", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
             "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
+            "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
@@ -139,6 +142,34 @@ def _np_ptr(a):
 def _as(a, dtype):
     a = np.ascontiguousarray(a, dtype=dtype)
     return a
+
+
+def cigar_tiles(n_records):
+    """XM_CIG_TILES: 256-record tiles of the packed CIGAR columns."""
+    return (int(n_records) + 255) // 256
+
+
+def cigar_pack(cig_off, cig_oplen):
+    """CSR CIGAR columns -> packed CIGAR columns (xm_cigar_pack; host only, no device): a byte of op count per record,
+    the op position of every 256-record tile, and the op array (the input array itself unless a record has 255 ops or
+    more and gets its trailer word).  -> (cig_cnt uint8[n], cig_tile uint32[tiles + 1], cig_oplen uint32[])"""
+    off = _as(cig_off, np.uint32)
+    ops = _as(cig_oplen, np.uint32)
+    n = off.shape[0] - 1
+    assert n >= 0 and ops.shape[0] >= int(off[-1])
+    cnt = np.empty(max(n, 1), dtype=np.uint8)
+    tile = np.empty(cigar_tiles(n) + 1, dtype=np.uint32)
+    n_packed = ctypes.c_uint64(0)
+    L = lib()
+    rc = L.xm_cigar_pack(n, _np_ptr(off), _np_ptr(ops), _np_ptr(cnt), _np_ptr(tile), None, 0, ctypes.byref(n_packed))
+    if rc == XM_OK and n_packed.value != int(off[-1]):
+        packed = np.empty(n_packed.value, dtype=np.uint32)
+        rc = L.xm_cigar_pack(n, _np_ptr(off), _np_ptr(ops), _np_ptr(cnt), _np_ptr(tile), _np_ptr(packed), packed.shape[0],
+                             ctypes.byref(n_packed))
+        ops = packed
+    if rc != XM_OK:
+        raise _ERRORS.get(rc, RuntimeError)("xm_cigar_pack: %s" % L.xm_strerror(rc).decode())
+    return cnt[:n], tile, ops[:n_packed.value]
 
 
 def comm_unique_id():
@@ -389,6 +420,18 @@ class Context(object):
             ctypes.c_void_p(idx_out.data_ptr()), ctypes.c_void_p(bin_offsets.data_ptr()),
             ctypes.c_void_p(counts.data_ptr()))
         self._check(rc, "xm_classify_compact_cigar_dev")
+
+    def classify_compact_cigar_packed_dev(self, mode, nm1, cnt1, tile1, ops1, xs1, nm2, cnt2, tile2, ops2, xs2, unit_bits,
+                                          min_score_floor, code_out, idx_out, bin_offsets, counts, bins4=None,
+                                          range_flag=None, stream=None):
+        """One whole --cigar_scores loop on device-resident PACKED CIGAR columns (cigar_pack): the classify kernel
+        synthesises AS, counts, and writes category bytes (code_out) and/or the compact stream (bins4)."""
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (nm1, cnt1, tile1, ops1, xs1, nm2, cnt2, tile2, ops2, xs2, unit_bits)]
+        opt = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None     # noqa: E731
+        rc = self._L.xm_classify_compact_cigar_packed_dev(
+            self._h, self._stream_handle(stream), mode, nm1.numel(), *ptrs, int(min_score_floor), opt(code_out), opt(bins4),
+            opt(range_flag), opt(idx_out), opt(bin_offsets), opt(counts))
+        self._check(rc, "xm_classify_compact_cigar_packed_dev")
 
     # ---- the count all-reduce (RCCL inside the library) -----------------------------------
     def comm_init(self, n_ranks, rank, unique_id):

@@ -250,6 +250,37 @@ int xm_ctx_device_info(const xm_ctx *ctx, int *n_cu, char *name, size_t name_len
     return XM_OK;
 }
 
+/* ---- packed CIGAR columns (host-side conversion; needs no device) -------------------------------------------- */
+
+int xm_cigar_pack(uint64_t n, const uint32_t *cig_off, const uint32_t *cig_oplen, uint8_t *cig_cnt, uint32_t *cig_tile,
+                  uint32_t *ops_packed, uint64_t ops_capacity, uint64_t *n_ops_packed)
+{
+    if (n > XM_MAX_RECORDS || !cig_tile || !n_ops_packed || (n && (!cig_off || !cig_cnt))) return XM_ERR_INVALID_ARG;
+    if (ops_packed && n && cig_off[n] && !cig_oplen) return XM_ERR_INVALID_ARG;
+    uint64_t pos = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if ((i & (XM_CIG_TILE - 1u)) == 0) {
+            if (pos > 0xFFFFFFFFull) return XM_ERR_RANGE;
+            cig_tile[i / XM_CIG_TILE] = (uint32_t)pos;
+        }
+        if (cig_off[i + 1] < cig_off[i]) return XM_ERR_INVALID_ARG;
+        const uint32_t k = cig_off[i + 1] - cig_off[i];
+        const bool esc = k >= 255u;
+        if (esc && k >= (1u << 28)) return XM_ERR_RANGE;
+        cig_cnt[i] = esc ? (uint8_t)255 : (uint8_t)k;
+        if (ops_packed) {
+            if (pos + k + (esc ? 1u : 0u) > ops_capacity) return XM_ERR_INVALID_ARG;
+            if (k) memcpy(ops_packed + pos, cig_oplen + cig_off[i], (size_t)k * sizeof(uint32_t));
+            if (esc) ops_packed[pos + k] = (k << 4) | 15u;
+        }
+        pos += (uint64_t)k + (esc ? 1u : 0u);
+    }
+    if (pos > 0xFFFFFFFFull) return XM_ERR_RANGE;
+    cig_tile[XM_CIG_TILES(n)] = (uint32_t)pos;
+    *n_ops_packed = pos;
+    return XM_OK;
+}
+
 /* ---- device-resident entry points ------------------------------------------------------ */
 
 int xm_classify_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
@@ -458,6 +489,36 @@ int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t 
     return xm_compact_dev(ctx, stream, mode, n, code_out, idx_out, bin_offsets, counts);
 }
 
+int xm_classify_compact_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                                         const int32_t *nm1, const uint8_t *cnt1, const uint32_t *tile1, const uint32_t *ops1,
+                                         const int32_t *xs1,
+                                         const int32_t *nm2, const uint8_t *cnt2, const uint32_t *tile2, const uint32_t *ops2,
+                                         const int32_t *xs2,
+                                         const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
+                                         uint32_t *range_flag, uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    if (!bin_offsets || !counts) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return empty_compact(ctx, st, bin_offsets, counts);
+    if (!nm1 || !cnt1 || !tile1 || !ops1 || !xs1 || !nm2 || !cnt2 || !tile2 || !ops2 || !xs2 || !unit_bits ||
+        (!code_out && !bins4) || !idx_out)
+        return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)nm1 | (uintptr_t)xs1 | (uintptr_t)nm2 | (uintptr_t)xs2 | (uintptr_t)code_out | (uintptr_t)bins4) & 15u) ||
+        (((uintptr_t)cnt1 | (uintptr_t)cnt2 | (uintptr_t)tile1 | (uintptr_t)tile2 | (uintptr_t)ops1 | (uintptr_t)ops2) & 3u))
+        return XM_ERR_INVALID_ARG;
+    xm::CountPlan cp = count_plan(ctx, n);
+    cp.bins4 = bins4;
+    const xm::CigCols s1 = {nm1, xs1, cnt1, tile1, ops1}, s2 = {nm2, xs2, cnt2, tile2, ops2};
+    int rc;
+    {
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_cigp(st, mode, n, s1, s2, unit_bits, min_score_floor, code_out, range_flag, cp);
+    }
+    if ((rc = check_launch(ctx, "classify_cigp_kernel")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code_out, cp, idx_out, bin_offsets, counts);
+}
+
 int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,
                           const double *density, double *out)
 {
@@ -575,6 +636,29 @@ int xm_cigar_scores(xm_ctx *ctx, uint64_t n, const int32_t *nm, const uint32_t *
     return flag ? XM_ERR_RANGE : XM_OK;
 }
 
+// CSR columns of one species, packed on the host (no copy of the ops unless a record has 255 ops or more)
+struct PackedSpecies {
+    std::vector<uint8_t> cnt;
+    std::vector<uint32_t> tile, ops_buf;
+    const uint32_t *ops;
+    uint64_t n_ops;
+};
+
+static int pack_species(uint64_t n, const uint32_t *off, const uint32_t *oplen, PackedSpecies &p)
+{
+    p.cnt.resize(n);
+    p.tile.resize(XM_CIG_TILES(n) + 1);
+    int rc = xm_cigar_pack(n, off, oplen, p.cnt.data(), p.tile.data(), nullptr, 0, &p.n_ops);
+    if (rc != XM_OK) return rc;
+    p.ops = oplen;
+    if (p.n_ops != off[n]) {                      // escaped records: the op array gets their trailer words
+        p.ops_buf.resize(p.n_ops);
+        rc = xm_cigar_pack(n, off, oplen, p.cnt.data(), p.tile.data(), p.ops_buf.data(), p.n_ops, &p.n_ops);
+        p.ops = p.ops_buf.data();
+    }
+    return rc;
+}
+
 static int classify_cigar_host(xm_ctx *ctx, int mode, uint64_t n,
                                const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
                                const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
@@ -588,17 +672,19 @@ static int classify_cigar_host(xm_ctx *ctx, int mode, uint64_t n,
     if (!nm1 || !off1 || !xs1 || !nm2 || !off2 || !xs2 || !unit_bits) return XM_ERR_INVALID_ARG;
     if (compact ? !idx_out : !code_out) return XM_ERR_INVALID_ARG;
     XM_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t n_ops1 = off1[n], n_ops2 = off2[n];
-    if ((n_ops1 && !ops1) || (n_ops2 && !ops2)) return XM_ERR_INVALID_ARG;
-    // one scratch slab: [nm1 | off1 | xs1 | nm2 | off2 | xs2 | bits | flag | ops1 | ops2], every piece 16-byte aligned
-    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t sz_col = up(n * 4), sz_off = up((n + 1) * 4), sz_bits = up(((n + 63) / 64) * 8);
-    const size_t total = 4 * sz_col + 2 * sz_off + sz_bits + 256 + up(n_ops1 * 4 + 4) + up(n_ops2 * 4 + 4);
+    if ((off1[n] && !ops1) || (off2[n] && !ops2)) return XM_ERR_INVALID_ARG;
+    // CSR -> packed columns (a byte per record instead of a 4-byte offset goes over PCIe, too)
+    PackedSpecies p1, p2;
     int rc;
+    if ((rc = pack_species(n, off1, ops1, p1)) != XM_OK || (rc = pack_species(n, off2, ops2, p2)) != XM_OK) return rc;
+    // one scratch slab: [nm1 | xs1 | nm2 | xs2 | cnt1 | cnt2 | tile1 | tile2 | bits | flag | ops1 | ops2], every piece 256-byte aligned
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sz_col = up(n * 4), sz_cnt = up(n + 4), sz_tile = up((XM_CIG_TILES(n) + 1) * 4), sz_bits = up(((n + 63) / 64) * 8);
+    const size_t total = 4 * sz_col + 2 * sz_cnt + 2 * sz_tile + sz_bits + 256 + up(p1.n_ops * 4 + 4) + up(p2.n_ops * 4 + 4);
     if ((rc = ensure_scratch(ctx, 0, total)) != XM_OK) return rc;
-    if ((rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 5, code_out ? (size_t)n + 16 : (size_t)XM_BINS4_BYTES(n))) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 6, (size_t)n * 4)) != XM_OK) return rc;
     if ((rc = ensure_scratch(ctx, 7, 72 * sizeof(uint64_t))) != XM_OK) return rc;
-    if (compact && (rc = ensure_scratch(ctx, 6, (size_t)n * 4)) != XM_OK) return rc;
     uint8_t *base = (uint8_t *)ctx->d_scratch[0];
     size_t o = 0;
     auto put = [&](const void *src, size_t bytes, size_t reserve) -> void * {
@@ -607,38 +693,32 @@ static int classify_cigar_host(xm_ctx *ctx, int mode, uint64_t n,
         if (bytes && src && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
         return d;
     };
-    void *d_nm1 = put(nm1, n * 4, sz_col), *d_off1 = put(off1, (n + 1) * 4, sz_off), *d_xs1 = put(xs1, n * 4, sz_col);
-    void *d_nm2 = put(nm2, n * 4, sz_col), *d_off2 = put(off2, (n + 1) * 4, sz_off), *d_xs2 = put(xs2, n * 4, sz_col);
+    void *d_nm1 = put(nm1, n * 4, sz_col), *d_xs1 = put(xs1, n * 4, sz_col);
+    void *d_nm2 = put(nm2, n * 4, sz_col), *d_xs2 = put(xs2, n * 4, sz_col);
+    void *d_cnt1 = put(p1.cnt.data(), n, sz_cnt), *d_cnt2 = put(p2.cnt.data(), n, sz_cnt);
+    void *d_tile1 = put(p1.tile.data(), p1.tile.size() * 4, sz_tile), *d_tile2 = put(p2.tile.data(), p2.tile.size() * 4, sz_tile);
     void *d_bits = put(unit_bits, ((n + 63) / 64) * 8, sz_bits);
     void *d_flag = put(nullptr, 0, 256);
-    void *d_ops1 = put(ops1, n_ops1 * 4, up(n_ops1 * 4 + 4)), *d_ops2 = put(ops2, n_ops2 * 4, up(n_ops2 * 4 + 4));
-    if (!d_nm1 || !d_off1 || !d_xs1 || !d_nm2 || !d_off2 || !d_xs2 || !d_bits || !d_ops1 || !d_ops2)
+    void *d_ops1 = put(p1.ops, p1.n_ops * 4, up(p1.n_ops * 4 + 4)), *d_ops2 = put(p2.ops, p2.n_ops * 4, up(p2.n_ops * 4 + 4));
+    if (!d_nm1 || !d_xs1 || !d_nm2 || !d_xs2 || !d_cnt1 || !d_cnt2 || !d_tile1 || !d_tile2 || !d_bits || !d_ops1 || !d_ops2)
         return fail_hip(ctx, hipGetLastError(), "hipMemcpy(cigar columns)");
     XM_HIP(ctx, hipMemset(d_flag, 0, 16));
-    uint8_t *d_code = (uint8_t *)ctx->d_scratch[5];
+    // the category bytes when the caller wants them, else the compact category stream (as classify_compact_host)
+    uint8_t *d_code = code_out ? (uint8_t *)ctx->d_scratch[5] : nullptr;
+    uint8_t *d_bins4 = code_out ? nullptr : (uint8_t *)ctx->d_scratch[5];
+    uint32_t *d_idx = (uint32_t *)ctx->d_scratch[6];
     uint64_t *d_off = (uint64_t *)ctx->d_scratch[7];
-    {
-        Span span(ctx, nullptr, XM_K_CLASSIFY);
-        xm::launch_classify_cigar(nullptr, mode, n, (const int32_t *)d_nm1, (const uint32_t *)d_off1, (const uint32_t *)d_ops1,
-                                  (const int32_t *)d_xs1, (const int32_t *)d_nm2, (const uint32_t *)d_off2,
-                                  (const uint32_t *)d_ops2, (const int32_t *)d_xs2, (const uint64_t *)d_bits,
-                                  min_score_floor, d_code, (uint32_t *)d_flag);
-    }
-    if ((rc = check_launch(ctx, "classify_cigar_kernel")) != XM_OK) return rc;
-    // the CIGAR kernel does not count: the histogram pass over its category bytes does
-    if (compact) {
-        rc = xm_compact_dev(ctx, nullptr, mode, n, d_code, (uint32_t *)ctx->d_scratch[6], d_off, d_off + 8);
-    } else if (counts) {
-        const xm::CountPlan cp = count_plan(ctx, n);
-        xm::launch_hist(nullptr, mode, n, d_code, cp);
-        if ((rc = check_launch(ctx, "hist_kernel")) == XM_OK) rc = counts_only_tail(ctx, cp, d_off + 8);
-    }
+    // the list split is cheap next to the copies, so the one fused entry point serves xm_classify_cigar as well
+    rc = xm_classify_compact_cigar_packed_dev(ctx, nullptr, mode, n, (const int32_t *)d_nm1, (const uint8_t *)d_cnt1,
+                                              (const uint32_t *)d_tile1, (const uint32_t *)d_ops1, (const int32_t *)d_xs1,
+                                              (const int32_t *)d_nm2, (const uint8_t *)d_cnt2, (const uint32_t *)d_tile2,
+                                              (const uint32_t *)d_ops2, (const int32_t *)d_xs2, (const uint64_t *)d_bits,
+                                              min_score_floor, d_code, d_bins4, (uint32_t *)d_flag, d_idx, d_off, d_off + 8);
     if (rc != XM_OK) return rc;
     uint32_t flag = 0;
     XM_HIP(ctx, hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
     if (flag) return XM_ERR_RANGE;
-    if (compact)
-        return fetch_compact_results(ctx, n, d_code, (const uint32_t *)ctx->d_scratch[6], d_off, code_out, idx_out, bin_offsets, counts);
+    if (compact) return fetch_compact_results(ctx, n, d_code, d_idx, d_off, code_out, idx_out, bin_offsets, counts);
     XM_HIP(ctx, hipMemcpy(code_out, d_code, (size_t)n, hipMemcpyDeviceToHost));
     if (counts) XM_HIP(ctx, hipMemcpy(counts, d_off + 8, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return XM_OK;

@@ -19,6 +19,7 @@
 #ifndef XM_CIGAR_BLOCK
 #define XM_CIGAR_BLOCK 256     // classify_cigar workgroup (128: 0.650, 256: 0.626, 512: 0.649, 1024: 0.754 ms per 50 M pairs)
 #endif
+#define XM_CIGP_BLOCK 512      // classify from packed CIGAR columns: workgroup = one granule (it counts)
 #define XM_CLASSIFY_NT true    // non-temporal loads of the score columns in classify
 
 namespace xm {
@@ -39,6 +40,15 @@ struct CountPlan {
 
 GranPlan plan_granules(uint64_t n);
 
+// packed CIGAR columns of one species (include/xenomapper_hip.h, "packed CIGAR columns")
+struct CigCols {
+    const int32_t *nm;          // [n] NM value, XM_ABSENT = no NM field
+    const int32_t *xs;          // [n]
+    const uint8_t *cnt;         // [n] ops of the record; 255 = 255 or more, the record's ops are followed by a trailer word
+    const uint32_t *tile;       // [ceil(n / 256) + 1] where the ops of each 256-record tile begin; last = length of ops
+    const uint32_t *ops;        // BAM-style len << 4 | op
+};
+
 // cp != nullptr: the fused form, the kernel also counts (granule = its workgroup)
 void launch_classify_i32(hipStream_t st, int mode, uint64_t n,
                          const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
@@ -50,6 +60,9 @@ void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
                            const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
                            const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
                            const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag);
+// the counting form only (workgroup = granule): category bytes and/or the compact stream (cp.bins4), counts, gran_counts
+void launch_classify_cigp(hipStream_t st, int mode, uint64_t n, const CigCols &s1, const CigCols &s2,
+                          const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag, const CountPlan &cp);
 void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, const CountPlan &cp);
 void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64_t *bin_totals, uint64_t *counts);
 // code_is_bins4: `code` is the compact category stream of a counting classify kernel, not category bytes

@@ -928,6 +928,269 @@ classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1p: classify from PACKED CIGAR columns (round 3; what the --cigar_scores path runs: xm_classify_compact_cigar*).
+// Same arithmetic as K1c (get_cigarbased_AS_tag :228-256 fused into the state function), other column contract:
+// per species and record NM (int32), XS (int32) and ONE BYTE -- the number of CIGAR ops of the record -- instead of
+// a 4-byte CSR offset; per tile of 256 records (= one wave) one u32, the position in the op array where the tile's
+// ops begin (cig_tile[n_tiles + 1]).  A record with 255 ops or more carries 255 and its ops are followed by one
+// trailer word (n_ops << 4 | 15: op code 15 scores nothing), so that every begin can be found from the tile's end.
+//
+// What that buys on the device: the tile base is wave-uniform (scalar loads), so the op stretch of the wave is known
+// before any per-record load comes back -- NM, XS, the counts and the first 512 ops of both species are all fetched
+// at once: ONE memory latency per wave instead of K1c's two (offsets, then ops).  The records' positions inside the
+// stretch are a DPP prefix sum of the counts.  Scores as in K1c: every lane turns 8 consecutive ops into penalty terms, a
+// DPP prefix sum of the terms goes to a per-wave LDS table T, a record's penalty is T[end] - T[begin].  The kernel
+// counts its units and writes the compact category stream exactly as the counting K1 does (workgroup = granule).
+// Anything unusual -- an escape byte, a tile with 1024 ops or more, an op of length >= 2^20, counts that do not add
+// up to the tile's stretch, the last (partial) workgroup -- is settled wave-uniformly by the bounds-checked per-record
+// path (cigp_slow), 64-bit accumulation, no read past cig_tile[n_tiles] whatever the columns hold.
+// ---------------------------------------------------------------------------------------------
+#define XM_CIGP_CHUNK 512u          // ops per prefix pass: 8 per lane
+
+struct TileOps {
+    uint32_t tb, te;                // the tile's stretch [tb, te) of the op array
+    uint32_t v[8];                  // ops tb + 8 lane .. + 7 (first chunk), 0 where past the stretch
+    bool fast;                      // wave-uniform: stretch sane, shorter than XM_CIG_WAVE_OPS
+};
+
+// ops [base + s0, base + s0 + 8) of a stretch of W ops; vector loads when the over-read (< 8 words) stays inside the array
+__device__ __forceinline__ void cigp_load8(const uint32_t *__restrict__ ops, uint32_t n_ops, uint32_t base, uint32_t W,
+                                           uint32_t s0, uint32_t v[8])
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0u;
+    if (base + W + 8u <= n_ops) {                                        // wave-uniform
+        if (s0 < W) {
+            const v4i32 a = *reinterpret_cast<const v4i32_a4 *>(ops + base + s0);
+            v[0] = (uint32_t)a.x; v[1] = (uint32_t)a.y; v[2] = (uint32_t)a.z; v[3] = (uint32_t)a.w;
+        }
+        if (s0 + 4u < W) {
+            const v4i32 b = *reinterpret_cast<const v4i32_a4 *>(ops + base + s0 + 4u);
+            v[4] = (uint32_t)b.x; v[5] = (uint32_t)b.y; v[6] = (uint32_t)b.z; v[7] = (uint32_t)b.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (s0 + (uint32_t)q < W) v[q] = ops[base + s0 + (uint32_t)q];
+    }
+}
+
+__device__ __forceinline__ void cigp_fetch_tile(const CigCols &s, uint32_t t, uint32_t n_ops, TileOps &o)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    o.tb = s.tile[t];                                                    // t is wave-uniform: scalar loads
+    o.te = s.tile[t + 1u];
+    o.fast = o.te >= o.tb && o.te <= n_ops && (o.te - o.tb) < (uint32_t)XM_CIG_WAVE_OPS;
+    if (o.fast) cigp_load8(s.ops, n_ops, o.tb, o.te - o.tb, 8u * lane, o.v);
+}
+
+// The usual case.  cw = the lane's four op counts (one byte each).  false: the wave must take cigp_slow.
+__device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, uint32_t n_ops, const TileOps &o, uint32_t cw,
+                                          const int32_t nmv[4], uint32_t *T, int32_t as_out[4], bool &bad)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t W = o.te - o.tb;
+    const uint32_t c0 = cw & 255u, c1 = (cw >> 8) & 255u, c2 = (cw >> 16) & 255u, c3 = cw >> 24;
+    const uint32_t lsum = c0 + c1 + c2 + c3;
+    const uint32_t incl = wave_scan_incl(lsum);
+    const bool esc = c0 == 255u || c1 == 255u || c2 == 255u || c3 == 255u;
+    if (lane_value(incl, 63) != W || __ballot(esc) != 0ull) return false;
+    bool odd = false;
+    uint32_t carry = 0;
+    for (uint32_t c = 0; c * XM_CIGP_CHUNK <= W; ++c) {                  // slot W (the grand total) is written too
+        const uint32_t s0 = c * XM_CIGP_CHUNK + 8u * lane;
+        uint32_t v[8];
+        if (c == 0u) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = o.v[q];
+        } else {
+            cigp_load8(ops, n_ops, o.tb, W, s0, v);
+        }
+        uint32_t p[8], run = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            p[q] = run;                                                  // exclusive inside the lane
+            odd |= (v[q] >> 4) >= (1u << 20);                            // slots past the stretch hold 0
+            run += cigar_term32(v[q]);
+        }
+        const uint32_t tincl = wave_scan_incl(run);
+        const uint32_t ex = tincl - run + carry;
+        *reinterpret_cast<uint4 *>(T + s0) = make_uint4(ex + p[0], ex + p[1], ex + p[2], ex + p[3]);
+        *reinterpret_cast<uint4 *>(T + s0 + 4u) = make_uint4(ex + p[4], ex + p[5], ex + p[6], ex + p[7]);
+        carry += lane_value(tincl, 63);
+    }
+    if (__ballot(odd) != 0ull) return false;
+    const uint32_t b0 = incl - lsum, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2, b4 = b3 + c3;      // <= W < XM_CIG_WAVE_OPS
+    const uint32_t t0 = T[b0], t1 = T[b1], t2 = T[b2], t3 = T[b3], t4 = T[b4];
+    const uint32_t d[4] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long sc = -6ll * (long long)nmv[j] - (long long)d[j];
+        const bool present = nmv[j] != INT32_MIN;
+        const bool out = present && (sc <= (long long)INT32_MIN || sc > (long long)INT32_MAX);
+        bad |= out;
+        const long long cl = out ? (sc < 0 ? (long long)INT32_MIN + 1 : (long long)INT32_MAX) : sc;
+        as_out[j] = present ? (int32_t)cl : INT32_MIN;
+    }
+    return true;
+}
+
+// one record's score from ops [b, e), bounds-checked against the array
+__device__ __forceinline__ int32_t cigp_score_range(const uint32_t *__restrict__ ops, uint32_t n_ops, int32_t nmv,
+                                                    uint32_t b, uint32_t e, uint32_t *range_flag)
+{
+    if (nmv == INT32_MIN) return INT32_MIN;                               // :248-249
+    long long s = -6ll * (long long)nmv;
+    if (e > n_ops) e = n_ops;
+    for (uint32_t k = b; k < e; ++k) s -= cigar_term(ops[k]);
+    return cigar_clamp(s, range_flag);
+}
+
+// number of ops of an escaped record whose stretch (trailer included) ends at `end`
+__device__ __forceinline__ uint32_t cigp_trailer(const uint32_t *__restrict__ ops, uint32_t n_ops, uint32_t end)
+{
+    return (end > 0u && end <= n_ops) ? (ops[end - 1u] >> 4) : 0u;
+}
+
+// The careful path of one wave and species (rare): begins from the counts -- forwards by prefix sum, or, when the tile
+// holds escaped records, backwards from the tile's end, one record after the other -- then one loop per record.
+__device__ __attribute__((noinline)) v4i32 cigp_slow(const uint32_t *__restrict__ ops, uint32_t n_ops, uint32_t tb, uint32_t te,
+                                                     uint32_t cw, v4i32 nmv, uint32_t *range_flag)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if (te > n_ops) te = n_ops;
+    if (tb > te) tb = te;
+    const uint32_t c0 = cw & 255u, c1 = (cw >> 8) & 255u, c2 = (cw >> 16) & 255u, c3 = cw >> 24;
+    uint32_t b0, b1, b2, b3, e0, e1, e2, e3;
+    if (__ballot(c0 == 255u || c1 == 255u || c2 == 255u || c3 == 255u) == 0ull) {
+        const uint32_t lsum = c0 + c1 + c2 + c3;
+        b0 = tb + wave_scan_incl(lsum) - lsum;
+        e0 = b1 = b0 + c0; e1 = b2 = b1 + c1; e2 = b3 = b2 + c2; e3 = b3 + c3;
+    } else {
+        b0 = b1 = b2 = b3 = e0 = e1 = e2 = e3 = tb;
+        uint32_t end = te;
+        for (int L = 63; L >= 0; --L) {
+            const uint32_t w = lane_value(cw, L);
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                uint32_t k = (w >> (8 * j)) & 255u, e = end;
+                if (k == 255u) { k = cigp_trailer(ops, n_ops, end); e = end > tb ? end - 1u : tb; }
+                const uint32_t b = (e - tb >= k) ? e - k : tb;
+                if (lane == (uint32_t)L) {
+                    if (j == 0) { b0 = b; e0 = e; } else if (j == 1) { b1 = b; e1 = e; }
+                    else if (j == 2) { b2 = b; e2 = e; } else { b3 = b; e3 = e; }
+                }
+                end = b;
+            }
+        }
+    }
+    v4i32 r;
+    r.x = cigp_score_range(ops, n_ops, nmv.x, b0, e0, range_flag);
+    r.y = cigp_score_range(ops, n_ops, nmv.y, b1, e1, range_flag);
+    r.z = cigp_score_range(ops, n_ops, nmv.z, b2, e2, range_flag);
+    r.w = cigp_score_range(ops, n_ops, nmv.w, b3, e3, range_flag);
+    return r;
+}
+
+// AS of record h, the last record in front of a workgroup, whose ops end where the workgroup's first tile begins
+__device__ __attribute__((noinline)) int32_t cigp_score_before(const int32_t *__restrict__ nm, const uint8_t *__restrict__ cnt,
+                                                               const uint32_t *__restrict__ ops, uint32_t n_ops, uint64_t h,
+                                                               uint32_t end, uint32_t *range_flag)
+{
+    if (end > n_ops) end = n_ops;
+    uint32_t k = cnt[h], e = end;
+    if (k == 255u) { k = cigp_trailer(ops, n_ops, end); e = end > 0u ? end - 1u : 0u; }
+    return cigp_score_range(ops, n_ops, nm[h], e >= k ? e - k : 0u, e, range_flag);
+}
+
+// the lane's four count bytes; records past the end count nothing
+template <bool FULL>
+__device__ __forceinline__ uint32_t cigp_counts4(const uint8_t *__restrict__ cnt, uint64_t r0, uint64_t n)
+{
+    if (FULL || r0 + 4 <= n) return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cnt + r0));
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (r0 + j < n) w |= (uint32_t)cnt[r0 + j] << (8 * j);
+    return w;
+}
+
+template <bool PAIRED, int BLOCK, bool FULL, bool COUNTS, int BINMODE>
+__device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCols s2, const uint8_t *__restrict__ unit_bits8,
+                                                   int32_t m, uint8_t *__restrict__ code, uint64_t n, uint32_t n_tiles,
+                                                   uint32_t *__restrict__ range_flag, uint32_t *last_state, uint32_t *cig_T,
+                                                   uint32_t *count_lds, const CountSink &sink)
+{
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t t = blockIdx.x * (BLOCK / 64) + wave;                 // this wave's tile
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t r0 = g * 4;
+    const bool have_tile = FULL || t < n_tiles;                          // wave-uniform
+    const uint32_t n_ops1 = s1.tile[n_tiles], n_ops2 = s2.tile[n_tiles];
+
+    // everything the wave needs, fetched at once
+    TileOps o1, o2;
+    o1.tb = o1.te = o2.tb = o2.te = 0u; o1.fast = o2.fast = false;
+    if (have_tile) { cigp_fetch_tile(s1, t, n_ops1, o1); cigp_fetch_tile(s2, t, n_ops2, o2); }
+    int32_t a1[4], x1[4], a2[4], x2[4], nmv1[4], nmv2[4];
+    load4<int32_t, true, FULL>(s1.nm, r0, n, nmv1);
+    load4<int32_t, true, FULL>(s2.nm, r0, n, nmv2);
+    const uint32_t cw1 = cigp_counts4<FULL>(s1.cnt, r0, n), cw2 = cigp_counts4<FULL>(s2.cnt, r0, n);
+    load4<int32_t, true, FULL>(s1.xs, r0, n, x1);
+    load4<int32_t, true, FULL>(s2.xs, r0, n, x2);
+    uint32_t mb = 0;
+    if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+    if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+
+    bool bad = false;
+    if (!(FULL && o1.fast && cigp_fast(s1.ops, n_ops1, o1, cw1, nmv1, cig_T, a1, bad))) {
+        v4i32 q; q.x = nmv1[0]; q.y = nmv1[1]; q.z = nmv1[2]; q.w = nmv1[3];
+        q = cigp_slow(s1.ops, n_ops1, o1.tb, o1.te, cw1, q, range_flag);
+        a1[0] = q.x; a1[1] = q.y; a1[2] = q.z; a1[3] = q.w;
+    }
+    if (!(FULL && o2.fast && cigp_fast(s2.ops, n_ops2, o2, cw2, nmv2, cig_T, a2, bad))) {
+        v4i32 q; q.x = nmv2[0]; q.y = nmv2[1]; q.z = nmv2[2]; q.w = nmv2[3];
+        q = cigp_slow(s2.ops, n_ops2, o2.tb, o2.te, cw2, q, range_flag);
+        a2[0] = q.x; a2[1] = q.y; a2[2] = q.z; a2[3] = q.w;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u && range_flag) atomicOr(range_flag, 1u);
+
+    // the record in front of the workgroup: only when the workgroup's first record closes a unit (never with strictly
+    // interleaved mates: workgroups begin at even records)
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 == 0) {
+            mb &= ~1u;                                                    // record 0 has no predecessor (:402)
+        } else if (mb & 1u) {
+            const uint64_t h = r0 - 1;
+            halo = mapping_state<int32_t>(cigp_score_before(s1.nm, s1.cnt, s1.ops, n_ops1, h, o1.tb, range_flag), s1.xs[h],
+                                          cigp_score_before(s2.nm, s2.cnt, s2.ops, n_ops2, h, o2.tb, range_flag), s2.xs[h], m);
+        }
+    }
+    classify_finish<int32_t, PAIRED, BLOCK, FULL, COUNTS, BINMODE>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n,
+                                                                   count_lds, sink);
+}
+
+template <bool PAIRED, int BLOCK, bool COUNTS, int BINMODE>
+__global__ void __launch_bounds__(BLOCK)
+classify_cigp_kernel(const CigCols s1, const CigCols s2, const uint8_t *__restrict__ unit_bits8, int32_t m,
+                     uint8_t *__restrict__ code, uint64_t n, uint32_t n_tiles, uint32_t *__restrict__ range_flag, CountSink sink)
+{
+    static_assert(!COUNTS || BLOCK * 4 == XM_GRAN, "the counting workgroup is one granule");
+    __shared__ uint32_t last_state[BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t cig_table[BLOCK / 64][XM_CIG_WAVE_OPS + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t count_lds[COUNTS ? XM_COUNT_LDS_WORDS : 4];
+    uint32_t *cig_T = cig_table[threadIdx.x >> 6];
+    if (COUNTS) count_lds_clear<BLOCK>(count_lds);
+    if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
+        classify_cigp_body<PAIRED, BLOCK, true, COUNTS, BINMODE>(s1, s2, unit_bits8, m, code, n, n_tiles, range_flag, last_state,
+                                                                 cig_T, count_lds, sink);
+    else
+        classify_cigp_body<PAIRED, BLOCK, false, COUNTS, BINMODE>(s1, s2, unit_bits8, m, code, n, n_tiles, range_flag, last_state,
+                                                                  cig_T, count_lds, sink);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: mate-density correlation of a single-end mappability track (xenomappability, SURVEY 8f-4;
 // Mappability.single_end_to_paired, /root/reference/xenomapper/mappability.py:94-124).
 // out[i] = 1.0 where track[i] == 1, else sum_j track[i+j] * density[j] for j < min(m, n - i), accumulated left to
@@ -1048,6 +1311,25 @@ void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
     else
         classify_cigar_kernel<true, XM_CIGAR_BLOCK><<<grid, XM_CIGAR_BLOCK, 0, st>>>(
             nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, bits8, m, code, n, range_flag);
+}
+
+void launch_classify_cigp(hipStream_t st, int mode, uint64_t n, const CigCols &s1, const CigCols &s2,
+                          const uint64_t *unit_bits, int32_t m, uint8_t *code, uint32_t *range_flag, const CountPlan &cp)
+{
+    const uint64_t per_block = (uint64_t)XM_CIGP_BLOCK * 4;
+    const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
+    const uint32_t n_tiles = (uint32_t)((n + 255) / 256);
+    const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
+    const CountSink sink = make_sink(&cp, mode);
+#define XM_LAUNCH_CIGP(P, B) classify_cigp_kernel<P, XM_CIGP_BLOCK, true, B><<<grid, XM_CIGP_BLOCK, 0, st>>>(s1, s2, bits8, m, code, n, n_tiles, range_flag, sink)
+    if (cp.bins4) {
+        if (mode == XM_MODE_SE) XM_LAUNCH_CIGP(false, XM_MODE_SE);
+        else if (mode == XM_MODE_PE_LIBERAL) XM_LAUNCH_CIGP(true, XM_MODE_PE_LIBERAL);
+        else XM_LAUNCH_CIGP(true, XM_MODE_PE_CONSERVATIVE);
+    } else {
+        if (mode == XM_MODE_SE) XM_LAUNCH_CIGP(false, -1); else XM_LAUNCH_CIGP(true, -1);
+    }
+#undef XM_LAUNCH_CIGP
 }
 
 void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, const CountPlan &cp)

@@ -437,3 +437,20 @@ def cigar_columns_torch(n_records, seed, device, read_len=150, mapped_p=0.9):
     if ops.numel() == 0:
         ops = torch.zeros(1, dtype=torch.int32, device=device)
     return {"nm": nm.contiguous(), "cig_off": off.to(torch.int32).contiguous(), "cig_oplen": ops.contiguous()}
+
+
+def cigar_pack_torch(cig):
+    """Packed CIGAR columns (include/xenomapper_hip.h) from cigar_columns_torch() output, on the same device.  The
+    synthetic records have at most 5 operations, so no record needs a trailer word and the op array is unchanged.
+    Returns dict(nm, cig_cnt uint8[n], cig_tile int32[tiles + 1] (bit pattern of uint32), cig_oplen)."""
+    import torch
+    off = cig["cig_off"].to(torch.int64) & 0xFFFFFFFF
+    n = off.numel() - 1
+    k = off[1:] - off[:-1]
+    assert int(k.max().item()) < 255 if n else True
+    n_tiles = (n + 255) // 256
+    tile = torch.empty(n_tiles + 1, dtype=torch.int64, device=off.device)
+    tile[:n_tiles] = off[0:n:256]
+    tile[n_tiles] = off[n]
+    return {"nm": cig["nm"], "cig_cnt": k.to(torch.uint8).contiguous(), "cig_tile": tile.to(torch.int32).contiguous(),
+            "cig_oplen": cig["cig_oplen"]}
