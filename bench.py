@@ -38,6 +38,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBPS = 8000.0                 # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 BYTES_PER_PAIR_CLASSIFY = 33.0         # algorithmic: 2 mates x 4 int32 scores in + 1 category byte out
 BYTES_PER_PAIR_COMPACT = 5.0           # 1 category byte in + one u32 pair index out
+EXTRA_WORKLOADS = (("configs[2]", "cfg3"), ("configs[4]", "cfg5"))     # timed after the default run, reported under `workloads`
 
 
 def parse_args():
@@ -52,10 +53,21 @@ def parse_args():
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5", "f64", "se"), default="cfg2",
                     help="BASELINE.json configs[1] (default, the quoted metric), [2] --cigar_scores path, [4] HISAT ZS + "
                          "conservative; f64 = configs[1] through the binary64 kernel; se = the single-end loop (units = reads)")
+    ap.add_argument("--sharded-input", action="store_true",
+                    help="configs[3] as ONE input: --strong-total pairs (default 400000000) cut into read blocks with the one-record "
+                         "halo (shard.plan_blocks / take_block rule), one block per GPU; strong scaling")
+    ap.add_argument("--singletons-pct", type=float, default=0.0,
+                    help="cfg2/cfg5: this percentage of the reads are singletons (no mate), so the mates are not strictly "
+                         "interleaved and the scatter takes its general path")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="default run only: skip timing configs[2] and configs[4] after the timed region (the `workloads` key)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the transfer-inclusive side measurements")
     return ap.parse_args()
+
+
+_REAL_STDOUT = [None]      # while stdout_to_stderr() is active: a duplicate of the real stdout (the watchdog writes there)
 
 
 @contextlib.contextmanager
@@ -64,12 +76,47 @@ def stdout_to_stderr():
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
+    _REAL_STDOUT[0] = saved
     try:
         yield
     finally:
         sys.stdout.flush()
+        _REAL_STDOUT[0] = None
         os.dup2(saved, 1)
         os.close(saved)
+
+
+WATCHDOG_EXIT = 3
+
+
+def run_with_watchdog(fn, seconds, line, what, rank=0):
+    """Run fn() -- something that may block for ever inside a collective -- under a timer.  When the timer fires, rank 0
+    writes the JSON line (with the failure recorded under `what`) to the REAL stdout, whatever fd 1 currently points
+    at, and the process exits with WATCHDOG_EXIT: a hung collective must never reach the driver as rc 0 without a line."""
+    import threading
+
+    def give_up():
+        if rank == 0 and line is not None:
+            line[what] = {"error": "no answer within %g s" % seconds, "rank": rank}
+            data = (json.dumps(line) + "\n").encode()
+            fd = _REAL_STDOUT[0] if _REAL_STDOUT[0] is not None else 1
+            try:
+                sys.stdout.flush()
+            except Exception:                                         # noqa: BLE001
+                pass
+            while data:
+                data = data[os.write(fd, data):]
+        sys.stderr.write("bench.py: rank %d gave up on %s after %g s\n" % (rank, what, seconds))
+        sys.stderr.flush()
+        os._exit(WATCHDOG_EXIT)
+
+    timer = threading.Timer(seconds, give_up)
+    timer.daemon = True
+    timer.start()
+    try:
+        return fn()
+    finally:
+        timer.cancel()
 
 
 def spawn_ranks(args):
@@ -170,6 +217,301 @@ def e2e_sam_text(pairs=4_000_000, to_files=True):
             "what": "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> stripper -> H2D -> fused pass -> D2H -> six SAM outputs"}
 
 
+class Workload(object):
+    """One BASELINE.json workload on one GPU: synthetic columns resident in HBM, the output buffers, step() = one
+    C-ABI call over the whole batch, verify() = the last step's outputs against the C oracle on the same columns."""
+
+    DESCR = {
+        "cfg2": "configs[1]: %d paired-end 2x150 bp read pairs per GPU, AS/XS present, %s pair rule, min_score=-inf, score "
+                "columns resident in HBM",
+        "cfg3": "configs[2]: %d paired-end pairs per GPU on the --cigar_scores path (no AS/XS; NM + CIGAR ops in %s columns, "
+                "AS synthesised in the classify kernel), %s pair rule, columns resident in HBM",
+        "cfg5": "configs[4]: %d paired-end pairs per GPU, HISAT-style scores with ZS as second-best (AS=0/ZS=0 present), %s "
+                "pair rule, columns resident in HBM",
+        "f64": "configs[1] columns as binary64 (the reference's own arithmetic; used for non-integral scores): %d paired-end "
+               "pairs per GPU, %s pair rule, columns resident in HBM",
+        "se": "configs[0]'s kernel shape at size: single-end loop over 2 x %d reads per GPU, every record a unit (%s ignored), "
+              "columns resident in HBM",
+    }
+
+    def __init__(self, name, ctx, dev, n_pairs, rank, mode_name=None, n_slots=1, singletons_pct=0.0, shard=None):
+        import numpy as np
+        import torch
+        from xenomapper_amd import _ffi, synth
+        self.name, self.ctx, self.dev = name, ctx, dev
+        self.mode_name = mode_name or ("conservative" if name == "cfg5" else "liberal")
+        self.mode = _ffi.MODE_SE if name == "se" else (_ffi.MODE_PE_LIBERAL if self.mode_name == "liberal" else _ffi.MODE_PE_CONSERVATIVE)
+        self.bytes_classify, self.bytes_compact, self.dtype = BYTES_PER_PAIR_CLASSIFY, BYTES_PER_PAIR_COMPACT, "int32"
+        self.cig = self.cigp = self.range_flag = None
+        self.cigar_csr = os.environ.get("XM_BENCH_CIGAR_CSR") == "1"     # A/B only: the CSR-column kernel (K1c + stand-alone histogram)
+        self.unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"        # A/B only: xm_classify_dev + xm_compact_dev
+        self.shard = shard
+        self.layout = "strictly interleaved mates"
+        n = 2 * n_pairs
+        units = n_pairs
+        if shard is not None:
+            cols, n, units = self._sharded_block(shard, rank)
+        elif name == "cfg3":
+            # no AS tag: AS is synthesised in-kernel from NM + CIGAR; XS mostly absent
+            self.cig = [synth.cigar_columns_torch(n, seed=3003 + 2 * rank, device=dev),
+                        synth.cigar_columns_torch(n, seed=3004 + 2 * rank, device=dev, mapped_p=0.3)]
+            g = torch.Generator(device=dev)
+            g.manual_seed(3005 + rank)
+            xs1 = torch.where(torch.rand(n, generator=g, device=dev) < 0.95, torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
+                              -torch.randint(0, 40, (n,), generator=g, device=dev, dtype=torch.int32))
+            cols = {"xs1": xs1, "xs2": torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
+                    "unit_bits": torch.from_numpy(synth.interleaved_unit_bits(n).view(np.int64)).to(dev)}
+            self.k_bar = (self.cig[0]["cig_oplen"].numel() + self.cig[1]["cig_oplen"].numel()) / (2.0 * n)
+            if self.cigar_csr:
+                self.bytes_classify = 4 * (12 + 4 * self.k_bar) + 1      # per record and species NM + XS + CSR offset + ops
+            else:
+                # packed CIGAR columns: NM + XS + one count byte per record and species, one tile base per 256 records, the ops
+                self.cigp = [synth.cigar_pack_torch(c) for c in self.cig]
+                self.bytes_classify = 4 * (9 + 1.0 / 64 + 4 * self.k_bar) + 1
+            self.range_flag = torch.zeros(4, dtype=torch.int32, device=dev)
+        else:
+            cols = synth.score_columns_torch(n_pairs, seed=(5005 if name == "cfg5" else 2002) + rank, device=dev,
+                                             profile="hisat" if name == "cfg5" else "bowtie2")      # own read block per rank
+            if name == "se":
+                cols["unit_bits"] = torch.full(((n + 63) // 64,), -1, dtype=torch.int64, device=dev)     # every record is a unit
+                self.bytes_classify, self.bytes_compact, units = 17.0, 5.0, n     # 4 int32 in + 1 byte out; 1 byte in + 1 index out
+            elif singletons_pct > 0.0:
+                flags = singleton_unit_flags(n, singletons_pct / 100.0, seed=77 + rank)
+                units = int(flags.sum())
+                cols["unit_bits"] = torch.from_numpy(synth.pack_unit_bits(flags).view(np.int64)).to(dev)
+                self.layout = "%.3g %% of the reads are singletons: mates not strictly interleaved" % singletons_pct
+            if name == "f64":
+                for k in ("as1", "xs1", "as2", "xs2"):
+                    c = cols[k]
+                    cols[k] = torch.where(c == _ffi.ABSENT, torch.full((), float("-inf"), dtype=torch.float64, device=dev),
+                                          c.to(torch.float64))
+                self.bytes_classify, self.dtype = 65.0, "f64"            # 2 mates x 4 binary64 scores in + 1 byte out
+        self.cols, self.n, self.n_pairs, self.units_per_step = cols, n, n_pairs, units
+        self.floor_min = float("-inf") if name == "f64" else _ffi.ABSENT             # min_score = -inf
+        # XM_BENCH_CATEGORY_BYTES=1 (A/B): the per-record output of the step is the category byte (fwd*8+rev) instead
+        self.category_bytes = os.environ.get("XM_BENCH_CATEGORY_BYTES") == "1" or (name == "cfg3" and self.cigar_csr) or self.unfused
+        self.code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+        self.bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)  # compact category stream: a nibble per record
+        self.idx = torch.empty(n, dtype=torch.int32, device=dev)
+        self.off = torch.zeros(8, dtype=torch.int64, device=dev)
+        self.n_slots = max(n_slots, 1)
+        self.step_counts = torch.zeros((self.n_slots, 64), dtype=torch.int64, device=dev)   # category_counts of every step of the job
+        self.step_no = 0
+        self.counts = self.step_counts[0]
+
+    # configs[3] as one input: PARTS seeded parts (seed 4004 + part) put end to end, mates at records (2k-1, 2k) so that
+    # every 64-record-aligned cut separates a pair; this rank's read block + the halo record in front of it
+    PARTS = 8
+
+    def _sharded_block(self, shard, rank):
+        import torch
+        from xenomapper_amd import shard as sh, synth
+        total_pairs, world = shard
+        part_pairs = total_pairs // self.PARTS
+        n_all = 2 * part_pairs * self.PARTS
+        start, end = sh.plan_blocks(n_all, world)[rank]
+        halo = 1 if start > 0 else 0
+        lo = start - halo
+        part_rec = 2 * part_pairs
+        pieces = {k: [] for k in ("as1", "xs1", "as2", "xs2")}
+        for p in range(lo // part_rec, (end - 1) // part_rec + 1):
+            part = synth.score_columns_torch(part_pairs, seed=4004 + p, device=self.dev)
+            a, b = max(lo, p * part_rec) - p * part_rec, min(end, (p + 1) * part_rec) - p * part_rec
+            for k in pieces:
+                pieces[k].append(part[k][a:b].clone())
+            del part
+        cols = {k: torch.cat(v) if len(v) > 1 else v[0] for k, v in pieces.items()}
+        gidx = torch.arange(lo, end, device=self.dev, dtype=torch.int64)
+        flags = ((gidx % 2 == 0) & (gidx >= 2)).to(torch.uint8)
+        if halo:
+            flags[0] = 0                                   # the halo's own unit belongs to the previous block (shard.take_block)
+        units = int(flags.sum().item())
+        pad = (-flags.numel()) % 64
+        if pad:
+            flags = torch.cat([flags, torch.zeros(pad, dtype=torch.uint8, device=self.dev)])
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=self.dev)
+        cols["unit_bits"] = (flags.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8).view(torch.int64)
+        self.layout = "mates at records (2k-1, 2k) of the whole input: every cut separates a pair (halo record in front of the block)"
+        self.block = (start, end, halo)
+        return cols, end - lo, units
+
+    def describe(self):
+        if self.name == "cfg3":
+            return self.DESCR["cfg3"] % (self.n_pairs, "CSR" if self.cigar_csr else "packed", self.mode_name)
+        return self.DESCR[self.name] % (self.n_pairs, self.mode_name)
+
+    def kernel_name(self):
+        if self.cigp is not None:
+            return "classify_cigp_kernel<paired, counts, bins4>"
+        if self.cig is not None:
+            return "classify_cigar_kernel<paired>"
+        return "classify_kernel<%s, %s, counts>" % (self.dtype, "single" if self.name == "se" else "paired")
+
+    def call_name(self):
+        if self.unfused:
+            return "A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)"
+        return "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % (
+            "_cigar_packed" if self.cigp is not None else "_cigar" if self.cig is not None else "_f64" if self.dtype == "f64" else "")
+
+    def _packed_call(self, code, bins4, counts):
+        c, p = self.cols, self.cigp
+        self.ctx.classify_compact_cigar_packed_dev(self.mode, p[0]["nm"], p[0]["cig_cnt"], p[0]["cig_tile"], p[0]["cig_oplen"], c["xs1"],
+                                                   p[1]["nm"], p[1]["cig_cnt"], p[1]["cig_tile"], p[1]["cig_oplen"], c["xs2"],
+                                                   c["unit_bits"], self.floor_min, code, self.idx, self.off, counts,
+                                                   bins4=bins4, range_flag=self.range_flag)
+
+    def step(self):
+        c, ctx, mode = self.cols, self.ctx, self.mode
+        counts = self.counts = self.step_counts[self.step_no % self.n_slots]
+        self.step_no += 1
+        code = self.code if self.category_bytes else None
+        bins4 = None if self.category_bytes else self.bins4
+        if self.unfused:
+            if self.cig is not None:
+                g = self.cig
+                ctx.classify_cigar_dev(mode, g[0]["nm"], g[0]["cig_off"], g[0]["cig_oplen"], c["xs1"], g[1]["nm"], g[1]["cig_off"],
+                                       g[1]["cig_oplen"], c["xs2"], c["unit_bits"], self.floor_min, self.code, range_flag=self.range_flag)
+            else:
+                ctx.classify_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, self.code)
+            ctx.compact_dev(mode, self.code[:self.n], self.idx, self.off, counts)
+        elif self.cigp is not None:
+            self._packed_call(code, bins4, counts)
+        elif self.cig is not None:
+            g = self.cig
+            ctx.classify_compact_cigar_dev(mode, g[0]["nm"], g[0]["cig_off"], g[0]["cig_oplen"], c["xs1"], g[1]["nm"], g[1]["cig_off"],
+                                           g[1]["cig_oplen"], c["xs2"], c["unit_bits"], self.floor_min, self.code, self.idx, self.off,
+                                           counts, range_flag=self.range_flag)
+        else:
+            ctx.classify_compact_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, code,
+                                     self.idx, self.off, counts, bins4=bins4)
+
+    def reset_counts(self):
+        self.step_counts.zero_()
+        self.step_no = 0
+
+    def host_columns(self):
+        import numpy as np
+        hc = {k: v.cpu().numpy() for k, v in self.cols.items()}
+        hc["unit_bits"] = hc["unit_bits"].view(np.uint64)
+        return hc
+
+    def verify(self):
+        """What the last step left on the device against the C oracle on the same columns (rank-local)."""
+        import numpy as np
+        import torch
+        from tests import helpers as H
+        from xenomapper_amd import _ffi
+        n, mode = self.n, self.mode
+        hc = self.host_columns()
+        if self.cig is not None:
+            for f, key in ((0, "as1"), (1, "as2")):
+                g = {k: v.cpu().numpy() for k, v in self.cig[f].items()}
+                hc[key], bad = H.c_cigar_scores(g["nm"], g["cig_off"].view(np.uint32), g["cig_oplen"].view(np.uint32))
+                assert bad == 0
+        want_code, want_counts = H.c_classify(mode, hc["as1"], hc["xs1"], hc["as2"], hc["xs2"], hc["unit_bits"], self.floor_min)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        ok = True
+        if not self.category_bytes:
+            # the timed step left the compact stream: check it, then ask for the category bytes as well (same kernels,
+            # both outputs) so that they are checked too
+            want_bins = np.full(n, 7, dtype=np.uint8)
+            for b in range(7):
+                want_bins[want_idx[int(want_off[b]):int(want_off[b + 1])]] = b
+            ok = bool((_ffi.unpack_bins4(self.bins4.cpu().numpy(), n) == want_bins).all())
+            c = self.cols
+            if self.cigp is not None:
+                self._packed_call(self.code, self.bins4, self.counts)
+            else:
+                self.ctx.classify_compact_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min,
+                                              self.code, self.idx, self.off, self.counts, bins4=self.bins4)
+            torch.cuda.synchronize()
+        ok &= bool((self.code[:n].cpu().numpy() == want_code).all())
+        ok &= bool((self.off.cpu().numpy().astype(np.uint64) == want_off).all())
+        ok &= bool((self.idx[:int(want_off[7])].cpu().numpy().view(np.uint32) == want_idx).all())
+        ok &= bool((self.counts.cpu().numpy().astype(np.uint64) == want_counts).all())
+        ok &= int(want_off[7]) == self.units_per_step
+        if self.range_flag is not None:
+            ok &= int(self.range_flag[0].item()) == 0
+        self.host_cols = hc
+        return ok
+
+
+def singleton_unit_flags(n_records, p_single, seed):
+    """Unit flags of a read stream in which a fraction p_single of the reads has no mate: pairs occupy two adjacent
+    records (the second closes the unit), singletons one (closes none), so the parity of the mates flips at every
+    singleton."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    items = int(n_records / (2.0 - p_single)) + 1024
+    single = rng.random(items) < (p_single / (2.0 - p_single)) * 2.0 / (1.0 + (p_single / (2.0 - p_single)))
+    length = np.where(single, 1, 2)
+    begin = np.cumsum(length) - length
+    keep = (begin + length <= n_records)
+    second = begin[keep & ~single] + 1
+    flags = np.zeros(n_records, dtype=np.uint8)
+    flags[second] = 1
+    return flags
+
+
+def time_steps(ctx, wl, steps, warmup, fence, finish=None):
+    """`warmup` untimed steps, then exactly `steps` steps (+ finish()) between two fences, HIP events around the classify
+    kernel only; then a diagnostic pass with every kernel bracketed.  -> (elapsed s, classify timing, all-kernel timing)"""
+    for _ in range(warmup):
+        wl.step()
+    if finish is not None:
+        with stdout_to_stderr():
+            finish(max(warmup, 1))                                # warms the RCCL communicator up as well
+    fence()
+    wl.reset_counts()
+    fence()
+    ctx.timing_select(["classify"])          # the timed region brackets only the kernel the roofline is about
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    if finish is not None:
+        finish(steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing = ctx.timing_read()
+    # diagnostic pass outside the timed region: every kernel bracketed (the event pairs cost stream time)
+    ctx.timing_select(None)
+    ctx.timing_reset()
+    for _ in range(min(steps, 20)):
+        wl.step()
+    fence()
+    timing_all = ctx.timing_read()
+    ctx.timing_enable(False)
+    return elapsed, timing, timing_all
+
+
+def rooflines(wl, elapsed, steps, timing, timing_all, unit_name):
+    """The `roofline` (dominant kernel) and `roofline_step` (whole step) objects + per-kernel means of one workload."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import kernel_hash
+    k_cls = timing["classify"]
+    cls_ms = k_cls["ms"] / max(1, k_cls["launches"])
+    achieved = wl.bytes_classify * wl.units_per_step / (cls_ms * 1e-3) / 1e9
+    kernels = {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in timing_all.items() if v["launches"]}
+    sum_ms = sum(kernels.values())
+    step_bytes = (wl.bytes_classify + wl.bytes_compact) * wl.units_per_step
+    step_achieved = step_bytes / (sum_ms * 1e-3) / 1e9
+    ms_per_step = 1e3 * elapsed / steps
+    traffic = step_traffic = source = None
+    if not (wl.unfused or wl.category_bytes or wl.shard or "singletons" in wl.layout):
+        traffic, step_traffic, source = kernel_hash.load_traffic(wl.name, wl.n_pairs)
+    roof = {"bound": "hbm", "kernel": wl.kernel_name(), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes_per_unit": wl.bytes_classify, "kernel_ms": cls_ms}
+    step = {"bound": "hbm", "what": "SURVEY 8d: (classify + compact) algorithmic bytes per %s / sum of the kernels' mean durations" % unit_name,
+            "algorithmic_bytes_per_unit": wl.bytes_classify + wl.bytes_compact, "sum_kernel_ms": round(sum_ms, 5),
+            "achieved": step_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": step_achieved / HBM_PEAK_GBPS,
+            "traffic": step_traffic, "traffic_source": source,
+            "frac_by_ms_per_step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    return roof, step, kernels
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -178,7 +520,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from xenomapper_amd import _ffi, synth
+    from xenomapper_amd import _ffi
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,11 +532,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the classifier has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.sharded_input and args.workload != "cfg2":
+        print("bench.py: --sharded-input is configs[3], i.e. the cfg2 columns", file=sys.stderr)
+        sys.exit(2)
     # Rehearsal on a one-GPU box (not for reported numbers): XM_BENCH_REHEARSAL=1 lets every rank use cuda:0
     # and swaps RCCL for gloo, so that the N > 1 code path can be exercised where only one GPU is visible.
     rehearsal = os.environ.get("XM_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    watchdog_s = float(os.environ.get("XM_BENCH_WATCHDOG_S", "120"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
@@ -224,102 +570,23 @@ def main():
         n_ranks_seen = int(allreduce(one, dist.ReduceOp.SUM).item()) if world > 1 else 1
 
     n_pairs = args.pairs
-    if args.strong_total:
+    shard = None
+    if args.sharded_input:
+        total = args.strong_total or 400_000_000
+        total -= total % (Workload.PARTS * 32)                       # whole 64-record words per part
+        shard = (total, world)
+        n_pairs = total // world
+        args.strong_total = total
+    elif args.strong_total:
         n_pairs = (args.strong_total // world + 3) // 4 * 4          # a read block per GPU, whole 64-record words of the unit mask
-    n = 2 * n_pairs
-    if args.mode is None:
-        args.mode = "conservative" if args.workload == "cfg5" else "liberal"
-    if args.workload == "se":
-        mode = _ffi.MODE_SE
-    else:
-        mode = _ffi.MODE_PE_LIBERAL if args.mode == "liberal" else _ffi.MODE_PE_CONSERVATIVE
-    units_per_step = n if args.workload == "se" else n_pairs            # se: a unit is a read
     ctx = _ffi.Context(local_rank)
-    bytes_per_unit = BYTES_PER_PAIR_CLASSIFY
-    bytes_per_unit_compact = BYTES_PER_PAIR_COMPACT
-    dtype = "int32"
-    cig = cigp = None
-    cigar_csr = os.environ.get("XM_BENCH_CIGAR_CSR") == "1"     # A/B only: the CSR-column kernel (K1c + stand-alone histogram)
-    if args.workload == "cfg3":
-        # no AS tag: AS is synthesised in-kernel from NM + CIGAR (CSR); XS mostly absent
-        cig = [synth.cigar_columns_torch(n, seed=3003 + 2 * rank, device=dev),
-               synth.cigar_columns_torch(n, seed=3004 + 2 * rank, device=dev, mapped_p=0.3)]
-        g = torch.Generator(device=dev)
-        g.manual_seed(3005 + rank)
-        xs1 = torch.where(torch.rand(n, generator=g, device=dev) < 0.95, torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
-                          -torch.randint(0, 40, (n,), generator=g, device=dev, dtype=torch.int32))
-        cols = {"xs1": xs1, "xs2": torch.full((n,), _ffi.ABSENT, dtype=torch.int32, device=dev),
-                "unit_bits": torch.from_numpy(synth.interleaved_unit_bits(n).view(np.int64)).to(dev)}
-        k_bar = (cig[0]["cig_oplen"].numel() + cig[1]["cig_oplen"].numel()) / (2.0 * n)
-        if cigar_csr:
-            bytes_per_unit = 4 * (12 + 4 * k_bar) + 1        # per record and species NM + XS + offset + ops
-        else:
-            # packed CIGAR columns: NM + XS + one count byte per record and species, one tile base per 256 records, the ops
-            cigp = [synth.cigar_pack_torch(c) for c in cig]
-            bytes_per_unit = 4 * (9 + 1.0 / 64 + 4 * k_bar) + 1
-        range_flag = torch.zeros(4, dtype=torch.int32, device=dev)
-    else:
-        cols = synth.score_columns_torch(n_pairs, seed=(5005 if args.workload == "cfg5" else 2002) + rank, device=dev,
-                                         profile="hisat" if args.workload == "cfg5" else "bowtie2")   # own read block per rank
-        if args.workload == "se":
-            cols["unit_bits"] = torch.full(((n + 63) // 64,), -1, dtype=torch.int64, device=dev)      # every record is a unit
-            bytes_per_unit, bytes_per_unit_compact = 17.0, 5.0                   # 4 int32 in + 1 byte out; 1 byte in + 1 index out
-        if args.workload == "f64":
-            for k in ("as1", "xs1", "as2", "xs2"):
-                c = cols[k]
-                cols[k] = torch.where(c == _ffi.ABSENT, torch.full((), float("-inf"), dtype=torch.float64, device=dev),
-                                      c.to(torch.float64))
-            bytes_per_unit = 65.0                                                # 2 mates x 4 binary64 scores in + 1 byte out
-            dtype = "f64"
-    code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
-    bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)      # compact category stream: a nibble per record
-    # XM_BENCH_CATEGORY_BYTES=1 (A/B): the per-record output of the step is the category byte (fwd*8+rev) instead
-    category_bytes = os.environ.get("XM_BENCH_CATEGORY_BYTES") == "1" or (args.workload == "cfg3" and cigar_csr)
-    idx = torch.empty(n, dtype=torch.int32, device=dev)
-    off = torch.zeros(8, dtype=torch.int64, device=dev)
     n_slots = max(args.steps, args.warmup, 1)
-    step_counts = torch.zeros((n_slots, 64), dtype=torch.int64, device=dev)       # category_counts of every step of the job
-    counts = step_counts[0]
+    wl = Workload(args.workload, ctx, dev, n_pairs, rank, args.mode, n_slots, args.singletons_pct, shard)
     job_counts = torch.zeros(64, dtype=torch.int64, device=dev)
-    step_no = [0]
-    floor_min = float("-inf") if args.workload == "f64" else _ffi.ABSENT          # min_score = -inf
-
-    unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"          # A/B only: two C-ABI calls (classify, then compact with its own histogram)
-
-    def step_unfused():
-        counts = step_counts[step_no[0] % n_slots]
-        step_no[0] += 1
-        if cig is not None:
-            ctx.classify_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
-                                   cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"], cols["unit_bits"],
-                                   floor_min, code, range_flag=range_flag)
-        else:
-            ctx.classify_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min, code)
-        ctx.compact_dev(mode, code[:n], idx, off, counts)
-
-    def step():
-        if unfused:
-            return step_unfused()
-        counts = step_counts[step_no[0] % n_slots]
-        step_no[0] += 1
-        if cigp is not None:
-            ctx.classify_compact_cigar_packed_dev(mode, cigp[0]["nm"], cigp[0]["cig_cnt"], cigp[0]["cig_tile"], cigp[0]["cig_oplen"],
-                                                  cols["xs1"], cigp[1]["nm"], cigp[1]["cig_cnt"], cigp[1]["cig_tile"],
-                                                  cigp[1]["cig_oplen"], cols["xs2"], cols["unit_bits"], floor_min,
-                                                  code if category_bytes else None, idx, off, counts,
-                                                  bins4=None if category_bytes else bins4, range_flag=range_flag)
-        elif cig is not None:
-            ctx.classify_compact_cigar_dev(mode, cig[0]["nm"], cig[0]["cig_off"], cig[0]["cig_oplen"], cols["xs1"],
-                                           cig[1]["nm"], cig[1]["cig_off"], cig[1]["cig_oplen"], cols["xs2"],
-                                           cols["unit_bits"], floor_min, code, idx, off, counts, range_flag=range_flag)
-        else:
-            ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min,
-                                     code if category_bytes else None, idx, off, counts,
-                                     bins4=None if category_bytes else bins4)
 
     def finish(n_steps):
-        torch.sum(step_counts[:n_steps], dim=0, out=job_counts)  # category_counts of the job: the sum over its steps
-        allreduce(job_counts, dist.ReduceOp.SUM)                 # RCCL over xGMI: 64 x int64, once per job
+        torch.sum(wl.step_counts[:n_steps], dim=0, out=job_counts)   # category_counts of the job: the sum over its steps
+        allreduce(job_counts, dist.ReduceOp.SUM)                     # RCCL over xGMI: 64 x int64, once per job
 
     def fence():
         torch.cuda.synchronize()
@@ -327,170 +594,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    with stdout_to_stderr():
-        finish(max(args.warmup, 1))                               # warms the RCCL communicator up as well
-    fence()
-    step_counts.zero_()
-    job_counts.zero_()
-    step_no[0] = 0
-    fence()
-    ctx.timing_select(["classify"])          # the timed region brackets only the kernel the roofline is about
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    finish(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    timing = ctx.timing_read()
+    elapsed, timing, timing_all = time_steps(ctx, wl, args.steps, args.warmup, fence, finish)
     job_total = int(job_counts.sum().item())
     job_final = job_counts.clone()
-    # diagnostic pass outside the timed region: every kernel bracketed (the event pairs cost stream time)
-    ctx.timing_select(None)
-    ctx.timing_reset()
-    for _ in range(min(args.steps, 20)):
-        step()
-    fence()
-    timing_all = ctx.timing_read()
-    ctx.timing_enable(False)
+    last_counts = wl.counts.clone()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     elapsed = float(allreduce(t, dist.ReduceOp.MAX).item()) if world > 1 else elapsed
+    u = torch.tensor([wl.units_per_step], dtype=torch.int64, device=dev)
+    units_all_ranks = int(allreduce(u, dist.ReduceOp.SUM).item()) if world > 1 else wl.units_per_step
 
     # parity of what was just timed (rank-local): against the C oracle on the same columns
     verified = None
-    host_cols = None
     if not args.no_verify:
         from tests import helpers as H
         if rank == 0:
             H.c_oracle()                       # (re)builds oracle/libxm_oracle.so if stale: once, not in N ranks at a time
         if world > 1:
             dist.barrier()
-        host_cols = {k: v.cpu().numpy() for k, v in cols.items()}
-        host_cols["unit_bits"] = host_cols["unit_bits"].view(np.uint64)
-        if cig is not None:
-            for f, key in ((0, "as1"), (1, "as2")):
-                hc = {k: v.cpu().numpy() for k, v in cig[f].items()}
-                host_cols[key], bad = H.c_cigar_scores(hc["nm"], hc["cig_off"].view(np.uint32), hc["cig_oplen"].view(np.uint32))
-                assert bad == 0
-        want_code, want_counts = H.c_classify(mode, host_cols["as1"], host_cols["xs1"], host_cols["as2"],
-                                              host_cols["xs2"], host_cols["unit_bits"], floor_min)
-        want_idx, want_off = H.c_compact(mode, want_code)
-        if not category_bytes and not unfused:
-            # the timed step left the compact stream: check it, then ask for the category bytes as well (same kernels,
-            # both outputs) so that they are checked too
-            want_bins = np.full(n, 7, dtype=np.uint8)
-            for b in range(7):
-                want_bins[want_idx[int(want_off[b]):int(want_off[b + 1])]] = b
-            ok_bins = bool((_ffi.unpack_bins4(bins4.cpu().numpy(), n) == want_bins).all())
-            if cigp is not None:
-                ctx.classify_compact_cigar_packed_dev(mode, cigp[0]["nm"], cigp[0]["cig_cnt"], cigp[0]["cig_tile"], cigp[0]["cig_oplen"],
-                                                      cols["xs1"], cigp[1]["nm"], cigp[1]["cig_cnt"], cigp[1]["cig_tile"],
-                                                      cigp[1]["cig_oplen"], cols["xs2"], cols["unit_bits"], floor_min,
-                                                      code, idx, off, counts, bins4=bins4, range_flag=range_flag)
-            else:
-                ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], floor_min,
-                                         code, idx, off, counts, bins4=bins4)
-            torch.cuda.synchronize()
-        else:
-            ok_bins = True
-        ok = ok_bins and bool((code[:n].cpu().numpy() == want_code).all())
-        ok &= bool((off.cpu().numpy().astype(np.uint64) == want_off).all())
-        ok &= bool((idx[:int(want_off[7])].cpu().numpy().view(np.uint32) == want_idx).all())
-        ok &= bool((counts.cpu().numpy().astype(np.uint64) == want_counts).all())
-        ok &= job_total == world * units_per_step * args.steps
+        ok = wl.verify()
+        ok &= job_total == units_all_ranks * args.steps
         flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
         verified = bool(allreduce(flag, dist.ReduceOp.MIN).item()) if world > 1 else ok
 
+    line = None
     if rank == 0:
         unit_name = "read" if args.workload == "se" else "read-pair"
-        k_cls = timing["classify"]
-        cls_ms = k_cls["ms"] / max(1, k_cls["launches"])
-        achieved = bytes_per_unit * units_per_step / (cls_ms * 1e-3) / 1e9
-        kernels = {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in timing_all.items() if v["launches"]}
-        sum_ms = sum(kernels.values())
-        step_bytes = (bytes_per_unit + bytes_per_unit_compact) * units_per_step
-        step_achieved = step_bytes / (sum_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        pmc_name = {"cfg2": "pmc_classify.json", "cfg3": "pmc_classify_cigar.json"}.get(args.workload)
-        if pmc_name and n_pairs == 50_000_000:
-            try:
-                with open(os.path.join(REPO, "profiles", pmc_name)) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, replayed; not measured in this run)" % pmc_name
-            except Exception:
-                traffic = None
-        step_traffic = None
-        if args.workload == "cfg2" and n_pairs == 50_000_000 and not unfused and not category_bytes:
-            try:
-                with open(os.path.join(REPO, "profiles", "pmc_step.json")) as fh:
-                    step_traffic = json.load(fh).get("hbm_bytes_per_step")
-            except Exception:
-                step_traffic = None
-        ms_per_step = 1e3 * elapsed / args.steps
+        roof, roof_step, kernels = rooflines(wl, elapsed, args.steps, timing, timing_all, unit_name)
+        if args.sharded_input:
+            job = ("ONE %d-pair input (%d seeded parts end to end) cut into %d read blocks of ~%d pairs with a one-record halo%s"
+                   % (args.strong_total, Workload.PARTS, world, n_pairs,
+                      " = BASELINE.json configs[3] (400 M pairs sharded across 8 GPUs, RCCL count all-reduce)"
+                      if args.strong_total == 400_000_000 and world == 8 else ""))
+            sharding = "sharded input: shard.plan_blocks cut + halo record per block (units belong to the block holding their second record)"
+        else:
+            job = ("%d read pairs in all, one %d-pair read block per GPU%s" % (world * n_pairs, n_pairs,
+                   " = BASELINE.json configs[3] (400 M pairs sharded across 8 GPUs, RCCL count all-reduce)"
+                   if world * n_pairs == 400_000_000 and world == 8 and args.workload == "cfg2" else ""))
+            sharding = "independent read block per GPU (weak), no halo exchange"
         line = {
             "metric": "reads/sec classified" if args.workload == "se" else "read-pairs/sec classified",
-            "value": world * units_per_step * args.steps / elapsed,
+            "value": units_all_ranks * args.steps / elapsed,
             "unit": unit_name + "s/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "collective_backend": backend,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if args.strong_total else "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
-            "config": {"workload": {"cfg2": "configs[1]: %d paired-end 2x150 bp read pairs per GPU, AS/XS present, %s "
-                                           "pair rule, min_score=-inf, score columns resident in HBM",
-                                    "cfg3": "configs[2]: %d paired-end pairs per GPU on the --cigar_scores path (no AS/XS; NM + "
-                                            "CIGAR ops in " + ("CSR" if cigar_csr else "packed") + " columns, AS synthesised in the classify kernel), %s pair rule, columns resident in HBM",
-                                    "cfg5": "configs[4]: %d paired-end pairs per GPU, HISAT-style scores with ZS as second-best "
-                                            "(AS=0/ZS=0 present), %s pair rule, columns resident in HBM",
-                                    "f64": "configs[1] columns as binary64 (the reference's own arithmetic; used for non-integral "
-                                           "scores): %d paired-end pairs per GPU, %s pair rule, columns resident in HBM",
-                                    "se": "configs[0]'s kernel shape at size: single-end loop over 2 x %d reads per GPU, every "
-                                          "record a unit (%s ignored), columns resident in HBM"}[args.workload]
-                                   % (n_pairs, args.mode),
-                       "job": ("%d read pairs in all, one %d-pair read block per GPU%s" % (world * n_pairs, n_pairs,
-                               " = BASELINE.json configs[3] (400 M pairs sharded across 8 GPUs, RCCL count all-reduce)"
-                               if world * n_pairs == 400_000_000 and world == 8 and args.workload == "cfg2" else "")),
-                       "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": n,
-                       "step": ("A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)" if unfused else
-                                "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % ("_cigar_packed" if cigp is not None else "_cigar" if cig is not None else "")),
-                       "category_per_record": ("category byte (fwd*8+rev, 1 B per record)" if category_bytes or unfused else
+            "dtype": wl.dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
+            "config": {"workload": wl.describe(), "job": job,
+                       "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": wl.n, "record_layout": wl.layout,
+                       "step": wl.call_name(),
+                       "category_per_record": ("category byte (fwd*8+rev, 1 B per record)" if wl.category_bytes else
                                                "compact stream bins4: the output bin as a nibble per record = 1 B per pair (SURVEY 8d's "
                                                "algorithmic figure); the category byte is produced on request and checked outside the timed region"),
-                       "sharding": "read-block per GPU, no halo exchange" + (", one RCCL all-reduce of the final category_counts" if world > 1 else "")},
-            "roofline": {"bound": "hbm",
-                         "kernel": "classify_cigp_kernel<paired, counts, bins4>" if cigp is not None else "classify_cigar_kernel<paired>" if cig is not None else "classify_kernel<%s, %s, counts>" % (dtype, "single" if args.workload == "se" else "paired"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_unit": bytes_per_unit, "kernel_ms": cls_ms},
-            "roofline_step": {"bound": "hbm", "what": "SURVEY 8d: (classify + compact) algorithmic bytes per %s / sum of the kernels' mean durations" % unit_name,
-                              "algorithmic_bytes_per_unit": bytes_per_unit + bytes_per_unit_compact,
-                              "sum_kernel_ms": round(sum_ms, 5), "achieved": step_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": step_achieved / HBM_PEAK_GBPS,
-                              "traffic": step_traffic,
-                              "traffic_source": "profiles/pmc_step.json (replayed)" if step_traffic else None,
-                              "frac_by_ms_per_step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-            "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region (scan = its two launches)",
+                       "sharding": sharding + (", one RCCL all-reduce of the final category_counts" if world > 1 else "")},
+            "roofline": roof, "roofline_step": roof_step,
+            "kernel_ms": kernels, "kernel_ms_note": "all kernels bracketed in a separate pass after the timed region (scan = its launches)",
             "verified_vs_oracle": verified,
             "xm_allreduce_counts": None,
         }
+        host_cols = getattr(wl, "host_cols", None)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_python()
-            if host_cols is not None and args.workload in ("cfg2", "cfg5"):
+            if host_cols is not None and args.workload in ("cfg2", "cfg5") and not args.sharded_input:
                 m = min(n_pairs, 5_000_000)
                 sub = {k: np.ascontiguousarray(v[:2 * m]) for k, v in host_cols.items() if k != "unit_bits"}
                 sub["unit_bits"] = np.ascontiguousarray(host_cols["unit_bits"][:(2 * m + 63) // 64])
                 line["cpu_baseline_c"] = cpu_baseline_c(sub, m)
-        if world == 1 and not args.no_e2e and args.workload == "cfg2":
+        if world == 1 and not args.no_e2e and args.workload == "cfg2" and not args.sharded_input and not args.singletons_pct:
             e2e = {"note": "transfer-inclusive rates beside `value` (which is HBM-resident); measured after the timed region"}
             try:
-                hc = host_cols if host_cols is not None else {k: v.cpu().numpy() for k, v in cols.items()}
-                if hc["unit_bits"].dtype != np.uint64:
-                    hc["unit_bits"] = hc["unit_bits"].view(np.uint64)
-                e2e["h2d_inclusive"] = e2e_h2d_inclusive(ctx, mode, hc, min(n_pairs, 25_000_000))
+                hc = host_cols if host_cols is not None else wl.host_columns()
+                e2e["h2d_inclusive"] = e2e_h2d_inclusive(ctx, wl.mode, hc, min(n_pairs, 25_000_000))
             except Exception as e:                               # noqa: BLE001
                 e2e["h2d_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
             for key, to_files in (("sam_text", True), ("sam_text_devnull", False)):
@@ -499,45 +674,67 @@ def main():
                 except Exception as e:                           # noqa: BLE001
                     e2e[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             line["e2e"] = e2e
+
+    # The other single-GPU BASELINE configs, timed the same way in this process after the headline run (default
+    # invocation only): configs[2] --cigar_scores and configs[4] HISAT ZS + conservative.  `value`/`config` stay configs[1].
+    default_run = (world == 1 and args.workload == "cfg2" and not args.no_extra_workloads and not args.sharded_input
+                   and not args.singletons_pct and not args.strong_total and args.pairs == 50_000_000
+                   and not wl.unfused and os.environ.get("XM_BENCH_CATEGORY_BYTES") != "1")
+    if default_run:
+        mode0 = wl.mode
+        del wl
+        torch.cuda.empty_cache()
+        extra = {}
+        for key, name in EXTRA_WORKLOADS:
+            try:
+                w2 = Workload(name, ctx, dev, n_pairs, rank, None, 20)
+                el2, tm2, tma2 = time_steps(ctx, w2, 20, 5, fence)
+                ok2 = None if args.no_verify else bool(w2.verify())
+                r2, rs2, k2 = rooflines(w2, el2, 20, tm2, tma2, "read-pair")
+                extra[key] = {"workload": w2.describe(), "step": w2.call_name(), "steps": 20, "warmup": 5,
+                              "ms_per_step": 1e3 * el2 / 20, "value": w2.units_per_step * 20 / el2, "unit": "read-pairs/s",
+                              "dtype": w2.dtype, "roofline": r2, "roofline_step": rs2, "kernel_ms": k2,
+                              "verified_vs_oracle": ok2}
+                if name == "cfg3":
+                    extra[key]["mean_cigar_ops_per_record"] = w2.k_bar
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as e:                               # noqa: BLE001 -- reported, the headline line still goes out
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["workloads"] = extra
+        line["workloads_note"] = ("configs[2] and configs[4] timed in this process after the headline run: 5 warm-up + 20 steps each, "
+                                  "same protocol (HIP events on the classify kernel inside the timed region)")
+
     # The same reduction through the library's own RCCL communicator (xm_allreduce_counts, the C ABI's collective), on
     # every rank, after everything else and under a watchdog: the job total above came from torch.distributed, so
-    # whatever happens here the line is printed -- with the outcome (or the error, or "timed out") in it.
-    if rank != 0:
-        line = None
+    # whatever happens here the line is printed -- with the outcome (or the error) in it -- and a hang exits non-zero.
+    def library_allreduce():
+        with stdout_to_stderr():
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [_ffi.comm_unique_id()]
+                except Exception as e:                           # noqa: BLE001 -- every rank must still reach the broadcast
+                    uid = ["%s: %s" % (type(e).__name__, e)]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            if not isinstance(uid[0], bytes):
+                raise RuntimeError("xm_comm_unique_id on rank 0: %s" % uid[0])
+            if os.environ.get("XM_BENCH_FAKE_HANG") == "1":      # test hook: a collective that never returns
+                time.sleep(3600)
+            ctx.comm_init(world, rank, uid[0])
+            mine = last_counts * args.steps                      # every step saw the same block: this rank's job total
+            ctx.allreduce_counts(mine)
+            torch.cuda.synchronize()
+            out = {"ranks": ctx.comm_size(), "matches_torch_distributed": bool(torch.equal(mine, job_final))}
+            ctx.comm_destroy()
+            return out
 
-    def give_up():
-        if rank == 0:
-            line["xm_allreduce_counts"] = {"error": "no answer within 120 s"}
-            print(json.dumps(line), flush=True)
-        os._exit(0)
-
-    if not rehearsal:
-        import threading
-        watchdog = threading.Timer(120.0, give_up)
-        watchdog.daemon = True
-        watchdog.start()
-        outcome = None
+    if not rehearsal or os.environ.get("XM_BENCH_FAKE_HANG") == "1":
         try:
-            with stdout_to_stderr():
-                uid = [None]
-                if rank == 0:
-                    try:
-                        uid = [_ffi.comm_unique_id()]
-                    except Exception as e:                       # noqa: BLE001 -- every rank must still reach the broadcast
-                        uid = ["%s: %s" % (type(e).__name__, e)]
-                if world > 1:
-                    dist.broadcast_object_list(uid, src=0)
-                if not isinstance(uid[0], bytes):
-                    raise RuntimeError("xm_comm_unique_id on rank 0: %s" % uid[0])
-                ctx.comm_init(world, rank, uid[0])
-                mine = counts * args.steps                       # every step saw the same block: this rank's job total
-                ctx.allreduce_counts(mine)
-                torch.cuda.synchronize()
-                outcome = {"ranks": ctx.comm_size(), "matches_torch_distributed": bool(torch.equal(mine, job_final))}
-                ctx.comm_destroy()
+            outcome = run_with_watchdog(library_allreduce, watchdog_s, line, "xm_allreduce_counts", rank)
         except Exception as e:                                   # noqa: BLE001 -- reported, not raised
             outcome = {"error": "%s: %s" % (type(e).__name__, e)}
-        watchdog.cancel()
         if rank == 0:
             line["xm_allreduce_counts"] = outcome
     if rank == 0:

@@ -14,7 +14,8 @@ import sys
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libxenomapper_hip.so")
+# XENOMAPPER_HIP_LIB: another build of the same library (tuning builds for A/B runs); never a different implementation
+LIB_PATH = os.environ.get("XENOMAPPER_HIP_LIB") or os.path.join(PKG, "libxenomapper_hip.so")
 
 MODE_SE, MODE_PE_LIBERAL, MODE_PE_CONSERVATIVE = 0, 1, 2
 NO_UNIT = 0xFF

@@ -89,6 +89,18 @@ __device__ __forceinline__ void load4(const T *__restrict__ col, uint64_t r0, ui
     }
 }
 
+// The same for a workgroup whose records all exist: `wg` = the column at the workgroup's first record (uniform, lives in
+// scalar registers), `byte_off` = this lane's offset from there -- one 32-bit VGPR shared by every column of the same
+// element size instead of a 64-bit address per load (global_load ... v_off, s[base:base+1]).
+template <typename T, bool NT>
+__device__ __forceinline__ void load4_wg(const T *__restrict__ wg, uint32_t byte_off, T out[4])
+{
+    typedef typename Vec4<T>::type V;
+    const V *p = reinterpret_cast<const V *>(reinterpret_cast<const char *>(wg) + byte_off);
+    const V v = NT ? __builtin_nontemporal_load(p) : *p;
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+
 // wave64 inclusive prefix sum with DPP (row_shr 1,2,4,8, row_bcast15, row_bcast31): no LDS traffic
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 {
@@ -946,46 +958,42 @@ classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restric
 // path (cigp_slow), 64-bit accumulation, no read past cig_tile[n_tiles] whatever the columns hold.
 // ---------------------------------------------------------------------------------------------
 #define XM_CIGP_CHUNK 512u          // ops per prefix pass: 8 per lane
+// XM_CIGP_LATE_XS=0 (tuning builds): let the compiler hoist the XS / unit-mask loads to the top again
+#ifndef XM_CIGP_LATE_XS
+#define XM_CIGP_LATE_XS 1
+#endif
+#if XM_CIGP_LATE_XS
+#define XM_CIGP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define XM_CIGP_SCHED_FENCE() do { } while (0)
+#endif
 
 struct TileOps {
     uint32_t tb, te;                // the tile's stretch [tb, te) of the op array
     uint32_t v[8];                  // ops tb + 8 lane .. + 7 (first chunk), 0 where past the stretch
-    bool fast;                      // wave-uniform: stretch sane, shorter than XM_CIG_WAVE_OPS
+    bool fast;                      // wave-uniform: stretch sane, shorter than XM_CIG_WAVE_OPS, 16-byte loads stay inside the array
 };
 
-// ops [base + s0, base + s0 + 8) of a stretch of W ops; vector loads when the over-read (< 8 words) stays inside the array
-__device__ __forceinline__ void cigp_load8(const uint32_t *__restrict__ ops, uint32_t n_ops, uint32_t base, uint32_t W,
-                                           uint32_t s0, uint32_t v[8])
+// ops [base + s0, base + s0 + 8) of a stretch of W ops with two 16-byte loads, unconditionally (a conditional load would make
+// the compiler wait for it at the join): lanes past the stretch read its first words instead, and whatever lies past the
+// stretch is masked by the caller.  The over-read (< 8 words) stays inside the array because the caller has checked
+// base + W + 8 <= n_ops (TileOps::fast).
+__device__ __forceinline__ void cigp_load8(const uint32_t *__restrict__ ops, uint32_t base, uint32_t W, uint32_t s0, uint32_t v[8])
 {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = 0u;
-    if (base + W + 8u <= n_ops) {                                        // wave-uniform
-        if (s0 < W) {
-            const v4i32 a = *reinterpret_cast<const v4i32_a4 *>(ops + base + s0);
-            v[0] = (uint32_t)a.x; v[1] = (uint32_t)a.y; v[2] = (uint32_t)a.z; v[3] = (uint32_t)a.w;
-        }
-        if (s0 + 4u < W) {
-            const v4i32 b = *reinterpret_cast<const v4i32_a4 *>(ops + base + s0 + 4u);
-            v[4] = (uint32_t)b.x; v[5] = (uint32_t)b.y; v[6] = (uint32_t)b.z; v[7] = (uint32_t)b.w;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (s0 + (uint32_t)q < W) v[q] = ops[base + s0 + (uint32_t)q];
-    }
-}
-
-__device__ __forceinline__ void cigp_fetch_tile(const CigCols &s, uint32_t t, uint32_t n_ops, TileOps &o)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    o.tb = s.tile[t];                                                    // t is wave-uniform: scalar loads
-    o.te = s.tile[t + 1u];
-    o.fast = o.te >= o.tb && o.te <= n_ops && (o.te - o.tb) < (uint32_t)XM_CIG_WAVE_OPS;
-    if (o.fast) cigp_load8(s.ops, n_ops, o.tb, o.te - o.tb, 8u * lane, o.v);
+    const uint32_t *p = ops + base + ((s0 < W) ? s0 : 0u);
+#ifdef XM_CIGP_OPS_NT
+    const v4i32 a = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p));
+    const v4i32 b = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p + 4));
+#else
+    const v4i32 a = *reinterpret_cast<const v4i32_a4 *>(p);
+    const v4i32 b = *reinterpret_cast<const v4i32_a4 *>(p + 4);
+#endif
+    v[0] = (uint32_t)a.x; v[1] = (uint32_t)a.y; v[2] = (uint32_t)a.z; v[3] = (uint32_t)a.w;
+    v[4] = (uint32_t)b.x; v[5] = (uint32_t)b.y; v[6] = (uint32_t)b.z; v[7] = (uint32_t)b.w;
 }
 
 // The usual case.  cw = the lane's four op counts (one byte each).  false: the wave must take cigp_slow.
-__device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, uint32_t n_ops, const TileOps &o, uint32_t cw,
+__device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, const TileOps &o, uint32_t cw,
                                           const int32_t nmv[4], uint32_t *T, int32_t as_out[4], bool &bad)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1004,14 +1012,15 @@ __device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, uint
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = o.v[q];
         } else {
-            cigp_load8(ops, n_ops, o.tb, W, s0, v);
+            cigp_load8(ops, o.tb, W, s0, v);
         }
         uint32_t p[8], run = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             p[q] = run;                                                  // exclusive inside the lane
-            odd |= (v[q] >> 4) >= (1u << 20);                            // slots past the stretch hold 0
-            run += cigar_term32(v[q]);
+            const uint32_t vq = (s0 + (uint32_t)q < W) ? v[q] : 0u;      // the 16-byte loads run up to 7 words past the stretch
+            odd |= (vq >> 4) >= (1u << 20);
+            run += cigar_term32(vq);
         }
         const uint32_t tincl = wave_scan_incl(run);
         const uint32_t ex = tincl - run + carry;
@@ -1054,7 +1063,9 @@ __device__ __forceinline__ uint32_t cigp_trailer(const uint32_t *__restrict__ op
 
 // The careful path of one wave and species (rare): begins from the counts -- forwards by prefix sum, or, when the tile
 // holds escaped records, backwards from the tile's end, one record after the other -- then one loop per record.
-__device__ __attribute__((noinline)) v4i32 cigp_slow(const uint32_t *__restrict__ ops, uint32_t n_ops, uint32_t tb, uint32_t te,
+// (inlined on purpose: as a called function it pins everything that lives across the call into the callee-saved VGPR
+// blocks v40-47 / v56-63 / v72-79, which costs the kernel two waves per SIMD)
+__device__ __forceinline__ v4i32 cigp_slow(const uint32_t *__restrict__ ops, uint32_t n_ops, uint32_t tb, uint32_t te,
                                                      uint32_t cw, v4i32 nmv, uint32_t *range_flag)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1126,29 +1137,59 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
     const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t r0 = g * 4;
     const bool have_tile = FULL || t < n_tiles;                          // wave-uniform
-    const uint32_t n_ops1 = s1.tile[n_tiles], n_ops2 = s2.tile[n_tiles];
+    const uint32_t lane = threadIdx.x & 63u;
 
-    // everything the wave needs, fetched at once
-    TileOps o1, o2;
-    o1.tb = o1.te = o2.tb = o2.te = 0u; o1.fast = o2.fast = false;
-    if (have_tile) { cigp_fetch_tile(s1, t, n_ops1, o1); cigp_fetch_tile(s2, t, n_ops2, o2); }
+    // What the scores need is fetched at once: NM and the op counts of both species (no dependency at all) ...
     int32_t a1[4], x1[4], a2[4], x2[4], nmv1[4], nmv2[4];
-    load4<int32_t, true, FULL>(s1.nm, r0, n, nmv1);
-    load4<int32_t, true, FULL>(s2.nm, r0, n, nmv2);
-    const uint32_t cw1 = cigp_counts4<FULL>(s1.cnt, r0, n), cw2 = cigp_counts4<FULL>(s2.cnt, r0, n);
-    load4<int32_t, true, FULL>(s1.xs, r0, n, x1);
-    load4<int32_t, true, FULL>(s2.xs, r0, n, x2);
-    uint32_t mb = 0;
-    if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
-    if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+    uint32_t cw1, cw2, mb = 0;
+    const uint64_t wg0 = (uint64_t)blockIdx.x * (BLOCK * 4);              // the workgroup's first record (uniform)
+    const uint32_t t16 = threadIdx.x * 16u, t4 = threadIdx.x * 4u;
+    if (FULL) {
+        load4_wg<int32_t, true>(s1.nm + wg0, t16, nmv1);
+        load4_wg<int32_t, true>(s2.nm + wg0, t16, nmv2);
+        cw1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(s1.cnt + wg0 + t4));
+        cw2 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(s2.cnt + wg0 + t4));
+    } else {
+        load4<int32_t, true, false>(s1.nm, r0, n, nmv1);
+        load4<int32_t, true, false>(s2.nm, r0, n, nmv2);
+        cw1 = cigp_counts4<false>(s1.cnt, r0, n);
+        cw2 = cigp_counts4<false>(s2.cnt, r0, n);
+    }
+    // ... the tile bases of both species (wave-uniform: scalar loads, one wait for all of them) ...
+    TileOps o1, o2;
+    o1.tb = o1.te = o2.tb = o2.te = 0u;
+    const uint32_t n_ops1 = s1.tile[n_tiles], n_ops2 = s2.tile[n_tiles];
+    if (have_tile) { o1.tb = s1.tile[t]; o1.te = s1.tile[t + 1u]; o2.tb = s2.tile[t]; o2.te = s2.tile[t + 1u]; }
+    o1.fast = FULL && o1.te >= o1.tb && o1.te - o1.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o1.te + 8u <= n_ops1;
+    o2.fast = FULL && o2.te >= o2.tb && o2.te - o2.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o2.te + 8u <= n_ops2;
+    // ... and the first 512 ops of both stretches.
+    if (o1.fast) cigp_load8(s1.ops, o1.tb, o1.te - o1.tb, 8u * lane, o1.v);
+    if (o2.fast) cigp_load8(s2.ops, o2.tb, o2.te - o2.tb, 8u * lane, o2.v);
+    XM_CIGP_SCHED_FENCE();
 
     bool bad = false;
-    if (!(FULL && o1.fast && cigp_fast(s1.ops, n_ops1, o1, cw1, nmv1, cig_T, a1, bad))) {
+    if (!(o1.fast && cigp_fast(s1.ops, o1, cw1, nmv1, cig_T, a1, bad))) {
         v4i32 q; q.x = nmv1[0]; q.y = nmv1[1]; q.z = nmv1[2]; q.w = nmv1[3];
         q = cigp_slow(s1.ops, n_ops1, o1.tb, o1.te, cw1, q, range_flag);
         a1[0] = q.x; a1[1] = q.y; a1[2] = q.z; a1[3] = q.w;
     }
-    if (!(FULL && o2.fast && cigp_fast(s2.ops, n_ops2, o2, cw2, nmv2, cig_T, a2, bad))) {
+    // XS and the unit mask are only needed by the state function at the very end: they are fetched here, so that their
+    // registers are not held while species 1 is worked on, and arrive while species 2 is (the fences keep the compiler
+    // from moving the loads back up: with everything in flight at once the kernel needs 72 registers = 6 waves per SIMD
+    // for its 512-thread workgroups instead of 8)
+    XM_CIGP_SCHED_FENCE();
+    if (FULL) {
+        load4_wg<int32_t, true>(s1.xs + wg0, t16, x1);
+        load4_wg<int32_t, true>(s2.xs + wg0, t16, x2);
+        mb = (uint32_t)((unit_bits8 + (wg0 >> 3))[threadIdx.x >> 1] >> ((threadIdx.x & 1u) * 4u)) & 0xFu;
+    } else {
+        load4<int32_t, true, false>(s1.xs, r0, n, x1);
+        load4<int32_t, true, false>(s2.xs, r0, n, x2);
+        if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+        if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+    }
+    XM_CIGP_SCHED_FENCE();
+    if (!(o2.fast && cigp_fast(s2.ops, o2, cw2, nmv2, cig_T, a2, bad))) {
         v4i32 q; q.x = nmv2[0]; q.y = nmv2[1]; q.z = nmv2[2]; q.w = nmv2[3];
         q = cigp_slow(s2.ops, n_ops2, o2.tb, o2.te, cw2, q, range_flag);
         a2[0] = q.x; a2[1] = q.y; a2[2] = q.z; a2[3] = q.w;
@@ -1171,8 +1212,19 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
                                                                    count_lds, sink);
 }
 
+// XM_CIGP_WPE = waves per SIMD the register allocator must make room for: 8 = 64 VGPRs = four 512-thread workgroups per
+// CU.  Left alone the allocator takes 65 (6 waves per SIMD); held to 64 it spills one register, in the careful path.
+// (0 in a tuning build: no constraint.)
+#ifndef XM_CIGP_WPE
+#define XM_CIGP_WPE 8
+#endif
+#if XM_CIGP_WPE
+#define XM_CIGP_ATTR __attribute__((amdgpu_waves_per_eu(XM_CIGP_WPE, XM_CIGP_WPE)))
+#else
+#define XM_CIGP_ATTR
+#endif
 template <bool PAIRED, int BLOCK, bool COUNTS, int BINMODE>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) XM_CIGP_ATTR
 classify_cigp_kernel(const CigCols s1, const CigCols s2, const uint8_t *__restrict__ unit_bits8, int32_t m,
                      uint8_t *__restrict__ code, uint64_t n, uint32_t n_tiles, uint32_t *__restrict__ range_flag, CountSink sink)
 {
