@@ -443,7 +443,7 @@ def singleton_unit_flags(n_records, p_single, seed):
     import numpy as np
     rng = np.random.default_rng(seed)
     items = int(n_records / (2.0 - p_single)) + 1024
-    single = rng.random(items) < (p_single / (2.0 - p_single)) * 2.0 / (1.0 + (p_single / (2.0 - p_single)))
+    single = rng.random(items) < p_single                          # per read template
     length = np.where(single, 1, 2)
     begin = np.cumsum(length) - length
     keep = (begin + length <= n_records)

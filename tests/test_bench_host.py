@@ -1,0 +1,93 @@
+"""bench.py's host-side machinery that must work before any GPU is involved: the watchdog around the library
+collective (a hang must put the JSON line on the REAL stdout and exit non-zero) and the tie between the replayed PMC
+traffic figures and the kernel sources they were measured on."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+from tests import helpers as H
+
+
+def test_watchdog_delivers_the_line_on_stdout_and_exits_nonzero():
+    """A collective that never returns, entered -- as bench.py does -- while fd 1 is redirected to stderr."""
+    prog = (
+        "import sys, time; sys.path.insert(0, %r); import bench\n"
+        "line = {'metric': 'm', 'value': 1.0, 'xm_allreduce_counts': None}\n"
+        "def hang():\n"
+        "    with bench.stdout_to_stderr():\n"
+        "        print('RCCL banner that must not reach stdout')\n"
+        "        time.sleep(60)\n"
+        "bench.run_with_watchdog(hang, 0.5, line, 'xm_allreduce_counts', rank=0)\n" % H.REPO)
+    p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3
+    rec = json.loads(p.stdout)                                  # exactly the line, nothing else
+    assert rec["value"] == 1.0 and "no answer within" in rec["xm_allreduce_counts"]["error"]
+    assert "RCCL banner" in p.stderr and "gave up" in p.stderr
+
+
+def test_watchdog_other_ranks_exit_nonzero_without_a_line():
+    prog = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "bench.run_with_watchdog(lambda: time.sleep(60), 0.3, None, 'xm_allreduce_counts', rank=1)\n" % H.REPO)
+    p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3 and p.stdout == ""
+
+
+def test_watchdog_is_transparent_when_the_call_returns():
+    sys.path.insert(0, H.REPO)
+    import bench
+    line = {"x": None}
+    assert bench.run_with_watchdog(lambda: 42, 5.0, line, "x") == 42 and line == {"x": None}
+
+
+def test_replayed_traffic_goes_stale_when_a_kernel_source_changes(tmp_path):
+    """profiles/pmc_traffic.json carries the hash of xm_kernels.hip + xm_kernels.h; editing a comment flips bench.py's
+    traffic to null / "stale"."""
+    sys.path.insert(0, os.path.join(H.REPO, "tools"))
+    import kernel_hash
+    repo = tmp_path / "repo"
+    for rel in kernel_hash.KERNEL_SOURCES:
+        (repo / os.path.dirname(rel)).mkdir(parents=True, exist_ok=True)
+        shutil.copy(os.path.join(H.REPO, rel), repo / rel)
+    (repo / "profiles").mkdir()
+    rec = {"kernel_src_sha256": kernel_hash.kernel_src_sha256(str(repo), flags=""),
+           "workloads": {"cfg2": {"pairs": 50_000_000, "classify_hbm_bytes_per_launch": 1.7e9, "step_hbm_bytes": 2.0e9,
+                                  "profile": "profiles/rXX_cfg2_pmc.json"}}}
+    (repo / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec))
+    os.environ.pop("XENOMAPPER_HIPCC_FLAGS", None)
+    assert kernel_hash.load_traffic("cfg2", 50_000_000, str(repo))[:2] == (1.7e9, 2.0e9)
+    assert kernel_hash.load_traffic("cfg2", 1_000_000, str(repo)) == (None, None, None)        # another size: no claim
+    assert kernel_hash.load_traffic("cfg3", 50_000_000, str(repo)) == (None, None, None)       # never collected
+    with open(repo / kernel_hash.KERNEL_SOURCES[0], "a") as fh:
+        fh.write("// a comment\n")
+    assert kernel_hash.load_traffic("cfg2", 50_000_000, str(repo)) == (None, None, "stale")
+    os.environ["XENOMAPPER_HIPCC_FLAGS"] = "-DXM_CIGP_WPE=0"
+    try:
+        assert kernel_hash.kernel_src_sha256(str(repo)) != kernel_hash.kernel_src_sha256(str(repo), flags="")
+    finally:
+        del os.environ["XENOMAPPER_HIPCC_FLAGS"]
+
+
+def test_committed_traffic_file_matches_its_schema():
+    path = os.path.join(H.REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return
+    rec = json.load(open(path))
+    assert len(rec["kernel_src_sha256"]) == 64
+    for name, ent in rec["workloads"].items():
+        assert name in ("cfg2", "cfg3", "cfg5", "f64", "se") and ent["pairs"] > 0
+        assert ent["classify_hbm_bytes_per_launch"] > 0 and ent["step_hbm_bytes"] >= ent["classify_hbm_bytes_per_launch"]
+
+
+def test_singleton_flags_model():
+    sys.path.insert(0, H.REPO)
+    import bench
+    f = bench.singleton_unit_flags(200_000, 0.01, seed=3)
+    assert f[0] == 0 and f.dtype.itemsize == 1
+    pairs = int(f.sum())
+    singles = 200_000 - 2 * pairs
+    assert 0.005 < singles / (pairs + singles) < 0.02
+    import numpy as np
+    assert not (f[1:] & f[:-1]).any()                          # two units never touch: a unit's first record closes none
+    assert np.flatnonzero(f)[:50].tolist() != list(range(1, 100, 2))   # parity flips: not strictly interleaved

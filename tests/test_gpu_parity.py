@@ -207,13 +207,14 @@ def _oracle_cigar_classify(mode, c1, xs1, c2, xs2, bits, mi):
     return H.c_classify(mode, a1, xs1, a2, xs2, bits, mi)
 
 
-def _random_cigar(rng, n, max_ops=12):
+def _random_cigar(rng, n, max_ops=12, op_hi=9):
     n_ops = rng.integers(0, max_ops + 1, n).astype(np.uint32)
     n_ops[rng.random(n) < 0.5] = 1
     off = np.zeros(n + 1, dtype=np.uint32)
     np.cumsum(n_ops, out=off[1:])
     total = int(off[-1])
-    ops = (rng.integers(1, 60, total).astype(np.uint32) << 4) | rng.integers(0, 9, total).astype(np.uint32)
+    # op codes 0..8 = MIDNSHP=X; op_hi = 16 also draws the codes no CIGAR operation has (they score nothing)
+    ops = (rng.integers(1, 60, total).astype(np.uint32) << 4) | rng.integers(0, op_hi, total).astype(np.uint32)
     nm = np.where(rng.random(n) < 0.15, ABSENT, rng.integers(0, 6, n)).astype(np.int32)
     return {"nm": nm, "cig_off": off, "cig_oplen": ops}
 
@@ -285,6 +286,38 @@ def test_split_edges_two_bins(ctx, mode, k):
         if mode:
             flags[0::2] = 0
         check_all(ctx, mode, cols, H.synth.pack_unit_bits(flags), NEG)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n", [2 * (1 << 21) + 5, 7 * (1 << 21) + 2049, 8 * (1 << 21)])
+def test_scan_carry_between_parts_of_the_one_launch_scan(ctx, n, mode):
+    """2 to 8 scan parts (a part = 1024 granules = 2^21 records): the one-launch K2b adds up the granule counts in front
+    of its part itself (scan_kernel<DIRECT>).  One bin has no unit at all in part 0 and one none after part 0, so a
+    wrong carry shows up in gran_off / the index lists; the stand-alone and the fused forms are both compared."""
+    rng = np.random.default_rng(n % 1000 + mode)
+    states = rng.integers(0, 6, n)
+    part0 = np.arange(n) < (1 << 21)
+    states[part0 & (states == 3)] = 0                              # bin 3: nothing in part 0
+    states[~part0 & (states == 1)] = 2                             # bin 1: nothing after part 0
+    if mode:
+        states[0::2] = states[1::2][: len(states[0::2])] if n % 2 == 0 else np.append(states[1::2], states[-1])[: len(states[0::2])]
+    cols = _columns_of_states(states)
+    flags = np.ones(n, dtype=np.uint8)
+    if mode:
+        flags[0::2] = 0
+    bits = H.synth.pack_unit_bits(flags)
+    want_code, want_counts = H.c_classify(mode, *cols, bits, ABSENT)
+    want_idx, want_off = H.c_compact(mode, want_code)
+    first3 = want_idx[int(want_off[3])] if want_off[4] > want_off[3] else None
+    assert first3 is None or first3 >= (1 << 21)
+    code, counts = ctx.classify(mode, *cols, bits, ABSENT)
+    assert np.array_equal(code, want_code) and np.array_equal(counts, want_counts)
+    idx, off, counts2 = ctx.compact(mode, code)
+    assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx) and np.array_equal(counts2, want_counts)
+    for want_bytes in (True, False):                               # category bytes / compact stream between K1 and K2c
+        fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, ABSENT, want_code=want_bytes)
+        assert np.array_equal(fcounts, want_counts) and np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
+        assert fcode is None or np.array_equal(fcode, want_code)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -410,7 +443,7 @@ def test_classify_cigar_packed_dev(ctx, n):
     """The packed-column kernel (K1p) through its device-resident entry point: all modes, a threshold, irregular
     unit masks (so that workgroups begin with units: the halo), every output form."""
     rng = np.random.default_rng(300 + n)
-    c1, c2 = _random_cigar(rng, n), _random_cigar(rng, n)
+    c1, c2 = _random_cigar(rng, n, op_hi=16), _random_cigar(rng, n)
     xs = [np.where(rng.random(n) < 0.8, ABSENT, -rng.integers(0, 200, n)).astype(np.int32) for _ in range(2)]
     for mode, m in itertools.product((0, 1, 2), (NEG, -40.5)):
         flags = rng.random(n) < (0.55 if mode else 0.9)

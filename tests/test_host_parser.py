@@ -597,3 +597,29 @@ def test_bam_lines_grows_its_buffer_for_a_line_longer_than_8_mib(tmp_path):
         assert fields[9][:4] == "ACAC" and fields[10][:2] == "??"
     with open(path, "rb") as fh:
         assert xm.get_bam_header(fh) == []
+
+
+def test_bam_reader_maps_the_handle_it_was_given(tmp_path):
+    """A binary handle without a usable name (open(fd, 'rb')), a handle that has been read from, and a file that was
+    renamed and replaced after it was opened: the decoder reads the file the HANDLE refers to (it used to pass an int
+    to np.memmap, and to reopen the path)."""
+    import os
+    import shutil
+    from xenomapper_amd import xenomapper as xm
+    base = os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_human")
+    with open(base + ".sam") as fh:
+        want = [line for line in fh.read().split("\n") if line and not line.startswith("@")]
+    path = tmp_path / "a.bam"
+    shutil.copy(base + ".bam", path)
+    fd = os.open(path, os.O_RDONLY)
+    with open(fd, "rb") as fh:                                   # fh.name is the int fd
+        assert isinstance(fh.name, int)
+        got = [line.rstrip("\n") for line in xm.bam_lines(fh)]
+    assert got == want
+    with open(path, "rb") as fh:
+        fh.read(10)                                              # position moved: the whole file is decoded all the same
+        os.rename(path, tmp_path / "moved.bam")
+        path.write_bytes(b"not a bam file")                      # the old name now points at something else
+        got = [line.rstrip("\n") for line in xm.bam_lines(fh)]
+        assert fh.tell() == 10
+    assert got == want

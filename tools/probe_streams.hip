@@ -1,0 +1,76 @@
+// probe_streams.hip -- on-box microbenchmark (not shipped): how fast does HBM deliver a fixed number of bytes when they
+// come as K concurrent streams?  Every lane reads 16 bytes from each of K equally long arrays (one 1 KiB request per
+// wave and array, as the classify kernels do), nothing is written.  Variants: workgroup size, and "tiled": the same
+// bytes as ONE array in which each 256-record tile holds its K pieces back to back (an AoSoA layout).
+//   hipcc -O3 --offload-arch=gfx950 tools/probe_streams.hip -o /tmp/probe_streams && /tmp/probe_streams
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int K, int BLOCK, bool TILED>
+__global__ void __launch_bounds__(BLOCK) read_k(const v4i *base, size_t stride_v4, size_t groups, unsigned *out)
+{
+    const size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= groups) return;
+    v4i acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        // SoA: array k starts at k * stride; tiled: tile (g / 64) holds K pieces of 64 x 16 bytes back to back
+        const v4i *p = TILED ? base + (g / 64) * (64 * K) + k * 64 + (g % 64) : base + k * stride_v4 + g;
+        acc ^= __builtin_nontemporal_load(p);
+    }
+    unsigned r = (unsigned)(acc.x ^ acc.y ^ acc.z ^ acc.w);
+    r ^= (unsigned)__shfl_xor((int)r, 32, 64);
+    if (r == 0x12345678u && (threadIdx.x & 63) == 0) out[g >> 6] = r;      // practically never
+}
+
+template <int K, int BLOCK, bool TILED>
+static void run(const v4i *buf, size_t total_bytes, unsigned *out)
+{
+    const size_t groups = total_bytes / 16 / K;                  // 16-byte groups per stream
+    const size_t stride = (groups + 4095 + 977) & ~(size_t)63;   // not a power of two apart
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    std::vector<float> ms;
+    for (int it = 0; it < 12; ++it) {
+        CK(hipEventRecord(a));
+        read_k<K, BLOCK, TILED><<<(unsigned)((groups + BLOCK - 1) / BLOCK), BLOCK>>>(buf, stride, groups, out);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float t; CK(hipEventElapsedTime(&t, a, b));
+        if (it >= 2) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const double bytes = (double)groups * 16 * K;
+    printf("K=%2d block=%4d %-5s  median %.1f us  min %.1f us  ->  %.2f TB/s (median)\n", K, BLOCK, TILED ? "tiled" : "soa",
+           ms[ms.size() / 2] * 1e3, ms[0] * 1e3, bytes / (ms[ms.size() / 2] * 1e-3) / 1e12);
+}
+
+int main()
+{
+    const size_t total = 2400ull << 20;                          // 2.4 GiB read per launch, whatever K
+    v4i *buf; unsigned *out;
+    CK(hipMalloc(&buf, total + (64u << 20)));
+    CK(hipMemset(buf, 1, total + (64u << 20)));
+    CK(hipMalloc(&out, 64u << 20));
+    run<1, 256, false>(buf, total, out);
+    run<2, 256, false>(buf, total, out);
+    run<4, 256, false>(buf, total, out);
+    run<4, 512, false>(buf, total, out);
+    run<6, 256, false>(buf, total, out);
+    run<8, 256, false>(buf, total, out);
+    run<8, 512, false>(buf, total, out);
+    run<10, 256, false>(buf, total, out);
+    run<10, 512, false>(buf, total, out);
+    run<12, 256, false>(buf, total, out);
+    run<4, 256, true>(buf, total, out);
+    run<8, 256, true>(buf, total, out);
+    run<10, 512, true>(buf, total, out);
+    run<12, 256, true>(buf, total, out);
+    return 0;
+}

@@ -32,7 +32,9 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--pairs", type=int, default=50_000_000)
     ap.add_argument("--out", required=True)
-    ap.add_argument("--pmc-classify-out", help="write the classify kernel's per-launch HBM bytes here (read by bench.py)")
+    ap.add_argument("--traffic-json", help="profiles/pmc_traffic.json: add/replace this workload's entry (read by bench.py), "
+                                           "stamped with the hash of the kernel sources in the tree")
+    ap.add_argument("--workload", help="bench.py workload name of this profile (cfg2, cfg3, cfg5 ...)")
     a = ap.parse_args()
     if a.stats:
         rows = list(csv.DictReader(open(a.stats)))
@@ -69,14 +71,27 @@ def main():
                 d["hbm_bytes_per_launch"] = d["read_bytes_per_launch_corrected"] + d["write_bytes_per_launch"]
                 d["hbm_bytes_per_pair"] = d["hbm_bytes_per_launch"] / a.pairs
         json.dump(pmc, open(a.out + "_pmc.json", "w"), indent=1, sort_keys=True)
-        if a.pmc_classify_out:
-            for k, d in pmc.items():
-                if k.startswith("classify_kernel") and "hbm_bytes_per_launch" in d:
-                    json.dump({"kernel": k, "hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "pairs": a.pairs,
-                               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE x2 "
-                                         "per the gfx950 correction of MI355X_MICROARCH.md section HBM",
-                               "profile": a.out + "_pmc.json"},
-                              open(a.pmc_classify_out, "w"), indent=1, sort_keys=True)
+        if a.traffic_json and a.workload:
+            import os
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import kernel_hash
+            sha = kernel_hash.kernel_src_sha256()
+            try:
+                rec = json.load(open(a.traffic_json))
+            except (OSError, ValueError):
+                rec = {}
+            if rec.get("kernel_src_sha256") != sha:             # entries measured on other sources are void
+                rec = {"kernel_src_sha256": sha, "workloads": {}}
+            rec["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --workload W`; "
+                             "FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md section HBM; kernel_src_sha256 = "
+                             "tools/kernel_hash.py over xm_kernels.hip + xm_kernels.h (+ extra hipcc flags)")
+            per = {k: d["hbm_bytes_per_launch"] for k, d in pmc.items() if "hbm_bytes_per_launch" in d}
+            cls = [v for k, v in per.items() if k.startswith("classify")]
+            if cls:
+                rec["workloads"][a.workload] = {"pairs": a.pairs, "classify_hbm_bytes_per_launch": max(cls),
+                                                "step_hbm_bytes": sum(per.values()), "kernels": per,
+                                                "profile": "profiles/" + os.path.basename(a.out) + "_pmc.json"}
+                json.dump(rec, open(a.traffic_json, "w"), indent=1, sort_keys=True)
         print(json.dumps(pmc, indent=1, sort_keys=True))
 
 

@@ -701,6 +701,17 @@ __device__ __forceinline__ uint32_t cigar_term32(uint32_t v)
     return t;
 }
 
+// the same for an op of length < 2^24, branch- and compare-free: penalty = A[op] + B[op] * len with the two 9-entry tables
+// packed into nibbles (A: I, D -> 5; B: I, D -> 3, S -> 2); op codes above 8 are not CIGAR operations and score nothing
+__device__ __forceinline__ uint32_t cigar_term24(uint32_t v)
+{
+    uint32_t op = v & 15u;
+    op = op < 8u ? op : 8u;
+    const uint32_t a = __builtin_amdgcn_ubfe(0x00000550u, op * 4u, 4u);
+    const uint32_t b = __builtin_amdgcn_ubfe(0x00020330u, op * 4u, 4u);     // offset 32 (op 8) reads as offset 0: nibble 0 = 0
+    return __umul24(b, v >> 4) + a;
+}
+
 __device__ __forceinline__ int32_t cigar_clamp(long long s, uint32_t *range_flag)
 {
     if (s <= (long long)INT32_MIN || s > (long long)INT32_MAX) {
@@ -962,6 +973,13 @@ classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restric
 #ifndef XM_CIGP_LATE_XS
 #define XM_CIGP_LATE_XS 1
 #endif
+#ifndef XM_CIGP_OPS_NT
+#define XM_CIGP_OPS_NT 1
+#endif
+// XM_CIGP_ABL (tuning builds, results wrong on purpose): 1 = no op loads, no scoring; 2 = op loads, no scans / LDS table
+#ifndef XM_CIGP_ABL
+#define XM_CIGP_ABL 0
+#endif
 #if XM_CIGP_LATE_XS
 #define XM_CIGP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -981,7 +999,9 @@ struct TileOps {
 __device__ __forceinline__ void cigp_load8(const uint32_t *__restrict__ ops, uint32_t base, uint32_t W, uint32_t s0, uint32_t v[8])
 {
     const uint32_t *p = ops + base + ((s0 < W) ? s0 : 0u);
-#ifdef XM_CIGP_OPS_NT
+    // non-temporal like every other input of the kernel: read once.  (Measured: with plain loads the ops push the compact
+    // category stream this kernel writes out of the cache before K2c reads it -- K2c 70 instead of 48 us per 50 M pairs.)
+#if XM_CIGP_OPS_NT
     const v4i32 a = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p));
     const v4i32 b = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p + 4));
 #else
@@ -1014,14 +1034,17 @@ __device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, cons
         } else {
             cigp_load8(ops, o.tb, W, s0, v);
         }
-        uint32_t p[8], run = 0;
+        // No masking of the slots past the stretch (the loads run up to 7 words over it, lanes behind it re-read its
+        // first words): T[j] sums the slots below j, and only T[0 .. W] is ever read.  A long op out there can at worst
+        // send the wave to the careful path.
+        uint32_t p[8], run = 0, any = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             p[q] = run;                                                  // exclusive inside the lane
-            const uint32_t vq = (s0 + (uint32_t)q < W) ? v[q] : 0u;      // the 16-byte loads run up to 7 words past the stretch
-            odd |= (vq >> 4) >= (1u << 20);
-            run += cigar_term32(vq);
+            any |= v[q];
+            run += cigar_term24(v[q]);
         }
+        odd |= any >= (1u << 24);                                        // some op of length >= 2^20
         const uint32_t tincl = wave_scan_incl(run);
         const uint32_t ex = tincl - run + carry;
         *reinterpret_cast<uint4 *>(T + s0) = make_uint4(ex + p[0], ex + p[1], ex + p[2], ex + p[3]);
@@ -1163,11 +1186,28 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
     o1.fast = FULL && o1.te >= o1.tb && o1.te - o1.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o1.te + 8u <= n_ops1;
     o2.fast = FULL && o2.te >= o2.tb && o2.te - o2.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o2.te + 8u <= n_ops2;
     // ... and the first 512 ops of both stretches.
+#if XM_CIGP_ABL != 1
     if (o1.fast) cigp_load8(s1.ops, o1.tb, o1.te - o1.tb, 8u * lane, o1.v);
     if (o2.fast) cigp_load8(s2.ops, o2.tb, o2.te - o2.tb, 8u * lane, o2.v);
+#endif
     XM_CIGP_SCHED_FENCE();
 
     bool bad = false;
+#if XM_CIGP_ABL
+    if (FULL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a1[j] = nmv1[j] == INT32_MIN ? INT32_MIN : -6 * nmv1[j] - (int32_t)((cw1 >> (8 * j)) & 255u);
+            a2[j] = nmv2[j] == INT32_MIN ? INT32_MIN : -6 * nmv2[j] - (int32_t)((cw2 >> (8 * j)) & 255u);
+        }
+#if XM_CIGP_ABL == 2
+        uint32_t x = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x ^= o1.v[q] ^ o2.v[q];
+        if (x == 0x87654321u) a1[0] = 0;
+#endif
+    } else
+#endif
     if (!(o1.fast && cigp_fast(s1.ops, o1, cw1, nmv1, cig_T, a1, bad))) {
         v4i32 q; q.x = nmv1[0]; q.y = nmv1[1]; q.z = nmv1[2]; q.w = nmv1[3];
         q = cigp_slow(s1.ops, n_ops1, o1.tb, o1.te, cw1, q, range_flag);
@@ -1189,6 +1229,9 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
         if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
     }
     XM_CIGP_SCHED_FENCE();
+#if XM_CIGP_ABL
+    if (!FULL)
+#endif
     if (!(o2.fast && cigp_fast(s2.ops, o2, cw2, nmv2, cig_T, a2, bad))) {
         v4i32 q; q.x = nmv2[0]; q.y = nmv2[1]; q.z = nmv2[2]; q.w = nmv2[3];
         q = cigp_slow(s2.ops, n_ops2, o2.tb, o2.te, cw2, q, range_flag);
@@ -1212,11 +1255,11 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
                                                                    count_lds, sink);
 }
 
-// XM_CIGP_WPE = waves per SIMD the register allocator must make room for: 8 = 64 VGPRs = four 512-thread workgroups per
-// CU.  Left alone the allocator takes 65 (6 waves per SIMD); held to 64 it spills one register, in the careful path.
-// (0 in a tuning build: no constraint.)
+// XM_CIGP_WPE (tuning builds) = waves per SIMD the register allocator must make room for: 8 = 64 VGPRs = four 512-thread
+// workgroups per CU.  Left alone the allocator takes 65 (three workgroups per CU) -- and the kernel is exactly as fast
+// (profiles/r03_ab_cigp.txt), so the product build leaves it alone.
 #ifndef XM_CIGP_WPE
-#define XM_CIGP_WPE 8
+#define XM_CIGP_WPE 0
 #endif
 #if XM_CIGP_WPE
 #define XM_CIGP_ATTR __attribute__((amdgpu_waves_per_eu(XM_CIGP_WPE, XM_CIGP_WPE)))

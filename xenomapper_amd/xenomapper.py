@@ -24,6 +24,7 @@ from __future__ import annotations
 import argparse
 import contextlib
 import io
+import mmap
 import math
 import os
 import re
@@ -94,9 +95,10 @@ def _bam_reader(bamfile):
         fd = bamfile.fileno()
         st = os.fstat(fd)
         if stat.S_ISREG(st.st_mode) and st.st_size > 0:
-            data = np.memmap(bamfile.name if isinstance(getattr(bamfile, "name", None), (str, bytes)) else fd,
-                             dtype=np.uint8, mode="r", shape=(st.st_size,))
-    except (AttributeError, OSError, ValueError, io.UnsupportedOperation):
+            # mapped through the handle's own descriptor: the file the caller opened (not whatever its name points
+            # at by now), whatever kind of name the handle has, and its read position is left alone
+            data = np.frombuffer(mmap.mmap(fd, 0, access=mmap.ACCESS_READ), dtype=np.uint8)
+    except (AttributeError, OSError, ValueError, TypeError, io.UnsupportedOperation):
         data = None
     if data is None:
         data = np.frombuffer(bamfile.read(), dtype=np.uint8)
