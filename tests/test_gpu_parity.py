@@ -291,9 +291,10 @@ def test_split_edges_two_bins(ctx, mode, k):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("n", [2 * (1 << 21) + 5, 7 * (1 << 21) + 2049, 8 * (1 << 21)])
 def test_scan_carry_between_parts_of_the_one_launch_scan(ctx, n, mode):
-    """2 to 8 scan parts (a part = 1024 granules = 2^21 records): the one-launch K2b adds up the granule counts in front
-    of its part itself (scan_kernel<DIRECT>).  One bin has no unit at all in part 0 and one none after part 0, so a
-    wrong carry shows up in gran_off / the index lists; the stand-alone and the fused forms are both compared."""
+    """2 to 8 scan parts (a part = 1024 granules = 2^21 records): K2b's carry between parts -- the part totals the
+    counting side adds up in replicas (count_flush), summed by every scan workgroup for the parts in front of its own.
+    One bin has no unit at all in part 0 and one none after part 0, so a wrong carry shows up in gran_off / the index
+    lists; the stand-alone and the fused forms are both compared, and each twice (the totals must be zero again)."""
     rng = np.random.default_rng(n % 1000 + mode)
     states = rng.integers(0, 6, n)
     part0 = np.arange(n) < (1 << 21)
@@ -314,7 +315,7 @@ def test_scan_carry_between_parts_of_the_one_launch_scan(ctx, n, mode):
     assert np.array_equal(code, want_code) and np.array_equal(counts, want_counts)
     idx, off, counts2 = ctx.compact(mode, code)
     assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx) and np.array_equal(counts2, want_counts)
-    for want_bytes in (True, False):                               # category bytes / compact stream between K1 and K2c
+    for want_bytes in (True, False, True):                         # category bytes / compact stream between K1 and K2c
         fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, ABSENT, want_code=want_bytes)
         assert np.array_equal(fcounts, want_counts) and np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
         assert fcode is None or np.array_equal(fcode, want_code)

@@ -51,6 +51,40 @@ static void run(const v4i *buf, size_t total_bytes, unsigned *out)
            ms[ms.size() / 2] * 1e3, ms[0] * 1e3, bytes / (ms[ms.size() / 2] * 1e-3) / 1e12);
 }
 
+// write-only ceiling: every lane stores 4 (W4 = false) or 16 bytes, consecutive lanes consecutive addresses
+template <bool W4, bool NT>
+__global__ void __launch_bounds__(256) write_k(unsigned *out, size_t words)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * (W4 ? 4 : 1);
+    if (i >= words) return;
+    if (W4) {
+        v4i v = {(int)i, (int)i + 1, (int)i + 2, (int)i + 3};
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4i *>(out + i)); else *reinterpret_cast<v4i *>(out + i) = v;
+    } else {
+        if (NT) __builtin_nontemporal_store((unsigned)i, out + i); else out[i] = (unsigned)i;
+    }
+}
+
+template <bool W4, bool NT>
+static void run_write(unsigned *buf, size_t bytes)
+{
+    const size_t words = bytes / 4, threads = W4 ? words / 4 : words;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    std::vector<float> ms;
+    for (int it = 0; it < 12; ++it) {
+        CK(hipEventRecord(a));
+        write_k<W4, NT><<<(unsigned)((threads + 255) / 256), 256>>>(buf, words);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float t; CK(hipEventElapsedTime(&t, a, b));
+        if (it >= 2) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    printf("write %5zu MB  %2d B/lane %-5s  median %.1f us  min %.1f us  ->  %.2f TB/s (median)\n", bytes >> 20, W4 ? 16 : 4,
+           NT ? "nt" : "plain", ms[ms.size() / 2] * 1e3, ms[0] * 1e3, (double)bytes / (ms[ms.size() / 2] * 1e-3) / 1e12);
+}
+
 int main()
 {
     const size_t total = 2400ull << 20;                          // 2.4 GiB read per launch, whatever K
@@ -72,5 +106,11 @@ int main()
     run<8, 256, true>(buf, total, out);
     run<10, 512, true>(buf, total, out);
     run<12, 256, true>(buf, total, out);
+    for (size_t mb : {200, 400, 2000}) {
+        run_write<false, false>((unsigned *)buf, mb << 20);
+        run_write<false, true>((unsigned *)buf, mb << 20);
+        run_write<true, false>((unsigned *)buf, mb << 20);
+        run_write<true, true>((unsigned *)buf, mb << 20);
+    }
     return 0;
 }

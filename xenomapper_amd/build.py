@@ -73,12 +73,6 @@ def build_host_sanitized(out_path, verbose=False):
     return out_path
 
 
-def build_oracle(verbose=False):
-    """The C oracle is test infrastructure; building it here is not using it."""
-    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s"])
-    return os.path.join(REPO, "oracle", "libxm_oracle.so")
-
-
 def build_all(force=False, verbose=False):
     out = [build_hip(force, verbose)]
     host = build_host(force, verbose)

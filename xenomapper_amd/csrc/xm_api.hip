@@ -130,7 +130,7 @@ int check_launch(xm_ctx *ctx, const char *what)
 }
 
 const size_t COUNTS_REP_BYTES = (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t);
-const size_t PART_TOT_BYTES = 8 * XM_PART_STRIDE * sizeof(uint32_t);
+const size_t PART_TOT_BYTES = (size_t)XM_PART_REPLICAS * 8 * XM_PART_STRIDE * sizeof(uint32_t);
 
 // a launch failed between counting and K2b: the count replicas may be non-zero -- clear them, so that the next call
 // starts from zero again
@@ -148,6 +148,7 @@ bool wrong_device(const xm_ctx *ctx)
 void reset_count_state(xm_ctx *ctx, hipStream_t st)
 {
     (void)hipMemsetAsync(ctx->d_counts_rep, 0, COUNTS_REP_BYTES, st);
+    (void)hipMemsetAsync(ctx->d_part_tot, 0, PART_TOT_BYTES, st);
 }
 
 }  // namespace
@@ -211,6 +212,7 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counts_rep, COUNTS_REP_BYTES);
     if (e == hipSuccess) e = hipMemset(ctx->d_counts_rep, 0, COUNTS_REP_BYTES);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_part_tot, PART_TOT_BYTES);
+    if (e == hipSuccess) e = hipMemset(ctx->d_part_tot, 0, PART_TOT_BYTES);
     if (e != hipSuccess) {
         const int rc = fail_hip(nullptr, e, "xm_ctx_create: workspace");
         if (ctx->d_gran_counts) (void)hipFree(ctx->d_gran_counts);
@@ -372,9 +374,10 @@ static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const
     {
         Span span(ctx, st, XM_K_SCATTER);
         xm::launch_scatter(st, cp.plan, mode, n, from_bins4 ? cp.bins4 : code, from_bins4, ctx->d_gran_off, bin_totals,
-                           bin_offsets, idx_out);
+                           bin_offsets, idx_out, ctx->d_part_tot);
     }
-    return check_launch(ctx, "scatter_kernel");
+    if ((rc = check_launch(ctx, "scatter_kernel")) != XM_OK) reset_count_state(ctx, st);      // K2c zeroes the part totals
+    return rc;
 }
 
 static xm::CountPlan count_plan(xm_ctx *ctx, uint64_t n)
@@ -544,6 +547,7 @@ static int counts_only_tail(xm_ctx *ctx, const xm::CountPlan &cp, uint64_t *d_co
     xm::launch_scan(nullptr, cp, ctx->d_gran_off, ctx->d_counts_rep + XM_COUNT_REPLICAS * 64, d_counts);
     const int rc = check_launch(ctx, "scan_kernel");
     if (rc != XM_OK) reset_count_state(ctx, nullptr);
+    else (void)hipMemsetAsync(ctx->d_part_tot, 0, PART_TOT_BYTES, nullptr);         // no K2c here to zero the part totals
     return rc;
 }
 

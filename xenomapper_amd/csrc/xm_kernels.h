@@ -10,10 +10,7 @@
 #define XM_MAX_GRANULES ((uint32_t)((0xFFFFF000ull + XM_GRAN - 1) / XM_GRAN))
 #define XM_PART_GRAN 1024u     // K2b: granules per part (first scan level; one K2b workgroup scans one part of one bin)
 #define XM_PART_STRIDE 2112u   // row pitch of part_tot: >= XM_MAX_GRANULES / XM_PART_GRAN (2048) + slack
-#ifndef XM_SCAN_DIRECT_PARTS
-#define XM_SCAN_DIRECT_PARTS 8u   // up to this many parts (16 M records: the file path's blocks) K2b is one launch, carries summed
-                                  // from the granule counts; at 48 parts the two-launch form measured faster (10.8 vs 12.1 us)
-#endif
+#define XM_PART_REPLICAS 64u  // the part totals are added into one of 64 copies (rows 8 x XM_PART_STRIDE words apart); K2b sums them
 #define XM_COUNT_REPLICAS 64u // category_counts is added into one of 64 copies; K2b sums them
 #define XM_CLASSIFY_BLOCK 512  // classify workgroup (tuned on the box with tools/tune_kernels.hip)
 #ifndef XM_CIGAR_BLOCK
@@ -33,7 +30,7 @@ struct GranPlan {
 struct CountPlan {
     GranPlan plan = {0, 0};
     uint32_t *gran_counts = nullptr;   // [8][gran_stride]
-    uint32_t *part_tot = nullptr;      // [8][XM_PART_STRIDE]: K2b's first level (units per bin and part)
+    uint32_t *part_tot = nullptr;      // [XM_PART_REPLICAS][8][XM_PART_STRIDE]: K2b's first level (units per bin and part), all zero between calls
     uint8_t *bins4 = nullptr;          // where a counting classify kernel writes the compact category stream, or null
     uint64_t *counts_rep = nullptr;    // [XM_COUNT_REPLICAS][64], all zero between calls
 };
@@ -66,8 +63,9 @@ void launch_classify_cigp(hipStream_t st, int mode, uint64_t n, const CigCols &s
 void launch_hist(hipStream_t st, int mode, uint64_t n, const uint8_t *code, const CountPlan &cp);
 void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64_t *bin_totals, uint64_t *counts);
 // code_is_bins4: `code` is the compact category stream of a counting classify kernel, not category bytes
+// also zeroes the part totals K2b has consumed
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
-                    const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out);
+                    const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out, uint32_t *part_tot);
 void launch_mate_correlate(hipStream_t st, uint64_t n, const double *track, uint32_t m, const double *density, double *out);
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,
                   const uint32_t *cig_oplen, int32_t *as_out, uint32_t *range_flag);

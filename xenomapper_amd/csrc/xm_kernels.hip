@@ -141,6 +141,7 @@ __device__ __forceinline__ void lds_settle()
 
 struct CountSink {
     uint32_t *gran_counts;               // [8][gran_stride]
+    uint32_t *part_tot;                  // [XM_PART_REPLICAS][8][XM_PART_STRIDE]: units per bin and part, in replicas (all zero between calls)
     unsigned long long *counts_rep;      // [XM_COUNT_REPLICAS][64]
     uint8_t *bins4;                      // compact category stream (XM_GRAN / 2 bytes per granule) or null
     uint32_t gran_stride;
@@ -160,7 +161,14 @@ __device__ __forceinline__ void count_flush(uint32_t *lds, uint32_t granule, con
         atomicAdd(&misc[8u + bin_of_code(sink.mode, lane)], s);          // a counted slot is never 0xFF: bin <= 6
     }
     lds_settle();
-    if (lane < 8u) sink.gran_counts[(uint64_t)lane * sink.gran_stride + granule] = misc[8u + lane];
+    if (lane < 8u) {
+        const uint32_t v = misc[8u + lane];
+        sink.gran_counts[(uint64_t)lane * sink.gran_stride + granule] = v;
+        // the first level of K2b's scan on the fly: units per bin and part (= XM_PART_GRAN granules).  One of
+        // XM_PART_REPLICAS copies, 67 KB apart: the few (part, bin) cells that are hot at any moment would otherwise be
+        // ~14 addresses taking 150 k atomics (that form cost K1 220 us; spread like this it costs nothing measurable)
+        if (v != 0u) atomicAdd(&sink.part_tot[((granule & (XM_PART_REPLICAS - 1u)) * 8u + lane) * XM_PART_STRIDE + granule / XM_PART_GRAN], v);
+    }
 }
 
 // K1 side: every wave adds its (up to 4 per lane) category bytes; the last wave to arrive flushes.  `lds` must have
@@ -410,13 +418,14 @@ hist_kernel(const uint8_t *__restrict__ code, uint64_t n, uint32_t n_gran, Count
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2b: exclusive scan of the per-granule bin counts, two levels; two small launches (one for small inputs).  A part = XM_PART_GRAN = 1024
-// consecutive granules.  part_sum_kernel: workgroup (part p, bin b) adds up its 1024 granule counts.  scan_kernel:
-// workgroup (p, b) takes its carry from the part totals before p and scans its own 1024 counts once -- nobody passes
-// over all counts, nothing depends on another workgroup of the same launch.  gran_off[b][g] = units of bin b in
-// granules < g; bin_totals[b] = units of bin b.  Workgroups of part 0 also add up the replicas of category_counts (8
-// slots per bin row) and zero them again.  (Adding the part totals up from the counting kernels with atomics
-// instead was tried: ~14 hot addresses at a time, K1 282 -> 506 us.)
+// K2b: exclusive scan of the per-granule bin counts, two levels, ONE launch.  A part = XM_PART_GRAN = 1024 consecutive
+// granules.  The first level -- units per bin and part -- is added up by the counting side itself while it flushes a
+// granule (count_flush: replicated atomics); workgroup (part p, bin b) takes its carry from the part totals in front of p
+// and scans its own 1024 counts once -- nobody passes over all counts, nothing depends on another workgroup of the
+// launch.  gran_off[b][g] = units of bin b in granules < g; bin_totals[b] = units of bin b.  Workgroups of part 0 also
+// add up the replicas of category_counts (8 slots per bin row) and zero them again; the part totals are zeroed by K2c
+// (every workgroup of this launch may still read them).
+// (Round 2 had a second kernel for the part sums: two launches + the gap between them, 10-12 us per 100 M records.)
 // ---------------------------------------------------------------------------------------------
 #define XM_SCAN_THREADS 1024
 __device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long v, unsigned long long *wsum)
@@ -431,21 +440,6 @@ __device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long 
     return total;
 }
 
-__global__ void __launch_bounds__(XM_SCAN_THREADS)
-part_sum_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t gran_stride, uint32_t *__restrict__ part_tot)
-{
-    __shared__ unsigned long long wsum[XM_SCAN_THREADS / 64];
-    const uint32_t p = blockIdx.x, b = blockIdx.y;
-    const uint32_t g = p * XM_PART_GRAN + threadIdx.x;
-    const unsigned long long x = (g < n_gran) ? gran_counts[(uint64_t)b * gran_stride + g] : 0u;
-    const unsigned long long total = block_sum_1024(x, wsum);
-    if (threadIdx.x == 0u) part_tot[b * XM_PART_STRIDE + p] = (uint32_t)total;        // <= 1024 granules x 2048 units
-}
-
-// DIRECT: no part totals -- the workgroup adds up the granule counts in front of its part itself (8 loads in flight per
-// thread).  One launch less; the redundant reads grow with the square of the number of parts, so only for inputs of up
-// to XM_SCAN_DIRECT_PARTS parts (16 M records).
-template <bool DIRECT>
 __global__ void __launch_bounds__(XM_SCAN_THREADS)
 scan_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t gran_stride,
             const uint32_t *__restrict__ part_tot, uint32_t *__restrict__ gran_off,
@@ -468,27 +462,15 @@ scan_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t 
         acc += __shfl_xor(acc, 4, 64);
         if (part == 0) counts[slot] = acc;
     }
-    const uint32_t *row = gran_counts + (uint64_t)b * gran_stride;
     // this part's granules: one per thread (loaded first: the carry loop below hides the latency)
     const uint32_t g = p * XM_PART_GRAN + t;
-    const uint32_t x = (g < n_gran) ? row[g] : 0u;
-    // carry: units of bin b in front of this part
+    const uint32_t x = (g < n_gran) ? gran_counts[(uint64_t)b * gran_stride + g] : 0u;
+    // carry: units of bin b in front of this part = the p part totals before it, each in XM_PART_REPLICAS pieces;
+    // consecutive threads walk consecutive parts of one replica row
     unsigned long long part_sum = 0;
-    if (DIRECT) {
-        const uint32_t before = p * XM_PART_GRAN;            // a multiple of 1024: every thread runs the same trip count
-        for (uint32_t k0 = 0; k0 < before; k0 += XM_SCAN_THREADS * 8u) {
-            uint32_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t k = k0 + (uint32_t)u * XM_SCAN_THREADS + t;
-                v[u] = (k < before) ? row[k] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) part_sum += v[u];
-        }
-    } else {
-        const uint32_t *tot_row = part_tot + b * XM_PART_STRIDE;
-        for (uint32_t q = t; q < p; q += XM_SCAN_THREADS) part_sum += tot_row[q];
+    for (uint32_t e = t; e < p * XM_PART_REPLICAS; e += XM_SCAN_THREADS) {
+        const uint32_t r = e / p, q = e - r * p;
+        part_sum += part_tot[(r * 8u + b) * XM_PART_STRIDE + q];
     }
     const unsigned long long carry = block_sum_1024(part_sum, wsum);
 
@@ -564,6 +546,8 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0
 #pragma unroll
         for (int i = 0; i < j; ++i)
             if (((SLOTS >> j) & 1) && ((SLOTS >> i) & 1)) pos[j] += (bin[i] == bin[j]) ? 1u : 0u;
+    // (One 8- or 16-byte store per lane whose units share a bin -- they go to consecutive places -- measured slower than
+    // these dword stores in every workload, 0.0587 against 0.0547 ms at 50 M interleaved pairs: profiles/r03_ab_scatter.txt.)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (((SLOTS >> j) & 1) && bin[j] < 7u && (!XM_SCATTER_GUARD || pos[j] < n_units))
@@ -577,10 +561,15 @@ template <int NSUB, bool WIDE, bool NIB>
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
                const uint32_t *__restrict__ gran_off, const unsigned long long *__restrict__ bin_totals,
-               unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out)
+               unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ part_tot)
 {
     __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
     const uint32_t lane = threadIdx.x & 63u;
+    {   // K2b has consumed the part totals: leave them zeroed for the next count (n_parts cells in each of the 8 x replicas rows)
+        const uint32_t n_parts = (n_gran + XM_PART_GRAN - 1u) / XM_PART_GRAN, cells = 8u * XM_PART_REPLICAS * n_parts;
+        for (uint32_t i = blockIdx.x * XM_BLOCK + threadIdx.x; i < cells; i += gridDim.x * XM_BLOCK)
+            part_tot[(i / n_parts) * XM_PART_STRIDE + i % n_parts] = 0u;
+    }
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t g = blockIdx.x * (XM_BLOCK / 64) + wave;
     if (g >= n_gran) return;                                              // wave-uniform; no barrier in this kernel
@@ -926,7 +915,7 @@ __device__ __forceinline__ void classify_cigar_body(
     }
     // no fused counting here: this kernel runs at the rate its eleven concurrent streams get out of HBM, and the counting
     // epilogue cost it 36-45 us per 50 M pairs -- more than the separate histogram pass (30 us) it would save
-    const CountSink none = {nullptr, nullptr, nullptr, 0u, 0};
+    const CountSink none = {nullptr, nullptr, nullptr, nullptr, 0u, 0};
     classify_finish<int32_t, PAIRED, BLOCK, FULL, false, -1>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, nullptr, none);
 }
 
@@ -1012,6 +1001,27 @@ __device__ __forceinline__ void cigp_load8(const uint32_t *__restrict__ ops, uin
     v[4] = (uint32_t)b.x; v[5] = (uint32_t)b.y; v[6] = (uint32_t)b.z; v[7] = (uint32_t)b.w;
 }
 
+// One prefix pass over 512 op slots (8 per lane, slot s0 + q in v[q]): penalty terms, their running sums inside the lane, a
+// DPP scan over the lanes, T[s0 + q] = carry + the terms of the slots below s0 + q.  Returns carry + the pass's total.
+// No masking of the slots past the stretch (the loads run up to 7 words over it, lanes behind it re-read its first
+// words): T[j] sums the slots below j, and only T[0 .. W] is ever read.  A long op out there can at worst send the wave
+// to the careful path (`any` collects the bits of every word seen).
+__device__ __forceinline__ uint32_t cigp_chunk(const uint32_t v[8], uint32_t s0, uint32_t carry, uint32_t *T, uint32_t &any)
+{
+    uint32_t p[8], run = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        p[q] = run;                                                      // exclusive inside the lane
+        any |= v[q];
+        run += cigar_term24(v[q]);
+    }
+    const uint32_t tincl = wave_scan_incl(run);
+    const uint32_t ex = tincl - run + carry;
+    *reinterpret_cast<uint4 *>(T + s0) = make_uint4(ex + p[0], ex + p[1], ex + p[2], ex + p[3]);
+    *reinterpret_cast<uint4 *>(T + s0 + 4u) = make_uint4(ex + p[4], ex + p[5], ex + p[6], ex + p[7]);
+    return carry + lane_value(tincl, 63);
+}
+
 // The usual case.  cw = the lane's four op counts (one byte each).  false: the wave must take cigp_slow.
 __device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, const TileOps &o, uint32_t cw,
                                           const int32_t nmv[4], uint32_t *T, int32_t as_out[4], bool &bad)
@@ -1023,34 +1033,16 @@ __device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, cons
     const uint32_t incl = wave_scan_incl(lsum);
     const bool esc = c0 == 255u || c1 == 255u || c2 == 255u || c3 == 255u;
     if (lane_value(incl, 63) != W || __ballot(esc) != 0ull) return false;
-    bool odd = false;
-    uint32_t carry = 0;
-    for (uint32_t c = 0; c * XM_CIGP_CHUNK <= W; ++c) {                  // slot W (the grand total) is written too
-        const uint32_t s0 = c * XM_CIGP_CHUNK + 8u * lane;
+    // the stretch is shorter than XM_CIG_WAVE_OPS = 2 chunks: the first (fetched by the caller) always -- it holds slot W,
+    // the grand total, whenever W < 512 --, the second only for a stretch of 512 ops or more
+    uint32_t any = 0;
+    uint32_t carry = cigp_chunk(o.v, 8u * lane, 0u, T, any);
+    if (W >= XM_CIGP_CHUNK) {
         uint32_t v[8];
-        if (c == 0u) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = o.v[q];
-        } else {
-            cigp_load8(ops, o.tb, W, s0, v);
-        }
-        // No masking of the slots past the stretch (the loads run up to 7 words over it, lanes behind it re-read its
-        // first words): T[j] sums the slots below j, and only T[0 .. W] is ever read.  A long op out there can at worst
-        // send the wave to the careful path.
-        uint32_t p[8], run = 0, any = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            p[q] = run;                                                  // exclusive inside the lane
-            any |= v[q];
-            run += cigar_term24(v[q]);
-        }
-        odd |= any >= (1u << 24);                                        // some op of length >= 2^20
-        const uint32_t tincl = wave_scan_incl(run);
-        const uint32_t ex = tincl - run + carry;
-        *reinterpret_cast<uint4 *>(T + s0) = make_uint4(ex + p[0], ex + p[1], ex + p[2], ex + p[3]);
-        *reinterpret_cast<uint4 *>(T + s0 + 4u) = make_uint4(ex + p[4], ex + p[5], ex + p[6], ex + p[7]);
-        carry += lane_value(tincl, 63);
+        cigp_load8(ops, o.tb, W, XM_CIGP_CHUNK + 8u * lane, v);
+        carry = cigp_chunk(v, XM_CIGP_CHUNK + 8u * lane, carry, T, any);
     }
+    const bool odd = any >= (1u << 24);                                  // some op of length >= 2^20
     if (__ballot(odd) != 0ull) return false;
     const uint32_t b0 = incl - lsum, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2, b4 = b3 + c3;      // <= W < XM_CIG_WAVE_OPS
     const uint32_t t0 = T[b0], t1 = T[b1], t2 = T[b2], t3 = T[b3], t4 = T[b4];
@@ -1350,6 +1342,7 @@ static CountSink make_sink(const CountPlan *cp, int mode)
 {
     CountSink s;
     s.gran_counts = cp ? cp->gran_counts : nullptr;
+    s.part_tot = cp ? cp->part_tot : nullptr;
     s.counts_rep = cp ? reinterpret_cast<unsigned long long *>(cp->counts_rep) : nullptr;
     s.bins4 = cp ? cp->bins4 : nullptr;
     s.gran_stride = cp ? cp->plan.gran_stride : 0u;
@@ -1439,24 +1432,18 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
     unsigned long long *bt = reinterpret_cast<unsigned long long *>(bin_totals);
     unsigned long long *rep = reinterpret_cast<unsigned long long *>(cp.counts_rep);
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(counts);
-    if (n_parts <= XM_SCAN_DIRECT_PARTS) {
-        scan_kernel<true><<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride,
-                                                                        cp.part_tot, gran_off, bt, rep, cnt);
-    } else {
-        part_sum_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot);
-        scan_kernel<false><<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride,
-                                                                         cp.part_tot, gran_off, bt, rep, cnt);
-    }
+    scan_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot,
+                                                             gran_off, bt, rep, cnt);
 }
 
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
-                    const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out)
+                    const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out, uint32_t *part_tot)
 {
     const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
     const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
-#define XM_LAUNCH_SCT(W, NIB) scatter_kernel<XM_GRAN / 256, W, NIB><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_off, bt, bo, idx_out)
+#define XM_LAUNCH_SCT(W, NIB) scatter_kernel<XM_GRAN / 256, W, NIB><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_off, bt, bo, idx_out, part_tot)
     if (code_is_bins4) { if (wide) XM_LAUNCH_SCT(true, true); else XM_LAUNCH_SCT(false, true); }
     else               { if (wide) XM_LAUNCH_SCT(true, false); else XM_LAUNCH_SCT(false, false); }
 #undef XM_LAUNCH_SCT
