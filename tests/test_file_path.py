@@ -414,3 +414,52 @@ def test_g8_large_runs_through_the_python_reader(name):
     for n in H.STATES:
         text = outs[n].getvalue()
         assert (hashlib.sha224(text.encode("latin-1")).hexdigest(), len(text)) == (exp["bins"][n]["sha224"], exp["bins"][n]["len"]), n
+
+
+@pytest.mark.parametrize("via", ["bam_files", "sam_files", "iterator"])
+def test_records_with_more_than_65535_cigar_operations_through_cigar_scores(via, tmp_path):
+    """tests/golden/long_cigar_cg.{bam,sam} (written from the SAM/BAM specification's CG:B,I rule by
+    tools/make_bam_long_cigar_fixture.py) as the primary input of the --cigar_scores loop, a twin with other NM values as
+    the secondary: 70 000 / 65 537 / 65 535-operation records reach the kernel as escaped records of the packed CIGAR
+    columns (count byte 255 + trailer word).  Expected: the oracle's text-level loop on the SAM texts."""
+    import os
+    from oracle import xm_oracle as O
+    from tests.test_host_parser import _long_cigar_tool
+    from xenomapper_amd import xenomapper as xm
+    tool = _long_cigar_tool()
+    base = os.path.join(H.GOLDEN, "long_cigar_cg")
+    header = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chrL\tLN:400000\n"
+    twin = []
+    for k, rec in enumerate(tool.logical_records()):               # same reads in the other species: fewer / more mismatches
+        q, flag, pos, mapq, cigar, seq, qual, tags = rec
+        tags = [(t, ty, (v - 3 if k % 2 == 0 else v + 2) if t == "NM" else v) for t, ty, v in tags]
+        twin.append((q, flag, pos, mapq, cigar if k != 2 else [(20, "S"), (30, "M")], seq, qual, tags))
+    sam1 = open(base + ".sam").read()
+    sam2 = header + "".join(tool.sam_line(r) + "\n" for r in twin)
+    bam2 = b"BAM\1" + len(header.encode()).to_bytes(4, "little", signed=True) + header.encode() + (1).to_bytes(4, "little") + \
+        (5).to_bytes(4, "little") + b"chrL\0" + (400000).to_bytes(4, "little") + b"".join(tool.bam_record(r) for r in twin)
+    (tmp_path / "two.bam").write_bytes(tool.bgzf(bam2))
+    (tmp_path / "one.sam").write_text(sam1)
+    (tmp_path / "two.sam").write_text(sam2)
+    # expected
+    want_outs = [io.StringIO() for _ in H.STATES]
+    s1, s2 = io.StringIO(sam1), io.StringIO(sam2)
+    O.write_headers(s1, s2, want_outs)
+    want = O.run_single_end(O.read_pairs(s1, s2), want_outs, scorer=O.cigar_score)
+    assert len(want.units) == 4 and len(set(u[1] for u in want.units)) >= 2
+    # product
+    outs = {name: open(tmp_path / (name + ".out"), "wt") for name in H.STATES}
+    if via == "sam_files":
+        p1, p2, bam, mode = str(tmp_path / "one.sam"), str(tmp_path / "two.sam"), False, "rt"
+    else:
+        p1, p2, bam, mode = base + ".bam", str(tmp_path / "two.bam"), True, "rb"
+    with open(p1, mode) as f1, open(p2, mode) as f2:
+        xm.process_headers(f1, f2, bam=bam, **outs)
+        if via == "iterator":
+            counts = xm.main_single_end(xm.getBamReadPairs(f1, f2), tag_func=xm.get_cigarbased_AS_tag, **outs)
+        else:
+            counts = xm.classify_sam_files(p1, p2, paired=False, tag_func=xm.get_cigarbased_AS_tag, bam=bam, **outs)
+    assert {H.STATES.index(k): v for k, v in counts.items()} == {k: v for k, v in want.counts.items() if v}
+    for name, sink, w in zip(H.STATES, outs.values(), want_outs):
+        sink.close()
+        assert (tmp_path / (name + ".out")).read_text() == w.getvalue(), name

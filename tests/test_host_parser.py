@@ -623,3 +623,38 @@ def test_bam_reader_maps_the_handle_it_was_given(tmp_path):
         got = [line.rstrip("\n") for line in xm.bam_lines(fh)]
         assert fh.tell() == 10
     assert got == want
+
+
+def _long_cigar_tool():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_bam_long_cigar_fixture",
+                                                  os.path.join(H.REPO, "tools", "make_bam_long_cigar_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bam_long_cigar_fixture_from_the_specification():
+    """tests/golden/long_cigar_cg.bam holds alignments with 70 000 and 65 537 CIGAR operations, written by
+    tools/make_bam_long_cigar_fixture.py from the SAM/BAM specification's rule (SAMv1 section 4.2.2: real CIGAR in
+    CG:B,I, CIGAR field = kSmN), next to a record with exactly 65 535 operations and an ordinary one; the .sam beside
+    it is the text those records stand for.  The decoder must print exactly that text -- the one BAM rule the
+    reference's own fixtures do not exercise."""
+    import os
+    from xenomapper_amd import xenomapper as xm
+    base = os.path.join(H.GOLDEN, "long_cigar_cg")
+    with open(base + ".sam") as fh:
+        want = fh.read()
+    hdr, body = _decode_bam(base + ".bam", 1 << 20)
+    assert hdr + body == want
+    with open(base + ".bam", "rb") as fh:
+        lines = list(xm.bam_lines(fh))
+    assert "".join(lines) == "".join(line + "\n" for line in want.split("\n") if line and not line.startswith("@"))
+    assert [len(line.split("\t")[5]) for line in lines] == [140000, 131074, 3, 131070]      # CIGAR texts: 2 characters per one-digit operation
+    assert all("CG:B" not in line for line in lines)
+    # the committed fixture is what the committed script writes
+    tool = _long_cigar_tool()
+    recs = tool.logical_records()
+    assert "".join(tool.sam_line(r) + "\n" for r in recs) == "".join(lines)
+    assert [len(r[4]) for r in recs] == [70000, 65537, 1, 65535]

@@ -958,22 +958,6 @@ classify_cigar_kernel(const int32_t *__restrict__ nm1, const uint32_t *__restric
 // path (cigp_slow), 64-bit accumulation, no read past cig_tile[n_tiles] whatever the columns hold.
 // ---------------------------------------------------------------------------------------------
 #define XM_CIGP_CHUNK 512u          // ops per prefix pass: 8 per lane
-// XM_CIGP_LATE_XS=0 (tuning builds): let the compiler hoist the XS / unit-mask loads to the top again
-#ifndef XM_CIGP_LATE_XS
-#define XM_CIGP_LATE_XS 1
-#endif
-#ifndef XM_CIGP_OPS_NT
-#define XM_CIGP_OPS_NT 1
-#endif
-// XM_CIGP_ABL (tuning builds, results wrong on purpose): 1 = no op loads, no scoring; 2 = op loads, no scans / LDS table
-#ifndef XM_CIGP_ABL
-#define XM_CIGP_ABL 0
-#endif
-#if XM_CIGP_LATE_XS
-#define XM_CIGP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define XM_CIGP_SCHED_FENCE() do { } while (0)
-#endif
 
 struct TileOps {
     uint32_t tb, te;                // the tile's stretch [tb, te) of the op array
@@ -990,13 +974,8 @@ __device__ __forceinline__ void cigp_load8(const uint32_t *__restrict__ ops, uin
     const uint32_t *p = ops + base + ((s0 < W) ? s0 : 0u);
     // non-temporal like every other input of the kernel: read once.  (Measured: with plain loads the ops push the compact
     // category stream this kernel writes out of the cache before K2c reads it -- K2c 70 instead of 48 us per 50 M pairs.)
-#if XM_CIGP_OPS_NT
     const v4i32 a = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p));
     const v4i32 b = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p + 4));
-#else
-    const v4i32 a = *reinterpret_cast<const v4i32_a4 *>(p);
-    const v4i32 b = *reinterpret_cast<const v4i32_a4 *>(p + 4);
-#endif
     v[0] = (uint32_t)a.x; v[1] = (uint32_t)a.y; v[2] = (uint32_t)a.z; v[3] = (uint32_t)a.w;
     v[4] = (uint32_t)b.x; v[5] = (uint32_t)b.y; v[6] = (uint32_t)b.z; v[7] = (uint32_t)b.w;
 }
@@ -1178,38 +1157,18 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
     o1.fast = FULL && o1.te >= o1.tb && o1.te - o1.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o1.te + 8u <= n_ops1;
     o2.fast = FULL && o2.te >= o2.tb && o2.te - o2.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o2.te + 8u <= n_ops2;
     // ... and the first 512 ops of both stretches.
-#if XM_CIGP_ABL != 1
     if (o1.fast) cigp_load8(s1.ops, o1.tb, o1.te - o1.tb, 8u * lane, o1.v);
     if (o2.fast) cigp_load8(s2.ops, o2.tb, o2.te - o2.tb, 8u * lane, o2.v);
-#endif
-    XM_CIGP_SCHED_FENCE();
 
     bool bad = false;
-#if XM_CIGP_ABL
-    if (FULL) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a1[j] = nmv1[j] == INT32_MIN ? INT32_MIN : -6 * nmv1[j] - (int32_t)((cw1 >> (8 * j)) & 255u);
-            a2[j] = nmv2[j] == INT32_MIN ? INT32_MIN : -6 * nmv2[j] - (int32_t)((cw2 >> (8 * j)) & 255u);
-        }
-#if XM_CIGP_ABL == 2
-        uint32_t x = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x ^= o1.v[q] ^ o2.v[q];
-        if (x == 0x87654321u) a1[0] = 0;
-#endif
-    } else
-#endif
     if (!(o1.fast && cigp_fast(s1.ops, o1, cw1, nmv1, cig_T, a1, bad))) {
         v4i32 q; q.x = nmv1[0]; q.y = nmv1[1]; q.z = nmv1[2]; q.w = nmv1[3];
         q = cigp_slow(s1.ops, n_ops1, o1.tb, o1.te, cw1, q, range_flag);
         a1[0] = q.x; a1[1] = q.y; a1[2] = q.z; a1[3] = q.w;
     }
-    // XS and the unit mask are only needed by the state function at the very end: they are fetched here, so that their
-    // registers are not held while species 1 is worked on, and arrive while species 2 is (the fences keep the compiler
-    // from moving the loads back up: with everything in flight at once the kernel needs 72 registers = 6 waves per SIMD
-    // for its 512-thread workgroups instead of 8)
-    XM_CIGP_SCHED_FENCE();
+    // XS and the unit mask are only needed by the state function at the very end: fetched here, they arrive while
+    // species 2 is worked on.  (Where the compiler puts them makes no measurable difference, nor does the occupancy:
+    // 63 registers; held to six waves per SIMD the kernel is exactly as fast -- profiles/r03_ab_cigp.txt.)
     if (FULL) {
         load4_wg<int32_t, true>(s1.xs + wg0, t16, x1);
         load4_wg<int32_t, true>(s2.xs + wg0, t16, x2);
@@ -1220,10 +1179,6 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
         if (r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
         if (r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
     }
-    XM_CIGP_SCHED_FENCE();
-#if XM_CIGP_ABL
-    if (!FULL)
-#endif
     if (!(o2.fast && cigp_fast(s2.ops, o2, cw2, nmv2, cig_T, a2, bad))) {
         v4i32 q; q.x = nmv2[0]; q.y = nmv2[1]; q.z = nmv2[2]; q.w = nmv2[3];
         q = cigp_slow(s2.ops, n_ops2, o2.tb, o2.te, cw2, q, range_flag);
@@ -1247,19 +1202,8 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
                                                                    count_lds, sink);
 }
 
-// XM_CIGP_WPE (tuning builds) = waves per SIMD the register allocator must make room for: 8 = 64 VGPRs = four 512-thread
-// workgroups per CU.  Left alone the allocator takes 65 (three workgroups per CU) -- and the kernel is exactly as fast
-// (profiles/r03_ab_cigp.txt), so the product build leaves it alone.
-#ifndef XM_CIGP_WPE
-#define XM_CIGP_WPE 0
-#endif
-#if XM_CIGP_WPE
-#define XM_CIGP_ATTR __attribute__((amdgpu_waves_per_eu(XM_CIGP_WPE, XM_CIGP_WPE)))
-#else
-#define XM_CIGP_ATTR
-#endif
 template <bool PAIRED, int BLOCK, bool COUNTS, int BINMODE>
-__global__ void __launch_bounds__(BLOCK) XM_CIGP_ATTR
+__global__ void __launch_bounds__(BLOCK)
 classify_cigp_kernel(const CigCols s1, const CigCols s2, const uint8_t *__restrict__ unit_bits8, int32_t m,
                      uint8_t *__restrict__ code, uint64_t n, uint32_t n_tiles, uint32_t *__restrict__ range_flag, CountSink sink)
 {
