@@ -214,6 +214,9 @@ def e2e_sam_text(pairs=4_000_000, to_files=True):
                       out_dir=("/dev/shm" if shm else "/tmp") if to_files else None)
     return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"],
             "seconds": round(r["seconds"], 4), "outputs": r["outputs"], "output_bytes": r["output_bytes"],
+            "text_bytes_in_per_pair": round(r["input_bytes"] / max(r["units"], 1), 1),
+            "text_bytes_out_per_pair": round(r["output_bytes"] / max(r["units"], 1), 1),
+            "output_GBps": r["output_bytes"] / r["seconds"] / 1e9,
             "what": "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> stripper -> H2D -> fused pass -> D2H -> six SAM outputs"}
 
 
@@ -673,6 +676,15 @@ def main():
                     e2e[key] = e2e_sam_text(to_files=to_files)
                 except Exception as e:                           # noqa: BLE001
                     e2e[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import bench_e2e
+                e2e["host_ceilings"] = bench_e2e.host_ceilings("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+                e2e["host_ceilings"]["what"] = ("the file path's own rooflines on this box: memory copy (one core / all granted threads), "
+                                                "one write(2) stream against all threads filling the mapped tmpfs file, the stripper's "
+                                                "GB/s of SAM text against its thread count")
+            except Exception as e:                               # noqa: BLE001
+                e2e["host_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
             line["e2e"] = e2e
 
     # The other single-GPU BASELINE configs, timed the same way in this process after the headline run (default

@@ -658,3 +658,44 @@ def test_bam_long_cigar_fixture_from_the_specification():
     recs = tool.logical_records()
     assert "".join(tool.sam_line(r) + "\n" for r in recs) == "".join(lines)
     assert [len(r[4]) for r in recs] == [70000, 65537, 1, 65535]
+
+
+def test_writer_fills_the_mapped_output_file_directly(tmp_path, monkeypatch):
+    """_emit_into_file: the bin's text gathered by the writer's threads straight into the extended, mapped output file
+    must be byte for byte what the buffered path writes, land after what the sink already holds, and leave the sink
+    usable; sinks that are not regular files at their end are declined."""
+    import io
+    import os
+    from xenomapper_amd import _host, synth, xenomapper as xm
+    t1, t2, _ = synth.sam_text_pair(n_pairs=3000, seed=5, profile="bowtie2", paired=True, read_len=150)
+
+    def head_end(t):
+        e = 0
+        while t[e] == "@":
+            e = t.index("\n", e) + 1
+        return e
+    a1, a2 = np.frombuffer(t1.encode(), dtype=np.uint8), np.frombuffer(t2.encode(), dtype=np.uint8)
+    o1, o2 = head_end(t1), head_end(t2)
+    parser = _host.Parser(4)
+    blk = parser.parse(a1, o1, len(a1) - o1, True, a2, o2, len(a2) - o2, True, _host.SCORE_AS_XS, True, False, True, 1 << 22)
+    idx = np.arange(1, blk.n, 2, dtype=np.uint32)
+    want = bytes(parser.emit(True, 0, idx))
+    assert len(want) > 100_000
+    monkeypatch.setattr(xm, "MMAP_EMIT_MIN_BYTES", 1000)
+    out = tmp_path / "bin.sam"
+    with open(out, "wt") as sink:
+        sink.write("@CO\twhat process_headers wrote\n")
+        assert xm._emit_into_file(parser, True, 0, idx, sink) is True
+        assert xm._emit_into_file(parser, True, 0, idx[:1], sink) is False         # too little: the caller writes it
+        sink.write("after\n")
+        assert xm._emit_into_file(parser, True, 0, idx, sink) is True             # page-unaligned start
+    assert out.read_bytes() == b"@CO\twhat process_headers wrote\n" + want + b"after\n" + want
+    with open(os.devnull, "wt") as sink:
+        assert xm._emit_into_file(parser, True, 0, idx, sink) is False             # not a regular file
+    assert xm._emit_into_file(parser, True, 0, idx, io.StringIO()) is False
+    with open(out, "r+") as sink:                                                  # not at the end of the file
+        assert xm._emit_into_file(parser, True, 0, idx, sink) is False
+    monkeypatch.setenv("XENOMAPPER_MMAP_EMIT", "0")
+    with open(tmp_path / "off.sam", "wt") as sink:
+        assert xm._emit_into_file(parser, True, 0, idx, sink) is False
+    parser.close()

@@ -66,6 +66,72 @@ def run(pairs=2_000_000, threads=0, mode="liberal", workdir="/dev/shm", out_dir=
                 os.unlink(p)
 
 
+def host_ceilings(workdir="/dev/shm", mb=512, parse_mb=64):
+    """What the host side of the file path can do at best on this box (the file path's own rooflines): one-core and
+    all-core memory copy rates, one write(2) stream into a tmpfs file against all threads filling the mapped file, and
+    the stripper's parse rate against its thread count."""
+    import mmap
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from xenomapper_amd import _host, synth
+    n_thr = _host.lib().xmh_default_threads()
+    src = np.ones(mb << 20, dtype=np.uint8)
+    dst = np.empty_like(src)
+    out = {"threads_granted": n_thr, "buffer_MB": mb}
+
+    def best(fn, reps=3):
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            t.append(time.perf_counter() - t0)
+        return min(t)
+
+    def par_copy(target):
+        step = (src.shape[0] + n_thr - 1) // n_thr
+        with ThreadPoolExecutor(n_thr) as ex:
+            list(ex.map(lambda k: np.copyto(target[k * step:(k + 1) * step], src[k * step:(k + 1) * step]), range(n_thr)))
+    out["memcpy_1_thread_GBps"] = src.nbytes / best(lambda: np.copyto(dst, src)) / 1e9
+    out["memcpy_all_threads_GBps"] = src.nbytes / best(lambda: par_copy(dst)) / 1e9
+    path = os.path.join(workdir, "xm_ceiling_%d.bin" % os.getpid())
+    try:
+        def one_stream():
+            with open(path, "wb", buffering=0) as fh:
+                mv = memoryview(src)
+                for at in range(0, src.nbytes, 64 << 20):
+                    fh.write(mv[at:at + (64 << 20)])
+
+        def mapped():
+            with open(path, "w+b") as fh:
+                os.posix_fallocate(fh.fileno(), 0, src.nbytes)
+                mm = mmap.mmap(fh.fileno(), src.nbytes)
+                view = np.frombuffer(mm, dtype=np.uint8)
+                par_copy(view)
+                del view
+                mm.close()
+        out["tmpfs_one_write_stream_GBps"] = src.nbytes / best(one_stream) / 1e9
+        out["tmpfs_mapped_all_threads_GBps"] = src.nbytes / best(mapped) / 1e9
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    t1, t2, _ = synth.sam_text_pair(n_pairs=20_000, seed=2002, profile="bowtie2", paired=True, read_len=150)
+    bodies = []
+    for text in (t1, t2):
+        body = "".join(line for line in text.splitlines(True) if not line.startswith("@")).encode("ascii")
+        bodies.append(np.frombuffer(body * max(1, (parse_mb << 20) // len(body)), dtype=np.uint8).copy())
+    total = bodies[0].shape[0] + bodies[1].shape[0]
+    scaling = {}
+    for k in sorted(set(t for t in (1, 2, 4, 8, 16, n_thr) if t <= max(n_thr, 1))):
+        parser = _host.Parser(k)
+        el = best(lambda: parser.parse(bodies[0], 0, bodies[0].shape[0], True, bodies[1], 0, bodies[1].shape[0], True,
+                                       0, True, False, True, 1 << 22))
+        scaling[str(k)] = round(total / el / 1e9, 2)
+        parser.close()
+    out["stripper_GBps_of_text_by_threads"] = scaling
+    out["stripper_input"] = "2 x %d MB of 2x150 bp SAM text" % parse_mb
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=2_000_000)
@@ -73,7 +139,11 @@ def main():
     ap.add_argument("--mode", default="liberal", choices=("liberal", "conservative", "se"))
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--out-dir", default=None, help="write the six outputs to real files here (default: /dev/null)")
+    ap.add_argument("--ceilings", action="store_true", help="print the host-side ceilings of this box instead")
     a = ap.parse_args()
+    if a.ceilings:
+        print(json.dumps(host_ceilings(a.dir)))
+        return
     print(json.dumps(run(a.pairs, a.threads, a.mode, a.dir, a.out_dir)))
 
 

@@ -129,6 +129,28 @@ class Parser(object):
         self._keep = (arr1, arr2)            # the windows must outlive emit()
         return Block(raw, score_mode == SCORE_CIGAR)
 
+    def emit_size(self, paired, bin_index, idx):
+        """Bytes xmh_emit would write for these units (first half of its two-call protocol).  -> (idx as uint32, bytes)"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        if idx.shape[0] == 0:
+            return idx, 0
+        need = ctypes.c_uint64()
+        rc = self._L.xmh_emit(self._h, self._win[0], self._win[1], int(paired), bin_index, idx.ctypes.data_as(_P), idx.shape[0],
+                              None, 0, ctypes.byref(need))
+        if rc != 0:
+            raise RuntimeError("xmh_emit: " + self._L.xmh_strerror(rc).decode())
+        return idx, int(need.value)
+
+    def emit_to(self, paired, bin_index, idx, address, capacity):
+        """xmh_emit straight into caller memory (e.g. the mapped pages of an output file); idx: uint32, as emit_size
+        returned it.  -> bytes written"""
+        need = ctypes.c_uint64()
+        rc = self._L.xmh_emit(self._h, self._win[0], self._win[1], int(paired), bin_index, idx.ctypes.data_as(_P), idx.shape[0],
+                              _P(address), capacity, ctypes.byref(need))
+        if rc != 0:
+            raise RuntimeError("xmh_emit: " + self._L.xmh_strerror(rc).decode())
+        return int(need.value)
+
     def emit(self, paired, bin_index, idx, reuse=False):
         """Text (bytes) of one output bin for the last parsed block; idx: ascending uint32 unit indices.
         reuse=True returns a view of a buffer the parser keeps (valid until the next emit): a fresh multi-megabyte
