@@ -159,6 +159,16 @@ int xm_classify_compact_cigar(xm_ctx *ctx, int mode, uint64_t n_records,
  */
 int xm_mate_correlate(xm_ctx *ctx, uint64_t n, const double *track, uint64_t m, const double *density, double *out);
 
+/*
+ * Optional: page-lock caller memory that is handed to the host-buffer entry points again and again (the column
+ * buffers of a parser, the index buffer of a writer).  From registered memory the copies run as direct DMA at the
+ * PCIe rate; from ordinary pageable memory the HIP runtime stages them through its own pinned buffers (~40 GB/s
+ * instead of ~55 GB/s on this platform).  Registering costs about as much as one copy of the buffer, so it only pays
+ * for buffers that live across calls.  Unregister before freeing the memory.  Results never depend on it.
+ */
+int xm_host_register(xm_ctx *ctx, void *ptr, size_t bytes);
+int xm_host_unregister(xm_ctx *ctx, void *ptr);
+
 /* ---- device-resident entry points (asynchronous on `stream`) -------------------------- */
 /*
  * All pointers are device memory of the context's device; `stream` is a hipStream_t passed

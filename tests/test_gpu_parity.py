@@ -545,6 +545,33 @@ def test_classify_cigar_packed_inconsistent_columns_stay_in_bounds(ctx):
         assert bool((idx[n:] == 0x5A5A5A5A).all())
 
 
+def test_host_buffer_calls_from_registered_memory(ctx):
+    """xm_host_register / xm_host_unregister: the host-buffer entry points give the same answers from page-locked
+    caller arrays (direct DMA) as from pageable ones; registering twice or unregistering unknown memory is an error."""
+    n = 300_001
+    rng = np.random.default_rng(9)
+    cols = random_columns(rng, n)
+    bits = H.synth.pack_unit_bits(rng.random(n) < 0.55)
+    want_code, want_counts = H.c_classify(1, *cols, bits, ABSENT)
+    want_idx, want_off = H.c_compact(1, want_code)
+    for a in cols + [bits]:
+        ctx.host_register(a)
+    try:
+        for _ in range(2):
+            code, idx, off, counts = ctx.classify_compact(1, *cols, bits, ABSENT)
+            assert np.array_equal(code, want_code) and np.array_equal(counts, want_counts)
+            assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx)
+        with pytest.raises(RuntimeError):
+            ctx.host_register(cols[0])                                   # already registered
+    finally:
+        for a in cols + [bits]:
+            ctx.host_unregister(a)
+    with pytest.raises(RuntimeError):
+        ctx.host_unregister(cols[0])                                     # not registered any more
+    code, idx, off, counts = ctx.classify_compact(1, *cols, bits, ABSENT)
+    assert np.array_equal(code, want_code) and np.array_equal(idx, want_idx)
+
+
 def test_classify_cigar_range_error(ctx):
     big = np.array([((2**28 - 1) << 4) | 1] * 8, dtype=np.uint32)
     one = {"nm": np.array([0], np.int32), "off": np.array([0, 8], np.uint32)}

@@ -107,6 +107,8 @@ def lib():
         "xm_classify_compact_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, P, P], I),
         "xm_classify_compact_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P, P], I),
         "xm_classify_compact_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P], I),
+        "xm_host_register": ([P, P, ctypes.c_size_t], I),
+        "xm_host_unregister": ([P, P], I),
         "xm_cigar_pack": ([U64, P, P, P, P, P, U64, ctypes.POINTER(U64)], I),
         "xm_classify_compact_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P], I),
         "xm_comm_unique_id": ([P], I),
@@ -131,7 +133,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_classify_cigar",
             "xm_compact", "xm_classify_compact", "xm_classify_compact_f64", "xm_classify_compact_cigar", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
             "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
-            "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev",
+            "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
@@ -222,6 +224,16 @@ class Context(object):
         if detail and rc in (-3, -4, -6):
             msg += " [" + detail + "]"
         raise _ERRORS.get(rc, RuntimeError)(msg)
+
+    def host_register(self, array):
+        """Page-lock a NumPy array that will be handed to the host-buffer calls repeatedly (direct DMA instead of the
+        runtime's staging copies).  Call host_unregister(array) before the array is freed."""
+        rc = self._L.xm_host_register(self._h, _np_ptr(array), array.nbytes)
+        self._check(rc, "xm_host_register")
+
+    def host_unregister(self, array):
+        rc = self._L.xm_host_unregister(self._h, _np_ptr(array))
+        self._check(rc, "xm_host_unregister")
 
     def device_info(self):
         n_cu = ctypes.c_int()

@@ -867,6 +867,24 @@ int xm_classify_compact_f64(xm_ctx *ctx, int mode, uint64_t n,
                                  code_out, idx_out, bin_offsets, counts);
 }
 
+/* ---- page-locking caller buffers ------------------------------------------------------------------------------- */
+
+int xm_host_register(xm_ctx *ctx, void *ptr, size_t bytes)
+{
+    if (!ctx || !ptr || !bytes) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    XM_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return XM_OK;
+}
+
+int xm_host_unregister(xm_ctx *ctx, void *ptr)
+{
+    if (!ctx || !ptr) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    XM_HIP(ctx, hipHostUnregister(ptr));
+    return XM_OK;
+}
+
 /* ---- the one collective of the path: category_counts summed over the GPUs (RCCL) ------------------------------ */
 
 namespace {
