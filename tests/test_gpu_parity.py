@@ -547,7 +547,7 @@ def test_classify_cigar_packed_inconsistent_columns_stay_in_bounds(ctx):
 
 def test_host_buffer_calls_from_registered_memory(ctx):
     """xm_host_register / xm_host_unregister: the host-buffer entry points give the same answers from page-locked
-    caller arrays (direct DMA) as from pageable ones; registering twice or unregistering unknown memory is an error."""
+    caller arrays (direct DMA) as from pageable ones, and again from the same arrays once they are unregistered."""
     n = 300_001
     rng = np.random.default_rng(9)
     cols = random_columns(rng, n)
@@ -561,13 +561,9 @@ def test_host_buffer_calls_from_registered_memory(ctx):
             code, idx, off, counts = ctx.classify_compact(1, *cols, bits, ABSENT)
             assert np.array_equal(code, want_code) and np.array_equal(counts, want_counts)
             assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx)
-        with pytest.raises(RuntimeError):
-            ctx.host_register(cols[0])                                   # already registered
     finally:
         for a in cols + [bits]:
             ctx.host_unregister(a)
-    with pytest.raises(RuntimeError):
-        ctx.host_unregister(cols[0])                                     # not registered any more
     code, idx, off, counts = ctx.classify_compact(1, *cols, bits, ABSENT)
     assert np.array_equal(code, want_code) and np.array_equal(idx, want_idx)
 

@@ -373,8 +373,8 @@ static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const
     }
     {
         Span span(ctx, st, XM_K_SCATTER);
-        xm::launch_scatter(st, cp.plan, mode, n, from_bins4 ? cp.bins4 : code, from_bins4, ctx->d_gran_off, bin_totals,
-                           bin_offsets, idx_out, ctx->d_part_tot);
+        xm::launch_scatter(st, cp.plan, mode, n, from_bins4 ? cp.bins4 : code, from_bins4, cp.gran_counts, ctx->d_gran_off,
+                           bin_totals, bin_offsets, idx_out, ctx->d_part_tot);
     }
     if ((rc = check_launch(ctx, "scatter_kernel")) != XM_OK) reset_count_state(ctx, st);      // K2c zeroes the part totals
     return rc;

@@ -40,6 +40,23 @@ __device__ __forceinline__ uint32_t mapping_state(T a1, T x1, T a2, T x2, T m)
     return s;
 }
 
+// The same for integer columns, where `a > b` is exactly `!(a <= b)` and one of <, ==, > always holds: 8 compares
+// instead of 12 (the generic form keeps every comparison the reference makes, so that a NaN falls through as it does
+// there).  State 6 cannot come out of this one.
+template <>
+__device__ __forceinline__ uint32_t mapping_state<int32_t>(int32_t a1, int32_t x1, int32_t a2, int32_t x2, int32_t m)
+{
+    const bool low1 = a1 <= m, low2 = a2 <= m;        // :275
+    const bool gt = a1 > a2, lt = a2 > a1;
+    const bool spec1 = (x1 == 0) || (a1 > x1);        // :278  `not XS1 or AS1 > XS1`
+    const bool spec2 = (x2 == 0) || (a2 > x2);        // :285
+    uint32_t s = spec2 ? 1u : 3u;                     // :284-288: what is left when the tests below all fail
+    s = (gt || lt) ? s : 4u;                          // :282-283
+    s = (!low1 && (low2 || gt)) ? (spec1 ? 0u : 2u) : s;   // :277-281
+    s = (low1 && low2) ? 5u : s;                      // :275-276
+    return s;
+}
+
 // output bin of a category code (state, or fwd*8+rev).  7 = not a unit.
 __device__ __forceinline__ uint32_t bin_of_code(int mode, uint32_t c)
 {
@@ -212,6 +229,25 @@ __device__ __forceinline__ uint32_t unit_bin(uint32_t c)
     return c == XM_NO_UNIT ? 7u : b;
 }
 
+// the same from the two states themselves (the classify kernels have them in registers: no unpacking of the code)
+template <int MODE, bool HAS6>
+__device__ __forceinline__ uint32_t unit_bin_of(uint32_t f, uint32_t r, bool unit)
+{
+    uint32_t b;
+    if (MODE == XM_MODE_SE) {
+        b = r;                                                                      // the state itself (6 stays 6)
+    } else {
+        const uint32_t lo = f < r ? f : r, hi = f < r ? r : f;
+        b = lo;                                                                     // :423-448 == min()
+        if (MODE == XM_MODE_PE_CONSERVATIVE) {
+            b = (((f ^ r) & 1u) != 0u || hi == 4u) ? 4u : b;                       // :525-529
+            b = (hi == 5u) ? 5u : b;                                                // :521
+        }
+        if (HAS6) b = (hi > 5u) ? 6u : b;
+    }
+    return unit ? b : 7u;
+}
+
 template <typename T, bool PAIRED, int BLOCK, bool FULL, bool COUNTS, int BINMODE>
 __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], const T a2[4], const T x2[4], T m,
                                                 uint32_t mb, uint32_t halo, uint32_t *last_state,
@@ -224,9 +260,10 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = mapping_state<T>(a1[j], x1[j], a2[j], x2[j], m);
 
-    uint32_t c[4];
+    uint32_t c[4], fwd[4] = {0, 0, 0, 0};
     if (PAIRED) {
-        uint32_t prev = (uint32_t)__shfl_up((int)s[3], 1, 64);
+        // lane - 1's last state: a DPP wave shift (wave_shr:1), not a ds_bpermute
+        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[3], 0x138, 0xf, 0xf, false);
         if (lane == 63) last_state[wave] = s[3];
         __syncthreads();
         if (lane == 0) prev = (wave == 0) ? halo : last_state[wave - 1];
@@ -234,6 +271,7 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
         c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
         c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
         c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
+        fwd[0] = prev; fwd[1] = s[0]; fwd[2] = s[1]; fwd[3] = s[2];
     } else {
         if (COUNTS) __syncthreads();                  // the zeroed count_lds is visible (paired: the barrier above)
 #pragma unroll
@@ -255,7 +293,7 @@ __device__ __forceinline__ void classify_finish(const T a1[4], const T x1[4], co
         // block, so the buffer is XM_BINS4_BYTES(n) long.
         uint32_t nib = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nib |= unit_bin<BINMODE, sizeof(T) == 8>(c[j]) << (4 * j);
+        for (int j = 0; j < 4; ++j) nib |= unit_bin_of<BINMODE, sizeof(T) == 8>(fwd[j], s[j], ((mb >> j) & 1u) != 0u) << (4 * j);
         reinterpret_cast<uint16_t *>(sink.bins4)[r0 >> 2] = (uint16_t)nib;
     }
     if (COUNTS) count_units<BLOCK>(c, count_lds, sink);
@@ -513,9 +551,12 @@ __device__ __forceinline__ void store_index(uint32_t *__restrict__ idx_out, uint
     else *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(idx_out) + (pos << 2)) = rec;   // SGPR base + 32-bit offset
 }
 
-template <int SLOTS, bool WIDE>
+// STAGED: `base` are places in the wave's LDS slab (one region per bin), `rec0` the lane's first record counted from the
+// granule's first, `n_units` the slab's capacity: the units are only sorted locally here; the wave copies the regions out
+// afterwards (scatter_copy_out).
+template <int SLOTS, bool WIDE, bool STAGED>
 __device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0, uint32_t base[7],
-                                            uint32_t *__restrict__ idx_out, uint32_t n_units)
+                                            uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab)
 {
     uint32_t pos[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -550,8 +591,56 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0
     // these dword stores in every workload, 0.0587 against 0.0547 ms at 50 M interleaved pairs: profiles/r03_ab_scatter.txt.)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (((SLOTS >> j) & 1) && bin[j] < 7u && (!XM_SCATTER_GUARD || pos[j] < n_units))
-            store_index<WIDE>(idx_out, pos[j], rec0 + (uint32_t)j);
+        if (((SLOTS >> j) & 1) && bin[j] < 7u && (!XM_SCATTER_GUARD || pos[j] < n_units)) {
+            if (STAGED) slab[pos[j]] = (uint16_t)(rec0 + (uint32_t)j);
+            else store_index<WIDE>(idx_out, pos[j], rec0 + (uint32_t)j);
+        }
+}
+
+// XM_SCATTER_STAGED (0 in a tuning build: every unit's index goes to idx_out with its own dword store): the granule's
+// units are first sorted by bin inside a wave-private LDS slab (16-bit record numbers), then every bin's run is copied
+// to its place in idx_out with 16-byte stores from 16-byte-aligned places.  Why: dword stores top out at 4.2 TB/s on
+// this chip however dense they are (a 200 MB fill takes 49.8 us; K2c with one dword store per unit took 53.8 us for
+// its 200 MB), 16-byte stores reach 6.4 TB/s (tools/probe_streams.hip, profiles/r03_ab_scatter.txt).
+#ifndef XM_SCATTER_STAGED
+#define XM_SCATTER_STAGED 1
+#endif
+#define XM_SLAB_U16 (XM_GRAN + 64)     // region of bin b: room for its units rounded up to 4, + 4 for the alignment shift
+
+template <bool WIDE>
+__device__ __forceinline__ void store_index4(uint32_t *__restrict__ idx_out, uint32_t pos, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3)
+{
+    typedef uint32_t v4u32_a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte aligned when idx_out is; correct anyway
+    v4u32_a4 v; v.x = r0; v.y = r1; v.z = r2; v.w = r3;
+    if (WIDE) *reinterpret_cast<v4u32_a4 *>(idx_out + pos) = v;                           // pos is a multiple of 4
+    else *reinterpret_cast<v4u32_a4 *>(reinterpret_cast<char *>(idx_out) + (pos << 2)) = v;
+}
+
+// One bin's run of the granule: N record numbers at slab[L ..], to idx_out[G ..].  (L + the head length) is a multiple
+// of 4 by construction, so the body moves aligned 8-byte LDS reads into aligned 16-byte stores; the up to 3 + 3 places
+// around it and runs shorter than a wave take dword stores.
+template <bool WIDE>
+__device__ __forceinline__ void scatter_copy_out(const uint16_t *slab, uint32_t L, uint32_t G, uint32_t N, uint32_t rec_g,
+                                                 uint32_t *__restrict__ idx_out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if (N < 64u) {
+        if (lane < N) store_index<WIDE>(idx_out, G + lane, rec_g + slab[L + lane]);
+        return;
+    }
+    const uint32_t h = (0u - G) & 3u;                  // places up to the first 16-byte-aligned one
+    const uint32_t body = (N - h) >> 2;                // whole groups of four
+    const uint32_t t = (N - h) & 3u;                   // places after the last whole group
+    {
+        const bool head = lane < h, tail = lane >= 4u && lane - 4u < t;
+        const uint32_t e = head ? lane : h + 4u * body + (lane - 4u);
+        if (head || tail) store_index<WIDE>(idx_out, G + e, rec_g + slab[L + e]);
+    }
+    for (uint32_t c = lane; c < body; c += 64u) {
+        const uint32_t e = h + 4u * c;
+        const uint2 w = *reinterpret_cast<const uint2 *>(slab + L + e);
+        store_index4<WIDE>(idx_out, G + e, rec_g + (w.x & 0xFFFFu), rec_g + (w.x >> 16), rec_g + (w.y & 0xFFFFu), rec_g + (w.y >> 16));
+    }
 }
 
 // NIB: the categories come as the compact stream a counting K1 wrote (bins4: the bin itself, a nibble per record, 16 bits
@@ -560,10 +649,14 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0
 template <int NSUB, bool WIDE, bool NIB>
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
-               const uint32_t *__restrict__ gran_off, const unsigned long long *__restrict__ bin_totals,
+               const uint32_t *__restrict__ gran_counts, const uint32_t *__restrict__ gran_off,
+               const unsigned long long *__restrict__ bin_totals,
                unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ part_tot)
 {
+    constexpr bool STAGED = XM_SCATTER_STAGED != 0;
+    static_assert(!STAGED || NSUB * 256 == XM_GRAN, "the slab holds one granule");
     __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
+    __shared__ __attribute__((aligned(16))) uint16_t slab_all[STAGED ? XM_BLOCK / 64 : 1][STAGED ? XM_SLAB_U16 : 4];
     const uint32_t lane = threadIdx.x & 63u;
     {   // K2b has consumed the part totals: leave them zeroed for the next count (n_parts cells in each of the 8 x replicas rows)
         const uint32_t n_parts = (n_gran + XM_PART_GRAN - 1u) / XM_PART_GRAN, cells = 8u * XM_PART_REPLICAS * n_parts;
@@ -588,8 +681,21 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
         if (g == 0u && lane < 8u) bin_offsets[lane] = bin_start;
     }
     uint32_t base[7];
+    // STAGED: lane b < 7 lays out bin b's region of the slab: room for its units (what the counting side reported for
+    // this granule) rounded up to 4, + 4, regions back to back; the run starts (place in idx_out) mod 4 words into its
+    // region, so that 16-byte-aligned places of idx_out are 8-byte-aligned places of the slab.
+    uint16_t *slab = slab_all[STAGED ? wave : 0];
+    uint32_t run_start = 0, run_len = 0;
+    if (STAGED) {
+        uint32_t cnt = (lane < 7u) ? gran_counts[(uint64_t)lane * gran_stride + g] : 0u;
+        const uint32_t room = (lane < 7u) ? ((cnt + 3u) & ~3u) + 4u : 0u;
+        run_start = wave_scan_incl(room) - room + (lane_base & 3u);
+        // never past the number of units, never past the slab, whatever the counts hold
+        cnt = lane_base < n_units ? (cnt < n_units - lane_base ? cnt : n_units - lane_base) : 0u;
+        run_len = run_start < (uint32_t)XM_SLAB_U16 ? (cnt < XM_SLAB_U16 - run_start ? cnt : XM_SLAB_U16 - run_start) : 0u;
+    }
 #pragma unroll
-    for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
+    for (int b = 0; b < 7; ++b) base[b] = lane_value(STAGED ? run_start : lane_base, b);
 
     const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
     uint32_t w[NSUB];
@@ -608,7 +714,8 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
     if (!NIB) lds_settle();
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
-        const uint32_t rec0 = (uint32_t)rec_g + (uint32_t)s * 256u + lane * 4u;
+        const uint32_t rec0 = (STAGED ? 0u : (uint32_t)rec_g) + (uint32_t)s * 256u + lane * 4u;
+        const uint32_t limit = STAGED ? (uint32_t)XM_SLAB_U16 : n_units;
         uint32_t bin[4];
         bool even_free;
         if (NIB) {
@@ -620,13 +727,22 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
         }
         if (__ballot(!even_free) == 0ull) {                               // strictly interleaved mates: positions 1 and 3 only
             if (!NIB) { bin[0] = bin[2] = 7u; bin[1] = lut[(w[s] >> 8) & 63u]; bin[3] = lut[(w[s] >> 24) & 63u]; }
-            scatter_256<0xA, WIDE>(bin, rec0, base, idx_out, n_units);
+            scatter_256<0xA, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
         } else {
             if (!NIB) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bin[j] = lut[(w[s] >> (8 * j)) & 63u];
             }
-            scatter_256<0xF, WIDE>(bin, rec0, base, idx_out, n_units);
+            scatter_256<0xF, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
+        }
+    }
+    if (STAGED) {
+        lds_settle();                                                     // the wave's slab is complete
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const uint32_t N = lane_value(run_len, b);
+            if (N == 0u) continue;                                        // wave-uniform
+            scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, idx_out);
         }
     }
 }
@@ -1381,13 +1497,14 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
 }
 
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
-                    const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets, uint32_t *idx_out, uint32_t *part_tot)
+                    const uint32_t *gran_counts, const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets,
+                    uint32_t *idx_out, uint32_t *part_tot)
 {
     const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
     const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
-#define XM_LAUNCH_SCT(W, NIB) scatter_kernel<XM_GRAN / 256, W, NIB><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_off, bt, bo, idx_out, part_tot)
+#define XM_LAUNCH_SCT(W, NIB) scatter_kernel<XM_GRAN / 256, W, NIB><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot)
     if (code_is_bins4) { if (wide) XM_LAUNCH_SCT(true, true); else XM_LAUNCH_SCT(false, true); }
     else               { if (wide) XM_LAUNCH_SCT(true, false); else XM_LAUNCH_SCT(false, false); }
 #undef XM_LAUNCH_SCT
