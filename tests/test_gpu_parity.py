@@ -322,6 +322,31 @@ def test_scan_carry_between_parts_of_the_one_launch_scan(ctx, n, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
+def test_scatter_staging_threshold_granule_by_granule(ctx, mode):
+    """In the single-end loop K2c sorts a granule's units inside an LDS slab and copies the bins' runs out with wide
+    stores when the granule holds XM_STAGE_MIN_UNITS (1536) units or more, and writes every index directly otherwise --
+    decided per granule (the paired loops always write directly; they run the same inputs here).
+    Granules with 0, 1, 1535, 1536, 1537, 2047 and 2048 units side by side (in the paired modes every record of a dense
+    granule closes a unit: runs of equal names), random states, so that runs of every length -- shorter than a wave,
+    with and without head / tail places around the 16-byte groups -- start at every alignment."""
+    rng = np.random.default_rng(1536 + mode)
+    per_gran = [2048, 0, 1535, 1, 1536, 2047, 1537, 2048, 1536, 700, 2048]
+    n = 2048 * len(per_gran) + 300
+    flags = np.zeros(n, dtype=np.uint8)
+    for k, units in enumerate(per_gran):
+        at = rng.choice(2048, units, replace=False) + 2048 * k
+        flags[at] = 1
+    flags[2048 * len(per_gran):] = 1                                # a dense ragged tail
+    flags[0] = 0
+    for skew in (None, 0, 3):                                       # flat, and two heavily skewed state distributions
+        if skew is None:
+            states = rng.integers(0, 6, n)
+        else:
+            states = np.where(rng.random(n) < 0.9, skew, rng.integers(0, 6, n))
+        check_all(ctx, mode, _columns_of_states(states), H.synth.pack_unit_bits(flags), NEG)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_split_edges_with_state6_units(ctx, mode):
     """State-6 units (NaN scores, binary64 path) inside otherwise single-bin granules: they go to slot 6 and leave
     the ranks of the units around them intact."""

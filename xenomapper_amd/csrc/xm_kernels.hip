@@ -597,8 +597,8 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0
         }
 }
 
-// XM_SCATTER_STAGED (0 in a tuning build: every unit's index goes to idx_out with its own dword store): the granule's
-// units are first sorted by bin inside a wave-private LDS slab (16-bit record numbers), then every bin's run is copied
+// XM_SCATTER_STAGED (0 in a tuning build: every unit's index goes to idx_out with its own dword store): where a granule
+// holds XM_STAGE_MIN_UNITS units or more, they are first sorted by bin inside a wave-private LDS slab (16-bit record numbers), then every bin's run is copied
 // to its place in idx_out with 16-byte stores from 16-byte-aligned places.  Why: dword stores top out at 4.2 TB/s on
 // this chip however dense they are (a 200 MB fill takes 49.8 us; K2c with one dword store per unit took 53.8 us for
 // its 200 MB), 16-byte stores reach 6.4 TB/s (tools/probe_streams.hip, profiles/r03_ab_scatter.txt).
@@ -606,6 +606,9 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0
 #define XM_SCATTER_STAGED 1
 #endif
 #define XM_SLAB_U16 (XM_GRAN + 64)     // region of bin b: room for its units rounded up to 4, + 4 for the alignment shift
+#ifndef XM_STAGE_MIN_UNITS
+#define XM_STAGE_MIN_UNITS 1536        // units in a granule from which its wave stages them
+#endif
 
 template <bool WIDE>
 __device__ __forceinline__ void store_index4(uint32_t *__restrict__ idx_out, uint32_t pos, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3)
@@ -646,17 +649,51 @@ __device__ __forceinline__ void scatter_copy_out(const uint16_t *slab, uint32_t 
 // NIB: the categories come as the compact stream a counting K1 wrote (bins4: the bin itself, a nibble per record, 16 bits
 // per lane and 256 records, no table); otherwise as category bytes (one dword per lane and 256 records, the
 // byte -> bin rule of the mode in a 64-entry wave-private LDS table).
-template <int NSUB, bool WIDE, bool NIB>
+// the wave's granule, 256 records at a time: ranks by ballots, indices straight to idx_out or (STAGED) into the slab
+template <int NSUB, bool WIDE, bool NIB, bool STAGED>
+__device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const uint8_t *lut, uint32_t rec_g, uint32_t base[7],
+                                                uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        const uint32_t rec0 = (STAGED ? 0u : rec_g) + (uint32_t)s * 256u + lane * 4u;
+        const uint32_t limit = STAGED ? (uint32_t)XM_SLAB_U16 : n_units;
+        uint32_t bin[4];
+        bool even_free;
+        if (NIB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bin[j] = (w[s] >> (4 * j)) & 7u;
+            even_free = (w[s] & 0x0707u) == 0x0707u;
+        } else {
+            even_free = (w[s] & 0x00FF00FFu) == 0x00FF00FFu;
+        }
+        if (__ballot(!even_free) == 0ull) {                               // strictly interleaved mates: positions 1 and 3 only
+            if (!NIB) { bin[0] = bin[2] = 7u; bin[1] = lut[(w[s] >> 8) & 63u]; bin[3] = lut[(w[s] >> 24) & 63u]; }
+            scatter_256<0xA, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
+        } else {
+            if (!NIB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bin[j] = lut[(w[s] >> (8 * j)) & 63u];
+            }
+            scatter_256<0xF, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
+        }
+    }
+}
+
+// STAGE: this launch may stage (the single-end loop, where every record can be a unit; the paired loops, whose granules
+// hold half as many units at most in ordinary input, use the instantiation without the slab and its bookkeeping, which
+// costs them 2 us per 50 M pairs)
+template <int NSUB, bool WIDE, bool NIB, bool STAGE>
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
                const uint32_t *__restrict__ gran_counts, const uint32_t *__restrict__ gran_off,
                const unsigned long long *__restrict__ bin_totals,
                unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ part_tot)
 {
-    constexpr bool STAGED = XM_SCATTER_STAGED != 0;
-    static_assert(!STAGED || NSUB * 256 == XM_GRAN, "the slab holds one granule");
+    constexpr bool CAN_STAGE = STAGE && XM_SCATTER_STAGED != 0 && NSUB * 256 == XM_GRAN;
     __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
-    __shared__ __attribute__((aligned(16))) uint16_t slab_all[STAGED ? XM_BLOCK / 64 : 1][STAGED ? XM_SLAB_U16 : 4];
+    __shared__ __attribute__((aligned(16))) uint16_t slab_all[CAN_STAGE ? XM_BLOCK / 64 : 1][CAN_STAGE ? XM_SLAB_U16 : 4];
     const uint32_t lane = threadIdx.x & 63u;
     {   // K2b has consumed the part totals: leave them zeroed for the next count (n_parts cells in each of the 8 x replicas rows)
         const uint32_t n_parts = (n_gran + XM_PART_GRAN - 1u) / XM_PART_GRAN, cells = 8u * XM_PART_REPLICAS * n_parts;
@@ -680,22 +717,28 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
         n_units = lane_value(bin_start, 7);                               // slot 7 counts nothing: the total
         if (g == 0u && lane < 8u) bin_offsets[lane] = bin_start;
     }
-    uint32_t base[7];
-    // STAGED: lane b < 7 lays out bin b's region of the slab: room for its units (what the counting side reported for
-    // this granule) rounded up to 4, + 4, regions back to back; the run starts (place in idx_out) mod 4 words into its
-    // region, so that 16-byte-aligned places of idx_out are 8-byte-aligned places of the slab.
-    uint16_t *slab = slab_all[STAGED ? wave : 0];
+    // Staging pays where a granule holds many units (single-end input: 2048 of them; 117 against 166 us per 100 M reads)
+    // and costs where it holds few (strictly interleaved mates, 1024: 62 against 55 us): decided per launch (STAGE) and
+    // then per wave from the granule's unit count (what the counting side reported).
+    uint16_t *slab = slab_all[CAN_STAGE ? wave : 0];
     uint32_t run_start = 0, run_len = 0;
-    if (STAGED) {
+    bool staged = false;
+    if (CAN_STAGE) {
+        // lane b < 7 lays out bin b's region of the slab: room for its units rounded up to 4, + 4, regions back to back;
+        // the run starts (its place in idx_out) mod 4 words into its region, so that 16-byte-aligned places of idx_out
+        // are 8-byte-aligned places of the slab
         uint32_t cnt = (lane < 7u) ? gran_counts[(uint64_t)lane * gran_stride + g] : 0u;
         const uint32_t room = (lane < 7u) ? ((cnt + 3u) & ~3u) + 4u : 0u;
-        run_start = wave_scan_incl(room) - room + (lane_base & 3u);
+        const uint32_t incl_room = wave_scan_incl(room), incl_cnt = wave_scan_incl(cnt);
+        staged = lane_value(incl_cnt, 6) >= (uint32_t)XM_STAGE_MIN_UNITS;
+        run_start = incl_room - room + (lane_base & 3u);
         // never past the number of units, never past the slab, whatever the counts hold
         cnt = lane_base < n_units ? (cnt < n_units - lane_base ? cnt : n_units - lane_base) : 0u;
         run_len = run_start < (uint32_t)XM_SLAB_U16 ? (cnt < XM_SLAB_U16 - run_start ? cnt : XM_SLAB_U16 - run_start) : 0u;
     }
+    uint32_t base[7];
 #pragma unroll
-    for (int b = 0; b < 7; ++b) base[b] = lane_value(STAGED ? run_start : lane_base, b);
+    for (int b = 0; b < 7; ++b) base[b] = lane_value(staged ? run_start : lane_base, b);
 
     const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
     uint32_t w[NSUB];
@@ -712,31 +755,8 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
         for (int s = 0; s < NSUB; ++s) w[s] = load_codes4_tail(code, rec_g + s * 256u + lane * 4u, n);
     }
     if (!NIB) lds_settle();
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-        const uint32_t rec0 = (STAGED ? 0u : (uint32_t)rec_g) + (uint32_t)s * 256u + lane * 4u;
-        const uint32_t limit = STAGED ? (uint32_t)XM_SLAB_U16 : n_units;
-        uint32_t bin[4];
-        bool even_free;
-        if (NIB) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bin[j] = (w[s] >> (4 * j)) & 7u;
-            even_free = (w[s] & 0x0707u) == 0x0707u;
-        } else {
-            even_free = (w[s] & 0x00FF00FFu) == 0x00FF00FFu;
-        }
-        if (__ballot(!even_free) == 0ull) {                               // strictly interleaved mates: positions 1 and 3 only
-            if (!NIB) { bin[0] = bin[2] = 7u; bin[1] = lut[(w[s] >> 8) & 63u]; bin[3] = lut[(w[s] >> 24) & 63u]; }
-            scatter_256<0xA, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
-        } else {
-            if (!NIB) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bin[j] = lut[(w[s] >> (8 * j)) & 63u];
-            }
-            scatter_256<0xF, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
-        }
-    }
-    if (STAGED) {
+    if (CAN_STAGE && staged) {
+        scatter_granule<NSUB, WIDE, NIB, true>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab);
         lds_settle();                                                     // the wave's slab is complete
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
@@ -744,6 +764,8 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
             if (N == 0u) continue;                                        // wave-uniform
             scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, idx_out);
         }
+    } else {
+        scatter_granule<NSUB, WIDE, NIB, false>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab);
     }
 }
 
@@ -1504,9 +1526,12 @@ void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, con
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
     const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
-#define XM_LAUNCH_SCT(W, NIB) scatter_kernel<XM_GRAN / 256, W, NIB><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot)
-    if (code_is_bins4) { if (wide) XM_LAUNCH_SCT(true, true); else XM_LAUNCH_SCT(false, true); }
-    else               { if (wide) XM_LAUNCH_SCT(true, false); else XM_LAUNCH_SCT(false, false); }
+    const bool stage = mode == XM_MODE_SE;
+#define XM_LAUNCH_SCT(W, NIB, STG) scatter_kernel<XM_GRAN / 256, W, NIB, STG><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot)
+#define XM_LAUNCH_SCT2(W, NIB) do { if (stage) XM_LAUNCH_SCT(W, NIB, true); else XM_LAUNCH_SCT(W, NIB, false); } while (0)
+    if (code_is_bins4) { if (wide) XM_LAUNCH_SCT2(true, true); else XM_LAUNCH_SCT2(false, true); }
+    else               { if (wide) XM_LAUNCH_SCT2(true, false); else XM_LAUNCH_SCT2(false, false); }
+#undef XM_LAUNCH_SCT2
 #undef XM_LAUNCH_SCT
 }
 
