@@ -224,6 +224,33 @@ def e2e_h2d_inclusive(ctx, mode, host_cols, pairs, reps=3):
     return out
 
 
+def pcie_ceiling(dev, mb=512):
+    """What the link itself delivers on this box: one pinned-host <-> device copy of `mb` MB each way (torch, best of 3)."""
+    import torch
+    host = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
+    devt = torch.empty(mb << 20, dtype=torch.uint8, device=dev)
+    out = {}
+    for name, dst, src in (("h2d_pinned_GBps", devt, host), ("d2h_pinned_GBps", host, devt)):
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dst.copy_(src, non_blocking=False)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        out[name] = (mb << 20) / best / 1e9
+    pageable = torch.empty(mb << 20, dtype=torch.uint8)
+    pageable.fill_(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    devt.copy_(pageable)
+    torch.cuda.synchronize()
+    out["h2d_pageable_GBps"] = (mb << 20) / (time.perf_counter() - t0) / 1e9
+    out["what"] = "single %d MB copies through torch (hipMemcpy): the ceiling of e2e.h2d_inclusive on this box" % mb
+    return out
+
+
 def e2e_sam_text(pairs=4_000_000, to_files=True):
     """SAM text in -> six SAM files out through the file fast path (C++ stripper -> GPU -> C++ writer); outputs on
     tmpfs (`to_files`) or /dev/null (what is left is parser-bound).  Never `value`."""
@@ -691,6 +718,10 @@ def main():
                 e2e["h2d_inclusive"] = e2e_h2d_inclusive(ctx, wl.mode, hc, min(n_pairs, 25_000_000))
             except Exception as e:                               # noqa: BLE001
                 e2e["h2d_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                e2e["pcie_ceiling"] = pcie_ceiling(dev)
+            except Exception as e:                               # noqa: BLE001
+                e2e["pcie_ceiling"] = {"error": "%s: %s" % (type(e).__name__, e)}
             for key, to_files in (("sam_text", True), ("sam_text_devnull", False)):
                 try:
                     e2e[key] = e2e_sam_text(to_files=to_files)
