@@ -1164,16 +1164,19 @@ __device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, cons
     const uint32_t b0 = incl - lsum, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2, b4 = b3 + c3;      // <= W < XM_CIG_WAVE_OPS
     const uint32_t t0 = T[b0], t1 = T[b1], t2 = T[b2], t3 = T[b3], t4 = T[b4];
     const uint32_t d[4] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3};
+    // 32-bit scores: exact and inside int32 while |NM| < 2^23 and the penalty < 2^30 (|6 NM| < 2^26).  A wave with a
+    // record outside that (never, in practice) takes the careful path, which works in 64 bits and reports overflow.
+    // (64-bit scores here: +2 us per 50 M pairs, profiles/r03_ab_cigp.txt.)
+    bool big = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const long long sc = -6ll * (long long)nmv[j] - (long long)d[j];
         const bool present = nmv[j] != INT32_MIN;
-        const bool out = present && (sc <= (long long)INT32_MIN || sc > (long long)INT32_MAX);
-        bad |= out;
-        const long long cl = out ? (sc < 0 ? (long long)INT32_MIN + 1 : (long long)INT32_MAX) : sc;
-        as_out[j] = present ? (int32_t)cl : INT32_MIN;
+        const int32_t nme = present ? nmv[j] : 0;
+        big |= (uint32_t)(nme + (1 << 23)) >= (1u << 24) || d[j] >= (1u << 30);
+        as_out[j] = present ? __mul24(nme, -6) - (int32_t)d[j] : INT32_MIN;
     }
-    return true;
+    (void)bad;
+    return __ballot(big) == 0ull;
 }
 
 // one record's score from ops [b, e), bounds-checked against the array
