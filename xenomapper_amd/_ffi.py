@@ -306,16 +306,21 @@ class Context(object):
         self._check(rc, "xm_compact")
         return idx[:int(off[7])], off, counts
 
-    def classify_compact(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, want_code=True):
+    def classify_compact(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, want_code=True, idx_out=None):
         """One fused pass: classify + count + stable split.  Columns int32 (min_score = int floor) or float64
-        (min_score = float).  -> (code or None, idx, bin_offsets[8], counts[64])"""
+        (min_score = float).  -> (code or None, idx, bin_offsets[8], counts[64]).  idx_out: a uint32 array of at least
+        n elements to receive the lists (e.g. one that lives across calls and has been host_register()ed)."""
         f64 = np.asarray(as1).dtype == np.float64
         cols = [_as(c, np.float64 if f64 else np.int32) for c in (as1, xs1, as2, xs2)]
         n = cols[0].shape[0]
         bits = _as(unit_bits, np.uint64)
         assert bits.shape[0] >= (n + 63) // 64 and all(c.shape[0] == n for c in cols)
         code = np.empty(n, dtype=np.uint8) if want_code else None
-        idx = np.empty(max(n, 1), dtype=np.uint32)
+        if idx_out is not None:
+            assert idx_out.dtype == np.uint32 and idx_out.flags.c_contiguous and idx_out.shape[0] >= max(n, 1)
+            idx = idx_out
+        else:
+            idx = np.empty(max(n, 1), dtype=np.uint32)
         off = np.zeros(8, dtype=np.uint64)
         counts = np.zeros(64, dtype=np.uint64)
         fn = self._L.xm_classify_compact_f64 if f64 else self._L.xm_classify_compact
