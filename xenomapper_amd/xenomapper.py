@@ -674,7 +674,7 @@ def _emit_into_file(parser, paired, b, seg, sink):
     idx, need = parser.emit_size(paired, b, seg)
     if need < MMAP_EMIT_MIN_BYTES:
         return False
-    fd2 = None
+    fd2, pos, extended = None, 0, False
     try:
         sink.flush()
         fd = sink.fileno()
@@ -684,6 +684,7 @@ def _emit_into_file(parser, paired, b, seg, sink):
             return False
         # a mapping needs a descriptor opened for reading as well; sinks are usually write-only
         fd2 = os.open("/proc/self/fd/%d" % fd, os.O_RDWR)
+        extended = True
         try:
             os.posix_fallocate(fd2, pos, need)         # extends the file AND allocates its pages in one go: the threads
         except OSError:                                # then only copy (page by page faults cost 3x on tmpfs)
@@ -692,6 +693,11 @@ def _emit_into_file(parser, paired, b, seg, sink):
         mm = mmap.mmap(fd2, pos + need - start, offset=start, access=mmap.ACCESS_WRITE)
     except (OSError, ValueError, AttributeError, io.UnsupportedOperation):
         if fd2 is not None:
+            if extended:
+                try:
+                    os.ftruncate(fd2, pos)             # the file is as the sink left it; the caller writes the text
+                except OSError:
+                    pass
             os.close(fd2)
         return False
     try:
