@@ -321,6 +321,23 @@ def test_scan_carry_between_parts_of_the_one_launch_scan(ctx, n, mode):
         assert fcode is None or np.array_equal(fcode, want_code)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("p_single,p_triple", [(0.01, 0.0), (0.3, 0.0), (0.05, 0.002), (0.0, 0.2)])
+def test_paired_input_with_unpaired_reads(ctx, mode, p_single, p_triple):
+    """Mates that are not strictly interleaved: reads without a mate flip the parity of everything behind them, so a
+    lane of K2c holds its (at most two) units at any of its four records -- the two-units-per-lane form; a few runs of
+    three equal names (three units in a lane can then occur) send single 256-record groups to the general form."""
+    rng = np.random.default_rng(int(1000 * p_single + 7 * mode + 100000 * p_triple))
+    n = 3 * 2048 * 7 + 1234
+    sizes = rng.choice([1, 2, 3], size=n, p=[p_single, 1.0 - p_single - p_triple, p_triple])
+    names = np.repeat(np.arange(n), sizes)[:n]
+    flags = np.zeros(n, dtype=np.uint8)
+    flags[1:] = names[1:] == names[:-1]
+    for skew in (None, 0):
+        states = rng.integers(0, 6, n) if skew is None else np.where(rng.random(n) < 0.9, skew, rng.integers(0, 6, n))
+        check_all(ctx, mode, _columns_of_states(states), H.synth.pack_unit_bits(flags), NEG)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_scatter_staging_threshold_granule_by_granule(ctx, mode):
     """In the single-end loop K2c sorts a granule's units inside an LDS slab and copies the bins' runs out with wide

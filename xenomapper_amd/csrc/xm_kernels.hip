@@ -554,8 +554,10 @@ __device__ __forceinline__ void store_index(uint32_t *__restrict__ idx_out, uint
 // STAGED: `base` are places in the wave's LDS slab (one region per bin), `rec0` the lane's first record counted from the
 // granule's first, `n_units` the slab's capacity: the units are only sorted locally here; the wave copies the regions out
 // afterwards (scatter_copy_out).
+// rec[j]: the record the lane's position j stands for (rec0 + j when the positions are the lane's four records; the lane's
+// first / second unit in the two-units-per-lane form, SLOTS 0x3)
 template <int SLOTS, bool WIDE, bool STAGED>
-__device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0, uint32_t base[7],
+__device__ __forceinline__ void scatter_256(const uint32_t bin[4], const uint32_t rec[4], uint32_t base[7],
                                             uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab)
 {
     uint32_t pos[4] = {0, 0, 0, 0};
@@ -592,8 +594,8 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], uint32_t rec0
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (((SLOTS >> j) & 1) && bin[j] < 7u && (!XM_SCATTER_GUARD || pos[j] < n_units)) {
-            if (STAGED) slab[pos[j]] = (uint16_t)(rec0 + (uint32_t)j);
-            else store_index<WIDE>(idx_out, pos[j], rec0 + (uint32_t)j);
+            if (STAGED) slab[pos[j]] = (uint16_t)rec[j];
+            else store_index<WIDE>(idx_out, pos[j], rec[j]);
         }
 }
 
@@ -668,15 +670,46 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
         } else {
             even_free = (w[s] & 0x00FF00FFu) == 0x00FF00FFu;
         }
+        const uint32_t rec[4] = {rec0, rec0 + 1u, rec0 + 2u, rec0 + 3u};
         if (__ballot(!even_free) == 0ull) {                               // strictly interleaved mates: positions 1 and 3 only
             if (!NIB) { bin[0] = bin[2] = 7u; bin[1] = lut[(w[s] >> 8) & 63u]; bin[3] = lut[(w[s] >> 24) & 63u]; }
-            scatter_256<0xA, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
-        } else {
-            if (!NIB) {
+            scatter_256<0xA, WIDE, STAGED>(bin, rec, base, idx_out, limit, slab);
+            continue;
+        }
+        if (!NIB) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bin[j] = lut[(w[s] >> (8 * j)) & 63u];
+            for (int j = 0; j < 4; ++j) bin[j] = lut[(w[s] >> (8 * j)) & 63u];
+        }
+        // Mates that are not strictly interleaved (unpaired reads in between flip the parity): a lane still holds two
+        // units at most unless three records in a row share a name.  Then the lane's first and second unit take the
+        // place of its four records -- half the ballots and rank chains of the general form below.
+        // y: bit 4 j set where position j holds a unit (from the nibbles themselves, or from the four bins)
+        uint32_t y;
+        if (NIB) {
+            const uint32_t x = w[s] ^ 0x7777u;                             // nibble != 0  <=>  bin != 7
+            y = (x | (x >> 1) | (x >> 2)) & 0x1111u;
+        } else {
+            y = (bin[0] < 7u ? 1u : 0u) | (bin[1] < 7u ? 0x10u : 0u) | (bin[2] < 7u ? 0x100u : 0u) | (bin[3] < 7u ? 0x1000u : 0u);
+        }
+        if (!STAGED && __ballot(__builtin_popcount(y) > 2) == 0ull) {
+            const uint32_t rest = y & (y - 1u);                            // without the lane's first unit
+            const uint32_t c0 = y ? (uint32_t)__builtin_ctz(y) : 0u, c1 = rest ? (uint32_t)__builtin_ctz(rest) : 0u;   // 4 j0, 4 j1
+            const uint32_t j0 = c0 >> 2, j1 = c1 >> 2;
+            uint32_t vb[4] = {7u, 7u, 7u, 7u};
+            if (NIB) {
+                vb[0] = y ? (w[s] >> c0) & 7u : 7u;
+                vb[1] = rest ? (w[s] >> c1) & 7u : 7u;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                              // bin[j0], bin[j1] without indexing registers dynamically
+                    vb[0] = (y && j0 == (uint32_t)j) ? bin[j] : vb[0];
+                    vb[1] = (rest && j1 == (uint32_t)j) ? bin[j] : vb[1];
+                }
             }
-            scatter_256<0xF, WIDE, STAGED>(bin, rec0, base, idx_out, limit, slab);
+            const uint32_t vrec[4] = {rec0 + j0, rec0 + j1, 0u, 0u};
+            scatter_256<0x3, WIDE, STAGED>(vb, vrec, base, idx_out, limit, slab);
+        } else {
+            scatter_256<0xF, WIDE, STAGED>(bin, rec, base, idx_out, limit, slab);
         }
     }
 }
