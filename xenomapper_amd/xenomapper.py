@@ -30,7 +30,6 @@ import os
 import re
 import stat
 import sys
-import textwrap
 import time
 from collections import Counter
 from concurrent.futures import ThreadPoolExecutor
