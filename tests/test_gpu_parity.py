@@ -219,6 +219,50 @@ def _random_cigar(rng, n, max_ops=12, op_hi=9):
     return {"nm": nm, "cig_off": off, "cig_oplen": ops}
 
 
+def _check_csr_dev(ctx, mode, c1, xs1, c2, xs2, bits, mi):
+    """The CSR-column device entry points (K1c, round 1's fused kernel): xm_classify_cigar_dev and
+    xm_classify_compact_cigar_dev against the oracle."""
+    import torch
+    n = c1["nm"].shape[0]
+    dev = torch.device("cuda:0")
+    want, want_counts = _oracle_cigar_classify(mode, c1, xs1, c2, xs2, bits, mi)
+    want_idx, want_off = H.c_compact(mode, want)
+
+    def up(a):
+        if a.shape[0] == 0:
+            a = np.zeros(4, dtype=a.dtype)
+        return torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else (a.view(np.int64) if a.dtype == np.uint64 else a)).to(dev)
+    d = [up(x) for x in (c1["nm"], c1["cig_off"], c1["cig_oplen"], xs1, c2["nm"], c2["cig_off"], c2["cig_oplen"], xs2, bits)]
+    code = torch.full((n + 16,), 0xAA, dtype=torch.uint8, device=dev)
+    flag = torch.zeros(4, dtype=torch.int32, device=dev)
+    ctx.classify_cigar_dev(mode, *d, mi, code, range_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag[0].item()) == 0 and np.array_equal(code[:n].cpu().numpy(), want)
+    code.fill_(0xAA)
+    idx = torch.full((max(n, 1),), -1, dtype=torch.int32, device=dev)
+    off = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    ctx.classify_compact_cigar_dev(mode, *d, mi, code, idx, off, counts, range_flag=flag)
+    torch.cuda.synchronize()
+    assert np.array_equal(code[:n].cpu().numpy(), want)
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+    h_off = off.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(h_off, want_off)
+    assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 257, 1023, 1025, 2049, 4097, 100_003])
+def test_classify_cigar_csr_dev(ctx, n):
+    """K1c keeps serving CSR columns that are already on the device: ragged tails (its bounds-checked partial
+    workgroup), all modes, a threshold."""
+    rng = np.random.default_rng(500 + n)
+    c1, c2 = _random_cigar(rng, n), _random_cigar(rng, n)
+    xs = [np.where(rng.random(n) < 0.8, ABSENT, -rng.integers(0, 200, n)).astype(np.int32) for _ in range(2)]
+    for mode, m in itertools.product((0, 1, 2), (NEG, -40.5)):
+        flags = rng.random(n) < (0.55 if mode else 0.9)
+        _check_csr_dev(ctx, mode, c1, xs[0], c2, xs[1], H.synth.pack_unit_bits(flags), H.floor_min_score(m))
+
+
 @pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 257, 2047, 2048, 2049, 4097, 100_003])
 def test_classify_cigar_fused(ctx, n):
     """K3 fused into K1 (the --cigar_scores path) against oracle CIGAR scores + oracle classify."""
@@ -432,6 +476,7 @@ def test_classify_cigar_guards_of_the_op_parallel_path(ctx, flavour):
                                           c2["nm"], c2["cig_off"], c2["cig_oplen"], xs[1], bits, ABSENT)
         want, want_counts = _oracle_cigar_classify(mode, c1, xs[0], c2, xs[1], bits, ABSENT)
         assert np.array_equal(code, want) and np.array_equal(counts, want_counts)
+        _check_csr_dev(ctx, mode, c1, xs[0], c2, xs[1], bits, ABSENT)          # the same guards exist in K1c
 
 
 def _packed_on_device(c, xs):

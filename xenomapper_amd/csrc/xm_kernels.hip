@@ -911,10 +911,13 @@ __device__ __forceinline__ void cigar_fetch_offsets(const int32_t *__restrict__ 
         o[0] = (uint32_t)q.x; o[1] = (uint32_t)q.y; o[2] = (uint32_t)q.z; o[3] = (uint32_t)q.w;
         o[4] = off[r0 + 4];
     } else {
+        uint32_t prev = 0u;                                              // records past the end own no ops: begin = end
 #pragma unroll
-        for (int j = 0; j < 5; ++j) o[j] = (r0 + j <= n) ? off[r0 + j] : 0u;
-#pragma unroll
-        for (int j = 1; j < 5; ++j) o[j] = (r0 + j <= n) ? o[j] : o[j - 1];
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t v = (r0 + j <= n) ? off[r0 + j] : prev;
+            o[j] = v;
+            prev = v;
+        }
     }
 }
 
