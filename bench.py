@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the classification hot path on MI355X (BASELINE.json metric).
 
-    python bench.py                              # 1 GPU, configs[1]
+    python bench.py                              # 1 GPU: configs[1] timed; configs[2] and [4] reported under `workloads`
+    python bench.py --workload cfg3|cfg5|se|f64  # another workload as the timed one
     python bench.py --gpus N --steps K --warmup W   # N > 1: starts its own N ranks (one per GPU, RCCL)
+    python bench.py --gpus N --sharded-input     # configs[3] as ONE input cut into N read blocks with halo (strong scaling)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W            # ... or is started as a rank
 
 One step = one pass of the hot path over one batch of synthetic input that is already resident in HBM, through
-ONE C-ABI call (xm_classify_compact_dev): K1 classify + count (score columns -> category byte per record,
-category_counts, per-granule bin counts), K2b scan, K2c scatter (stable split of the pair indices into the six
-bins); every step leaves its category_counts in its own 64-word slot on the device, and the job ends -- inside the timed
-region -- by summing the slots into the job's category_counts and, on N > 1 GPUs, with the one RCCL all-reduce of them
-(the reference also only reports them at the end of a run).  Workload = BASELINE.json configs[1]: 50 M paired-end 2x150 bp read pairs with
-AS/XS scores per GPU (weak scaling: every rank holds its own 50 M-pair read block).
+ONE C-ABI call (xm_classify_compact_dev; --cigar_scores: xm_classify_compact_cigar_packed_dev): K1 classify + count
+(columns -> category per record as the compact stream, category_counts, per-granule and per-part bin counts), K2b scan,
+K2c scatter (stable split of the pair indices into the six bins); every step leaves its category_counts in its own
+64-word slot on the device, and the job ends -- inside the timed region -- by summing the slots into the job's
+category_counts and, on N > 1 GPUs, with the one RCCL all-reduce of them (the reference also only reports them at the
+end of a run).  Workload = BASELINE.json configs[1]: 50 M paired-end 2x150 bp read pairs with AS/XS scores per GPU
+(weak scaling: every rank holds its own 50 M-pair read block).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (classify): algorithmic bytes (33 B per pair:
-4 int32 scores x 2 mates in, 1 category byte out) / the kernel's mean duration, measured with HIP
-events on the launch stream inside the timed region.  `roofline_step` is SURVEY 8d's whole-step figure: 38 B per pair
-/ the sum of the kernels' mean durations.  `cpu_baseline` is the oracle's Python restatement of the reference's whole
-CPU path (parse + classify + write) on SAM text, timed on one host core at N = 1 on a bounded sample.  `e2e` holds
-the two transfer-inclusive rates SURVEY 8d asks for beside it (never `value`): host columns in / bin lists out over
-PCIe, and SAM text in / six SAM files out.
+4 int32 scores x 2 mates in, 1 category byte out; packed CIGAR columns: 4 (9 + 1/64 + 4 k) + 1) / the
+kernel's mean duration, measured with HIP events on the launch stream inside the timed region; `traffic` = HBM bytes
+per launch from the committed rocprofv3 --pmc passes, printed only while the kernel sources still hash to what they
+were measured on (tools/kernel_hash.py).  `roofline_step` is SURVEY 8d's whole-step figure: 38 B per pair / the sum of
+the kernels' mean durations (and / ms_per_step).  `workloads` (default run): configs[2] and configs[4] timed the same
+way in the same process.  `cpu_baseline` is the oracle's Python restatement of the reference's whole CPU path (parse +
+classify + write) on SAM text, timed on one host core at N = 1 on a bounded sample.  `e2e` holds the transfer-inclusive
+rates SURVEY 8d asks for beside it (never `value`) with their own ceilings: host columns in / bin lists out over PCIe
+(pageable and page-locked buffers; the link's measured rate), SAM text in / six SAM files out (the host side's memory,
+write and parse ceilings).  A hang in the library's own RCCL collective (run after everything else, under a watchdog)
+still delivers the line -- with the error in it -- and exits with status 3.
 """
 import argparse
 import contextlib
