@@ -480,8 +480,9 @@ int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t 
     if ((((uintptr_t)nm1 | (uintptr_t)off1 | (uintptr_t)xs1 | (uintptr_t)nm2 | (uintptr_t)off2 | (uintptr_t)xs2 |
           (uintptr_t)code_out) & 15u))
         return XM_ERR_INVALID_ARG;
-    // the CIGAR kernel does not count (it measured slower with the counting epilogue than with a separate histogram
-    // pass): classify, then the stand-alone compaction on the category bytes it wrote
+    // K1c (CSR columns) does not count (it measured slower with the counting epilogue than with a separate histogram
+    // pass): classify, then the stand-alone compaction on the category bytes it wrote.  The counting form of this path
+    // is xm_classify_compact_cigar_packed_dev.
     int rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);

@@ -1,14 +1,17 @@
 // xm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the xenograft read classifier.
 //
 // Three stages, all HBM-bound integer/byte work (no MFMA):
-//   K1 classify   score columns -> one category byte per record     (16 B in, 1 B out / record)
-//                 fused form: K1 also counts its units per category and per bin (LDS histogram, last wave flushes)
-//                 and can emit the compact category stream instead (the output bin as a nibble per record)
-//   K2 compact    categories -> category_counts + a stable split of unit indices by bin
+//   K1  classify  score columns -> one category per record          (16 B in, 1 B or 1/2 B out / record)
+//                 fused form: K1 also counts its units per category, per bin and granule, per bin and part (LDS
+//                 histogram, last wave flushes) and can emit the compact category stream (the output bin as a nibble)
+//   K1p           the same from packed CIGAR columns: AS synthesised from NM + CIGAR ops in the kernel (--cigar_scores)
+//   K1c           round 1's form of that on CSR columns (kept for CSR columns that are already on the device)
+//   K2  compact   categories -> category_counts + a stable split of unit indices by bin
 //                 K2a histogram (only when category bytes come from memory: wave-private LDS) -> per-granule bin counts
-//                 K2b scan of the per-granule counts, two levels (part sums, then one workgroup per part and bin)
-//                 K2c scatter: ballot + mbcnt ranks, scalar per-bin bases -> dense index runs, no LDS staging
-//   K3 cigar      NM + packed CIGAR (CSR) -> synthesised AS column
+//                 K2b scan of the per-granule counts: one launch, carries from the part totals the counting side added up
+//                 K2c scatter: ballot + mbcnt ranks, scalar per-bin bases -> dense index runs; straight to idx_out, or
+//                     (single-end input) through a wave-private LDS slab and 16-byte stores
+//   K3  cigar     NM + packed CIGAR ops (CSR) -> synthesised AS column (stand-alone xm_cigar_scores)
 //
 // Reference semantics restated (file:line into /root/reference/xenomapper/xenomapper.py):
 //   get_mapping_state :258-289, pair rules :423-448 / :521-550, unit rule :402-405,
@@ -530,10 +533,12 @@ scan_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t 
 // A unit's place in its bin is   (bin start) + (bin's units in earlier granules: K2b) + (rank inside the granule),
 // and the rank comes from ballots: for every bin that occurs in the 256 records, the lanes holding it form a 64-bit
 // mask per byte position, v_mbcnt counts the mask bits below the lane, and the running per-bin base lives in scalar
-// registers.  Lanes of one bin therefore write one dense run of idx_out per store instruction -- no LDS staging, no
-// barrier.  The byte -> bin rule (mode dependent) is a 64-entry wave-private LDS table, read conflict-free.
-// SLOTS: which of a lane's 4 byte positions can hold units -- 0b1010 for strictly interleaved mates (a wave-uniform
-// test per 256 records), else 0b1111.  WIDE: byte offsets into idx_out need more than 32 bits.
+// registers.  Lanes of one bin therefore write one dense run of idx_out per store instruction -- no barrier, and in
+// the direct form no LDS staging.  The byte -> bin rule (mode dependent) is a 64-entry wave-private LDS table, read
+// conflict-free.
+// SLOTS: which of a lane's 4 positions can hold units -- 0b1010 for strictly interleaved mates (a wave-uniform test per
+// 256 records); 0b0011 = the lane's first and second unit, wherever they sit (paired input with unpaired reads: two
+// units per lane at most); else 0b1111.  WIDE: byte offsets into idx_out need more than 32 bits.
 // ---------------------------------------------------------------------------------------------
 // XM_SCATTER_GUARD: no index is stored past the number of units (what K2b reported), whatever the category bytes hold
 #ifndef XM_SCATTER_GUARD
@@ -1087,8 +1092,8 @@ __device__ __forceinline__ void classify_cigar_body(
             mb &= ~1u;
         }
     }
-    // no fused counting here: this kernel runs at the rate its eleven concurrent streams get out of HBM, and the counting
-    // epilogue cost it 36-45 us per 50 M pairs -- more than the separate histogram pass (30 us) it would save
+    // no fused counting here: the counting epilogue cost this kernel 36-45 us per 50 M pairs, more than the separate
+    // histogram pass (30 us) it would save; K1p (packed columns) is the counting form of the --cigar_scores path
     const CountSink none = {nullptr, nullptr, nullptr, nullptr, 0u, 0};
     classify_finish<int32_t, PAIRED, BLOCK, FULL, false, -1>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, nullptr, none);
 }
