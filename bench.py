@@ -309,6 +309,7 @@ class Workload(object):
         self.cigar_csr = os.environ.get("XM_BENCH_CIGAR_CSR") == "1"     # A/B only: the CSR-column kernel (K1c + stand-alone histogram)
         self.unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"        # A/B only: xm_classify_dev + xm_compact_dev
         self.shard = shard
+        self.place = os.environ.get("XM_BENCH_PLACE") == "1" and name in ("cfg2", "cfg5", "se", "f64")   # single-pass kernel, six lists
         self.layout = "strictly interleaved mates"
         n = 2 * n_pairs
         units = n_pairs
@@ -357,6 +358,9 @@ class Workload(object):
         self.bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)  # compact category stream: a nibble per record
         self.idx = torch.empty(n, dtype=torch.int32, device=dev)
         self.off = torch.zeros(8, dtype=torch.int64, device=dev)
+        if self.place:
+            self.lists = [torch.empty(units + 64, dtype=torch.int32, device=dev) for _ in range(7 if name == "f64" else 6)]
+            self.n_out = torch.zeros(8, dtype=torch.int64, device=dev)
         self.n_slots = max(n_slots, 1)
         self.step_counts = torch.zeros((self.n_slots, 64), dtype=torch.int64, device=dev)   # category_counts of every step of the job
         self.step_no = 0
@@ -404,6 +408,8 @@ class Workload(object):
         return self.DESCR[self.name] % (self.n_pairs, self.mode_name)
 
     def kernel_name(self):
+        if self.place:
+            return "classify_place_kernel<%s, %s>" % (self.dtype, "single" if self.name == "se" else "paired")
         if self.cigp is not None:
             return "classify_cigp_kernel<paired, counts, bins4>"
         if self.cig is not None:
@@ -411,6 +417,8 @@ class Workload(object):
         return "classify_kernel<%s, %s, counts>" % (self.dtype, "single" if self.name == "se" else "paired")
 
     def call_name(self):
+        if self.place:
+            return "one xm_classify_place%s_dev call: ONE kernel (classify, count, look-back, place into six lists)" % ("_f64" if self.dtype == "f64" else "")
         if self.unfused:
             return "A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)"
         return "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % (
@@ -429,7 +437,10 @@ class Workload(object):
         self.step_no += 1
         code = self.code if self.category_bytes else None
         bins4 = None if self.category_bytes else self.bins4
-        if self.unfused:
+        if self.place:
+            ctx.classify_place_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, self.lists[:6],
+                                   self.n_out, counts, list_state6=self.lists[6] if len(self.lists) > 6 else None)
+        elif self.unfused:
             if self.cig is not None:
                 g = self.cig
                 ctx.classify_cigar_dev(mode, g[0]["nm"], g[0]["cig_off"], g[0]["cig_oplen"], c["xs1"], g[1]["nm"], g[1]["cig_off"],
@@ -474,6 +485,16 @@ class Workload(object):
         want_code, want_counts = H.c_classify(mode, hc["as1"], hc["xs1"], hc["as2"], hc["xs2"], hc["unit_bits"], self.floor_min)
         want_idx, want_off = H.c_compact(mode, want_code)
         ok = True
+        if self.place:
+            n_out = self.n_out.cpu().numpy().astype(np.uint64)
+            for b in range(len(self.lists)):
+                want = want_idx[int(want_off[b]):int(want_off[b + 1])]
+                ok &= int(n_out[b]) == want.shape[0]
+                ok &= bool((self.lists[b][:want.shape[0]].cpu().numpy().view(np.uint32) == want).all())
+            ok &= int(n_out[7]) == int(want_off[7]) == self.units_per_step
+            ok &= bool((self.counts.cpu().numpy().astype(np.uint64) == want_counts).all())
+            self.host_cols = hc
+            return ok
         if not self.category_bytes:
             # the timed step left the compact stream: check it, then ask for the category bytes as well (same kernels,
             # both outputs) so that they are checked too
@@ -562,7 +583,7 @@ def rooflines(wl, elapsed, steps, timing, timing_all, unit_name):
     step_achieved = step_bytes / (sum_ms * 1e-3) / 1e9
     ms_per_step = 1e3 * elapsed / steps
     traffic = step_traffic = source = None
-    if not (wl.unfused or wl.category_bytes or wl.shard or "singletons" in wl.layout):
+    if not (wl.unfused or wl.place or wl.category_bytes or wl.shard or "singletons" in wl.layout):
         traffic, step_traffic, source = kernel_hash.load_traffic(wl.name, wl.n_pairs)
     roof = {"bound": "hbm", "kernel": wl.kernel_name(), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,

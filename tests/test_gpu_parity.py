@@ -30,6 +30,21 @@ def random_columns(rng, n, spread=8):
     return [vals[rng.integers(0, len(vals), n)].astype(np.int32) for _ in range(4)]
 
 
+def check_place(ctx, mode, cols, bits, m, want_code, want_counts, want_idx, want_off, want_code_out=True):
+    """The single-pass entry point (xm_classify_place: six lists) against the oracle's split."""
+    code, lists, n_out, counts = ctx.classify_place(mode, *cols, bits, m, want_code=want_code_out)
+    if want_code_out:
+        assert np.array_equal(code, want_code)
+    assert np.array_equal(counts, want_counts)
+    for b in range(len(lists)):
+        want = want_idx[int(want_off[b]):int(want_off[b + 1])]
+        assert int(n_out[b]) == want.shape[0], (b, n_out, want_off)
+        assert np.array_equal(lists[b], want), b
+    if len(lists) == 6:
+        assert int(n_out[6]) == int(want_off[7] - want_off[6])
+    assert int(n_out[7]) == int(want_off[7])
+
+
 def check_all(ctx, mode, cols, bits, m_float):
     n = cols[0].shape[0]
     mi = H.floor_min_score(m_float)
@@ -46,8 +61,10 @@ def check_all(ctx, mode, cols, bits, m_float):
     fcode, fidx, foff, fcounts = ctx.classify_compact(mode, *cols, bits, mi)
     assert np.array_equal(fcode, want_code) and np.array_equal(fcounts, want_counts)
     assert np.array_equal(foff, want_off) and np.array_equal(fidx, want_idx)
+    check_place(ctx, mode, cols, bits, mi, want_code, want_counts, want_idx, want_off)
     # the binary64 path must agree with the integer path on integral input
     fcols = [np.where(c == ABSENT, NEG, c.astype(np.float64)) for c in cols]
+    check_place(ctx, mode, fcols, bits, m_float, want_code, want_counts, want_idx, want_off)
     codef, countsf = ctx.classify_f64(mode, *fcols, bits, m_float)
     assert np.array_equal(codef, want_code)
     assert np.array_equal(countsf, want_counts)

@@ -111,6 +111,14 @@ def lib():
         "xm_host_unregister": ([P, P], I),
         "xm_cigar_pack": ([U64, P, P, P, P, P, U64, ctypes.POINTER(U64)], I),
         "xm_classify_compact_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P], I),
+        "xm_classify_place": ([P, I, U64, P, P, P, P, P, I32, P, P, U64, P, P], I),
+        "xm_classify_place_f64": ([P, I, U64, P, P, P, P, P, F64, P, P, P, U64, P, P], I),
+        "xm_classify_place_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, U64, P, P], I),
+        "xm_classify_place_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, U64, P, P], I),
+        "xm_place_status": ([P, I], I),
+        "xm_place_debug_set_epoch": ([P, ctypes.c_uint32], I),
+        "xm_place_debug_stats": ([P, P, I], I),
+        "xm_place_debug_trace": ([P, U64, P], I),
         "xm_comm_unique_id": ([P], I),
         "xm_comm_init": ([P, I, I, P], I),
         "xm_comm_destroy": ([P], I),
@@ -134,6 +142,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_compact", "xm_classify_compact", "xm_classify_compact_f64", "xm_classify_compact_cigar", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
             "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
             "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister",
+            "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev", "xm_place_status", "xm_place_debug_set_epoch", "xm_place_debug_stats", "xm_place_debug_trace",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
@@ -350,6 +359,30 @@ class Context(object):
         self._check(rc, "xm_classify_compact_cigar")
         return code, idx[:int(off[7])], off, counts
 
+    def classify_place(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, want_code=True, capacity=None):
+        """One main loop in one kernel, six lists out (xm_classify_place / _f64).  -> (code or None, lists, n_out[8],
+        counts[64]); lists = six uint32 arrays (seven for float64 columns: the last holds the units with state 6)."""
+        f64 = np.asarray(as1).dtype == np.float64
+        cols = [_as(c, np.float64 if f64 else np.int32) for c in (as1, xs1, as2, xs2)]
+        n = cols[0].shape[0]
+        bits = _as(unit_bits, np.uint64)
+        assert bits.shape[0] >= (n + 63) // 64 and all(c.shape[0] == n for c in cols)
+        cap = n if capacity is None else int(capacity)
+        code = np.empty(n, dtype=np.uint8) if want_code else None
+        lists = [np.empty(max(cap, 1), dtype=np.uint32) for _ in range(7 if f64 else 6)]
+        arr = (ctypes.c_void_p * 6)(*[l.ctypes.data for l in lists[:6]])
+        n_out = np.zeros(8, dtype=np.uint64)
+        counts = np.zeros(64, dtype=np.uint64)
+        if f64:
+            rc = self._L.xm_classify_place_f64(self._h, mode, n, *[_np_ptr(c) for c in cols], _np_ptr(bits), float(min_score),
+                                               _np_ptr(code) if want_code else None, arr, _np_ptr(lists[6]), cap,
+                                               _np_ptr(n_out), _np_ptr(counts))
+        else:
+            rc = self._L.xm_classify_place(self._h, mode, n, *[_np_ptr(c) for c in cols], _np_ptr(bits), int(min_score),
+                                           _np_ptr(code) if want_code else None, arr, cap, _np_ptr(n_out), _np_ptr(counts))
+        self._check(rc, "xm_classify_place")
+        return code, [l[:min(int(n_out[b]), cap)] for b, l in enumerate(lists)], n_out, counts
+
     def mate_correlate(self, track, density):
         """Paired-end mappability of one chromosome track (float64 in, float64 out)."""
         track = _as(track, np.float64)
@@ -450,6 +483,45 @@ class Context(object):
             self._h, self._stream_handle(stream), mode, nm1.numel(), *ptrs, int(min_score_floor), opt(code_out), opt(bins4),
             opt(range_flag), opt(idx_out), opt(bin_offsets), opt(counts))
         self._check(rc, "xm_classify_compact_cigar_packed_dev")
+
+    def classify_place_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, lists, n_out, counts, code_out=None,
+                           list_state6=None, capacity=None, stream=None):
+        """One whole main loop in ONE kernel: classify, count and place the unit indices into six
+        caller-allocated device lists (`lists`: six uint32 tensors, one per output bin).  n_out: 8 x int64/uint64 device
+        tensor (six list lengths, state-6 units, all units); counts: 64.  Columns int32 or float64.  Asynchronous."""
+        n = as1.numel()
+        st = self._stream_handle(stream)
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (as1, xs1, as2, xs2, unit_bits)]
+        assert len(lists) == 6
+        cap = min(t.numel() for t in lists) if capacity is None else int(capacity)
+        arr = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in lists])
+        opt = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None     # noqa: E731
+        if as1.element_size() == 4:
+            rc = self._L.xm_classify_place_dev(self._h, st, mode, n, *ptrs, int(min_score), opt(code_out), arr, cap,
+                                               opt(n_out), opt(counts))
+        else:
+            rc = self._L.xm_classify_place_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), opt(code_out), arr,
+                                                   opt(list_state6), cap, opt(n_out), opt(counts))
+        self._check(rc, "xm_classify_place_dev")
+
+    def place_status(self, reset=False):
+        self._check(self._L.xm_place_status(self._h, 1 if reset else 0), "xm_place_status")
+
+    def place_debug_stats(self, reset=False):
+        out = np.zeros(16, dtype=np.uint32)
+        self._check(self._L.xm_place_debug_stats(self._h, _np_ptr(out), 1 if reset else 0), "xm_place_debug_stats")
+        return out
+
+    def place_debug_trace(self, n_granules, fetch=False):
+        if not fetch:
+            self._check(self._L.xm_place_debug_trace(self._h, int(n_granules), None), "xm_place_debug_trace")
+            return None
+        out = np.zeros((int(n_granules), 8), dtype=np.uint64)
+        self._check(self._L.xm_place_debug_trace(self._h, int(n_granules), _np_ptr(out)), "xm_place_debug_trace")
+        return out
+
+    def place_debug_set_epoch(self, epoch):
+        self._check(self._L.xm_place_debug_set_epoch(self._h, int(epoch)), "xm_place_debug_set_epoch")
 
     # ---- the count all-reduce (RCCL inside the library) -----------------------------------
     def comm_init(self, n_ranks, rank, unique_id):

@@ -808,6 +808,419 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1s: classify AND place in one pass (xm_classify_place*).  Output contract of SURVEY 8b (4): six caller-allocated
+// lists, one per output bin -- the reference's six independent sinks (xenomapper.py:332-350, :423-448, :521-550) -- so a
+// unit's place depends only on the units of ITS bin in front of it, never on the totals of other bins; no category
+// stream goes through memory, no scan launch, no scatter launch.
+//
+// A workgroup = one granule of XM_GRAN records, as in the counting K1.  Inside the workgroup: ranks by ballot + mbcnt
+// per 256-record wave tile (K2c's scheme, on the bins still in registers), wave counts through LDS.  Across workgroups:
+// a two-level decoupled look-back.
+//   gdesc[g]   the granule's units per bin, 16 bits each, in 8-byte {epoch, data} words (sc1 stores; the data is the flag)
+//   bsum[B]    the same summed over block B = XM_PLACE_S consecutive granules, by 64-bit atomic adds that carry an
+//              arrival count in the same word: complete when the count reads XM_PLACE_S (zero between calls)
+//   bpre[B/4]  inclusive prefix per bin behind block B, B = 3 mod 4, {epoch, value} words, published by the workgroup of
+//              the block's last granule once it knows its own prefix
+// Wave 0 of granule g = (B, k) publishes gdesc and adds to bsum as soon as the workgroup's counts are known, then reads,
+// all at once: the k descriptors in front of it in its block (lanes 0-30), the sums of the 24 blocks before B (lanes
+// 32-55) and the six prefix records inside that window (lanes 56-61); its prefix = the nearest published prefix + the
+// complete block sums between + its in-block descriptors.  Nothing in that chain waits for another workgroup's look-back
+// except the prefix record, which lags by a few microseconds = a few blocks; 24 blocks = 768 granules cover ~4.6 us of
+// arrivals at 50 M pairs per 0.29 ms.  Everything else a workgroup does (ranks, category histogram, its flush) overlaps
+// the wait.  Polls are bounded; a workgroup that gives up reports through ctl[2] and n_out[7] and stores nothing.
+// Lower-numbered workgroups must have been dispatched before higher-numbered ones wait on them (the hardware
+// dispatcher's order); the bounded polls turn a violation into an error, never into a hang.
+// The epoch lives in device memory (ctl[0]; a kernel argument would be frozen in a captured graph); the workgroup that
+// finishes last -- two-level arrival counters done1 / ctl[1] -- adds up the category_counts replicas, zeroes bsum,
+// and moves the epoch on (on wrap-around it clears the tagged words up to the high-water mark first).
+// ---------------------------------------------------------------------------------------------
+#define XM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+typedef unsigned long long xm_u64;
+__device__ __forceinline__ void g_store64(xm_u64 *p, xm_u64 v) { __hip_atomic_store(p, v, XM_RLX_AGENT); }
+__device__ __forceinline__ xm_u64 g_load64(const xm_u64 *p) { return __hip_atomic_load(p, XM_RLX_AGENT); }
+__device__ __forceinline__ void g_add64(xm_u64 *p, xm_u64 v) { (void)__hip_atomic_fetch_add(p, v, XM_RLX_AGENT); }
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#ifdef XM_PLACE_TRACE
+#define XM_TRACE(slot, value) do { if (ps.trace && (threadIdx.x & 63u) == 0u) ps.trace[(uint64_t)blockIdx.x * 8u + (slot)] = (value); } while (0)
+#else
+#define XM_TRACE(slot, value) do { } while (0)
+#endif
+#define XM_PLACE_LDS_WORDS (64 * XM_HREP + 16 + 64)   // category histogram | base[8], ok, ... | wave_cnt[8][8]
+
+// ranks of the lane's units inside the wave's 256-record tile, per bin, in record order (K2c's scatter_256 without a
+// base); returns, in lane b, the tile's number of units of bin b
+template <int SLOTS, int NB>
+__device__ __forceinline__ uint32_t place_ranks(const uint32_t bin[4], uint32_t pos[4])
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t wc = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        uint64_t m[4], any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = ((SLOTS >> j) & 1) ? __ballot(bin[j] == (uint32_t)b) : 0ull;
+            any |= m[j];
+        }
+        if (any == 0ull) continue;                                        // wave-uniform
+        uint32_t t = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((SLOTS >> j) & 1) { t = mbcnt64(m[j], t); total += (uint32_t)__builtin_popcountll(m[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((SLOTS >> j) & 1) pos[j] = (bin[j] == (uint32_t)b) ? t : pos[j];
+        wc = (lane == (uint32_t)b) ? total : wc;
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < j; ++i)
+            if (((SLOTS >> j) & 1) && ((SLOTS >> i) & 1)) pos[j] += (bin[i] == bin[j]) ? 1u : 0u;
+    return wc;
+}
+
+// fin: lane b holds where this wave's run of bin b starts in list b
+template <int SLOTS, int NB, bool WIDE>
+__device__ __forceinline__ void place_store(const uint32_t bin[4], const uint32_t pos[4], uint32_t rec0, uint32_t fin,
+                                            const PlaceSink &ps)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        uint64_t any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((SLOTS >> j) & 1) any |= __ballot(bin[j] == (uint32_t)b);
+        uint32_t *__restrict__ list = ps.list[b];
+        if (any == 0ull || list == nullptr) continue;                     // wave-uniform
+        const uint32_t s = lane_value(fin, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (((SLOTS >> j) & 1) && bin[j] == (uint32_t)b) {
+                const uint32_t p = s + pos[j];
+                if (p < ps.cap) store_index<WIDE>(list, p, rec0 + (uint32_t)j);
+            }
+    }
+}
+
+// Wave 0 of granule g: publish the granule's counts (tot: lane b < 7 holds the units of bin b, lane 7 holds 0), find
+// the exclusive prefix per bin (base: lane b), publish what others need from this granule.  false: gave up.
+template <bool HAS6>
+__device__ __forceinline__ bool place_lookback(const PlaceSink &ps, uint32_t g, uint32_t tot, uint32_t epoch, uint32_t &base)
+{
+    constexpr uint32_t NW = HAS6 ? 4u : 3u;          // words of a descriptor / block sum: two bins each
+    constexpr uint32_t NP = HAS6 ? 7u : 6u;          // words of a prefix record: one bin each
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t B = g / XM_PLACE_S, k = g % XM_PLACE_S;
+    {
+        const uint32_t lo = (uint32_t)__shfl((int)tot, (int)((2u * lane) & 7u), 64);
+        const uint32_t hi = (uint32_t)__shfl((int)tot, (int)((2u * lane + 1u) & 7u), 64);
+        if (lane < NW) {
+            g_store64(ps.gdesc + XM_PLACE_GD_AT(g) + lane, ((xm_u64)epoch << 32) | (hi << 16) | lo);
+#ifndef XM_PLACE_DBG_NOATOM
+            g_add64(ps.bsum + XM_PLACE_BS_AT(B) + lane, (1ull << 48) | ((xm_u64)hi << 24) | lo);
+#endif
+        }
+    }
+    base = 0;
+    bool ok = true;
+#ifdef XM_PLACE_DBG_NOWAIT
+    if (false) {
+#else
+    if (g != 0u) {
+#endif
+        // what this lane reads: role 1 = a descriptor of this block, 2 = a block sum, 3 = a prefix record
+        const xm_u64 *src = nullptr;
+        uint32_t nw = 0, role = 0;
+        if (lane < k) { role = 1; nw = NW; src = ps.gdesc + XM_PLACE_GD_AT(B * XM_PLACE_S + lane); }
+        else if (lane >= 32u && lane < 32u + XM_PLACE_WIN && lane - 32u < B) {
+            role = 2; nw = NW; src = ps.bsum + XM_PLACE_BS_AT(B - 1u - (lane - 32u));
+        } else if (lane >= 56u && lane < 56u + XM_PLACE_PROBES) {
+            const uint32_t need = (B & 3u) + 4u * (lane - 56u);             // blocks between the record's block and B
+            role = 3;
+            if (need < B) { nw = NP; src = ps.bpre + XM_PLACE_BP_AT((B - 1u - need) >> 2); }   // else: the beginning, prefix 0
+        }
+        xm_u64 x[7] = {0, 0, 0, 0, 0, 0, 0};
+        bool have = nw == 0u;
+        int pick = -1;
+        uint32_t need_pick = 0;
+        uint32_t spins = 0;
+        for (;; ++spins) {
+            if (!have) {
+#pragma unroll
+                for (uint32_t w = 0; w < 7u; ++w)
+                    if (w < nw) x[w] = g_load64(src + w);
+                bool good = true;
+#pragma unroll
+                for (uint32_t w = 0; w < 7u; ++w) {
+                    const bool tag = (role == 2u) ? (uint32_t)(x[w] >> 48) == XM_PLACE_S : (uint32_t)(x[w] >> 32) == epoch;
+                    good &= (w >= nw) || tag;
+                }
+                have = good;
+            }
+            const uint64_t vb = __ballot(have);
+            const uint32_t va = (uint32_t)(vb >> 32) & ((1u << XM_PLACE_WIN) - 1u), vp = (uint32_t)(vb >> 56) & ((1u << XM_PLACE_PROBES) - 1u);
+            if (((uint32_t)vb & 0x7FFFFFFFu) == 0x7FFFFFFFu && vp != 0u) {
+                const uint32_t mm = (uint32_t)__builtin_ctz(vp);              // the nearest prefix record that is there
+                uint32_t need = (B & 3u) + 4u * mm;
+                need = need < B ? need : B;
+                const uint32_t mask = (1u << need) - 1u;                       // need <= 23
+                if ((va & mask) == mask) { pick = (int)mm; need_pick = need; break; }
+            }
+            if (spins >= (uint32_t)XM_PLACE_SPIN_LIMIT) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(XM_PLACE_SLEEP);
+        }
+#ifdef XM_PLACE_STATS
+        XM_TRACE(5, spins);
+        XM_TRACE(6, (xm_u64)(int64_t)pick);
+        if (lane == 0u) {     // polls beyond the first, the largest number of them, which prefix record was taken
+            atomicAdd(ps.ctl + 4, spins);
+            atomicMax(ps.ctl + 5, spins);
+            atomicAdd(ps.ctl + 8 + (pick < 0 ? 7 : pick), 1u);
+        }
+#endif
+        if (ok) {
+            const bool use = (role == 1u) || (role == 2u && lane - 32u < need_pick) || (role == 3u && lane == 56u + (uint32_t)pick);
+#pragma unroll
+            for (uint32_t b = 0; b < NP; ++b) {
+                const xm_u64 w2 = x[b >> 1];
+                const uint32_t f16 = (uint32_t)(w2 >> ((b & 1u) * 16u)) & 0xFFFFu, f24 = (uint32_t)(w2 >> ((b & 1u) * 24u)) & 0xFFFFFFu;
+                uint32_t v = (role == 1u) ? f16 : (role == 2u) ? f24 : (uint32_t)x[b];
+                v = use ? v : 0u;
+                const uint32_t sum = lane_value(wave_scan_incl(v), 63);
+                base = (lane == b) ? sum : base;
+            }
+        }
+    }
+    if (!ok) {
+        if (lane == 0u) {
+            __hip_atomic_store(ps.ctl + 2, 1u, XM_RLX_AGENT);
+            if (g + 1u == ps.n_gran) ps.n_out[7] = ~0ull;
+        }
+        return false;
+    }
+    const uint32_t incl = base + tot;
+    if (k == XM_PLACE_S - 1u && (B & 3u) == 3u && lane < NP)
+        g_store64(ps.bpre + XM_PLACE_BP_AT(B >> 2) + lane, ((xm_u64)epoch << 32) | incl);
+    if (g + 1u == ps.n_gran) {                                                // the last granule's inclusive prefix = the list lengths
+        const uint32_t units = lane < 7u ? incl : 0u;
+        xm_u64 all = units;
+        all += __shfl_xor(all, 1, 64); all += __shfl_xor(all, 2, 64); all += __shfl_xor(all, 4, 64);
+        if (lane < 7u) ps.n_out[lane] = units;
+        if (lane == 7u) ps.n_out[7] = all;
+    }
+    return true;
+}
+
+// the workgroup that finishes last: category_counts from the replicas, workspace back to its between-calls state, next epoch
+__device__ __forceinline__ void place_finalize(const PlaceSink &ps, uint32_t epoch)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    xm_u64 acc = 0;
+    for (uint32_t r = 0; r < XM_COUNT_REPLICAS; ++r) {
+        acc += g_load64(ps.counts_rep + r * 64u + lane);
+        g_store64(ps.counts_rep + r * 64u + lane, 0ull);
+    }
+    ps.counts[lane] = acc;
+    const uint32_t n_blocks = (ps.n_gran + XM_PLACE_S - 1u) / XM_PLACE_S;
+    for (uint32_t i = lane; i < n_blocks * 4u; i += 64u) g_store64(ps.bsum + XM_PLACE_BS_AT(i >> 2) + (i & 3u), 0ull);
+    uint32_t next = epoch + 1u;
+    if (next == 0u) {                                                         // 2^32 calls: no stale tag may ever match again
+        for (uint64_t i = lane; i < XM_PLACE_GD_WORDS; i += 64u) g_store64(ps.gdesc + i, 0ull);
+        for (uint64_t i = lane; i < XM_PLACE_BP_WORDS; i += 64u) g_store64(ps.bpre + i, 0ull);
+        next = 1u;
+    }
+    if (lane == 0u) __hip_atomic_store(ps.ctl + 0, next, XM_RLX_AGENT);
+}
+
+template <typename T, bool PAIRED, int BLOCK, bool FULL, int BINMODE, bool WIDE>
+__device__ __forceinline__ void place_finish(const T a1[4], const T x1[4], const T a2[4], const T x2[4], T m,
+                                             uint32_t mb, uint32_t halo, uint32_t *last_state,
+                                             uint8_t *__restrict__ code, uint64_t r0, uint64_t n,
+                                             uint32_t *lds, uint32_t epoch, const PlaceSink &ps)
+{
+    static_assert(BLOCK == 512, "eight waves: wave_cnt[8][8] is one word per lane");
+    constexpr bool HAS6 = sizeof(T) == 8;
+    constexpr int NB = HAS6 ? 7 : 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t g = blockIdx.x;
+    uint32_t s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = mapping_state<T>(a1[j], x1[j], a2[j], x2[j], m);
+
+    uint32_t c[4], fwd[4] = {0, 0, 0, 0};
+    if (PAIRED) {
+        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[3], 0x138, 0xf, 0xf, false);
+        if (lane == 63) last_state[wave] = s[3];
+        __syncthreads();                                                   // also: the cleared histogram is visible
+        if (lane == 0) prev = (wave == 0) ? halo : last_state[wave - 1];
+        c[0] = (mb & 1u) ? ((prev << 3) | s[0]) : XM_NO_UNIT;
+        c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
+        c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
+        c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
+        fwd[0] = prev; fwd[1] = s[0]; fwd[2] = s[1]; fwd[3] = s[2];
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = ((mb >> j) & 1u) ? s[j] : XM_NO_UNIT;
+    }
+    if (code != nullptr) {                                                 // optional per-record output (wave-uniform test)
+        if (FULL || r0 + 4 <= n) {
+            *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r0 + j < n) code[r0 + j] = (uint8_t)c[j];
+        }
+    }
+    uint32_t bin[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bin[j] = unit_bin_of<BINMODE, HAS6>(fwd[j], s[j], ((mb >> j) & 1u) != 0u);
+    if (wave == 0u) XM_TRACE(1, wall_clock64());
+
+    // category_counts: the workgroup's histogram (64 slots x 8 replicas), as the counting K1
+    {
+        const uint32_t rep = lane & (XM_HREP - 1u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool unit = c[j] != XM_NO_UNIT;
+            if (__ballot(unit) == 0ull) continue;
+            if (unit) atomicAdd(&lds[(c[j] & 63u) * XM_HREP + rep], 1u);
+        }
+    }
+    // ranks inside the wave's tile, and the tile's units per bin
+    uint32_t pos[4] = {0, 0, 0, 0};
+    const bool inter = PAIRED && __ballot((mb & 5u) != 0u) == 0ull;        // strictly interleaved mates: positions 1, 3 only
+    const uint32_t wc = inter ? place_ranks<0xA, NB>(bin, pos) : place_ranks<0xF, NB>(bin, pos);
+    uint32_t *misc = lds + 64 * XM_HREP, *wave_cnt = misc + 16;
+    if (lane < 8u) wave_cnt[wave * 8u + lane] = wc;
+    __syncthreads();
+    // lane b: units of bin b in the waves in front of this one / in the whole granule
+    uint32_t off, tot;
+    {
+        const uint32_t v = wave_cnt[lane];
+        off = (lane >> 3) < wave ? v : 0u;
+        tot = v;
+        off += (uint32_t)__shfl_xor((int)off, 8, 64);  tot += (uint32_t)__shfl_xor((int)tot, 8, 64);
+        off += (uint32_t)__shfl_xor((int)off, 16, 64); tot += (uint32_t)__shfl_xor((int)tot, 16, 64);
+        off += (uint32_t)__shfl_xor((int)off, 32, 64); tot += (uint32_t)__shfl_xor((int)tot, 32, 64);
+    }
+    if (wave == 0u) {
+        uint32_t base = 0;
+        XM_TRACE(2, wall_clock64());
+        const bool ok = place_lookback<HAS6>(ps, g, tot, epoch, base);
+        XM_TRACE(3, wall_clock64());
+        if (lane < 8u) misc[lane] = base;
+        if (lane == 8u) misc[8] = ok ? 1u : 0u;
+        vm_drain();                                                        // what this wave published has been performed
+    } else if (wave == 1u) {
+        const uint4 h0 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP);
+        const uint4 h1 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP + 4);
+        const uint32_t sum = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
+        if (sum != 0u) g_add64(ps.counts_rep + (g % XM_COUNT_REPLICAS) * 64u + lane, (xm_u64)sum);
+        vm_drain();
+    }
+    __syncthreads();
+    const uint32_t fin = misc[lane & 7u] + off;
+    const bool ok = misc[8] != 0u;
+    // this workgroup's share of the shared state is complete: arrive (the last one to arrive finalizes)
+#ifndef XM_PLACE_DBG_NODONE
+    if (wave == 0u && lane == 0u) (void)__hip_atomic_fetch_add(ps.done1 + (g % XM_PLACE_DONE_WORDS), 1u, XM_RLX_AGENT);
+#endif
+#ifdef XM_PLACE_DBG_NOSTORE
+    if (false) {
+#else
+    if (ok) {
+#endif
+        const uint32_t rec0 = (uint32_t)r0;
+        if (inter) place_store<0xA, NB, WIDE>(bin, pos, rec0, fin, ps);
+        else place_store<0xF, NB, WIDE>(bin, pos, rec0, fin, ps);
+    }
+    if (wave == 0u) {
+        XM_TRACE(4, wall_clock64());
+        XM_TRACE(7, (xm_u64)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));     // HW_REG_XCC_ID, bits 0..3
+    }
+#ifdef XM_PLACE_DBG_NODONE
+    if (false) {
+#else
+    if (wave == 0u && g + 1u == ps.n_gran) {
+#endif
+        // The workgroup of the last granule waits until every workgroup has arrived (all of them were dispatched before
+        // this one and none waits for it), then puts the workspace back into its between-calls state.
+        const uint32_t n_gran = ps.n_gran;
+        bool all_in = false;
+        for (uint32_t spins = 0; spins < (uint32_t)XM_PLACE_SPIN_LIMIT; ++spins) {
+            bool in = true;
+#pragma unroll
+            for (uint32_t i = 0; i < XM_PLACE_DONE_WORDS / 64u; ++i) {
+                const uint32_t w = lane + 64u * i;
+                const uint32_t expect = w < n_gran ? (n_gran - w + XM_PLACE_DONE_WORDS - 1u) / XM_PLACE_DONE_WORDS : 0u;
+                in &= __hip_atomic_load(ps.done1 + w, XM_RLX_AGENT) == expect;
+            }
+            if (__ballot(!in) == 0ull) { all_in = true; break; }
+            __builtin_amdgcn_s_sleep(XM_PLACE_SLEEP);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < XM_PLACE_DONE_WORDS / 64u; ++i) __hip_atomic_store(ps.done1 + lane + 64u * i, 0u, XM_RLX_AGENT);
+        if (!all_in && lane == 0u) {
+            __hip_atomic_store(ps.ctl + 2, 1u, XM_RLX_AGENT);
+            ps.n_out[7] = ~0ull;
+        }
+        place_finalize(ps, epoch);
+    }
+}
+
+template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL, int BINMODE, bool WIDE>
+__device__ __forceinline__ void classify_place_body(const T *__restrict__ as1, const T *__restrict__ xs1,
+                                                    const T *__restrict__ as2, const T *__restrict__ xs2,
+                                                    const uint8_t *__restrict__ unit_bits8, T m,
+                                                    uint8_t *__restrict__ code, uint64_t n, uint32_t *last_state,
+                                                    uint32_t *lds, uint32_t epoch, const PlaceSink &ps)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
+    const uint64_t r0 = g * 4;
+    T a1[4], x1[4], a2[4], x2[4];
+    load4<T, NT, FULL>(as1, r0, n, a1);
+    load4<T, NT, FULL>(xs1, r0, n, x1);
+    load4<T, NT, FULL>(as2, r0, n, a2);
+    load4<T, NT, FULL>(xs2, r0, n, x2);
+    uint32_t mb = 0;
+    if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
+    if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 > 0) {
+            const uint64_t h = r0 - 1;
+            halo = mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m);
+        } else {
+            mb &= ~1u;                                         // record 0 has no predecessor (:402)
+        }
+    }
+    place_finish<T, PAIRED, BLOCK, FULL, BINMODE, WIDE>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, lds, epoch, ps);
+}
+
+template <typename T, bool PAIRED, bool NT, int BLOCK, int BINMODE, bool WIDE>
+__global__ void __launch_bounds__(BLOCK)
+classify_place_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
+                      const T *__restrict__ as2, const T *__restrict__ xs2,
+                      const uint8_t *__restrict__ unit_bits8, T m,
+                      uint8_t *__restrict__ code, uint64_t n, PlaceSink ps)
+{
+    static_assert(BLOCK * 4 == XM_GRAN, "the placing workgroup is one granule");
+    __shared__ uint32_t last_state[BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[XM_PLACE_LDS_WORDS];
+    for (uint32_t i = threadIdx.x; i < 64u * XM_HREP; i += BLOCK) lds[i] = 0;
+    const uint32_t epoch = ps.ctl[0];                                    // written by the previous call's last workgroup
+    if (threadIdx.x < 64u) XM_TRACE(0, wall_clock64());
+    if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
+        classify_place_body<T, PAIRED, NT, BLOCK, true, BINMODE, WIDE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, lds, epoch, ps);
+    else
+        classify_place_body<T, PAIRED, NT, BLOCK, false, BINMODE, WIDE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, lds, epoch, ps);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3: CIGAR-derived AS (one lane per record, CSR ops)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(XM_BLOCK)
@@ -1509,6 +1922,37 @@ void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
                          const uint64_t *unit_bits, double m, uint8_t *code, const CountPlan *cp)
 {
     launch_classify_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, cp);
+}
+
+template <typename T>
+static void launch_classify_place_t(hipStream_t st, int mode, uint64_t n,
+                                    const T *as1, const T *xs1, const T *as2, const T *xs2,
+                                    const uint64_t *unit_bits, T m, uint8_t *code, const PlaceSink &ps)
+{
+    const uint32_t grid = ps.n_gran;
+    const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
+    const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
+#define XM_LAUNCH_PLC(P, B, W) classify_place_kernel<T, P, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK, B, W><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n, ps)
+#define XM_LAUNCH_PLC2(P, B) do { if (wide) XM_LAUNCH_PLC(P, B, true); else XM_LAUNCH_PLC(P, B, false); } while (0)
+    if (mode == XM_MODE_SE) XM_LAUNCH_PLC2(false, XM_MODE_SE);
+    else if (mode == XM_MODE_PE_LIBERAL) XM_LAUNCH_PLC2(true, XM_MODE_PE_LIBERAL);
+    else XM_LAUNCH_PLC2(true, XM_MODE_PE_CONSERVATIVE);
+#undef XM_LAUNCH_PLC2
+#undef XM_LAUNCH_PLC
+}
+
+void launch_classify_place_i32(hipStream_t st, int mode, uint64_t n,
+                               const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                               const uint64_t *unit_bits, int32_t m, uint8_t *code, const PlaceSink &ps)
+{
+    launch_classify_place_t<int32_t>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, ps);
+}
+
+void launch_classify_place_f64(hipStream_t st, int mode, uint64_t n,
+                               const double *as1, const double *xs1, const double *as2, const double *xs2,
+                               const uint64_t *unit_bits, double m, uint8_t *code, const PlaceSink &ps)
+{
+    launch_classify_place_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, ps);
 }
 
 void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
