@@ -34,6 +34,7 @@ struct xm_ctx {
     // arrival counters, control words (xm_kernels.h: PlaceSink)
     uint64_t *d_gdesc, *d_bsum, *d_bpre;
     uint32_t *d_done1, *d_ctl;
+    uint16_t *d_ring;
     uint64_t *d_trace;              // tuning only (xm_place_debug_trace)
     uint64_t trace_gran;
     // the stream the workspace was last used on: a call on another stream is ordered behind it (order_workspace)
@@ -146,6 +147,7 @@ const size_t BSUM_BYTES = (size_t)XM_PLACE_BS_WORDS * sizeof(uint64_t);
 const size_t BPRE_BYTES = (size_t)XM_PLACE_BP_WORDS * sizeof(uint64_t);
 const size_t DONE1_BYTES = (size_t)XM_PLACE_DONE_WORDS * sizeof(uint32_t);
 const size_t CTL_BYTES = 64;
+const size_t RING_BYTES = (size_t)XM_PLACE_RING * (XM_GRAN / 2);
 
 // the placing kernels' workspace in its between-calls state: everything zero, epoch 1
 int reset_place_state(xm_ctx *ctx, hipStream_t st);
@@ -254,6 +256,7 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     ctx->d_part_tot = nullptr;
     ctx->d_gdesc = ctx->d_bsum = ctx->d_bpre = nullptr;
     ctx->d_done1 = ctx->d_ctl = nullptr;
+    ctx->d_ring = nullptr;
     ctx->d_trace = nullptr;
     ctx->trace_gran = 0;
     ctx->ws_stream = nullptr;
@@ -278,6 +281,7 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bpre, BPRE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_done1, DONE1_BYTES);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ctl, CTL_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ring, RING_BYTES);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming);
     int rc0 = XM_OK;
     if (e == hipSuccess && (rc0 = reset_place_state(ctx, nullptr)) == XM_OK) e = hipDeviceSynchronize();
@@ -293,6 +297,7 @@ int xm_ctx_create(int device_id, xm_ctx **out)
         if (ctx->d_bpre) (void)hipFree(ctx->d_bpre);
         if (ctx->d_done1) (void)hipFree(ctx->d_done1);
         if (ctx->d_ctl) (void)hipFree(ctx->d_ctl);
+        if (ctx->d_ring) (void)hipFree(ctx->d_ring);
         if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
         delete ctx;
         return rc;
@@ -320,6 +325,7 @@ int xm_ctx_destroy(xm_ctx *ctx)
     (void)hipFree(ctx->d_bpre);
     (void)hipFree(ctx->d_done1);
     (void)hipFree(ctx->d_ctl);
+    (void)hipFree(ctx->d_ring);
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     (void)hipEventDestroy(ctx->ws_event);
     delete ctx;
@@ -621,6 +627,8 @@ static int place_sink(xm_ctx *ctx, uint64_t n, uint32_t *const idx_out[6], uint3
     ps.list[6] = idx_state6;
     ps.cap = list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)list_capacity;
     ps.n_gran = xm::plan_granules(n).n_gran;
+    ps.lag = ps.n_gran < XM_PLACE_LAG ? ps.n_gran : XM_PLACE_LAG;
+    ps.ring = ctx->d_ring;
     ps.gdesc = reinterpret_cast<unsigned long long *>(ctx->d_gdesc);
     ps.bsum = reinterpret_cast<unsigned long long *>(ctx->d_bsum);
     ps.bpre = reinterpret_cast<unsigned long long *>(ctx->d_bpre);
@@ -629,7 +637,7 @@ static int place_sink(xm_ctx *ctx, uint64_t n, uint32_t *const idx_out[6], uint3
     ps.n_out = reinterpret_cast<unsigned long long *>(n_out);
     ps.counts = reinterpret_cast<unsigned long long *>(counts);
     ps.counts_rep = reinterpret_cast<unsigned long long *>(ctx->d_counts_rep);
-    ps.trace = (ctx->d_trace && ps.n_gran <= ctx->trace_gran) ? reinterpret_cast<unsigned long long *>(ctx->d_trace) : nullptr;
+    ps.trace = (ctx->d_trace && (uint64_t)ps.n_gran + ps.lag <= ctx->trace_gran) ? reinterpret_cast<unsigned long long *>(ctx->d_trace) : nullptr;
     return XM_OK;
 }
 

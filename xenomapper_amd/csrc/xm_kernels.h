@@ -78,6 +78,10 @@ struct CigCols {
 #define XM_PLACE_GD_WORDS ((uint64_t)XM_PLACE_GD_ROWS * XM_PLACE_GD_PITCH * 4u)
 #define XM_PLACE_BS_WORDS ((uint64_t)XM_PLACE_BS_ROWS * XM_PLACE_BS_PITCH * 4u)
 #define XM_PLACE_BP_WORDS ((uint64_t)XM_PLACE_BP_ROWS * XM_PLACE_BP_PITCH * 8u)
+#define XM_PLACE_RING 8192u        // granules of the bins ring (1 KB each): > lag + twice the resident workgroups
+#ifndef XM_PLACE_LAG
+#define XM_PLACE_LAG 2560u         // workgroup i places granule i - lag: ~15 us of arrivals at 50 M pairs per 0.3 ms
+#endif
 #define XM_PLACE_DONE_WORDS 256u   // arrival counters of finished workgroups: workgroup g adds to word g % 256
 #ifndef XM_PLACE_SLEEP
 #define XM_PLACE_SLEEP 4           // s_sleep argument between two polls (x 64 clocks)
@@ -88,6 +92,8 @@ struct PlaceSink {
     uint32_t *list[7];                 // the six bin lists, [6] = units holding state 6 (binary64 only; may be null)
     uint32_t cap;                      // capacity of every list, in entries
     uint32_t n_gran;
+    uint32_t lag;                      // min(XM_PLACE_LAG, n_gran); the grid is n_gran + lag workgroups
+    uint16_t *ring;                    // [XM_PLACE_RING][XM_GRAN / 4]: the bins of the granules in flight, a nibble per record
     unsigned long long *gdesc;         // [granule][4]   {epoch, 2 x 16-bit counts}
     unsigned long long *bsum;          // [block][4]     {arrivals, 2 x 24-bit sums}, all zero between calls
     unsigned long long *bpre;          // [block / 4][8] {epoch, inclusive prefix}

@@ -846,7 +846,9 @@ __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 #else
 #define XM_TRACE(slot, value) do { } while (0)
 #endif
-#define XM_PLACE_LDS_WORDS (64 * XM_HREP + 16 + 64)   // category histogram | base[8], ok, ... | wave_cnt[8][8]
+// LDS of a placing workgroup, in words: category histogram [64][XM_HREP] | misc: base[8], ok, -, bin accumulators [16..23], -,
+// wave_cnt[8][8] at misc + 32, the granule's bins staged for the ring at misc + 96 (1 KB)
+#define XM_PLACE_LDS_WORDS (64 * XM_HREP + 96 + 256)
 
 // ranks of the lane's units inside the wave's 256-record tile, per bin, in record order (K2c's scatter_256 without a
 // base); returns, in lane b, the tile's number of units of bin b
@@ -904,8 +906,24 @@ __device__ __forceinline__ void place_store(const uint32_t bin[4], const uint32_
     }
 }
 
-// Wave 0 of granule g: publish the granule's counts (tot: lane b < 7 holds the units of bin b, lane 7 holds 0), find
-// the exclusive prefix per bin (base: lane b), publish what others need from this granule.  false: gave up.
+// Publish granule g's units per bin (cnt: lane b < 7 holds the count of bin b, lane 7 holds 0): the descriptor, and the
+// block sum with its arrival count.
+template <bool HAS6>
+__device__ __forceinline__ void place_publish(const PlaceSink &ps, uint32_t g, uint32_t cnt, uint32_t epoch)
+{
+    constexpr uint32_t NW = HAS6 ? 4u : 3u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lo = (uint32_t)__shfl((int)cnt, (int)((2u * lane) & 7u), 64);
+    const uint32_t hi = (uint32_t)__shfl((int)cnt, (int)((2u * lane + 1u) & 7u), 64);
+    if (lane < NW) {
+        g_store64(ps.gdesc + XM_PLACE_GD_AT(g) + lane, ((xm_u64)epoch << 32) | (hi << 16) | lo);
+        g_add64(ps.bsum + XM_PLACE_BS_AT(g / XM_PLACE_S) + lane, (1ull << 48) | ((xm_u64)hi << 24) | lo);
+    }
+}
+
+// Wave 0, placing granule g: the exclusive prefix per bin (base: lane b) from the records in front of g; tot (lane b:
+// the granule's units of bin b) only serves what this granule publishes in turn (a prefix record, the list lengths).
+// false: gave up.
 template <bool HAS6>
 __device__ __forceinline__ bool place_lookback(const PlaceSink &ps, uint32_t g, uint32_t tot, uint32_t epoch, uint32_t &base)
 {
@@ -913,23 +931,9 @@ __device__ __forceinline__ bool place_lookback(const PlaceSink &ps, uint32_t g, 
     constexpr uint32_t NP = HAS6 ? 7u : 6u;          // words of a prefix record: one bin each
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t B = g / XM_PLACE_S, k = g % XM_PLACE_S;
-    {
-        const uint32_t lo = (uint32_t)__shfl((int)tot, (int)((2u * lane) & 7u), 64);
-        const uint32_t hi = (uint32_t)__shfl((int)tot, (int)((2u * lane + 1u) & 7u), 64);
-        if (lane < NW) {
-            g_store64(ps.gdesc + XM_PLACE_GD_AT(g) + lane, ((xm_u64)epoch << 32) | (hi << 16) | lo);
-#ifndef XM_PLACE_DBG_NOATOM
-            g_add64(ps.bsum + XM_PLACE_BS_AT(B) + lane, (1ull << 48) | ((xm_u64)hi << 24) | lo);
-#endif
-        }
-    }
     base = 0;
     bool ok = true;
-#ifdef XM_PLACE_DBG_NOWAIT
-    if (false) {
-#else
     if (g != 0u) {
-#endif
         // what this lane reads: role 1 = a descriptor of this block, 2 = a block sum, 3 = a prefix record
         const xm_u64 *src = nullptr;
         uint32_t nw = 0, role = 0;
@@ -971,9 +975,9 @@ __device__ __forceinline__ bool place_lookback(const PlaceSink &ps, uint32_t g, 
             if (spins >= (uint32_t)XM_PLACE_SPIN_LIMIT) { ok = false; break; }
             __builtin_amdgcn_s_sleep(XM_PLACE_SLEEP);
         }
-#ifdef XM_PLACE_STATS
         XM_TRACE(5, spins);
         XM_TRACE(6, (xm_u64)(int64_t)pick);
+#ifdef XM_PLACE_STATS
         if (lane == 0u) {     // polls beyond the first, the largest number of them, which prefix record was taken
             atomicAdd(ps.ctl + 4, spins);
             atomicMax(ps.ctl + 5, spins);
@@ -1013,7 +1017,8 @@ __device__ __forceinline__ bool place_lookback(const PlaceSink &ps, uint32_t g, 
     return true;
 }
 
-// the workgroup that finishes last: category_counts from the replicas, workspace back to its between-calls state, next epoch
+// the last workgroup of the grid, once every workgroup has arrived: category_counts from the replicas, workspace back to
+// its between-calls state, next epoch
 __device__ __forceinline__ void place_finalize(const PlaceSink &ps, uint32_t epoch)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1034,144 +1039,11 @@ __device__ __forceinline__ void place_finalize(const PlaceSink &ps, uint32_t epo
     if (lane == 0u) __hip_atomic_store(ps.ctl + 0, next, XM_RLX_AGENT);
 }
 
-template <typename T, bool PAIRED, int BLOCK, bool FULL, int BINMODE, bool WIDE>
-__device__ __forceinline__ void place_finish(const T a1[4], const T x1[4], const T a2[4], const T x2[4], T m,
-                                             uint32_t mb, uint32_t halo, uint32_t *last_state,
-                                             uint8_t *__restrict__ code, uint64_t r0, uint64_t n,
-                                             uint32_t *lds, uint32_t epoch, const PlaceSink &ps)
-{
-    static_assert(BLOCK == 512, "eight waves: wave_cnt[8][8] is one word per lane");
-    constexpr bool HAS6 = sizeof(T) == 8;
-    constexpr int NB = HAS6 ? 7 : 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t g = blockIdx.x;
-    uint32_t s[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = mapping_state<T>(a1[j], x1[j], a2[j], x2[j], m);
-
-    uint32_t c[4], fwd[4] = {0, 0, 0, 0};
-    if (PAIRED) {
-        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[3], 0x138, 0xf, 0xf, false);
-        if (lane == 63) last_state[wave] = s[3];
-        __syncthreads();                                                   // also: the cleared histogram is visible
-        if (lane == 0) prev = (wave == 0) ? halo : last_state[wave - 1];
-        c[0] = (mb & 1u) ? ((prev << 3) | s[0]) : XM_NO_UNIT;
-        c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
-        c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
-        c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
-        fwd[0] = prev; fwd[1] = s[0]; fwd[2] = s[1]; fwd[3] = s[2];
-    } else {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = ((mb >> j) & 1u) ? s[j] : XM_NO_UNIT;
-    }
-    if (code != nullptr) {                                                 // optional per-record output (wave-uniform test)
-        if (FULL || r0 + 4 <= n) {
-            *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (r0 + j < n) code[r0 + j] = (uint8_t)c[j];
-        }
-    }
-    uint32_t bin[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bin[j] = unit_bin_of<BINMODE, HAS6>(fwd[j], s[j], ((mb >> j) & 1u) != 0u);
-    if (wave == 0u) XM_TRACE(1, wall_clock64());
-
-    // category_counts: the workgroup's histogram (64 slots x 8 replicas), as the counting K1
-    {
-        const uint32_t rep = lane & (XM_HREP - 1u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool unit = c[j] != XM_NO_UNIT;
-            if (__ballot(unit) == 0ull) continue;
-            if (unit) atomicAdd(&lds[(c[j] & 63u) * XM_HREP + rep], 1u);
-        }
-    }
-    // ranks inside the wave's tile, and the tile's units per bin
-    uint32_t pos[4] = {0, 0, 0, 0};
-    const bool inter = PAIRED && __ballot((mb & 5u) != 0u) == 0ull;        // strictly interleaved mates: positions 1, 3 only
-    const uint32_t wc = inter ? place_ranks<0xA, NB>(bin, pos) : place_ranks<0xF, NB>(bin, pos);
-    uint32_t *misc = lds + 64 * XM_HREP, *wave_cnt = misc + 16;
-    if (lane < 8u) wave_cnt[wave * 8u + lane] = wc;
-    __syncthreads();
-    // lane b: units of bin b in the waves in front of this one / in the whole granule
-    uint32_t off, tot;
-    {
-        const uint32_t v = wave_cnt[lane];
-        off = (lane >> 3) < wave ? v : 0u;
-        tot = v;
-        off += (uint32_t)__shfl_xor((int)off, 8, 64);  tot += (uint32_t)__shfl_xor((int)tot, 8, 64);
-        off += (uint32_t)__shfl_xor((int)off, 16, 64); tot += (uint32_t)__shfl_xor((int)tot, 16, 64);
-        off += (uint32_t)__shfl_xor((int)off, 32, 64); tot += (uint32_t)__shfl_xor((int)tot, 32, 64);
-    }
-    if (wave == 0u) {
-        uint32_t base = 0;
-        XM_TRACE(2, wall_clock64());
-        const bool ok = place_lookback<HAS6>(ps, g, tot, epoch, base);
-        XM_TRACE(3, wall_clock64());
-        if (lane < 8u) misc[lane] = base;
-        if (lane == 8u) misc[8] = ok ? 1u : 0u;
-        vm_drain();                                                        // what this wave published has been performed
-    } else if (wave == 1u) {
-        const uint4 h0 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP);
-        const uint4 h1 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP + 4);
-        const uint32_t sum = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
-        if (sum != 0u) g_add64(ps.counts_rep + (g % XM_COUNT_REPLICAS) * 64u + lane, (xm_u64)sum);
-        vm_drain();
-    }
-    __syncthreads();
-    const uint32_t fin = misc[lane & 7u] + off;
-    const bool ok = misc[8] != 0u;
-    // this workgroup's share of the shared state is complete: arrive (the last one to arrive finalizes)
-#ifndef XM_PLACE_DBG_NODONE
-    if (wave == 0u && lane == 0u) (void)__hip_atomic_fetch_add(ps.done1 + (g % XM_PLACE_DONE_WORDS), 1u, XM_RLX_AGENT);
-#endif
-#ifdef XM_PLACE_DBG_NOSTORE
-    if (false) {
-#else
-    if (ok) {
-#endif
-        const uint32_t rec0 = (uint32_t)r0;
-        if (inter) place_store<0xA, NB, WIDE>(bin, pos, rec0, fin, ps);
-        else place_store<0xF, NB, WIDE>(bin, pos, rec0, fin, ps);
-    }
-    if (wave == 0u) {
-        XM_TRACE(4, wall_clock64());
-        XM_TRACE(7, (xm_u64)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));     // HW_REG_XCC_ID, bits 0..3
-    }
-#ifdef XM_PLACE_DBG_NODONE
-    if (false) {
-#else
-    if (wave == 0u && g + 1u == ps.n_gran) {
-#endif
-        // The workgroup of the last granule waits until every workgroup has arrived (all of them were dispatched before
-        // this one and none waits for it), then puts the workspace back into its between-calls state.
-        const uint32_t n_gran = ps.n_gran;
-        bool all_in = false;
-        for (uint32_t spins = 0; spins < (uint32_t)XM_PLACE_SPIN_LIMIT; ++spins) {
-            bool in = true;
-#pragma unroll
-            for (uint32_t i = 0; i < XM_PLACE_DONE_WORDS / 64u; ++i) {
-                const uint32_t w = lane + 64u * i;
-                const uint32_t expect = w < n_gran ? (n_gran - w + XM_PLACE_DONE_WORDS - 1u) / XM_PLACE_DONE_WORDS : 0u;
-                in &= __hip_atomic_load(ps.done1 + w, XM_RLX_AGENT) == expect;
-            }
-            if (__ballot(!in) == 0ull) { all_in = true; break; }
-            __builtin_amdgcn_s_sleep(XM_PLACE_SLEEP);
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < XM_PLACE_DONE_WORDS / 64u; ++i) __hip_atomic_store(ps.done1 + lane + 64u * i, 0u, XM_RLX_AGENT);
-        if (!all_in && lane == 0u) {
-            __hip_atomic_store(ps.ctl + 2, 1u, XM_RLX_AGENT);
-            ps.n_out[7] = ~0ull;
-        }
-        place_finalize(ps, epoch);
-    }
-}
-
+// One workgroup of the single-pass kernel.  Workgroup i CLASSIFIES granule i (i < n_gran): scores -> states -> category
+// bytes (optional output), category histogram, the granule's units per bin -> published; its bins, a nibble per record, go
+// into a ring (1 KB per granule, write-through).  And it PLACES granule j = i - lag (i >= lag): bins back from the ring,
+// ranks, look-back over records that were published ~lag granules = several microseconds ago, index stores.  The
+// placement's loads are issued first and its work runs while the score loads of granule i are in flight.
 template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL, int BINMODE, bool WIDE>
 __device__ __forceinline__ void classify_place_body(const T *__restrict__ as1, const T *__restrict__ xs1,
                                                     const T *__restrict__ as2, const T *__restrict__ xs2,
@@ -1179,30 +1051,192 @@ __device__ __forceinline__ void classify_place_body(const T *__restrict__ as1, c
                                                     uint8_t *__restrict__ code, uint64_t n, uint32_t *last_state,
                                                     uint32_t *lds, uint32_t epoch, const PlaceSink &ps)
 {
-    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
-    const uint64_t r0 = g * 4;
+    static_assert(BLOCK == 512, "eight waves: wave_cnt[8][8] is one word per lane");
+    constexpr bool HAS6 = sizeof(T) == 8;
+    constexpr int NB = HAS6 ? 7 : 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t i = blockIdx.x, lag = ps.lag;
+    const bool do_class = i < ps.n_gran, do_place = i >= lag;              // uniform; the grid is n_gran + lag workgroups
+    uint32_t *misc = lds + 64 * XM_HREP, *wave_cnt = misc + 32;
+
+    // ---- loads: the bins of the granule to place first, then the scores of the granule to classify
+    uint32_t nib = 0x7777u;
+    if (do_place) {
+        const uint16_t *slot = ps.ring + (uint64_t)((i - lag) % XM_PLACE_RING) * (XM_GRAN / 4u);
+        nib = __hip_atomic_load(slot + threadIdx.x, XM_RLX_AGENT);
+    }
+    const uint64_t g4 = (uint64_t)i * BLOCK + threadIdx.x;                // group of 4 records
+    const uint64_t r0 = g4 * 4;
     T a1[4], x1[4], a2[4], x2[4];
-    load4<T, NT, FULL>(as1, r0, n, a1);
-    load4<T, NT, FULL>(xs1, r0, n, x1);
-    load4<T, NT, FULL>(as2, r0, n, a2);
-    load4<T, NT, FULL>(xs2, r0, n, x2);
-    uint32_t mb = 0;
-    if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g >> 1] >> ((g & 1u) * 4u)) & 0xFu;
-    if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
-    uint32_t halo = 0;
-    if (PAIRED && threadIdx.x == 0) {
-        if (r0 > 0) {
-            const uint64_t h = r0 - 1;
-            halo = mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m);
-        } else {
-            mb &= ~1u;                                         // record 0 has no predecessor (:402)
+    uint32_t mb = 0, halo = 0;
+    if (do_class) {
+        load4<T, NT, FULL>(as1, r0, n, a1);
+        load4<T, NT, FULL>(xs1, r0, n, x1);
+        load4<T, NT, FULL>(as2, r0, n, a2);
+        load4<T, NT, FULL>(xs2, r0, n, x2);
+        if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g4 >> 1] >> ((g4 & 1u) * 4u)) & 0xFu;
+        if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+        if (PAIRED && threadIdx.x == 0) {
+            if (r0 > 0) {
+                const uint64_t h = r0 - 1;
+                halo = mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m);
+            } else {
+                mb &= ~1u;                                     // record 0 has no predecessor (:402)
+            }
         }
     }
-    place_finish<T, PAIRED, BLOCK, FULL, BINMODE, WIDE>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, lds, epoch, ps);
+
+    // ---- place granule j
+    if (do_place) {
+        const uint32_t j = i - lag;
+        uint32_t bin[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bin[q] = (nib >> (4 * q)) & 7u;
+        uint32_t pos[4] = {0, 0, 0, 0};
+        const bool inter = PAIRED && __ballot((nib & 0x0707u) != 0x0707u) == 0ull;   // strictly interleaved mates: positions 1, 3 only
+        const uint32_t wc = inter ? place_ranks<0xA, NB>(bin, pos) : place_ranks<0xF, NB>(bin, pos);
+        if (lane < 8u) wave_cnt[wave * 8u + lane] = wc;
+        __syncthreads();
+        uint32_t off, tot;      // lane b: units of bin b in the waves in front of this one / in the whole granule
+        {
+            const uint32_t v = wave_cnt[lane];
+            off = (lane >> 3) < wave ? v : 0u;
+            tot = v;
+            off += (uint32_t)__shfl_xor((int)off, 8, 64);  tot += (uint32_t)__shfl_xor((int)tot, 8, 64);
+            off += (uint32_t)__shfl_xor((int)off, 16, 64); tot += (uint32_t)__shfl_xor((int)tot, 16, 64);
+            off += (uint32_t)__shfl_xor((int)off, 32, 64); tot += (uint32_t)__shfl_xor((int)tot, 32, 64);
+        }
+        if (wave == 0u) {
+            uint32_t base = 0;
+            XM_TRACE(2, wall_clock64());
+#ifdef XM_PLACE_DBG_NOWAIT
+            const bool ok = true;
+#else
+            const bool ok = place_lookback<HAS6>(ps, j, tot, epoch, base);
+#endif
+            XM_TRACE(3, wall_clock64());
+            if (lane < 8u) misc[lane] = base;
+            if (lane == 8u) misc[8] = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        const uint32_t fin = misc[lane & 7u] + off;
+#ifndef XM_PLACE_DBG_NOSTORE
+        if (misc[8] != 0u) {
+            const uint32_t rec0 = j * (uint32_t)XM_GRAN + threadIdx.x * 4u;
+            if (inter) place_store<0xA, NB, WIDE>(bin, pos, rec0, fin, ps);
+            else place_store<0xF, NB, WIDE>(bin, pos, rec0, fin, ps);
+        }
+#endif
+    }
+
+    // ---- classify granule i
+    if (do_class) {
+        uint32_t s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = mapping_state<T>(a1[q], x1[q], a2[q], x2[q], m);
+        uint32_t c[4], fwd[4] = {0, 0, 0, 0};
+        if (PAIRED) {
+            uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[3], 0x138, 0xf, 0xf, false);
+            if (lane == 63) last_state[wave] = s[3];
+            __syncthreads();                                               // also: the cleared histogram is visible
+            if (lane == 0) prev = (wave == 0) ? halo : last_state[wave - 1];
+            c[0] = (mb & 1u) ? ((prev << 3) | s[0]) : XM_NO_UNIT;
+            c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
+            c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
+            c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
+            fwd[0] = prev; fwd[1] = s[0]; fwd[2] = s[1]; fwd[3] = s[2];
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = ((mb >> q) & 1u) ? s[q] : XM_NO_UNIT;
+        }
+        if (code != nullptr) {                                             // optional per-record output (uniform test)
+            if (FULL || r0 + 4 <= n) {
+                *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q < n) code[r0 + q] = (uint8_t)c[q];
+            }
+        }
+        uint32_t nibs = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nibs |= unit_bin_of<BINMODE, HAS6>(fwd[q], s[q], ((mb >> q) & 1u) != 0u) << (4 * q);
+        // the granule's bins, staged so that one wave writes them with 16-byte write-through stores
+        uint16_t *stage = reinterpret_cast<uint16_t *>(misc + 96);
+        stage[threadIdx.x] = (uint16_t)nibs;
+        // category_counts: the workgroup's histogram (64 slots x 8 replicas), as the counting K1
+        {
+            const uint32_t rep = lane & (XM_HREP - 1u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool unit = c[q] != XM_NO_UNIT;
+                if (__ballot(unit) == 0ull) continue;
+                if (unit) atomicAdd(&lds[(c[q] & 63u) * XM_HREP + rep], 1u);
+            }
+        }
+        __syncthreads();
+        if (wave == 0u) {
+            // lane = category slot: its count -> category_counts replica; folded into the granule's units per bin -> published
+            const uint4 h0 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP);
+            const uint4 h1 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP + 4);
+            const uint32_t sum = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
+            if (sum != 0u) {
+                g_add64(ps.counts_rep + (i % XM_COUNT_REPLICAS) * 64u + lane, (xm_u64)sum);
+                atomicAdd(&misc[16u + unit_bin<BINMODE, HAS6>(lane)], sum);      // a counted slot is never 0xFF: bin <= 6
+            }
+            lds_settle();
+            const uint32_t cnt = lane < 7u ? misc[16u + lane] : 0u;
+            place_publish<HAS6>(ps, i, cnt, epoch);
+        } else if (wave == 1u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(misc + 96 + lane * 4u);
+            uint4 *dst = reinterpret_cast<uint4 *>(ps.ring + (uint64_t)(i % XM_PLACE_RING) * (XM_GRAN / 4u)) + lane;
+            g_store64(reinterpret_cast<xm_u64 *>(dst), ((xm_u64)v.y << 32) | v.x);
+            g_store64(reinterpret_cast<xm_u64 *>(dst) + 1, ((xm_u64)v.w << 32) | v.z);
+        }
+    }
+    if (wave == 0u) XM_TRACE(4, wall_clock64());
+
+    // ---- this workgroup's share of the shared state is complete once its stores and atomics have been performed
+#ifndef XM_PLACE_DBG_NODONE
+    if (wave < 2u) vm_drain();
+    __syncthreads();
+    if (wave == 0u) {
+        const uint32_t n_wg = ps.n_gran + lag;
+        if (lane == 0u) (void)__hip_atomic_fetch_add(ps.done1 + (i % XM_PLACE_DONE_WORDS), 1u, XM_RLX_AGENT);
+        if (i + 1u == n_wg) {
+            // The last workgroup waits until every workgroup has arrived (all of them were dispatched before this one
+            // and none waits for it), then puts the workspace back into its between-calls state.
+            bool all_in = false;
+            for (uint32_t spins = 0; spins < (uint32_t)XM_PLACE_SPIN_LIMIT; ++spins) {
+                bool in = true;
+#pragma unroll
+                for (uint32_t q = 0; q < XM_PLACE_DONE_WORDS / 64u; ++q) {
+                    const uint32_t w = lane + 64u * q;
+                    const uint32_t expect = w < n_wg ? (n_wg - w + XM_PLACE_DONE_WORDS - 1u) / XM_PLACE_DONE_WORDS : 0u;
+                    in &= __hip_atomic_load(ps.done1 + w, XM_RLX_AGENT) == expect;
+                }
+                if (__ballot(!in) == 0ull) { all_in = true; break; }
+                __builtin_amdgcn_s_sleep(XM_PLACE_SLEEP);
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < XM_PLACE_DONE_WORDS / 64u; ++q) __hip_atomic_store(ps.done1 + lane + 64u * q, 0u, XM_RLX_AGENT);
+            if (!all_in && lane == 0u) {
+                __hip_atomic_store(ps.ctl + 2, 1u, XM_RLX_AGENT);
+                ps.n_out[7] = ~0ull;
+            }
+            place_finalize(ps, epoch);
+        }
+    }
+#endif
 }
 
+#ifndef XM_PLACE_WAVES_PER_EU
+#define XM_PLACE_WAVES_PER_EU 8
+#endif
 template <typename T, bool PAIRED, bool NT, int BLOCK, int BINMODE, bool WIDE>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(XM_PLACE_WAVES_PER_EU, XM_PLACE_WAVES_PER_EU)))
 classify_place_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
                       const T *__restrict__ as2, const T *__restrict__ xs2,
                       const uint8_t *__restrict__ unit_bits8, T m,
@@ -1211,7 +1245,7 @@ classify_place_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
     static_assert(BLOCK * 4 == XM_GRAN, "the placing workgroup is one granule");
     __shared__ uint32_t last_state[BLOCK / 64];
     __shared__ __attribute__((aligned(16))) uint32_t lds[XM_PLACE_LDS_WORDS];
-    for (uint32_t i = threadIdx.x; i < 64u * XM_HREP; i += BLOCK) lds[i] = 0;
+    for (uint32_t q = threadIdx.x; q < 64u * XM_HREP + 32u; q += BLOCK) lds[q] = 0;    // histogram + bin accumulators
     const uint32_t epoch = ps.ctl[0];                                    // written by the previous call's last workgroup
     if (threadIdx.x < 64u) XM_TRACE(0, wall_clock64());
     if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
@@ -1929,7 +1963,7 @@ static void launch_classify_place_t(hipStream_t st, int mode, uint64_t n,
                                     const T *as1, const T *xs1, const T *as2, const T *xs2,
                                     const uint64_t *unit_bits, T m, uint8_t *code, const PlaceSink &ps)
 {
-    const uint32_t grid = ps.n_gran;
+    const uint32_t grid = ps.n_gran + ps.lag;
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
 #define XM_LAUNCH_PLC(P, B, W) classify_place_kernel<T, P, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK, B, W><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n, ps)
