@@ -408,8 +408,6 @@ class Workload(object):
         return self.DESCR[self.name] % (self.n_pairs, self.mode_name)
 
     def kernel_name(self):
-        if self.place:
-            return "classify_place_kernel<%s, %s>" % (self.dtype, "single" if self.name == "se" else "paired")
         if self.cigp is not None:
             return "classify_cigp_kernel<paired, counts, bins4>"
         if self.cig is not None:
@@ -418,7 +416,7 @@ class Workload(object):
 
     def call_name(self):
         if self.place:
-            return "one xm_classify_place%s_dev call: ONE kernel (classify, count, look-back, place into six lists)" % ("_f64" if self.dtype == "f64" else "")
+            return "one xm_classify_place%s_dev call: classify+count, scan, scatter into six lists" % ("_f64" if self.dtype == "f64" else "")
         if self.unfused:
             return "A/B: xm_classify_dev + xm_compact_dev (classify, hist, scan, scatter)"
         return "one xm_classify_compact%s_dev call: classify+count, scan, scatter" % (
@@ -439,7 +437,8 @@ class Workload(object):
         bins4 = None if self.category_bytes else self.bins4
         if self.place:
             ctx.classify_place_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, self.lists[:6],
-                                   self.n_out, counts, list_state6=self.lists[6] if len(self.lists) > 6 else None)
+                                   self.n_out, counts, code_out=code, bins4=bins4,
+                                   list_state6=self.lists[6] if len(self.lists) > 6 else None)
         elif self.unfused:
             if self.cig is not None:
                 g = self.cig

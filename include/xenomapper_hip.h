@@ -152,12 +152,12 @@ int xm_classify_compact_cigar(xm_ctx *ctx, int mode, uint64_t n_records,
                               uint32_t *idx_out, uint64_t bin_offsets[8], uint64_t counts[64]);
 
 /*
- * The same main loop with the reference's own output shape -- six independent sinks (xenomapper.py:332-350, :423-448,
- * :521-550; SURVEY 8b (4): idx_out[6], n_out[6]) -- from ONE kernel (see xm_classify_place_dev below).  idx_out: six
- * host buffers of list_capacity entries each, one per output bin; list b receives the record indices of the units
- * routed to bin b in input order, n_out[b] its length (n_out[6] = units holding state 6, n_out[7] = all units).
- * idx_state6 (binary64 form; may be NULL) lists the units holding state 6.  A list longer than list_capacity is
- * truncated, n_out reports the full length.  code_out and counts may be NULL.
+ * The same main loop with the reference's own output shape: six independent sinks (the loops print into six file objects,
+ * xenomapper.py:332-350, :423-448, :521-550; SURVEY 8b (4): idx_out[6], n_out[6]).  idx_out: six host buffers of
+ * list_capacity entries each, one per output bin in the priority order above; list b receives the record indices of the
+ * units routed to bin b in input order, n_out[b] its length; n_out[6] = units holding state 6 (binary64 columns with NaN
+ * only; listed in idx_state6 when given), n_out[7] = all units.  A list longer than list_capacity is truncated, n_out
+ * reports the full length (the number of units never exceeds n_records).  code_out and counts may be NULL.
  */
 int xm_classify_place(xm_ctx *ctx, int mode, uint64_t n_records,
                       const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
@@ -221,9 +221,11 @@ int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *t
                           const double *density, double *out);
 
 /* bin_offsets: 8 device uint64; counts: 64 device uint64 (both overwritten).
- * The compaction workspace (per-granule counts and offsets, the count replicas) belongs to the context: ONE
- * xm_compact_dev / xm_classify_compact*_dev call may be in flight per context at a time -- issue them on one stream,
- * or order them with events; use one context per concurrent stream. */
+ * The compaction workspace (per-granule counts and offsets, the count replicas, the part totals) belongs to the context:
+ * ONE xm_compact_dev / xm_classify_compact*_dev / xm_classify_place*_dev call can be in flight per context at a time.
+ * Calls on one stream are ordered anyway; a call issued on another stream than the previous one is put behind
+ * everything enqueued on that stream so far by the library (an event); calls captured into graphs are ordered by the
+ * graph's own edges only.  For real concurrency use one context per stream. */
 int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, const uint8_t *code,
                    uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
 
@@ -302,44 +304,35 @@ int xm_classify_compact_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, ui
                                          uint32_t *range_flag, uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
 
 /*
- * One whole main loop in ONE kernel, with the reference's own output shape: six independent sinks
- * (xenomapper.py:332-350, :423-448, :521-550 print into six file objects; SURVEY 8b (4): idx_out[6], n_out[6]).
- * idx_out: host array of six DEVICE pointers, one list per output bin in the priority order above
- * (primary_specific, secondary_specific, primary_multi, secondary_multi, unresolved, unassigned), each with room for
- * list_capacity entries (the number of units never exceeds n_records).  List b receives the record index of every
- * unit routed to bin b, in input order; n_out (8 device uint64) receives the six list lengths, [6] = units holding
- * state 6 (binary64 columns with NaN only: listed in idx_state6 when given, counted otherwise) and [7] = all units.
- * A list that would overflow its capacity is truncated, n_out still reports its full length.  counts (64 device
- * uint64) = category_counts.  code_out (n_records category bytes as xm_classify_dev) may be NULL.
- * Because a unit's place depends only on its own bin, the kernel classifies, counts and places in one pass: the
- * categories never go through memory (no compact stream, no scan launch, no scatter launch).  Workgroups hand their
- * per-bin counts to the workgroups behind them through the context's workspace, so the one-in-flight rule applies; a
- * call on another stream than the previous one is ordered behind it by the library.  Should a workgroup ever give up
- * waiting (it cannot while the device dispatches workgroups in order), nothing is stored for it, n_out[7] reads
- * UINT64_MAX and xm_place_status() returns XM_ERR_HIP.
+ * The fused main loop with the six-list output contract of SURVEY 8b (4) (see xm_classify_place above) on device-resident
+ * columns: idx_out is a HOST array of six DEVICE pointers (4-byte aligned; 16-byte alignment lets the single-end form
+ * store 16 bytes at a time), each list with room for list_capacity entries; n_out = 8 device uint64 (six list lengths,
+ * units holding state 6, all units), counts = 64 device uint64.  code_out / bins4 as for xm_classify_compact_dev (at
+ * least one).  Same three launches and the same one-in-flight rule as xm_classify_compact_dev: the classify kernel
+ * counts per bin and granule, the scan gives every granule its place in each bin, and the scatter writes bin b's units
+ * to list b -- a unit's place no longer depends on the totals of the bins in front of its own.
+ * (A single-kernel form of this call -- classify and place in one pass behind a decoupled look-back -- was built and
+ * measured in round 4 and lost, 1.0-1.7 ms against 0.35 ms per 50 M pairs: DESIGN.md, profiles/r04_place_*.txt.)
  */
 int xm_classify_place_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
                           const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                          const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                          const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
                           uint32_t *const idx_out[6], uint64_t list_capacity, uint64_t *n_out, uint64_t *counts);
 
 int xm_classify_place_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
                               const double *as1, const double *xs1, const double *as2, const double *xs2,
-                              const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                              const uint64_t *unit_bits, double min_score, uint8_t *code_out, uint8_t *bins4,
                               uint32_t *const idx_out[6], uint32_t *idx_state6, uint64_t list_capacity,
                               uint64_t *n_out, uint64_t *counts);
 
-/* Synchronises the device and reports whether a placing kernel gave up since the last reset (XM_OK / XM_ERR_HIP);
- * reset != 0 puts the workspace back into its initial state. */
-int xm_place_status(xm_ctx *ctx, int reset);
-/* Test hook: sets the epoch counter the placing kernels tag their hand-off words with (non-zero; it wraps at 2^32). */
-int xm_place_debug_set_epoch(xm_ctx *ctx, uint32_t epoch);
-/* Test / tuning hook: the 16 control words of the placing kernels (epoch, arrival counter, gave-up flag, high-water mark;
- * words 4.. are poll statistics, filled only by builds with -DXM_PLACE_STATS). */
-int xm_place_debug_stats(xm_ctx *ctx, uint32_t out[16], int reset);
-/* Tuning hook (-DXM_PLACE_TRACE builds record; other builds leave the buffer zero): out == NULL allocates (n_granules > 0)
- * or frees (0) a device buffer of 8 words per granule; out != NULL copies the records of the last call out. */
-int xm_place_debug_trace(xm_ctx *ctx, uint64_t n_granules, uint64_t *out);
+int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                                       const int32_t *nm1, const uint8_t *cig_cnt1, const uint32_t *cig_tile1,
+                                       const uint32_t *cig_oplen1, const int32_t *xs1,
+                                       const int32_t *nm2, const uint8_t *cig_cnt2, const uint32_t *cig_tile2,
+                                       const uint32_t *cig_oplen2, const int32_t *xs2,
+                                       const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
+                                       uint32_t *range_flag, uint32_t *const idx_out[6], uint64_t list_capacity,
+                                       uint64_t *n_out, uint64_t *counts);
 
 /* ---- multi-GPU: the one collective of the path ------------------------------------------ */
 /*

@@ -541,6 +541,20 @@ def _check_packed_dev(ctx, mode, c1, xs1, c2, xs2, bits, mi, forms=("code", "bin
         h_off = off.cpu().numpy().astype(np.uint64)
         assert np.array_equal(h_off, want_off), form
         assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx), form
+    if n and n <= 2_000_000:
+        # the six-list form of the same call (xm_classify_place_cigar_packed_dev)
+        lists = [torch.full((n,), -1, dtype=torch.int32, device=dev) for _ in range(6)]
+        n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+        counts = torch.zeros(64, dtype=torch.int64, device=dev)
+        bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+        ctx.classify_place_cigar_packed_dev(mode, *d, mi, lists, n_out, counts, bins4=bins4)
+        torch.cuda.synchronize()
+        h_n = n_out.cpu().numpy()
+        for b in range(6):
+            w = want_idx[int(want_off[b]):int(want_off[b + 1])]
+            assert int(h_n[b]) == w.shape[0] and np.array_equal(lists[b][:w.shape[0]].cpu().numpy().view(np.uint32), w), b
+        assert int(h_n[7]) == int(want_off[7])
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 256, 257, 2047, 2048, 2049, 4097, 6145, 100_003])
@@ -920,6 +934,148 @@ def test_full_size_cfg5_zs_conservative(ctx):
         h_off = off.cpu().numpy().astype(np.uint64)
         assert np.array_equal(h_off, want_off)
         assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)
+        # the FUSED call on the same columns (what bench.py --workload cfg5 and the product run): compact stream only,
+        # then the six-list form of it
+        bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+        idx.zero_(); off.zero_(); counts.zero_()
+        ctx.classify_compact_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], m, None,
+                                 idx, off, counts, bins4=bins4)
+        torch.cuda.synchronize()
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+        assert np.array_equal(idx[:int(h_off[7])].cpu().numpy().view(np.uint32), want_idx)
+        lists = [torch.zeros(n_pairs, dtype=torch.int32, device=dev) for _ in range(6)]
+        n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+        counts.zero_()
+        ctx.classify_place_dev(mode, cols["as1"], cols["xs1"], cols["as2"], cols["xs2"], cols["unit_bits"], m, lists, n_out,
+                               counts, bins4=bins4)
+        torch.cuda.synchronize()
+        _check_lists(lists, n_out.cpu().numpy(), want_idx, want_off)
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+        del lists
+
+
+def _check_lists(lists, n_out, want_idx, want_off):
+    """Six (or seven) device lists + n_out[8] against the oracle's packed split."""
+    for b, lst in enumerate(lists):
+        want = want_idx[int(want_off[b]):int(want_off[b + 1])]
+        assert int(n_out[b]) == want.shape[0], (b, n_out.tolist(), want_off.tolist())
+        assert np.array_equal(lst[:want.shape[0]].cpu().numpy().view(np.uint32), want), b
+    assert int(n_out[7]) == int(want_off[7])
+    assert int(n_out[6]) == int(want_off[7] - want_off[6])
+
+
+def test_six_list_form_on_the_device_every_mode_and_layout(ctx):
+    """xm_classify_place_dev / _f64_dev (idx_out[6], n_out[6]) against the oracle: every loop, compact
+    stream and category bytes as the scatter's input, interleaved and irregular unit masks, single-end input with
+    staged granules, a state-6 list for binary64 columns, and lists too short for their bin (truncated, never
+    overrun: guard words behind every list)."""
+    import torch
+    from xenomapper_amd import _ffi
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(606)
+    for n, mode, p_unit in ((100_003, 0, 1.0), (100_003, 0, 0.8), (250_001, 1, None), (250_001, 2, 0.5), (6_000, 1, 0.3),
+                            (2_049, 2, None), (1, 0, 1.0), (5_000_000, 1, None)):
+        cols = random_columns(rng, n)
+        if p_unit is None:
+            bits = H.synth.interleaved_unit_bits(n)
+        else:
+            bits = H.synth.pack_unit_bits(rng.random(n) < p_unit)
+        want_code, want_counts = H.c_classify(mode, *cols, bits, -2)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        d_cols = [torch.from_numpy(c).to(dev) for c in cols]
+        d_bits = torch.from_numpy(bits.view(np.int64)).to(dev)
+        for form in ("bins4", "code"):
+            cap = n
+            guard = 0x7FFFFFF0
+            lists = [torch.full((cap + 8,), guard, dtype=torch.int32, device=dev) for _ in range(6)]
+            n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+            counts = torch.zeros(64, dtype=torch.int64, device=dev)
+            code = torch.empty(n + 16, dtype=torch.uint8, device=dev) if form == "code" else None
+            bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev) if form == "bins4" else None
+            ctx.classify_place_dev(mode, *d_cols, d_bits, -2, lists, n_out, counts, code_out=code, bins4=bins4, capacity=cap)
+            torch.cuda.synchronize()
+            _check_lists(lists, n_out.cpu().numpy(), want_idx, want_off)
+            assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+            for b, lst in enumerate(lists):
+                k = int(want_off[b + 1] - want_off[b])
+                assert bool((lst[k:] == guard).all()), (n, mode, form, b)
+        # lists shorter than their bins: truncated at the capacity, lengths still reported in full
+        cap = max(1, int((want_off[1] - want_off[0]) // 2))
+        lists = [torch.full((cap + 8,), 0x7FFFFFF0, dtype=torch.int32, device=dev) for _ in range(6)]
+        n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+        counts = torch.zeros(64, dtype=torch.int64, device=dev)
+        bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+        ctx.classify_place_dev(mode, *d_cols, d_bits, -2, lists, n_out, counts, bins4=bins4, capacity=cap)
+        torch.cuda.synchronize()
+        h_n = n_out.cpu().numpy()
+        for b, lst in enumerate(lists):
+            want = want_idx[int(want_off[b]):int(want_off[b + 1])]
+            assert int(h_n[b]) == want.shape[0]
+            k = min(cap, want.shape[0])
+            assert np.array_equal(lst[:k].cpu().numpy().view(np.uint32), want[:k])
+            assert bool((lst[cap:] == 0x7FFFFFF0).all()), (n, mode, b)
+    # binary64 columns with NaN: the seventh list
+    nan = float("nan")
+    n = 4099
+    f = [rng.integers(-5, 6, n).astype(np.float64) for _ in range(4)]
+    f[0][rng.random(n) < 0.1] = nan
+    f[2][rng.random(n) < 0.05] = nan
+    bits = H.synth.pack_unit_bits(rng.random(n) < 0.7)
+    for mode in (0, 1, 2):
+        want_code, want_counts = H.c_classify(mode, *f, bits, 0.5)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        assert want_off[7] > want_off[6]
+        d_cols = [torch.from_numpy(c).to(dev) for c in f]
+        d_bits = torch.from_numpy(bits.view(np.int64)).to(dev)
+        for with_list6 in (True, False):
+            lists = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(7)]
+            n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+            counts = torch.zeros(64, dtype=torch.int64, device=dev)
+            code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+            ctx.classify_place_dev(mode, *d_cols, d_bits, 0.5, lists[:6], n_out, counts, code_out=code,
+                                   list_state6=lists[6] if with_list6 else None)
+            torch.cuda.synchronize()
+            _check_lists(lists if with_list6 else lists[:6], n_out.cpu().numpy(), want_idx, want_off)
+            assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+            assert np.array_equal(code[:n].cpu().numpy(), want_code)
+
+
+def test_two_streams_on_one_context_are_ordered_by_the_library(ctx):
+    """The compaction workspace belongs to the context (include/xenomapper_hip.h): fused calls issued alternately on two
+    streams, without any synchronisation by the caller, must still give each call its own right answer -- the library puts
+    a call on another stream behind the previous one."""
+    import torch
+    from xenomapper_amd import _ffi
+    dev = torch.device("cuda:0")
+    n = 3_000_001
+    rng = np.random.default_rng(9090)
+    jobs = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for k in range(6):
+        cols = random_columns(rng, n - 1000 * k)
+        nk = cols[0].shape[0]
+        mode = k % 3
+        bits = H.synth.pack_unit_bits(rng.random(nk) < (0.9 if mode == 0 else 0.5))
+        d = dict(cols=cols, bits=bits, mode=mode, n=nk,
+                 d_cols=[torch.from_numpy(c).to(dev) for c in cols], d_bits=torch.from_numpy(bits.view(np.int64)).to(dev),
+                 bins4=torch.empty(_ffi.bins4_bytes(nk), dtype=torch.uint8, device=dev),
+                 idx=torch.zeros(nk, dtype=torch.int32, device=dev), off=torch.zeros(8, dtype=torch.int64, device=dev),
+                 counts=torch.zeros(64, dtype=torch.int64, device=dev))
+        jobs.append(d)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, d in enumerate(jobs):
+            st = streams[k % 2]
+            ctx.classify_compact_dev(d["mode"], *d["d_cols"], d["d_bits"], -1, None, d["idx"], d["off"], d["counts"],
+                                     bins4=d["bins4"], stream=st)
+    torch.cuda.synchronize()
+    for d in jobs:
+        want_code, want_counts = H.c_classify(d["mode"], *d["cols"], d["bits"], -1)
+        want_idx, want_off = H.c_compact(d["mode"], want_code)
+        assert np.array_equal(d["counts"].cpu().numpy().astype(np.uint64), want_counts)
+        assert np.array_equal(d["off"].cpu().numpy().astype(np.uint64), want_off)
+        assert np.array_equal(d["idx"][:int(want_off[7])].cpu().numpy().view(np.uint32), want_idx)
 
 
 def test_large_batch_64bit_offsets(ctx):

@@ -113,12 +113,9 @@ def lib():
         "xm_classify_compact_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P], I),
         "xm_classify_place": ([P, I, U64, P, P, P, P, P, I32, P, P, U64, P, P], I),
         "xm_classify_place_f64": ([P, I, U64, P, P, P, P, P, F64, P, P, P, U64, P, P], I),
-        "xm_classify_place_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, U64, P, P], I),
-        "xm_classify_place_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, U64, P, P], I),
-        "xm_place_status": ([P, I], I),
-        "xm_place_debug_set_epoch": ([P, ctypes.c_uint32], I),
-        "xm_place_debug_stats": ([P, P, I], I),
-        "xm_place_debug_trace": ([P, U64, P], I),
+        "xm_classify_place_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, U64, P, P], I),
+        "xm_classify_place_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P, U64, P, P], I),
+        "xm_classify_place_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, U64, P, P], I),
         "xm_comm_unique_id": ([P], I),
         "xm_comm_init": ([P, I, I, P], I),
         "xm_comm_destroy": ([P], I),
@@ -142,7 +139,8 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_compact", "xm_classify_compact", "xm_classify_compact_f64", "xm_classify_compact_cigar", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
             "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
             "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister",
-            "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev", "xm_place_status", "xm_place_debug_set_epoch", "xm_place_debug_stats", "xm_place_debug_trace",
+            "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev",
+            "xm_classify_place_cigar_packed_dev",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
@@ -360,7 +358,7 @@ class Context(object):
         return code, idx[:int(off[7])], off, counts
 
     def classify_place(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, want_code=True, capacity=None):
-        """One main loop in one kernel, six lists out (xm_classify_place / _f64).  -> (code or None, lists, n_out[8],
+        """One main loop, six lists out (xm_classify_place / _f64: SURVEY 8b (4)).  -> (code or None, lists, n_out[8],
         counts[64]); lists = six uint32 arrays (seven for float64 columns: the last holds the units with state 6)."""
         f64 = np.asarray(as1).dtype == np.float64
         cols = [_as(c, np.float64 if f64 else np.int32) for c in (as1, xs1, as2, xs2)]
@@ -485,10 +483,10 @@ class Context(object):
         self._check(rc, "xm_classify_compact_cigar_packed_dev")
 
     def classify_place_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, lists, n_out, counts, code_out=None,
-                           list_state6=None, capacity=None, stream=None):
-        """One whole main loop in ONE kernel: classify, count and place the unit indices into six
-        caller-allocated device lists (`lists`: six uint32 tensors, one per output bin).  n_out: 8 x int64/uint64 device
-        tensor (six list lengths, state-6 units, all units); counts: 64.  Columns int32 or float64.  Asynchronous."""
+                           bins4=None, list_state6=None, capacity=None, stream=None):
+        """The fused main loop with the six-list output contract: `lists` = six uint32 device tensors,
+        one per output bin; n_out: 8 x int64 device tensor (six list lengths, state-6 units, all units); counts: 64.
+        code_out and/or bins4 as for classify_compact_dev.  Columns int32 or float64.  Asynchronous."""
         n = as1.numel()
         st = self._stream_handle(stream)
         ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (as1, xs1, as2, xs2, unit_bits)]
@@ -497,31 +495,25 @@ class Context(object):
         arr = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in lists])
         opt = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None     # noqa: E731
         if as1.element_size() == 4:
-            rc = self._L.xm_classify_place_dev(self._h, st, mode, n, *ptrs, int(min_score), opt(code_out), arr, cap,
+            rc = self._L.xm_classify_place_dev(self._h, st, mode, n, *ptrs, int(min_score), opt(code_out), opt(bins4), arr, cap,
                                                opt(n_out), opt(counts))
         else:
-            rc = self._L.xm_classify_place_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), opt(code_out), arr,
+            rc = self._L.xm_classify_place_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), opt(code_out), opt(bins4), arr,
                                                    opt(list_state6), cap, opt(n_out), opt(counts))
         self._check(rc, "xm_classify_place_dev")
 
-    def place_status(self, reset=False):
-        self._check(self._L.xm_place_status(self._h, 1 if reset else 0), "xm_place_status")
-
-    def place_debug_stats(self, reset=False):
-        out = np.zeros(16, dtype=np.uint32)
-        self._check(self._L.xm_place_debug_stats(self._h, _np_ptr(out), 1 if reset else 0), "xm_place_debug_stats")
-        return out
-
-    def place_debug_trace(self, n_granules, fetch=False):
-        if not fetch:
-            self._check(self._L.xm_place_debug_trace(self._h, int(n_granules), None), "xm_place_debug_trace")
-            return None
-        out = np.zeros((int(n_granules), 8), dtype=np.uint64)
-        self._check(self._L.xm_place_debug_trace(self._h, int(n_granules), _np_ptr(out)), "xm_place_debug_trace")
-        return out
-
-    def place_debug_set_epoch(self, epoch):
-        self._check(self._L.xm_place_debug_set_epoch(self._h, int(epoch)), "xm_place_debug_set_epoch")
+    def classify_place_cigar_packed_dev(self, mode, nm1, cnt1, tile1, ops1, xs1, nm2, cnt2, tile2, ops2, xs2, unit_bits,
+                                        min_score_floor, lists, n_out, counts, code_out=None, bins4=None, range_flag=None,
+                                        capacity=None, stream=None):
+        """--cigar_scores loop on packed CIGAR columns with the six-list output contract."""
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (nm1, cnt1, tile1, ops1, xs1, nm2, cnt2, tile2, ops2, xs2, unit_bits)]
+        opt = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None     # noqa: E731
+        cap = min(t.numel() for t in lists) if capacity is None else int(capacity)
+        arr = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in lists])
+        rc = self._L.xm_classify_place_cigar_packed_dev(
+            self._h, self._stream_handle(stream), mode, nm1.numel(), *ptrs, int(min_score_floor), opt(code_out), opt(bins4),
+            opt(range_flag), arr, cap, opt(n_out), opt(counts))
+        self._check(rc, "xm_classify_place_cigar_packed_dev")
 
     # ---- the count all-reduce (RCCL inside the library) -----------------------------------
     def comm_init(self, n_ranks, rank, unique_id):

@@ -30,13 +30,6 @@ struct xm_ctx {
     uint32_t *d_gran_off;           // [8 bins][granule]: K2b's exclusive scan of the above
     uint64_t *d_counts_rep;         // XM_COUNT_REPLICAS x 64 partial category_counts (all zero between calls), then 8 bin totals
     uint32_t *d_part_tot;           // [8][XM_PART_STRIDE]: per-part bin totals (K2b's first level)
-    // workspace of the single-pass placing kernels (xm_classify_place*): look-back descriptors, block sums, prefix records,
-    // arrival counters, control words (xm_kernels.h: PlaceSink)
-    uint64_t *d_gdesc, *d_bsum, *d_bpre;
-    uint32_t *d_done1, *d_ctl;
-    uint16_t *d_ring;
-    uint64_t *d_trace;              // tuning only (xm_place_debug_trace)
-    uint64_t trace_gran;
     // the stream the workspace was last used on: a call on another stream is ordered behind it (order_workspace)
     hipStream_t ws_stream;
     bool ws_used;
@@ -142,15 +135,6 @@ int check_launch(xm_ctx *ctx, const char *what)
 
 const size_t COUNTS_REP_BYTES = (XM_COUNT_REPLICAS * 64 + 8) * sizeof(uint64_t);
 const size_t PART_TOT_BYTES = (size_t)XM_PART_REPLICAS * 8 * XM_PART_STRIDE * sizeof(uint32_t);
-const size_t GDESC_BYTES = (size_t)XM_PLACE_GD_WORDS * sizeof(uint64_t);
-const size_t BSUM_BYTES = (size_t)XM_PLACE_BS_WORDS * sizeof(uint64_t);
-const size_t BPRE_BYTES = (size_t)XM_PLACE_BP_WORDS * sizeof(uint64_t);
-const size_t DONE1_BYTES = (size_t)XM_PLACE_DONE_WORDS * sizeof(uint32_t);
-const size_t CTL_BYTES = 64;
-const size_t RING_BYTES = (size_t)XM_PLACE_RING * (XM_GRAN / 2);
-
-// the placing kernels' workspace in its between-calls state: everything zero, epoch 1
-int reset_place_state(xm_ctx *ctx, hipStream_t st);
 
 // a launch failed between counting and K2b: the count replicas may be non-zero -- clear them, so that the next call
 // starts from zero again
@@ -171,32 +155,20 @@ void reset_count_state(xm_ctx *ctx, hipStream_t st)
     (void)hipMemsetAsync(ctx->d_part_tot, 0, PART_TOT_BYTES, st);
 }
 
-int reset_place_state(xm_ctx *ctx, hipStream_t st)
-{
-    static const uint32_t ctl0[4] = {1u, 0u, 0u, 0u};
-    XM_HIP(ctx, hipMemsetAsync(ctx->d_gdesc, 0, GDESC_BYTES, st));
-    XM_HIP(ctx, hipMemsetAsync(ctx->d_bsum, 0, BSUM_BYTES, st));
-    XM_HIP(ctx, hipMemsetAsync(ctx->d_bpre, 0, BPRE_BYTES, st));
-    XM_HIP(ctx, hipMemsetAsync(ctx->d_done1, 0, DONE1_BYTES, st));
-    XM_HIP(ctx, hipMemsetAsync(ctx->d_ctl, 0, CTL_BYTES, st));
-    XM_HIP(ctx, hipMemcpyAsync(ctx->d_ctl, ctl0, sizeof ctl0, hipMemcpyHostToDevice, st));
-    XM_HIP(ctx, hipMemsetAsync(ctx->d_counts_rep, 0, COUNTS_REP_BYTES, st));
-    return XM_OK;
-}
-
-// The compaction / placing workspace belongs to the context: calls that use it must not overlap.  Calls on one stream
-// are ordered anyway; a call on ANOTHER stream than the previous one is put behind everything enqueued on that stream
-// so far (an event recorded there now, waited for here): no per-call cost while one stream is used.  A capturing stream
-// is left alone: the graph's own edges order its nodes, and events cannot be mixed into a capture from outside.
+// The compaction workspace (per-granule counts and offsets, the count replicas, the part totals) belongs to the context:
+// calls that use it must not overlap.  Calls on one stream are ordered anyway; a call on ANOTHER stream than the previous
+// one is put behind everything enqueued on that stream so far (an event recorded there now, waited for here): no per-call
+// cost while one stream is used.  A capturing stream is left alone: the graph's own edges order its nodes, and events
+// cannot be mixed into a capture from outside.
 int order_workspace(xm_ctx *ctx, hipStream_t st)
 {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return XM_OK;
-    (void)hipGetLastError();
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone) return XM_OK;
     if (ctx->ws_used && ctx->ws_stream != st) {
         hipStreamCaptureStatus ps = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(ctx->ws_stream, &ps) != hipSuccess || ps == hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
+        if (hipStreamIsCapturing(ctx->ws_stream, &ps) != hipSuccess) { (void)hipGetLastError(); ps = hipStreamCaptureStatusNone; }
+        if (ps == hipStreamCaptureStatusNone) {
             XM_HIP(ctx, hipEventRecord(ctx->ws_event, ctx->ws_stream));
             XM_HIP(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
         }
@@ -254,11 +226,6 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     ctx->d_gran_off = nullptr;
     ctx->d_counts_rep = nullptr;
     ctx->d_part_tot = nullptr;
-    ctx->d_gdesc = ctx->d_bsum = ctx->d_bpre = nullptr;
-    ctx->d_done1 = ctx->d_ctl = nullptr;
-    ctx->d_ring = nullptr;
-    ctx->d_trace = nullptr;
-    ctx->trace_gran = 0;
     ctx->ws_stream = nullptr;
     ctx->ws_used = false;
     ctx->ws_event = nullptr;
@@ -276,28 +243,13 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     if (e == hipSuccess) e = hipMemset(ctx->d_counts_rep, 0, COUNTS_REP_BYTES);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_part_tot, PART_TOT_BYTES);
     if (e == hipSuccess) e = hipMemset(ctx->d_part_tot, 0, PART_TOT_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_gdesc, GDESC_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bsum, BSUM_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_bpre, BPRE_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_done1, DONE1_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ctl, CTL_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ring, RING_BYTES);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming);
-    int rc0 = XM_OK;
-    if (e == hipSuccess && (rc0 = reset_place_state(ctx, nullptr)) == XM_OK) e = hipDeviceSynchronize();
-    if (e != hipSuccess || rc0 != XM_OK) {
-        const int rc = rc0 != XM_OK ? rc0 : fail_hip(nullptr, e, "xm_ctx_create: workspace");
-        if (rc0 != XM_OK) g_create_error = ctx->last_error;
+    if (e != hipSuccess) {
+        const int rc = fail_hip(nullptr, e, "xm_ctx_create: workspace");
         if (ctx->d_gran_counts) (void)hipFree(ctx->d_gran_counts);
         if (ctx->d_gran_off) (void)hipFree(ctx->d_gran_off);
         if (ctx->d_counts_rep) (void)hipFree(ctx->d_counts_rep);
         if (ctx->d_part_tot) (void)hipFree(ctx->d_part_tot);
-        if (ctx->d_gdesc) (void)hipFree(ctx->d_gdesc);
-        if (ctx->d_bsum) (void)hipFree(ctx->d_bsum);
-        if (ctx->d_bpre) (void)hipFree(ctx->d_bpre);
-        if (ctx->d_done1) (void)hipFree(ctx->d_done1);
-        if (ctx->d_ctl) (void)hipFree(ctx->d_ctl);
-        if (ctx->d_ring) (void)hipFree(ctx->d_ring);
         if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
         delete ctx;
         return rc;
@@ -320,13 +272,6 @@ int xm_ctx_destroy(xm_ctx *ctx)
     (void)hipFree(ctx->d_gran_off);
     (void)hipFree(ctx->d_counts_rep);
     (void)hipFree(ctx->d_part_tot);
-    (void)hipFree(ctx->d_gdesc);
-    (void)hipFree(ctx->d_bsum);
-    (void)hipFree(ctx->d_bpre);
-    (void)hipFree(ctx->d_done1);
-    (void)hipFree(ctx->d_ctl);
-    (void)hipFree(ctx->d_ring);
-    if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     (void)hipEventDestroy(ctx->ws_event);
     delete ctx;
     return XM_OK;
@@ -446,7 +391,7 @@ int xm_cigar_scores_dev(xm_ctx *ctx, void *stream, uint64_t n, const int32_t *nm
 /* K2b + K2c after the counting side (fused K1 or K2a) has filled gran_counts / counts_rep.  When a launch fails
  * with the replicas possibly non-zero, they are cleared again so that the next call starts from zero. */
 static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const uint8_t *code, const xm::CountPlan &cp,
-                        uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts)
+                        uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts, const xm::ListOut *lists = nullptr)
 {
     const bool from_bins4 = cp.bins4 != nullptr;          // a counting classify kernel left the compact stream: K2c reads that
     uint64_t *bin_totals = ctx->d_counts_rep + XM_COUNT_REPLICAS * 64;
@@ -462,7 +407,7 @@ static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const
     {
         Span span(ctx, st, XM_K_SCATTER);
         xm::launch_scatter(st, cp.plan, mode, n, from_bins4 ? cp.bins4 : code, from_bins4, cp.gran_counts, ctx->d_gran_off,
-                           bin_totals, bin_offsets, idx_out, ctx->d_part_tot);
+                           bin_totals, bin_offsets, idx_out, ctx->d_part_tot, lists);
     }
     if ((rc = check_launch(ctx, "scatter_kernel")) != XM_OK) reset_count_state(ctx, st);      // K2c zeroes the part totals
     return rc;
@@ -615,140 +560,105 @@ int xm_classify_compact_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, ui
     return compact_tail(ctx, st, mode, n, code_out, cp, idx_out, bin_offsets, counts);
 }
 
-/* ---- single pass: classify + place into six lists ------------------------------------------------ */
+/* ---- the six-list output contract: the same three launches, the scatter writes one list per bin -------- */
 
-static int place_sink(xm_ctx *ctx, uint64_t n, uint32_t *const idx_out[6], uint32_t *idx_state6, uint64_t list_capacity,
-                      uint64_t *n_out, uint64_t *counts, xm::PlaceSink &ps)
+static int list_out(uint32_t *const idx_out[6], uint32_t *idx_state6, uint64_t list_capacity, xm::ListOut &lo)
 {
+    if (!idx_out) return XM_ERR_INVALID_ARG;
     for (int b = 0; b < 6; ++b) {
         if (!idx_out[b] || ((uintptr_t)idx_out[b] & 3u)) return XM_ERR_INVALID_ARG;
-        ps.list[b] = idx_out[b];
+        lo.p[b] = idx_out[b];
     }
-    ps.list[6] = idx_state6;
-    ps.cap = list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)list_capacity;
-    ps.n_gran = xm::plan_granules(n).n_gran;
-    ps.lag = ps.n_gran < XM_PLACE_LAG ? ps.n_gran : XM_PLACE_LAG;
-    ps.ring = ctx->d_ring;
-    ps.gdesc = reinterpret_cast<unsigned long long *>(ctx->d_gdesc);
-    ps.bsum = reinterpret_cast<unsigned long long *>(ctx->d_bsum);
-    ps.bpre = reinterpret_cast<unsigned long long *>(ctx->d_bpre);
-    ps.done1 = ctx->d_done1;
-    ps.ctl = ctx->d_ctl;
-    ps.n_out = reinterpret_cast<unsigned long long *>(n_out);
-    ps.counts = reinterpret_cast<unsigned long long *>(counts);
-    ps.counts_rep = reinterpret_cast<unsigned long long *>(ctx->d_counts_rep);
-    ps.trace = (ctx->d_trace && (uint64_t)ps.n_gran + ps.lag <= ctx->trace_gran) ? reinterpret_cast<unsigned long long *>(ctx->d_trace) : nullptr;
-    return XM_OK;
-}
-
-static int empty_place(xm_ctx *ctx, hipStream_t st, uint64_t *n_out, uint64_t *counts)
-{
-    XM_HIP(ctx, hipMemsetAsync(counts, 0, 64 * sizeof(uint64_t), st));
-    XM_HIP(ctx, hipMemsetAsync(n_out, 0, 8 * sizeof(uint64_t), st));
+    if ((uintptr_t)idx_state6 & 3u) return XM_ERR_INVALID_ARG;
+    lo.p[6] = idx_state6;
+    lo.cap = list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)list_capacity;
     return XM_OK;
 }
 
 int xm_classify_place_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                           const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                          const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out,
+                          const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
                           uint32_t *const idx_out[6], uint64_t list_capacity, uint64_t *n_out, uint64_t *counts)
 {
     if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
-    if (!n_out || !counts || !idx_out) return XM_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (n == 0) return empty_place(ctx, st, n_out, counts);
-    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits) return XM_ERR_INVALID_ARG;
-    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 15u) || ((uintptr_t)code_out & 3u))
-        return XM_ERR_INVALID_ARG;
-    xm::PlaceSink ps;
+    if (!n_out || !counts) return XM_ERR_INVALID_ARG;
+    xm::ListOut lo;
     int rc;
-    if ((rc = place_sink(ctx, n, idx_out, nullptr, list_capacity, n_out, counts, ps)) != XM_OK) return rc;
+    if ((rc = list_out(idx_out, nullptr, list_capacity, lo)) != XM_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return empty_compact(ctx, st, n_out, counts);
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || (!code_out && !bins4)) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2 | (uintptr_t)code_out | (uintptr_t)bins4) & 15u))
+        return XM_ERR_INVALID_ARG;
+    xm::CountPlan cp = count_plan(ctx, n);
+    cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_place_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, ps);
+        xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &cp);
     }
-    if ((rc = check_launch(ctx, "classify_place_kernel<int32>")) != XM_OK) (void)reset_place_state(ctx, st);
-    return rc;
+    if ((rc = check_launch(ctx, "classify_kernel<int32, counts>")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
 }
 
 int xm_classify_place_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                               const double *as1, const double *xs1, const double *as2, const double *xs2,
-                              const uint64_t *unit_bits, double min_score, uint8_t *code_out,
+                              const uint64_t *unit_bits, double min_score, uint8_t *code_out, uint8_t *bins4,
                               uint32_t *const idx_out[6], uint32_t *idx_state6, uint64_t list_capacity,
                               uint64_t *n_out, uint64_t *counts)
 {
     if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
-    if (!n_out || !counts || !idx_out) return XM_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (n == 0) return empty_place(ctx, st, n_out, counts);
-    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits) return XM_ERR_INVALID_ARG;
-    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || (((uintptr_t)code_out | (uintptr_t)idx_state6) & 3u))
-        return XM_ERR_INVALID_ARG;
-    xm::PlaceSink ps;
+    if (!n_out || !counts) return XM_ERR_INVALID_ARG;
+    xm::ListOut lo;
     int rc;
-    if ((rc = place_sink(ctx, n, idx_out, idx_state6, list_capacity, n_out, counts, ps)) != XM_OK) return rc;
+    if ((rc = list_out(idx_out, idx_state6, list_capacity, lo)) != XM_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return empty_compact(ctx, st, n_out, counts);
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || (!code_out && !bins4)) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & 31u) || (((uintptr_t)code_out | (uintptr_t)bins4) & 15u))
+        return XM_ERR_INVALID_ARG;
+    xm::CountPlan cp = count_plan(ctx, n);
+    cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
     {
         Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_place_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, ps);
+        xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &cp);
     }
-    if ((rc = check_launch(ctx, "classify_place_kernel<f64>")) != XM_OK) (void)reset_place_state(ctx, st);
-    return rc;
+    if ((rc = check_launch(ctx, "classify_kernel<f64, counts>")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
 }
 
-int xm_place_status(xm_ctx *ctx, int reset)
+int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                                       const int32_t *nm1, const uint8_t *cnt1, const uint32_t *tile1, const uint32_t *ops1,
+                                       const int32_t *xs1,
+                                       const int32_t *nm2, const uint8_t *cnt2, const uint32_t *tile2, const uint32_t *ops2,
+                                       const int32_t *xs2,
+                                       const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
+                                       uint32_t *range_flag, uint32_t *const idx_out[6], uint64_t list_capacity,
+                                       uint64_t *n_out, uint64_t *counts)
 {
-    if (!ctx) return XM_ERR_INVALID_ARG;
-    XM_HIP(ctx, hipSetDevice(ctx->device));
-    uint32_t ctl[4] = {0, 0, 0, 0};
-    XM_HIP(ctx, hipMemcpy(ctl, ctx->d_ctl, sizeof ctl, hipMemcpyDeviceToHost));
-    if (ctl[2] == 0) return XM_OK;
-    ctx->last_error = "classify_place_kernel: a workgroup gave up waiting for the workgroups in front of it";
-    if (reset) {
-        const int rc = reset_place_state(ctx, nullptr);
-        if (rc != XM_OK) return rc;
-        XM_HIP(ctx, hipDeviceSynchronize());
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    if (!n_out || !counts) return XM_ERR_INVALID_ARG;
+    xm::ListOut lo;
+    int rc;
+    if ((rc = list_out(idx_out, nullptr, list_capacity, lo)) != XM_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return empty_compact(ctx, st, n_out, counts);
+    if (!nm1 || !cnt1 || !tile1 || !ops1 || !xs1 || !nm2 || !cnt2 || !tile2 || !ops2 || !xs2 || !unit_bits || (!code_out && !bins4))
+        return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)nm1 | (uintptr_t)xs1 | (uintptr_t)nm2 | (uintptr_t)xs2 | (uintptr_t)code_out | (uintptr_t)bins4) & 15u) ||
+        (((uintptr_t)cnt1 | (uintptr_t)cnt2 | (uintptr_t)tile1 | (uintptr_t)tile2 | (uintptr_t)ops1 | (uintptr_t)ops2) & 3u))
+        return XM_ERR_INVALID_ARG;
+    xm::CountPlan cp = count_plan(ctx, n);
+    cp.bins4 = bins4;
+    const xm::CigCols s1 = {nm1, xs1, cnt1, tile1, ops1}, s2 = {nm2, xs2, cnt2, tile2, ops2};
+    if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    {
+        Span span(ctx, st, XM_K_CLASSIFY);
+        xm::launch_classify_cigp(st, mode, n, s1, s2, unit_bits, min_score_floor, code_out, range_flag, cp);
     }
-    return XM_ERR_HIP;
-}
-
-int xm_place_debug_stats(xm_ctx *ctx, uint32_t out[16], int reset)
-{
-    if (!ctx || !out) return XM_ERR_INVALID_ARG;
-    XM_HIP(ctx, hipSetDevice(ctx->device));
-    XM_HIP(ctx, hipDeviceSynchronize());
-    XM_HIP(ctx, hipMemcpy(out, ctx->d_ctl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (reset) XM_HIP(ctx, hipMemset(ctx->d_ctl + 4, 0, 12 * sizeof(uint32_t)));
-    return XM_OK;
-}
-
-int xm_place_debug_trace(xm_ctx *ctx, uint64_t n_granules, uint64_t *out)
-{
-    if (!ctx) return XM_ERR_INVALID_ARG;
-    XM_HIP(ctx, hipSetDevice(ctx->device));
-    XM_HIP(ctx, hipDeviceSynchronize());
-    if (out && ctx->d_trace) {
-        const uint64_t k = n_granules < ctx->trace_gran ? n_granules : ctx->trace_gran;
-        XM_HIP(ctx, hipMemcpy(out, ctx->d_trace, (size_t)k * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        return XM_OK;
-    }
-    if (ctx->d_trace) { (void)hipFree(ctx->d_trace); ctx->d_trace = nullptr; ctx->trace_gran = 0; }
-    if (n_granules) {
-        XM_HIP(ctx, hipMalloc((void **)&ctx->d_trace, (size_t)n_granules * 8 * sizeof(uint64_t)));
-        XM_HIP(ctx, hipMemset(ctx->d_trace, 0, (size_t)n_granules * 8 * sizeof(uint64_t)));
-        ctx->trace_gran = n_granules;
-    }
-    return XM_OK;
-}
-
-int xm_place_debug_set_epoch(xm_ctx *ctx, uint32_t epoch)
-{
-    if (!ctx || epoch == 0) return XM_ERR_INVALID_ARG;
-    XM_HIP(ctx, hipSetDevice(ctx->device));
-    XM_HIP(ctx, hipDeviceSynchronize());
-    XM_HIP(ctx, hipMemcpy(ctx->d_ctl, &epoch, sizeof epoch, hipMemcpyHostToDevice));
-    return XM_OK;
+    if ((rc = check_launch(ctx, "classify_cigp_kernel")) != XM_OK) return rc;
+    return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
 }
 
 int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,
@@ -1098,7 +1008,7 @@ int xm_classify_compact_f64(xm_ctx *ctx, int mode, uint64_t n,
 }
 
 
-/* ---- host-buffer form of the single pass: columns up, one kernel, six lists down ------------------------------ */
+/* ---- host-buffer form of the six-list contract: columns up, the fused pass, six lists down ------------------------- */
 
 static int classify_place_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const void *as1, const void *xs1,
                                const void *as2, const void *xs2, const uint64_t *unit_bits, int32_t mi, double mf,
@@ -1108,10 +1018,10 @@ static int classify_place_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, c
     if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || !n_out || !idx_out) return XM_ERR_INVALID_ARG;
     memset(n_out, 0, 8 * sizeof(uint64_t));
     if (counts) memset(counts, 0, 64 * sizeof(uint64_t));
-    if (n == 0) return XM_OK;
-    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits) return XM_ERR_INVALID_ARG;
     for (int b = 0; b < 6; ++b)
         if (!idx_out[b]) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits) return XM_ERR_INVALID_ARG;
     XM_HIP(ctx, hipSetDevice(ctx->device));
     const size_t col_bytes = (size_t)n * elem;
     const size_t bits_bytes = (size_t)((n + 63) / 64) * 8;
@@ -1123,7 +1033,7 @@ static int classify_place_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, c
     }
     if ((rc = ensure_scratch(ctx, 4, bits_bytes)) != XM_OK) return rc;
     XM_HIP(ctx, hipMemcpy(ctx->d_scratch[4], unit_bits, bits_bytes, hipMemcpyHostToDevice));
-    if (code_out && (rc = ensure_scratch(ctx, 5, (size_t)n + 16)) != XM_OK) return rc;
+    if ((rc = ensure_scratch(ctx, 5, code_out ? (size_t)n + 16 : (size_t)XM_BINS4_BYTES(n))) != XM_OK) return rc;
     // seven device lists (the seventh only for binary64 columns), each with room for min(capacity, n) entries
     const uint64_t cap = list_capacity < n ? list_capacity : n;
     const size_t pitch = (((size_t)cap * 4) + 255) & ~(size_t)255;
@@ -1131,21 +1041,21 @@ static int classify_place_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, c
     if ((rc = ensure_scratch(ctx, 6, pitch * n_lists + 256)) != XM_OK) return rc;
     if ((rc = ensure_scratch(ctx, 7, 72 * sizeof(uint64_t))) != XM_OK) return rc;
     uint8_t *d_code = code_out ? (uint8_t *)ctx->d_scratch[5] : nullptr;
+    uint8_t *d_bins4 = code_out ? nullptr : (uint8_t *)ctx->d_scratch[5];
     uint32_t *d_list[7];
     for (int b = 0; b < 7; ++b) d_list[b] = b < n_lists ? (uint32_t *)((uint8_t *)ctx->d_scratch[6] + pitch * b) : nullptr;
     uint64_t *d_out = (uint64_t *)ctx->d_scratch[7];
     if (elem == 4)
         rc = xm_classify_place_dev(ctx, nullptr, mode, n, (const int32_t *)ctx->d_scratch[0], (const int32_t *)ctx->d_scratch[1],
                                    (const int32_t *)ctx->d_scratch[2], (const int32_t *)ctx->d_scratch[3],
-                                   (const uint64_t *)ctx->d_scratch[4], mi, d_code, d_list, cap, d_out, d_out + 8);
+                                   (const uint64_t *)ctx->d_scratch[4], mi, d_code, d_bins4, d_list, cap, d_out, d_out + 8);
     else
         rc = xm_classify_place_f64_dev(ctx, nullptr, mode, n, (const double *)ctx->d_scratch[0], (const double *)ctx->d_scratch[1],
                                        (const double *)ctx->d_scratch[2], (const double *)ctx->d_scratch[3],
-                                       (const uint64_t *)ctx->d_scratch[4], mf, d_code, d_list, d_list[6], cap, d_out, d_out + 8);
+                                       (const uint64_t *)ctx->d_scratch[4], mf, d_code, d_bins4, d_list, d_list[6], cap, d_out, d_out + 8);
     if (rc != XM_OK) return rc;
     uint64_t host[72];
     XM_HIP(ctx, hipMemcpy(host, d_out, sizeof host, hipMemcpyDeviceToHost));
-    if (host[7] == ~0ull) return xm_place_status(ctx, 1);
     memcpy(n_out, host, 8 * sizeof(uint64_t));
     if (counts) memcpy(counts, host + 8, 64 * sizeof(uint64_t));
     for (int b = 0; b < n_lists; ++b) {

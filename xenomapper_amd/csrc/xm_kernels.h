@@ -46,71 +46,11 @@ struct CigCols {
     const uint32_t *ops;        // BAM-style len << 4 | op
 };
 
-// ---- single-pass classify + place (xm_classify_place*) ---------------------------------------------------------
-#define XM_PLACE_S 32u          // granules per block of the look-back (block sums carry an arrival count up to this)
-#define XM_PLACE_WIN 24u        // blocks of look-back window
-#define XM_PLACE_PROBES 6u      // prefix records inside the window (every 4th block publishes one)
-#ifndef XM_PLACE_SPIN_LIMIT
-#define XM_PLACE_SPIN_LIMIT (1u << 17)   // polls before a workgroup gives up (each is a memory round trip: >= 0.1 s)
-#endif
-#define XM_PLACE_BLOCKS(n_gran) (((uint64_t)(n_gran) + XM_PLACE_S - 1u) / XM_PLACE_S)
-// Where the hand-off records live.  Everything a workgroup reads in one look-back comes from different rows, the rows far
-// apart and not a power of two apart, so that the polls of the ~800 resident workgroups spread over the memory channels
-// instead of queueing on the few lines a contiguous window would occupy (XM_PLACE_SPREAD=0: contiguous, for A/B runs).
-#ifndef XM_PLACE_SPREAD
-#define XM_PLACE_SPREAD 1
-#endif
-#define XM_PLACE_GD_ROWS 64u
-#define XM_PLACE_GD_PITCH ((XM_MAX_GRANULES + 64u) / XM_PLACE_GD_ROWS + 9u)                       // entries of 4 words
-#define XM_PLACE_BS_ROWS 32u
-#define XM_PLACE_BS_PITCH (((uint32_t)XM_PLACE_BLOCKS(XM_MAX_GRANULES) + 64u) / XM_PLACE_BS_ROWS + 9u)   // entries of 4 words
-#define XM_PLACE_BP_ROWS 8u
-#define XM_PLACE_BP_PITCH (((uint32_t)XM_PLACE_BLOCKS(XM_MAX_GRANULES) / 4u + 64u) / XM_PLACE_BP_ROWS + 5u)  // entries of 8 words
-#if XM_PLACE_SPREAD
-#define XM_PLACE_GD_AT(g) ((uint64_t)(((g) % XM_PLACE_GD_ROWS) * (uint64_t)XM_PLACE_GD_PITCH + (g) / XM_PLACE_GD_ROWS) * 4u)
-#define XM_PLACE_BS_AT(b) ((uint64_t)(((b) % XM_PLACE_BS_ROWS) * (uint64_t)XM_PLACE_BS_PITCH + (b) / XM_PLACE_BS_ROWS) * 4u)
-#define XM_PLACE_BP_AT(q) ((uint64_t)(((q) % XM_PLACE_BP_ROWS) * (uint64_t)XM_PLACE_BP_PITCH + (q) / XM_PLACE_BP_ROWS) * 8u)
-#else
-#define XM_PLACE_GD_AT(g) ((uint64_t)(g) * 4u)
-#define XM_PLACE_BS_AT(b) ((uint64_t)(b) * 4u)
-#define XM_PLACE_BP_AT(q) ((uint64_t)(q) * 8u)
-#endif
-#define XM_PLACE_GD_WORDS ((uint64_t)XM_PLACE_GD_ROWS * XM_PLACE_GD_PITCH * 4u)
-#define XM_PLACE_BS_WORDS ((uint64_t)XM_PLACE_BS_ROWS * XM_PLACE_BS_PITCH * 4u)
-#define XM_PLACE_BP_WORDS ((uint64_t)XM_PLACE_BP_ROWS * XM_PLACE_BP_PITCH * 8u)
-#define XM_PLACE_RING 8192u        // granules of the bins ring (1 KB each): > lag + twice the resident workgroups
-#ifndef XM_PLACE_LAG
-#define XM_PLACE_LAG 2560u         // workgroup i places granule i - lag: ~15 us of arrivals at 50 M pairs per 0.3 ms
-#endif
-#define XM_PLACE_DONE_WORDS 256u   // arrival counters of finished workgroups: workgroup g adds to word g % 256
-#ifndef XM_PLACE_SLEEP
-#define XM_PLACE_SLEEP 4           // s_sleep argument between two polls (x 64 clocks)
-#endif
-
-// workspace + outputs of the placing kernels (passed by value)
-struct PlaceSink {
-    uint32_t *list[7];                 // the six bin lists, [6] = units holding state 6 (binary64 only; may be null)
-    uint32_t cap;                      // capacity of every list, in entries
-    uint32_t n_gran;
-    uint32_t lag;                      // min(XM_PLACE_LAG, n_gran); the grid is n_gran + lag workgroups
-    uint16_t *ring;                    // [XM_PLACE_RING][XM_GRAN / 4]: the bins of the granules in flight, a nibble per record
-    unsigned long long *gdesc;         // [granule][4]   {epoch, 2 x 16-bit counts}
-    unsigned long long *bsum;          // [block][4]     {arrivals, 2 x 24-bit sums}, all zero between calls
-    unsigned long long *bpre;          // [block / 4][8] {epoch, inclusive prefix}
-    uint32_t *done1;                   // [XM_PLACE_DONE_WORDS] workgroups that have finished (word g % 256), all zero between calls
-    uint32_t *ctl;                     // [0] epoch  [2] a workgroup gave up (sticky)  [3] high-water granule count
-    unsigned long long *n_out;         // [8]: list lengths 0..5, [6] units holding state 6, [7] all units (~0: gave up)
-    unsigned long long *counts;        // [64] category_counts
-    unsigned long long *counts_rep;    // [XM_COUNT_REPLICAS][64], all zero between calls
-    unsigned long long *trace;         // tuning builds (-DXM_PLACE_TRACE): [granule][8] timestamps (100 MHz) and poll data; else unused
+// the six-list output contract of the scatter (xm_classify_place*): one caller-allocated list per output bin
+struct ListOut {
+    uint32_t *p[7];             // lists of bins 0..5; [6] = units holding state 6 (binary64 columns only; may be null)
+    uint32_t cap;               // capacity of every list, in entries
 };
-
-void launch_classify_place_i32(hipStream_t st, int mode, uint64_t n,
-                               const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                               const uint64_t *unit_bits, int32_t m, uint8_t *code, const PlaceSink &ps);
-void launch_classify_place_f64(hipStream_t st, int mode, uint64_t n,
-                               const double *as1, const double *xs1, const double *as2, const double *xs2,
-                               const uint64_t *unit_bits, double m, uint8_t *code, const PlaceSink &ps);
 
 // cp != nullptr: the fused form, the kernel also counts (granule = its workgroup)
 void launch_classify_i32(hipStream_t st, int mode, uint64_t n,
@@ -132,7 +72,7 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
 // also zeroes the part totals K2b has consumed
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_counts, const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets,
-                    uint32_t *idx_out, uint32_t *part_tot);
+                    uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists = nullptr);
 void launch_mate_correlate(hipStream_t st, uint64_t n, const double *track, uint32_t m, const double *density, double *out);
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,
                   const uint32_t *cig_oplen, int32_t *as_out, uint32_t *range_flag);

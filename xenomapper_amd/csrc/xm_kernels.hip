@@ -604,6 +604,40 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], const uint32_
         }
 }
 
+// The same for the six-list output contract (xm_classify_place*, SURVEY 8b (4): the reference's six independent sinks,
+// xenomapper.py:332-350, :423-448, :521-550): bin b's units go to their own caller-allocated list lo.p[b], so base[b] counts
+// from the start of that list and the stores sit inside the bin loop, where the list pointer is uniform.
+template <int SLOTS, bool WIDE>
+__device__ __forceinline__ void scatter_256_lists(const uint32_t bin[4], const uint32_t rec[4], uint32_t base[7], const ListOut &lo)
+{
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        uint64_t m[4], any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = ((SLOTS >> j) & 1) ? __ballot(bin[j] == (uint32_t)b) : 0ull;
+            any |= m[j];
+        }
+        if (any == 0ull) continue;              // wave-uniform: bin b does not occur here
+        uint32_t t = base[b], total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((SLOTS >> j) & 1) { t = mbcnt64(m[j], t); total += (uint32_t)__builtin_popcountll(m[j]); }
+        base[b] += total;
+        uint32_t *__restrict__ list = lo.p[b];
+        if (list == nullptr) continue;          // uniform: the optional list of the units holding state 6
+        uint32_t r = 0;                         // units of bin b earlier in this lane
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((SLOTS >> j) & 1) {
+                const bool mine = bin[j] == (uint32_t)b;
+                const uint32_t p = t + r;
+                if (mine && (!XM_SCATTER_GUARD || p < lo.cap)) store_index<WIDE>(list, p, rec[j]);
+                r += mine ? 1u : 0u;
+            }
+    }
+}
+
 // XM_SCATTER_STAGED (0 in a tuning build: every unit's index goes to idx_out with its own dword store): where a granule
 // holds XM_STAGE_MIN_UNITS units or more, they are first sorted by bin inside a wave-private LDS slab (16-bit record numbers), then every bin's run is copied
 // to its place in idx_out with 16-byte stores from 16-byte-aligned places.  Why: dword stores top out at 4.2 TB/s on
@@ -657,9 +691,9 @@ __device__ __forceinline__ void scatter_copy_out(const uint16_t *slab, uint32_t 
 // per lane and 256 records, no table); otherwise as category bytes (one dword per lane and 256 records, the
 // byte -> bin rule of the mode in a 64-entry wave-private LDS table).
 // the wave's granule, 256 records at a time: ranks by ballots, indices straight to idx_out or (STAGED) into the slab
-template <int NSUB, bool WIDE, bool NIB, bool STAGED>
+template <int NSUB, bool WIDE, bool NIB, bool STAGED, bool LISTS>
 __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const uint8_t *lut, uint32_t rec_g, uint32_t base[7],
-                                                uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab)
+                                                uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab, const ListOut &lo)
 {
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
@@ -678,7 +712,8 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
         const uint32_t rec[4] = {rec0, rec0 + 1u, rec0 + 2u, rec0 + 3u};
         if (__ballot(!even_free) == 0ull) {                               // strictly interleaved mates: positions 1 and 3 only
             if (!NIB) { bin[0] = bin[2] = 7u; bin[1] = lut[(w[s] >> 8) & 63u]; bin[3] = lut[(w[s] >> 24) & 63u]; }
-            scatter_256<0xA, WIDE, STAGED>(bin, rec, base, idx_out, limit, slab);
+            if (LISTS && !STAGED) scatter_256_lists<0xA, WIDE>(bin, rec, base, lo);
+            else scatter_256<0xA, WIDE, STAGED>(bin, rec, base, idx_out, limit, slab);
             continue;
         }
         if (!NIB) {
@@ -712,7 +747,10 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
                 }
             }
             const uint32_t vrec[4] = {rec0 + j0, rec0 + j1, 0u, 0u};
-            scatter_256<0x3, WIDE, STAGED>(vb, vrec, base, idx_out, limit, slab);
+            if (LISTS) scatter_256_lists<0x3, WIDE>(vb, vrec, base, lo);
+            else scatter_256<0x3, WIDE, STAGED>(vb, vrec, base, idx_out, limit, slab);
+        } else if (LISTS && !STAGED) {
+            scatter_256_lists<0xF, WIDE>(bin, rec, base, lo);
         } else {
             scatter_256<0xF, WIDE, STAGED>(bin, rec, base, idx_out, limit, slab);
         }
@@ -722,12 +760,15 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
 // STAGE: this launch may stage (the single-end loop, where every record can be a unit; the paired loops, whose granules
 // hold half as many units at most in ordinary input, use the instantiation without the slab and its bookkeeping, which
 // costs them 2 us per 50 M pairs)
-template <int NSUB, bool WIDE, bool NIB, bool STAGE>
+// LISTS: the six-list output contract -- bin b's units go to lo.p[b] (positions count from the start of that list, so the
+// totals of the bins in front are not needed), bin_offsets receives the list lengths ([7] = all units).
+template <int NSUB, bool WIDE, bool NIB, bool STAGE, bool LISTS>
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
                const uint32_t *__restrict__ gran_counts, const uint32_t *__restrict__ gran_off,
                const unsigned long long *__restrict__ bin_totals,
-               unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ part_tot)
+               unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ part_tot,
+               const ListOut lo)
 {
     constexpr bool CAN_STAGE = STAGE && XM_SCATTER_STAGED != 0 && NSUB * 256 == XM_GRAN;
     __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
@@ -751,9 +792,9 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
         const uint32_t tot = (lane < 8u) ? (uint32_t)bin_totals[lane] : 0u;
         const uint32_t off = (lane < 7u) ? gran_off[(uint64_t)lane * gran_stride + g] : 0u;
         const uint32_t bin_start = wave_scan_incl(tot) - tot;
-        lane_base = bin_start + off;
-        n_units = lane_value(bin_start, 7);                               // slot 7 counts nothing: the total
-        if (g == 0u && lane < 8u) bin_offsets[lane] = bin_start;
+        lane_base = LISTS ? off : bin_start + off;
+        n_units = LISTS ? lo.cap : lane_value(bin_start, 7);              // slot 7 counts nothing: the total
+        if (g == 0u && lane < 8u) bin_offsets[lane] = (LISTS && lane < 7u) ? tot : bin_start;
     }
     // Staging pays where a granule holds many units (single-end input: 2048 of them; 117 against 166 us per 100 M reads)
     // and costs where it holds few (strictly interleaved mates, 1024: 62 against 55 us): decided per launch (STAGE) and
@@ -794,464 +835,18 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
     }
     if (!NIB) lds_settle();
     if (CAN_STAGE && staged) {
-        scatter_granule<NSUB, WIDE, NIB, true>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab);
+        scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lo);
         lds_settle();                                                     // the wave's slab is complete
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
             const uint32_t N = lane_value(run_len, b);
-            if (N == 0u) continue;                                        // wave-uniform
-            scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, idx_out);
+            uint32_t *__restrict__ dst = LISTS ? lo.p[b] : idx_out;
+            if (N == 0u || dst == nullptr) continue;                      // wave-uniform
+            scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, dst);
         }
     } else {
-        scatter_granule<NSUB, WIDE, NIB, false>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab);
+        scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lo);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1s: classify AND place in one pass (xm_classify_place*).  Output contract of SURVEY 8b (4): six caller-allocated
-// lists, one per output bin -- the reference's six independent sinks (xenomapper.py:332-350, :423-448, :521-550) -- so a
-// unit's place depends only on the units of ITS bin in front of it, never on the totals of other bins; no category
-// stream goes through memory, no scan launch, no scatter launch.
-//
-// A workgroup = one granule of XM_GRAN records, as in the counting K1.  Inside the workgroup: ranks by ballot + mbcnt
-// per 256-record wave tile (K2c's scheme, on the bins still in registers), wave counts through LDS.  Across workgroups:
-// a two-level decoupled look-back.
-//   gdesc[g]   the granule's units per bin, 16 bits each, in 8-byte {epoch, data} words (sc1 stores; the data is the flag)
-//   bsum[B]    the same summed over block B = XM_PLACE_S consecutive granules, by 64-bit atomic adds that carry an
-//              arrival count in the same word: complete when the count reads XM_PLACE_S (zero between calls)
-//   bpre[B/4]  inclusive prefix per bin behind block B, B = 3 mod 4, {epoch, value} words, published by the workgroup of
-//              the block's last granule once it knows its own prefix
-// Wave 0 of granule g = (B, k) publishes gdesc and adds to bsum as soon as the workgroup's counts are known, then reads,
-// all at once: the k descriptors in front of it in its block (lanes 0-30), the sums of the 24 blocks before B (lanes
-// 32-55) and the six prefix records inside that window (lanes 56-61); its prefix = the nearest published prefix + the
-// complete block sums between + its in-block descriptors.  Nothing in that chain waits for another workgroup's look-back
-// except the prefix record, which lags by a few microseconds = a few blocks; 24 blocks = 768 granules cover ~4.6 us of
-// arrivals at 50 M pairs per 0.29 ms.  Everything else a workgroup does (ranks, category histogram, its flush) overlaps
-// the wait.  Polls are bounded; a workgroup that gives up reports through ctl[2] and n_out[7] and stores nothing.
-// Lower-numbered workgroups must have been dispatched before higher-numbered ones wait on them (the hardware
-// dispatcher's order); the bounded polls turn a violation into an error, never into a hang.
-// The epoch lives in device memory (ctl[0]; a kernel argument would be frozen in a captured graph); the workgroup that
-// finishes last -- two-level arrival counters done1 / ctl[1] -- adds up the category_counts replicas, zeroes bsum,
-// and moves the epoch on (on wrap-around it clears the tagged words up to the high-water mark first).
-// ---------------------------------------------------------------------------------------------
-#define XM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-typedef unsigned long long xm_u64;
-__device__ __forceinline__ void g_store64(xm_u64 *p, xm_u64 v) { __hip_atomic_store(p, v, XM_RLX_AGENT); }
-__device__ __forceinline__ xm_u64 g_load64(const xm_u64 *p) { return __hip_atomic_load(p, XM_RLX_AGENT); }
-__device__ __forceinline__ void g_add64(xm_u64 *p, xm_u64 v) { (void)__hip_atomic_fetch_add(p, v, XM_RLX_AGENT); }
-__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-#ifdef XM_PLACE_TRACE
-#define XM_TRACE(slot, value) do { if (ps.trace && (threadIdx.x & 63u) == 0u) ps.trace[(uint64_t)blockIdx.x * 8u + (slot)] = (value); } while (0)
-#else
-#define XM_TRACE(slot, value) do { } while (0)
-#endif
-// LDS of a placing workgroup, in words: category histogram [64][XM_HREP] | misc: base[8], ok, -, bin accumulators [16..23], -,
-// wave_cnt[8][8] at misc + 32, the granule's bins staged for the ring at misc + 96 (1 KB)
-#define XM_PLACE_LDS_WORDS (64 * XM_HREP + 96 + 256)
-
-// ranks of the lane's units inside the wave's 256-record tile, per bin, in record order (K2c's scatter_256 without a
-// base); returns, in lane b, the tile's number of units of bin b
-template <int SLOTS, int NB>
-__device__ __forceinline__ uint32_t place_ranks(const uint32_t bin[4], uint32_t pos[4])
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t wc = 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        uint64_t m[4], any = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            m[j] = ((SLOTS >> j) & 1) ? __ballot(bin[j] == (uint32_t)b) : 0ull;
-            any |= m[j];
-        }
-        if (any == 0ull) continue;                                        // wave-uniform
-        uint32_t t = 0, total = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) { t = mbcnt64(m[j], t); total += (uint32_t)__builtin_popcountll(m[j]); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) pos[j] = (bin[j] == (uint32_t)b) ? t : pos[j];
-        wc = (lane == (uint32_t)b) ? total : wc;
-    }
-#pragma unroll
-    for (int j = 1; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < j; ++i)
-            if (((SLOTS >> j) & 1) && ((SLOTS >> i) & 1)) pos[j] += (bin[i] == bin[j]) ? 1u : 0u;
-    return wc;
-}
-
-// fin: lane b holds where this wave's run of bin b starts in list b
-template <int SLOTS, int NB, bool WIDE>
-__device__ __forceinline__ void place_store(const uint32_t bin[4], const uint32_t pos[4], uint32_t rec0, uint32_t fin,
-                                            const PlaceSink &ps)
-{
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        uint64_t any = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) any |= __ballot(bin[j] == (uint32_t)b);
-        uint32_t *__restrict__ list = ps.list[b];
-        if (any == 0ull || list == nullptr) continue;                     // wave-uniform
-        const uint32_t s = lane_value(fin, b);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (((SLOTS >> j) & 1) && bin[j] == (uint32_t)b) {
-                const uint32_t p = s + pos[j];
-                if (p < ps.cap) store_index<WIDE>(list, p, rec0 + (uint32_t)j);
-            }
-    }
-}
-
-// Publish granule g's units per bin (cnt: lane b < 7 holds the count of bin b, lane 7 holds 0): the descriptor, and the
-// block sum with its arrival count.
-template <bool HAS6>
-__device__ __forceinline__ void place_publish(const PlaceSink &ps, uint32_t g, uint32_t cnt, uint32_t epoch)
-{
-    constexpr uint32_t NW = HAS6 ? 4u : 3u;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t lo = (uint32_t)__shfl((int)cnt, (int)((2u * lane) & 7u), 64);
-    const uint32_t hi = (uint32_t)__shfl((int)cnt, (int)((2u * lane + 1u) & 7u), 64);
-    if (lane < NW) {
-        g_store64(ps.gdesc + XM_PLACE_GD_AT(g) + lane, ((xm_u64)epoch << 32) | (hi << 16) | lo);
-        g_add64(ps.bsum + XM_PLACE_BS_AT(g / XM_PLACE_S) + lane, (1ull << 48) | ((xm_u64)hi << 24) | lo);
-    }
-}
-
-// Wave 0, placing granule g: the exclusive prefix per bin (base: lane b) from the records in front of g; tot (lane b:
-// the granule's units of bin b) only serves what this granule publishes in turn (a prefix record, the list lengths).
-// false: gave up.
-template <bool HAS6>
-__device__ __forceinline__ bool place_lookback(const PlaceSink &ps, uint32_t g, uint32_t tot, uint32_t epoch, uint32_t &base)
-{
-    constexpr uint32_t NW = HAS6 ? 4u : 3u;          // words of a descriptor / block sum: two bins each
-    constexpr uint32_t NP = HAS6 ? 7u : 6u;          // words of a prefix record: one bin each
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t B = g / XM_PLACE_S, k = g % XM_PLACE_S;
-    base = 0;
-    bool ok = true;
-    if (g != 0u) {
-        // what this lane reads: role 1 = a descriptor of this block, 2 = a block sum, 3 = a prefix record
-        const xm_u64 *src = nullptr;
-        uint32_t nw = 0, role = 0;
-        if (lane < k) { role = 1; nw = NW; src = ps.gdesc + XM_PLACE_GD_AT(B * XM_PLACE_S + lane); }
-        else if (lane >= 32u && lane < 32u + XM_PLACE_WIN && lane - 32u < B) {
-            role = 2; nw = NW; src = ps.bsum + XM_PLACE_BS_AT(B - 1u - (lane - 32u));
-        } else if (lane >= 56u && lane < 56u + XM_PLACE_PROBES) {
-            const uint32_t need = (B & 3u) + 4u * (lane - 56u);             // blocks between the record's block and B
-            role = 3;
-            if (need < B) { nw = NP; src = ps.bpre + XM_PLACE_BP_AT((B - 1u - need) >> 2); }   // else: the beginning, prefix 0
-        }
-        xm_u64 x[7] = {0, 0, 0, 0, 0, 0, 0};
-        bool have = nw == 0u;
-        int pick = -1;
-        uint32_t need_pick = 0;
-        uint32_t spins = 0;
-        for (;; ++spins) {
-            if (!have) {
-#pragma unroll
-                for (uint32_t w = 0; w < 7u; ++w)
-                    if (w < nw) x[w] = g_load64(src + w);
-                bool good = true;
-#pragma unroll
-                for (uint32_t w = 0; w < 7u; ++w) {
-                    const bool tag = (role == 2u) ? (uint32_t)(x[w] >> 48) == XM_PLACE_S : (uint32_t)(x[w] >> 32) == epoch;
-                    good &= (w >= nw) || tag;
-                }
-                have = good;
-            }
-            const uint64_t vb = __ballot(have);
-            const uint32_t va = (uint32_t)(vb >> 32) & ((1u << XM_PLACE_WIN) - 1u), vp = (uint32_t)(vb >> 56) & ((1u << XM_PLACE_PROBES) - 1u);
-            if (((uint32_t)vb & 0x7FFFFFFFu) == 0x7FFFFFFFu && vp != 0u) {
-                const uint32_t mm = (uint32_t)__builtin_ctz(vp);              // the nearest prefix record that is there
-                uint32_t need = (B & 3u) + 4u * mm;
-                need = need < B ? need : B;
-                const uint32_t mask = (1u << need) - 1u;                       // need <= 23
-                if ((va & mask) == mask) { pick = (int)mm; need_pick = need; break; }
-            }
-            if (spins >= (uint32_t)XM_PLACE_SPIN_LIMIT) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(XM_PLACE_SLEEP);
-        }
-        XM_TRACE(5, spins);
-        XM_TRACE(6, (xm_u64)(int64_t)pick);
-#ifdef XM_PLACE_STATS
-        if (lane == 0u) {     // polls beyond the first, the largest number of them, which prefix record was taken
-            atomicAdd(ps.ctl + 4, spins);
-            atomicMax(ps.ctl + 5, spins);
-            atomicAdd(ps.ctl + 8 + (pick < 0 ? 7 : pick), 1u);
-        }
-#endif
-        if (ok) {
-            const bool use = (role == 1u) || (role == 2u && lane - 32u < need_pick) || (role == 3u && lane == 56u + (uint32_t)pick);
-#pragma unroll
-            for (uint32_t b = 0; b < NP; ++b) {
-                const xm_u64 w2 = x[b >> 1];
-                const uint32_t f16 = (uint32_t)(w2 >> ((b & 1u) * 16u)) & 0xFFFFu, f24 = (uint32_t)(w2 >> ((b & 1u) * 24u)) & 0xFFFFFFu;
-                uint32_t v = (role == 1u) ? f16 : (role == 2u) ? f24 : (uint32_t)x[b];
-                v = use ? v : 0u;
-                const uint32_t sum = lane_value(wave_scan_incl(v), 63);
-                base = (lane == b) ? sum : base;
-            }
-        }
-    }
-    if (!ok) {
-        if (lane == 0u) {
-            __hip_atomic_store(ps.ctl + 2, 1u, XM_RLX_AGENT);
-            if (g + 1u == ps.n_gran) ps.n_out[7] = ~0ull;
-        }
-        return false;
-    }
-    const uint32_t incl = base + tot;
-    if (k == XM_PLACE_S - 1u && (B & 3u) == 3u && lane < NP)
-        g_store64(ps.bpre + XM_PLACE_BP_AT(B >> 2) + lane, ((xm_u64)epoch << 32) | incl);
-    if (g + 1u == ps.n_gran) {                                                // the last granule's inclusive prefix = the list lengths
-        const uint32_t units = lane < 7u ? incl : 0u;
-        xm_u64 all = units;
-        all += __shfl_xor(all, 1, 64); all += __shfl_xor(all, 2, 64); all += __shfl_xor(all, 4, 64);
-        if (lane < 7u) ps.n_out[lane] = units;
-        if (lane == 7u) ps.n_out[7] = all;
-    }
-    return true;
-}
-
-// the last workgroup of the grid, once every workgroup has arrived: category_counts from the replicas, workspace back to
-// its between-calls state, next epoch
-__device__ __forceinline__ void place_finalize(const PlaceSink &ps, uint32_t epoch)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    xm_u64 acc = 0;
-    for (uint32_t r = 0; r < XM_COUNT_REPLICAS; ++r) {
-        acc += g_load64(ps.counts_rep + r * 64u + lane);
-        g_store64(ps.counts_rep + r * 64u + lane, 0ull);
-    }
-    ps.counts[lane] = acc;
-    const uint32_t n_blocks = (ps.n_gran + XM_PLACE_S - 1u) / XM_PLACE_S;
-    for (uint32_t i = lane; i < n_blocks * 4u; i += 64u) g_store64(ps.bsum + XM_PLACE_BS_AT(i >> 2) + (i & 3u), 0ull);
-    uint32_t next = epoch + 1u;
-    if (next == 0u) {                                                         // 2^32 calls: no stale tag may ever match again
-        for (uint64_t i = lane; i < XM_PLACE_GD_WORDS; i += 64u) g_store64(ps.gdesc + i, 0ull);
-        for (uint64_t i = lane; i < XM_PLACE_BP_WORDS; i += 64u) g_store64(ps.bpre + i, 0ull);
-        next = 1u;
-    }
-    if (lane == 0u) __hip_atomic_store(ps.ctl + 0, next, XM_RLX_AGENT);
-}
-
-// One workgroup of the single-pass kernel.  Workgroup i CLASSIFIES granule i (i < n_gran): scores -> states -> category
-// bytes (optional output), category histogram, the granule's units per bin -> published; its bins, a nibble per record, go
-// into a ring (1 KB per granule, write-through).  And it PLACES granule j = i - lag (i >= lag): bins back from the ring,
-// ranks, look-back over records that were published ~lag granules = several microseconds ago, index stores.  The
-// placement's loads are issued first and its work runs while the score loads of granule i are in flight.
-template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL, int BINMODE, bool WIDE>
-__device__ __forceinline__ void classify_place_body(const T *__restrict__ as1, const T *__restrict__ xs1,
-                                                    const T *__restrict__ as2, const T *__restrict__ xs2,
-                                                    const uint8_t *__restrict__ unit_bits8, T m,
-                                                    uint8_t *__restrict__ code, uint64_t n, uint32_t *last_state,
-                                                    uint32_t *lds, uint32_t epoch, const PlaceSink &ps)
-{
-    static_assert(BLOCK == 512, "eight waves: wave_cnt[8][8] is one word per lane");
-    constexpr bool HAS6 = sizeof(T) == 8;
-    constexpr int NB = HAS6 ? 7 : 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t i = blockIdx.x, lag = ps.lag;
-    const bool do_class = i < ps.n_gran, do_place = i >= lag;              // uniform; the grid is n_gran + lag workgroups
-    uint32_t *misc = lds + 64 * XM_HREP, *wave_cnt = misc + 32;
-
-    // ---- loads: the bins of the granule to place first, then the scores of the granule to classify
-    uint32_t nib = 0x7777u;
-    if (do_place) {
-        const uint16_t *slot = ps.ring + (uint64_t)((i - lag) % XM_PLACE_RING) * (XM_GRAN / 4u);
-        nib = __hip_atomic_load(slot + threadIdx.x, XM_RLX_AGENT);
-    }
-    const uint64_t g4 = (uint64_t)i * BLOCK + threadIdx.x;                // group of 4 records
-    const uint64_t r0 = g4 * 4;
-    T a1[4], x1[4], a2[4], x2[4];
-    uint32_t mb = 0, halo = 0;
-    if (do_class) {
-        load4<T, NT, FULL>(as1, r0, n, a1);
-        load4<T, NT, FULL>(xs1, r0, n, x1);
-        load4<T, NT, FULL>(as2, r0, n, a2);
-        load4<T, NT, FULL>(xs2, r0, n, x2);
-        if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g4 >> 1] >> ((g4 & 1u) * 4u)) & 0xFu;
-        if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
-        if (PAIRED && threadIdx.x == 0) {
-            if (r0 > 0) {
-                const uint64_t h = r0 - 1;
-                halo = mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m);
-            } else {
-                mb &= ~1u;                                     // record 0 has no predecessor (:402)
-            }
-        }
-    }
-
-    // ---- place granule j
-    if (do_place) {
-        const uint32_t j = i - lag;
-        uint32_t bin[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bin[q] = (nib >> (4 * q)) & 7u;
-        uint32_t pos[4] = {0, 0, 0, 0};
-        const bool inter = PAIRED && __ballot((nib & 0x0707u) != 0x0707u) == 0ull;   // strictly interleaved mates: positions 1, 3 only
-        const uint32_t wc = inter ? place_ranks<0xA, NB>(bin, pos) : place_ranks<0xF, NB>(bin, pos);
-        if (lane < 8u) wave_cnt[wave * 8u + lane] = wc;
-        __syncthreads();
-        uint32_t off, tot;      // lane b: units of bin b in the waves in front of this one / in the whole granule
-        {
-            const uint32_t v = wave_cnt[lane];
-            off = (lane >> 3) < wave ? v : 0u;
-            tot = v;
-            off += (uint32_t)__shfl_xor((int)off, 8, 64);  tot += (uint32_t)__shfl_xor((int)tot, 8, 64);
-            off += (uint32_t)__shfl_xor((int)off, 16, 64); tot += (uint32_t)__shfl_xor((int)tot, 16, 64);
-            off += (uint32_t)__shfl_xor((int)off, 32, 64); tot += (uint32_t)__shfl_xor((int)tot, 32, 64);
-        }
-        if (wave == 0u) {
-            uint32_t base = 0;
-            XM_TRACE(2, wall_clock64());
-#ifdef XM_PLACE_DBG_NOWAIT
-            const bool ok = true;
-#else
-            const bool ok = place_lookback<HAS6>(ps, j, tot, epoch, base);
-#endif
-            XM_TRACE(3, wall_clock64());
-            if (lane < 8u) misc[lane] = base;
-            if (lane == 8u) misc[8] = ok ? 1u : 0u;
-        }
-        __syncthreads();
-        const uint32_t fin = misc[lane & 7u] + off;
-#ifndef XM_PLACE_DBG_NOSTORE
-        if (misc[8] != 0u) {
-            const uint32_t rec0 = j * (uint32_t)XM_GRAN + threadIdx.x * 4u;
-            if (inter) place_store<0xA, NB, WIDE>(bin, pos, rec0, fin, ps);
-            else place_store<0xF, NB, WIDE>(bin, pos, rec0, fin, ps);
-        }
-#endif
-    }
-
-    // ---- classify granule i
-    if (do_class) {
-        uint32_t s[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] = mapping_state<T>(a1[q], x1[q], a2[q], x2[q], m);
-        uint32_t c[4], fwd[4] = {0, 0, 0, 0};
-        if (PAIRED) {
-            uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[3], 0x138, 0xf, 0xf, false);
-            if (lane == 63) last_state[wave] = s[3];
-            __syncthreads();                                               // also: the cleared histogram is visible
-            if (lane == 0) prev = (wave == 0) ? halo : last_state[wave - 1];
-            c[0] = (mb & 1u) ? ((prev << 3) | s[0]) : XM_NO_UNIT;
-            c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
-            c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
-            c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
-            fwd[0] = prev; fwd[1] = s[0]; fwd[2] = s[1]; fwd[3] = s[2];
-        } else {
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = ((mb >> q) & 1u) ? s[q] : XM_NO_UNIT;
-        }
-        if (code != nullptr) {                                             // optional per-record output (uniform test)
-            if (FULL || r0 + 4 <= n) {
-                *reinterpret_cast<uint32_t *>(code + r0) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (r0 + q < n) code[r0 + q] = (uint8_t)c[q];
-            }
-        }
-        uint32_t nibs = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nibs |= unit_bin_of<BINMODE, HAS6>(fwd[q], s[q], ((mb >> q) & 1u) != 0u) << (4 * q);
-        // the granule's bins, staged so that one wave writes them with 16-byte write-through stores
-        uint16_t *stage = reinterpret_cast<uint16_t *>(misc + 96);
-        stage[threadIdx.x] = (uint16_t)nibs;
-        // category_counts: the workgroup's histogram (64 slots x 8 replicas), as the counting K1
-        {
-            const uint32_t rep = lane & (XM_HREP - 1u);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool unit = c[q] != XM_NO_UNIT;
-                if (__ballot(unit) == 0ull) continue;
-                if (unit) atomicAdd(&lds[(c[q] & 63u) * XM_HREP + rep], 1u);
-            }
-        }
-        __syncthreads();
-        if (wave == 0u) {
-            // lane = category slot: its count -> category_counts replica; folded into the granule's units per bin -> published
-            const uint4 h0 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP);
-            const uint4 h1 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP + 4);
-            const uint32_t sum = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
-            if (sum != 0u) {
-                g_add64(ps.counts_rep + (i % XM_COUNT_REPLICAS) * 64u + lane, (xm_u64)sum);
-                atomicAdd(&misc[16u + unit_bin<BINMODE, HAS6>(lane)], sum);      // a counted slot is never 0xFF: bin <= 6
-            }
-            lds_settle();
-            const uint32_t cnt = lane < 7u ? misc[16u + lane] : 0u;
-            place_publish<HAS6>(ps, i, cnt, epoch);
-        } else if (wave == 1u) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(misc + 96 + lane * 4u);
-            uint4 *dst = reinterpret_cast<uint4 *>(ps.ring + (uint64_t)(i % XM_PLACE_RING) * (XM_GRAN / 4u)) + lane;
-            g_store64(reinterpret_cast<xm_u64 *>(dst), ((xm_u64)v.y << 32) | v.x);
-            g_store64(reinterpret_cast<xm_u64 *>(dst) + 1, ((xm_u64)v.w << 32) | v.z);
-        }
-    }
-    if (wave == 0u) XM_TRACE(4, wall_clock64());
-
-    // ---- this workgroup's share of the shared state is complete once its stores and atomics have been performed
-#ifndef XM_PLACE_DBG_NODONE
-    if (wave < 2u) vm_drain();
-    __syncthreads();
-    if (wave == 0u) {
-        const uint32_t n_wg = ps.n_gran + lag;
-        if (lane == 0u) (void)__hip_atomic_fetch_add(ps.done1 + (i % XM_PLACE_DONE_WORDS), 1u, XM_RLX_AGENT);
-        if (i + 1u == n_wg) {
-            // The last workgroup waits until every workgroup has arrived (all of them were dispatched before this one
-            // and none waits for it), then puts the workspace back into its between-calls state.
-            bool all_in = false;
-            for (uint32_t spins = 0; spins < (uint32_t)XM_PLACE_SPIN_LIMIT; ++spins) {
-                bool in = true;
-#pragma unroll
-                for (uint32_t q = 0; q < XM_PLACE_DONE_WORDS / 64u; ++q) {
-                    const uint32_t w = lane + 64u * q;
-                    const uint32_t expect = w < n_wg ? (n_wg - w + XM_PLACE_DONE_WORDS - 1u) / XM_PLACE_DONE_WORDS : 0u;
-                    in &= __hip_atomic_load(ps.done1 + w, XM_RLX_AGENT) == expect;
-                }
-                if (__ballot(!in) == 0ull) { all_in = true; break; }
-                __builtin_amdgcn_s_sleep(XM_PLACE_SLEEP);
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < XM_PLACE_DONE_WORDS / 64u; ++q) __hip_atomic_store(ps.done1 + lane + 64u * q, 0u, XM_RLX_AGENT);
-            if (!all_in && lane == 0u) {
-                __hip_atomic_store(ps.ctl + 2, 1u, XM_RLX_AGENT);
-                ps.n_out[7] = ~0ull;
-            }
-            place_finalize(ps, epoch);
-        }
-    }
-#endif
-}
-
-#ifndef XM_PLACE_WAVES_PER_EU
-#define XM_PLACE_WAVES_PER_EU 8
-#endif
-template <typename T, bool PAIRED, bool NT, int BLOCK, int BINMODE, bool WIDE>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(XM_PLACE_WAVES_PER_EU, XM_PLACE_WAVES_PER_EU)))
-classify_place_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
-                      const T *__restrict__ as2, const T *__restrict__ xs2,
-                      const uint8_t *__restrict__ unit_bits8, T m,
-                      uint8_t *__restrict__ code, uint64_t n, PlaceSink ps)
-{
-    static_assert(BLOCK * 4 == XM_GRAN, "the placing workgroup is one granule");
-    __shared__ uint32_t last_state[BLOCK / 64];
-    __shared__ __attribute__((aligned(16))) uint32_t lds[XM_PLACE_LDS_WORDS];
-    for (uint32_t q = threadIdx.x; q < 64u * XM_HREP + 32u; q += BLOCK) lds[q] = 0;    // histogram + bin accumulators
-    const uint32_t epoch = ps.ctl[0];                                    // written by the previous call's last workgroup
-    if (threadIdx.x < 64u) XM_TRACE(0, wall_clock64());
-    if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
-        classify_place_body<T, PAIRED, NT, BLOCK, true, BINMODE, WIDE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, lds, epoch, ps);
-    else
-        classify_place_body<T, PAIRED, NT, BLOCK, false, BINMODE, WIDE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, lds, epoch, ps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1958,37 +1553,6 @@ void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
     launch_classify_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, cp);
 }
 
-template <typename T>
-static void launch_classify_place_t(hipStream_t st, int mode, uint64_t n,
-                                    const T *as1, const T *xs1, const T *as2, const T *xs2,
-                                    const uint64_t *unit_bits, T m, uint8_t *code, const PlaceSink &ps)
-{
-    const uint32_t grid = ps.n_gran + ps.lag;
-    const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
-    const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
-#define XM_LAUNCH_PLC(P, B, W) classify_place_kernel<T, P, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK, B, W><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, code, n, ps)
-#define XM_LAUNCH_PLC2(P, B) do { if (wide) XM_LAUNCH_PLC(P, B, true); else XM_LAUNCH_PLC(P, B, false); } while (0)
-    if (mode == XM_MODE_SE) XM_LAUNCH_PLC2(false, XM_MODE_SE);
-    else if (mode == XM_MODE_PE_LIBERAL) XM_LAUNCH_PLC2(true, XM_MODE_PE_LIBERAL);
-    else XM_LAUNCH_PLC2(true, XM_MODE_PE_CONSERVATIVE);
-#undef XM_LAUNCH_PLC2
-#undef XM_LAUNCH_PLC
-}
-
-void launch_classify_place_i32(hipStream_t st, int mode, uint64_t n,
-                               const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                               const uint64_t *unit_bits, int32_t m, uint8_t *code, const PlaceSink &ps)
-{
-    launch_classify_place_t<int32_t>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, ps);
-}
-
-void launch_classify_place_f64(hipStream_t st, int mode, uint64_t n,
-                               const double *as1, const double *xs1, const double *as2, const double *xs2,
-                               const uint64_t *unit_bits, double m, uint8_t *code, const PlaceSink &ps)
-{
-    launch_classify_place_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, ps);
-}
-
 void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,
                            const int32_t *nm1, const uint32_t *off1, const uint32_t *ops1, const int32_t *xs1,
                            const int32_t *nm2, const uint32_t *off2, const uint32_t *ops2, const int32_t *xs2,
@@ -2042,18 +1606,21 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
 
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_counts, const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets,
-                    uint32_t *idx_out, uint32_t *part_tot)
+                    uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists)
 {
     const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
     const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
     const bool stage = mode == XM_MODE_SE;
-#define XM_LAUNCH_SCT(W, NIB, STG) scatter_kernel<XM_GRAN / 256, W, NIB, STG><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot)
-#define XM_LAUNCH_SCT2(W, NIB) do { if (stage) XM_LAUNCH_SCT(W, NIB, true); else XM_LAUNCH_SCT(W, NIB, false); } while (0)
+    const ListOut lo = lists ? *lists : ListOut{{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0u};
+#define XM_LAUNCH_SCT(W, NIB, STG, L) scatter_kernel<XM_GRAN / 256, W, NIB, STG, L><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot, lo)
+#define XM_LAUNCH_SCT1(W, NIB, STG) do { if (lists) XM_LAUNCH_SCT(W, NIB, STG, true); else XM_LAUNCH_SCT(W, NIB, STG, false); } while (0)
+#define XM_LAUNCH_SCT2(W, NIB) do { if (stage) XM_LAUNCH_SCT1(W, NIB, true); else XM_LAUNCH_SCT1(W, NIB, false); } while (0)
     if (code_is_bins4) { if (wide) XM_LAUNCH_SCT2(true, true); else XM_LAUNCH_SCT2(false, true); }
     else               { if (wide) XM_LAUNCH_SCT2(true, false); else XM_LAUNCH_SCT2(false, false); }
 #undef XM_LAUNCH_SCT2
+#undef XM_LAUNCH_SCT1
 #undef XM_LAUNCH_SCT
 }
 
