@@ -176,6 +176,7 @@ def cpu_baseline_python(sample_pairs=20000, passes=0, budget_s=12.0):
             "host_cpus_visible": os.cpu_count(), "kind": "port",
             "sample": "%d passes over a %d-pair 2x150 bp SAM text twin (seed 2002): parse + classify + "
                       "write six bins, pure-Python restatement of the reference loop" % (n_pass, sample_pairs),
+            "sample_short": "%d x %d-pair SAM text twin, parse+classify+write, %.0f s" % (n_pass, sample_pairs, el),
             "seconds": round(el, 2)}
 
 
@@ -402,6 +403,19 @@ class Workload(object):
         self.block = (start, end, halo)
         return cols, end - lo, units
 
+    def short(self):
+        return {"cfg2": "configs[1]: %d PE 2x150 pairs/GPU, AS/XS, %s, HBM-resident", "cfg3": "configs[2]: %d PE pairs/GPU, --cigar_scores packed columns, %s",
+                "cfg5": "configs[4]: %d PE pairs/GPU, HISAT ZS, %s", "f64": "configs[1] as binary64: %d PE pairs/GPU, %s",
+                "se": "single-end loop: 2 x %d reads/GPU (%s ignored)"}[self.name] % (self.n_pairs, self.mode_name)
+
+    def step_short(self):
+        if self.place:
+            return "xm_classify_place%s_dev: classify+count, scan, scatter into six lists" % ("_f64" if self.dtype == "f64" else "")
+        if self.unfused:
+            return "A/B: xm_classify_dev + xm_compact_dev"
+        return "xm_classify_compact%s_dev: classify+count, scan, scatter (3 launches)" % (
+            "_cigar_packed" if self.cigp is not None else "_cigar" if self.cig is not None else "_f64" if self.dtype == "f64" else "")
+
     def describe(self):
         if self.name == "cfg3":
             return self.DESCR["cfg3"] % (self.n_pairs, "CSR" if self.cigar_csr else "packed", self.mode_name)
@@ -569,6 +583,122 @@ def time_steps(ctx, wl, steps, warmup, fence, finish=None):
     return elapsed, timing, timing_all
 
 
+def median_step_ms(wl, steps=20):
+    """Median duration of one step: `steps` further steps, each between two events on the stream the library launches
+    on (torch's current stream), after the timed region ("report median"; `ms_per_step` stays elapsed / K)."""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for k in range(steps):
+        wl.step()
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(steps))
+    return ms[steps // 2]
+
+
+def stream_ceiling_gbps(ctx, wl, reps=11):
+    """The box's own ceiling for the classify kernel's access pattern: xm_stream_probe_dev reads the workload's four
+    score columns (16 B per record) and writes 1/2 B per record, no arithmetic; median of `reps`; GB/s of the bytes it
+    moves.  None for workloads without four int32 score columns."""
+    import torch
+    c = wl.cols
+    if wl.dtype != "int32" or any(k not in c for k in ("as1", "xs1", "as2", "xs2")):
+        return None
+    n = wl.n - wl.n % 4
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ctx.stream_probe_dev(c["as1"][:n], c["xs1"][:n], c["as2"][:n], c["xs2"][:n], wl.bins4)
+    ev[0].record()
+    for k in range(reps):
+        ctx.stream_probe_dev(c["as1"][:n], c["xs1"][:n], c["as2"][:n], c["xs2"][:n], wl.bins4)
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))[reps // 2]
+    return 16.5 * n / (ms * 1e-3) / 1e9
+
+
+def copy_ceiling_gbps(dev, bytes_moved, reps=11):
+    """What a plain streaming copy reaches on THIS box with the classify kernel's footprint: a device-to-device copy
+    that reads bytes_moved / 2 and writes as much (torch -> hipMemcpyDtoD), median of `reps`; GB/s of read + written bytes."""
+    import torch
+    half = int(bytes_moved // 2) & ~15
+    src = torch.empty(half, dtype=torch.uint8, device=dev)
+    dst = torch.empty(half, dtype=torch.uint8, device=dev)
+    src.fill_(3)
+    dst.copy_(src)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        dst.copy_(src)
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))[reps // 2]
+    del src, dst
+    return 2.0 * half / (ms * 1e-3) / 1e9
+
+
+def _r(x, digits=5):
+    """Round to `digits` significant digits (the printed line is short; the full record keeps everything)."""
+    if x is None or isinstance(x, (bool, int, str)):
+        return x
+    return float("%.*g" % (digits, x))
+
+
+def compact_line(full):
+    """The ONE JSON line rank 0 prints: numbers only, well under 2 000 characters, so that a record which keeps the
+    line's tail still holds every workload.  The sentences (what each number is) live in profiles/README.md; the full
+    record of the run is written next to it (`full_record`)."""
+    roof, step = full["roofline"], full["roofline_step"]
+    line = {k: full[k] for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline",
+                                 "dtype", "data")}
+    line["value"] = _r(full["value"], 6)
+    line["ms_per_step"] = _r(full["ms_per_step"])
+    line["ms_per_step_median"] = _r(full.get("ms_per_step_median"))
+    line["config"] = {"workload": full["config"]["workload_short"], "pairs_per_gpu": full["config"]["pairs_per_gpu"],
+                      "step": full["config"]["step_short"], "sharding": full["config"]["sharding_short"]}
+    line["roofline"] = {"bound": "hbm", "kernel": roof["kernel"].split("<")[0], "achieved": _r(roof["achieved"]), "peak": roof["peak"],
+                        "unit": "GB/s", "frac": _r(roof["frac"], 4), "traffic": _r(roof["traffic"]), "kernel_ms": _r(roof["kernel_ms"]),
+                        "bytes_per_unit": _r(roof["algorithmic_bytes_per_unit"]), "copy_ceiling_GBps": _r(roof.get("copy_ceiling_GBps"), 4),
+                        "memcpy_d2d_GBps": _r(roof.get("memcpy_d2d_GBps"), 4), "frac_of_copy": _r(roof.get("frac_of_copy"), 4)}
+    line["roofline_step"] = {"frac": _r(step["frac"], 4), "frac_by_ms_per_step": _r(step["frac_by_ms_per_step"], 4),
+                             "sum_kernel_ms": _r(step["sum_kernel_ms"]), "bytes_per_unit": _r(step["algorithmic_bytes_per_unit"]),
+                             "traffic": _r(step["traffic"])}
+    line["kernel_ms"] = {k: _r(v, 4) for k, v in full["kernel_ms"].items()}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample_short"]}
+    line["verified_vs_oracle"] = full["verified_vs_oracle"]
+    line["n_ranks_seen"] = full["n_ranks_seen"]
+    x = full.get("xm_allreduce_counts")
+    if x is not None:
+        line["xm_allreduce_counts"] = ({"ranks": x.get("ranks"), "ok": x.get("matches_torch_distributed")} if "error" not in x
+                                       else {"error": str(x["error"])[:120]})
+    w = {}
+    for key, short in (("configs[2]", "cfg3"), ("configs[4]", "cfg5")):
+        e = (full.get("workloads") or {}).get(key)
+        if e is not None:      # [ms_per_step, roofline.frac (classify kernel), frac by ms_per_step (whole step), verified]
+            w[short] = ([_r(e["ms_per_step"]), _r(e["roofline"]["frac"], 4), _r(e["roofline_step"]["frac_by_ms_per_step"], 4),
+                         e["verified_vs_oracle"]] if "error" not in e else [None, None, None, str(e["error"])[:80]])
+    e = (full.get("workloads") or {}).get("sharded_input")
+    if e is not None:          # [ms_per_step, read-pairs/s of the whole job, verified]: configs[3]'s input cut into N blocks with halo
+        w["sharded"] = ([_r(e["ms_per_step"]), _r(e["value"], 6), e["verified_vs_oracle"]] if "error" not in e
+                        else [None, None, str(e["error"])[:80]])
+    if w:
+        line["workloads"] = w
+    e2e = full.get("e2e")
+    if e2e:                    # [G read-pairs/s host columns -> lists over PCIe (page-locked), M read-pairs/s SAM text -> six SAM files, M pairs/s BAM -> files]
+        def rate(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        line["e2e"] = [_r((rate(e2e, "h2d_inclusive", "registered_buffers", "read_pairs_per_s") or 0) / 1e9, 4),
+                       _r((rate(e2e, "sam_text", "read_pairs_per_s") or 0) / 1e6, 4),
+                       _r((rate(e2e, "bam", "read_pairs_per_s") or 0) / 1e6, 4)]
+    line["full_record"] = full.get("full_record")
+    return line
+
+
 def rooflines(wl, elapsed, steps, timing, timing_all, unit_name):
     """The `roofline` (dominant kernel) and `roofline_step` (whole step) objects + per-kernel means of one workload."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
@@ -678,6 +808,7 @@ def main():
         torch.cuda.synchronize()
 
     elapsed, timing, timing_all = time_steps(ctx, wl, args.steps, args.warmup, fence, finish)
+    step_median_ms = median_step_ms(wl, 20)
     job_total = int(job_counts.sum().item())
     job_final = job_counts.clone()
     last_counts = wl.counts.clone()
@@ -704,6 +835,14 @@ def main():
     if rank == 0:
         unit_name = "read" if args.workload == "se" else "read-pair"
         roof, roof_step, kernels = rooflines(wl, elapsed, args.steps, timing, timing_all, unit_name)
+        try:        # an on-box streaming-copy ceiling beside the spec peak, same footprint as the classify kernel
+            roof["memcpy_d2d_GBps"] = copy_ceiling_gbps(dev, wl.bytes_classify * wl.units_per_step)
+            probe = stream_ceiling_gbps(ctx, wl)
+            roof["copy_ceiling_GBps"] = probe if probe is not None else roof["memcpy_d2d_GBps"]
+            roof["copy_ceiling_kind"] = "xm_stream_probe_dev" if probe is not None else "hipMemcpyDtoD"
+            roof["frac_of_copy"] = roof["achieved"] / roof["copy_ceiling_GBps"]
+        except Exception as e:                                   # noqa: BLE001
+            roof["copy_ceiling_GBps"], roof["frac_of_copy"], roof["copy_ceiling_error"] = None, None, "%s: %s" % (type(e).__name__, e)
         if args.sharded_input:
             job = ("ONE %d-pair input (%d seeded parts end to end) cut into %d read blocks of ~%d pairs with a one-record halo%s"
                    % (args.strong_total, Workload.PARTS, world, n_pairs,
@@ -721,10 +860,13 @@ def main():
             "unit": unit_name + "s/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "collective_backend": backend,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": step_median_ms,
             "higher_is_better": True, "scaling": "strong" if args.strong_total else "weak", "vs_baseline": None,
             "dtype": wl.dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
-            "config": {"workload": wl.describe(), "job": job,
+            "config": {"workload": wl.describe(), "workload_short": wl.short(), "step_short": wl.step_short(),
+                       "sharding_short": ("sharded input (%d pairs, halo)" % args.strong_total if args.sharded_input else
+                                          "strong" if args.strong_total else "weak: own block per GPU") + (", 1 RCCL all-reduce of counts" if world > 1 else ""),
+                       "job": job,
                        "pairs_per_gpu": n_pairs, "records_per_species_per_gpu": wl.n, "record_layout": wl.layout,
                        "step": wl.call_name(),
                        "category_per_record": ("category byte (fwd*8+rev, 1 B per record)" if wl.category_bytes else
@@ -771,16 +913,19 @@ def main():
                 e2e["host_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
             line["e2e"] = e2e
 
-    # The other single-GPU BASELINE configs, timed the same way in this process after the headline run (default
-    # invocation only): configs[2] --cigar_scores and configs[4] HISAT ZS + conservative.  `value`/`config` stay configs[1].
-    default_run = (world == 1 and args.workload == "cfg2" and not args.no_extra_workloads and not args.sharded_input
-                   and not args.singletons_pct and not args.strong_total and args.pairs == 50_000_000
-                   and not wl.unfused and os.environ.get("XM_BENCH_CATEGORY_BYTES") != "1")
-    if default_run:
-        mode0 = wl.mode
+    # The other BASELINE configs, timed the same way in this process after the headline run (default invocation only):
+    # configs[2] --cigar_scores and configs[4] HISAT ZS + conservative (one GPU), and -- at every N -- configs[3]'s input:
+    # 400 M pairs as ONE input cut into N read blocks with the halo record (strong scaling), so that one scaling run of
+    # the default command yields both curves of SURVEY 8d.  `value`/`config` stay configs[1].
+    plain_default = (args.workload == "cfg2" and not args.no_extra_workloads and not args.sharded_input
+                     and not args.singletons_pct and not args.strong_total and args.pairs == 50_000_000
+                     and not wl.unfused and not wl.place and os.environ.get("XM_BENCH_CATEGORY_BYTES") != "1")
+    default_run = world == 1 and plain_default
+    extra = {}
+    if plain_default:
         del wl
         torch.cuda.empty_cache()
-        extra = {}
+    if default_run:
         for key, name in EXTRA_WORKLOADS:
             try:
                 w2 = Workload(name, ctx, dev, n_pairs, rank, None, 20)
@@ -797,9 +942,32 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:                               # noqa: BLE001 -- reported, the headline line still goes out
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if plain_default:
+        try:
+            total = 400_000_000 - 400_000_000 % (Workload.PARTS * 32)
+            w3 = Workload("cfg2", ctx, dev, total // world, rank, None, 10, 0.0, (total, world))
+            el3, _, tma3 = time_steps(ctx, w3, 10, 3, fence)
+            t3 = torch.tensor([el3], dtype=torch.float64, device=dev)
+            el3 = float(allreduce(t3, dist.ReduceOp.MAX).item()) if world > 1 else el3
+            u3 = torch.tensor([w3.units_per_step], dtype=torch.int64, device=dev)
+            units3 = int(allreduce(u3, dist.ReduceOp.SUM).item()) if world > 1 else w3.units_per_step
+            ok3 = None
+            if not args.no_verify:
+                f3 = torch.tensor([1 if w3.verify() else 0], dtype=torch.int64, device=dev)
+                ok3 = bool(allreduce(f3, dist.ReduceOp.MIN).item()) if world > 1 else bool(f3.item())
+            extra["sharded_input"] = {"total_pairs": total, "blocks": world, "steps": 10, "warmup": 3, "ms_per_step": 1e3 * el3 / 10,
+                                      "value": units3 * 10 / el3, "unit": "read-pairs/s", "scaling": "strong", "units_per_step": units3,
+                                      "kernel_ms": {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in tma3.items() if v["launches"]},
+                                      "verified_vs_oracle": ok3}
+            del w3
+            torch.cuda.empty_cache()
+        except Exception as e:                                   # noqa: BLE001
+            extra["sharded_input"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0 and extra:
         line["workloads"] = extra
-        line["workloads_note"] = ("configs[2] and configs[4] timed in this process after the headline run: 5 warm-up + 20 steps each, "
-                                  "same protocol (HIP events on the classify kernel inside the timed region)")
+        line["workloads_note"] = ("timed in this process after the headline run, same protocol: configs[2] / configs[4] 5 warm-up + 20 "
+                                  "steps (one GPU only); sharded_input = configs[3]'s 400 M-pair input cut into N read blocks with halo, "
+                                  "3 warm-up + 10 steps, max over ranks")
 
     # The same reduction through the library's own RCCL communicator (xm_allreduce_counts, the C ABI's collective), on
     # every rank, after everything else and under a watchdog: the job total above came from torch.distributed, so
@@ -834,7 +1002,19 @@ def main():
         if rank == 0:
             line["xm_allreduce_counts"] = outcome
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        # the full record goes to a file, the printed line stays short (numbers only)
+        path = os.environ.get("XM_BENCH_FULL_JSON") or os.path.join(REPO, "gpurun_out", "bench_full_%dgpu_%s.json" % (world, args.workload))
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "wt") as fh:
+                json.dump(line, fh, indent=1)
+            line["full_record"] = os.path.relpath(path, REPO)
+        except OSError:
+            line["full_record"] = None
+        out = compact_line(line)
+        if os.environ.get("XM_BENCH_VERBOSE") == "1":
+            out = line
+        print(json.dumps(out, separators=(",", ":")), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

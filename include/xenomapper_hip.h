@@ -277,7 +277,8 @@ int xm_classify_compact_cigar_dev(xm_ctx *ctx, void *stream, int mode, uint64_t 
  * memory, no device needed): it fills cig_cnt[n_records] and cig_tile[XM_CIG_TILES(n_records) + 1], stores the length
  * of the packed op array in *n_ops_packed and, when ops_packed is not NULL (capacity in words: ops_capacity), writes the
  * packed op array.  When *n_ops_packed == cig_off[n_records] no record needed a trailer and the packed op array IS
- * cig_oplen: call with ops_packed = NULL first and skip the copy.  XM_ERR_RANGE: a record with 2^28 ops or more, or more
+ * cig_oplen: call with ops_packed = NULL first and skip the copy.  cig_off[0] must be 0 (XM_ERR_INVALID_ARG otherwise: the
+ * tile positions count from the start of the packed array).  XM_ERR_RANGE: a record with 2^28 ops or more, or more
  * than 2^32 - 1 packed ops.
  */
 #define XM_CIG_TILE 256u
@@ -333,6 +334,15 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
                                        const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
                                        uint32_t *range_flag, uint32_t *const idx_out[6], uint64_t list_capacity,
                                        uint64_t *n_out, uint64_t *counts);
+
+/*
+ * Measurement aid ("measure an on-box streaming-copy ceiling alongside" the 8 TB/s specification): the classify
+ * kernel's memory shape without its arithmetic -- reads 16 bytes per record from four int32 columns (n_records rounded down
+ * to a multiple of 4), writes XM_BINS4_BYTES(n_records) bytes at most to `out` (the compact stream's size).  The values
+ * written mean nothing.  Timed by the caller (events on `stream`).
+ */
+int xm_stream_probe_dev(xm_ctx *ctx, void *stream, uint64_t n_records,
+                        const int32_t *c0, const int32_t *c1, const int32_t *c2, const int32_t *c3, uint8_t *out);
 
 /* ---- multi-GPU: the one collective of the path ------------------------------------------ */
 /*

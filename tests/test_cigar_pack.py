@@ -69,3 +69,19 @@ def test_pack_rejects_bad_columns():
     assert L.xm_cigar_pack(2, p(good), p(big), p(cnt), p(tile), None, 0, ctypes.byref(out)) == 0 and out.value == 302
     assert L.xm_cigar_pack(2, p(good), p(big), p(cnt), p(tile), p(small), 301, ctypes.byref(out)) == -1
     assert L.xm_cigar_pack(2, p(good), p(big), None, p(tile), None, 0, ctypes.byref(out)) == -1
+
+
+def test_cigar_pack_rejects_offsets_that_do_not_start_at_zero():
+    """The packed op array may BE the CSR op array when no record needed a trailer (n_ops_packed == cig_off[n]); that
+    equality only means "nothing was escaped" when the offsets start at 0, so anything else is refused."""
+    import ctypes
+    from xenomapper_amd import _ffi
+    L = _ffi.lib()
+    off = np.array([3, 4, 6], dtype=np.uint32)
+    ops = np.zeros(8, dtype=np.uint32)
+    cnt = np.zeros(2, dtype=np.uint8)
+    tile = np.zeros(2, dtype=np.uint32)
+    n_packed = ctypes.c_uint64(0)
+    rc = L.xm_cigar_pack(2, off.ctypes.data_as(ctypes.c_void_p), ops.ctypes.data_as(ctypes.c_void_p),
+                         cnt.ctypes.data_as(ctypes.c_void_p), tile.ctypes.data_as(ctypes.c_void_p), None, 0, ctypes.byref(n_packed))
+    assert rc == -1

@@ -232,3 +232,58 @@ def test_c_example_refuses_without_a_device(tmp_path):
     import subprocess
     proc = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
     assert proc.returncode == 2 and "gfx950" in proc.stderr and proc.stdout == ""
+
+
+class _FakeParser(object):
+    """Stands in for the C++ writer in the mapped-file tests: `need` bytes of 'x' per call."""
+
+    def __init__(self, need):
+        self.need, self.calls = need, 0
+
+    def emit_size(self, paired, b, seg):
+        return None, self.need
+
+    def emit_to(self, paired, b, idx, addr, size):
+        import ctypes
+        self.calls += 1
+        ctypes.memset(addr, ord("x"), size)
+        return size
+
+
+@pytest.mark.parametrize("err", ["ENOSPC", "EDQUOT", "EFBIG"])
+def test_mapped_writer_does_not_map_what_it_could_not_allocate(tmp_path, monkeypatch, err):
+    """posix_fallocate failing for lack of space (or quota, or the file size limit) must not be papered over with a
+    sparse ftruncate -- storing into pages that cannot be backed dies with SIGBUS.  The range is given back and the
+    caller's ordinary write raises the real error, as the reference's print() would."""
+    import errno
+    import os
+    from xenomapper_amd import xenomapper as xm
+    path = tmp_path / "bin.sam"
+    with open(path, "wt") as sink:
+        sink.write("@HD\tVN:1.0\n")
+
+        def no_space(fd, off, length):
+            raise OSError(getattr(errno, err), os.strerror(getattr(errno, err)))
+        monkeypatch.setattr(os, "posix_fallocate", no_space)
+        fake = _FakeParser(4 << 20)
+        assert xm._emit_into_file(fake, True, 0, None, sink) is False
+        assert fake.calls == 0
+    assert path.read_text() == "@HD\tVN:1.0\n"              # not extended, nothing left behind
+
+
+def test_mapped_writer_falls_back_to_a_sparse_extension_only_where_preallocation_is_unsupported(tmp_path, monkeypatch):
+    import errno
+    import os
+    from xenomapper_amd import xenomapper as xm
+    path = tmp_path / "bin.sam"
+    with open(path, "wt") as sink:
+        sink.write("@HD\n")
+
+        def unsupported(fd, off, length):
+            raise OSError(errno.EOPNOTSUPP, os.strerror(errno.EOPNOTSUPP))
+        monkeypatch.setattr(os, "posix_fallocate", unsupported)
+        fake = _FakeParser(2 << 20)
+        assert xm._emit_into_file(fake, True, 0, None, sink) is True
+        sink.write("tail\n")
+    data = path.read_bytes()
+    assert data[:4] == b"@HD\n" and data[4:4 + (2 << 20)] == b"x" * (2 << 20) and data[-5:] == b"tail\n"

@@ -2,14 +2,16 @@
 
 `profiles/pmc_traffic.json` (HBM bytes per launch from rocprofv3 --pmc passes) is replayed by bench.py next to freshly
 measured times; it carries the hash below, and bench.py prints the traffic only while the tree still hashes to it
-(otherwise `traffic: null, traffic_source: "stale"`).  The hash covers the two files the device code is compiled from
-and any extra hipcc flags of a tuning build.
+(otherwise `traffic: null, traffic_source: "stale"`).  The hash covers the files the device code is compiled from, the
+file that decides which launches make up a step (xm_api.hip) with the header it implements, and any extra hipcc flags of
+a tuning build.
 """
 import hashlib
 import os
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("xenomapper_amd/csrc/xm_kernels.hip", "xenomapper_amd/csrc/xm_kernels.h")
+KERNEL_SOURCES = ("xenomapper_amd/csrc/xm_kernels.hip", "xenomapper_amd/csrc/xm_kernels.h", "xenomapper_amd/csrc/xm_api.hip",
+                  "include/xenomapper_hip.h")
 
 
 def kernel_src_sha256(repo=REPO, flags=None):

@@ -292,6 +292,7 @@ int xm_cigar_pack(uint64_t n, const uint32_t *cig_off, const uint32_t *cig_oplen
 {
     if (n > XM_MAX_RECORDS || !cig_tile || !n_ops_packed || (n && (!cig_off || !cig_cnt))) return XM_ERR_INVALID_ARG;
     if (ops_packed && n && cig_off[n] && !cig_oplen) return XM_ERR_INVALID_ARG;
+    if (n && cig_off[0] != 0u) return XM_ERR_INVALID_ARG;      // "n_ops_packed == cig_off[n]: reuse cig_oplen as it is" relies on it
     uint64_t pos = 0;
     for (uint64_t i = 0; i < n; ++i) {
         if ((i & (XM_CIG_TILE - 1u)) == 0) {
@@ -659,6 +660,17 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
     }
     if ((rc = check_launch(ctx, "classify_cigp_kernel")) != XM_OK) return rc;
     return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
+}
+
+int xm_stream_probe_dev(xm_ctx *ctx, void *stream, uint64_t n,
+                        const int32_t *c0, const int32_t *c1, const int32_t *c2, const int32_t *c3, uint8_t *out)
+{
+    if (!ctx || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    if (n == 0) return XM_OK;
+    if (!c0 || !c1 || !c2 || !c3 || !out) return XM_ERR_INVALID_ARG;
+    if ((((uintptr_t)c0 | (uintptr_t)c1 | (uintptr_t)c2 | (uintptr_t)c3) & 15u) || ((uintptr_t)out & 1u)) return XM_ERR_INVALID_ARG;
+    xm::launch_stream_probe((hipStream_t)stream, n, c0, c1, c2, c3, out);
+    return check_launch(ctx, "stream_probe_kernel");
 }
 
 int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *track, uint64_t m,

@@ -73,6 +73,9 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_counts, const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets,
                     uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists = nullptr);
+// memory shape of the classify kernel without arithmetic (bench.py: the box's streaming ceiling); n a multiple of 4
+void launch_stream_probe(hipStream_t st, uint64_t n, const int32_t *c0, const int32_t *c1, const int32_t *c2, const int32_t *c3,
+                         uint8_t *out);
 void launch_mate_correlate(hipStream_t st, uint64_t n, const double *track, uint32_t m, const double *density, double *out);
 void launch_cigar(hipStream_t st, uint32_t max_blocks, uint64_t n, const int32_t *nm, const uint32_t *cig_off,
                   const uint32_t *cig_oplen, int32_t *as_out, uint32_t *range_flag);

@@ -1492,6 +1492,35 @@ mate_correlate_kernel(const double *__restrict__ track, uint64_t n, const double
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming probe: the classify kernel's memory shape without its arithmetic -- every lane reads 16 bytes of each of the
+// four score columns (non-temporal) and writes 2 bytes (one workgroup = XM_GRAN records, one tile per wave, the grid covers
+// the input once).  What it reaches is the box's own ceiling for this access pattern ("measure an on-box
+// streaming-copy ceiling alongside" the 8 TB/s specification); bench.py reports it as roofline.copy_ceiling_GBps.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(XM_CLASSIFY_BLOCK)
+stream_probe_kernel(const v4i32 *__restrict__ c0, const v4i32 *__restrict__ c1, const v4i32 *__restrict__ c2,
+                    const v4i32 *__restrict__ c3, uint16_t *__restrict__ out, uint64_t n_groups)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * XM_CLASSIFY_BLOCK + threadIdx.x;
+    if (g >= n_groups) return;
+    const v4i32 a = __builtin_nontemporal_load(c0 + g), b = __builtin_nontemporal_load(c1 + g);
+    const v4i32 c = __builtin_nontemporal_load(c2 + g), d = __builtin_nontemporal_load(c3 + g);
+    const v4i32 x = a ^ b ^ c ^ d;
+    out[g] = (uint16_t)(x.x ^ x.y ^ x.z ^ x.w);
+}
+
+void launch_stream_probe(hipStream_t st, uint64_t n, const int32_t *c0, const int32_t *c1, const int32_t *c2, const int32_t *c3,
+                         uint8_t *out)
+{
+    const uint64_t n_groups = n / 4;
+    const uint32_t grid = (uint32_t)((n_groups + XM_CLASSIFY_BLOCK - 1) / XM_CLASSIFY_BLOCK);
+    if (grid == 0) return;
+    stream_probe_kernel<<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(reinterpret_cast<const v4i32 *>(c0), reinterpret_cast<const v4i32 *>(c1),
+                                                            reinterpret_cast<const v4i32 *>(c2), reinterpret_cast<const v4i32 *>(c3),
+                                                            reinterpret_cast<uint16_t *>(out), n_groups);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 static_assert(XM_CLASSIFY_BLOCK * 4 == XM_GRAN, "the counting classify workgroup is one granule");

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import argparse
 import contextlib
+import errno
 import io
 import mmap
 import math
@@ -686,7 +687,12 @@ def _emit_into_file(parser, paired, b, seg, sink):
         extended = True
         try:
             os.posix_fallocate(fd2, pos, need)         # extends the file AND allocates its pages in one go: the threads
-        except OSError:                                # then only copy (page by page faults cost 3x on tmpfs)
+        except OSError as e:                           # then only copy (page by page faults cost 3x on tmpfs)
+            # Only a file system that cannot preallocate may be extended sparsely instead.  Anything else -- no space
+            # left, a quota, the file size limit -- must NOT be papered over: stores into a mapping whose pages cannot
+            # be backed end in SIGBUS.  Give the range back and let the ordinary write raise the real OSError.
+            if e.errno not in (errno.EOPNOTSUPP, errno.ENOSYS, errno.EINVAL):
+                raise
             os.ftruncate(fd2, pos + need)
         start = pos - pos % mmap.ALLOCATIONGRANULARITY
         mm = mmap.mmap(fd2, pos + need - start, offset=start, access=mmap.ACCESS_WRITE)
