@@ -26,13 +26,14 @@
 extern "C" {
 #endif
 
-#define XMH_ABI_VERSION 1
+#define XMH_ABI_VERSION 2
 
 #define XMH_OK              0
 #define XMH_ERR_INVALID_ARG (-1)
 #define XMH_ERR_OOM         (-2)
 #define XMH_ERR_NON_ASCII   (-3)   /* a byte >= 0x80 in the window: Python's str.split() rules would apply */
 #define XMH_ERR_BAD_BAM     (-4)   /* not a BGZF/BAM image, or a truncated / corrupt one */
+#define XMH_NEED_TEXT       1     /* xmh_parse_pre: a record of this window must be split by the text rules; call xmh_parse */
 
 /* which optional fields feed the score columns (the three tag_func plugins) */
 #define XMH_SCORE_AS_XS 0   /* get_tag                 xenomapper.py:176-191 */
@@ -82,6 +83,8 @@ typedef struct {
     uint64_t n_exc;
     const uint32_t *exc_record;
     const uint8_t  *exc_col, *exc_kind;
+    /* lines of each window in front of consumed1 / consumed2 (skipped repeats included) */
+    uint64_t consumed_lines1, consumed_lines2;
 } xmh_block;
 
 int xmh_abi_version(void);
@@ -125,6 +128,38 @@ int xmh_bam_header(xmh_bam *b, const char **text, uint64_t *len);
 /* Append the SAM lines of the next alignments to dst (whole lines only, at most cap bytes; cap must hold at
  * least one line).  *eof = 1 once every alignment has been returned. */
 int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof);
+
+/*
+ * BAM already holds what the stripper would have to dig out of the text again: AS / XS / ZS / NM as typed values and the
+ * CIGAR as len << 4 | op words.  xmh_bam_read_pre is xmh_bam_read that also describes every line it
+ * writes, in order -- the tag_func plugins' rules (xenomapper.py:186-190 substring match with the duplicate error, :247
+ * first NM match, :251 the CIGAR operations "MIDNSHP=X") applied to the typed fields:
+ *   a tag is matched by the field of that name and by any Z / H field whose printed text contains the two letters; an
+ *   integer-typed match inside [-(2^31-1), 2^31-1] gives the value, any other match XMH_EX_NONINT (the host re-reads that
+ *   record's text with the reference-equivalent plugin), two matches XMH_EX_DUP (NM: the first match counts).
+ * XMH_PRE_WEIRD marks a line the text rules might split differently (white space, control or non-ASCII bytes in a name,
+ * tag or string value): xmh_parse_pre then answers XMH_NEED_TEXT and the window goes through xmh_parse as before.
+ * pre / ops: caller arrays of pre_cap / ops_cap entries; the call stops early (as when dst is full) rather than overrun them.
+ */
+#define XMH_PRE_WEIRD 1
+typedef struct {
+    uint32_t line_len;                      /* bytes of the line without its '\n' */
+    uint16_t name_len;                      /* bytes of QNAME, the first field */
+    uint8_t  flags;                         /* XMH_PRE_* */
+    uint8_t  ex_as, ex_xs, ex_zs, ex_nm;    /* 0, XMH_EX_NONINT or XMH_EX_DUP */
+    uint8_t  pad_;
+    int32_t  as, xs, zs, nm;                /* INT32_MIN: no field matches the tag */
+    uint32_t n_ops, ops_at;                 /* CIGAR operations with codes 0..8, in order: ops[ops_at .. ops_at + n_ops) */
+} xmh_pre;
+int xmh_bam_read_pre(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof,
+                     xmh_pre *pre, uint64_t pre_cap, uint64_t *n_pre, uint32_t *ops, uint64_t ops_cap, uint64_t *n_ops);
+
+/* xmh_parse on windows of text that xmh_bam_read_pre wrote, without tokenising it again: pre1 / pre2 describe the lines
+ * from the first byte of buf1 / buf2 on (entries past the window are ignored), ops1 / ops2 are the arrays their ops_at
+ * refer to.  Same results as xmh_parse, or XMH_NEED_TEXT (nothing parsed) when a line is marked XMH_PRE_WEIRD. */
+int xmh_parse_pre(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const xmh_pre *pre1, uint64_t n_pre1, const uint32_t *ops1,
+                  const char *buf2, uint64_t len2, int eof2, const xmh_pre *pre2, uint64_t n_pre2, const uint32_t *ops2,
+                  int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out);
 
 #ifdef __cplusplus
 }

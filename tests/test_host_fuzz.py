@@ -230,3 +230,155 @@ def test_bam_decoder_agrees_with_the_spec_restatement(image, threads, cap):
     r.close()
     assert got_header == want_header
     assert b"".join(parts).decode("latin-1") == "".join(l + "\n" for l in want_lines)
+
+
+# ---- BAM line descriptions (xmh_bam_read_pre / xmh_parse_pre) against the text rules ------------------------------------
+
+_SCORE_TAGS = st.sampled_from(["AS", "XS", "ZS", "NM", "AS", "XS", "YS", "XA", "SA", "MN", "NH"])
+
+
+@st.composite
+def score_tag(draw):
+    """Optional fields around the four tags the plugins look for: typed integers at and beyond the int32 edges, floats and
+    characters under those names, and strings that merely CONTAIN the letters (substring match, duplicate error)."""
+    tag = draw(_SCORE_TAGS).encode()
+    kind = draw(st.sampled_from(list("cCsSiIiiIfAZZH")))
+    if kind in _INT_TYPES:
+        lo, hi = _INT_TYPES[kind]
+        v = draw(st.one_of(st.integers(lo, hi), st.sampled_from([lo, hi, 0, max(lo, -2**31 + 1), min(hi, 2**31 - 1)])))
+        return tag + kind.encode() + struct.pack(bam_oracle._SCALAR[kind], v)
+    if kind == "f":
+        return tag + b"f" + struct.pack("<f", draw(st.sampled_from([0.0, 12.0, -3.5, 1e10])))
+    if kind == "A":
+        return tag + b"A" + draw(st.sampled_from(list("+-S7"))).encode()
+    if kind == "Z":
+        return tag + b"Z" + draw(st.text(alphabet="ASXZNM12:- ", max_size=10)).encode() + b"\0"
+    return tag + b"H" + draw(st.text(alphabet="0123456789ABCDEF", max_size=6)).encode() + b"\0"
+
+
+def _bam_image_of(records, refs=("chr1", "chrX")):
+    head = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", len(refs))
+    for r in refs:
+        rn = r.encode() + b"\0"
+        head += struct.pack("<i", len(rn)) + rn + struct.pack("<i", 1000)
+    payload = head + b"".join(records)
+    out = []
+    for at in range(0, len(payload), 3000):
+        part = payload[at:at + 3000]
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = comp.compress(part) + comp.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                   struct.pack("<II", zlib.crc32(part), len(part)))
+    return b"".join(out)
+
+
+@st.composite
+def bam_file_pair(draw):
+    n = draw(st.integers(0, 40))
+    names = []
+    for _ in range(n):
+        if names and draw(st.integers(0, 2)) == 0:
+            names.append(names[-1])                                  # mates / repeated names
+        else:
+            names.append(draw(st.text(alphabet="abXY01:/", min_size=1, max_size=8)))
+    odd = draw(st.integers(0, 9)) == 0                               # now and then a name the text rules would split
+    images = []
+    for f in (0, 1):
+        recs = []
+        for k, nm in enumerate(names):
+            name = ((nm + " x") if (odd and k == n // 2 and f == 0) else nm).encode() + b"\0"
+            cigar = draw(st.lists(st.tuples(st.integers(0, 2**28 - 1), st.integers(0, 10)), max_size=5))
+            l_seq = draw(st.sampled_from([0, 3, 20]))
+            seq = bytes(draw(st.lists(st.integers(0, 255), min_size=(l_seq + 1) // 2, max_size=(l_seq + 1) // 2)))
+            qual = bytes(draw(st.lists(st.integers(0, 93), min_size=l_seq, max_size=l_seq)))
+            tags = b"".join(draw(st.lists(st.one_of(score_tag(), score_tag(), bam_tag()), max_size=5)))
+            core = struct.pack("<iiBBHHHIiii", draw(st.integers(-1, 1)), draw(st.integers(-1, 10**6)), len(name), 30, 4680,
+                               len(cigar), draw(st.integers(0, 4095)), l_seq, -1, -1, 0)
+            body = core + name + b"".join(struct.pack("<I", (ln << 4) | op) for ln, op in cigar) + seq + qual + tags
+            recs.append(struct.pack("<I", len(body)) + body)
+        if f == 1 and recs and draw(st.integers(0, 5)) == 0:
+            recs = recs[:draw(st.integers(0, len(recs)))]            # the second file ends early
+        images.append(_bam_image_of(recs))
+    return images
+
+
+def _decode_with_descriptions(image, threads, cap):
+    from xenomapper_amd import _host
+    r = _host.BamReader(np.frombuffer(image, dtype=np.uint8), threads)
+    buf = np.empty(1 << 22, dtype=np.uint8)
+    at, pres, opss = 0, [], []
+    while not r.eof:
+        view = buf[:min(buf.shape[0], at + cap)]                     # small capacities: lines left pending between calls
+        got, pre, ops = r.read_into_pre(view, at)
+        if got == 0 and not r.eof:
+            cap *= 2
+            assert cap <= 1 << 22
+            continue
+        q = pre.copy()
+        q[:, _host.PRE_OPS_AT] += np.uint32(sum(o.shape[0] for o in opss))
+        pres.append(q)
+        opss.append(ops.copy())
+        at += got
+    r.close()
+    pre = np.concatenate(pres) if pres else np.zeros((0, _host.PRE_WORDS), dtype=np.uint32)
+    ops = np.concatenate(opss) if opss else np.zeros(0, dtype=np.uint32)
+    return buf[:at].copy(), pre, ops
+
+
+def _blocks_equal(a, b, cigar):
+    assert (a.n, a.consumed, a.consumed_lines, a.ended, a.starved, a.mismatch_at) == \
+           (b.n, b.consumed, b.consumed_lines, b.ended, b.starved, b.mismatch_at)
+    for x, y in zip(a.cols, b.cols):
+        if cigar:
+            x, y = x[:0], y[:0]                                      # the AS columns are not filled in CIGAR mode ...
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.cols[1], b.cols[1]) and np.array_equal(a.cols[3], b.cols[3])      # ... the XS columns always are
+    assert np.array_equal(a.unit_bits[:(a.n + 63) // 64], b.unit_bits[:(b.n + 63) // 64])
+    if cigar:
+        for f in (0, 1):
+            for x, y in zip(a.csr[f], b.csr[f]):
+                assert np.array_equal(x, y)
+    for f in (0, 1):
+        assert np.array_equal(a.line_off[f], b.line_off[f]) and np.array_equal(a.line_len[f], b.line_len[f])
+    assert a.exc == b.exc
+
+
+@settings(max_examples=int(os.environ.get('XM_FUZZ_EXAMPLES', '120')), deadline=None, suppress_health_check=list(HealthCheck))
+@given(images=bam_file_pair(), threads=st.sampled_from([1, 4]), cap=st.sampled_from([300, 1 << 12, 1 << 20]),
+       score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans(), skip=st.booleans(), halo=st.booleans(),
+       max_records=st.sampled_from([1 << 20, 7]))
+def test_bam_line_descriptions_give_what_the_text_rules_give(images, threads, cap, score_mode, paired, skip, halo, max_records):
+    """xmh_parse_pre (the stripper fed by the BAM decoder's own knowledge of every line: typed AS / XS / ZS / NM, CIGAR
+    operations) must return exactly what xmh_parse returns after tokenising the printed text -- columns, CIGAR CSR,
+    unit mask, line index, exceptions (non-integers, duplicate and substring matches), consumed bytes and lines -- or
+    decline (a line marked XMH_PRE_WEIRD), and it may only decline for lines the text rules could really split."""
+    from xenomapper_amd import _host
+    t1, p1, o1 = _decode_with_descriptions(images[0], threads, cap)
+    t2, p2, o2 = _decode_with_descriptions(images[1], threads, cap)
+    v1, v2 = _host.pre_view(p1), _host.pre_view(p2)
+    for text, pre in ((t1, v1), (t2, v2)):
+        lines = bytes(text).split(b"\n")[:-1] if text.shape[0] else []
+        assert [len(l) for l in lines] == pre["line_len"].tolist()
+        for l, q in zip(lines, pre):
+            risky = any(c <= 0x20 and c != 9 or c >= 0x7F for c in l) or l.startswith(b"\t") or b"\t\t" in l
+            assert bool(q["flags"] & 1) == risky, l
+    a = _host.Parser(threads)
+    b = _host.Parser(threads)
+    try:
+        want = a.parse(t1, 0, t1.shape[0], True, t2, 0, t2.shape[0], True, score_mode, paired, skip, halo, max_records)
+        got = b.parse_pre(t1, 0, t1.shape[0], True, p1, o1, t2, 0, t2.shape[0], True, p2, o2, score_mode, paired, skip, halo,
+                          max_records)
+        if got is None:
+            assert bool((v1["flags"] & 1).any() or (v2["flags"] & 1).any())
+        else:
+            assert not bool((v1["flags"] & 1).any() or (v2["flags"] & 1).any())
+            _blocks_equal(got, want, score_mode == 2)
+        # a window that ends inside a line: the same lines are seen complete
+        if t1.shape[0] > 5 and t2.shape[0] > 5 and got is not None:
+            c1, c2 = t1.shape[0] - 3, t2.shape[0] - 3
+            want = a.parse(t1, 0, c1, False, t2, 0, c2, False, score_mode, paired, skip, halo, max_records)
+            got = b.parse_pre(t1, 0, c1, False, p1, o1, t2, 0, c2, False, p2, o2, score_mode, paired, skip, halo, max_records)
+            _blocks_equal(got, want, score_mode == 2)
+    finally:
+        a.close()
+        b.close()

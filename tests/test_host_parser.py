@@ -1,6 +1,7 @@
 """The C++ SAM column stripper / line writer (libxenomapper_host.so) against the oracle's text-level
 restatement, on every golden end-to-end input plus newline / whitespace / error edge cases.  CPU only."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -699,3 +700,48 @@ def test_writer_fills_the_mapped_output_file_directly(tmp_path, monkeypatch):
     with open(tmp_path / "off.sam", "wt") as sink:
         assert xm._emit_into_file(parser, True, 0, idx, sink) is False
     parser.close()
+
+
+@pytest.mark.parametrize("cap", [1 << 16, 1 << 20, 1 << 24])
+def test_bam_line_descriptions_over_many_batches_and_pending_lines(cap, tmp_path):
+    """xmh_bam_read_pre on an input of many BGZF batches read through small and large buffers (lines left pending between
+    calls, batches in which some workers own no record): every call's descriptions must describe exactly the lines it
+    wrote -- same text as xmh_bam_read, line lengths adding up, names and CIGAR operations in place."""
+    import sys
+    sys.path.insert(0, os.path.join(H.REPO, "tools"))
+    import bench_bam
+    from xenomapper_amd import _host
+    path = str(tmp_path / "tiled.bam")
+    bench_bam.tiled_bam(os.path.join(H.GOLDEN, "ref_data", "paired_end_testdata_human.bam"), path, 60)
+    data = np.fromfile(path, dtype=np.uint8)
+    plain = _host.BamReader(data, 8)
+    big = np.empty(1 << 25, dtype=np.uint8)
+    n = 0
+    while not plain.eof:
+        n += plain.read_into(big, n)
+    plain.close()
+    want = bytes(big[:n])
+    r = _host.BamReader(data, 8)
+    buf = np.empty(cap, dtype=np.uint8)
+    got, lines = [], 0
+    while not r.eof:
+        w, pre, ops = r.read_into_pre(buf, 0)
+        pre = _host.pre_view(pre)
+        assert w > 0 or r.eof
+        chunk = bytes(buf[:w])
+        assert int(pre["line_len"].sum(dtype=np.int64)) + pre.shape[0] == w
+        at = 0
+        for q in pre[:50]:                                           # spot checks: the name and the CIGAR of the first lines
+            line = chunk[at:at + int(q["line_len"])]
+            f = line.split(b"\t")
+            assert len(f[0]) == int(q["name_len"]) and not q["flags"]
+            cig = [] if f[5] == b"*" else [(int(a), b"MIDNSHP=X".index(o)) for a, o in __import__("re").findall(rb"([0-9]+)([MIDNSHPX=])", f[5])]
+            assert [(int(v) >> 4, int(v) & 15) for v in ops[int(q["ops_at"]):int(q["ops_at"]) + int(q["n_ops"])]] == cig
+            tags = {t[:2]: t for t in f[11:]}
+            for key, col in ((b"AS", "as"), (b"XS", "xs"), (b"NM", "nm")):
+                assert int(q[col]) == (int(tags[key].split(b":")[-1]) if key in tags else -2**31)
+            at += int(q["line_len"]) + 1
+        got.append(chunk)
+        lines += pre.shape[0]
+    r.close()
+    assert b"".join(got) == want and lines == want.count(b"\n")

@@ -15,7 +15,21 @@ EX_NONINT, EX_DUP, EX_SHORT, EX_BIGLEN = 1, 2, 3, 4
 ERR_NON_ASCII = -3
 
 EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_default_threads", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
-            "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read")
+            "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read", "xmh_bam_read_pre", "xmh_parse_pre")
+NEED_TEXT = 1
+# xmh_pre (include/xenomapper_host.h): what the BAM decoder knows about every line it prints
+PRE_DTYPE = np.dtype([("line_len", np.uint32), ("name_len", np.uint16), ("flags", np.uint8), ("ex_as", np.uint8),
+                      ("ex_xs", np.uint8), ("ex_zs", np.uint8), ("ex_nm", np.uint8), ("pad", np.uint8),
+                      ("as", np.int32), ("xs", np.int32), ("zs", np.int32), ("nm", np.int32),
+                      ("n_ops", np.uint32), ("ops_at", np.uint32)], align=True)
+assert PRE_DTYPE.itemsize == 36
+PRE_WORDS = 9            # the arrays travel as uint32[n, 9] (plain copies; numpy moves structured arrays field by field):
+PRE_LINE_LEN, PRE_OPS_AT = 0, 8        # ... columns that are whole words
+
+
+def pre_view(pre):
+    """The named fields of a uint32[n, 9] description array (a view)."""
+    return np.ascontiguousarray(pre).view(PRE_DTYPE).reshape(-1)
 
 _P = ctypes.c_void_p
 
@@ -27,7 +41,8 @@ class _Block(ctypes.Structure):
                 ("cig_off1", _P), ("cig_off2", _P), ("cig_ops1", _P), ("cig_ops2", _P), ("unit_bits", _P),
                 ("line_off1", _P), ("line_off2", _P), ("line_len1", _P), ("line_len2", _P),
                 ("norm_len1", _P), ("norm_len2", _P), ("line_flags1", _P), ("line_flags2", _P),
-                ("n_exc", ctypes.c_uint64), ("exc_record", _P), ("exc_col", _P), ("exc_kind", _P)]
+                ("n_exc", ctypes.c_uint64), ("exc_record", _P), ("exc_col", _P), ("exc_kind", _P),
+                ("consumed_lines1", ctypes.c_uint64), ("consumed_lines2", ctypes.c_uint64)]
 
 
 class NonAsciiInput(Exception):
@@ -58,6 +73,12 @@ def lib():
         L.xmh_bam_close.argtypes = [_P]
         L.xmh_bam_header.argtypes = [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_bam_read.argtypes = [_P, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+        L.xmh_bam_read_pre.argtypes = [_P, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int),
+                                       _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), _P, ctypes.c_uint64,
+                                       ctypes.POINTER(ctypes.c_uint64)]
+        L.xmh_parse_pre.argtypes = [_P, _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P,
+                                    _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_Block)]
         _lib = L
     return _lib
 
@@ -75,6 +96,7 @@ class Block(object):
     def __init__(self, raw, cigar):
         n = self.n = int(raw.n_records)
         self.consumed = (int(raw.consumed1), int(raw.consumed2))
+        self.consumed_lines = (int(raw.consumed_lines1), int(raw.consumed_lines2))
         self.ended, self.starved, self.mismatch_at = bool(raw.ended), bool(raw.starved), int(raw.mismatch_at)
         self.cols = [_view(p, n, np.int32) for p in (raw.as1, raw.xs1, raw.as2, raw.xs2)]
         self.unit_bits = _view(raw.unit_bits, (n + 63) // 64, np.uint64)
@@ -127,6 +149,27 @@ class Parser(object):
             raise RuntimeError("xmh_parse: " + self._L.xmh_strerror(rc).decode())
         self._win = (p1, p2)
         self._keep = (arr1, arr2)            # the windows must outlive emit()
+        return Block(raw, score_mode == SCORE_CIGAR)
+
+    def parse_pre(self, arr1, pos1, len1, eof1, pre1, ops1, arr2, pos2, len2, eof2, pre2, ops2, score_mode, paired, skip_repeated,
+                  keep_halo, max_records):
+        """parse() on windows of text the BAM decoder wrote, from its line descriptions (pre*: PRE_DTYPE arrays for the lines
+        from pos* on, ops*: the uint32 arrays their ops_at index) instead of tokenising the text again.  None: a line
+        needs the text rules -- call parse() on the same windows.  pre*: uint32[n, 9] as read_into_pre returns them."""
+        raw = _Block()
+        p1 = arr1.ctypes.data + pos1 if len1 else None
+        p2 = arr2.ctypes.data + pos2 if len2 else None
+        rc = self._L.xmh_parse_pre(self._h, p1, len1, int(eof1), pre1.ctypes.data if pre1.shape[0] else None, pre1.shape[0],
+                                   ops1.ctypes.data if ops1.shape[0] else None,
+                                   p2, len2, int(eof2), pre2.ctypes.data if pre2.shape[0] else None, pre2.shape[0],
+                                   ops2.ctypes.data if ops2.shape[0] else None,
+                                   score_mode, int(paired), int(skip_repeated), int(keep_halo), int(max_records), ctypes.byref(raw))
+        if rc == NEED_TEXT:
+            return None
+        if rc != 0:
+            raise RuntimeError("xmh_parse_pre: " + self._L.xmh_strerror(rc).decode())
+        self._win = (p1, p2)
+        self._keep = (arr1, arr2, pre1, ops1, pre2, ops2)
         return Block(raw, score_mode == SCORE_CIGAR)
 
     def emit_size(self, paired, bin_index, idx):
@@ -207,6 +250,22 @@ class BamReader(object):
         text, n = _P(), ctypes.c_uint64()
         self._L.xmh_bam_header(self._h, ctypes.byref(text), ctypes.byref(n))
         return ctypes.string_at(text, n.value).decode("ascii") if n.value else ""
+
+    def read_into_pre(self, out, start):
+        """read_into() that also returns what the decoder knows about the lines it wrote:
+        -> (bytes written, uint32[n, 9] descriptions of the lines (pre_view() names the fields), uint32 array of their
+        CIGAR operations)."""
+        cap = out.shape[0] - start
+        pre = np.empty((cap // 24 + 16, PRE_WORDS), dtype=np.uint32)   # no SAM line of 11 fields is shorter than 21 bytes + '\n'
+        ops = np.empty(max(cap // 8, 1 << 16), dtype=np.uint32)
+        w, eof, n_pre, n_ops = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = self._L.xmh_bam_read_pre(self._h, out.ctypes.data + start, cap, ctypes.byref(w), ctypes.byref(eof),
+                                      pre.ctypes.data, pre.shape[0], ctypes.byref(n_pre), ops.ctypes.data, ops.shape[0],
+                                      ctypes.byref(n_ops))
+        if rc != 0:
+            raise ValueError("xmh_bam_read_pre: " + self._L.xmh_strerror(rc).decode())
+        self.eof = bool(eof.value)
+        return int(w.value), pre[:n_pre.value], ops[:n_ops.value]
 
     def read_into(self, out, start):
         """Append whole SAM lines to the uint8 array `out` from offset `start`; returns bytes written."""

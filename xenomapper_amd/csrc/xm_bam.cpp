@@ -196,6 +196,8 @@ struct BamWorker {
     std::unique_ptr<char[]> text;       // formatted lines of this worker's records (uninitialised storage, reused)
     size_t text_cap = 0, text_len = 0, n_rec = 0;
     std::vector<uint64_t> rec;          // stream offsets of this worker's records in the current batch
+    std::vector<xmh_pre> pre;           // what the stripper would dig out of each line again (xmh_bam_read_pre)
+    std::vector<uint32_t> ops;          // CIGAR operations the pre records point into
     bool ok = true;
 };
 
@@ -214,6 +216,11 @@ struct xmh_bam {
     bool header_done = false;
     std::vector<char> pending;          // formatted lines that did not fit the caller's buffer, from pending_pos
     size_t pending_pos = 0;
+    std::vector<xmh_pre> pending_pre;   // their descriptions, from pending_pre_pos (ops_at counts into pending_ops)
+    std::vector<uint32_t> pending_ops;
+    size_t pending_pre_pos = 0;
+    bool want_pre = false;              // the current read call asked for descriptions
+    std::vector<uint8_t> ref_weird;     // reference names the text rules might split
 
     // make at least `want` bytes available after stream.pos (or reach the end of the file): one parallel pass
     // over as many blocks as that takes
@@ -257,6 +264,21 @@ struct xmh_bam {
 
 namespace {
 
+// a byte the text rules (Python's str.split(), ASCII input only) might treat specially
+inline bool odd_byte(uint8_t c) { return c <= 0x20 || c >= 0x7F; }
+inline bool odd_bytes(const uint8_t *s, size_t n)
+{
+    uint8_t any = 0;
+    for (size_t i = 0; i < n; ++i) any |= (uint8_t)(odd_byte(s[i]) ? 1 : 0);
+    return any != 0;
+}
+inline bool has2(const uint8_t *s, size_t n, char c0, char c1)
+{
+    for (size_t i = 0; i + 1 < n; ++i)
+        if (s[i] == (uint8_t)c0 && s[i + 1] == (uint8_t)c1) return true;
+    return false;
+}
+
 bool read_header(xmh_bam *b)
 {
     if (!b->fill(12) || b->avail() < 12 || memcmp(b->cur(), "BAM\1", 4) != 0) return false;
@@ -273,6 +295,7 @@ bool read_header(xmh_bam *b)
         std::string name((const char *)b->cur() + 4, l_name);
         while (!name.empty() && name.back() == '\0') name.pop_back();
         b->ref_names.push_back(name);
+        b->ref_weird.push_back((uint8_t)((name.empty() || odd_bytes((const uint8_t *)name.data(), name.size())) ? 1 : 0));
         b->stream.pos += 8 + l_name;
     }
     b->header_done = true;
@@ -331,12 +354,38 @@ inline uint64_t real_cigar_field(const uint8_t *r, uint32_t size, uint64_t aux0,
     return 0;
 }
 
+// the four tags of the tag_func plugins, matched as the text rules match them (header: xmh_bam_read_pre)
+struct TagScan {
+    uint32_t n[4] = {0, 0, 0, 0};             // matches of AS, XS, ZS, NM
+    int32_t v[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+    uint8_t ex[4] = {0, 0, 0, 0};
+    void hit(int k, bool is_int, int64_t val)
+    {
+        if (++n[k] != 1) return;                                  // only the first match carries a value
+        if (is_int && val >= -2147483647ll && val <= 2147483647ll) v[k] = (int32_t)val;
+        else ex[k] = XMH_EX_NONINT;
+    }
+    void finish(xmh_pre &q) const
+    {
+        q.as = v[0]; q.xs = v[1]; q.zs = v[2]; q.nm = v[3];
+        q.ex_as = n[0] > 1 ? XMH_EX_DUP : ex[0];
+        q.ex_xs = n[1] > 1 ? XMH_EX_DUP : ex[1];
+        q.ex_zs = n[2] > 1 ? XMH_EX_DUP : ex[2];
+        q.ex_nm = ex[3];                                          // NM: the first match decides, no duplicate rule (:247-250)
+    }
+};
+const char TAGS[4][2] = {{'A', 'S'}, {'X', 'S'}, {'Z', 'S'}, {'N', 'M'}};
+
 // one alignment record (without its block_size word) -> one SAM line at o, the way `samtools view` prints it.
 // Returns the end of the line, or nullptr for a malformed record.  The caller guarantees room for 5 * size + 128
 // bytes plus the longest reference name twice.
-char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
+// q / qops (may be null): the line's description for xmh_parse_pre and the array its CIGAR operations are appended to.
+char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o, xmh_pre *q = nullptr, std::vector<uint32_t> *qops = nullptr)
 {
     if (size < 32) return nullptr;
+    char *const line0 = o;
+    bool weird = false;
+    TagScan scan;
     const int32_t ref_id = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
     const uint32_t l_read_name = r[8], mapq = r[9], n_cigar = le16(r + 12), flag = le16(r + 14);
     const uint32_t l_seq = le32(r + 16);
@@ -346,6 +395,12 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
     if (need > size || l_read_name == 0) return nullptr;
     const size_t nl = strnlen((const char *)r + p, l_read_name);
     memcpy(o, r + p, nl);
+    if (q) {
+        weird |= nl == 0 || nl > 0xFFFF || odd_bytes(r + p, nl);
+        q->name_len = (uint16_t)nl;
+        if (ref_id >= 0 && (size_t)ref_id < b->ref_weird.size()) weird |= b->ref_weird[(size_t)ref_id] != 0;
+        if (next_ref >= 0 && (size_t)next_ref < b->ref_weird.size()) weird |= b->ref_weird[(size_t)next_ref] != 0;
+    }
     o += nl;
     p += l_read_name;
     *o++ = '\t'; o = put_uint(o, flag);
@@ -359,11 +414,14 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
     const uint8_t *ops = cg_at ? r + cg_at + 8 : r + p;
     const uint32_t n_ops = cg_at ? cg_count : n_cigar;
     if (n_ops == 0) *o++ = '*';
+    if (q) { q->ops_at = (uint32_t)qops->size(); }
     for (uint32_t k = 0; k < n_ops; ++k) {
         const uint32_t v = le32(ops + 4ull * k);
         o = put_uint(o, v >> 4);
         *o++ = "MIDNSHP=XB??????"[v & 15];
+        if (q && (v & 15u) <= 8u) qops->push_back(v);               // re.findall(r'([0-9]+)([MIDNSHPX=])'): other codes print letters it skips
     }
+    if (q) q->n_ops = (uint32_t)qops->size() - q->ops_at;
     p += 4ull * n_cigar;
     *o++ = '\t';
     if (next_ref < 0 || (size_t)next_ref >= b->ref_names.size()) *o++ = '*';
@@ -379,7 +437,9 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
     *o++ = '\t';
     if (l_seq == 0 || r[p] == 0xFF) *o++ = '*';
     else {
-        for (uint32_t k = 0; k < l_seq; ++k) o[k] = (char)(r[p + k] + 33);
+        uint8_t hi = 0;
+        for (uint32_t k = 0; k < l_seq; ++k) { const uint8_t c = (uint8_t)(r[p + k] + 33); o[k] = (char)c; hi |= c; }
+        weird |= (hi & 0x80) != 0;                                   // a quality above 94: not ASCII any more
         o += l_seq;
     }
     p += l_seq;
@@ -392,7 +452,28 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
         *o++ = '\t';
         *o++ = (char)r[p]; *o++ = (char)r[p + 1]; *o++ = ':';
         const char type = (char)r[p + 2];
+        const uint8_t t0 = r[p], t1 = r[p + 1];
+        char *const field0 = o - 3;
         p += 3;
+        if (q) {
+            weird |= odd_byte(t0) || odd_byte(t1);
+            int64_t ival = 0;
+            bool is_int = true;
+            switch (type) {
+            case 'c': ival = p + 1 <= size ? (int8_t)r[p] : 0; break;
+            case 'C': ival = p + 1 <= size ? r[p] : 0; break;
+            case 's': ival = p + 2 <= size ? (int16_t)le16(r + p) : 0; break;
+            case 'S': ival = p + 2 <= size ? le16(r + p) : 0; break;
+            case 'i': ival = p + 4 <= size ? (int32_t)le32(r + p) : 0; break;
+            case 'I': ival = p + 4 <= size ? (int64_t)le32(r + p) : 0; break;
+            default: is_int = false;
+            }
+            if (type != 'Z' && type != 'H') {                           // only the tag itself can hold the two letters
+                for (int k = 0; k < 4; ++k)
+                    if (t0 == (uint8_t)TAGS[k][0] && t1 == (uint8_t)TAGS[k][1]) scan.hit(k, is_int, ival);
+                if (type == 'A' && p + 1 <= size) weird |= odd_byte(r[p]);
+            }
+        }
         auto scalar = [&](char t) -> bool {                          // appends one value of type t, advances p
             switch (t) {
             case 'A': if (p + 1 > size) return false; *o++ = (char)r[p]; p += 1; return true;
@@ -436,6 +517,12 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
             if (p + l >= size) return nullptr;
             memcpy(o, r + p, l);
             o += l;
+            if (q) {                                                    // the printed field "TG:Z:value" as the text rules see it
+                weird |= odd_bytes(r + p, l);
+                const size_t fl = (size_t)(o - field0);
+                for (int k = 0; k < 4; ++k)
+                    if (has2((const uint8_t *)field0, fl, TAGS[k][0], TAGS[k][1])) scan.hit(k, false, 0);
+            }
             p += l + 1;
         } else if (type == 'B') {
             if (p + 5 > size) return nullptr;
@@ -446,24 +533,68 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o)
             for (uint32_t k = 0; k < cnt; ++k) { *o++ = ','; if (!scalar(sub)) return nullptr; }
         } else return nullptr;
     }
+    if (q) {
+        q->line_len = (uint32_t)(o - line0);
+        q->flags = weird ? XMH_PRE_WEIRD : 0;
+        q->pad_ = 0;
+        scan.finish(*q);
+    }
     *o++ = '\n';
     return p == size ? o : nullptr;
 }
 
+// where a read call puts the descriptions of the lines it hands out (null: none wanted)
+struct PreOut {
+    xmh_pre *pre;
+    uint64_t pre_cap, n_pre;
+    uint32_t *ops;
+    uint64_t ops_cap, n_ops;
+};
+
 // hand out pending text in whole lines; returns bytes copied (0 when the first pending line does not fit)
-uint64_t take_pending(xmh_bam *b, char *dst, uint64_t cap)
+uint64_t take_pending(xmh_bam *b, char *dst, uint64_t cap, PreOut *po)
 {
     const size_t have = b->pending.size() - b->pending_pos;
     if (have == 0) return 0;
     size_t take = have;
-    if (take > cap) {
+    if (po) {
+        // line by line: the text, the description and the operations must all fit
+        take = 0;
+        size_t k = b->pending_pre_pos;
+        while (k < b->pending_pre.size()) {
+            const xmh_pre &q = b->pending_pre[k];
+            if (take + q.line_len + 1 > cap || po->n_pre + (k - b->pending_pre_pos) + 1 > po->pre_cap) break;
+            const uint64_t ops_so_far = (uint64_t)q.ops_at + q.n_ops - b->pending_pre[b->pending_pre_pos].ops_at;
+            if (po->n_ops + ops_so_far > po->ops_cap) break;
+            take += (size_t)q.line_len + 1;
+            ++k;
+        }
+        const size_t n_lines = k - b->pending_pre_pos;
+        if (n_lines) {
+            const uint32_t ops0 = b->pending_pre[b->pending_pre_pos].ops_at;
+            const xmh_pre &last = b->pending_pre[k - 1];
+            const uint32_t ops1 = last.ops_at + last.n_ops;
+            for (size_t i = 0; i < n_lines; ++i) {
+                xmh_pre q = b->pending_pre[b->pending_pre_pos + i];
+                q.ops_at = q.ops_at - ops0 + (uint32_t)po->n_ops;
+                po->pre[po->n_pre + i] = q;
+            }
+            if (ops1 > ops0) memcpy(po->ops + po->n_ops, b->pending_ops.data() + ops0, (size_t)(ops1 - ops0) * 4);
+            po->n_pre += n_lines;
+            po->n_ops += ops1 - ops0;
+            b->pending_pre_pos = k;
+        }
+    } else if (take > cap) {
         const char *base = b->pending.data() + b->pending_pos;
         const void *nl = cap ? memrchr(base, '\n', (size_t)cap) : nullptr;
         take = nl ? (size_t)((const char *)nl - base) + 1 : 0;
     }
     memcpy(dst, b->pending.data() + b->pending_pos, take);
     b->pending_pos += take;
-    if (b->pending_pos == b->pending.size()) { b->pending.clear(); b->pending_pos = 0; }
+    if (b->pending_pos == b->pending.size()) {
+        b->pending.clear(); b->pending_pos = 0;
+        b->pending_pre.clear(); b->pending_ops.clear(); b->pending_pre_pos = 0;
+    }
     return take;
 }
 
@@ -515,7 +646,9 @@ bool produce_batch(xmh_bam *b, size_t budget, size_t *n_records, int *n_workers)
             range[(size_t)t] = i < nb ? off[i] : acc;
         }
     }
-    for (auto &w : b->workers) { w.ok = true; w.text_len = 0; w.n_rec = 0; }
+    for (auto &w : b->workers) { w.ok = true; w.text_len = 0; w.n_rec = 0; w.pre.clear(); w.ops.clear(); }
+    static const bool profile = getenv("XMH_PROFILE") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     uint8_t *sp = st.data();
     b->pool->run(nt, [&](int t) {
         BamWorker &w = b->workers[(size_t)t];
@@ -527,6 +660,7 @@ bool produce_batch(xmh_bam *b, size_t budget, size_t *n_records, int *n_workers)
     for (int t = 0; t < nt; ++t)
         if (!b->workers[(size_t)t].ok) return false;
     b->next_block += nb;
+    const auto tp1 = std::chrono::steady_clock::now();
 
     size_t longest_ref = 0;
     for (auto &name : b->ref_names) longest_ref = std::max(longest_ref, name.size());
@@ -557,9 +691,20 @@ bool produce_batch(xmh_bam *b, size_t budget, size_t *n_records, int *n_workers)
             w.text_cap = room;
         }
         char *o = w.text.get();
-        for (uint64_t at : w.rec) {
-            o = format_record(b, sp + at + 4, le32(sp + at), o);
-            if (!o) { w.ok = false; return; }
+        w.pre.clear();
+        w.ops.clear();
+        if (b->want_pre) {
+            w.pre.resize(w.rec.size());
+            size_t k = 0;
+            for (uint64_t at : w.rec) {
+                o = format_record(b, sp + at + 4, le32(sp + at), o, &w.pre[k++], &w.ops);
+                if (!o) { w.ok = false; return; }
+            }
+        } else {
+            for (uint64_t at : w.rec) {
+                o = format_record(b, sp + at + 4, le32(sp + at), o);
+                if (!o) { w.ok = false; return; }
+            }
         }
         w.text_len = (size_t)(o - w.text.get());
         w.n_rec = w.rec.size();
@@ -571,6 +716,15 @@ bool produce_batch(xmh_bam *b, size_t budget, size_t *n_records, int *n_workers)
         text += b->workers[(size_t)t].text_len;
     }
     const uint64_t done = chain[(size_t)nt].load(std::memory_order_acquire);
+    if (profile) {
+        const auto tp2 = std::chrono::steady_clock::now();
+        static double acc_inf = 0, acc_print = 0, acc_bytes = 0, acc_text = 0;
+        acc_inf += std::chrono::duration<double, std::milli>(tp1 - tp0).count();
+        acc_print += std::chrono::duration<double, std::milli>(tp2 - tp1).count();
+        acc_bytes += (double)(acc - old_end);
+        acc_text += (double)text;
+        fprintf(stderr, "produce_batch totals: inflate %.1f ms (%.1f MB)  chain+print %.1f ms (%.1f MB text)\n", acc_inf, acc_bytes / 1e6, acc_print, acc_text / 1e6);
+    }
     if (n) b->text_per_byte = std::max(1.0, (double)text / (double)done);
     st.pos = (size_t)done;
     *n_records = n;
@@ -619,14 +773,16 @@ int xmh_bam_header(xmh_bam *b, const char **text, uint64_t *len)
     return XMH_OK;
 }
 
-int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof)
+static int bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof, PreOut *po)
 {
     if (!b || !dst || !written || !eof) return XMH_ERR_INVALID_ARG;
+    if (po && !b->pending.empty() && b->pending_pre.empty()) return XMH_ERR_INVALID_ARG;   // text left over by a plain read
     try {
         static const bool profile = getenv("XMH_PROFILE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         *eof = 0;
-        uint64_t w = take_pending(b, dst, cap);
+        b->want_pre = po != nullptr;
+        uint64_t w = take_pending(b, dst, cap, po);
         *written = w;
         // batches small enough for a worker's share to stay in its cache between inflating, scanning and printing
         const size_t batch_max = (size_t)b->pool->size() << 21;
@@ -635,6 +791,7 @@ int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eo
             if (b->next_block >= b->blocks.size() && b->avail() == 0) break;
             const uint64_t room = cap - w;
             if (w > 0 && room < (64u << 10)) break;                  // close enough to full
+            if (po && w > 0 && (po->pre_cap - po->n_pre < 4096 || po->ops_cap - po->n_ops < 65536)) break;
             const size_t fit = (size_t)((double)room / (b->text_per_byte * 1.02));
             budget = std::max(budget, std::min(batch_max, std::max<size_t>((size_t)64 << 10, fit)));
             size_t n_rec = 0;
@@ -651,20 +808,38 @@ int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eo
             }
             budget = 0;
             // whole worker buffers while they fit (copied in parallel), the rest becomes pending
-            std::vector<uint64_t> at((size_t)nt + 1, w);
+            std::vector<uint64_t> at((size_t)nt + 1, w), pat((size_t)nt + 1, po ? po->n_pre : 0), oat((size_t)nt + 1, po ? po->n_ops : 0);
             int whole = 0;
-            for (; whole < nt && at[(size_t)whole] + b->workers[(size_t)whole].text_len <= cap; ++whole)
-                at[(size_t)whole + 1] = at[(size_t)whole] + b->workers[(size_t)whole].text_len;
+            for (; whole < nt; ++whole) {
+                const BamWorker &wk = b->workers[(size_t)whole];
+                if (at[(size_t)whole] + wk.text_len > cap) break;
+                if (po && (pat[(size_t)whole] + wk.pre.size() > po->pre_cap || oat[(size_t)whole] + wk.ops.size() > po->ops_cap)) break;
+                at[(size_t)whole + 1] = at[(size_t)whole] + wk.text_len;
+                pat[(size_t)whole + 1] = pat[(size_t)whole] + wk.pre.size();
+                oat[(size_t)whole + 1] = oat[(size_t)whole] + wk.ops.size();
+            }
             b->pool->run(whole, [&](int t) {
                 const BamWorker &wk = b->workers[(size_t)t];
                 if (wk.text_len) memcpy(dst + at[(size_t)t], wk.text.get(), wk.text_len);
+                if (po) {
+                    const uint32_t shift = (uint32_t)oat[(size_t)t];
+                    xmh_pre *out = po->pre + pat[(size_t)t];
+                    for (size_t i = 0; i < wk.pre.size(); ++i) { out[i] = wk.pre[i]; out[i].ops_at += shift; }
+                    if (!wk.ops.empty()) memcpy(po->ops + oat[(size_t)t], wk.ops.data(), wk.ops.size() * 4);
+                }
             });
             w = at[(size_t)whole];
+            if (po) { po->n_pre = pat[(size_t)whole]; po->n_ops = oat[(size_t)whole]; }
             for (int t = whole; t < nt; ++t) {
                 const BamWorker &wk = b->workers[(size_t)t];
                 if (wk.text_len) b->pending.insert(b->pending.end(), wk.text.get(), wk.text.get() + wk.text_len);
+                if (po) {
+                    const uint32_t shift = (uint32_t)b->pending_ops.size();
+                    for (xmh_pre q : wk.pre) { q.ops_at += shift; b->pending_pre.push_back(q); }
+                    b->pending_ops.insert(b->pending_ops.end(), wk.ops.begin(), wk.ops.end());
+                }
             }
-            w += take_pending(b, dst + w, cap - w);
+            w += take_pending(b, dst + w, cap - w, po);
         }
         *written = w;
         *eof = (b->pending.empty() && b->avail() == 0 && b->next_block >= b->blocks.size()) ? 1 : 0;
@@ -675,6 +850,22 @@ int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eo
     } catch (const std::bad_alloc &) {
         return XMH_ERR_OOM;
     }
+}
+
+int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof)
+{
+    return bam_read(b, dst, cap, written, eof, nullptr);
+}
+
+int xmh_bam_read_pre(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof,
+                     xmh_pre *pre, uint64_t pre_cap, uint64_t *n_pre, uint32_t *ops, uint64_t ops_cap, uint64_t *n_ops)
+{
+    if (!pre || !n_pre || !ops || !n_ops || pre_cap == 0) return XMH_ERR_INVALID_ARG;
+    PreOut po = {pre, pre_cap, 0, ops, ops_cap, 0};
+    const int rc = bam_read(b, dst, cap, written, eof, &po);
+    *n_pre = po.n_pre;
+    *n_ops = po.n_ops;
+    return rc;
 }
 
 }  // extern "C"

@@ -389,8 +389,88 @@ int xmh_parser_destroy(xmh_parser *p)
     return XMH_OK;
 }
 
-int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const char *buf2, uint64_t len2, int eof2,
-              int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out)
+// lines and records of one window from what the BAM decoder already knows about them (xmh_bam_read_pre): no byte of the
+// text is looked at.  false: a line the text rules might split differently -- the caller parses the text instead.
+static bool fill_from_pre(const xmh_pre *pre, uint64_t n_pre, const uint32_t *ops, uint64_t len, int score_mode, Pool &pool,
+                          FileParse &fp)
+{
+    // the lines that lie in the window completely (every line of BAM text ends with '\n'): line starts = prefix sums of
+    // the line lengths, in two parallel passes over the same slices
+    std::vector<uint64_t> part((size_t)pool.size() + 1, 0);
+    parallel_for(pool, n_pre, [&](int t, uint64_t b, uint64_t e) {
+        uint64_t sum = 0;
+        for (uint64_t i = b; i < e; ++i) sum += (uint64_t)pre[i].line_len + 1;
+        part[(size_t)t + 1] = sum;
+    });
+    for (size_t t = 1; t < part.size(); ++t) part[t] += part[t - 1];
+    fp.lines.resize((size_t)n_pre);
+    parallel_for(pool, n_pre, [&](int t, uint64_t b, uint64_t e) {
+        uint64_t at = part[(size_t)t];
+        for (uint64_t i = b; i < e; ++i) {
+            fp.lines[(size_t)i] = Line{at, pre[i].line_len};
+            at += (uint64_t)pre[i].line_len + 1;
+        }
+    });
+    uint64_t n = n_pre;                                  // the first line that does not end inside the window cuts the list
+    {
+        uint64_t lo = 0, hi = n_pre;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (fp.lines[(size_t)mid].off + fp.lines[(size_t)mid].len + 1 <= len) lo = mid + 1; else hi = mid;
+        }
+        n = lo;
+    }
+    fp.lines.resize((size_t)n);
+    const uint64_t off = n ? fp.lines[(size_t)n - 1].off + fp.lines[(size_t)n - 1].len + 1 : 0;
+    fp.complete_end = off;
+    fp.non_ascii = false;
+    fp.recs.resize((size_t)n);
+    if (fp.slots.size() < (size_t)pool.size()) fp.slots.resize((size_t)pool.size());
+    std::vector<uint8_t> weird((size_t)pool.size() + 1, 0);
+    const bool cigar = score_mode == XMH_SCORE_CIGAR;
+    auto &all_ops = fp.slots[0].ops;                 // one shared operation array: the records point into it
+    all_ops.clear();
+    if (cigar && n) {
+        const uint64_t lo = pre[0].ops_at, hi = (uint64_t)pre[n - 1].ops_at + pre[n - 1].n_ops;
+        all_ops.assign(ops + lo, ops + hi);
+    }
+    const uint32_t ops_base = (cigar && n) ? pre[0].ops_at : 0u;
+    parallel_for(pool, n, [&](int t, uint64_t b, uint64_t e) {
+        uint8_t w = 0;
+        for (uint64_t i = b; i < e; ++i) {
+            const xmh_pre &q = pre[i];
+            Rec &r = fp.recs[(size_t)i];
+            w |= q.flags & XMH_PRE_WEIRD;
+            r.name_off = 0;
+            r.name_len = q.name_len;
+            r.norm_len = q.line_len;                 // the decoder prints '\t'.join(fields)
+            r.normal = 1;
+            r.n_tok = 11;                            // never blank, never short
+            r.a = r.x = r.nm = ABSENT;
+            r.ex_a = r.ex_x = 0;
+            r.ops_begin = r.ops_count = 0;
+            r.worker = 0;
+            if (cigar) {
+                r.nm = q.nm;
+                r.ex_a = q.ex_nm;
+                r.x = q.xs; r.ex_x = q.ex_xs;
+                if (q.nm != ABSENT || q.ex_nm) { r.ops_begin = q.ops_at - ops_base; r.ops_count = q.n_ops; }   // parse_line: ops only with NM
+            } else {
+                r.a = q.as; r.ex_a = q.ex_as;
+                if (score_mode == XMH_SCORE_AS_ZS) { r.x = q.zs; r.ex_x = q.ex_zs; } else { r.x = q.xs; r.ex_x = q.ex_xs; }
+            }
+        }
+        weird[(size_t)t] = w;
+    });
+    for (uint8_t w : weird)
+        if (w) return false;
+    return true;
+}
+
+static int parse_common(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const xmh_pre *pre1, uint64_t n_pre1, const uint32_t *pops1,
+                        const char *buf2, uint64_t len2, int eof2, const xmh_pre *pre2, uint64_t n_pre2, const uint32_t *pops2,
+                        bool from_pre, int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records,
+                        xmh_block *out)
 {
     if (!p || !out || (!buf1 && len1) || (!buf2 && len2) || score_mode < 0 || score_mode > 2)
         return XMH_ERR_INVALID_ARG;
@@ -404,14 +484,22 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
         const char *buf[2] = {buf1, buf2};
         const uint64_t len[2] = {len1, len2};
         const int eof[2] = {eof1, eof2};
-        for (int f = 0; f < 2; ++f) prefault(buf[f], len[f], *p->pool);
+        if (!from_pre)
+            for (int f = 0; f < 2; ++f) prefault(buf[f], len[f], *p->pool);
         const auto t0b = now();
-        for (int f = 0; f < 2; ++f) {
-            index_lines(buf[f], len[f], eof[f] != 0, *p->pool, p->f[f]);
-            if (p->f[f].non_ascii) return XMH_ERR_NON_ASCII;
+        if (from_pre) {
+            if (!fill_from_pre(pre1, n_pre1, pops1, len1, score_mode, *p->pool, p->f[0]) ||
+                !fill_from_pre(pre2, n_pre2, pops2, len2, score_mode, *p->pool, p->f[1]))
+                return XMH_NEED_TEXT;
+        } else {
+            for (int f = 0; f < 2; ++f) {
+                index_lines(buf[f], len[f], eof[f] != 0, *p->pool, p->f[f]);
+                if (p->f[f].non_ascii) return XMH_ERR_NON_ASCII;
+            }
         }
         const auto t1 = now();
-        for (int f = 0; f < 2; ++f) parse_file(buf[f], score_mode, *p->pool, p->f[f]);
+        if (!from_pre)
+            for (int f = 0; f < 2; ++f) parse_file(buf[f], score_mode, *p->pool, p->f[f]);
         const auto t2 = now();
 
         // ---- the lock-step walk (xenomapper.py:103-117) ------------------------------------------------
@@ -510,9 +598,13 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
         if (keep_halo && n > 0 && !ended && mismatch < 0) {
             out->consumed1 = start_of(0, p->sel[0][n - 1]);
             out->consumed2 = start_of(1, p->sel[1][n - 1]);
+            out->consumed_lines1 = p->sel[0][n - 1];
+            out->consumed_lines2 = p->sel[1][n - 1];
         } else {
             out->consumed1 = start_of(0, i1);
             out->consumed2 = start_of(1, i2);
+            out->consumed_lines1 = std::min<uint64_t>(i1, L[0]);
+            out->consumed_lines2 = std::min<uint64_t>(i2, L[1]);
         }
 
         // ---- gather columns for the yielded records -------------------------------------------------
@@ -608,6 +700,22 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
     } catch (const std::bad_alloc &) {
         return XMH_ERR_OOM;
     }
+}
+
+int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const char *buf2, uint64_t len2, int eof2,
+              int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out)
+{
+    return parse_common(p, buf1, len1, eof1, nullptr, 0, nullptr, buf2, len2, eof2, nullptr, 0, nullptr, false, score_mode, paired,
+                        skip_repeated, keep_halo, max_records, out);
+}
+
+int xmh_parse_pre(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const xmh_pre *pre1, uint64_t n_pre1, const uint32_t *ops1,
+                  const char *buf2, uint64_t len2, int eof2, const xmh_pre *pre2, uint64_t n_pre2, const uint32_t *ops2,
+                  int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out)
+{
+    if ((n_pre1 && !pre1) || (n_pre2 && !pre2)) return XMH_ERR_INVALID_ARG;
+    return parse_common(p, buf1, len1, eof1, pre1, n_pre1, ops1, buf2, len2, eof2, pre2, n_pre2, ops2, true, score_mode, paired,
+                        skip_repeated, keep_halo, max_records, out);
 }
 
 static inline char *put_line(char *dst, const char *src, uint32_t len, uint8_t flags)

@@ -778,7 +778,7 @@ class _SamSource(object):
         n = min(want, self.raw.shape[0] - self.pos)
         return self.raw, self.pos, n, self.pos + n >= self.raw.shape[0]
 
-    def advance(self, consumed):
+    def advance(self, consumed, lines=0):
         self.pos += consumed
 
     def close(self):
@@ -803,7 +803,13 @@ class _BamSource(object):
         self.start = self.end = self.HEAD
         self.advanced = False
         self.decoder = ThreadPoolExecutor(max_workers=1)
-        self.ahead = None                     # Future of (buffer index, bytes decoded at [HEAD, HEAD + n))
+        self.ahead = None                     # Future of (buffer index, bytes decoded at [HEAD, HEAD + n), line descriptions)
+        # What the decoder knows about the lines in [start, end), in order: chunks of (xmh_pre array, CIGAR operations) as
+        # xmh_bam_read_pre returned them, the first `pre_skip` lines of the first chunk already consumed.  With them the
+        # stripper does not tokenise the text again (xmh_parse_pre); XENOMAPPER_BAM_PRE=0 switches that off.
+        self.pre_ok = os.environ.get("XENOMAPPER_BAM_PRE") != "0"
+        self.pre = []
+        self.pre_skip = 0
 
     def _buffer(self, k, room):
         if self.bufs[k] is None or self.bufs[k].shape[0] < self.HEAD + room:
@@ -811,21 +817,49 @@ class _BamSource(object):
         return self.bufs[k]
 
     def _decode(self, buf, at):
-        """Decode behind buf[:at] until the buffer is full or the file ends; returns the new end."""
+        """Decode behind buf[:at] until the buffer is full or the file ends; returns (the new end, the line descriptions)."""
+        chunks = []
         while not self.reader.eof:
-            got = self.reader.read_into(buf, at)
+            if self.pre_ok:
+                got, pre, ops = self.reader.read_into_pre(buf, at)
+                if got:
+                    chunks.append((pre, ops))
+            else:
+                got = self.reader.read_into(buf, at)
             if got == 0:
                 break                                              # the next line does not fit what is left
             at += got
-        return at
+        return at, chunks
 
     def _decode_ahead(self, k):
-        return k, self._decode(self.bufs[k], self.HEAD) - self.HEAD
+        end, chunks = self._decode(self.bufs[k], self.HEAD)
+        return k, end - self.HEAD, chunks
 
     def _take_ahead(self):
-        k, n = self.ahead.result()
+        k, n, chunks = self.ahead.result()
         self.ahead = None
+        self.pre.extend(chunks)                                    # the text decoded ahead always goes right behind the live text
         return self.bufs[k], n
+
+    def pre_window(self):
+        """(xmh_pre array, operation array) of the lines from the window's first byte on, or None without descriptions."""
+        if not self.pre_ok:
+            return None
+        from . import _host
+        if not self.pre:
+            return np.zeros((0, _host.PRE_WORDS), dtype=np.uint32), np.zeros(0, dtype=np.uint32)
+        if len(self.pre) == 1:
+            return self.pre[0][0][self.pre_skip:], self.pre[0][1]      # a view: the operation offsets stay valid
+        parts, ops, base = [], [], 0
+        for k, (pre, op) in enumerate(self.pre):
+            q = (pre[self.pre_skip:] if k == 0 else pre).copy()
+            q[:, _host.PRE_OPS_AT] += np.uint32(base)
+            parts.append(q)
+            ops.append(op)
+            base += op.shape[0]
+        merged = (np.concatenate(parts), np.concatenate(ops))
+        self.pre, self.pre_skip = [merged], 0
+        return merged
 
     def window(self, want):
         buf = self.bufs[self.cur]
@@ -864,7 +898,8 @@ class _BamSource(object):
                     buf[self.end:self.end + extra[1]] = extra[0][self.HEAD:self.HEAD + extra[1]]
                     self.end += extra[1]
             if self.end - self.start < want:
-                self.end = self._decode(buf, self.end)
+                self.end, chunks = self._decode(buf, self.end)
+                self.pre.extend(chunks)
             if not self.reader.eof:                                # decode what follows while this window is parsed
                 k = (self.cur + 1) % 3
                 self._buffer(k, max(FILE_WINDOW_BYTES, want))
@@ -872,9 +907,25 @@ class _BamSource(object):
         n = min(want, self.end - self.start)
         return buf, self.start, n, self.reader.eof and self.ahead is None and n == self.end - self.start
 
-    def advance(self, consumed):
+    def advance(self, consumed, lines=0):
         self.start += consumed
         self.advanced = self.advanced or consumed > 0
+        if self.pre_ok:
+            # the descriptions of the consumed lines must add up to the consumed bytes: they do unless a string value
+            # held a line break (the text rules then saw more lines than the decoder printed records) -- from there on
+            # the text is parsed as text
+            left, total = lines, 0
+            while left and self.pre:
+                pre = self.pre[0][0]
+                take = min(left, pre.shape[0] - self.pre_skip)
+                total += int(pre[self.pre_skip:self.pre_skip + take, 0].sum(dtype=np.int64)) + take
+                left -= take
+                self.pre_skip += take
+                if self.pre_skip >= pre.shape[0]:
+                    self.pre.pop(0)
+                    self.pre_skip = 0
+            if left or total != consumed:
+                self.pre_ok, self.pre, self.pre_skip = False, [], 0
 
     def close(self):
         if self.ahead is not None:
@@ -915,8 +966,17 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         with prof("window"):
             wins = [src.window(want) for src in sources]
         with prof("parse"):
-            blk = parsers[which].parse(wins[0][0], wins[0][1], wins[0][2], wins[0][3], wins[1][0], wins[1][1], wins[1][2],
-                                       wins[1][3], score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
+            blk = None
+            if bam and all(src.pre_ok for src in sources):
+                # BAM holds AS / XS / ZS / NM as typed values and the CIGAR as operations: the decoder described every line
+                # it printed, the stripper only walks the two files in lock-step (no tokenising of its own output)
+                pw = [src.pre_window() for src in sources]
+                blk = parsers[which].parse_pre(wins[0][0], wins[0][1], wins[0][2], wins[0][3], pw[0][0], pw[0][1],
+                                               wins[1][0], wins[1][1], wins[1][2], wins[1][3], pw[1][0], pw[1][1],
+                                               score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
+            if blk is None:                                       # SAM input, or a line that needs the text rules
+                blk = parsers[which].parse(wins[0][0], wins[0][1], wins[0][2], wins[0][3], wins[1][0], wins[1][1], wins[1][2],
+                                           wins[1][3], score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
         return blk, [w[0] for w in wins], [w[1] for w in wins], [w[3] for w in wins]
 
     def settle(block, raws, pos, parser, pending):
@@ -985,7 +1045,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             last = block.ended or pending is not None or (eofs[0] and eofs[1] and not progressed)
             if not last:
                 for f in (0, 1):
-                    sources[f].advance(block.consumed[f])
+                    sources[f].advance(block.consumed[f], block.consumed_lines[f])
                 future = pool.submit(parse_next, which ^ 1, window)   # parse the next window while this one is classified
             pending = settle(block, raws, pos, parsers[which], pending)
             if pending is not None:
