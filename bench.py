@@ -273,7 +273,7 @@ def e2e_sam_text(pairs=4_000_000, to_files=True):
     shm = os.path.isdir("/dev/shm")
     r = bench_e2e.run(pairs=pairs, threads=0, mode="liberal", workdir="/dev/shm" if shm else "/tmp",
                       out_dir=("/dev/shm" if shm else "/tmp") if to_files else None)
-    return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"],
+    return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"], "phases": r["phases"],
             "seconds": round(r["seconds"], 4), "outputs": r["outputs"], "output_bytes": r["output_bytes"],
             "text_bytes_in_per_pair": round(r["input_bytes"] / max(r["units"], 1), 1),
             "text_bytes_out_per_pair": round(r["output_bytes"] / max(r["units"], 1), 1),
@@ -904,11 +904,21 @@ def main():
                     e2e[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 sys.path.insert(0, os.path.join(REPO, "tools"))
+                import bench_bam
+                r = bench_bam.run(copies=4000, workdir="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+                e2e["bam"] = {"read_pairs_per_s": r["value"], "pairs": r["units"], "bam_GBps": r["bam_GBps"], "seconds": round(r["seconds"], 4),
+                              "threads": r["threads"], "phases": r["phases"],
+                              "what": "two BAM files (the reference's fixtures tiled) -> BGZF/BAM decoder with line descriptions -> "
+                                      "lock-step walk -> fused pass -> six SAM outputs on /dev/null"}
+            except Exception as e:                               # noqa: BLE001
+                e2e["bam"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
                 import bench_e2e
                 e2e["host_ceilings"] = bench_e2e.host_ceilings("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
                 e2e["host_ceilings"]["what"] = ("the file path's own rooflines on this box: memory copy (one core / all granted threads), "
-                                                "one write(2) stream against all threads filling the mapped tmpfs file, the stripper's "
-                                                "GB/s of SAM text against its thread count")
+                                                "one write(2) stream into tmpfs, posix_fallocate alone, the writer gathering lines into a "
+                                                "mapped tmpfs file and into memory, the stripper's GB/s of SAM text against its thread count")
             except Exception as e:                               # noqa: BLE001
                 e2e["host_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
             line["e2e"] = e2e

@@ -54,12 +54,10 @@ def tiled_bam(src, dst, copies):
     return len(raw) - at
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--copies", type=int, default=4000)
-    ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--dir", default="/dev/shm")
-    a = ap.parse_args()
+def run(copies=4000, threads=0, workdir="/dev/shm"):
+    """One warm-up and one timed pass over the tiled fixtures; returns the result record (also bench.py's `e2e.bam`)."""
+    import types
+    a = types.SimpleNamespace(copies=copies, threads=threads, dir=workdir)
     from xenomapper_amd import _host, xenomapper as xm
     paths = []
     for tag in ("human", "mouse"):
@@ -76,12 +74,22 @@ def main():
             counts = xm.classify_sam_files(paths[0], paths[1], paired=True, n_threads=a.threads, bam=True, **sinks)
             el = time.perf_counter() - t0
         units = sum(counts.values())
-        print(json.dumps({"metric": "end-to-end read-pairs/s (BAM in, six SAM files out)", "value": units / el,
-                          "units": units, "seconds": el, "bam_bytes": size, "bam_GBps": size / el / 1e9,
-                          "threads": a.threads or _host.lib().xmh_default_threads()}))
+        return {"metric": "end-to-end read-pairs/s (BAM in, six SAM files out)", "value": units / el,
+                "units": units, "seconds": el, "bam_bytes": size, "bam_GBps": size / el / 1e9,
+                "threads": a.threads or _host.lib().xmh_default_threads(),
+                "phases": {k: round(v, 4) for k, v in xm.LAST_FILE_PROFILE.items()}}
     finally:
         for p in paths:
             os.unlink(p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--copies", type=int, default=4000)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--dir", default="/dev/shm")
+    a = ap.parse_args()
+    print(json.dumps(run(a.copies, a.threads, a.dir)))
 
 
 if __name__ == "__main__":

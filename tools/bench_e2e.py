@@ -57,7 +57,9 @@ def run(pairs=2_000_000, threads=0, mode="liberal", workdir="/dev/shm", out_dir=
                 "units": units, "seconds": el, "input_bytes": size, "input_GBps": size / el / 1e9,
                 "threads": threads or _host.lib().xmh_default_threads(), "mode": mode,
                 "outputs": "files" if out_dir else "/dev/null",
-                "output_bytes": sum(os.path.getsize(p) for p in out_paths)}
+                "output_bytes": sum(os.path.getsize(p) for p in out_paths),
+                # wall seconds per phase of the timed pass: window + parse run in a helper thread beside classify + emit + write
+                "phases": {k: round(v, 4) for k, v in xm.LAST_FILE_PROFILE.items()}}
     finally:
         for sink in sinks.values():
             sink.close()
@@ -101,16 +103,11 @@ def host_ceilings(workdir="/dev/shm", mb=512, parse_mb=64):
                 for at in range(0, src.nbytes, 64 << 20):
                     fh.write(mv[at:at + (64 << 20)])
 
-        def mapped():
+        def allocate():
             with open(path, "w+b") as fh:
                 os.posix_fallocate(fh.fileno(), 0, src.nbytes)
-                mm = mmap.mmap(fh.fileno(), src.nbytes)
-                view = np.frombuffer(mm, dtype=np.uint8)
-                par_copy(view)
-                del view
-                mm.close()
         out["tmpfs_one_write_stream_GBps"] = src.nbytes / best(one_stream) / 1e9
-        out["tmpfs_mapped_all_threads_GBps"] = src.nbytes / best(mapped) / 1e9
+        out["tmpfs_fallocate_GBps"] = src.nbytes / best(allocate) / 1e9          # the kernel allocating (and zeroing) the pages, one thread
     finally:
         if os.path.exists(path):
             os.unlink(path)
@@ -129,6 +126,30 @@ def host_ceilings(workdir="/dev/shm", mb=512, parse_mb=64):
         parser.close()
     out["stripper_GBps_of_text_by_threads"] = scaling
     out["stripper_input"] = "2 x %d MB of 2x150 bp SAM text" % parse_mb
+    # the writer itself, as the file path uses it: the lines of ALL units of the parsed block gathered by the writer's own
+    # threads straight into the pages of an extended, mapped tmpfs file (posix_fallocate + mmap + xmh_emit), against the
+    # same text gathered into ordinary memory
+    from xenomapper_amd import xenomapper as xm
+    parser = _host.Parser(n_thr)
+    try:
+        blk = parser.parse(bodies[0], 0, bodies[0].shape[0], True, bodies[1], 0, bodies[1].shape[0], True, 0, True, False, True, 1 << 22)
+        flags = np.unpackbits(blk.unit_bits.view(np.uint8), bitorder="little")[:blk.n].astype(bool)
+        idx = np.flatnonzero(flags).astype(np.uint32)
+        _, need = parser.emit_size(True, 0, idx)
+
+        def into_file():
+            with open(path, "wt") as sink:
+                assert xm._emit_into_file(parser, True, 0, idx, sink)
+
+        def into_memory():
+            parser.emit(True, 0, idx, reuse=True)
+        out["writer_into_mapped_tmpfs_file_GBps"] = need / best(into_file) / 1e9
+        out["writer_into_memory_GBps"] = need / best(into_memory) / 1e9
+        out["writer_input"] = "%d MB of lines (the file-1 lines of every unit of the stripper input)" % (need >> 20)
+    finally:
+        parser.close()
+        if os.path.exists(path):
+            os.unlink(path)
     return out
 
 

@@ -754,6 +754,9 @@ def _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode):
     return patches, None, None
 
 
+LAST_FILE_PROFILE = {}      # wall seconds per phase of the last file-to-file run (window / parse overlap classify / emit / write)
+
+
 class _PhaseClock(dict):
     """Wall time per phase of the file path (printed when XENOMAPPER_PROFILE is set)."""
 
@@ -1065,9 +1068,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 prs.close()
             for src in sources:
                 src.close()
+        total = time.perf_counter() - t_all
+        prof["other"] = total - sum(prof.values())               # negative: helper-thread phases overlap the rest
+        LAST_FILE_PROFILE.clear()
+        LAST_FILE_PROFILE.update(prof, total=total)
         if os.environ.get("XENOMAPPER_PROFILE"):
-            total = time.perf_counter() - t_all
-            prof["other"] = total - sum(prof.values())           # negative: helper-thread phases overlap the rest
             print("xenomapper file path: %.3f s  " % total + "  ".join("%s %.3f" % kv for kv in prof.items()), file=sys.stderr)
     ordered = Counter()
     for key in key_order:
