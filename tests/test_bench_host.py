@@ -91,3 +91,41 @@ def test_singleton_flags_model():
     import numpy as np
     assert not (f[1:] & f[:-1]).any()                          # two units never touch: a unit's first record closes none
     assert np.flatnonzero(f)[:50].tolist() != list(range(1, 100, 2))   # parity flips: not strictly interleaved
+
+
+def test_printed_line_stays_short_enough_for_a_truncating_record():
+    """The ONE line bench.py prints must survive a record that keeps only its last 2 000 characters: numbers only,
+    every workload in it (configs[2] / configs[4] / the sharded input / the transfer-inclusive rates)."""
+    import json
+    import bench
+    roof = {"bound": "hbm", "kernel": "classify_kernel<int32, paired, counts>", "achieved": 5825.123456, "peak": 8000.0, "unit": "GB/s",
+            "frac": 0.72814043, "traffic": 1724123456.0, "traffic_source": "x" * 300, "algorithmic_bytes_per_unit": 33.0,
+            "kernel_ms": 0.283262, "copy_ceiling_GBps": 6234.5678, "memcpy_d2d_GBps": 5377.123, "frac_of_copy": 0.93421}
+    step = {"frac": 0.694612, "frac_by_ms_per_step": 0.677912, "sum_kernel_ms": 0.34194, "algorithmic_bytes_per_unit": 38.0,
+            "traffic": 1998123456.0, "what": "y" * 300}
+    sub = {"ms_per_step": 0.514341234, "roofline": dict(roof), "roofline_step": dict(step), "verified_vs_oracle": True, "workload": "z" * 400}
+    full = {"metric": "read-pairs/sec classified", "value": 142726123456.789, "unit": "read-pairs/s", "n_gpus": 8, "steps": 50, "warmup": 5,
+            "ms_per_step": 0.350321234, "ms_per_step_median": 0.339481234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload_short": "configs[1]: 50000000 PE 2x150 pairs/GPU, AS/XS, liberal, HBM-resident", "pairs_per_gpu": 50_000_000,
+                       "step_short": "xm_classify_compact_dev: classify+count, scan, scatter (3 launches)",
+                       "sharding_short": "weak: own block per GPU, 1 RCCL all-reduce of counts", "workload": "w" * 500},
+            "roofline": roof, "roofline_step": step, "kernel_ms": {"classify": 0.280412, "scan": 0.008012, "scatter": 0.053551},
+            "cpu_baseline": {"value": 135060.123, "unit": "read-pairs/s", "cores": 1, "kind": "port", "sample": "s" * 300,
+                             "sample_short": "82 x 20000-pair SAM text twin, parse+classify+write, 12 s"},
+            "verified_vs_oracle": True, "n_ranks_seen": 8, "xm_allreduce_counts": {"ranks": 8, "matches_torch_distributed": True},
+            "workloads": {"configs[2]": sub, "configs[4]": sub,
+                          "sharded_input": {"ms_per_step": 3.127712, "value": 127890123456.0, "verified_vs_oracle": True}},
+            "e2e": {"h2d_inclusive": {"registered_buffers": {"read_pairs_per_s": 1.56e9}}, "sam_text": {"read_pairs_per_s": 6.869e6},
+                    "bam": {"read_pairs_per_s": 2.8e6}, "note": "n" * 500},
+            "full_record": "gpurun_out/bench_full_8gpu_cfg2.json"}
+    line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(line) < 1900, len(line)
+    rec = json.loads(line)
+    assert rec["workloads"]["cfg3"][:3] == [0.51434, 0.7281, 0.6779] and rec["workloads"]["sharded"][2] is True
+    assert rec["roofline"]["frac"] == 0.7281 and rec["cpu_baseline"]["cores"] == 1 and rec["e2e"] == [1.56, 6.869, 2.8]
+    # an error in a side measurement is carried as text, the line still parses and stays short
+    full["workloads"]["configs[2]"] = {"error": "RuntimeError: " + "e" * 500}
+    full["xm_allreduce_counts"] = {"error": "watchdog: " + "h" * 500}
+    line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(line) < 1900 and json.loads(line)["workloads"]["cfg3"][0] is None

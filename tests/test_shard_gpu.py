@@ -153,5 +153,6 @@ def test_bench_starts_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
     assert rec["verified_vs_oracle"] is True
-    assert rec["value"] > 0 and abs(rec["value"] - 2 * 1_000_000 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+    # the printed line rounds to 5-6 significant digits (the full record keeps everything)
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 1_000_000 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-4
     assert {"roofline", "roofline_step", "kernel_ms", "config"} <= set(rec)
