@@ -84,8 +84,9 @@ def main():
                 rec = {"kernel_src_sha256": sha, "workloads": {}}
             rec["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --workload W`; "
                              "FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md section HBM; kernel_src_sha256 = "
-                             "tools/kernel_hash.py over xm_kernels.hip + xm_kernels.h (+ extra hipcc flags)")
-            per = {k: d["hbm_bytes_per_launch"] for k, d in pmc.items() if "hbm_bytes_per_launch" in d}
+                             "tools/kernel_hash.py over xm_kernels.hip, xm_kernels.h, xm_api.hip, xenomapper_hip.h (+ extra hipcc flags)")
+            per = {k: d["hbm_bytes_per_launch"] for k, d in pmc.items()
+                   if "hbm_bytes_per_launch" in d and not k.startswith("stream_probe")}    # the ceiling probe is no part of a step
             cls = [v for k, v in per.items() if k.startswith("classify")]
             if cls:
                 rec["workloads"][a.workload] = {"pairs": a.pairs, "classify_hbm_bytes_per_launch": max(cls),
