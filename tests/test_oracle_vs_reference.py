@@ -59,3 +59,27 @@ def test_oracle_behaves_like_the_reference(texts, mode, func, m, skip):
     assert [o.getvalue() for o in outs] == [want_outs[name].getvalue() for name in H.STATES], (t1, t2)
     if err is None:
         assert counts == want_counts
+
+
+def test_mappability_host_functions_behave_like_the_reference():
+    """The text and small-list functions of the companion tool (wiggle and FASTA readers, smoothing, normalisation) side by
+    side with the reference's on odd inputs: tracks without values, files without declarations, repeated chromosomes, names
+    with '=' in them, nameless FASTA records, text in front of the first header."""
+    _reference()                                           # skips where the reference is not mounted
+    import importlib
+    ref = importlib.import_module("xenomapper.mappability")
+    from xenomapper_amd import mappability as ours
+    dec = "fixedStep\tchrom=%s\tstart=1\tstep=1\n"
+    wiggles = ["", dec % "a" + "1\n0.5\n" + dec % "b" + dec % "c=d" + "2\n", "3\n4\n", dec % "a",
+               dec % "a" + "1\n" + dec % "a" + "7\n8\n", dec % "z" + "1e-3\n" + dec % "y" + dec % "x"]
+    for text in wiggles:
+        a, b = ref.Mappability(chromosome_sizes={}), ours.Mappability(chromosome_sizes={})
+        a.from_wiggle(io.StringIO(text))
+        b.from_wiggle(io.StringIO(text))
+        assert dict(a) == dict(b) and a.chromosome_sizes == b.chromosome_sizes, text
+    for text in ["", "junk\n>a desc\nAC\nGT\n>\nTT\n>b\n\n>c\nA\n", ">x\n", "no header\n", ">>double\nAA\n  >  sp\nCC\n"]:
+        assert list(ref.parse_fasta(io.StringIO(text))) == list(ours.parse_fasta(io.StringIO(text))), text
+    for values in ([1, 2, 3, 10, 0, 0, 5] * 5, [0.1, 0.25, 7.0], [3]):
+        for width in (10, 2, 1):
+            assert ref.smoothed_list(values, width) == ours.smoothed_list(values, width)
+        assert ref.normalised_list(values) == ours.normalised_list(values)

@@ -8,6 +8,7 @@ right).  Everything else here is text handling and small-list statistics and sta
 from __future__ import annotations
 
 import argparse
+import itertools
 import sys
 from collections import Counter
 from statistics import mean
@@ -36,22 +37,26 @@ class Mappability(dict):
                 wigglefile.write("".join(str(score) + "\n" for score in self[chrom]))
 
     def from_wiggle(self, wigglefile=sys.stdin, datatype=float):
-        """Load (and overwrite) chromosomes from a fixedStep start=1 step=1 wiggle (ref :59-92)."""
-        chrom, values = None, []
-        for line in wigglefile:
-            if line.startswith("fixedStep"):
-                fields = line.strip().split("\t")
-                if fields[1].split("=")[0] != "chrom" or fields[2] != "start=1" or fields[3] != "step=1":
-                    raise ValueError('Unsupported wiggle fixed step format [must be in the format "fixedStep '
-                                     'chrom=chrX start=1 step=1"] {0}'.format(fields))
-                if chrom and values:
-                    self[chrom] = values
-                chrom, values = fields[1].split("=")[1], []
-            else:
-                values.append(datatype(line))
-        self[chrom] = values
-        for name in self:
-            self.chromosome_sizes[name] = len(self[name])
+        """Load chromosomes from a fixedStep wiggle (declaration lines "fixedStep<TAB>chrom=NAME<TAB>start=1<TAB>step=1",
+        one value per line after them), replacing tracks of the same name; may be called again for more files.
+        Behaviour pinned by the reference's tests (ref :59-92): a declared track that stays empty is dropped unless it is
+        the last one of the file, which is always stored -- under the key None when the file declares nothing."""
+        tracks = [(None, [])]                         # (name, values) in file order; values go to the last one
+        for text in wigglefile:
+            if not text.startswith("fixedStep"):
+                tracks[-1][1].append(datatype(text))
+                continue
+            declared = text.strip().split("\t")
+            key_and_name = declared[1].split("=")
+            if key_and_name[0] != "chrom" or declared[2] != "start=1" or declared[3] != "step=1":
+                raise ValueError('Unsupported wiggle fixed step format [must be in the format "fixedStep '
+                                 'chrom=chrX start=1 step=1"] {0}'.format(declared))
+            tracks.append((key_and_name[1], []))
+        for name, values in tracks[:-1]:
+            if name and values:
+                self[name] = values
+        self[tracks[-1][0]] = tracks[-1][1]
+        self.chromosome_sizes.update((name, len(track)) for name, track in self.items())
 
     def single_end_to_paired(self, mate_density=[1]):
         """Paired-end mappability: a uniquely mappable position stays 1.0, any other gets the density-weighted
@@ -70,19 +75,24 @@ class Mappability(dict):
 
 
 def parse_fasta(fastafile, token=">"):
-    """Yield (name, sequence) from a (multi-)FASTA handle, which is closed at the end (ref :127-146)."""
+    """(name, sequence) of every record of a (multi-)FASTA handle, streamed record by record; the handle is closed when
+    the generator finishes.  As the reference's parser (ref :127-146): lines are stripped, a header is a line that starts
+    with `token` and its name is that line without its first character, lines in front of the first header are ignored,
+    and a record whose name is empty is not reported."""
+    def numbered(handle):                                  # every line with the number of headers seen so far
+        seen = 0
+        for raw in handle:
+            line = raw.strip()
+            seen += line.startswith(token)
+            yield seen, line
     with fastafile as handle:
-        name, seq = None, None
-        for line in handle:
-            line = line.strip()
-            if line.startswith(token):
-                if name:
-                    yield (name, seq)
-                name, seq = line[1:], ""
-            elif seq is not None:
-                seq += line
-        if name:
-            yield (name, seq)
+        for record, lines in itertools.groupby(numbered(handle), key=lambda pair: pair[0]):
+            if record == 0:
+                continue
+            header = next(lines)[1]
+            sequence = "".join(line for _, line in lines)
+            if header[1:]:
+                yield (header[1:], sequence)
 
 
 def make_blocklist(seqstring, block_size=80):
@@ -134,20 +144,30 @@ def single_end_mappability_from_sam(samfile, outfile=sys.stdout, fill_sequence_g
 
 
 def paired_end_mappability(wiggle, mate_density, outfile=sys.stdout, chromosome_sizes={}):
-    """Paired-end mappability wiggle from a single-end wiggle and a mate density (ref :216-235)."""
-    mappable = Mappability(chromosome_sizes=chromosome_sizes)
-    chromosomes = list(chromosome_sizes.keys())
-    mappable.from_wiggle(wiggle, datatype=float)
-    mappable.single_end_to_paired(mate_density=mate_density).to_wiggle(wigglefile=outfile, chromosomes=chromosomes)
+    """Paired-end mappability wiggle from a single-end wiggle and a mate density (ref :216-235).  Only the chromosomes
+    named in chromosome_sizes BEFORE the wiggle is read are written (all of them when it is empty): reading adds the
+    wiggle's own chromosomes to that dictionary."""
+    wanted = [*chromosome_sizes]
+    single_end = Mappability(chromosome_sizes=chromosome_sizes)
+    single_end.from_wiggle(wiggle, datatype=float)
+    paired = single_end.single_end_to_paired(mate_density=mate_density)        # the GPU part
+    paired.to_wiggle(wigglefile=outfile, chromosomes=wanted)
 
 
 def smoothed_list(the_list, width=10):
-    return [mean(the_list[max(0, x - width - 1):x + width]) for x in range(len(the_list))]
+    """Running mean over the window [x - width - 1, x + width) clipped at the front (ref :237-238); statistics.mean, i.e.
+    the exactly rounded mean, as there."""
+    out = []
+    for x in range(len(the_list)):
+        first = x - width - 1
+        out.append(mean(the_list[first if first > 0 else 0:x + width]))
+    return out
 
 
 def normalised_list(the_list):
-    total = sum(the_list)
-    return [x / total for x in the_list]
+    """Every value divided by the sum of all (ref :240-242)."""
+    scale = sum(the_list)
+    return [value / scale for value in the_list]
 
 
 def remove_small_values(the_list, relative_limit=0.1):
