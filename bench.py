@@ -310,8 +310,7 @@ class Workload(object):
         self.cigar_csr = os.environ.get("XM_BENCH_CIGAR_CSR") == "1"     # A/B only: the CSR-column kernel (K1c + stand-alone histogram)
         self.unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"        # A/B only: xm_classify_dev + xm_compact_dev
         self.shard = shard
-        self.place = os.environ.get("XM_BENCH_PLACE") in ("1", "2") and name in ("cfg2", "cfg5", "se", "f64")   # six lists
-        self.onepass = self.place and os.environ.get("XM_BENCH_PLACE") == "2"     # tuning builds: the single-kernel experiment
+        self.place = os.environ.get("XM_BENCH_PLACE") == "1" and name in ("cfg2", "cfg5", "se", "f64")   # A/B: the six-list form
         self.layout = "strictly interleaved mates"
         n = 2 * n_pairs
         units = n_pairs
@@ -450,10 +449,7 @@ class Workload(object):
         self.step_no += 1
         code = self.code if self.category_bytes else None
         bins4 = None if self.category_bytes else self.bins4
-        if self.place and self.onepass:
-            ctx.classify_place_onepass_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, self.lists[:6],
-                                           self.n_out, counts)
-        elif self.place:
+        if self.place:
             ctx.classify_place_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, self.lists[:6],
                                    self.n_out, counts, code_out=code, bins4=bins4,
                                    list_state6=self.lists[6] if len(self.lists) > 6 else None)

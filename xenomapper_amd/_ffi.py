@@ -503,27 +503,6 @@ class Context(object):
                                                    opt(list_state6), cap, opt(n_out), opt(counts))
         self._check(rc, "xm_classify_place_dev")
 
-    def classify_place_onepass_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, lists, n_out, counts, stream=None):
-        """Tuning builds (-DXM_ONEPASS=1) only: the single-kernel experiment of DESIGN.md section 6."""
-        fn = self._L.xm_classify_place_onepass_dev
-        P, U64 = ctypes.c_void_p, ctypes.c_uint64
-        fn.argtypes = [P, P, ctypes.c_int, U64, P, P, P, P, P, ctypes.c_int32, P, U64, P, P]
-        fn.restype = ctypes.c_int
-        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (as1, xs1, as2, xs2, unit_bits)]
-        arr = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in lists])
-        rc = fn(self._h, self._stream_handle(stream), mode, as1.numel(), *ptrs, int(min_score), arr,
-                min(t.numel() for t in lists), ctypes.c_void_p(n_out.data_ptr()), ctypes.c_void_p(counts.data_ptr()))
-        self._check(rc, "xm_classify_place_onepass_dev")
-
-    def onepass_debug(self, n_granules=0, fetch=False):
-        fn = self._L.xm_onepass_debug
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
-        fn.restype = ctypes.c_int
-        ctl = np.zeros(16, dtype=np.uint32)
-        trace = np.zeros((int(n_granules), 8), dtype=np.uint64) if fetch else None
-        self._check(fn(self._h, int(n_granules), _np_ptr(trace) if fetch else None, _np_ptr(ctl)), "xm_onepass_debug")
-        return ctl, trace
-
     def classify_place_cigar_packed_dev(self, mode, nm1, cnt1, tile1, ops1, xs1, nm2, cnt2, tile2, ops2, xs2, unit_bits,
                                         min_score_floor, lists, n_out, counts, code_out=None, bins4=None, range_flag=None,
                                         capacity=None, stream=None):

@@ -34,11 +34,6 @@ struct xm_ctx {
     hipStream_t ws_stream;
     bool ws_used;
     hipEvent_t ws_event;
-#if XM_ONEPASS
-    void *op_ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // tuning builds: workspace of the single-kernel experiment
-    uint64_t op_trace_gran = 0;
-    uint32_t op_prev_gran[2] = {0, 0};
-#endif
     // scratch of the host-buffer entry points (grown on demand, never inside *_dev calls)
     void *d_scratch[8];
     size_t scratch_bytes[8];
@@ -666,73 +661,6 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
     if ((rc = check_launch(ctx, "classify_cigp_kernel")) != XM_OK) return rc;
     return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
 }
-
-#if XM_ONEPASS
-/* tuning builds only: the single-kernel experiment (xm_onepass.inc); not declared in the public header */
-extern "C" int xm_classify_place_onepass_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
-                                             const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
-                                             const uint64_t *unit_bits, int32_t min_score_floor,
-                                             uint32_t *const idx_out[6], uint64_t list_capacity, uint64_t *n_out, uint64_t *counts)
-{
-    if (!ctx || bad_mode(mode) || n == 0 || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
-    const size_t max_blocks = (XM_MAX_GRANULES + 15u) / 16u + 16u, max_groups = (XM_MAX_GRANULES + 255u) / 256u + 16u;
-    if (!ctx->op_ws[0]) {
-        const size_t sizes[5] = {((size_t)XM_MAX_GRANULES + 64) * 32, 2 * max_blocks * 32, 2 * max_groups * 32, max_groups * 64, 4096};
-        const int slot[5] = {0, 1, 2, 5, 3};
-        for (int k = 0; k < 5; ++k) {
-            XM_HIP(ctx, hipMalloc(&ctx->op_ws[slot[k]], sizes[k]));
-            XM_HIP(ctx, hipMemset(ctx->op_ws[slot[k]], 0, sizes[k]));
-        }
-        const uint32_t one = 1;
-        XM_HIP(ctx, hipMemcpy((char *)ctx->op_ws[3] + 2048, &one, 4, hipMemcpyHostToDevice));      // ctl[0] = epoch 1
-        ctx->op_prev_gran[0] = ctx->op_prev_gran[1] = 0;
-    }
-    xm::OnePassSink ps;
-    for (int b = 0; b < 6; ++b) ps.list[b] = idx_out[b];
-    ps.list[6] = nullptr;
-    ps.cap = list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)list_capacity;
-    ps.n_gran = xm::plan_granules(n).n_gran;
-    {   // what the call before the previous one (same parity as the next one) left in the idle copies
-        const uint32_t dirty = ctx->op_prev_gran[0] > ctx->op_prev_gran[1] ? ctx->op_prev_gran[0] : ctx->op_prev_gran[1];
-        ps.zero_blocks = (dirty + 15u) / 16u;
-        ps.zero_groups = (dirty + 255u) / 256u;
-        ctx->op_prev_gran[1] = ctx->op_prev_gran[0];
-        ctx->op_prev_gran[0] = ps.n_gran;
-    }
-    ps.gdesc = (unsigned long long *)ctx->op_ws[0];
-    ps.bsum = (unsigned long long *)ctx->op_ws[1];
-    ps.gsum = (unsigned long long *)ctx->op_ws[2];
-    ps.p2 = (unsigned long long *)ctx->op_ws[5];
-    ps.ctl = (uint32_t *)((char *)ctx->op_ws[3] + 2048);
-    ps.n_out = (unsigned long long *)n_out;
-    ps.counts = (unsigned long long *)counts;
-    ps.counts_rep = (unsigned long long *)ctx->d_counts_rep;
-    ps.trace = (ctx->op_ws[4] && ps.n_gran <= ctx->op_trace_gran) ? (unsigned long long *)ctx->op_ws[4] : nullptr;
-    hipStream_t st = (hipStream_t)stream;
-    {
-        Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_onepass_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, ps);
-    }
-    return check_launch(ctx, "onepass_kernel");
-}
-
-extern "C" int xm_onepass_debug(xm_ctx *ctx, uint64_t n_granules, uint64_t *trace_out, uint32_t ctl_out[16])
-{
-    if (!ctx) return XM_ERR_INVALID_ARG;
-    XM_HIP(ctx, hipDeviceSynchronize());
-    if (ctl_out && ctx->op_ws[3]) XM_HIP(ctx, hipMemcpy(ctl_out, (char *)ctx->op_ws[3] + 2048, 64, hipMemcpyDeviceToHost));
-    if (trace_out && ctx->op_ws[4]) {
-        const uint64_t k = n_granules < ctx->op_trace_gran ? n_granules : ctx->op_trace_gran;
-        XM_HIP(ctx, hipMemcpy(trace_out, ctx->op_ws[4], (size_t)k * 64, hipMemcpyDeviceToHost));
-    } else if (!trace_out && n_granules) {
-        if (ctx->op_ws[4]) (void)hipFree(ctx->op_ws[4]);
-        XM_HIP(ctx, hipMalloc(&ctx->op_ws[4], (size_t)n_granules * 64));
-        XM_HIP(ctx, hipMemset(ctx->op_ws[4], 0, (size_t)n_granules * 64));
-        ctx->op_trace_gran = n_granules;
-    }
-    return XM_OK;
-}
-#endif
 
 int xm_stream_probe_dev(xm_ctx *ctx, void *stream, uint64_t n,
                         const int32_t *c0, const int32_t *c1, const int32_t *c2, const int32_t *c3, uint8_t *out)

@@ -46,23 +46,6 @@ struct CigCols {
     const uint32_t *ops;        // BAM-style len << 4 | op
 };
 
-#ifndef XM_ONEPASS
-#define XM_ONEPASS 0
-#endif
-#if XM_ONEPASS
-// tuning builds only: sink of the single-kernel experiment (xm_onepass.inc)
-struct OnePassSink {
-    uint32_t *list[7];
-    uint32_t cap, n_gran;
-    uint32_t zero_blocks, zero_groups;   // entries of the idle parity copies of bsum / gsum this launch zeroes for the next one
-    unsigned long long *gdesc, *bsum, *gsum, *p2;
-    uint32_t *ctl;
-    unsigned long long *n_out, *counts, *counts_rep, *trace;
-};
-void launch_onepass_i32(hipStream_t st, int mode, uint64_t n, const int32_t *as1, const int32_t *xs1, const int32_t *as2,
-                        const int32_t *xs2, const uint64_t *unit_bits, int32_t m, const OnePassSink &ps);
-#endif
-
 // the six-list output contract of the scatter (xm_classify_place*): one caller-allocated list per output bin
 struct ListOut {
     uint32_t *p[7];             // lists of bins 0..5; [6] = units holding state 6 (binary64 columns only; may be null)

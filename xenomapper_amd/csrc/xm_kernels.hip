@@ -849,10 +849,6 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
     }
 }
 
-#if XM_ONEPASS
-#include "xm_onepass.inc"            // tuning builds only: the single-kernel experiment
-#endif
-
 // ---------------------------------------------------------------------------------------------
 // K3: CIGAR-derived AS (one lane per record, CSR ops)
 // ---------------------------------------------------------------------------------------------
