@@ -561,9 +561,13 @@ __device__ __forceinline__ void store_index(uint32_t *__restrict__ idx_out, uint
 // afterwards (scatter_copy_out).
 // rec[j]: the record the lane's position j stands for (rec0 + j when the positions are the lane's four records; the lane's
 // first / second unit in the two-units-per-lane form, SLOTS 0x3)
-template <int SLOTS, bool WIDE, bool STAGED>
+// LISTS (the six-list output contract, xm_classify_place*: SURVEY 8b (4), the reference's six sinks :332-350, :423-448,
+// :521-550): bin b's units go to their own caller-allocated list; base[b] then counts from the start of list b and a lane
+// takes its list's address from `lptr`, a wave-private LDS table of the seven list pointers (null: not listed).
+template <int SLOTS, bool WIDE, bool STAGED, bool LISTS = false>
 __device__ __forceinline__ void scatter_256(const uint32_t bin[4], const uint32_t rec[4], uint32_t base[7],
-                                            uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab)
+                                            uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab,
+                                            const uint64_t *lptr = nullptr)
 {
     uint32_t pos[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -600,42 +604,12 @@ __device__ __forceinline__ void scatter_256(const uint32_t bin[4], const uint32_
     for (int j = 0; j < 4; ++j)
         if (((SLOTS >> j) & 1) && bin[j] < 7u && (!XM_SCATTER_GUARD || pos[j] < n_units)) {
             if (STAGED) slab[pos[j]] = (uint16_t)rec[j];
+            else if (LISTS) {
+                uint32_t *list = reinterpret_cast<uint32_t *>(lptr[bin[j]]);
+                if (list != nullptr) list[pos[j]] = rec[j];
+            }
             else store_index<WIDE>(idx_out, pos[j], rec[j]);
         }
-}
-
-// The same for the six-list output contract (xm_classify_place*, SURVEY 8b (4): the reference's six independent sinks,
-// xenomapper.py:332-350, :423-448, :521-550): bin b's units go to their own caller-allocated list lo.p[b], so base[b] counts
-// from the start of that list and the stores sit inside the bin loop, where the list pointer is uniform.
-template <int SLOTS, bool WIDE>
-__device__ __forceinline__ void scatter_256_lists(const uint32_t bin[4], const uint32_t rec[4], uint32_t base[7], const ListOut &lo)
-{
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        uint64_t m[4], any = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            m[j] = ((SLOTS >> j) & 1) ? __ballot(bin[j] == (uint32_t)b) : 0ull;
-            any |= m[j];
-        }
-        if (any == 0ull) continue;              // wave-uniform: bin b does not occur here
-        uint32_t t = base[b], total = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) { t = mbcnt64(m[j], t); total += (uint32_t)__builtin_popcountll(m[j]); }
-        base[b] += total;
-        uint32_t *__restrict__ list = lo.p[b];
-        if (list == nullptr) continue;          // uniform: the optional list of the units holding state 6
-        uint32_t r = 0;                         // units of bin b earlier in this lane
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((SLOTS >> j) & 1) {
-                const bool mine = bin[j] == (uint32_t)b;
-                const uint32_t p = t + r;
-                if (mine && (!XM_SCATTER_GUARD || p < lo.cap)) store_index<WIDE>(list, p, rec[j]);
-                r += mine ? 1u : 0u;
-            }
-    }
 }
 
 // XM_SCATTER_STAGED (0 in a tuning build: every unit's index goes to idx_out with its own dword store): where a granule
@@ -693,7 +667,7 @@ __device__ __forceinline__ void scatter_copy_out(const uint16_t *slab, uint32_t 
 // the wave's granule, 256 records at a time: ranks by ballots, indices straight to idx_out or (STAGED) into the slab
 template <int NSUB, bool WIDE, bool NIB, bool STAGED, bool LISTS>
 __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const uint8_t *lut, uint32_t rec_g, uint32_t base[7],
-                                                uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab, const ListOut &lo)
+                                                uint32_t *__restrict__ idx_out, uint32_t n_units, uint16_t *slab, const uint64_t *lptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
@@ -712,8 +686,7 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
         const uint32_t rec[4] = {rec0, rec0 + 1u, rec0 + 2u, rec0 + 3u};
         if (__ballot(!even_free) == 0ull) {                               // strictly interleaved mates: positions 1 and 3 only
             if (!NIB) { bin[0] = bin[2] = 7u; bin[1] = lut[(w[s] >> 8) & 63u]; bin[3] = lut[(w[s] >> 24) & 63u]; }
-            if (LISTS && !STAGED) scatter_256_lists<0xA, WIDE>(bin, rec, base, lo);
-            else scatter_256<0xA, WIDE, STAGED>(bin, rec, base, idx_out, limit, slab);
+            scatter_256<0xA, WIDE, STAGED, LISTS && !STAGED>(bin, rec, base, idx_out, limit, slab, lptr);
             continue;
         }
         if (!NIB) {
@@ -747,12 +720,9 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
                 }
             }
             const uint32_t vrec[4] = {rec0 + j0, rec0 + j1, 0u, 0u};
-            if (LISTS) scatter_256_lists<0x3, WIDE>(vb, vrec, base, lo);
-            else scatter_256<0x3, WIDE, STAGED>(vb, vrec, base, idx_out, limit, slab);
-        } else if (LISTS && !STAGED) {
-            scatter_256_lists<0xF, WIDE>(bin, rec, base, lo);
+            scatter_256<0x3, WIDE, STAGED, LISTS>(vb, vrec, base, idx_out, limit, slab, lptr);
         } else {
-            scatter_256<0xF, WIDE, STAGED>(bin, rec, base, idx_out, limit, slab);
+            scatter_256<0xF, WIDE, STAGED, LISTS && !STAGED>(bin, rec, base, idx_out, limit, slab, lptr);
         }
     }
 }
@@ -772,6 +742,7 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
 {
     constexpr bool CAN_STAGE = STAGE && XM_SCATTER_STAGED != 0 && NSUB * 256 == XM_GRAN;
     __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
+    __shared__ uint64_t lptr_all[LISTS ? XM_BLOCK / 64 : 1][8];
     __shared__ __attribute__((aligned(16))) uint16_t slab_all[CAN_STAGE ? XM_BLOCK / 64 : 1][CAN_STAGE ? XM_SLAB_U16 : 4];
     const uint32_t lane = threadIdx.x & 63u;
     {   // K2b has consumed the part totals: leave them zeroed for the next count (n_parts cells in each of the 8 x replicas rows)
@@ -784,6 +755,8 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
     if (g >= n_gran) return;                                              // wave-uniform; no barrier in this kernel
     uint8_t *lut = lut_all[NIB ? 0 : wave];
     if (!NIB) lut[lane] = (uint8_t)bin_of_code(mode, lane == 63u ? XM_NO_UNIT : lane);
+    uint64_t *lptr = lptr_all[LISTS ? wave : 0];
+    if (LISTS && lane < 8u) lptr[lane] = lane < 7u ? (uint64_t)(uintptr_t)lo.p[lane] : 0ull;      // read back by this wave only
 
     // lane b < 8: where bin b starts in idx_out (exclusive prefix of the bin totals) plus what the granules before
     // this one hold of it
@@ -833,9 +806,9 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) w[s] = load_codes4_tail(code, rec_g + s * 256u + lane * 4u, n);
     }
-    if (!NIB) lds_settle();
+    if (!NIB || LISTS) lds_settle();
     if (CAN_STAGE && staged) {
-        scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lo);
+        scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lptr);
         lds_settle();                                                     // the wave's slab is complete
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
@@ -845,7 +818,7 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
             scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, dst);
         }
     } else {
-        scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lo);
+        scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lptr);
     }
 }
 
@@ -1184,6 +1157,7 @@ struct TileOps {
     uint32_t tb, te;                // the tile's stretch [tb, te) of the op array
     uint32_t v[8];                  // ops tb + 8 lane .. + 7 (first chunk), 0 where past the stretch
     bool fast;                      // wave-uniform: stretch sane, shorter than XM_CIG_WAVE_OPS, 16-byte loads stay inside the array
+    bool brief;                     // wave-uniform: fast and fewer than 256 ops -- four op slots per lane do (v[0..3] only)
 };
 
 // ops [base + s0, base + s0 + 8) of a stretch of W ops with two 16-byte loads, unconditionally (a conditional load would make
@@ -1199,6 +1173,31 @@ __device__ __forceinline__ void cigp_load8(const uint32_t *__restrict__ ops, uin
     const v4i32 b = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p + 4));
     v[0] = (uint32_t)a.x; v[1] = (uint32_t)a.y; v[2] = (uint32_t)a.z; v[3] = (uint32_t)a.w;
     v[4] = (uint32_t)b.x; v[5] = (uint32_t)b.y; v[6] = (uint32_t)b.z; v[7] = (uint32_t)b.w;
+}
+
+// the same for a stretch of fewer than 256 ops: ops [base + s0, base + s0 + 4), one 16-byte load per lane
+__device__ __forceinline__ void cigp_load4(const uint32_t *__restrict__ ops, uint32_t base, uint32_t W, uint32_t s0, uint32_t v[8])
+{
+    const uint32_t *p = ops + base + ((s0 < W) ? s0 : 0u);
+    const v4i32 a = __builtin_nontemporal_load(reinterpret_cast<const v4i32_a4 *>(p));
+    v[0] = (uint32_t)a.x; v[1] = (uint32_t)a.y; v[2] = (uint32_t)a.z; v[3] = (uint32_t)a.w;
+}
+
+// ... and its prefix pass over 256 op slots (4 per lane): half the term arithmetic of cigp_chunk.  Typical tiles hold
+// ~200 ops (k = 0.78 per record), so this is the usual case.
+__device__ __forceinline__ uint32_t cigp_chunk4(const uint32_t v[8], uint32_t s0, uint32_t *T, uint32_t &any)
+{
+    uint32_t p[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        p[q] = run;
+        any |= v[q];
+        run += cigar_term24(v[q]);
+    }
+    const uint32_t tincl = wave_scan_incl(run);
+    const uint32_t ex = tincl - run;
+    *reinterpret_cast<uint4 *>(T + s0) = make_uint4(ex + p[0], ex + p[1], ex + p[2], ex + p[3]);
+    return lane_value(tincl, 63);
 }
 
 // One prefix pass over 512 op slots (8 per lane, slot s0 + q in v[q]): penalty terms, their running sums inside the lane, a
@@ -1236,7 +1235,7 @@ __device__ __forceinline__ bool cigp_fast(const uint32_t *__restrict__ ops, cons
     // the stretch is shorter than XM_CIG_WAVE_OPS = 2 chunks: the first (fetched by the caller) always -- it holds slot W,
     // the grand total, whenever W < 512 --, the second only for a stretch of 512 ops or more
     uint32_t any = 0;
-    uint32_t carry = cigp_chunk(o.v, 8u * lane, 0u, T, any);
+    uint32_t carry = o.brief ? cigp_chunk4(o.v, 4u * lane, T, any) : cigp_chunk(o.v, 8u * lane, 0u, T, any);
     if (W >= XM_CIGP_CHUNK) {
         uint32_t v[8];
         cigp_load8(ops, o.tb, W, XM_CIGP_CHUNK + 8u * lane, v);
@@ -1381,8 +1380,15 @@ __device__ __forceinline__ void classify_cigp_body(const CigCols s1, const CigCo
     o1.fast = FULL && o1.te >= o1.tb && o1.te - o1.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o1.te + 8u <= n_ops1;
     o2.fast = FULL && o2.te >= o2.tb && o2.te - o2.tb < (uint32_t)XM_CIG_WAVE_OPS && (uint64_t)o2.te + 8u <= n_ops2;
     // ... and the first 512 ops of both stretches.
-    if (o1.fast) cigp_load8(s1.ops, o1.tb, o1.te - o1.tb, 8u * lane, o1.v);
-    if (o2.fast) cigp_load8(s2.ops, o2.tb, o2.te - o2.tb, 8u * lane, o2.v);
+#ifndef XM_CIGP_BRIEF
+#define XM_CIGP_BRIEF 1            // 0 in a tuning build: always eight op slots per lane
+#endif
+    o1.brief = XM_CIGP_BRIEF && o1.fast && o1.te - o1.tb < 256u;
+    o2.brief = XM_CIGP_BRIEF && o2.fast && o2.te - o2.tb < 256u;
+    if (o1.brief) cigp_load4(s1.ops, o1.tb, o1.te - o1.tb, 4u * lane, o1.v);
+    else if (o1.fast) cigp_load8(s1.ops, o1.tb, o1.te - o1.tb, 8u * lane, o1.v);
+    if (o2.brief) cigp_load4(s2.ops, o2.tb, o2.te - o2.tb, 4u * lane, o2.v);
+    else if (o2.fast) cigp_load8(s2.ops, o2.tb, o2.te - o2.tb, 8u * lane, o2.v);
 
     bool bad = false;
     if (!(o1.fast && cigp_fast(s1.ops, o1, cw1, nmv1, cig_T, a1, bad))) {
