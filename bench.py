@@ -948,6 +948,19 @@ def main():
                               "verified_vs_oracle": ok2}
                 if name == "cfg3":
                     extra[key]["mean_cigar_ops_per_record"] = w2.k_bar
+                    # the timed step takes PACKED CIGAR columns (packed once, during set-up); callers that hold CSR columns pay
+                    # xm_cigar_pack on the host per block (the host-buffer entry points do it themselves) -- its rate, one thread:
+                    try:
+                        m = min(w2.n, 10_000_000)
+                        off = w2.cig[0]["cig_off"][:m + 1].cpu().numpy().view(np.uint32)
+                        ops = w2.cig[0]["cig_oplen"][:int(off[-1])].cpu().numpy().view(np.uint32)
+                        t0 = time.perf_counter()
+                        _ffi.cigar_pack(off, ops)
+                        el = time.perf_counter() - t0
+                        extra[key]["host_cigar_pack"] = {"records": m, "seconds": round(el, 4), "M_records_per_s": m / el / 1e6,
+                                                         "what": "xm_cigar_pack (CSR -> packed columns) on one host thread; outside the timed region"}
+                    except Exception as e:                       # noqa: BLE001
+                        extra[key]["host_cigar_pack"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 del w2
                 torch.cuda.empty_cache()
             except Exception as e:                               # noqa: BLE001 -- reported, the headline line still goes out

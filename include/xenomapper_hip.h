@@ -336,6 +336,14 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
                                        uint64_t *n_out, uint64_t *counts);
 
 /*
+ * Test aid: synchronises the device and reports (*clean = 1) whether the context's counting workspace -- the replicated
+ * category_counts and the per-part bin totals, which every counting kernel adds into and every scan / scatter consumes and
+ * zeroes -- is all zero, as it must be between calls whatever the sequence of calls (counts only, compaction, a smaller input
+ * after a larger one, failed launches).
+ */
+int xm_workspace_is_clean(xm_ctx *ctx, int *clean);
+
+/*
  * Measurement aid ("measure an on-box streaming-copy ceiling alongside" the 8 TB/s specification): the classify
  * kernel's memory shape without its arithmetic -- reads 16 bytes per record from four int32 columns (n_records rounded down
  * to a multiple of 4), writes XM_BINS4_BYTES(n_records) bytes at most to `out` (the compact stream's size).  The values

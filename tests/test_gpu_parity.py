@@ -1078,6 +1078,40 @@ def test_two_streams_on_one_context_are_ordered_by_the_library(ctx):
         assert np.array_equal(d["idx"][:int(want_off[7])].cpu().numpy().view(np.uint32), want_idx)
 
 
+def test_counting_workspace_is_zero_between_calls_whatever_the_sequence(ctx):
+    """The replicated category_counts and the per-part bin totals are added into by every counting kernel and consumed by
+    the scan / scatter (include/xenomapper_hip.h): after any mix of calls -- counts only, fused compaction, stand-alone
+    compaction, the six-list form, CIGAR columns, a small input after a large one, an empty one -- they must be all zero
+    again, and the results right."""
+    rng = np.random.default_rng(515)
+    assert ctx.workspace_is_clean()
+    for n, mode in ((3_000_001, 1), (5, 2), (70_000, 0), (0, 1), (2_200_000, 2), (2049, 1)):
+        cols = random_columns(rng, n)
+        bits = H.synth.pack_unit_bits(rng.random(n) < 0.6) if n else np.zeros(1, dtype=np.uint64)
+        want_code, want_counts = H.c_classify(mode, *cols, bits, -1)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        code, counts = ctx.classify(mode, *cols, bits, -1)                    # counting K1 + scan only
+        assert np.array_equal(code, want_code) and np.array_equal(counts, want_counts)
+        assert ctx.workspace_is_clean()
+        _, idx, off, counts = ctx.classify_compact(mode, *cols, bits, -1, want_code=False)
+        assert np.array_equal(idx, want_idx) and np.array_equal(off, want_off) and np.array_equal(counts, want_counts)
+        assert ctx.workspace_is_clean()
+        idx, off, counts = ctx.compact(mode, want_code)                       # K2a counts from memory
+        assert np.array_equal(idx, want_idx) and np.array_equal(counts, want_counts)
+        assert ctx.workspace_is_clean()
+        _, lists, n_out, counts = ctx.classify_place(mode, *cols, bits, -1, want_code=False)
+        assert int(n_out[7]) == int(want_off[7]) and np.array_equal(counts, want_counts)
+        assert ctx.workspace_is_clean()
+    c1 = H.synth.cigar_columns(300_001, seed=11)
+    c2 = H.synth.cigar_columns(300_001, seed=12, mapped_p=0.4)
+    xs = np.full(300_001, ABSENT, dtype=np.int32)
+    bits = H.synth.interleaved_unit_bits(300_001)
+    ctx.classify_compact_cigar(1, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs, c2["nm"], c2["cig_off"], c2["cig_oplen"], xs, bits, ABSENT)
+    assert ctx.workspace_is_clean()
+    ctx.classify_cigar(1, c1["nm"], c1["cig_off"], c1["cig_oplen"], xs, c2["nm"], c2["cig_off"], c2["cig_oplen"], xs, bits, ABSENT)
+    assert ctx.workspace_is_clean()
+
+
 def test_large_batch_64bit_offsets(ctx):
     """300 M records per species (column byte offsets beyond 2^32, record indices beyond 2^28), ragged tail;
     exact against the C oracle."""

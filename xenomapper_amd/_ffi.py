@@ -117,6 +117,7 @@ def lib():
         "xm_classify_place_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P, U64, P, P], I),
         "xm_classify_place_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, U64, P, P], I),
         "xm_stream_probe_dev": ([P, P, U64, P, P, P, P, P], I),
+        "xm_workspace_is_clean": ([P, ctypes.POINTER(I)], I),
         "xm_comm_unique_id": ([P], I),
         "xm_comm_init": ([P, I, I, P], I),
         "xm_comm_destroy": ([P], I),
@@ -141,7 +142,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
             "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister",
             "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev",
-            "xm_classify_place_cigar_packed_dev", "xm_stream_probe_dev",
+            "xm_classify_place_cigar_packed_dev", "xm_stream_probe_dev", "xm_workspace_is_clean",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
 
@@ -515,6 +516,12 @@ class Context(object):
             self._h, self._stream_handle(stream), mode, nm1.numel(), *ptrs, int(min_score_floor), opt(code_out), opt(bins4),
             opt(range_flag), arr, cap, opt(n_out), opt(counts))
         self._check(rc, "xm_classify_place_cigar_packed_dev")
+
+    def workspace_is_clean(self):
+        """Synchronises; True when the counting workspace is in its between-calls state (all zero)."""
+        flag = ctypes.c_int(0)
+        self._check(self._L.xm_workspace_is_clean(self._h, ctypes.byref(flag)), "xm_workspace_is_clean")
+        return bool(flag.value)
 
     def stream_probe_dev(self, c0, c1, c2, c3, out, stream=None):
         """The classify kernel's memory shape without arithmetic (the box's streaming ceiling for it).  Asynchronous."""

@@ -662,6 +662,22 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
     return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
 }
 
+int xm_workspace_is_clean(xm_ctx *ctx, int *clean)
+{
+    if (!ctx || !clean) return XM_ERR_INVALID_ARG;
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    XM_HIP(ctx, hipDeviceSynchronize());
+    std::vector<uint32_t> part(PART_TOT_BYTES / sizeof(uint32_t));
+    std::vector<uint64_t> rep(XM_COUNT_REPLICAS * 64);
+    XM_HIP(ctx, hipMemcpy(part.data(), ctx->d_part_tot, PART_TOT_BYTES, hipMemcpyDeviceToHost));
+    XM_HIP(ctx, hipMemcpy(rep.data(), ctx->d_counts_rep, rep.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint64_t any = 0;
+    for (uint32_t v : part) any |= v;
+    for (uint64_t v : rep) any |= v;
+    *clean = any == 0 ? 1 : 0;
+    return XM_OK;
+}
+
 int xm_stream_probe_dev(xm_ctx *ctx, void *stream, uint64_t n,
                         const int32_t *c0, const int32_t *c1, const int32_t *c2, const int32_t *c3, uint8_t *out)
 {
