@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XMH_ABI_VERSION 2
+#define XMH_ABI_VERSION 3
 
 #define XMH_OK              0
 #define XMH_ERR_INVALID_ARG (-1)
@@ -114,6 +114,16 @@ int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const ch
  */
 int xmh_emit(xmh_parser *p, const char *buf1, const char *buf2, int paired, int bin,
              const uint32_t *idx, uint64_t n_idx, char *out, uint64_t out_cap, uint64_t *out_len);
+
+/* ---- blocks stripped on the GPU (include/xenomapper_strip.h) -------------------------------------------------
+ * xmh_copy: memcpy by the parser's threads (the window of a mapped file into a page-locked staging buffer: the pages are
+ * mapped in bulk first, then copied at the memory system's rate rather than one core's).
+ * xmh_adopt_lines: make the line tables of a block that was stripped elsewhere the parser's current block, so that
+ * xmh_emit writes its units (window offsets as 32-bit values; of the flags only XMH_LINE_NORMAL is looked at). */
+int xmh_copy(xmh_parser *p, void *dst, const void *src, uint64_t n);
+int xmh_adopt_lines(xmh_parser *p, uint64_t n_records,
+                    const uint32_t *line_off1, const uint32_t *line_len1, const uint32_t *norm_len1, const uint8_t *line_flags1,
+                    const uint32_t *line_off2, const uint32_t *line_len2, const uint32_t *norm_len2, const uint8_t *line_flags2);
 
 /* ---- BAM input ------------------------------------------------------------------------
  * The reference reads BAM by piping it through `samtools view` (get_bam_header, bam_lines, getBamReadPairs,

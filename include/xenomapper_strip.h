@@ -1,0 +1,115 @@
+/*
+ * xenomapper_strip.h -- C ABI of the SAM column stripper that runs ON the GPU (libxenomapper_hip.so, gfx950).
+ *
+ * The reference reads its two SAM files line by line on one core -- getReadPairs
+ * (/root/reference/xenomapper/xenomapper.py:95-118: readline, strip, split, compare the names) and the text half
+ * of tag_func (get_tag :176-191, get_tag_with_ZS_as_XS :193-206: find the optional fields that contain "AS" /
+ * "XS" / "ZS", int() of what follows the last ':').  include/xenomapper_host.h does that with host threads
+ * (xmh_parse); this header is the same step with the text shipped to the device instead: the host only copies
+ * the two windows of text into page-locked staging buffers, the kernels index the lines (universal newlines),
+ * split them by Python's white space rules, find the tags, compare the names and leave the score columns and
+ * the unit mask IN HBM, where the classify kernels (include/xenomapper_hip.h) read them -- no column ever
+ * crosses PCIe.  What comes back is what the line writer (xmh_emit) needs: where every line starts and ends.
+ *
+ * Same exactness contract as xmh_parse: a value that is not a plain int32 integer or a tag that matches twice
+ * is flagged per line (XMS_LINE_EX_*), never guessed; non-ASCII input is refused as a whole (non_ascii).  The
+ * caller resolves flagged records with the reference-equivalent text functions (xm_strip_columns brings the
+ * columns to the host for that) or hands the window to xmh_parse.
+ *
+ * Scope: the lock-step walk without --skip_repeated_reads (record k = line k of both files; the paired-end
+ * default, xenomapper.py:691) and the AS/XS and AS/ZS plugins.  The CIGAR plugin and the skipping walk stay with
+ * xmh_parse.  Windows are shorter than 4 GiB - 64 KiB.
+ *
+ * A stripper has two slots so that one window pair can be copied, uploaded and stripped (one host thread) while
+ * the block before it is classified and written (another thread); calls on one slot must not overlap.
+ */
+#ifndef XENOMAPPER_STRIP_H
+#define XENOMAPPER_STRIP_H
+
+#include "xenomapper_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMS_ABI_VERSION 1
+#define XMS_SLOTS 2
+#define XMS_MAX_WINDOW 0xFFFF0000ull
+
+/* score_mode (the values of XMH_SCORE_*) */
+#define XMS_SCORE_AS_XS 0   /* get_tag                 xenomapper.py:176-191 */
+#define XMS_SCORE_AS_ZS 1   /* get_tag_with_ZS_as_XS   xenomapper.py:193-206 */
+
+/* line flags; bit 0 is XMH_LINE_NORMAL of xenomapper_host.h */
+#define XMS_LINE_NORMAL   0x01u  /* the line already equals '\t'.join(fields)                                     */
+#define XMS_LINE_BLANK    0x02u  /* no field at all: ends the walk (xenomapper.py:105)                            */
+#define XMS_LINE_EX_A     0x0Cu  /* bits 2-3: exception kind of the AS column: 0, 1 = XMH_EX_NONINT, 2 = XMH_EX_DUP */
+#define XMS_LINE_EX_X     0x30u  /* bits 4-5: same for the XS (or ZS) column                                      */
+#define XMS_LINE_MISMATCH 0x40u  /* file-1 flags only: the names of the two files differ (xenomapper.py:106)      */
+
+typedef struct xm_strip xm_strip;
+
+/* Result of xm_strip_run; the fields up to mismatch_at mean what they mean in xmh_block.  The arrays are page-locked
+ * host memory owned by the stripper: n_records entries each, valid until the next xm_strip_run on the same slot. */
+typedef struct {
+    uint64_t n_records;
+    uint64_t consumed1, consumed2;
+    uint64_t consumed_lines1, consumed_lines2;
+    int32_t  ended, starved;
+    int64_t  mismatch_at;
+    int32_t  non_ascii;        /* 1: a byte >= 0x80 in either window; nothing else of the result is meaningful */
+    int32_t  pad_;
+    uint64_t n_exceptions;     /* records among the n_records whose flags carry XMS_LINE_EX_A / _EX_X on either line */
+    uint64_t n_lines1, n_lines2;                        /* lines found in each window (complete ones; the last one of a file too) */
+    const uint32_t *line_off1, *line_off2;              /* first byte of the record's line in its window */
+    const uint32_t *line_len1, *line_len2;              /* bytes without the terminator */
+    const uint32_t *norm_len1, *norm_len2;              /* length of '\t'.join(fields) */
+    const uint8_t  *line_flags1, *line_flags2;          /* XMS_LINE_* */
+    float ms_upload, ms_kernels;                        /* device time of the text upload and of the four kernels (HIP events) */
+} xm_strip_block;
+
+int xms_abi_version(void);
+
+/* ctx: the classifier context the columns will be classified with (same device).  Allocates nothing large. */
+int xm_strip_create(xm_ctx *ctx, int device_id, xm_strip **out);
+int xm_strip_destroy(xm_strip *s);
+
+/* Make the slot's buffers hold windows of window_bytes per file and max_records records (grows only; not to be called
+ * while the slot is in use).  XM_ERR_INVALID_ARG beyond XMS_MAX_WINDOW. */
+int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_records);
+
+/* Page-locked staging buffer of a slot for file 0 / 1 (window_bytes long): the caller copies the window there. */
+char *xm_strip_staging(xm_strip *s, int slot, int file);
+
+/*
+ * Upload the two staged windows (len1 / len2 bytes; eof*: the window reaches the end of its file) and strip them.
+ * paired: the unit mask is name[k] == name[k-1] (else every record is a unit); keep_halo / max_records as in
+ * xmh_parse.  Blocking (the slot's own stream).  The columns of the block stay on the device for xm_strip_classify.
+ */
+int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, int eof2,
+                 int score_mode, int paired, int keep_halo, uint64_t max_records, xm_strip_block *out);
+
+/*
+ * The fused main loop (xm_classify_compact_dev) on the first n_records records of the slot's block.  Results in
+ * page-locked host arrays owned by the stripper, valid until the next call on the slot: code (n_records bytes), the six
+ * index lists back to back (*idx) with bin_offsets[8], counts[64].
+ */
+int xm_strip_classify(xm_strip *s, int slot, int mode, uint64_t n_records, int32_t min_score_floor,
+                      const uint8_t **code, const uint32_t **idx, uint64_t bin_offsets[8], uint64_t counts[64]);
+
+/* Bring the first n_records of the slot's score columns and ceil(n/64) words of the unit mask to the host (for records
+ * the caller must patch by the text rules).  Any pointer may be NULL. */
+int xm_strip_columns(xm_strip *s, int slot, uint64_t n_records, int32_t *as1, int32_t *xs1, int32_t *as2, int32_t *xs2,
+                     uint64_t *unit_bits);
+
+/* Device addresses of the slot's columns: as1, xs1, as2, xs2 (int32) and unit_bits (uint64), for callers that launch the
+ * classify kernels themselves (xm_classify_*_dev). */
+int xm_strip_device_columns(xm_strip *s, int slot, void *ptrs[5]);
+
+/* Text of the last failing HIP call of this stripper (empty string if none). */
+const char *xm_strip_last_error(const xm_strip *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XENOMAPPER_STRIP_H */

@@ -1,0 +1,175 @@
+"""The SAM column stripper on the GPU (include/xenomapper_strip.h) against the host stripper (xmh_parse), which the CPU
+suite pins to the oracle's restatement of the reference's text rules: same records, same consumed bytes, same walk
+outcome, same score columns, unit mask, line tables and flagged values -- on random adversarial text, on windows cut
+in the middle of files, and on a large synthetic pair of files; then the fused classify pass on the device-resident
+columns against the same pass on the host stripper's columns."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from tests.test_host_fuzz import sam_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rig():
+    from xenomapper_amd import _ffi, _host
+    from xenomapper_amd.xenomapper import default_context
+    ctx = default_context()
+    s = _ffi.Stripper(ctx)
+    p = _host.Parser(4)
+    yield ctx, s, p
+    s.close()
+    p.close()
+
+
+def strip(s, slot, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records):
+    s.reserve(slot, max(len(b1), len(b2), 1), max_records)
+    for f, b in enumerate((b1, b2)):
+        if len(b):
+            s.staging(slot, f)[:len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return s.run(slot, len(b1), eof1, len(b2), eof2, score_mode, paired, keep_halo, max_records)
+
+
+def compare(s, p, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records, slot=0):
+    from xenomapper_amd import _host
+    r1, r2 = np.frombuffer(b1, dtype=np.uint8), np.frombuffer(b2, dtype=np.uint8)
+    got = strip(s, slot, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records)
+    try:
+        want = p.parse(r1, 0, len(r1), eof1, r2, 0, len(r2), eof2, score_mode, paired, False, keep_halo, max_records)
+    except _host.NonAsciiInput:
+        assert got.non_ascii
+        return got, None
+    assert not got.non_ascii
+    ctxt = (b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records)
+    assert got.n == want.n, ctxt
+    assert (got.ended, got.starved, got.mismatch_at) == (want.ended, want.starved, want.mismatch_at), ctxt
+    assert got.consumed == want.consumed, ctxt
+    assert got.consumed_lines == want.consumed_lines, ctxt
+    n = got.n
+    for f in (0, 1):
+        assert np.array_equal(got.line_off[f], want.line_off[f].astype(np.uint32)), ctxt
+        assert np.array_equal(got.line_len[f], want.line_len[f]), ctxt
+    assert sorted(got.exc) == sorted(want.exc), ctxt
+    cols = got.cols
+    for c in range(4):
+        assert np.array_equal(cols[c], want.cols[c]), (c, ctxt)
+    bits = lambda a: np.unpackbits(np.ascontiguousarray(a).view(np.uint8), bitorder="little")[:n]
+    assert np.array_equal(bits(got.unit_bits), bits(want.unit_bits)), ctxt
+    if n:                                   # the writer on the adopted tables writes what it writes on its own
+        idx = np.arange(1 if paired else 0, n, dtype=np.uint32)
+        want_text = [bytes(p.emit(paired, b, idx)) for b in (0, 1, 4)]
+        p.adopt_lines(r1, 0, r2, 0, n, got.tables)
+        assert [bytes(p.emit(paired, b, idx)) for b in (0, 1, 4)] == want_text, ctxt
+    return got, want
+
+
+@settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "300")), deadline=None, suppress_health_check=list(HealthCheck))
+@given(texts=sam_pair(), score_mode=st.sampled_from([0, 1]), paired=st.booleans(), keep_halo=st.booleans(),
+       eofs=st.tuples(st.booleans(), st.booleans()), max_records=st.sampled_from([1 << 16, 1 << 16, 3, 1]),
+       cut=st.tuples(st.integers(0, 40), st.integers(0, 40)))
+def test_gpu_stripper_agrees_with_the_host_stripper_on_random_text(rig, texts, score_mode, paired, keep_halo, eofs, max_records, cut):
+    _ctx, s, p = rig
+    b1, b2 = texts[0].encode("ascii"), texts[1].encode("ascii")
+    if not eofs[0]:
+        b1 = b1[:max(0, len(b1) - cut[0])]          # a window that stops somewhere inside the file
+    if not eofs[1]:
+        b2 = b2[:max(0, len(b2) - cut[1])]
+    compare(s, p, b1, b2, eofs[0], eofs[1], score_mode, paired, keep_halo, max_records)
+
+
+def test_non_ascii_windows_are_refused_as_a_whole(rig):
+    _ctx, s, p = rig
+    good = b"r1\t0\tc\t1\t9\t4M\t*\t0\t0\tACGT\tIIII\tAS:i:3\tXS:i:1\n"
+    bad = good.replace(b"ACGT", b"AC\xc3\xa9")
+    for b1, b2 in ((bad, good), (good, bad), (good + bad[:30], good)):
+        got = strip(s, 0, b1, b2, True, True, 0, False, False, 16)
+        assert got.non_ascii
+    assert not strip(s, 0, good, good, True, True, 0, False, False, 16).non_ascii
+
+
+def _big_pair(n_pairs, seed, crlf=False):
+    """Two files of 2 x n_pairs records in the same order: names, tags and a few oddities drawn at random."""
+    rng = np.random.default_rng(seed)
+    out = [[], []]
+    seq = "ACGT" * 37 + "AC"
+    qual = "I" * 150
+    for i in range(n_pairs):
+        name = "read%d/%d" % (i, int(rng.integers(0, 1000)))
+        for mate in (0, 1):
+            for f in (0, 1):
+                a, x = int(rng.integers(-60, 1)), int(rng.integers(-80, 1))
+                tags = []
+                r = int(rng.integers(0, 40))
+                if r != 0:
+                    tags.append("AS:i:%d" % a)
+                if r % 3:
+                    tags.append("XS:i:%d" % x)
+                if r == 7:
+                    tags.append("ZS:i:%d" % x)
+                if r == 11:
+                    tags.append("XS:f:1.5")              # flagged: not an integer
+                if r == 13:
+                    tags.append("RG:Z:BASS")             # flagged: a second field containing "AS"
+                tags += ["XN:i:0", "XM:i:%d" % (r % 5), "NM:i:%d" % (r % 5), "YT:Z:CP"]
+                sep = " " if r == 17 else "\t"
+                fields = [name, str(83 + 16 * mate), "chr%d" % (1 + f), str(1000 + i), "42", "150M", "=", str(1200 + i),
+                          "350", seq, qual] + tags
+                out[f].append(sep.join(fields))
+    nl = "\r\n" if crlf else "\n"
+    return (nl.join(out[0]) + nl).encode(), (nl.join(out[1]) + nl).encode()
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_large_files_in_windows_with_halo_like_the_file_path(rig, crlf):
+    ctx, s, p = rig
+    from xenomapper_amd import _ffi
+    b1, b2 = _big_pair(30000, 5, crlf)
+    pos = [0, 0]
+    window = 3 << 20
+    blocks = 0
+    totals_g, totals_h = np.zeros(64, np.uint64), np.zeros(64, np.uint64)
+    while True:
+        w1, w2 = b1[pos[0]:pos[0] + window], b2[pos[1]:pos[1] + window]
+        e1, e2 = pos[0] + window >= len(b1), pos[1] + window >= len(b2)
+        got, want = compare(s, p, w1, w2, e1, e2, 0, True, True, 1 << 20, slot=blocks & 1)
+        assert got.n > 1000
+        # the fused pass on the device-resident columns == the same pass on the host stripper's columns
+        # (flagged values are absent in both; the file path patches them before it classifies)
+        code, idx, off, counts = s.classify(blocks & 1, _ffi.MODE_PE_LIBERAL, got.n, -2**31)
+        hcode, hidx, hoff, hcounts = ctx.classify_compact(_ffi.MODE_PE_LIBERAL, *want.cols, want.unit_bits, -2**31)
+        assert np.array_equal(code, hcode) and np.array_equal(idx, hidx) and np.array_equal(off, hoff)
+        assert np.array_equal(counts, hcounts)
+        totals_g += counts
+        totals_h += hcounts
+        blocks += 1
+        if got.ended:
+            break
+        assert got.consumed[0] > 0
+        pos[0] += got.consumed[0]
+        pos[1] += got.consumed[1]
+    assert blocks >= 4 and int(totals_g.sum()) == 30000 and np.array_equal(totals_g, totals_h)
+
+
+def test_zs_plugin_and_single_end_units(rig):
+    _ctx, s, p = rig
+    b1, b2 = _big_pair(2000, 9)
+    for score_mode, paired in ((1, True), (1, False), (0, False)):
+        compare(s, p, b1, b2, True, True, score_mode, paired, paired, 1 << 20)
+
+
+def test_record_limit_and_empty_windows(rig):
+    _ctx, s, p = rig
+    b1, b2 = _big_pair(300, 3)
+    for max_records in (1, 2, 63, 64, 65, 600, 601):
+        compare(s, p, b1, b2, True, True, 0, True, True, max_records)
+        compare(s, p, b1, b2, False, False, 0, True, False, max_records)
+    compare(s, p, b"", b"", True, True, 0, True, True, 16)
+    compare(s, p, b1, b"", True, True, 0, True, True, 16)
+    compare(s, p, b"", b2, False, True, 0, False, False, 16)
+    compare(s, p, b1[:-1], b2[:-1], True, True, 0, True, True, 1 << 20)        # last line without a terminator
+    compare(s, p, b1[:-1], b2[:-1], False, False, 0, True, True, 1 << 20)
+    compare(s, p, b1 + b"\n" + b1, b2 + b"\n" + b2, True, True, 0, True, True, 1 << 20)   # a blank line ends the walk

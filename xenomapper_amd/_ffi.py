@@ -127,6 +127,17 @@ def lib():
         "xm_timing_select": ([P, ctypes.c_uint32], I),
         "xm_timing_reset": ([P], I),
         "xm_timing_read": ([P, P, P], I),
+        # include/xenomapper_strip.h
+        "xms_abi_version": ([], I),
+        "xm_strip_create": ([P, I, ctypes.POINTER(P)], I),
+        "xm_strip_destroy": ([P], I),
+        "xm_strip_reserve": ([P, I, U64, U64], I),
+        "xm_strip_staging": ([P, I, I], P),
+        "xm_strip_run": ([P, I, U64, I, U64, I, I, I, I, U64, P], I),
+        "xm_strip_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
+        "xm_strip_columns": ([P, I, U64, P, P, P, P, P], I),
+        "xm_strip_device_columns": ([P, I, P], I),
+        "xm_strip_last_error": ([P], ctypes.c_char_p),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -144,7 +155,9 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev",
             "xm_classify_place_cigar_packed_dev", "xm_stream_probe_dev", "xm_workspace_is_clean",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
-            "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read")
+            "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
+            "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_run",
+            "xm_strip_classify", "xm_strip_columns", "xm_strip_device_columns", "xm_strip_last_error")
 
 
 def _np_ptr(a):
@@ -565,3 +578,153 @@ class Context(object):
         launches = (ctypes.c_uint64 * len(KERNELS))()
         self._check(self._L.xm_timing_read(self._h, ms, launches), "xm_timing_read")
         return {k: {"ms": ms[i], "launches": int(launches[i])} for i, k in enumerate(KERNELS)}
+
+
+# ---- include/xenomapper_strip.h: the SAM column stripper on the GPU --------------------------------------------
+LINE_NORMAL, LINE_BLANK, LINE_EX_A, LINE_EX_X, LINE_MISMATCH = 0x01, 0x02, 0x0C, 0x30, 0x40
+STRIP_SLOTS = 2
+STRIP_MAX_WINDOW = 0xFFFF0000
+
+
+class _StripBlock(ctypes.Structure):
+    _fields_ = [("n_records", ctypes.c_uint64), ("consumed1", ctypes.c_uint64), ("consumed2", ctypes.c_uint64),
+                ("consumed_lines1", ctypes.c_uint64), ("consumed_lines2", ctypes.c_uint64),
+                ("ended", ctypes.c_int32), ("starved", ctypes.c_int32), ("mismatch_at", ctypes.c_int64),
+                ("non_ascii", ctypes.c_int32), ("pad_", ctypes.c_int32), ("n_exceptions", ctypes.c_uint64),
+                ("n_lines1", ctypes.c_uint64), ("n_lines2", ctypes.c_uint64),
+                ("line_off1", ctypes.c_void_p), ("line_off2", ctypes.c_void_p), ("line_len1", ctypes.c_void_p),
+                ("line_len2", ctypes.c_void_p), ("norm_len1", ctypes.c_void_p), ("norm_len2", ctypes.c_void_p),
+                ("line_flags1", ctypes.c_void_p), ("line_flags2", ctypes.c_void_p),
+                ("ms_upload", ctypes.c_float), ("ms_kernels", ctypes.c_float)]
+
+
+def _host_view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class StrippedBlock(object):
+    """One pair of windows stripped on the GPU (xm_strip_block): the walk's outcome and the line tables as NumPy views of
+    the stripper's page-locked arrays (valid until the slot is run again); the score columns stay on the device."""
+
+    def __init__(self, stripper, slot, raw):
+        self.stripper, self.slot = stripper, slot
+        n = self.n = int(raw.n_records)
+        self.consumed = (int(raw.consumed1), int(raw.consumed2))
+        self.consumed_lines = (int(raw.consumed_lines1), int(raw.consumed_lines2))
+        self.ended, self.starved, self.mismatch_at = bool(raw.ended), bool(raw.starved), int(raw.mismatch_at)
+        self.non_ascii = bool(raw.non_ascii)
+        self.n_exceptions = int(raw.n_exceptions)
+        self.n_lines = (int(raw.n_lines1), int(raw.n_lines2))
+        self.tables = (raw.line_off1, raw.line_len1, raw.norm_len1, raw.line_flags1,
+                       raw.line_off2, raw.line_len2, raw.norm_len2, raw.line_flags2)
+        self.line_off = [_host_view(raw.line_off1, n, np.uint32), _host_view(raw.line_off2, n, np.uint32)]
+        self.line_len = [_host_view(raw.line_len1, n, np.uint32), _host_view(raw.line_len2, n, np.uint32)]
+        self.norm_len = [_host_view(raw.norm_len1, n, np.uint32), _host_view(raw.norm_len2, n, np.uint32)]
+        self.line_flags = [_host_view(raw.line_flags1, n, np.uint8), _host_view(raw.line_flags2, n, np.uint8)]
+        self.ms_upload, self.ms_kernels = float(raw.ms_upload), float(raw.ms_kernels)
+        self.csr = None
+        self._host_cols = None
+
+    def _download(self):
+        if self._host_cols is None:
+            self._host_cols = self.stripper.columns(self.slot, self.n)
+        return self._host_cols
+
+    @property
+    def cols(self):
+        """The four score columns on the host (downloaded on first use: only blocks with flagged records need them)."""
+        return self._download()[:4]
+
+    @property
+    def unit_bits(self):
+        return self._download()[4]
+
+    @property
+    def exc(self):
+        """(record, column, kind) of every flagged value, ordered by (record, column) as xmh_block lists them."""
+        out = []
+        if self.n_exceptions:
+            flags = self.line_flags
+            hit = np.flatnonzero((flags[0] | flags[1]) & (LINE_EX_A | LINE_EX_X))
+            for k in hit.tolist():
+                for f in (0, 1):
+                    v = int(flags[f][k])
+                    if v & LINE_EX_A:
+                        out.append((k, 2 * f, (v >> 2) & 3))
+                    if v & LINE_EX_X:
+                        out.append((k, 2 * f + 1, (v >> 4) & 3))
+        return out
+
+
+class Stripper(object):
+    """xm_strip: SAM text in page-locked staging buffers -> score columns in HBM + line tables on the host."""
+
+    def __init__(self, ctx):
+        self._L = lib()
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        rc = self._L.xm_strip_create(ctx._h, ctx.device, ctypes.byref(h))
+        if rc != XM_OK:
+            raise _ERRORS.get(rc, RuntimeError)("xm_strip_create: " + self._L.xm_strerror(rc).decode())
+        self._h = h
+        self._cap = [(0, 0)] * STRIP_SLOTS
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.xm_strip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != XM_OK:
+            detail = self._L.xm_strip_last_error(self._h).decode()
+            raise _ERRORS.get(rc, RuntimeError)("%s: %s%s" % (what, self._L.xm_strerror(rc).decode(),
+                                                               " [" + detail + "]" if detail and rc in (-3, -4) else ""))
+
+    def reserve(self, slot, window_bytes, max_records):
+        have = self._cap[slot]
+        if window_bytes > have[0] or max_records > have[1]:
+            want = (max(window_bytes, have[0]), max(max_records, have[1]))
+            self._check(self._L.xm_strip_reserve(self._h, slot, want[0], want[1]), "xm_strip_reserve")
+            self._cap[slot] = want
+
+    def staging_address(self, slot, file):
+        return self._L.xm_strip_staging(self._h, slot, file)
+
+    def staging(self, slot, file):
+        """The slot's page-locked text buffer of one file as a uint8 array."""
+        return _host_view(self.staging_address(slot, file), self._cap[slot][0], np.uint8)
+
+    def run(self, slot, len1, eof1, len2, eof2, score_mode, paired, keep_halo, max_records):
+        raw = _StripBlock()
+        rc = self._L.xm_strip_run(self._h, slot, int(len1), int(bool(eof1)), int(len2), int(bool(eof2)), int(score_mode),
+                                  int(bool(paired)), int(bool(keep_halo)), int(max_records), ctypes.byref(raw))
+        self._check(rc, "xm_strip_run")
+        return StrippedBlock(self, slot, raw)
+
+    def classify(self, slot, mode, n_records, min_score_floor):
+        """The fused pass on the slot's device columns -> (code, idx, bin_offsets, counts); code / idx are views of
+        page-locked arrays, valid until the next classify on the slot."""
+        code, idx = ctypes.c_void_p(), ctypes.c_void_p()
+        off = np.zeros(8, dtype=np.uint64)
+        counts = np.zeros(64, dtype=np.uint64)
+        rc = self._L.xm_strip_classify(self._h, slot, int(mode), int(n_records), int(min_score_floor), ctypes.byref(code),
+                                       ctypes.byref(idx), _np_ptr(off), _np_ptr(counts))
+        self._check(rc, "xm_strip_classify")
+        return (_host_view(code.value, int(n_records), np.uint8), _host_view(idx.value, int(off[7]), np.uint32), off, counts)
+
+    def columns(self, slot, n_records):
+        """-> [as1, xs1, as2, xs2 (int32), unit_bits (uint64)] copied to the host."""
+        n = int(n_records)
+        out = [np.empty(n, dtype=np.int32) for _ in range(4)] + [np.zeros((n + 63) // 64, dtype=np.uint64)]
+        if n:
+            self._check(self._L.xm_strip_columns(self._h, slot, n, *[_np_ptr(a) for a in out]), "xm_strip_columns")
+        return out

@@ -15,7 +15,8 @@ EX_NONINT, EX_DUP, EX_SHORT, EX_BIGLEN = 1, 2, 3, 4
 ERR_NON_ASCII = -3
 
 EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_default_threads", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
-            "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read", "xmh_bam_read_pre", "xmh_parse_pre")
+            "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read", "xmh_bam_read_pre", "xmh_parse_pre",
+            "xmh_copy", "xmh_adopt_lines")
 NEED_TEXT = 1
 # xmh_pre (include/xenomapper_host.h): what the BAM decoder knows about every line it prints
 PRE_DTYPE = np.dtype([("line_len", np.uint32), ("name_len", np.uint16), ("flags", np.uint8), ("ex_as", np.uint8),
@@ -79,6 +80,8 @@ def lib():
         L.xmh_parse_pre.argtypes = [_P, _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P,
                                     _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_Block)]
+        L.xmh_copy.argtypes = [_P, _P, _P, ctypes.c_uint64]
+        L.xmh_adopt_lines.argtypes = [_P, ctypes.c_uint64] + [_P] * 8
         _lib = L
     return _lib
 
@@ -171,6 +174,23 @@ class Parser(object):
         self._win = (p1, p2)
         self._keep = (arr1, arr2, pre1, ops1, pre2, ops2)
         return Block(raw, score_mode == SCORE_CIGAR)
+
+    def copy(self, dst_address, arr, pos, n):
+        """arr[pos:pos + n] (uint8, e.g. a memory-mapped file) copied to dst_address by the parser's threads."""
+        if n:
+            rc = self._L.xmh_copy(self._h, _P(dst_address), _P(arr.ctypes.data + pos), int(n))
+            if rc != 0:
+                raise RuntimeError("xmh_copy: " + self._L.xmh_strerror(rc).decode())
+
+    def adopt_lines(self, arr1, pos1, arr2, pos2, n, tables):
+        """Make a block that was stripped on the GPU the parser's current block: tables = the eight host addresses
+        (line_off, line_len, norm_len, line_flags of file 1, then of file 2) of xm_strip_block; the windows start at
+        arr1[pos1] / arr2[pos2].  emit*() then write its units."""
+        rc = self._L.xmh_adopt_lines(self._h, int(n), *[_P(t) for t in tables])
+        if rc != 0:
+            raise RuntimeError("xmh_adopt_lines: " + self._L.xmh_strerror(rc).decode())
+        self._win = (arr1.ctypes.data + pos1, arr2.ctypes.data + pos2)
+        self._keep = (arr1, arr2)
 
     def emit_size(self, paired, bin_index, idx):
         """Bytes xmh_emit would write for these units (first half of its two-call protocol).  -> (idx as uint32, bytes)"""

@@ -718,6 +718,48 @@ int xmh_parse_pre(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, cons
                         skip_repeated, keep_halo, max_records, out);
 }
 
+// ---- blocks stripped elsewhere (on the GPU: include/xenomapper_strip.h) -----------------------------------------------
+int xmh_copy(xmh_parser *p, void *dst, const void *src, uint64_t n)
+{
+    if (!p || (n && (!dst || !src))) return XMH_ERR_INVALID_ARG;
+    prefault((const char *)src, n, *p->pool);
+    parallel_for(*p->pool, n, [&](int, uint64_t b, uint64_t e) {
+        memcpy((char *)dst + b, (const char *)src + b, (size_t)(e - b));
+    });
+    return XMH_OK;
+}
+
+int xmh_adopt_lines(xmh_parser *p, uint64_t n_records,
+                    const uint32_t *line_off1, const uint32_t *line_len1, const uint32_t *norm_len1, const uint8_t *line_flags1,
+                    const uint32_t *line_off2, const uint32_t *line_len2, const uint32_t *norm_len2, const uint8_t *line_flags2)
+{
+    if (!p || (n_records && (!line_off1 || !line_len1 || !norm_len1 || !line_flags1 || !line_off2 || !line_len2 || !norm_len2 ||
+                             !line_flags2)))
+        return XMH_ERR_INVALID_ARG;
+    try {
+        const uint32_t *off[2] = {line_off1, line_off2}, *len[2] = {line_len1, line_len2}, *nrm[2] = {norm_len1, norm_len2};
+        const uint8_t *flg[2] = {line_flags1, line_flags2};
+        std::vector<uint64_t> *loff[2] = {&p->loff1, &p->loff2};
+        std::vector<uint32_t> *llen[2] = {&p->llen1, &p->llen2}, *nlen[2] = {&p->nlen1, &p->nlen2};
+        std::vector<uint8_t> *lflag[2] = {&p->lflag1, &p->lflag2};
+        for (int f = 0; f < 2; ++f) {
+            p->sel[f].resize((size_t)n_records);                       // xmh_emit checks unit indices against its size
+            loff[f]->resize(n_records + 1); llen[f]->resize(n_records + 1); nlen[f]->resize(n_records + 1); lflag[f]->resize(n_records + 1);
+            parallel_for(*p->pool, n_records, [&](int, uint64_t b, uint64_t e) {
+                for (uint64_t k = b; k < e; ++k) {
+                    (*loff[f])[k] = off[f][k];
+                    (*llen[f])[k] = len[f][k];
+                    (*nlen[f])[k] = nrm[f][k];
+                    (*lflag[f])[k] = flg[f][k] & XMH_LINE_NORMAL;
+                }
+            });
+        }
+        return XMH_OK;
+    } catch (const std::bad_alloc &) {
+        return XMH_ERR_OOM;
+    }
+}
+
 static inline char *put_line(char *dst, const char *src, uint32_t len, uint8_t flags)
 {
     if (flags & XMH_LINE_NORMAL) {
