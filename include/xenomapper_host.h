@@ -121,6 +121,10 @@ int xmh_emit(xmh_parser *p, const char *buf1, const char *buf2, int paired, int 
  * xmh_adopt_lines: make the line tables of a block that was stripped elsewhere the parser's current block, so that
  * xmh_emit writes its units (window offsets as 32-bit values; of the flags only XMH_LINE_NORMAL is looked at). */
 int xmh_copy(xmh_parser *p, void *dst, const void *src, uint64_t n);
+/* xmh_pread: bytes [offset, offset + n) of an open file read into dst by the parser's threads (pread(2) on slices: the
+ * kernel copies from the page cache at the memory system's rate and no page of the file is ever mapped).
+ * XMH_ERR_INVALID_ARG when the file ends before offset + n or a read fails. */
+int xmh_pread(xmh_parser *p, int fd, uint64_t offset, void *dst, uint64_t n);
 int xmh_adopt_lines(xmh_parser *p, uint64_t n_records,
                     const uint32_t *line_off1, const uint32_t *line_len1, const uint32_t *norm_len1, const uint8_t *line_flags1,
                     const uint32_t *line_off2, const uint32_t *line_len2, const uint32_t *norm_len2, const uint8_t *line_flags2);

@@ -65,7 +65,7 @@ typedef struct {
     const uint32_t *line_len1, *line_len2;              /* bytes without the terminator */
     const uint32_t *norm_len1, *norm_len2;              /* length of '\t'.join(fields) */
     const uint8_t  *line_flags1, *line_flags2;          /* XMS_LINE_* */
-    float ms_upload, ms_kernels;                        /* device time of the text upload and of the four kernels (HIP events) */
+    float ms_upload, ms_kernels;                        /* device time from the first upload to the last, and of the kernels (HIP events) */
 } xm_strip_block;
 
 int xms_abi_version(void);
@@ -80,6 +80,11 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
 
 /* Page-locked staging buffer of a slot for file 0 / 1 (window_bytes long): the caller copies the window there. */
 char *xm_strip_staging(xm_strip *s, int slot, int file);
+
+/* Start the upload of bytes [offset, offset + bytes) of a staged window (asynchronous, on the slot's stream): called piece by
+ * piece, in order from offset 0, while the host is still copying the rest of the window into the staging buffer, it hides
+ * the copy behind the PCIe transfer.  Optional: xm_strip_run uploads whatever has not been sent. */
+int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t bytes);
 
 /*
  * Upload the two staged windows (len1 / len2 bytes; eof*: the window reaches the end of its file) and strip them.

@@ -15,19 +15,19 @@ from tests.helpers import NEG
 def _declared(header):
     text = open(os.path.join(H.REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(xm[h]?_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(xm[hs]?_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_hip_library_exports_every_declared_symbol():
     from xenomapper_amd import _ffi, build
     build.build_hip()
-    names = _declared("xenomapper_hip.h")
-    assert len(names) >= 17
+    names = sorted(_declared("xenomapper_hip.h") + _declared("xenomapper_strip.h"))
+    assert len(names) >= 17 + 10
     L = ctypes.CDLL(_ffi.LIB_PATH)
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_ffi.EXPORTED) == names
-    assert _ffi.lib().xm_abi_version() == 4
+    assert _ffi.lib().xm_abi_version() == 4 and _ffi.lib().xms_abi_version() == 1
     assert b"gfx950" in _ffi.lib().xm_strerror(-2)
 
 
@@ -287,3 +287,46 @@ def test_mapped_writer_falls_back_to_a_sparse_extension_only_where_preallocation
         sink.write("tail\n")
     data = path.read_bytes()
     assert data[:4] == b"@HD\n" and data[4:4 + (2 << 20)] == b"x" * (2 << 20) and data[-5:] == b"tail\n"
+
+
+def test_mapped_writer_extends_files_ahead_and_cuts_them_back(tmp_path):
+    """With the run's `ahead` table the output file stays longer than its content between calls (allocated by a helper
+    thread); ordinary writes in between land at the content's end, and finish() leaves exactly the content."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from xenomapper_amd import xenomapper as xm
+    path = tmp_path / "bin.sam"
+    ahead, pool = {}, ThreadPoolExecutor(max_workers=1)
+    with open(path, "wt") as sink:
+        sink.write("@HD\n")
+        fake = _FakeParser(2 << 20)
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True
+        state = ahead[id(sink)]
+        assert state.settle() == 4 + 3 * (2 << 20) == os.path.getsize(path)      # content + twice the last call, ahead
+        sink.write("small\n")                                                    # a bin too small for the mapping
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True  # fits what is there already
+        fake.need = 9 << 20
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True  # does not fit: extended on the spot
+        sink.write("tail\n")
+        state.finish(sink)
+    pool.shutdown()
+    data = path.read_bytes()
+    want = b"@HD\n" + b"x" * (2 << 20) + b"small\n" + b"x" * (2 << 20) + b"x" * (9 << 20) + b"tail\n"
+    assert data == want
+
+
+def test_mapped_writer_never_extends_an_append_mode_file_ahead(tmp_path):
+    """O_APPEND writes go to the end of the FILE: such a sink must never be longer than its content."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from xenomapper_amd import xenomapper as xm
+    path = tmp_path / "bin.sam"
+    path.write_text("@HD\n")
+    ahead, pool = {}, ThreadPoolExecutor(max_workers=1)
+    with open(path, "at") as sink:
+        fake = _FakeParser(2 << 20)
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True
+        assert not ahead and os.path.getsize(path) == 4 + (2 << 20)
+        sink.write("tail\n")
+    pool.shutdown()
+    assert path.read_bytes() == b"@HD\n" + b"x" * (2 << 20) + b"tail\n"

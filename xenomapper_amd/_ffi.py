@@ -133,6 +133,7 @@ def lib():
         "xm_strip_destroy": ([P], I),
         "xm_strip_reserve": ([P, I, U64, U64], I),
         "xm_strip_staging": ([P, I, I], P),
+        "xm_strip_upload": ([P, I, I, U64, U64], I),
         "xm_strip_run": ([P, I, U64, I, U64, I, I, I, I, U64, P], I),
         "xm_strip_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_strip_columns": ([P, I, U64, P, P, P, P, P], I),
@@ -156,7 +157,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_classify_place_cigar_packed_dev", "xm_stream_probe_dev", "xm_workspace_is_clean",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
-            "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_run",
+            "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_device_columns", "xm_strip_last_error")
 
 
@@ -702,6 +703,10 @@ class Stripper(object):
     def staging(self, slot, file):
         """The slot's page-locked text buffer of one file as a uint8 array."""
         return _host_view(self.staging_address(slot, file), self._cap[slot][0], np.uint8)
+
+    def upload(self, slot, file, offset, n):
+        """Start sending staged bytes [offset, offset + n) of one window to the device (in order, from 0)."""
+        self._check(self._L.xm_strip_upload(self._h, slot, file, int(offset), int(n)), "xm_strip_upload")
 
     def run(self, slot, len1, eof1, len2, eof2, score_mode, paired, keep_halo, max_records):
         raw = _StripBlock()

@@ -16,7 +16,7 @@ ERR_NON_ASCII = -3
 
 EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_default_threads", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
             "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read", "xmh_bam_read_pre", "xmh_parse_pre",
-            "xmh_copy", "xmh_adopt_lines")
+            "xmh_copy", "xmh_pread", "xmh_adopt_lines")
 NEED_TEXT = 1
 # xmh_pre (include/xenomapper_host.h): what the BAM decoder knows about every line it prints
 PRE_DTYPE = np.dtype([("line_len", np.uint32), ("name_len", np.uint16), ("flags", np.uint8), ("ex_as", np.uint8),
@@ -81,6 +81,7 @@ def lib():
                                     _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_Block)]
         L.xmh_copy.argtypes = [_P, _P, _P, ctypes.c_uint64]
+        L.xmh_pread.argtypes = [_P, ctypes.c_int, ctypes.c_uint64, _P, ctypes.c_uint64]
         L.xmh_adopt_lines.argtypes = [_P, ctypes.c_uint64] + [_P] * 8
         _lib = L
     return _lib
@@ -181,6 +182,13 @@ class Parser(object):
             rc = self._L.xmh_copy(self._h, _P(dst_address), _P(arr.ctypes.data + pos), int(n))
             if rc != 0:
                 raise RuntimeError("xmh_copy: " + self._L.xmh_strerror(rc).decode())
+
+    def pread(self, fd, offset, dst_address, n):
+        """Bytes [offset, offset + n) of the open file `fd` read to dst_address by the parser's threads."""
+        if n:
+            rc = self._L.xmh_pread(self._h, int(fd), int(offset), _P(dst_address), int(n))
+            if rc != 0:
+                raise OSError("xmh_pread: could not read %d bytes at offset %d" % (n, offset))
 
     def adopt_lines(self, arr1, pos1, arr2, pos2, n, tables):
         """Make a block that was stripped on the GPU the parser's current block: tables = the eight host addresses

@@ -23,6 +23,8 @@
 #include <new>
 #include <sched.h>
 #include <sys/mman.h>
+#include <cerrno>
+#include <unistd.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -726,6 +728,26 @@ int xmh_copy(xmh_parser *p, void *dst, const void *src, uint64_t n)
     parallel_for(*p->pool, n, [&](int, uint64_t b, uint64_t e) {
         memcpy((char *)dst + b, (const char *)src + b, (size_t)(e - b));
     });
+    return XMH_OK;
+}
+
+int xmh_pread(xmh_parser *p, int fd, uint64_t offset, void *dst, uint64_t n)
+{
+    if (!p || fd < 0 || (n && !dst)) return XMH_ERR_INVALID_ARG;
+    std::vector<int> bad((size_t)p->pool->size() + 1, 0);
+    parallel_for(*p->pool, n, [&](int t, uint64_t b, uint64_t e) {
+        while (b < e) {
+            const ssize_t got = pread(fd, (char *)dst + b, (size_t)(e - b), (off_t)(offset + b));
+            if (got <= 0) {
+                if (got < 0 && errno == EINTR) continue;
+                bad[(size_t)t] = 1;                                  // an error, or the file is shorter than the caller said
+                return;
+            }
+            b += (uint64_t)got;
+        }
+    });
+    for (int v : bad)
+        if (v) return XMH_ERR_INVALID_ARG;
     return XMH_OK;
 }
 

@@ -437,6 +437,8 @@ struct Slot {
     uint64_t *d_summary = nullptr, *h_summary = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    uint64_t uploaded[2] = {0, 0};                     // bytes of the staged windows already on their way (xm_strip_upload)
+    bool upload_timed = false;
 };
 
 }  // namespace
@@ -616,13 +618,35 @@ char *xm_strip_staging(xm_strip *s, int slot, int file)
     return s->slot[slot].h_text[file];
 }
 
+int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t bytes)
+{
+    if (!s || slot < 0 || slot >= XMS_SLOTS || file < 0 || file > 1) return XM_ERR_INVALID_ARG;
+    Slot &sl = s->slot[slot];
+    if (offset != sl.uploaded[file] || offset + bytes > sl.window_cap) return XM_ERR_INVALID_ARG;
+    if (bytes == 0) return XM_OK;
+    XMS_HIP(s, hipSetDevice(s->device));
+    if (!sl.upload_timed) {
+        XMS_HIP(s, hipEventRecord(sl.ev[0], sl.stream));
+        sl.upload_timed = true;
+    }
+    XMS_HIP(s, hipMemcpyAsync(sl.d_text[file] + offset, sl.h_text[file] + offset, (size_t)bytes, hipMemcpyHostToDevice, sl.stream));
+    sl.uploaded[file] = offset + bytes;
+    return XM_OK;
+}
+
 int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, int eof2,
                  int score_mode, int paired, int keep_halo, uint64_t max_records, xm_strip_block *out)
 {
     if (!s || !out || slot < 0 || slot >= XMS_SLOTS || (score_mode != XMS_SCORE_AS_XS && score_mode != XMS_SCORE_AS_ZS))
         return XM_ERR_INVALID_ARG;
     Slot &sl = s->slot[slot];
-    if (len1 > sl.window_cap || len2 > sl.window_cap || max_records == 0 || max_records > sl.record_cap) return XM_ERR_INVALID_ARG;
+    const uint64_t sent[2] = {sl.uploaded[0], sl.uploaded[1]};
+    const bool timed = sl.upload_timed;
+    sl.uploaded[0] = sl.uploaded[1] = 0;
+    sl.upload_timed = false;
+    if (len1 > sl.window_cap || len2 > sl.window_cap || max_records == 0 || max_records > sl.record_cap || sent[0] > len1 ||
+        sent[1] > len2)
+        return XM_ERR_INVALID_ARG;
     XMS_HIP(s, hipSetDevice(s->device));
     const uint64_t len[2] = {len1, len2};
     const int eof[2] = {eof1, eof2};
@@ -656,9 +680,11 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
     job.unit_bits = sl.d_bits;
 
     hipStream_t st = sl.stream;
-    XMS_HIP(s, hipEventRecord(sl.ev[0], st));
-    for (int f = 0; f < 2; ++f)
-        if (len[f]) XMS_HIP(s, hipMemcpyAsync(sl.d_text[f], sl.h_text[f], (size_t)len[f], hipMemcpyHostToDevice, st));
+    if (!timed) XMS_HIP(s, hipEventRecord(sl.ev[0], st));
+    for (int f = 0; f < 2; ++f)                        // what xm_strip_upload has not sent yet
+        if (len[f] > sent[f])
+            XMS_HIP(s, hipMemcpyAsync(sl.d_text[f] + sent[f], sl.h_text[f] + sent[f], (size_t)(len[f] - sent[f]),
+                                      hipMemcpyHostToDevice, st));
     XMS_HIP(s, hipEventRecord(sl.ev[1], st));
     XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), st));
     mark_kernel<<<dim3(max_chunks, 2), SB, 0, st>>>(job);

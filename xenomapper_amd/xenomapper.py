@@ -24,6 +24,7 @@ from __future__ import annotations
 import argparse
 import contextlib
 import errno
+import fcntl
 import io
 import mmap
 import math
@@ -65,8 +66,21 @@ def default_context():
 
 
 def set_context(ctx):
-    global _context
+    global _context, _stripper
     _context = ctx
+    _stripper = None
+
+
+_stripper = None
+
+
+def default_stripper():
+    """The process-wide GPU column stripper of the default context (its page-locked staging buffers are kept)."""
+    global _stripper
+    ctx = default_context()
+    if _stripper is None or _stripper.ctx is not ctx:
+        _stripper = _ffi.Stripper(ctx)
+    return _stripper
 
 
 # --------------------------------------------------------------------------------------------
@@ -615,6 +629,7 @@ def _run(mode, readpairs, sinks, min_score, tag_func):
 BAM_LINE_LIMIT = 1 << 32            # bam_lines gives up on a single SAM line longer than this (the stripper's own limit)
 FILE_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_WINDOW_MB", "128")) << 20     # bytes of each file parsed per block
 FILE_MAX_RECORDS = 1 << 22
+STAGE_PIECE = 16 << 20              # bytes copied into page-locked memory per upload of the GPU stripper
 
 
 def _record_start(raw):
@@ -659,52 +674,106 @@ def _write_bytes(sink, data):
 MMAP_EMIT_MIN_BYTES = 1 << 20        # below this one buffered write is cheaper than mapping the file
 
 
-def _emit_into_file(parser, paired, b, seg, sink):
+_EMIT_CLOCK = {}            # seconds inside _emit_into_file by step, since the run began (shown with the phases of the run)
+
+
+class _AheadFile(object):
+    """An output file that is kept LONGER than its content while a run is writing it: posix_fallocate is one kernel thread
+    zeroing pages (~18 GB/s on tmpfs) and used to sit in front of every bin of every block; extended in the background,
+    ahead of the writer, it is off the critical path.  finish() cuts the file back to its content."""
+
+    def __init__(self, fd2, size):
+        self.fd2, self.size, self.job = fd2, size, None
+
+    def settle(self):
+        """Wait for the background extension; -> the file's size."""
+        if self.job is not None:
+            job, self.job = self.job, None
+            try:
+                self.size = max(self.size, job.result())
+            except OSError:
+                pass                                   # no room ahead: the extension that is really needed will say so
+        return self.size
+
+    def extend_later(self, pool, upto):
+        if self.job is None and upto > self.size:
+            def work(fd2=self.fd2, start=self.size, n=upto - self.size):
+                os.posix_fallocate(fd2, start, n)
+                return start + n
+            self.job = pool.submit(work)
+
+    def finish(self, sink):
+        self.settle()
+        try:
+            sink.flush()
+            os.ftruncate(self.fd2, sink.buffer.tell())
+        finally:
+            os.close(self.fd2)
+
+
+def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
     """The text of one bin's units written by the writer's threads STRAIGHT into the output file: the file is extended,
     its new pages are mapped, and xmh_emit gathers the lines into them in parallel -- no intermediate buffer and no
     single write(2) stream (which tops out at ~5 GB/s on one file and made the file path write-bound).  Only for a
     regular file positioned at its end, with an ASCII-compatible encoding and at least MMAP_EMIT_MIN_BYTES to write;
-    False = not handled (the caller writes through the sink as before).  XENOMAPPER_MMAP_EMIT=0 switches it off."""
+    False = not handled (the caller writes through the sink as before).  XENOMAPPER_MMAP_EMIT=0 switches it off.
+    ahead: {id(sink): _AheadFile} of the run -- with it the file stays extended past its content between calls (twice the
+    bytes of the last call, allocated by ahead_pool's thread while the next block is classified); the run cuts the files
+    back when it ends (_AheadFile.finish)."""
     if os.environ.get("XENOMAPPER_MMAP_EMIT") == "0":
         return False
     raw = getattr(sink, "buffer", None)
     enc = (getattr(sink, "encoding", None) or "").lower().replace("-", "").replace("_", "")
     if raw is None or enc not in _ASCII_SUPERSETS:
         return False
+    t0 = time.perf_counter()
     idx, need = parser.emit_size(paired, b, seg)
+    _EMIT_CLOCK["emit_size"] = _EMIT_CLOCK.get("emit_size", 0.0) + time.perf_counter() - t0
     if need < MMAP_EMIT_MIN_BYTES:
         return False
-    fd2, pos, extended = None, 0, False
+    t0 = time.perf_counter()
+    state = ahead.get(id(sink)) if ahead is not None else None
+    fd2, pos, size, opened = None, 0, 0, False
     try:
         sink.flush()
-        fd = sink.fileno()
-        st = os.fstat(fd)
         pos = raw.tell()
-        if not stat.S_ISREG(st.st_mode) or pos != st.st_size:
-            return False
-        # a mapping needs a descriptor opened for reading as well; sinks are usually write-only
-        fd2 = os.open("/proc/self/fd/%d" % fd, os.O_RDWR)
-        extended = True
-        try:
-            os.posix_fallocate(fd2, pos, need)         # extends the file AND allocates its pages in one go: the threads
-        except OSError as e:                           # then only copy (page by page faults cost 3x on tmpfs)
-            # Only a file system that cannot preallocate may be extended sparsely instead.  Anything else -- no space
-            # left, a quota, the file size limit -- must NOT be papered over: stores into a mapping whose pages cannot
-            # be backed end in SIGBUS.  Give the range back and let the ordinary write raise the real OSError.
-            if e.errno not in (errno.EOPNOTSUPP, errno.ENOSYS, errno.EINVAL):
-                raise
-            os.ftruncate(fd2, pos + need)
+        if state is None:
+            fd = sink.fileno()
+            st = os.fstat(fd)
+            if not stat.S_ISREG(st.st_mode) or pos != st.st_size:
+                return False
+            # a mapping needs a descriptor opened for reading as well; sinks are usually write-only
+            fd2 = os.open("/proc/self/fd/%d" % fd, os.O_RDWR)
+            opened = True
+            size = pos
+        else:
+            fd2, size = state.fd2, state.settle()
+        if pos + need > size:
+            try:
+                os.posix_fallocate(fd2, size, pos + need - size)   # extends the file AND allocates its pages in one go: the
+            except OSError as e:                                   # threads then only copy (page by page faults cost 3x on tmpfs)
+                # Only a file system that cannot preallocate may be extended sparsely instead.  Anything else -- no space
+                # left, a quota, the file size limit -- must NOT be papered over: stores into a mapping whose pages cannot
+                # be backed end in SIGBUS.  Give the range back and let the ordinary write raise the real OSError.
+                if e.errno not in (errno.EOPNOTSUPP, errno.ENOSYS, errno.EINVAL):
+                    raise
+                os.ftruncate(fd2, pos + need)
+            size = pos + need
         start = pos - pos % mmap.ALLOCATIONGRANULARITY
         mm = mmap.mmap(fd2, pos + need - start, offset=start, access=mmap.ACCESS_WRITE)
     except (OSError, ValueError, AttributeError, io.UnsupportedOperation):
         if fd2 is not None:
-            if extended:
-                try:
-                    os.ftruncate(fd2, pos)             # the file is as the sink left it; the caller writes the text
-                except OSError:
-                    pass
-            os.close(fd2)
+            try:
+                os.ftruncate(fd2, pos)                 # the file is as the sink left it; the caller writes the text
+            except OSError:
+                pass
+            if state is not None:
+                state.size = pos
+            elif opened:
+                os.close(fd2)
         return False
+    t1 = time.perf_counter()
+    _EMIT_CLOCK["emit_extend"] = _EMIT_CLOCK.get("emit_extend", 0.0) + t1 - t0
     try:
         view = np.frombuffer(mm, dtype=np.uint8)
         try:
@@ -712,14 +781,31 @@ def _emit_into_file(parser, paired, b, seg, sink):
         finally:
             del view
         assert wrote == need
+        t0 = time.perf_counter()
+        _EMIT_CLOCK["emit_fill"] = _EMIT_CLOCK.get("emit_fill", 0.0) + t0 - t1
     except BaseException:
         mm.close()
         os.ftruncate(fd2, pos)                         # nothing of this bin's text stays behind
-        os.close(fd2)
+        if state is not None:
+            state.size = pos
+        else:
+            os.close(fd2)
         raise
-    mm.close()
-    os.close(fd2)
+    if ahead is not None and ahead_pool is not None:
+        ahead_pool.submit(mm.close)                    # taking ~10^5 pages out of the page table costs as much as a third of the fill
+    else:
+        mm.close()
+    _EMIT_CLOCK["emit_unmap"] = _EMIT_CLOCK.get("emit_unmap", 0.0) + time.perf_counter() - t0
     raw.seek(pos + need)
+    # (a descriptor in append mode writes at the END of the file whatever its position: it must never be longer than its content)
+    if ahead is not None and ahead_pool is not None and (state is not None or not fcntl.fcntl(fd2, fcntl.F_GETFL) & os.O_APPEND
+                                                           and not fcntl.fcntl(sink.fileno(), fcntl.F_GETFL) & os.O_APPEND):
+        if state is None:
+            state = ahead[id(sink)] = _AheadFile(fd2, size)
+        state.size = size
+        state.extend_later(ahead_pool, pos + need + 2 * need)
+    elif state is None:
+        os.close(fd2)
     return True
 
 
@@ -776,6 +862,13 @@ class _SamSource(object):
         self.path = path
         self.raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
         self.pos = _record_start(self.raw) if start is None else int(start)
+        self.fd = None
+
+    def fileno(self):
+        """A descriptor for positional reads (the GPU stripper reads windows straight into page-locked memory)."""
+        if self.fd is None:
+            self.fd = os.open(self.path, os.O_RDONLY)
+        return self.fd
 
     def window(self, want):
         n = min(want, self.raw.shape[0] - self.pos)
@@ -785,7 +878,9 @@ class _SamSource(object):
         self.pos += consumed
 
     def close(self):
-        pass
+        if self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
 
 
 class _BamSource(object):
@@ -952,6 +1047,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     if not n_threads:                                                # 0: the CPUs this process may use (cgroup-aware)
         n_threads = int(os.environ.get("XENOMAPPER_THREADS", "0"))
     prof = _PhaseClock()
+    _EMIT_CLOCK.clear()
     t_all = time.perf_counter()
     with prof("open"):
         sources = [(_BamSource(path, n_threads) if bam else _SamSource(path, None if starts is None else starts[k]))
@@ -960,14 +1056,42 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         # code runs without the GIL -- while the GPU classifies and the writer emits the current one.
         parsers = [_host.Parser(n_threads), _host.Parser(n_threads)]
         pool = ThreadPoolExecutor(max_workers=1)
+        ahead, ahead_pool = {}, ThreadPoolExecutor(max_workers=2)    # output files extended ahead of the writer, their pages unmapped behind it
     totals, key_order = Counter(), []
     window = FILE_WINDOW_BYTES
     active = [s for s in sinks if s]
     distinct = len(set(id(s) for s in active)) == len(active)
+    # SAM text, the plain lock-step walk and an AS/XS or AS/ZS plugin: the text itself goes to the GPU and is split there
+    # (include/xenomapper_strip.h) -- the host threads only copy windows into page-locked memory and write the outputs.
+    # XENOMAPPER_GPU_STRIP=0 keeps the host stripper.
+    stripper = None
+    if (not bam and not skip_repeated and not cigar_mode and min_score == min_score
+            and os.environ.get("XENOMAPPER_GPU_STRIP", "1") != "0"):
+        stripper = default_stripper()
 
     def parse_next(which, want):
         with prof("window"):
             wins = [src.window(want) for src in sources]
+        if stripper is not None and max(w[2] for w in wins) <= _ffi.STRIP_MAX_WINDOW:
+            with prof("stage"):
+                # no line of a record is shorter than two bytes with its terminator
+                records = min(FILE_MAX_RECORDS, max(w[2] for w in wins) // 2 + 2)
+                stripper.reserve(which, max(w[2] for w in wins), records)
+                # read(2) into page-locked memory, piece by piece: the upload of one piece hides the read of the next; no page
+                # of the inputs is mapped, and the writer gathers its lines from the staging buffer
+                for f, w in enumerate(wins):
+                    base = stripper.staging_address(which, f)
+                    for at in range(0, w[2], STAGE_PIECE):
+                        piece = min(STAGE_PIECE, w[2] - at)
+                        parsers[which].pread(sources[f].fileno(), w[1] + at, base + at, piece)
+                        stripper.upload(which, f, at, piece)
+            with prof("strip"):
+                blk = stripper.run(which, wins[0][2], wins[0][3], wins[1][2], wins[1][3], score_mode, paired, paired, records)
+                prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_upload
+                prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
+            if blk.non_ascii:
+                raise _host.NonAsciiInput()
+            return blk, [stripper.staging(which, f) for f in (0, 1)], [0, 0], [w[3] for w in wins]
         with prof("parse"):
             blk = None
             if bam and all(src.pre_ok for src in sources):
@@ -986,19 +1110,27 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         """Classify one parsed block and hand its units to the sinks.  Returns the input error to raise once the
         units in front of it have been written (one found while resolving the stripper's exceptions comes first)."""
         n = block.n
-        flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:n].astype(bool)
-        if paired:
-            needed = flags.copy()
-            needed[:-1] |= flags[1:]
-        else:
-            needed = np.ones(n, dtype=bool)
-        patches, bad, err = _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode) if block.exc \
-            else ({}, None, None)
+        on_device = isinstance(block, _ffi.StrippedBlock)
+        exc = block.exc
+        patches, bad, err = {}, None, None
+        if exc:
+            flags = np.unpackbits(block.unit_bits.view(np.uint8), bitorder="little")[:n].astype(bool)
+            if paired:
+                needed = flags.copy()
+                needed[:-1] |= flags[1:]
+            else:
+                needed = np.ones(n, dtype=bool)
+            patches, bad, err = _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode)
         if err is not None:
             n, pending = bad, err                                # units closing at index >= bad are not reached
+        if on_device and block.n:
+            parser.adopt_lines(raws[0], pos[0], raws[1], pos[1], block.n, block.tables)
         if n:
             with prof("classify"):          # one fused pass: category bytes, counts and the six bin lists
-                code, idx, off, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
+                if on_device and not patches:                    # the columns never left the device
+                    code, idx, off, counts = block.stripper.classify(block.slot, mode, n, _floor_min_score(min_score))
+                else:
+                    code, idx, off, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
             limit, state_error = None, None
             if int(off[7]) != int(off[6]):                       # a unit fell through every branch (ref :289)
                 limit = int(idx[int(off[6]):int(off[7])].min())
@@ -1014,7 +1146,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     if limit is not None:
                         seg = seg[seg < limit]
                     with prof("emit"):
-                        done = _emit_into_file(parser, paired, b, seg, sinks[b])
+                        done = _emit_into_file(parser, paired, b, seg, sinks[b], ahead, ahead_pool)
                         text = None if done else parser.emit(paired, b, seg, reuse=True)
                     with prof("write"):
                         _write_bytes(sinks[b], text)
@@ -1063,17 +1195,29 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             except Exception:
                 pass
         with prof("close"):
+            trouble = None
+            for sink in active:                                      # cut the output files back to their content
+                state = ahead.pop(id(sink), None)
+                if state is not None:
+                    try:
+                        state.finish(sink)
+                    except OSError as exc:
+                        trouble = trouble or exc
+            ahead_pool.shutdown(wait=True)
             pool.shutdown(wait=True)
             for prs in parsers:
                 prs.close()
             for src in sources:
                 src.close()
         total = time.perf_counter() - t_all
-        prof["other"] = total - sum(prof.values())               # negative: helper-thread phases overlap the rest
+        prof["other"] = total - sum(v for k, v in prof.items() if not k.endswith("_ms"))   # negative: helper-thread phases overlap the rest
         LAST_FILE_PROFILE.clear()
         LAST_FILE_PROFILE.update(prof, total=total)
+        LAST_FILE_PROFILE.update(_EMIT_CLOCK)
         if os.environ.get("XENOMAPPER_PROFILE"):
             print("xenomapper file path: %.3f s  " % total + "  ".join("%s %.3f" % kv for kv in prof.items()), file=sys.stderr)
+        if trouble is not None and sys.exc_info()[0] is None:
+            raise trouble
     ordered = Counter()
     for key in key_order:
         ordered[key] = totals[key]
