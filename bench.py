@@ -265,20 +265,33 @@ def pcie_ceiling(dev, mb=512):
     return out
 
 
-def e2e_sam_text(pairs=4_000_000, to_files=True):
-    """SAM text in -> six SAM files out through the file fast path (C++ stripper -> GPU -> C++ writer); outputs on
-    tmpfs (`to_files`) or /dev/null (what is left is parser-bound).  Never `value`."""
+def e2e_sam_text(pairs=4_000_000, to_files=True, gpu_strip=True):
+    """SAM text in -> six SAM files out through the file fast path (text -> page-locked staging -> GPU stripper -> fused
+    pass -> C++ writer; gpu_strip=False: the C++ host stripper instead); outputs on tmpfs (`to_files`) or /dev/null.
+    Never `value`."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import bench_e2e
     shm = os.path.isdir("/dev/shm")
-    r = bench_e2e.run(pairs=pairs, threads=0, mode="liberal", workdir="/dev/shm" if shm else "/tmp",
-                      out_dir=("/dev/shm" if shm else "/tmp") if to_files else None)
+    before = os.environ.get("XENOMAPPER_GPU_STRIP")
+    os.environ["XENOMAPPER_GPU_STRIP"] = "1" if gpu_strip else "0"
+    try:
+        r = bench_e2e.run(pairs=pairs, threads=0, mode="liberal", workdir="/dev/shm" if shm else "/tmp",
+                          out_dir=("/dev/shm" if shm else "/tmp") if to_files else None)
+    finally:
+        if before is None:
+            del os.environ["XENOMAPPER_GPU_STRIP"]
+        else:
+            os.environ["XENOMAPPER_GPU_STRIP"] = before
     return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"], "phases": r["phases"],
             "seconds": round(r["seconds"], 4), "outputs": r["outputs"], "output_bytes": r["output_bytes"],
             "text_bytes_in_per_pair": round(r["input_bytes"] / max(r["units"], 1), 1),
             "text_bytes_out_per_pair": round(r["output_bytes"] / max(r["units"], 1), 1),
             "output_GBps": r["output_bytes"] / r["seconds"] / 1e9,
-            "what": "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> stripper -> H2D -> fused pass -> D2H -> six SAM outputs"}
+            "stripper": "gpu" if gpu_strip else "host",
+            "what": ("two SAM text files (2x150 bp, tiled 50 k-pair twin) -> pread into page-locked memory -> H2D of the TEXT -> "
+                     "strip kernels -> fused pass on the columns in HBM -> D2H of line tables + lists -> six SAM outputs") if gpu_strip
+                    else "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> C++ host stripper -> H2D of columns -> fused pass "
+                         "-> D2H -> six SAM outputs"}
 
 
 class Workload(object):
@@ -687,14 +700,16 @@ def compact_line(full):
     if w:
         line["workloads"] = w
     e2e = full.get("e2e")
-    if e2e:                    # [G read-pairs/s host columns -> lists over PCIe (page-locked), M read-pairs/s SAM text -> six SAM files, M pairs/s BAM -> files]
+    if e2e:                    # [G read-pairs/s host columns -> lists over PCIe (page-locked), M read-pairs/s SAM text -> six SAM files (GPU stripper),
+                               #  M pairs/s BAM -> files, M pairs/s SAM text -> files with the host stripper]
         def rate(d, *path):
             for k in path:
                 d = d.get(k) if isinstance(d, dict) else None
             return d
         line["e2e"] = [_r((rate(e2e, "h2d_inclusive", "registered_buffers", "read_pairs_per_s") or 0) / 1e9, 4),
                        _r((rate(e2e, "sam_text", "read_pairs_per_s") or 0) / 1e6, 4),
-                       _r((rate(e2e, "bam", "read_pairs_per_s") or 0) / 1e6, 4)]
+                       _r((rate(e2e, "bam", "read_pairs_per_s") or 0) / 1e6, 4),
+                       _r((rate(e2e, "sam_text_host_stripper", "read_pairs_per_s") or 0) / 1e6, 4)]
     line["full_record"] = full.get("full_record")
     return line
 
@@ -897,9 +912,10 @@ def main():
                 e2e["pcie_ceiling"] = pcie_ceiling(dev)
             except Exception as e:                               # noqa: BLE001
                 e2e["pcie_ceiling"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            for key, to_files in (("sam_text", True), ("sam_text_devnull", False)):
+            for key, to_files, gpu_strip in (("sam_text", True, True), ("sam_text_devnull", False, True),
+                                             ("sam_text_host_stripper", True, False)):
                 try:
-                    e2e[key] = e2e_sam_text(to_files=to_files)
+                    e2e[key] = e2e_sam_text(to_files=to_files, gpu_strip=gpu_strip)
                 except Exception as e:                           # noqa: BLE001
                     e2e[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
