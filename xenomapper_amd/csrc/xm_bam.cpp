@@ -365,6 +365,25 @@ struct TagScan {
         if (is_int && val >= -2147483647ll && val <= 2147483647ll) v[k] = (int32_t)val;
         else ex[k] = XMH_EX_NONINT;
     }
+    // a match whose value is not an integer-typed field: what the text rules make of the printed field [s, e) -- the text
+    // behind its last ':' as a plain integer ("AS:H:0", "AS:A:7", a float that prints as "3"), else not vouched for
+    void hit_text(int k, const char *s, const char *e)
+    {
+        if (++n[k] != 1) return;
+        const char *b = s;
+        for (const char *c = s; c < e; ++c)
+            if (*c == ':') b = c + 1;
+        bool neg = false;
+        if (b < e && (*b == '-' || *b == '+')) { neg = *b == '-'; ++b; }
+        uint64_t val = 0;
+        bool ok = b < e && e - b <= 10;
+        for (const char *c = b; ok && c < e; ++c) {
+            if (*c < '0' || *c > '9') ok = false;
+            else val = val * 10 + (uint64_t)(*c - '0');
+        }
+        if (ok && val <= 2147483647ull) v[k] = neg ? -(int32_t)val : (int32_t)val;
+        else ex[k] = XMH_EX_NONINT;
+    }
     void finish(xmh_pre &q) const
     {
         q.as = v[0]; q.xs = v[1]; q.zs = v[2]; q.nm = v[3];
@@ -455,6 +474,7 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o, 
         const uint8_t t0 = r[p], t1 = r[p + 1];
         char *const field0 = o - 3;
         p += 3;
+        int by_name = -1;                                               // a tag whose value the printed text decides
         if (q) {
             weird |= odd_byte(t0) || odd_byte(t1);
             int64_t ival = 0;
@@ -470,7 +490,9 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o, 
             }
             if (type != 'Z' && type != 'H') {                           // only the tag itself can hold the two letters
                 for (int k = 0; k < 4; ++k)
-                    if (t0 == (uint8_t)TAGS[k][0] && t1 == (uint8_t)TAGS[k][1]) scan.hit(k, is_int, ival);
+                    if (t0 == (uint8_t)TAGS[k][0] && t1 == (uint8_t)TAGS[k][1]) {
+                        if (is_int) scan.hit(k, true, ival); else by_name = k;
+                    }
                 if (type == 'A' && p + 1 <= size) weird |= odd_byte(r[p]);
             }
         }
@@ -521,7 +543,7 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o, 
                 weird |= odd_bytes(r + p, l);
                 const size_t fl = (size_t)(o - field0);
                 for (int k = 0; k < 4; ++k)
-                    if (has2((const uint8_t *)field0, fl, TAGS[k][0], TAGS[k][1])) scan.hit(k, false, 0);
+                    if (has2((const uint8_t *)field0, fl, TAGS[k][0], TAGS[k][1])) scan.hit_text(k, field0, o);
             }
             p += l + 1;
         } else if (type == 'B') {
@@ -532,6 +554,7 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o, 
             *o++ = 'B'; *o++ = ':'; *o++ = sub;
             for (uint32_t k = 0; k < cnt; ++k) { *o++ = ','; if (!scalar(sub)) return nullptr; }
         } else return nullptr;
+        if (by_name >= 0) scan.hit_text(by_name, field0, o);
     }
     if (q) {
         q->line_len = (uint32_t)(o - line0);
