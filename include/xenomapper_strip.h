@@ -16,9 +16,8 @@
  * caller resolves flagged records with the reference-equivalent text functions (xm_strip_columns brings the
  * columns to the host for that) or hands the window to xmh_parse.
  *
- * Scope: the lock-step walk without --skip_repeated_reads (record k = line k of both files; the paired-end
- * default, xenomapper.py:691) and the AS/XS and AS/ZS plugins.  The CIGAR plugin and the skipping walk stay with
- * xmh_parse.  Windows are shorter than 4 GiB - 64 KiB.
+ * Scope: SAM text, all three built-in plugins, the walk with and without --skip_repeated_reads (xenomapper.py:110-117).
+ * Windows are shorter than 4 GiB - 64 KiB.  BAM input, windows beyond that and non-ASCII text stay with xenomapper_host.h.
  *
  * A stripper has two slots so that one window pair can be copied, uploaded and stripped (one host thread) while
  * the block before it is classified and written (another thread); calls on one slot must not overlap.
@@ -39,13 +38,18 @@ extern "C" {
 /* score_mode (the values of XMH_SCORE_*) */
 #define XMS_SCORE_AS_XS 0   /* get_tag                 xenomapper.py:176-191 */
 #define XMS_SCORE_AS_ZS 1   /* get_tag_with_ZS_as_XS   xenomapper.py:193-206 */
+#define XMS_SCORE_CIGAR 2   /* get_cigarbased_AS_tag   xenomapper.py:228-256: NM + the CIGAR operations, as the packed CIGAR columns of
+                               xenomapper_hip.h, left on the device; XS by get_tag */
 
 /* line flags; bit 0 is XMH_LINE_NORMAL of xenomapper_host.h */
 #define XMS_LINE_NORMAL   0x01u  /* the line already equals '\t'.join(fields)                                     */
 #define XMS_LINE_BLANK    0x02u  /* no field at all: ends the walk (xenomapper.py:105)                            */
-#define XMS_LINE_EX_A     0x0Cu  /* bits 2-3: exception kind of the AS column: 0, 1 = XMH_EX_NONINT, 2 = XMH_EX_DUP */
-#define XMS_LINE_EX_X     0x30u  /* bits 4-5: same for the XS (or ZS) column                                      */
-#define XMS_LINE_MISMATCH 0x40u  /* file-1 flags only: the names of the two files differ (xenomapper.py:106)      */
+#define XMS_LINE_EX_A     0x1Cu  /* bits 2-4: exception kind of the AS column (XMH_EX_*: 1 NONINT, 2 DUP; CIGAR mode, about NM and
+                                    the CIGAR field: 1 NONINT, 3 SHORT, 4 BIGLEN), 0 = none                           */
+#define XMS_LINE_EX_A_SHIFT 2
+#define XMS_LINE_EX_X     0x60u  /* bits 5-6: same for the XS (or ZS) column: 0, 1, 2                                */
+#define XMS_LINE_EX_X_SHIFT 5
+#define XMS_LINE_MISMATCH 0x80u  /* file-1 flags only: the names of the two files differ (xenomapper.py:106)      */
 
 typedef struct xm_strip xm_strip;
 
@@ -58,7 +62,8 @@ typedef struct {
     int32_t  ended, starved;
     int64_t  mismatch_at;
     int32_t  non_ascii;        /* 1: a byte >= 0x80 in either window; nothing else of the result is meaningful */
-    int32_t  pad_;
+    int32_t  overflow;         /* 1: the skipping walk met more lines than max_records + 1 in a window (or the packed CIGAR
+                                  operations outgrew their array): nothing else is meaningful, strip the window with xmh_parse */
     uint64_t n_exceptions;     /* records among the n_records whose flags carry XMS_LINE_EX_A / _EX_X on either line */
     uint64_t n_lines1, n_lines2;                        /* lines found in each window (complete ones; the last one of a file too) */
     const uint32_t *line_off1, *line_off2;              /* first byte of the record's line in its window */
@@ -88,14 +93,15 @@ int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t b
 
 /*
  * Upload the two staged windows (len1 / len2 bytes; eof*: the window reaches the end of its file) and strip them.
- * paired: the unit mask is name[k] == name[k-1] (else every record is a unit); keep_halo / max_records as in
- * xmh_parse.  Blocking (the slot's own stream).  The columns of the block stay on the device for xm_strip_classify.
+ * paired: the unit mask is name[k] == name[k-1] (else every record is a unit); skip_repeated / keep_halo / max_records as
+ * in xmh_parse.  Blocking (the slot's own stream).  The columns of the block stay on the device for xm_strip_classify.
  */
 int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, int eof2,
-                 int score_mode, int paired, int keep_halo, uint64_t max_records, xm_strip_block *out);
+                 int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xm_strip_block *out);
 
 /*
- * The fused main loop (xm_classify_compact_dev) on the first n_records records of the slot's block.  Results in
+ * The fused main loop (xm_classify_compact_dev; after a XMS_SCORE_CIGAR run xm_classify_compact_cigar_packed_dev, with
+ * XM_ERR_RANGE when a synthesised score leaves int32) on the first n_records records of the slot's block.  Results in
  * page-locked host arrays owned by the stripper, valid until the next call on the slot: code (n_records bytes), the six
  * index lists back to back (*idx) with bin_offsets[8], counts[64].
  */
@@ -106,6 +112,12 @@ int xm_strip_classify(xm_strip *s, int slot, int mode, uint64_t n_records, int32
  * the caller must patch by the text rules).  Any pointer may be NULL. */
 int xm_strip_columns(xm_strip *s, int slot, uint64_t n_records, int32_t *as1, int32_t *xs1, int32_t *as2, int32_t *xs2,
                      uint64_t *unit_bits);
+
+/* After a XMS_SCORE_CIGAR run: the packed CIGAR columns of one file for the first n_records records copied to the host (any
+ * pointer may be NULL; cig_tile: XM_CIG_TILES(n_records) + 1 words; *n_ops = words of cig_ops in use).  For tests and for
+ * callers that want the columns themselves. */
+int xm_strip_cigar_columns(xm_strip *s, int slot, int file, uint64_t n_records, int32_t *nm, uint8_t *cig_cnt, uint32_t *cig_tile,
+                           uint32_t *cig_ops, uint64_t ops_capacity, uint64_t *n_ops);
 
 /* Device addresses of the slot's columns: as1, xs1, as2, xs2 (int32) and unit_bits (uint64), for callers that launch the
  * classify kernels themselves (xm_classify_*_dev). */

@@ -26,25 +26,28 @@ def rig():
     p.close()
 
 
-def strip(s, slot, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records):
+def strip(s, slot, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records, skip=False):
     s.reserve(slot, max(len(b1), len(b2), 1), max_records)
     for f, b in enumerate((b1, b2)):
         if len(b):
             s.staging(slot, f)[:len(b)] = np.frombuffer(b, dtype=np.uint8)
-    return s.run(slot, len(b1), eof1, len(b2), eof2, score_mode, paired, keep_halo, max_records)
+    return s.run(slot, len(b1), eof1, len(b2), eof2, score_mode, paired, skip, keep_halo, max_records)
 
 
-def compare(s, p, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records, slot=0):
-    from xenomapper_amd import _host
+def compare(s, p, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records, slot=0, skip=False):
+    from xenomapper_amd import _ffi, _host
     r1, r2 = np.frombuffer(b1, dtype=np.uint8), np.frombuffer(b2, dtype=np.uint8)
-    got = strip(s, slot, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records)
+    got = strip(s, slot, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records, skip)
     try:
-        want = p.parse(r1, 0, len(r1), eof1, r2, 0, len(r2), eof2, score_mode, paired, False, keep_halo, max_records)
+        want = p.parse(r1, 0, len(r1), eof1, r2, 0, len(r2), eof2, score_mode, paired, skip, keep_halo, max_records)
     except _host.NonAsciiInput:
         assert got.non_ascii
         return got, None
     assert not got.non_ascii
-    ctxt = (b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records)
+    ctxt = (b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records, skip)
+    if got.overflow:                        # the skipping walk met more lines than the tables hold: the caller's cue to use xmh_parse
+        assert skip and max(b1.count(b"\n") + b1.count(b"\r"), b2.count(b"\n") + b2.count(b"\r")) >= max_records, ctxt
+        return got, want
     assert got.n == want.n, ctxt
     assert (got.ended, got.starved, got.mismatch_at) == (want.ended, want.starved, want.mismatch_at), ctxt
     assert got.consumed == want.consumed, ctxt
@@ -59,6 +62,14 @@ def compare(s, p, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records
         assert np.array_equal(cols[c], want.cols[c]), (c, ctxt)
     bits = lambda a: np.unpackbits(np.ascontiguousarray(a).view(np.uint8), bitorder="little")[:n]
     assert np.array_equal(bits(got.unit_bits), bits(want.unit_bits)), ctxt
+    if score_mode == 2:                     # NM + the CIGAR operations: the packed columns the classify kernel reads
+        for f in (0, 1):
+            nm, off, ops = want.csr[f]
+            cnt, tile, packed = _ffi.cigar_pack(off, ops)
+            gnm, gcnt, gtile, gops = s.cigar_columns(slot, f, n)
+            assert np.array_equal(gnm, nm) and np.array_equal(gcnt, cnt), ctxt
+            assert np.array_equal(gtile[:_ffi.cigar_tiles(n)], tile[:_ffi.cigar_tiles(n)]), ctxt
+            assert np.array_equal(gops[:packed.shape[0]], packed), ctxt
     if n:                                   # the writer on the adopted tables writes what it writes on its own
         idx = np.arange(1 if paired else 0, n, dtype=np.uint32)
         want_text = [bytes(p.emit(paired, b, idx)) for b in (0, 1, 4)]
@@ -68,17 +79,17 @@ def compare(s, p, b1, b2, eof1, eof2, score_mode, paired, keep_halo, max_records
 
 
 @settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "300")), deadline=None, suppress_health_check=list(HealthCheck))
-@given(texts=sam_pair(), score_mode=st.sampled_from([0, 1]), paired=st.booleans(), keep_halo=st.booleans(),
+@given(texts=sam_pair(), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans(), keep_halo=st.booleans(),
        eofs=st.tuples(st.booleans(), st.booleans()), max_records=st.sampled_from([1 << 16, 1 << 16, 3, 1]),
-       cut=st.tuples(st.integers(0, 40), st.integers(0, 40)))
-def test_gpu_stripper_agrees_with_the_host_stripper_on_random_text(rig, texts, score_mode, paired, keep_halo, eofs, max_records, cut):
+       cut=st.tuples(st.integers(0, 40), st.integers(0, 40)), skip=st.booleans())
+def test_gpu_stripper_agrees_with_the_host_stripper_on_random_text(rig, texts, score_mode, paired, keep_halo, eofs, max_records, cut, skip):
     _ctx, s, p = rig
     b1, b2 = texts[0].encode("ascii"), texts[1].encode("ascii")
     if not eofs[0]:
         b1 = b1[:max(0, len(b1) - cut[0])]          # a window that stops somewhere inside the file
     if not eofs[1]:
         b2 = b2[:max(0, len(b2) - cut[1])]
-    compare(s, p, b1, b2, eofs[0], eofs[1], score_mode, paired, keep_halo, max_records)
+    compare(s, p, b1, b2, eofs[0], eofs[1], score_mode, paired, keep_halo, max_records, skip=skip)
 
 
 def test_non_ascii_windows_are_refused_as_a_whole(rig):
@@ -91,8 +102,12 @@ def test_non_ascii_windows_are_refused_as_a_whole(rig):
     assert not strip(s, 0, good, good, True, True, 0, False, False, 16).non_ascii
 
 
-def _big_pair(n_pairs, seed, crlf=False):
-    """Two files of 2 x n_pairs records in the same order: names, tags and a few oddities drawn at random."""
+_CIGARS = ["150M", "100M2I48M", "20S130M", "75M1D75M", "10S50M3I40M2D47M", "*", "150=", "5H145M", "1M1I" * 150, "3S" + "2M1D" * 49]
+
+
+def _big_pair(n_pairs, seed, crlf=False, repeats=False):
+    """Two files of 2 x n_pairs records in the same order: names, tags and a few oddities drawn at random.  repeats: some
+    records are followed by further lines with the same name (secondary alignments), a different number in each file."""
     rng = np.random.default_rng(seed)
     out = [[], []]
     seq = "ACGT" * 37 + "AC"
@@ -100,7 +115,10 @@ def _big_pair(n_pairs, seed, crlf=False):
     for i in range(n_pairs):
         name = "read%d/%d" % (i, int(rng.integers(0, 1000)))
         for mate in (0, 1):
+            if repeats:
+                name = "read%d.%d" % (i, mate)
             for f in (0, 1):
+              for _rep in range(1 + (int(rng.integers(0, 4)) if repeats and rng.integers(0, 5) == 0 else 0)):
                 a, x = int(rng.integers(-60, 1)), int(rng.integers(-80, 1))
                 tags = []
                 r = int(rng.integers(0, 40))
@@ -114,9 +132,10 @@ def _big_pair(n_pairs, seed, crlf=False):
                     tags.append("XS:f:1.5")              # flagged: not an integer
                 if r == 13:
                     tags.append("RG:Z:BASS")             # flagged: a second field containing "AS"
-                tags += ["XN:i:0", "XM:i:%d" % (r % 5), "NM:i:%d" % (r % 5), "YT:Z:CP"]
+                tags += ["XN:i:0", "XM:i:%d" % (r % 5)] + (["NM:i:%d" % (r % 5)] if r != 19 else []) + ["YT:Z:CP"]
                 sep = " " if r == 17 else "\t"
-                fields = [name, str(83 + 16 * mate), "chr%d" % (1 + f), str(1000 + i), "42", "150M", "=", str(1200 + i),
+                cigar = _CIGARS[int(rng.integers(0, len(_CIGARS)))] if r % 4 == 0 else "150M"
+                fields = [name, str(83 + 16 * mate), "chr%d" % (1 + f), str(1000 + i), "42", cigar, "=", str(1200 + i),
                           "350", seq, qual] + tags
                 out[f].append(sep.join(fields))
     nl = "\r\n" if crlf else "\n"
@@ -173,3 +192,45 @@ def test_record_limit_and_empty_windows(rig):
     compare(s, p, b1[:-1], b2[:-1], True, True, 0, True, True, 1 << 20)        # last line without a terminator
     compare(s, p, b1[:-1], b2[:-1], False, False, 0, True, True, 1 << 20)
     compare(s, p, b1 + b"\n" + b1, b2 + b"\n" + b2, True, True, 0, True, True, 1 << 20)   # a blank line ends the walk
+
+
+def test_skipping_walk_over_runs_of_repeated_names_in_windows(rig):
+    _ctx, s, p = rig
+    b1, b2 = _big_pair(6000, 21, repeats=True)
+    pos, window, blocks, yielded = [0, 0], 2 << 20, 0, 0
+    while True:
+        w1, w2 = b1[pos[0]:pos[0] + window], b2[pos[1]:pos[1] + window]
+        e1, e2 = pos[0] + window >= len(b1), pos[1] + window >= len(b2)
+        got, _want = compare(s, p, w1, w2, e1, e2, 0, False, False, 1 << 20, slot=blocks & 1, skip=True)
+        yielded += got.n
+        blocks += 1
+        if got.ended:
+            break
+        assert got.consumed[0] > 0
+        pos[0] += got.consumed[0]
+        pos[1] += got.consumed[1]
+    assert blocks >= 4 and yielded == 12000
+    for paired, halo in ((True, True), (True, False), (False, True)):
+        compare(s, p, b1[:3 << 20], b2[:3 << 20], False, False, 1, paired, halo, 1 << 20, skip=True)
+    # more lines than the tables hold: reported, not guessed
+    got = strip(s, 0, b1[:1 << 20], b2[:1 << 20], False, False, 0, False, False, 100, skip=True)
+    assert got.overflow
+
+
+def test_cigar_plugin_columns_and_the_fused_pass_on_them(rig):
+    ctx, s, p = rig
+    from xenomapper_amd import _ffi
+    b1, b2 = _big_pair(20000, 33)
+    for skip in (False, True):
+        got, want = compare(s, p, b1, b2, True, True, 2, True, True, 1 << 20, skip=skip)
+        assert got.n == (20000 if skip else 40000)        # mates share a name: the skipping walk yields one of them
+        code, idx, off, counts = s.classify(0, _ffi.MODE_PE_LIBERAL, got.n, -2**31)
+        h = ctx.classify_compact_cigar(_ffi.MODE_PE_LIBERAL, want.csr[0][0], want.csr[0][1], want.csr[0][2], want.cols[1],
+                                       want.csr[1][0], want.csr[1][1], want.csr[1][2], want.cols[3], want.unit_bits, -2**31)
+        assert np.array_equal(code, h[0]) and np.array_equal(idx, h[1]) and np.array_equal(off, h[2]) and np.array_equal(counts, h[3])
+    # flagged lines: a non-integer NM, an operation length of 2^28 (a line too short for its NM to count is not flagged)
+    lines = [b"r1\t0\tc\t1\t9\t4M\t*\t0\t0\tACGT\tIIII\tNM:i:1.5\tXS:i:3", b"r2\t0\tc\t1\tNM:i:1",
+             b"r3\t0\tc\t1\t9\t268435456M5S\t*\t0\t0\tACGT\tIIII\tNM:i:2", b"r4\t0\tc\t1\t9\t4M2S\t*\t0\t0\tA\tI\tNM:i:0"]
+    text = b"\n".join(lines) + b"\n"
+    got, want = compare(s, p, text, text, True, True, 2, False, False, 64)
+    assert sorted(k for _, _, k in got.exc) == [1, 1, 4, 4]

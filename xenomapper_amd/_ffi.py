@@ -134,7 +134,8 @@ def lib():
         "xm_strip_reserve": ([P, I, U64, U64], I),
         "xm_strip_staging": ([P, I, I], P),
         "xm_strip_upload": ([P, I, I, U64, U64], I),
-        "xm_strip_run": ([P, I, U64, I, U64, I, I, I, I, U64, P], I),
+        "xm_strip_run": ([P, I, U64, I, U64, I, I, I, I, I, U64, P], I),
+        "xm_strip_cigar_columns": ([P, I, I, U64, P, P, P, P, U64, ctypes.POINTER(U64)], I),
         "xm_strip_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_strip_columns": ([P, I, U64, P, P, P, P, P], I),
         "xm_strip_device_columns": ([P, I, P], I),
@@ -158,7 +159,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
-            "xm_strip_classify", "xm_strip_columns", "xm_strip_device_columns", "xm_strip_last_error")
+            "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error")
 
 
 def _np_ptr(a):
@@ -582,7 +583,8 @@ class Context(object):
 
 
 # ---- include/xenomapper_strip.h: the SAM column stripper on the GPU --------------------------------------------
-LINE_NORMAL, LINE_BLANK, LINE_EX_A, LINE_EX_X, LINE_MISMATCH = 0x01, 0x02, 0x0C, 0x30, 0x40
+LINE_NORMAL, LINE_BLANK, LINE_EX_A, LINE_EX_X, LINE_MISMATCH = 0x01, 0x02, 0x1C, 0x60, 0x80
+LINE_EX_A_SHIFT, LINE_EX_X_SHIFT = 2, 5
 STRIP_SLOTS = 2
 STRIP_MAX_WINDOW = 0xFFFF0000
 
@@ -591,7 +593,7 @@ class _StripBlock(ctypes.Structure):
     _fields_ = [("n_records", ctypes.c_uint64), ("consumed1", ctypes.c_uint64), ("consumed2", ctypes.c_uint64),
                 ("consumed_lines1", ctypes.c_uint64), ("consumed_lines2", ctypes.c_uint64),
                 ("ended", ctypes.c_int32), ("starved", ctypes.c_int32), ("mismatch_at", ctypes.c_int64),
-                ("non_ascii", ctypes.c_int32), ("pad_", ctypes.c_int32), ("n_exceptions", ctypes.c_uint64),
+                ("non_ascii", ctypes.c_int32), ("overflow", ctypes.c_int32), ("n_exceptions", ctypes.c_uint64),
                 ("n_lines1", ctypes.c_uint64), ("n_lines2", ctypes.c_uint64),
                 ("line_off1", ctypes.c_void_p), ("line_off2", ctypes.c_void_p), ("line_len1", ctypes.c_void_p),
                 ("line_len2", ctypes.c_void_p), ("norm_len1", ctypes.c_void_p), ("norm_len2", ctypes.c_void_p),
@@ -617,6 +619,7 @@ class StrippedBlock(object):
         self.consumed_lines = (int(raw.consumed_lines1), int(raw.consumed_lines2))
         self.ended, self.starved, self.mismatch_at = bool(raw.ended), bool(raw.starved), int(raw.mismatch_at)
         self.non_ascii = bool(raw.non_ascii)
+        self.overflow = bool(raw.overflow)
         self.n_exceptions = int(raw.n_exceptions)
         self.n_lines = (int(raw.n_lines1), int(raw.n_lines2))
         self.tables = (raw.line_off1, raw.line_len1, raw.norm_len1, raw.line_flags1,
@@ -654,9 +657,9 @@ class StrippedBlock(object):
                 for f in (0, 1):
                     v = int(flags[f][k])
                     if v & LINE_EX_A:
-                        out.append((k, 2 * f, (v >> 2) & 3))
+                        out.append((k, 2 * f, (v & LINE_EX_A) >> LINE_EX_A_SHIFT))
                     if v & LINE_EX_X:
-                        out.append((k, 2 * f + 1, (v >> 4) & 3))
+                        out.append((k, 2 * f + 1, (v & LINE_EX_X) >> LINE_EX_X_SHIFT))
         return out
 
 
@@ -708,10 +711,11 @@ class Stripper(object):
         """Start sending staged bytes [offset, offset + n) of one window to the device (in order, from 0)."""
         self._check(self._L.xm_strip_upload(self._h, slot, file, int(offset), int(n)), "xm_strip_upload")
 
-    def run(self, slot, len1, eof1, len2, eof2, score_mode, paired, keep_halo, max_records):
+    def run(self, slot, len1, eof1, len2, eof2, score_mode, paired, skip_repeated, keep_halo, max_records):
         raw = _StripBlock()
         rc = self._L.xm_strip_run(self._h, slot, int(len1), int(bool(eof1)), int(len2), int(bool(eof2)), int(score_mode),
-                                  int(bool(paired)), int(bool(keep_halo)), int(max_records), ctypes.byref(raw))
+                                  int(bool(paired)), int(bool(skip_repeated)), int(bool(keep_halo)), int(max_records),
+                                  ctypes.byref(raw))
         self._check(rc, "xm_strip_run")
         return StrippedBlock(self, slot, raw)
 
@@ -725,6 +729,20 @@ class Stripper(object):
                                        ctypes.byref(idx), _np_ptr(off), _np_ptr(counts))
         self._check(rc, "xm_strip_classify")
         return (_host_view(code.value, int(n_records), np.uint8), _host_view(idx.value, int(off[7]), np.uint32), off, counts)
+
+    def cigar_columns(self, slot, file, n_records):
+        """After a CIGAR-mode run: (nm int32, cig_cnt uint8, cig_tile uint32, cig_ops uint32) of one file, on the host."""
+        n = int(n_records)
+        nm = np.empty(n, dtype=np.int32)
+        cnt = np.empty(n, dtype=np.uint8)
+        tile = np.zeros(cigar_tiles(n) + 1, dtype=np.uint32)
+        n_ops = ctypes.c_uint64()
+        self._check(self._L.xm_strip_cigar_columns(self._h, slot, file, n, _np_ptr(nm), _np_ptr(cnt), _np_ptr(tile), None, 0,
+                                                   ctypes.byref(n_ops)), "xm_strip_cigar_columns")
+        ops = np.zeros(max(int(n_ops.value), 1), dtype=np.uint32)
+        self._check(self._L.xm_strip_cigar_columns(self._h, slot, file, n, None, None, None, _np_ptr(ops), ops.shape[0],
+                                                   ctypes.byref(n_ops)), "xm_strip_cigar_columns")
+        return nm, cnt, tile, ops[:int(n_ops.value)]
 
     def columns(self, slot, n_records):
         """-> [as1, xs1, as2, xs2 (int32), unit_bits (uint64)] copied to the host."""

@@ -1,19 +1,27 @@
 // xm_strip.hip -- the SAM column stripper on the GPU (C ABI in include/xenomapper_strip.h), gfx950 only.
 //
 // Restates on the device what xm_sam.cpp does with host threads (and what the reference does in Python):
-//   getReadPairs without skipping   /root/reference/xenomapper/xenomapper.py:95-108  (readline / strip / split / names equal)
+//   getReadPairs                    /root/reference/xenomapper/xenomapper.py:95-118  (readline / strip / split / names equal /
+//                                   skip_repeated_reads)
 //   get_tag (field search)          :186-190      get_tag_with_ZS_as_XS :204-206
+//   get_cigarbased_AS_tag           :247-251      (first NM field, the CIGAR operations "MIDNSHP=X")
 //   the unit rule                   :402-405      (name equals the previous record's name)
-// Four kernels per pair of windows, all bound by reading the text from HBM (the text arrives over PCIe at a hundredth of
-// that rate, which is what bounds the step):
+// All kernels are bound by reading the text from HBM, and the text arrives over PCIe at a hundredth of that rate -- which
+// is what bounds the step:
 //   S1 mark_kernel    16 bytes per lane: terminator bits of '\n' / '\r\n' / '\r' (Python's universal newlines) as one 16-bit
 //                     mask per 16 bytes, terminators per 64 KiB chunk, non-ASCII test
 //   S2 chunk_scan     exclusive scan of the chunk counts (one workgroup per file)
-//   S3 fill_kernel    reads the masks (1/8 of the text): line k ends at lend[k], line k + 1 starts at lnext[k]
-//   S4 strip_kernel   one lane per record k = line k of both files: split by str.split()'s separators in aligned 8-byte words
-//                     (words inside the long leading fields are skipped whole), tags, names, unit bit (ballot -> one
-//                     64-bit word per wave), first stop (blank line / names differ) by atomicMin
-//   S5 summary_kernel one lane: the walk's outcome (records, consumed bytes, ended / starved / mismatch) as xmh_parse reports it
+//   S3 fill_kernel    reads the masks (1/8 of the text): line i ends at lend[i], line i + 1 starts at lnext[i]
+//   S4 parse_kernel   one lane per LINE of each file: split by str.split()'s separators in aligned 8-byte words (words
+//                     inside the long leading fields are skipped whole), tags (or NM + the CIGAR field), name -> a
+//                     per-line record
+//   S5 start_*        skip_repeated_reads only: a line starts a run when its name differs from the line in front; the run
+//                     starts of each file are compacted (count, scan, fill) -- pair k is run k of both files
+//   S6 pair_kernel    one lane per RECORD k: the two lines' records gathered into the score columns, names compared, unit
+//                     bit (ballot -> one 64-bit word per wave), first stop (blank line / names differ / open run) by atomicMin
+//   S7 cig_*          --cigar_scores only: operation counts scanned into positions, the CIGAR fields read again and written
+//                     as the packed columns the classify kernel reads (xenomapper_hip.h)
+//   S8 summary_kernel one lane: the walk's outcome (records, consumed bytes, ended / starved / mismatch) as xmh_parse reports it
 // The score columns and the unit mask never leave the device: xm_strip_classify runs the fused classify pass on them.
 #include "../../include/xenomapper_strip.h"
 
@@ -28,22 +36,38 @@
 
 namespace {
 
-constexpr int SB = 256;                               // lanes per workgroup of S1 / S3 / S4
+constexpr int SB = 256;                               // lanes per workgroup
 constexpr uint32_t CHUNK = 1u << 16;                  // bytes of text per workgroup in S1 / S3
 constexpr uint32_t GROUPS = CHUNK / 16;               // 16-byte groups per chunk
 constexpr uint32_t ITER = GROUPS / SB;
 constexpr int32_t ABSENT = INT32_MIN;
 
-enum { ST_NTERM0 = 0, ST_NTERM1 = 1, ST_NONASCII = 2, ST_KSTOP = 3, ST_WORDS = 8 };
+enum { ST_NTERM0 = 0, ST_NTERM1 = 1, ST_NONASCII = 2, ST_KSTOP = 3, ST_RUNS0 = 4, ST_RUNS1 = 5, ST_OPS0 = 6, ST_OPS1 = 7, ST_WORDS = 8 };
 enum { SUM_N = 0, SUM_CONS1, SUM_CONS2, SUM_CL1, SUM_CL2, SUM_ENDED, SUM_STARVED, SUM_MISMATCH, SUM_NONASCII, SUM_L1, SUM_L2,
-       SUM_WORDS = 16 };
+       SUM_OVERFLOW, SUM_WORDS = 16 };
 
-struct FileView {                                     // one file's window and its line index, on the device
+struct FileView {                                     // one file's window, its line index and its per-line records, on the device
     const uint8_t *text;
     uint32_t len, usable, eof, n_chunks;
     uint16_t *mask16;
     uint32_t *chunk_cnt, *chunk_base;
     uint32_t *lend, *lnext;                           // cap_lines entries each
+    // per-line records (S4), cap_lines entries
+    uint32_t *r_name_off, *r_name_len, *r_norm;
+    int32_t *r_a, *r_x, *r_nm;
+    uint32_t *r_nops, *r_cig_off, *r_cig_len;
+    uint8_t *r_flag;
+    // skip_repeated_reads: run starts
+    uint32_t *blk_cnt, *blk_base, *sel;
+    // per-record outputs
+    uint32_t *loff, *llen, *nlen;
+    uint8_t *lflag;
+    // packed CIGAR columns
+    int32_t *nm;
+    uint32_t *cpos;                                   // operations (+ trailer) per record, then their positions
+    uint8_t *cig_cnt;
+    uint32_t *cig_tile, *cig_ops;
+    uint32_t ops_cap;
 };
 
 struct Job {
@@ -53,11 +77,9 @@ struct Job {
     uint32_t cap_lines;                               // max_records + 1
     uint32_t max_records;
     uint32_t xtag0;                                   // 'X' or 'Z'
-    uint32_t paired, keep_halo;
+    uint32_t cigar, skip, paired, keep_halo;
     int32_t *col[4];                                  // as1, xs1, as2, xs2
     uint64_t *unit_bits;
-    uint32_t *loff[2], *llen[2], *nlen[2];
-    uint8_t *lflag[2];
 };
 
 // Python's str.split() separators in the ASCII range: \t \n \v \f \r, FS GS RS US, space
@@ -202,7 +224,7 @@ __device__ __forceinline__ Lines lines_of(const FileView &f, uint32_t n_terms, u
 {
     Lines L;
     L.n_terms = n_terms;
-    if (n_terms >= cap_lines) {                       // more lines than a block may hold: the end of the window is never reached
+    if (n_terms >= cap_lines) {                       // more lines than the tables hold: the end of the window is never reached
         L.count = n_terms;
         L.complete_end = 0;
         return L;
@@ -214,19 +236,11 @@ __device__ __forceinline__ Lines lines_of(const FileView &f, uint32_t n_terms, u
     return L;
 }
 
-__device__ __forceinline__ void line_span(const FileView &f, const Lines &L, uint32_t k, uint32_t &start, uint32_t &len)
+__device__ __forceinline__ void line_span(const FileView &f, const Lines &L, uint32_t i, uint32_t &start, uint32_t &len)
 {
-    start = k ? f.lnext[k - 1u] : 0u;
-    len = (k < L.n_terms ? f.lend[k] : f.len) - start;
+    start = i ? f.lnext[i - 1u] : 0u;
+    len = (i < L.n_terms ? f.lend[i] : f.len) - start;
 }
-
-struct Rec {
-    uint32_t name_off, name_len;                      // first field, window offsets
-    uint32_t norm_len, n_tok;
-    int32_t a, x;
-    uint32_t ex_a, ex_x;                              // 0, 1 = not a plain int32, 2 = tag matched more than once
-    bool normal;
-};
 
 // text[b, e): what follows the last ':' of a field as a plain integer in [-(2^31-1), 2^31-1] (xm_sam.cpp plain_int)
 __device__ bool plain_int(const uint8_t *text, uint32_t b, uint32_t e, int32_t &out)
@@ -246,14 +260,71 @@ __device__ bool plain_int(const uint8_t *text, uint32_t b, uint32_t e, int32_t &
     return true;
 }
 
-// One line: fields = line.split() (xenomapper.py:103-104), the tag search of get_tag over fields[11:] (:186-190).
-__device__ void parse_line(const uint8_t *text, uint32_t start, uint32_t n, uint32_t xtag0, Rec &r)
+__device__ __forceinline__ int cigar_op(uint32_t c)
 {
-    const uint32_t end = start + n;
+    switch (c) {
+    case 'M': return 0; case 'I': return 1; case 'D': return 2; case 'N': return 3; case 'S': return 4;
+    case 'H': return 5; case 'P': return 6; case '=': return 7; case 'X': return 8; default: return -1;
+    }
+}
+
+// re.findall(r'([0-9]+)([MIDNSHPX=])', cigar) over text[b, e): a run of ASCII digits directly followed by an operation
+// letter.  out != nullptr: the operations as len << 4 | op; returns how many; big: a length of 2^28 or more was met (that
+// operation is left out, as xm_sam.cpp does, and the line is flagged).
+__device__ uint32_t cigar_ops(const uint8_t *text, uint32_t b, uint32_t e, uint32_t *out, bool &big)
+{
+    uint64_t run = 0;
+    uint32_t digits = 0, n = 0;
+    for (uint32_t p = b; p < e; ++p) {
+        const uint32_t c = text[p];
+        if (c >= '0' && c <= '9') {
+            ++digits;
+            if (run < (1ull << 40)) run = run * 10u + (uint64_t)(c - '0');
+            continue;
+        }
+        const int op = cigar_op(c);
+        if (op >= 0 && digits > 0) {
+            if (run >= (1ull << 28)) big = true;
+            else {
+                if (out) out[n] = ((uint32_t)run << 4) | (uint32_t)op;
+                ++n;
+            }
+        }
+        run = 0;
+        digits = 0;
+    }
+    return n;
+}
+
+// ---- S4: one lane per line.  fields = line.split() (:103-104), the tag search of get_tag over fields[11:] (:186-190), in
+// CIGAR mode the first NM field and the operations of fields[5] (:247-251) ------------------------------------------
+__global__ void __launch_bounds__(SB) parse_kernel(const Job job)
+{
+    const int fi = (int)blockIdx.y;
+    const FileView &f = job.f[fi];
+    const Lines L0 = lines_of(job.f[0], job.state[ST_NTERM0], job.cap_lines);
+    const Lines L1 = lines_of(job.f[1], job.state[ST_NTERM1], job.cap_lines);
+    const Lines &L = fi ? L1 : L0;
+    // the plain walk only ever looks at the lines both files have; the skipping walk needs every line of the window
+    const uint32_t lim = job.skip ? min(L.count, job.cap_lines) : min(min(L0.count, L1.count), job.max_records);
+    const uint32_t i = blockIdx.x * SB + threadIdx.x;
+    if (i >= lim) return;
+    uint32_t start, n;
+    line_span(f, L, i, start, n);
+    const uint8_t *text = f.text;
+    const uint32_t end = start + n, xtag0 = job.xtag0;
+    const bool cigar = job.cigar != 0;
     uint32_t n_tok = 0, total = 0, name_off = start, name_len = 0;
-    bool normal = true, in_tok = false, prev_ws = false, ma = false, mx = false;
+    bool normal = true, in_tok = false, prev_ws = false, ma = false, mx = false, mn = false, have_nm = false;
     uint32_t k = 0, prevc = 0, last_colon = 0;
-    uint32_t n_a = 0, n_x = 0, a_b = 0, a_e = 0, x_b = 0, x_e = 0;
+    uint32_t n_a = 0, n_x = 0, a_b = 0, a_e = 0, x_b = 0, x_e = 0, nm_b = 0, nm_e = 0, cig_b = 0, cig_e = 0;
+    auto end_token = [&](uint32_t p) {
+        if (k == 0u) name_len = p - name_off;
+        if (k == 5u) cig_e = p;
+        if (ma && ++n_a == 1u) { a_b = last_colon; a_e = p; }
+        if (mx && ++n_x == 1u) { x_b = last_colon; x_e = p; }
+        if (mn && !have_nm) { have_nm = true; nm_b = last_colon; nm_e = p; }      // NM[0]: the first match, no duplicate rule
+    };
     uint32_t p = start;
     while (p < end) {
         const uint32_t wa = p & ~7u;
@@ -271,9 +342,7 @@ __device__ void parse_line(const uint8_t *text, uint32_t start, uint32_t n, uint
             const uint32_t c = (uint32_t)(w >> (8u * (p - wa))) & 0xFFu;
             if (is_ws(c)) {
                 if (in_tok) {
-                    if (k == 0u) name_len = p - name_off;
-                    if (ma && ++n_a == 1u) { a_b = last_colon; a_e = p; }
-                    if (mx && ++n_x == 1u) { x_b = last_colon; x_e = p; }
+                    end_token(p);
                     in_tok = false;
                 }
                 // '\t'.join(fields) == line  <=>  exactly one '\t' between fields, nothing in front or behind
@@ -284,14 +353,16 @@ __device__ void parse_line(const uint8_t *text, uint32_t start, uint32_t n, uint
                     in_tok = true;
                     k = n_tok++;
                     if (k == 0u) name_off = p;
+                    if (k == 5u) cig_b = p;
                     last_colon = p;
-                    ma = mx = false;
+                    ma = mx = mn = false;
                     prevc = 0u;
                 }
                 ++total;
                 if (k >= 11u) {
-                    ma = ma || (prevc == 'A' && c == 'S');
+                    ma = ma || (!cigar && prevc == 'A' && c == 'S');
                     mx = mx || (prevc == xtag0 && c == 'S');
+                    mn = mn || (cigar && prevc == 'N' && c == 'M');
                     if (c == ':') last_colon = p + 1u;
                 }
                 prevc = c;
@@ -299,23 +370,37 @@ __device__ void parse_line(const uint8_t *text, uint32_t start, uint32_t n, uint
             }
         }
     }
-    if (in_tok) {
-        if (k == 0u) name_len = end - name_off;
-        if (ma && ++n_a == 1u) { a_b = last_colon; a_e = end; }
-        if (mx && ++n_x == 1u) { x_b = last_colon; x_e = end; }
-    }
+    if (in_tok) end_token(end);
     if (prev_ws) normal = false;
-    r.name_off = name_off;
-    r.name_len = name_len;
-    r.n_tok = n_tok;
-    r.norm_len = n_tok ? total + (n_tok - 1u) : 0u;
-    r.normal = normal && n_tok > 0u;
-    r.a = r.x = ABSENT;
-    r.ex_a = r.ex_x = 0u;
-    if (n_a >= 1u && !plain_int(text, a_b, a_e, r.a)) { r.a = ABSENT; r.ex_a = 1u; }
-    if (n_x >= 1u && !plain_int(text, x_b, x_e, r.x)) { r.x = ABSENT; r.ex_x = 1u; }
-    if (n_a > 1u) r.ex_a = 2u;
-    if (n_x > 1u) r.ex_x = 2u;
+    int32_t a = ABSENT, x = ABSENT, nm = ABSENT;
+    uint32_t ex_a = 0, ex_x = 0, n_ops = 0;
+    if (n_a >= 1u && !plain_int(text, a_b, a_e, a)) { a = ABSENT; ex_a = 1u; }
+    if (n_x >= 1u && !plain_int(text, x_b, x_e, x)) { x = ABSENT; ex_x = 1u; }
+    if (n_a > 1u) ex_a = 2u;
+    if (n_x > 1u) ex_x = 2u;
+    if (cigar && have_nm) {
+        if (!plain_int(text, nm_b, nm_e, nm)) { nm = ABSENT; ex_a = 1u; }
+        if (n_tok < 6u) {
+            ex_a = 3u;                                               // IndexError in the reference: fields[5] does not exist
+        } else {
+            bool big = false;
+            n_ops = cigar_ops(text, cig_b, cig_e, nullptr, big);
+            if (big && ex_a == 0u) ex_a = 4u;
+        }
+    }
+    f.r_name_off[i] = name_off;
+    f.r_name_len[i] = name_len;
+    f.r_norm[i] = n_tok ? total + (n_tok - 1u) : 0u;
+    f.r_a[i] = a;
+    f.r_x[i] = x;
+    f.r_flag[i] = (uint8_t)(((normal && n_tok > 0u) ? XMS_LINE_NORMAL : 0u) | (n_tok == 0u ? XMS_LINE_BLANK : 0u) | (ex_a << 2) |
+                            (ex_x << 5));
+    if (cigar) {
+        f.r_nm[i] = nm;
+        f.r_nops[i] = n_ops;
+        f.r_cig_off[i] = cig_b;
+        f.r_cig_len[i] = n_ops ? cig_e - cig_b : 0u;
+    }
 }
 
 __device__ bool same_bytes(const uint8_t *a, const uint8_t *b, uint32_t n)
@@ -325,81 +410,236 @@ __device__ bool same_bytes(const uint8_t *a, const uint8_t *b, uint32_t n)
     return true;
 }
 
-// ---- S4: one lane per record ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SB) strip_kernel(const Job job)
+// xm_sam.cpp same_name: equal lengths and bytes (two blank lines have the same, empty, name)
+__device__ __forceinline__ bool same_name(const FileView &fa, uint32_t i, const FileView &fb, uint32_t j)
 {
-    const Lines L0 = lines_of(job.f[0], job.state[ST_NTERM0], job.cap_lines);
-    const Lines L1 = lines_of(job.f[1], job.state[ST_NTERM1], job.cap_lines);
-    const uint32_t lim = min(min(L0.count, L1.count), job.max_records);
+    const uint32_t n = fa.r_name_len[i];
+    return n == fb.r_name_len[j] && same_bytes(fa.text + fa.r_name_off[i], fb.text + fb.r_name_off[j], n);
+}
+
+// ---- S5: skip_repeated_reads (:110-117).  A file is cut into runs of adjacent lines with one name (a blank line is a run
+// of its own); pair k is the first line of run k of both files. ------------------------------------------------------
+__device__ __forceinline__ bool is_run_start(const FileView &f, uint32_t i)
+{
+    if (i == 0u) return true;
+    if ((f.r_flag[i] | f.r_flag[i - 1u]) & XMS_LINE_BLANK) return true;
+    return !same_name(f, i, f, i - 1u);
+}
+
+__global__ void __launch_bounds__(SB) start_count_kernel(const Job job)
+{
+    const int fi = (int)blockIdx.y;
+    const FileView &f = job.f[fi];
+    const Lines L = lines_of(f, job.state[ST_NTERM0 + fi], job.cap_lines);
+    const uint32_t lim = min(L.count, job.cap_lines);
+    if (blockIdx.x * SB >= lim) return;
+    __shared__ uint32_t red[SB / 64];
+    const uint32_t i = blockIdx.x * SB + threadIdx.x;
+    const bool st = i < lim && is_run_start(f, i);
+    const uint32_t c = (uint32_t)__popcll(__ballot(st));
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SB / 64; ++w) t += red[w];
+        f.blk_cnt[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(1024) start_scan_kernel(const Job job)
+{
+    const int fi = (int)blockIdx.x;
+    const FileView &f = job.f[fi];
+    const Lines L = lines_of(f, job.state[ST_NTERM0 + fi], job.cap_lines);
+    const uint32_t n_blk = (min(L.count, job.cap_lines) + SB - 1u) / SB;
+    __shared__ uint32_t ws[16];
+    const uint32_t per = (n_blk + 1023u) / 1024u;
+    const uint32_t b = min(threadIdx.x * per, n_blk), e = min(b + per, n_blk);
+    uint32_t sum = 0;
+    for (uint32_t c = b; c < e; ++c) sum += f.blk_cnt[c];
+    const uint32_t incl = wave_scan_incl(sum);
+    if ((threadIdx.x & 63u) == 63u) ws[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < (threadIdx.x >> 6)) wbase += ws[w];
+        total += ws[w];
+    }
+    uint32_t run = wbase + incl - sum;
+    for (uint32_t c = b; c < e; ++c) {
+        f.blk_base[c] = run;
+        run += f.blk_cnt[c];
+    }
+    if (threadIdx.x == 0) job.state[ST_RUNS0 + fi] = total;
+}
+
+__global__ void __launch_bounds__(SB) start_fill_kernel(const Job job)
+{
+    const int fi = (int)blockIdx.y;
+    const FileView &f = job.f[fi];
+    const Lines L = lines_of(f, job.state[ST_NTERM0 + fi], job.cap_lines);
+    const uint32_t lim = min(L.count, job.cap_lines);
+    if (blockIdx.x * SB >= lim) return;
+    __shared__ uint32_t ws[SB / 64];
+    const uint32_t i = blockIdx.x * SB + threadIdx.x;
+    const bool st = i < lim && is_run_start(f, i);
+    const uint64_t m = __ballot(st);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane == 0u) ws[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t wb = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += ws[w];
+    if (st) f.sel[f.blk_base[blockIdx.x] + wb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+// what the walk may pair: records (plain walk: lines) of each file, and the most the block may hold
+struct Walk {
+    Lines L[2];
+    uint32_t R[2];                                    // pairable entries per file: runs (skipping walk) or lines
+    uint32_t lim;
+    bool whole[2];
+};
+
+__device__ __forceinline__ Walk walk_of(const Job &job)
+{
+    Walk W;
+    for (int f = 0; f < 2; ++f) {
+        W.L[f] = lines_of(job.f[f], job.state[ST_NTERM0 + f], job.cap_lines);
+        W.R[f] = job.skip ? job.state[ST_RUNS0 + f] : W.L[f].count;
+        W.whole[f] = job.f[f].eof && W.L[f].n_terms < job.cap_lines && W.L[f].complete_end == job.f[f].len;
+    }
+    W.lim = min(min(W.R[0], W.R[1]), job.max_records);
+    return W;
+}
+
+// ---- S6: one lane per record ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SB) pair_kernel(const Job job)
+{
+    const Walk W = walk_of(job);
     const uint32_t k = blockIdx.x * SB + threadIdx.x;
-    if ((k & ~63u) >= lim) return;                     // the whole wave is past the end (wave-uniform)
+    if ((k & ~63u) >= W.lim) return;                    // the whole wave is past the end (wave-uniform)
     bool unit = false;
-    if (k < lim) {
-        Rec r[2];
-        uint32_t st[2], ln[2];
-        line_span(job.f[0], L0, k, st[0], ln[0]);
-        line_span(job.f[1], L1, k, st[1], ln[1]);
-        parse_line(job.f[0].text, st[0], ln[0], job.xtag0, r[0]);
-        parse_line(job.f[1].text, st[1], ln[1], job.xtag0, r[1]);
-        const bool blank0 = r[0].n_tok == 0u, blank1 = r[1].n_tok == 0u;
-        const bool same = r[0].name_len == r[1].name_len &&
-                          same_bytes(job.f[0].text + r[0].name_off, job.f[1].text + r[1].name_off, r[0].name_len);
-        if (blank0 || blank1 || !same) atomicMin(&job.state[ST_KSTOP], k);
+    if (k < W.lim) {
+        uint32_t i[2];
+        for (int f = 0; f < 2; ++f) i[f] = job.skip ? job.f[f].sel[k] : k;
+        const uint32_t fl0 = job.f[0].r_flag[i[0]], fl1 = job.f[1].r_flag[i[1]];
+        const bool blank = ((fl0 | fl1) & XMS_LINE_BLANK) != 0u;
+        const bool same = same_name(job.f[0], i[0], job.f[1], i[1]);
+        // the skipping walk also stops at a run that reaches the end of a window which is not the end of its file (the run
+        // may go on in the next window) -- after blank and mismatch, in that order (xm_sam.cpp)
+        const bool open_run = job.skip && ((k + 1u == W.R[0] && !W.whole[0]) || (k + 1u == W.R[1] && !W.whole[1]));
+        if (blank || !same || open_run) atomicMin(&job.state[ST_KSTOP], k);
         // the unit rule (:402-405): the name equals the name of the record in front (file 1's names, as the reference)
-        if (!job.paired) {
-            unit = true;
-        } else if (k > 0u) {
-            uint32_t ps, pl;
-            line_span(job.f[0], L0, k - 1u, ps, pl);
-            const uint8_t *t = job.f[0].text;
-            uint32_t q = ps;
-            const uint32_t pe = ps + pl;
-            while (q < pe && is_ws(t[q])) ++q;
-            const uint32_t nb = q;
-            while (q < pe && !is_ws(t[q])) ++q;
-            unit = (q - nb) == r[0].name_len && same_bytes(t + nb, t + r[0].name_off, r[0].name_len);
-        }
-        job.col[0][k] = r[0].a;
-        job.col[1][k] = r[0].x;
-        job.col[2][k] = r[1].a;
-        job.col[3][k] = r[1].x;
+        if (!job.paired) unit = true;
+        else if (k > 0u) unit = same_name(job.f[0], i[0], job.f[0], job.skip ? job.f[0].sel[k - 1u] : k - 1u);
         for (int f = 0; f < 2; ++f) {
-            job.loff[f][k] = st[f];
-            job.llen[f][k] = ln[f];
-            job.nlen[f][k] = r[f].norm_len;
-            uint32_t fl = (r[f].normal ? XMS_LINE_NORMAL : 0u) | (r[f].n_tok == 0u ? XMS_LINE_BLANK : 0u) |
-                          (r[f].ex_a << 2) | (r[f].ex_x << 4);
-            if (f == 0 && !blank0 && !blank1 && !same) fl |= XMS_LINE_MISMATCH;
-            job.lflag[f][k] = (uint8_t)fl;
+            const FileView &v = job.f[f];
+            uint32_t st, ln;
+            line_span(v, W.L[f], i[f], st, ln);
+            v.loff[k] = st;
+            v.llen[k] = ln;
+            v.nlen[k] = v.r_norm[i[f]];
+            uint32_t fl = f ? fl1 : fl0;
+            if (f == 0 && !blank && !same) fl |= XMS_LINE_MISMATCH;
+            v.lflag[k] = (uint8_t)fl;
+            job.col[2 * f][k] = v.r_a[i[f]];
+            job.col[2 * f + 1][k] = v.r_x[i[f]];
+            if (job.cigar) {
+                const uint32_t n_ops = v.r_nops[i[f]];
+                v.nm[k] = v.r_nm[i[f]];
+                v.cpos[k] = n_ops + (n_ops >= 255u ? 1u : 0u);
+            }
         }
     }
     const uint64_t word = __ballot(unit);
     if ((threadIdx.x & 63u) == 0u) job.unit_bits[k >> 6] = word;
 }
 
-// ---- S5: the outcome of the walk, as xm_sam.cpp parse_common reports it ------------------------------------------
+// ---- S7: the packed CIGAR columns of include/xenomapper_hip.h ------------------------------------------------------
+__global__ void __launch_bounds__(1024) cig_scan_kernel(const Job job)
+{
+    const int fi = (int)blockIdx.x;
+    const FileView &f = job.f[fi];
+    const Walk W = walk_of(job);
+    const uint32_t n = W.lim;
+    __shared__ uint32_t ws[16];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t b = min(threadIdx.x * per, n), e = min(b + per, n);
+    uint32_t sum = 0;
+    for (uint32_t c = b; c < e; ++c) sum += f.cpos[c];
+    const uint32_t incl = wave_scan_incl(sum);
+    if ((threadIdx.x & 63u) == 63u) ws[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < (threadIdx.x >> 6)) wbase += ws[w];
+        total += ws[w];
+    }
+    uint32_t run = wbase + incl - sum;
+    for (uint32_t c = b; c < e; ++c) {
+        const uint32_t mine = f.cpos[c];
+        f.cpos[c] = run;
+        run += mine;
+    }
+    if (threadIdx.x == 0) {
+        f.cpos[n] = total;
+        job.state[ST_OPS0 + fi] = total;
+    }
+}
+
+__global__ void __launch_bounds__(SB) cig_write_kernel(const Job job)
+{
+    const int fi = (int)blockIdx.y;
+    const FileView &f = job.f[fi];
+    const Walk W = walk_of(job);
+    const uint32_t k = blockIdx.x * SB + threadIdx.x;
+    if (k >= W.lim) return;
+    const uint32_t total = f.cpos[W.lim];
+    if (total > f.ops_cap) return;                      // cannot happen (an operation takes two bytes of text); S8 reports it
+    const uint32_t i = job.skip ? f.sel[k] : k;
+    const uint32_t pos = f.cpos[k], n_ops = f.r_nops[i];
+    if (n_ops) {
+        bool big = false;
+        const uint32_t b = f.r_cig_off[i];
+        (void)cigar_ops(f.text, b, b + f.r_cig_len[i], f.cig_ops + pos, big);
+        if (n_ops >= 255u) f.cig_ops[pos + n_ops] = (n_ops << 4) | 15u;     // the trailer: the record's begin from its end
+    }
+    f.cig_cnt[k] = (uint8_t)min(n_ops, 255u);
+    if ((k & 255u) == 0u) f.cig_tile[k >> 8] = pos;
+    if (k + 1u == W.lim) f.cig_tile[(W.lim + 255u) >> 8] = total;
+}
+
+// ---- S8: the outcome of the walk, as xm_sam.cpp parse_common reports it ------------------------------------------
 __global__ void summary_kernel(const Job job)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const Lines L[2] = {lines_of(job.f[0], job.state[ST_NTERM0], job.cap_lines),
-                        lines_of(job.f[1], job.state[ST_NTERM1], job.cap_lines)};
-    const uint32_t lim = min(min(L[0].count, L[1].count), job.max_records);
+    const Walk W = walk_of(job);
+    const uint32_t lim = W.lim;
     const uint32_t ks = min(job.state[ST_KSTOP], lim);
-    uint32_t ended = 0, starved = 0;
+    uint32_t ended = 0, starved = 0, overflow = 0;
     int64_t mismatch = -1;
+    if (job.skip && (W.L[0].n_terms >= job.cap_lines || W.L[1].n_terms >= job.cap_lines)) overflow = 1;   // more lines than the tables hold
+    if (job.cigar && (job.state[ST_OPS0] > job.f[0].ops_cap || job.state[ST_OPS1] > job.f[1].ops_cap)) overflow = 1;
     if (ks < lim) {
-        if ((job.lflag[0][ks] | job.lflag[1][ks]) & XMS_LINE_BLANK) ended = 1; else mismatch = (int64_t)ks;
+        const uint32_t fl = job.f[0].lflag[ks] | job.f[1].lflag[ks];
+        if (fl & XMS_LINE_BLANK) ended = 1;
+        else if (job.f[0].lflag[ks] & XMS_LINE_MISMATCH) mismatch = (int64_t)ks;
+        else starved = 1;                                            // an open run
     } else if (ks < job.max_records) {
-        const bool whole0 = job.f[0].eof && L[0].complete_end == job.f[0].len;
-        const bool whole1 = job.f[1].eof && L[1].complete_end == job.f[1].len;
-        if ((ks >= L[0].count && whole0) || (ks >= L[1].count && whole1)) ended = 1; else starved = 1;
+        const bool end0 = job.skip ? (W.R[0] == lim && W.whole[0]) : (ks >= W.L[0].count && W.whole[0]);
+        const bool end1 = job.skip ? (W.R[1] == lim && W.whole[1]) : (ks >= W.L[1].count && W.whole[1]);
+        if (end0 || end1) ended = 1; else starved = 1;
     }
     uint64_t cons[2], cl[2];
     const bool halo = job.keep_halo && ks > 0u && !ended && mismatch < 0;
     for (int f = 0; f < 2; ++f) {
-        const uint32_t i = halo ? ks - 1u : ks;
-        cons[f] = i < L[f].count ? (uint64_t)(i ? job.f[f].lnext[i - 1u] : 0u) : (uint64_t)L[f].complete_end;
-        cl[f] = min(i, L[f].count);
+        // the line the next window starts with: the last yielded record's (halo) or the one the walk stopped at
+        uint32_t i;
+        if (halo) i = job.skip ? job.f[f].sel[ks - 1u] : ks - 1u;
+        else if (job.skip) i = ks < W.R[f] ? job.f[f].sel[ks] : W.L[f].count;
+        else i = ks;
+        cons[f] = i < W.L[f].count ? (uint64_t)(i ? job.f[f].lnext[i - 1u] : 0u) : (uint64_t)W.L[f].complete_end;
+        cl[f] = min(i, W.L[f].count);
     }
     uint64_t *s = job.summary;
     s[SUM_N] = ks;
@@ -411,34 +651,50 @@ __global__ void summary_kernel(const Job job)
     s[SUM_STARVED] = starved;
     s[SUM_MISMATCH] = (uint64_t)mismatch;
     s[SUM_NONASCII] = job.state[ST_NONASCII];
-    s[SUM_L1] = L[0].count;
-    s[SUM_L2] = L[1].count;
+    s[SUM_L1] = W.L[0].count;
+    s[SUM_L2] = W.L[1].count;
+    s[SUM_OVERFLOW] = overflow;
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
+struct PerFile {
+    char *h_text = nullptr;                            // page-locked staging
+    uint8_t *d_text = nullptr;
+    uint16_t *d_mask = nullptr;
+    uint32_t *d_chunk_cnt = nullptr, *d_chunk_base = nullptr;
+    uint32_t *d_lend = nullptr, *d_lnext = nullptr;
+    uint32_t *d_r_name_off = nullptr, *d_r_name_len = nullptr, *d_r_norm = nullptr, *d_r_nops = nullptr, *d_r_cig_off = nullptr,
+             *d_r_cig_len = nullptr;
+    int32_t *d_r_a = nullptr, *d_r_x = nullptr, *d_r_nm = nullptr;
+    uint8_t *d_r_flag = nullptr;
+    uint32_t *d_blk_cnt = nullptr, *d_blk_base = nullptr, *d_sel = nullptr;
+    uint32_t *d_loff = nullptr, *d_llen = nullptr, *d_nlen = nullptr;
+    uint8_t *d_lflag = nullptr;
+    uint32_t *h_loff = nullptr, *h_llen = nullptr, *h_nlen = nullptr;
+    uint8_t *h_lflag = nullptr;
+    int32_t *d_nm = nullptr;
+    uint32_t *d_cpos = nullptr, *d_cig_tile = nullptr, *d_cig_ops = nullptr;
+    uint8_t *d_cig_cnt = nullptr;
+    uint64_t ops_cap = 0;
+};
+
 struct Slot {
     uint64_t window_cap = 0, record_cap = 0;
-    char *h_text[2] = {nullptr, nullptr};              // page-locked staging
-    uint8_t *d_text[2] = {nullptr, nullptr};
-    uint16_t *d_mask[2] = {nullptr, nullptr};
-    uint32_t *d_chunk_cnt[2] = {nullptr, nullptr}, *d_chunk_base[2] = {nullptr, nullptr};
-    uint32_t *d_lend[2] = {nullptr, nullptr}, *d_lnext[2] = {nullptr, nullptr};
+    bool cigar_ready = false;                          // the CIGAR-only arrays exist for the current capacities
+    PerFile pf[2];
     int32_t *d_col[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t *d_bits = nullptr;
-    uint32_t *d_loff[2] = {nullptr, nullptr}, *d_llen[2] = {nullptr, nullptr}, *d_nlen[2] = {nullptr, nullptr};
-    uint8_t *d_lflag[2] = {nullptr, nullptr};
-    uint32_t *h_loff[2] = {nullptr, nullptr}, *h_llen[2] = {nullptr, nullptr}, *h_nlen[2] = {nullptr, nullptr};
-    uint8_t *h_lflag[2] = {nullptr, nullptr};
     // classify outputs
     uint8_t *d_code = nullptr, *d_bins4 = nullptr, *h_code = nullptr;
-    uint32_t *d_idx = nullptr, *h_idx = nullptr;
-    uint64_t *d_off_counts = nullptr, *h_off_counts = nullptr;     // 8 + 64 words
+    uint32_t *d_idx = nullptr, *h_idx = nullptr, *d_range = nullptr;
+    uint64_t *d_off_counts = nullptr, *h_off_counts = nullptr;     // 8 + 64 words (+ the range flag's word on the host side)
     uint32_t *d_state = nullptr;
     uint64_t *d_summary = nullptr, *h_summary = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     uint64_t uploaded[2] = {0, 0};                     // bytes of the staged windows already on their way (xm_strip_upload)
     bool upload_timed = false;
+    int last_score_mode = -1;                          // of the block the slot holds
 };
 
 }  // namespace
@@ -466,54 +722,63 @@ int fail(xm_strip *s, hipError_t e, const char *what)
         if (e_ != hipSuccess) return fail((s), e_, #call); \
     } while (0)
 
-template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
-template <typename T> void hfree(T *&p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
-
-void free_slot(Slot &sl)
-{
-    for (int f = 0; f < 2; ++f) {
-        hfree(sl.h_text[f]); dfree(sl.d_text[f]); dfree(sl.d_mask[f]); dfree(sl.d_chunk_cnt[f]); dfree(sl.d_chunk_base[f]);
-        dfree(sl.d_lend[f]); dfree(sl.d_lnext[f]); dfree(sl.d_loff[f]); dfree(sl.d_llen[f]); dfree(sl.d_nlen[f]); dfree(sl.d_lflag[f]);
-        hfree(sl.h_loff[f]); hfree(sl.h_llen[f]); hfree(sl.h_nlen[f]); hfree(sl.h_lflag[f]);
-    }
-    for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
-    dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx); dfree(sl.d_off_counts);
-    hfree(sl.h_code); hfree(sl.h_idx); hfree(sl.h_off_counts);
-    sl.window_cap = sl.record_cap = 0;
-}
-
-template <typename T> int dalloc(xm_strip *s, T *&p, size_t count)
-{
-    XMS_HIP(s, hipMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T)));
-    return XM_OK;
-}
-template <typename T> int halloc(xm_strip *s, T *&p, size_t count)
-{
-    XMS_HIP(s, hipHostMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T), hipHostMallocDefault));
-    return XM_OK;
-}
-
 #define XMS_TRY(expr)                  \
     do {                               \
         int rc_ = (expr);              \
         if (rc_ != XM_OK) return rc_;  \
     } while (0)
 
+template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+template <typename T> void hfree(T *&p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+
+template <typename T> int dalloc(xm_strip *s, T *&p, size_t count)
+{
+    dfree(p);
+    XMS_HIP(s, hipMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T)));
+    return XM_OK;
+}
+template <typename T> int halloc(xm_strip *s, T *&p, size_t count)
+{
+    hfree(p);
+    XMS_HIP(s, hipHostMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T), hipHostMallocDefault));
+    return XM_OK;
+}
+
+void free_slot(Slot &sl)
+{
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        hfree(q.h_text); dfree(q.d_text); dfree(q.d_mask); dfree(q.d_chunk_cnt); dfree(q.d_chunk_base);
+        dfree(q.d_lend); dfree(q.d_lnext);
+        dfree(q.d_r_name_off); dfree(q.d_r_name_len); dfree(q.d_r_norm); dfree(q.d_r_nops); dfree(q.d_r_cig_off); dfree(q.d_r_cig_len);
+        dfree(q.d_r_a); dfree(q.d_r_x); dfree(q.d_r_nm); dfree(q.d_r_flag);
+        dfree(q.d_blk_cnt); dfree(q.d_blk_base); dfree(q.d_sel);
+        dfree(q.d_loff); dfree(q.d_llen); dfree(q.d_nlen); dfree(q.d_lflag);
+        hfree(q.h_loff); hfree(q.h_llen); hfree(q.h_nlen); hfree(q.h_lflag);
+        dfree(q.d_nm); dfree(q.d_cpos); dfree(q.d_cig_tile); dfree(q.d_cig_ops); dfree(q.d_cig_cnt);
+        q.ops_cap = 0;
+    }
+    for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
+    dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx);
+    hfree(sl.h_code); hfree(sl.h_idx);
+    sl.window_cap = sl.record_cap = 0;
+    sl.cigar_ready = false;
+}
+
 int grow_window(xm_strip *s, Slot &sl, uint64_t bytes)
 {
     if (bytes <= sl.window_cap) return XM_OK;
     const uint64_t cap = (bytes + CHUNK - 1) / CHUNK * CHUNK;
     const size_t n_chunks = (size_t)(cap / CHUNK);
-    for (int f = 0; f < 2; ++f) {
-        hfree(sl.h_text[f]); dfree(sl.d_text[f]); dfree(sl.d_mask[f]); dfree(sl.d_chunk_cnt[f]); dfree(sl.d_chunk_base[f]);
-    }
     sl.window_cap = 0;
+    sl.cigar_ready = false;
     for (int f = 0; f < 2; ++f) {
-        XMS_TRY(halloc(s, sl.h_text[f], (size_t)cap));
-        XMS_TRY(dalloc(s, sl.d_text[f], (size_t)cap + 64));            // S1 / S4 read whole 16- / 8-byte words
-        XMS_TRY(dalloc(s, sl.d_mask[f], (size_t)cap / 16 + 16));
-        XMS_TRY(dalloc(s, sl.d_chunk_cnt[f], n_chunks));
-        XMS_TRY(dalloc(s, sl.d_chunk_base[f], n_chunks));
+        PerFile &q = sl.pf[f];
+        XMS_TRY(halloc(s, q.h_text, (size_t)cap));
+        XMS_TRY(dalloc(s, q.d_text, (size_t)cap + 64));               // S1 / S4 read whole 16- / 8-byte words
+        XMS_TRY(dalloc(s, q.d_mask, (size_t)cap / 16 + 16));
+        XMS_TRY(dalloc(s, q.d_chunk_cnt, n_chunks));
+        XMS_TRY(dalloc(s, q.d_chunk_base, n_chunks));
     }
     sl.window_cap = cap;
     return XM_OK;
@@ -523,20 +788,16 @@ int grow_records(xm_strip *s, Slot &sl, uint64_t records)
 {
     if (records <= sl.record_cap) return XM_OK;
     const size_t n = (size_t)records + 64, lines = (size_t)records + 1;
-    for (int f = 0; f < 2; ++f) {
-        dfree(sl.d_lend[f]); dfree(sl.d_lnext[f]); dfree(sl.d_loff[f]); dfree(sl.d_llen[f]); dfree(sl.d_nlen[f]); dfree(sl.d_lflag[f]);
-        hfree(sl.h_loff[f]); hfree(sl.h_llen[f]); hfree(sl.h_nlen[f]); hfree(sl.h_lflag[f]);
-    }
-    for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
-    dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx);
-    hfree(sl.h_code); hfree(sl.h_idx);
     sl.record_cap = 0;
+    sl.cigar_ready = false;
     for (int f = 0; f < 2; ++f) {
-        XMS_TRY(dalloc(s, sl.d_lend[f], lines)); XMS_TRY(dalloc(s, sl.d_lnext[f], lines));
-        XMS_TRY(dalloc(s, sl.d_loff[f], n)); XMS_TRY(dalloc(s, sl.d_llen[f], n)); XMS_TRY(dalloc(s, sl.d_nlen[f], n));
-        XMS_TRY(dalloc(s, sl.d_lflag[f], n));
-        XMS_TRY(halloc(s, sl.h_loff[f], n)); XMS_TRY(halloc(s, sl.h_llen[f], n)); XMS_TRY(halloc(s, sl.h_nlen[f], n));
-        XMS_TRY(halloc(s, sl.h_lflag[f], n));
+        PerFile &q = sl.pf[f];
+        XMS_TRY(dalloc(s, q.d_lend, lines)); XMS_TRY(dalloc(s, q.d_lnext, lines));
+        XMS_TRY(dalloc(s, q.d_r_name_off, lines)); XMS_TRY(dalloc(s, q.d_r_name_len, lines)); XMS_TRY(dalloc(s, q.d_r_norm, lines));
+        XMS_TRY(dalloc(s, q.d_r_a, lines)); XMS_TRY(dalloc(s, q.d_r_x, lines)); XMS_TRY(dalloc(s, q.d_r_flag, lines + 64));
+        XMS_TRY(dalloc(s, q.d_blk_cnt, lines / SB + 2)); XMS_TRY(dalloc(s, q.d_blk_base, lines / SB + 2)); XMS_TRY(dalloc(s, q.d_sel, lines));
+        XMS_TRY(dalloc(s, q.d_loff, n)); XMS_TRY(dalloc(s, q.d_llen, n)); XMS_TRY(dalloc(s, q.d_nlen, n)); XMS_TRY(dalloc(s, q.d_lflag, n));
+        XMS_TRY(halloc(s, q.h_loff, n)); XMS_TRY(halloc(s, q.h_llen, n)); XMS_TRY(halloc(s, q.h_nlen, n)); XMS_TRY(halloc(s, q.h_lflag, n));
     }
     for (int c = 0; c < 4; ++c) XMS_TRY(dalloc(s, sl.d_col[c], n));
     XMS_TRY(dalloc(s, sl.d_bits, n / 64 + 2));
@@ -546,6 +807,25 @@ int grow_records(xm_strip *s, Slot &sl, uint64_t records)
     XMS_TRY(halloc(s, sl.h_code, n));
     XMS_TRY(halloc(s, sl.h_idx, n));
     sl.record_cap = records;
+    return XM_OK;
+}
+
+// the arrays only --cigar_scores needs, sized for the slot's current capacities (allocated on the first CIGAR run)
+int ensure_cigar(xm_strip *s, Slot &sl)
+{
+    if (sl.cigar_ready) return XM_OK;
+    const size_t n = (size_t)sl.record_cap + 64, lines = (size_t)sl.record_cap + 1;
+    // an operation is at least two bytes of text ("1M"); one trailer word per record at most
+    const uint64_t ops_cap = std::min<uint64_t>(sl.window_cap / 2 + sl.record_cap + 16, 0xFFFFFFF0ull);
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        XMS_TRY(dalloc(s, q.d_r_nm, lines)); XMS_TRY(dalloc(s, q.d_r_nops, lines)); XMS_TRY(dalloc(s, q.d_r_cig_off, lines));
+        XMS_TRY(dalloc(s, q.d_r_cig_len, lines));
+        XMS_TRY(dalloc(s, q.d_nm, n)); XMS_TRY(dalloc(s, q.d_cpos, n)); XMS_TRY(dalloc(s, q.d_cig_cnt, n));
+        XMS_TRY(dalloc(s, q.d_cig_tile, n / 256 + 4)); XMS_TRY(dalloc(s, q.d_cig_ops, (size_t)ops_cap + 16));
+        q.ops_cap = ops_cap;
+    }
+    sl.cigar_ready = true;
     return XM_OK;
 }
 
@@ -568,10 +848,11 @@ int xm_strip_create(xm_ctx *ctx, int device_id, xm_strip **out)
         e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
         for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, ST_WORDS * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_range, 4 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_summary, SUM_WORDS * sizeof(uint64_t));
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_summary, SUM_WORDS * sizeof(uint64_t), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off_counts, 72 * sizeof(uint64_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off_counts, 74 * sizeof(uint64_t), hipHostMallocDefault);
     }
     if (e != hipSuccess) {
         xm_strip_destroy(s);
@@ -589,7 +870,7 @@ int xm_strip_destroy(xm_strip *s)
         Slot &sl = s->slot[k];
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
         free_slot(sl);
-        dfree(sl.d_state); dfree(sl.d_summary); dfree(sl.d_off_counts);
+        dfree(sl.d_state); dfree(sl.d_range); dfree(sl.d_summary); dfree(sl.d_off_counts);
         hfree(sl.h_summary); hfree(sl.h_off_counts);
         for (int i = 0; i < 3; ++i)
             if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
@@ -615,7 +896,7 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
 char *xm_strip_staging(xm_strip *s, int slot, int file)
 {
     if (!s || slot < 0 || slot >= XMS_SLOTS || file < 0 || file > 1) return nullptr;
-    return s->slot[slot].h_text[file];
+    return s->slot[slot].pf[file].h_text;
 }
 
 int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t bytes)
@@ -629,25 +910,29 @@ int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t b
         XMS_HIP(s, hipEventRecord(sl.ev[0], sl.stream));
         sl.upload_timed = true;
     }
-    XMS_HIP(s, hipMemcpyAsync(sl.d_text[file] + offset, sl.h_text[file] + offset, (size_t)bytes, hipMemcpyHostToDevice, sl.stream));
+    PerFile &q = sl.pf[file];
+    XMS_HIP(s, hipMemcpyAsync(q.d_text + offset, q.h_text + offset, (size_t)bytes, hipMemcpyHostToDevice, sl.stream));
     sl.uploaded[file] = offset + bytes;
     return XM_OK;
 }
 
 int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, int eof2,
-                 int score_mode, int paired, int keep_halo, uint64_t max_records, xm_strip_block *out)
+                 int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xm_strip_block *out)
 {
-    if (!s || !out || slot < 0 || slot >= XMS_SLOTS || (score_mode != XMS_SCORE_AS_XS && score_mode != XMS_SCORE_AS_ZS))
+    if (!s || !out || slot < 0 || slot >= XMS_SLOTS || score_mode < XMS_SCORE_AS_XS || score_mode > XMS_SCORE_CIGAR)
         return XM_ERR_INVALID_ARG;
     Slot &sl = s->slot[slot];
     const uint64_t sent[2] = {sl.uploaded[0], sl.uploaded[1]};
     const bool timed = sl.upload_timed;
     sl.uploaded[0] = sl.uploaded[1] = 0;
     sl.upload_timed = false;
+    sl.last_score_mode = -1;
     if (len1 > sl.window_cap || len2 > sl.window_cap || max_records == 0 || max_records > sl.record_cap || sent[0] > len1 ||
         sent[1] > len2)
         return XM_ERR_INVALID_ARG;
     XMS_HIP(s, hipSetDevice(s->device));
+    const bool cigar = score_mode == XMS_SCORE_CIGAR;
+    if (cigar) XMS_TRY(ensure_cigar(s, sl));
     const uint64_t len[2] = {len1, len2};
     const int eof[2] = {eof1, eof2};
     Job job;
@@ -655,25 +940,31 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
     uint32_t max_chunks = 1;
     for (int f = 0; f < 2; ++f) {
         FileView &v = job.f[f];
-        v.text = sl.d_text[f];
+        PerFile &q = sl.pf[f];
+        v.text = q.d_text;
         v.len = (uint32_t)len[f];
         // a trailing '\r' may be the first half of a "\r\n" that continues in the next window
-        v.usable = (!eof[f] && len[f] > 0 && sl.h_text[f][len[f] - 1] == '\r') ? (uint32_t)len[f] - 1u : (uint32_t)len[f];
+        v.usable = (!eof[f] && len[f] > 0 && q.h_text[len[f] - 1] == '\r') ? (uint32_t)len[f] - 1u : (uint32_t)len[f];
         v.eof = eof[f] ? 1u : 0u;
         v.n_chunks = (uint32_t)((len[f] + CHUNK - 1) / CHUNK);
-        v.mask16 = sl.d_mask[f];
-        v.chunk_cnt = sl.d_chunk_cnt[f];
-        v.chunk_base = sl.d_chunk_base[f];
-        v.lend = sl.d_lend[f];
-        v.lnext = sl.d_lnext[f];
+        v.mask16 = q.d_mask; v.chunk_cnt = q.d_chunk_cnt; v.chunk_base = q.d_chunk_base;
+        v.lend = q.d_lend; v.lnext = q.d_lnext;
+        v.r_name_off = q.d_r_name_off; v.r_name_len = q.d_r_name_len; v.r_norm = q.d_r_norm;
+        v.r_a = q.d_r_a; v.r_x = q.d_r_x; v.r_nm = q.d_r_nm; v.r_nops = q.d_r_nops; v.r_cig_off = q.d_r_cig_off; v.r_cig_len = q.d_r_cig_len;
+        v.r_flag = q.d_r_flag;
+        v.blk_cnt = q.d_blk_cnt; v.blk_base = q.d_blk_base; v.sel = q.d_sel;
+        v.loff = q.d_loff; v.llen = q.d_llen; v.nlen = q.d_nlen; v.lflag = q.d_lflag;
+        v.nm = q.d_nm; v.cpos = q.d_cpos; v.cig_cnt = q.d_cig_cnt; v.cig_tile = q.d_cig_tile; v.cig_ops = q.d_cig_ops;
+        v.ops_cap = (uint32_t)q.ops_cap;
         max_chunks = std::max(max_chunks, v.n_chunks);
-        job.loff[f] = sl.d_loff[f]; job.llen[f] = sl.d_llen[f]; job.nlen[f] = sl.d_nlen[f]; job.lflag[f] = sl.d_lflag[f];
     }
     job.state = sl.d_state;
     job.summary = sl.d_summary;
     job.cap_lines = (uint32_t)max_records + 1u;
     job.max_records = (uint32_t)max_records;
     job.xtag0 = score_mode == XMS_SCORE_AS_ZS ? 'Z' : 'X';
+    job.cigar = cigar ? 1u : 0u;
+    job.skip = skip_repeated ? 1u : 0u;
     job.paired = paired ? 1u : 0u;
     job.keep_halo = keep_halo ? 1u : 0u;
     for (int c = 0; c < 4; ++c) job.col[c] = sl.d_col[c];
@@ -683,16 +974,29 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
     if (!timed) XMS_HIP(s, hipEventRecord(sl.ev[0], st));
     for (int f = 0; f < 2; ++f)                        // what xm_strip_upload has not sent yet
         if (len[f] > sent[f])
-            XMS_HIP(s, hipMemcpyAsync(sl.d_text[f] + sent[f], sl.h_text[f] + sent[f], (size_t)(len[f] - sent[f]),
+            XMS_HIP(s, hipMemcpyAsync(sl.pf[f].d_text + sent[f], sl.pf[f].h_text + sent[f], (size_t)(len[f] - sent[f]),
                                       hipMemcpyHostToDevice, st));
     XMS_HIP(s, hipEventRecord(sl.ev[1], st));
     XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), st));
     mark_kernel<<<dim3(max_chunks, 2), SB, 0, st>>>(job);
     chunk_scan_kernel<<<2, 1024, 0, st>>>(job);
     fill_kernel<<<dim3(max_chunks, 2), SB, 0, st>>>(job);
-    // a line takes at least one byte of its window: no more records than that
-    const uint64_t bound = std::min<uint64_t>(max_records, std::min(len1, len2) + 1);
-    strip_kernel<<<(uint32_t)((bound + SB - 1) / SB), SB, 0, st>>>(job);
+    // a line takes at least one byte of its window: no more lines than that, no more records than both files have lines
+    const uint64_t line_bound = std::min<uint64_t>(max_records + 1, std::max(len1, len2) + 1);
+    const uint64_t rec_bound = std::min<uint64_t>(max_records, std::min(len1, len2) + 1);
+    const uint64_t parse_bound = skip_repeated ? line_bound : rec_bound;
+    const uint32_t line_blocks = (uint32_t)((parse_bound + SB - 1) / SB), rec_blocks = (uint32_t)((rec_bound + SB - 1) / SB);
+    parse_kernel<<<dim3(line_blocks, 2), SB, 0, st>>>(job);
+    if (skip_repeated) {
+        start_count_kernel<<<dim3(line_blocks, 2), SB, 0, st>>>(job);
+        start_scan_kernel<<<2, 1024, 0, st>>>(job);
+        start_fill_kernel<<<dim3(line_blocks, 2), SB, 0, st>>>(job);
+    }
+    pair_kernel<<<rec_blocks, SB, 0, st>>>(job);
+    if (cigar) {
+        cig_scan_kernel<<<2, 1024, 0, st>>>(job);
+        cig_write_kernel<<<dim3(rec_blocks, 2), SB, 0, st>>>(job);
+    }
     summary_kernel<<<1, 64, 0, st>>>(job);
     XMS_HIP(s, hipGetLastError());
     XMS_HIP(s, hipEventRecord(sl.ev[2], st));
@@ -711,27 +1015,30 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
     out->starved = (int32_t)sum[SUM_STARVED];
     out->mismatch_at = (int64_t)sum[SUM_MISMATCH];
     out->non_ascii = (int32_t)sum[SUM_NONASCII];
+    out->overflow = (int32_t)sum[SUM_OVERFLOW];
     out->n_lines1 = sum[SUM_L1];
     out->n_lines2 = sum[SUM_L2];
     if (n) {
         for (int f = 0; f < 2; ++f) {
-            XMS_HIP(s, hipMemcpyAsync(sl.h_loff[f], sl.d_loff[f], n * 4, hipMemcpyDeviceToHost, st));
-            XMS_HIP(s, hipMemcpyAsync(sl.h_llen[f], sl.d_llen[f], n * 4, hipMemcpyDeviceToHost, st));
-            XMS_HIP(s, hipMemcpyAsync(sl.h_nlen[f], sl.d_nlen[f], n * 4, hipMemcpyDeviceToHost, st));
-            XMS_HIP(s, hipMemcpyAsync(sl.h_lflag[f], sl.d_lflag[f], n, hipMemcpyDeviceToHost, st));
+            PerFile &q = sl.pf[f];
+            XMS_HIP(s, hipMemcpyAsync(q.h_loff, q.d_loff, n * 4, hipMemcpyDeviceToHost, st));
+            XMS_HIP(s, hipMemcpyAsync(q.h_llen, q.d_llen, n * 4, hipMemcpyDeviceToHost, st));
+            XMS_HIP(s, hipMemcpyAsync(q.h_nlen, q.d_nlen, n * 4, hipMemcpyDeviceToHost, st));
+            XMS_HIP(s, hipMemcpyAsync(q.h_lflag, q.d_lflag, n, hipMemcpyDeviceToHost, st));
         }
         XMS_HIP(s, hipStreamSynchronize(st));
     }
     uint64_t n_exc = 0;
     for (int f = 0; f < 2; ++f)
-        for (uint64_t k = 0; k < n; ++k) n_exc += (sl.h_lflag[f][k] & (XMS_LINE_EX_A | XMS_LINE_EX_X)) ? 1 : 0;
+        for (uint64_t k = 0; k < n; ++k) n_exc += (sl.pf[f].h_lflag[k] & (XMS_LINE_EX_A | XMS_LINE_EX_X)) ? 1 : 0;
     out->n_exceptions = n_exc;
-    out->line_off1 = sl.h_loff[0]; out->line_off2 = sl.h_loff[1];
-    out->line_len1 = sl.h_llen[0]; out->line_len2 = sl.h_llen[1];
-    out->norm_len1 = sl.h_nlen[0]; out->norm_len2 = sl.h_nlen[1];
-    out->line_flags1 = sl.h_lflag[0]; out->line_flags2 = sl.h_lflag[1];
+    out->line_off1 = sl.pf[0].h_loff; out->line_off2 = sl.pf[1].h_loff;
+    out->line_len1 = sl.pf[0].h_llen; out->line_len2 = sl.pf[1].h_llen;
+    out->norm_len1 = sl.pf[0].h_nlen; out->norm_len2 = sl.pf[1].h_nlen;
+    out->line_flags1 = sl.pf[0].h_lflag; out->line_flags2 = sl.pf[1].h_lflag;
     (void)hipEventElapsedTime(&out->ms_upload, sl.ev[0], sl.ev[1]);
     (void)hipEventElapsedTime(&out->ms_kernels, sl.ev[1], sl.ev[2]);
+    sl.last_score_mode = score_mode;
     return XM_OK;
 }
 
@@ -740,7 +1047,7 @@ int xm_strip_classify(xm_strip *s, int slot, int mode, uint64_t n_records, int32
 {
     if (!s || slot < 0 || slot >= XMS_SLOTS || !code || !idx || !bin_offsets || !counts) return XM_ERR_INVALID_ARG;
     Slot &sl = s->slot[slot];
-    if (n_records > sl.record_cap) return XM_ERR_INVALID_ARG;
+    if (n_records > sl.record_cap || sl.last_score_mode < 0) return XM_ERR_INVALID_ARG;
     *code = sl.h_code;
     *idx = sl.h_idx;
     std::memset(bin_offsets, 0, 8 * sizeof(uint64_t));
@@ -748,15 +1055,27 @@ int xm_strip_classify(xm_strip *s, int slot, int mode, uint64_t n_records, int32
     if (n_records == 0) return XM_OK;
     XMS_HIP(s, hipSetDevice(s->device));
     hipStream_t st = sl.stream;
-    const int rc = xm_classify_compact_dev(s->ctx, st, mode, n_records, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3], sl.d_bits,
-                                           min_score_floor, sl.d_code, sl.d_bins4, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
+    const bool cigar = sl.last_score_mode == XMS_SCORE_CIGAR;
+    int rc;
+    if (cigar) {
+        XMS_HIP(s, hipMemsetAsync(sl.d_range, 0, sizeof(uint32_t), st));
+        const PerFile &a = sl.pf[0], &b = sl.pf[1];
+        rc = xm_classify_compact_cigar_packed_dev(s->ctx, st, mode, n_records, a.d_nm, a.d_cig_cnt, a.d_cig_tile, a.d_cig_ops, sl.d_col[1],
+                                                  b.d_nm, b.d_cig_cnt, b.d_cig_tile, b.d_cig_ops, sl.d_col[3], sl.d_bits, min_score_floor,
+                                                  sl.d_code, sl.d_bins4, sl.d_range, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
+    } else {
+        rc = xm_classify_compact_dev(s->ctx, st, mode, n_records, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3], sl.d_bits,
+                                     min_score_floor, sl.d_code, sl.d_bins4, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
+    }
     if (rc != XM_OK) {
         s->last_error = xm_last_hip_error(s->ctx);
         return rc;
     }
     XMS_HIP(s, hipMemcpyAsync(sl.h_code, sl.d_code, n_records, hipMemcpyDeviceToHost, st));
     XMS_HIP(s, hipMemcpyAsync(sl.h_off_counts, sl.d_off_counts, 72 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (cigar) XMS_HIP(s, hipMemcpyAsync(sl.h_off_counts + 72, sl.d_range, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     XMS_HIP(s, hipStreamSynchronize(st));
+    if (cigar && *reinterpret_cast<const uint32_t *>(sl.h_off_counts + 72) != 0u) return XM_ERR_RANGE;
     const uint64_t units = sl.h_off_counts[7];
     if (units > n_records) return XM_ERR_HIP;
     if (units) {
@@ -782,6 +1101,30 @@ int xm_strip_columns(xm_strip *s, int slot, uint64_t n_records, int32_t *as1, in
     if (unit_bits)
         XMS_HIP(s, hipMemcpyAsync(unit_bits, sl.d_bits, (n_records + 63) / 64 * 8, hipMemcpyDeviceToHost, sl.stream));
     XMS_HIP(s, hipStreamSynchronize(sl.stream));
+    return XM_OK;
+}
+
+int xm_strip_cigar_columns(xm_strip *s, int slot, int file, uint64_t n_records, int32_t *nm, uint8_t *cig_cnt, uint32_t *cig_tile,
+                           uint32_t *cig_ops, uint64_t ops_capacity, uint64_t *n_ops)
+{
+    if (!s || slot < 0 || slot >= XMS_SLOTS || file < 0 || file > 1 || !n_ops) return XM_ERR_INVALID_ARG;
+    Slot &sl = s->slot[slot];
+    if (n_records > sl.record_cap || sl.last_score_mode != XMS_SCORE_CIGAR) return XM_ERR_INVALID_ARG;
+    *n_ops = 0;
+    if (n_records == 0) return XM_OK;
+    XMS_HIP(s, hipSetDevice(s->device));
+    const PerFile &q = sl.pf[file];
+    const size_t tiles = (size_t)XM_CIG_TILES(n_records) + 1;
+    uint32_t last = 0;
+    XMS_HIP(s, hipMemcpy(&last, q.d_cig_tile + tiles - 1, 4, hipMemcpyDeviceToHost));
+    *n_ops = last;
+    if (nm) XMS_HIP(s, hipMemcpy(nm, q.d_nm, n_records * 4, hipMemcpyDeviceToHost));
+    if (cig_cnt) XMS_HIP(s, hipMemcpy(cig_cnt, q.d_cig_cnt, n_records, hipMemcpyDeviceToHost));
+    if (cig_tile) XMS_HIP(s, hipMemcpy(cig_tile, q.d_cig_tile, tiles * 4, hipMemcpyDeviceToHost));
+    if (cig_ops) {
+        if (ops_capacity < last) return XM_ERR_INVALID_ARG;
+        if (last) XMS_HIP(s, hipMemcpy(cig_ops, q.d_cig_ops, (size_t)last * 4, hipMemcpyDeviceToHost));
+    }
     return XM_OK;
 }
 

@@ -1061,12 +1061,10 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     window = FILE_WINDOW_BYTES
     active = [s for s in sinks if s]
     distinct = len(set(id(s) for s in active)) == len(active)
-    # SAM text, the plain lock-step walk and an AS/XS or AS/ZS plugin: the text itself goes to the GPU and is split there
-    # (include/xenomapper_strip.h) -- the host threads only copy windows into page-locked memory and write the outputs.
-    # XENOMAPPER_GPU_STRIP=0 keeps the host stripper.
+    # SAM text: the text itself goes to the GPU and is split there (include/xenomapper_strip.h) -- the host threads only copy
+    # windows into page-locked memory and write the outputs.  XENOMAPPER_GPU_STRIP=0 keeps the host stripper.
     stripper = None
-    if (not bam and not skip_repeated and not cigar_mode and min_score == min_score
-            and os.environ.get("XENOMAPPER_GPU_STRIP", "1") != "0"):
+    if not bam and min_score == min_score and os.environ.get("XENOMAPPER_GPU_STRIP", "1") != "0":
         stripper = default_stripper()
 
     def parse_next(which, want):
@@ -1086,12 +1084,20 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         parsers[which].pread(sources[f].fileno(), w[1] + at, base + at, piece)
                         stripper.upload(which, f, at, piece)
             with prof("strip"):
-                blk = stripper.run(which, wins[0][2], wins[0][3], wins[1][2], wins[1][3], score_mode, paired, paired, records)
+                blk = stripper.run(which, wins[0][2], wins[0][3], wins[1][2], wins[1][3], score_mode, paired, skip_repeated, paired,
+                                   records)
                 prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_upload
                 prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
             if blk.non_ascii:
                 raise _host.NonAsciiInput()
-            return blk, [stripper.staging(which, f) for f in (0, 1)], [0, 0], [w[3] for w in wins]
+            staged = [stripper.staging(which, f) for f in (0, 1)]
+            if blk.overflow or (cigar_mode and blk.n_exceptions):
+                # more lines than the device tables hold, or a --cigar_scores block with a value the kernels do not vouch for:
+                # this window goes through the host stripper (the text is in the staging buffers already)
+                with prof("parse"):
+                    blk = parsers[which].parse(staged[0], 0, wins[0][2], wins[0][3], staged[1], 0, wins[1][2], wins[1][3],
+                                               score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
+            return blk, staged, [0, 0], [w[3] for w in wins]
         with prof("parse"):
             blk = None
             if bam and all(src.pre_ok for src in sources):
