@@ -1065,16 +1065,24 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     # windows into page-locked memory and write the outputs.  XENOMAPPER_GPU_STRIP=0 keeps the host stripper.
     stripper = None
     if not bam and min_score == min_score and os.environ.get("XENOMAPPER_GPU_STRIP", "1") != "0":
-        stripper = default_stripper()
+        try:
+            stripper = default_stripper()
+        except MemoryError:                                          # no room for its buffers: the host threads strip
+            stripper = None
 
     def parse_next(which, want):
+        nonlocal stripper
         with prof("window"):
             wins = [src.window(want) for src in sources]
         if stripper is not None and max(w[2] for w in wins) <= _ffi.STRIP_MAX_WINDOW:
-            with prof("stage"):
-                # no line of a record is shorter than two bytes with its terminator
-                records = min(FILE_MAX_RECORDS, max(w[2] for w in wins) // 2 + 2)
+            # no line of a record is shorter than two bytes with its terminator
+            records = min(FILE_MAX_RECORDS, max(w[2] for w in wins) // 2 + 2)
+            try:
                 stripper.reserve(which, max(w[2] for w in wins), records)
+            except MemoryError:                                      # page-locked or device memory ran out: the host threads strip
+                stripper = None
+        if stripper is not None and max(w[2] for w in wins) <= _ffi.STRIP_MAX_WINDOW:
+            with prof("stage"):
                 # read(2) into page-locked memory, piece by piece: the upload of one piece hides the read of the next; no page
                 # of the inputs is mapped, and the writer gathers its lines from the staging buffer
                 for f, w in enumerate(wins):
