@@ -307,71 +307,77 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
     const Lines &L = fi ? L1 : L0;
     // the plain walk only ever looks at the lines both files have; the skipping walk needs every line of the window
     const uint32_t lim = job.skip ? min(L.count, job.cap_lines) : min(min(L0.count, L1.count), job.max_records);
-    const uint32_t i = blockIdx.x * SB + threadIdx.x;
-    if (i >= lim) return;
+    const uint8_t *text = f.text;
+    const uint32_t xtag0 = job.xtag0;
+    const bool cigar = job.cigar != 0;
+    const uint32_t as_on = cigar ? 0u : 1u, nm_on = cigar ? 1u : 0u;
+    for (uint32_t i = blockIdx.x * SB + threadIdx.x; i < lim; i += gridDim.x * SB) {
     uint32_t start, n;
     line_span(f, L, i, start, n);
-    const uint8_t *text = f.text;
-    const uint32_t end = start + n, xtag0 = job.xtag0;
-    const bool cigar = job.cigar != 0;
+    const uint32_t end = start + n;
+    // The state of the split, all of it in registers and every update a select: written with branches, each byte costs a dozen
+    // scalar instructions of exec-mask bookkeeping, and the one scalar unit of a CU -- shared by its four SIMDs -- became the
+    // limit of the kernel (229 M scalar against 105 M vector instructions per 2 x 128 MB; 487 us)
     uint32_t n_tok = 0, total = 0, name_off = start, name_len = 0;
-    bool normal = true, in_tok = false, prev_ws = false, ma = false, mx = false, mn = false, have_nm = false;
+    uint32_t normal = 1, in_tok = 0, prev_ws = 0, ma = 0, mx = 0, mn = 0, have_nm = 0;
     uint32_t k = 0, prevc = 0, last_colon = 0;
     uint32_t n_a = 0, n_x = 0, a_b = 0, a_e = 0, x_b = 0, x_e = 0, nm_b = 0, nm_e = 0, cig_b = 0, cig_e = 0;
-    auto end_token = [&](uint32_t p) {
-        if (k == 0u) name_len = p - name_off;
-        if (k == 5u) cig_e = p;
-        if (ma && ++n_a == 1u) { a_b = last_colon; a_e = p; }
-        if (mx && ++n_x == 1u) { x_b = last_colon; x_e = p; }
-        if (mn && !have_nm) { have_nm = true; nm_b = last_colon; nm_e = p; }      // NM[0]: the first match, no duplicate rule
+    auto end_token = [&](uint32_t t_end, uint32_t p) {                 // a field ends in front of p (t_end: 0 / 1)
+        name_len = (t_end & (uint32_t)(k == 0u)) ? p - name_off : name_len;
+        cig_e = (t_end & (uint32_t)(k == 5u)) ? p : cig_e;
+        const uint32_t hit_a = t_end & ma, hit_x = t_end & mx, hit_n = t_end & mn & (have_nm ^ 1u);
+        const uint32_t first_a = hit_a & (uint32_t)(n_a == 0u), first_x = hit_x & (uint32_t)(n_x == 0u);
+        n_a += hit_a;
+        n_x += hit_x;
+        a_b = first_a ? last_colon : a_b;
+        a_e = first_a ? p : a_e;
+        x_b = first_x ? last_colon : x_b;
+        x_e = first_x ? p : x_e;
+        nm_b = hit_n ? last_colon : nm_b;                               // NM[0]: the first match, no duplicate rule
+        nm_e = hit_n ? p : nm_e;
+        have_nm |= hit_n;
     };
-    uint32_t p = start;
-    while (p < end) {
-        const uint32_t wa = p & ~7u;
+    for (uint32_t wa = start & ~7u; wa < end; wa += 8u) {
         const uint64_t w = *reinterpret_cast<const uint64_t *>(text + wa);
-        const uint32_t hi = min(end, wa + 8u);
+        const uint32_t lo = start > wa ? start - wa : 0u, hi = min(end - wa, 8u);
         // a whole word inside one of the eleven mandatory fields without a byte below 0x21 (the input is ASCII, or the
         // result is thrown away): nothing to learn from it but its length
-        if (p == wa && hi == wa + 8u && in_tok && k < 11u &&
-            !((w - 0x2121212121212121ull) & ~w & 0x8080808080808080ull)) {
+        if (lo == 0u && hi == 8u && in_tok && k < 11u && !((w - 0x2121212121212121ull) & ~w & 0x8080808080808080ull)) {
             total += 8u;
-            p += 8u;
             continue;
         }
-        for (; p < hi; ++p) {
-            const uint32_t c = (uint32_t)(w >> (8u * (p - wa))) & 0xFFu;
-            if (is_ws(c)) {
-                if (in_tok) {
-                    end_token(p);
-                    in_tok = false;
-                }
-                // '\t'.join(fields) == line  <=>  exactly one '\t' between fields, nothing in front or behind
-                if (c != 9u || n_tok == 0u || prev_ws) normal = false;
-                prev_ws = true;
-            } else {
-                if (!in_tok) {
-                    in_tok = true;
-                    k = n_tok++;
-                    if (k == 0u) name_off = p;
-                    if (k == 5u) cig_b = p;
-                    last_colon = p;
-                    ma = mx = mn = false;
-                    prevc = 0u;
-                }
-                ++total;
-                if (k >= 11u) {
-                    ma = ma || (!cigar && prevc == 'A' && c == 'S');
-                    mx = mx || (prevc == xtag0 && c == 'S');
-                    mn = mn || (cigar && prevc == 'N' && c == 'M');
-                    if (c == ':') last_colon = p + 1u;
-                }
-                prevc = c;
-                prev_ws = false;
-            }
+#pragma unroll
+        for (uint32_t b = 0; b < 8u; ++b) {
+            const uint32_t c = (uint32_t)(w >> (8u * b)) & 0xFFu, p = wa + b;
+            const uint32_t valid = (uint32_t)(b >= lo) & (uint32_t)(b < hi);
+            const uint32_t ws = is_ws(c) ? 1u : 0u;
+            end_token(valid & ws & in_tok, p);
+            // '\t'.join(fields) == line  <=>  exactly one '\t' between fields, nothing in front or behind
+            normal &= (valid & ws & ((uint32_t)(c != 9u) | (uint32_t)(n_tok == 0u) | prev_ws)) ^ 1u;
+            const uint32_t t_start = valid & (ws ^ 1u) & (in_tok ^ 1u);      // a field starts at p
+            k = t_start ? n_tok : k;
+            name_off = (t_start & (uint32_t)(n_tok == 0u)) ? p : name_off;
+            cig_b = (t_start & (uint32_t)(n_tok == 5u)) ? p : cig_b;
+            last_colon = t_start ? p : last_colon;
+            ma = t_start ? 0u : ma;
+            mx = t_start ? 0u : mx;
+            mn = t_start ? 0u : mn;
+            prevc = t_start ? 0u : prevc;
+            n_tok += t_start;
+            const uint32_t nonws = valid & (ws ^ 1u);
+            total += nonws;
+            const uint32_t tz = nonws & (uint32_t)(k >= 11u);                 // inside an optional field
+            ma |= tz & as_on & (uint32_t)(prevc == 'A') & (uint32_t)(c == 'S');
+            mx |= tz & (uint32_t)(prevc == xtag0) & (uint32_t)(c == 'S');
+            mn |= tz & nm_on & (uint32_t)(prevc == 'N') & (uint32_t)(c == 'M');
+            last_colon = (tz & (uint32_t)(c == ':')) ? p + 1u : last_colon;
+            prevc = nonws ? c : prevc;
+            in_tok = valid ? (ws ^ 1u) : in_tok;
+            prev_ws = valid ? ws : prev_ws;
         }
     }
-    if (in_tok) end_token(end);
-    if (prev_ws) normal = false;
+    end_token(in_tok, end);
+    normal &= prev_ws ^ 1u;
     int32_t a = ABSENT, x = ABSENT, nm = ABSENT;
     uint32_t ex_a = 0, ex_x = 0, n_ops = 0;
     if (n_a >= 1u && !plain_int(text, a_b, a_e, a)) { a = ABSENT; ex_a = 1u; }
@@ -401,12 +407,21 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
         f.r_cig_off[i] = cig_b;
         f.r_cig_len[i] = n_ops ? cig_e - cig_b : 0u;
     }
+    }
 }
 
+// eight independent byte loads per side at a time (a loop with an exit after every byte waits a memory latency per byte)
 __device__ bool same_bytes(const uint8_t *a, const uint8_t *b, uint32_t n)
 {
-    for (uint32_t i = 0; i < n; ++i)
-        if (a[i] != b[i]) return false;
+    for (uint32_t i = 0; i < n; i += 8u) {
+        uint32_t diff = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t q = min(i + j, n - 1u);                   // past the end: the last byte again
+            diff |= (uint32_t)(a[q] ^ b[q]);
+        }
+        if (diff) return false;
+    }
     return true;
 }
 
@@ -432,17 +447,19 @@ __global__ void __launch_bounds__(SB) start_count_kernel(const Job job)
     const FileView &f = job.f[fi];
     const Lines L = lines_of(f, job.state[ST_NTERM0 + fi], job.cap_lines);
     const uint32_t lim = min(L.count, job.cap_lines);
-    if (blockIdx.x * SB >= lim) return;
     __shared__ uint32_t red[SB / 64];
-    const uint32_t i = blockIdx.x * SB + threadIdx.x;
-    const bool st = i < lim && is_run_start(f, i);
-    const uint32_t c = (uint32_t)__popcll(__ballot(st));
-    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < SB / 64; ++w) t += red[w];
-        f.blk_cnt[blockIdx.x] = t;
+    for (uint32_t blk = blockIdx.x; blk * SB < lim; blk += gridDim.x) {
+        const uint32_t i = blk * SB + threadIdx.x;
+        const bool st = i < lim && is_run_start(f, i);
+        const uint32_t c = (uint32_t)__popcll(__ballot(st));
+        if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < SB / 64; ++w) t += red[w];
+            f.blk_cnt[blk] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -479,17 +496,19 @@ __global__ void __launch_bounds__(SB) start_fill_kernel(const Job job)
     const FileView &f = job.f[fi];
     const Lines L = lines_of(f, job.state[ST_NTERM0 + fi], job.cap_lines);
     const uint32_t lim = min(L.count, job.cap_lines);
-    if (blockIdx.x * SB >= lim) return;
     __shared__ uint32_t ws[SB / 64];
-    const uint32_t i = blockIdx.x * SB + threadIdx.x;
-    const bool st = i < lim && is_run_start(f, i);
-    const uint64_t m = __ballot(st);
-    const uint32_t lane = threadIdx.x & 63u;
-    if (lane == 0u) ws[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t wb = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += ws[w];
-    if (st) f.sel[f.blk_base[blockIdx.x] + wb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    for (uint32_t blk = blockIdx.x; blk * SB < lim; blk += gridDim.x) {
+        const uint32_t i = blk * SB + threadIdx.x;
+        const bool st = i < lim && is_run_start(f, i);
+        const uint64_t m = __ballot(st);
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane == 0u) ws[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t wb = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += ws[w];
+        if (st) f.sel[f.blk_base[blk] + wb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+    }
 }
 
 // what the walk may pair: records (plain walk: lines) of each file, and the most the block may hold
@@ -516,8 +535,7 @@ __device__ __forceinline__ Walk walk_of(const Job &job)
 __global__ void __launch_bounds__(SB) pair_kernel(const Job job)
 {
     const Walk W = walk_of(job);
-    const uint32_t k = blockIdx.x * SB + threadIdx.x;
-    if ((k & ~63u) >= W.lim) return;                    // the whole wave is past the end (wave-uniform)
+    for (uint32_t k = blockIdx.x * SB + threadIdx.x; (k & ~63u) < W.lim; k += gridDim.x * SB) {      // wave-uniform bound
     bool unit = false;
     if (k < W.lim) {
         uint32_t i[2];
@@ -553,6 +571,7 @@ __global__ void __launch_bounds__(SB) pair_kernel(const Job job)
     }
     const uint64_t word = __ballot(unit);
     if ((threadIdx.x & 63u) == 0u) job.unit_bits[k >> 6] = word;
+    }
 }
 
 // ---- S7: the packed CIGAR columns of include/xenomapper_hip.h ------------------------------------------------------
@@ -592,10 +611,9 @@ __global__ void __launch_bounds__(SB) cig_write_kernel(const Job job)
     const int fi = (int)blockIdx.y;
     const FileView &f = job.f[fi];
     const Walk W = walk_of(job);
-    const uint32_t k = blockIdx.x * SB + threadIdx.x;
-    if (k >= W.lim) return;
     const uint32_t total = f.cpos[W.lim];
     if (total > f.ops_cap) return;                      // cannot happen (an operation takes two bytes of text); S8 reports it
+    for (uint32_t k = blockIdx.x * SB + threadIdx.x; k < W.lim; k += gridDim.x * SB) {
     const uint32_t i = job.skip ? f.sel[k] : k;
     const uint32_t pos = f.cpos[k], n_ops = f.r_nops[i];
     if (n_ops) {
@@ -607,6 +625,7 @@ __global__ void __launch_bounds__(SB) cig_write_kernel(const Job job)
     f.cig_cnt[k] = (uint8_t)min(n_ops, 255u);
     if ((k & 255u) == 0u) f.cig_tile[k >> 8] = pos;
     if (k + 1u == W.lim) f.cig_tile[(W.lim + 255u) >> 8] = total;
+    }
 }
 
 // ---- S8: the outcome of the walk, as xm_sam.cpp parse_common reports it ------------------------------------------
@@ -985,7 +1004,10 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
     const uint64_t line_bound = std::min<uint64_t>(max_records + 1, std::max(len1, len2) + 1);
     const uint64_t rec_bound = std::min<uint64_t>(max_records, std::min(len1, len2) + 1);
     const uint64_t parse_bound = skip_repeated ? line_bound : rec_bound;
-    const uint32_t line_blocks = (uint32_t)((parse_bound + SB - 1) / SB), rec_blocks = (uint32_t)((rec_bound + SB - 1) / SB);
+    // the kernels stride over their lines / records: a grid the size of the bound would mostly be waves with nothing to do
+    // (the bound is what a window could hold at two bytes a line; a 128 MB window of 2 x 150 bp reads holds 330 k lines)
+    const uint32_t line_blocks = (uint32_t)std::min<uint64_t>((parse_bound + SB - 1) / SB, 2048),
+                   rec_blocks = (uint32_t)std::min<uint64_t>((rec_bound + SB - 1) / SB, 2048);
     parse_kernel<<<dim3(line_blocks, 2), SB, 0, st>>>(job);
     if (skip_repeated) {
         start_count_kernel<<<dim3(line_blocks, 2), SB, 0, st>>>(job);
