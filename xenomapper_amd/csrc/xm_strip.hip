@@ -296,6 +296,21 @@ __device__ uint32_t cigar_ops(const uint8_t *text, uint32_t b, uint32_t e, uint3
     return n;
 }
 
+#ifndef XMS_PARSE_STEP
+#define XMS_PARSE_STEP 32
+#endif
+constexpr uint32_t STEP = XMS_PARSE_STEP;                 // bytes of a line per load step of S4 (the window is padded by as much)
+
+__device__ __forceinline__ void load_step(const uint8_t *at, uint64_t (&ww)[STEP / 8u])
+{
+#pragma unroll
+    for (uint32_t q = 0; q < STEP / 16u; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(at + 16u * q);
+        ww[2u * q] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        ww[2u * q + 1u] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+}
+
 // ---- S4: one lane per line.  fields = line.split() (:103-104), the tag search of get_tag over fields[11:] (:186-190), in
 // CIGAR mode the first NM field and the operations of fields[5] (:247-251) ------------------------------------------
 __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
@@ -315,16 +330,93 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
     uint32_t start, n;
     line_span(f, L, i, start, n);
     const uint32_t end = start + n;
-    // The state of the split, all of it in registers and every update a select: written with branches, each byte costs a dozen
-    // scalar instructions of exec-mask bookkeeping, and the one scalar unit of a CU -- shared by its four SIMDs -- became the
-    // limit of the kernel (229 M scalar against 105 M vector instructions per 2 x 128 MB; 487 us)
-    uint32_t n_tok = 0, total = 0, name_off = start, name_len = 0;
-    uint32_t normal = 1, in_tok = 0, prev_ws = 0, ma = 0, mx = 0, mn = 0, have_nm = 0;
-    uint32_t k = 0, prevc = 0, last_colon = 0;
-    uint32_t n_a = 0, n_x = 0, a_b = 0, a_e = 0, x_b = 0, x_e = 0, nm_b = 0, nm_e = 0, cig_b = 0, cig_e = 0;
-    auto end_token = [&](uint32_t t_end, uint32_t p) {                 // a field ends in front of p (t_end: 0 / 1)
-        name_len = (t_end & (uint32_t)(k == 0u)) ? p - name_off : name_len;
-        cig_e = (t_end & (uint32_t)(k == 5u)) ? p : cig_e;
+    // Phase 1 -- the eleven mandatory fields, a word at a time: the separators of 8 bytes as one 8-bit mask (SWAR range
+    // tests, the high bits gathered by a multiply), field starts and ends by shifts of that mask, counts by popcount.  Only
+    // the name (field 0), the CIGAR field (5), the field count, the joined length and the "already '\t'.join(fields)"
+    // property are wanted from them.  Phase 2 -- the optional fields, a byte at a time, every update a select: written with
+    // branches, each byte cost a dozen scalar instructions of exec-mask bookkeeping and the one scalar unit of a CU -- shared
+    // by its four SIMDs -- was the limit of the kernel (229 M scalar against 105 M vector instructions per 2 x 128 MB, 487 us).
+    uint32_t n_tok = 0, n_ends = 0, total = 0, name_off = start, name_len = 0, cig_b = 0, cig_e = 0;
+    uint32_t normal = 1, in_tok = 0, prev_ws = 0;
+    uint32_t p2 = end;                                                 // where the optional fields begin (none: end)
+    auto nth_set = [](uint32_t m, uint32_t nth) -> uint32_t {          // position of set bit number nth (< 6) of an 8-bit mask
+#pragma unroll
+        for (uint32_t j = 0; j < 5u; ++j) m = j < nth ? (m & (m - 1u)) : m;
+        return (uint32_t)__ffs((int)m) - 1u;
+    };
+    // STEP bytes per load step (16-byte loads, all in flight together): a word per step left the kernel waiting for memory --
+    // every step's load touches 64 different cache lines, one per lane
+    auto phase1_word = [&](uint32_t wa, uint64_t w) -> bool {          // true: the optional fields begin in this word
+        const uint32_t lo = start > wa ? start - wa : 0u, hi = min(end - wa, 8u);
+        const uint64_t H = 0x8080808080808080ull, O = 0x0101010101010101ull;
+        // a whole word inside a field without a byte below 0x21 (the input is ASCII, or the result is thrown away): nothing
+        // to learn from it but its length
+        if (lo == 0u && hi == 8u && in_tok && !((w - 0x21u * O) & ~w & H)) {
+            total += 8u;
+            return false;
+        }
+        // byte in [9, 13] or [28, 32]: Python's str.split() separators; byte == 9: the one '\t'.join() puts back
+        const uint64_t t = w | H;                                       // every byte >= 0x80: the subtractions do not borrow
+        const uint64_t ge9 = (t - 9u * O) & H, ge10 = (t - 10u * O) & H, ge14 = (t - 14u * O) & H, ge28 = (t - 28u * O) & H,
+                       ge33 = (t - 33u * O) & H;
+        auto pack = [](uint64_t m) -> uint32_t {                        // the high bit of every byte -> one bit per byte
+            const uint32_t l = ((((uint32_t)m >> 7) * 0x01020408u) >> 24) & 0xFu;
+            const uint32_t h = ((((uint32_t)(m >> 32) >> 7) * 0x01020408u) >> 24) & 0xFu;
+            return l | (h << 4);
+        };
+        uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        uint32_t wsm = pack((ge9 & ~ge14) | (ge28 & ~ge33)) & vm;
+        uint32_t nonws = ~wsm & vm;
+        uint32_t starts = nonws & ~((nonws << 1) | in_tok);
+        // the twelfth field starts in this word: phase 1 stops in front of it
+        const uint32_t cnt = (uint32_t)__popc(starts);
+        uint32_t stop = 8u;
+        if (n_tok + cnt > 11u) {
+            stop = nth_set(starts, 11u - n_tok);
+            p2 = wa + stop;
+            vm &= (1u << stop) - 1u;
+            wsm &= vm;
+            nonws &= vm;
+            starts &= vm;
+        }
+        if (vm) {
+            const uint32_t tabm = pack(ge9 & ~ge10) & vm;
+            const uint32_t pred = (nonws << 1) | in_tok;                // bit b: the byte in front of b is part of a field
+            const uint32_t ends = wsm & pred;                           // a field ends in front of these separators
+            // '\t'.join(fields) == line  <=>  exactly one '\t' between fields, nothing in front or behind
+            uint32_t bad = (wsm & ~tabm) | (wsm & ((wsm << 1) | prev_ws));
+            if (n_tok == 0u) bad |= wsm & ((starts ? (1u << ((uint32_t)__ffs((int)starts) - 1u)) : 256u) - 1u);
+            normal &= (uint32_t)(bad == 0u);
+            const uint32_t n_st = (uint32_t)__popc(starts), n_en = (uint32_t)__popc(ends);
+            if (n_tok == 0u && starts) name_off = wa + (uint32_t)__ffs((int)starts) - 1u;
+            if (n_tok <= 5u && n_tok + n_st > 5u) cig_b = wa + nth_set(starts, 5u - n_tok);
+            if (n_ends == 0u && ends) name_len = wa + (uint32_t)__ffs((int)ends) - 1u - name_off;
+            if (n_ends <= 5u && n_ends + n_en > 5u) cig_e = wa + nth_set(ends, 5u - n_ends);
+            n_tok += n_st;
+            n_ends += n_en;
+            total += (uint32_t)__popc(nonws);
+            const uint32_t last = 31u - (uint32_t)__clz((int)vm);
+            in_tok = (nonws >> last) & 1u;
+            prev_ws = (wsm >> last) & 1u;
+        }
+        return stop < 8u;
+    };
+    {
+        bool done = false;
+        for (uint32_t base = start & ~(STEP - 1u); base < end && !done; base += STEP) {
+            uint64_t ww[STEP / 8u];
+            load_step(text + base, ww);
+#pragma unroll
+            for (uint32_t j = 0; j < STEP / 8u; ++j) {
+                const uint32_t wa = base + 8u * j;
+                if (!done && wa + 8u > start && wa < end) done = phase1_word(wa, ww[j]);
+            }
+        }
+    }
+    // Phase 2: fields[11:], where the tags are
+    uint32_t ma = 0, mx = 0, mn = 0, have_nm = 0, prevc = 0, last_colon = 0;
+    uint32_t n_a = 0, n_x = 0, a_b = 0, a_e = 0, x_b = 0, x_e = 0, nm_b = 0, nm_e = 0;
+    auto end_token = [&](uint32_t t_end, uint32_t p) {                 // an optional field ends in front of p (t_end: 0 / 1)
         const uint32_t hit_a = t_end & ma, hit_x = t_end & mx, hit_n = t_end & mn & (have_nm ^ 1u);
         const uint32_t first_a = hit_a & (uint32_t)(n_a == 0u), first_x = hit_x & (uint32_t)(n_x == 0u);
         n_a += hit_a;
@@ -337,27 +429,16 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
         nm_e = hit_n ? p : nm_e;
         have_nm |= hit_n;
     };
-    for (uint32_t wa = start & ~7u; wa < end; wa += 8u) {
-        const uint64_t w = *reinterpret_cast<const uint64_t *>(text + wa);
-        const uint32_t lo = start > wa ? start - wa : 0u, hi = min(end - wa, 8u);
-        // a whole word inside one of the eleven mandatory fields without a byte below 0x21 (the input is ASCII, or the
-        // result is thrown away): nothing to learn from it but its length
-        if (lo == 0u && hi == 8u && in_tok && k < 11u && !((w - 0x2121212121212121ull) & ~w & 0x8080808080808080ull)) {
-            total += 8u;
-            continue;
-        }
+    auto phase2_word = [&](uint32_t wa, uint64_t w) {
+        const uint32_t lo = p2 > wa ? p2 - wa : 0u, hi = min(end - wa, 8u);
 #pragma unroll
         for (uint32_t b = 0; b < 8u; ++b) {
             const uint32_t c = (uint32_t)(w >> (8u * b)) & 0xFFu, p = wa + b;
             const uint32_t valid = (uint32_t)(b >= lo) & (uint32_t)(b < hi);
             const uint32_t ws = is_ws(c) ? 1u : 0u;
             end_token(valid & ws & in_tok, p);
-            // '\t'.join(fields) == line  <=>  exactly one '\t' between fields, nothing in front or behind
-            normal &= (valid & ws & ((uint32_t)(c != 9u) | (uint32_t)(n_tok == 0u) | prev_ws)) ^ 1u;
+            normal &= (valid & ws & ((uint32_t)(c != 9u) | prev_ws)) ^ 1u;
             const uint32_t t_start = valid & (ws ^ 1u) & (in_tok ^ 1u);      // a field starts at p
-            k = t_start ? n_tok : k;
-            name_off = (t_start & (uint32_t)(n_tok == 0u)) ? p : name_off;
-            cig_b = (t_start & (uint32_t)(n_tok == 5u)) ? p : cig_b;
             last_colon = t_start ? p : last_colon;
             ma = t_start ? 0u : ma;
             mx = t_start ? 0u : mx;
@@ -366,17 +447,31 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
             n_tok += t_start;
             const uint32_t nonws = valid & (ws ^ 1u);
             total += nonws;
-            const uint32_t tz = nonws & (uint32_t)(k >= 11u);                 // inside an optional field
-            ma |= tz & as_on & (uint32_t)(prevc == 'A') & (uint32_t)(c == 'S');
-            mx |= tz & (uint32_t)(prevc == xtag0) & (uint32_t)(c == 'S');
-            mn |= tz & nm_on & (uint32_t)(prevc == 'N') & (uint32_t)(c == 'M');
-            last_colon = (tz & (uint32_t)(c == ':')) ? p + 1u : last_colon;
+            ma |= nonws & as_on & (uint32_t)(prevc == 'A') & (uint32_t)(c == 'S');
+            mx |= nonws & (uint32_t)(prevc == xtag0) & (uint32_t)(c == 'S');
+            mn |= nonws & nm_on & (uint32_t)(prevc == 'N') & (uint32_t)(c == 'M');
+            last_colon = (nonws & (uint32_t)(c == ':')) ? p + 1u : last_colon;
             prevc = nonws ? c : prevc;
             in_tok = valid ? (ws ^ 1u) : in_tok;
             prev_ws = valid ? ws : prev_ws;
         }
+    };
+    for (uint32_t base = p2 & ~(STEP - 1u); base < end; base += STEP) {
+        uint64_t ww[STEP / 8u];
+        load_step(text + base, ww);
+#pragma unroll
+        for (uint32_t j = 0; j < STEP / 8u; ++j) {
+            const uint32_t wa = base + 8u * j;
+            if (wa + 8u > p2 && wa < end) phase2_word(wa, ww[j]);
+        }
     }
-    end_token(in_tok, end);
+    // the line ends: so does the field that is open
+    if (p2 < end) {
+        end_token(in_tok, end);
+    } else if (in_tok) {
+        if (n_ends == 0u) name_len = end - name_off;
+        if (n_ends == 5u) cig_e = end;
+    }
     normal &= prev_ws ^ 1u;
     int32_t a = ABSENT, x = ABSENT, nm = ABSENT;
     uint32_t ex_a = 0, ex_x = 0, n_ops = 0;
@@ -794,7 +889,7 @@ int grow_window(xm_strip *s, Slot &sl, uint64_t bytes)
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
         XMS_TRY(halloc(s, q.h_text, (size_t)cap));
-        XMS_TRY(dalloc(s, q.d_text, (size_t)cap + 64));               // S1 / S4 read whole 16- / 8-byte words
+        XMS_TRY(dalloc(s, q.d_text, (size_t)cap + 256));              // S1 / S4 read whole 16-byte words / load steps
         XMS_TRY(dalloc(s, q.d_mask, (size_t)cap / 16 + 16));
         XMS_TRY(dalloc(s, q.d_chunk_cnt, n_chunks));
         XMS_TRY(dalloc(s, q.d_chunk_base, n_chunks));
