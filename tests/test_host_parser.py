@@ -745,3 +745,44 @@ def test_bam_line_descriptions_over_many_batches_and_pending_lines(cap, tmp_path
         lines += pre.shape[0]
     r.close()
     assert b"".join(got) == want and lines == want.count(b"\n")
+
+
+def test_pread_and_copy_by_the_parser_threads_and_adopted_line_tables(tmp_path):
+    """The host half of the GPU stripper's file path: windows read (or copied) into a buffer by the parser's threads, and
+    xmh_emit on line tables that were made elsewhere (here: by another parser) writes what that parser writes itself."""
+    import ctypes
+    from xenomapper_amd import _host
+    rng = np.random.default_rng(4)
+    blob = rng.integers(0, 256, size=(5 << 20) + 12345, dtype=np.uint8)
+    path = tmp_path / "blob.bin"
+    path.write_bytes(blob.tobytes())
+    p = _host.Parser(4)
+    dst = np.zeros(blob.shape[0], dtype=np.uint8)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        p.pread(fd, 1000, dst.ctypes.data, blob.shape[0] - 1000)
+        assert np.array_equal(dst[:blob.shape[0] - 1000], blob[1000:])
+        with pytest.raises(OSError):
+            p.pread(fd, 1000, dst.ctypes.data, blob.shape[0])            # the file ends first
+    finally:
+        os.close(fd)
+    dst[:] = 0
+    p.copy(dst.ctypes.data + 7, blob, 11, 3 << 20)
+    assert np.array_equal(dst[7:7 + (3 << 20)], blob[11:11 + (3 << 20)]) and not dst[:7].any()
+    # adopted tables
+    lines = ["r%d\t0\tc\t1\t9\t4M\t*\t0\t0\tACGT\tIIII\tAS:i:%d" % (i // 2, -i) for i in range(400)]
+    lines[7] = lines[7].replace("\t", " ", 2)                               # one line that needs normalising
+    text = ("\n".join(lines) + "\n").encode()
+    raw = np.frombuffer(text, dtype=np.uint8)
+    blk = p.parse(raw, 0, len(raw), True, raw, 0, len(raw), True, 0, True, False, False, 1 << 20)
+    idx = np.arange(1, blk.n, 2, dtype=np.uint32)
+    want = [bytes(p.emit(True, b, idx)) for b in (0, 1, 4)]
+    q = _host.Parser(2)
+    u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
+    norm = [np.array([len("\t".join(l.split())) for l in lines], dtype=np.uint32)] * 2
+    flags = [np.array([1 if "\t".join(l.split()) == l else 0 for l in lines], dtype=np.uint8)] * 2
+    keep = [u32(blk.line_off[0]), u32(blk.line_len[0]), norm[0], flags[0], u32(blk.line_off[1]), u32(blk.line_len[1]), norm[1], flags[1]]
+    q.adopt_lines(raw, 0, raw, 0, blk.n, [a.ctypes.data for a in keep])
+    assert [bytes(q.emit(True, b, idx)) for b in (0, 1, 4)] == want
+    p.close()
+    q.close()
