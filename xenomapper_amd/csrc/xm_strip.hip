@@ -9,7 +9,7 @@
 // All kernels are bound by reading the text from HBM, and the text arrives over PCIe at a hundredth of that rate -- which
 // is what bounds the step:
 //   S1 mark_kernel    16 bytes per lane: terminator bits of '\n' / '\r\n' / '\r' (Python's universal newlines) as one 16-bit
-//                     mask per 16 bytes, terminators per 64 KiB chunk, non-ASCII test
+//                     mask per 16 bytes (SWAR, no branch), terminators per 64 KiB chunk, non-ASCII test
 //   S2 chunk_scan     exclusive scan of the chunk counts (one workgroup per file)
 //   S3 fill_kernel    reads the masks (1/8 of the text): line i ends at lend[i], line i + 1 starts at lnext[i]
 //   S4 parse_kernel   one lane per LINE of each file: split by str.split()'s separators in aligned 8-byte words (words
@@ -85,12 +85,6 @@ struct Job {
 // Python's str.split() separators in the ASCII range: \t \n \v \f \r, FS GS RS US, space
 __device__ __forceinline__ bool is_ws(uint32_t c) { return c == 32u || (c - 9u) <= 4u || (c - 28u) <= 3u; }
 
-__device__ __forceinline__ uint32_t has_byte(uint32_t w, uint32_t c)
-{
-    const uint32_t x = w ^ (c * 0x01010101u);
-    return (x - 0x01010101u) & ~x & 0x80808080u;
-}
-
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -121,22 +115,24 @@ __global__ void __launch_bounds__(SB) mark_kernel(const Job job)
         const uint32_t p0 = g * 16u;
         const uint4 v = *reinterpret_cast<const uint4 *>(f.text + p0);       // the buffer is readable past len (padding)
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        const bool full = p0 + 16u <= f.len;
-        uint32_t any = 0;
-        for (int q = 0; q < 4; ++q) any |= has_byte(w[q], 10u) | has_byte(w[q], 13u);
-        if (full) hi |= v.x | v.y | v.z | v.w;
-        uint32_t m = 0;
-        if (any || !full) {
-            uint32_t prev = p0 ? (uint32_t)f.text[p0 - 1] : 0u;
-            for (uint32_t i = 0; i < 16; ++i) {
-                const uint32_t c = (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu, p = p0 + i;
-                if (p < f.len) hi |= c;
-                // '\r' always ends a line (alone or as the first half of "\r\n"); '\n' unless it is that second half
-                const bool term = c == 13u || (c == 10u && prev != 13u);
-                if (term && p < f.usable) m |= 1u << i;
-                prev = c;
-            }
+        // bytes equal to '\r' / '\n' as 16-bit masks, without a branch (nearly every wave holds a line end somewhere, so a
+        // byte loop behind a test ran for all of them): exact zero-byte test of w ^ c, high bits gathered by a multiply
+        uint32_t crm = 0, lfm = 0, him = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t xr = w[q] ^ 0x0D0D0D0Du, xn = w[q] ^ 0x0A0A0A0Au;
+            const uint32_t zr = ~(((xr & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xr | 0x7F7F7F7Fu);      // 0x80 where the byte is '\r'
+            const uint32_t zn = ~(((xn & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xn | 0x7F7F7F7Fu);
+            crm |= ((((zr >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * q);
+            lfm |= ((((zn >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * q);
+            him |= (((((w[q] & 0x80808080u) >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * q);
         }
+        const uint32_t in_len = p0 + 16u <= f.len ? 0xFFFFu : (1u << (f.len - p0)) - 1u;           // p < len (p0 < len here)
+        const uint32_t in_use = p0 + 16u <= f.usable ? 0xFFFFu : (p0 < f.usable ? (1u << (f.usable - p0)) - 1u : 0u);
+        hi |= (him & in_len) ? 0x80u : 0u;
+        // '\r' always ends a line (alone or as the first half of "\r\n"); '\n' unless it is that second half
+        const uint32_t prev_cr = ((lfm & 1u) && p0 && f.text[p0 - 1u] == 13u) ? 1u : 0u;      // the byte in front of the group
+        const uint32_t m = (crm | (lfm & ~((crm << 1) | prev_cr))) & in_use;
         f.mask16[g] = (uint16_t)m;
         cnt += (uint32_t)__popc(m);
     }
