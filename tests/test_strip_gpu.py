@@ -234,3 +234,46 @@ def test_cigar_plugin_columns_and_the_fused_pass_on_them(rig):
     text = b"\n".join(lines) + b"\n"
     got, want = compare(s, p, text, text, True, True, 2, False, False, 64)
     assert sorted(k for _, _, k in got.exc) == [1, 1, 4, 4]
+
+
+_ALPHA = "ASXZNM:i0123456789-+.xyIDHP=*"
+_TOKEN = st.text(alphabet=_ALPHA, min_size=1, max_size=45)
+_SEP = st.sampled_from(["\t", "\t", "\t", " ", "\t\t", " \t", "\x0b", "\x1c\x1f", "   "])
+
+
+@st.composite
+def _long_lines(draw):
+    """A few lines of many fields of random lengths, so that field boundaries fall at every position of the 8-byte words and
+    32-byte load steps the parse kernel works in, with the odd separator, leading / trailing white space, tags in front of
+    the eleventh field and lines that stop short of it."""
+    n = draw(st.integers(1, 6))
+    names = [draw(st.text(alphabet="abcdefgh/._0123", min_size=1, max_size=30)) for _ in range(n)]
+    files = []
+    for _f in (0, 1):
+        lines = []
+        for nm in names:
+            toks = [nm] + [draw(_TOKEN) for _ in range(draw(st.integers(0, 18)))]
+            if len(toks) > 5 and draw(st.booleans()):
+                toks[5] = draw(st.sampled_from(["10M", "3S7M2I", "5M1D5M", "*", "12", "M", "1M" * 130]))
+            if len(toks) > 11 and draw(st.booleans()):
+                toks[draw(st.integers(11, len(toks) - 1))] = draw(st.sampled_from(["AS:i:-7", "XS:i:12", "ZS:i:0", "NM:i:3", "NM:i:x", "AS:f:1.5"]))
+            seps = [draw(_SEP) for _ in toks]
+            text = "".join(s + t for s, t in zip([""] + seps[1:], toks))
+            if draw(st.integers(0, 7)) == 0:
+                text = draw(_SEP) + text
+            if draw(st.integers(0, 7)) == 0:
+                text = text + draw(_SEP)
+            lines.append(text)
+        files.append(lines)
+    nl = draw(st.sampled_from(["\n", "\r\n", "\r"]))
+    pad = draw(st.integers(0, 31))                     # shifts every line against the word and load-step grid
+    head = "p" * pad + nl if pad else ""
+    return [(head + nl.join(lines) + nl).encode("ascii") for lines in files], bool(pad)
+
+
+@settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "300")), deadline=None, suppress_health_check=list(HealthCheck))
+@given(data=_long_lines(), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans(), skip=st.booleans())
+def test_long_random_fields_at_every_alignment(rig, data, score_mode, paired, skip):
+    _ctx, s, p = rig
+    (b1, b2), _padded = data
+    compare(s, p, b1, b2, True, True, score_mode, paired, False, 1 << 12, skip=skip)
