@@ -277,3 +277,17 @@ def test_long_random_fields_at_every_alignment(rig, data, score_mode, paired, sk
     _ctx, s, p = rig
     (b1, b2), _padded = data
     compare(s, p, b1, b2, True, True, score_mode, paired, False, 1 << 12, skip=skip)
+
+
+def test_whole_file_path_with_either_stripper_writes_the_same_bytes(tmp_path):
+    """tools/check_strip_scale.py at test size: 150 k units per mode (paired liberal, conservative + ZS, single-end with
+    the skipping walk, --cigar_scores) through classify_sam_files with the GPU stripper and with the host stripper."""
+    import json
+    import subprocess
+    import sys
+    from tests import helpers as H
+    out = subprocess.run([sys.executable, os.path.join(H.REPO, "tools", "check_strip_scale.py"), "--pairs", "150000", "--dir", str(tmp_path)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(rep) == 4 and all(v["identical"] and v["units"] == 150000 for v in rep.values())
