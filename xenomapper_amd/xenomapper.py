@@ -672,6 +672,7 @@ def _write_bytes(sink, data):
 
 
 MMAP_EMIT_MIN_BYTES = 1 << 20        # below this one buffered write is cheaper than mapping the file
+AHEAD_FACTOR = int(os.environ.get("XENOMAPPER_AHEAD", "2"))      # output files are kept this many calls' worth of bytes longer than their content
 
 
 _EMIT_CLOCK = {}            # seconds inside _emit_into_file by step, since the run began (shown with the phases of the run)
@@ -803,7 +804,7 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
         if state is None:
             state = ahead[id(sink)] = _AheadFile(fd2, size)
         state.size = size
-        state.extend_later(ahead_pool, pos + need + 2 * need)
+        state.extend_later(ahead_pool, pos + need + AHEAD_FACTOR * need)
     elif state is None:
         os.close(fd2)
     return True
