@@ -82,9 +82,6 @@ struct Job {
     uint64_t *unit_bits;
 };
 
-// Python's str.split() separators in the ASCII range: \t \n \v \f \r, FS GS RS US, space
-__device__ __forceinline__ bool is_ws(uint32_t c) { return c == 32u || (c - 9u) <= 4u || (c - 28u) <= 3u; }
-
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -326,148 +323,135 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
     uint32_t start, n;
     line_span(f, L, i, start, n);
     const uint32_t end = start + n;
-    // Phase 1 -- the eleven mandatory fields, a word at a time: the separators of 8 bytes as one 8-bit mask (SWAR range
-    // tests, the high bits gathered by a multiply), field starts and ends by shifts of that mask, counts by popcount.  Only
-    // the name (field 0), the CIGAR field (5), the field count, the joined length and the "already '\t'.join(fields)"
-    // property are wanted from them.  Phase 2 -- the optional fields, a byte at a time, every update a select: written with
-    // branches, each byte cost a dozen scalar instructions of exec-mask bookkeeping and the one scalar unit of a CU -- shared
-    // by its four SIMDs -- was the limit of the kernel (229 M scalar against 105 M vector instructions per 2 x 128 MB, 487 us).
+    // A word at a time: the separators of 8 bytes as one 8-bit mask (SWAR range tests, the high bits gathered by a multiply),
+    // field starts and ends by shifts of that mask, counts by popcount; the bytes 'A' 'S' 'X'/'Z' 'N' 'M' ':' as masks too, so
+    // that "AS" / "XS" / "NM" inside an optional field are bit tests and the only loop left is over the fields that END in the
+    // word.  History, per 2 x 128 MB: a byte at a time with branches 487 us (the CU's one scalar unit, shared by its four SIMDs,
+    // drowned in exec-mask bookkeeping: 229 M scalar against 105 M vector instructions); the same with selects 349 us; words
+    // for the mandatory fields and bytes for the optional ones 459 us at one word per load step (waiting for memory), 210 us at 32
+    // bytes per step.
     uint32_t n_tok = 0, n_ends = 0, total = 0, name_off = start, name_len = 0, cig_b = 0, cig_e = 0;
     uint32_t normal = 1, in_tok = 0, prev_ws = 0;
-    uint32_t p2 = end;                                                 // where the optional fields begin (none: end)
+    uint32_t o_ma = 0, o_mx = 0, o_mn = 0, o_colon = start;            // the field that is open: tag letters met so far, last ':' + 1
+    uint32_t pA = 0, pX = 0, pN = 0;                                   // the last byte of the word in front was 'A' / 'X' ('Z') / 'N'
+    uint32_t n_a = 0, n_x = 0, have_nm = 0, a_b = 0, a_e = 0, x_b = 0, x_e = 0, nm_b = 0, nm_e = 0;
     auto nth_set = [](uint32_t m, uint32_t nth) -> uint32_t {          // position of set bit number nth (< 6) of an 8-bit mask
 #pragma unroll
         for (uint32_t j = 0; j < 5u; ++j) m = j < nth ? (m & (m - 1u)) : m;
         return (uint32_t)__ffs((int)m) - 1u;
     };
-    // STEP bytes per load step (16-byte loads, all in flight together): a word per step left the kernel waiting for memory --
-    // every step's load touches 64 different cache lines, one per lane
-    auto phase1_word = [&](uint32_t wa, uint64_t w) -> bool {          // true: the optional fields begin in this word
+    auto field_ends = [&](uint32_t at, uint32_t ma, uint32_t mx, uint32_t mn, uint32_t colon) {   // field number n_ends ends in front of `at`
+        if (n_ends == 0u) name_len = at - name_off;
+        if (n_ends == 5u) cig_e = at;
+        if (n_ends >= 11u) {                                            // fields[11:]: where get_tag looks
+            if (ma) { if (n_a == 0u) { a_b = colon; a_e = at; } ++n_a; }
+            if (mx) { if (n_x == 0u) { x_b = colon; x_e = at; } ++n_x; }
+            if (mn && !have_nm) { have_nm = 1u; nm_b = colon; nm_e = at; }    // NM[0]: the first match, no duplicate rule
+        }
+        ++n_ends;
+    };
+    auto word = [&](uint32_t wa, uint64_t w) {
         const uint32_t lo = start > wa ? start - wa : 0u, hi = min(end - wa, 8u);
         const uint64_t H = 0x8080808080808080ull, O = 0x0101010101010101ull;
-        // a whole word inside a field without a byte below 0x21 (the input is ASCII, or the result is thrown away): nothing
-        // to learn from it but its length
-        if (lo == 0u && hi == 8u && in_tok && !((w - 0x21u * O) & ~w & H)) {
+        // a whole word inside a mandatory field without a byte below 0x21 (the input is ASCII, or the result is thrown away):
+        // nothing to learn from it but its length
+        if (lo == 0u && hi == 8u && in_tok && n_ends < 11u && !((w - 0x21u * O) & ~w & H)) {
             total += 8u;
-            return false;
+            return;
         }
-        // byte in [9, 13] or [28, 32]: Python's str.split() separators; byte == 9: the one '\t'.join() puts back
-        const uint64_t t = w | H;                                       // every byte >= 0x80: the subtractions do not borrow
-        const uint64_t ge9 = (t - 9u * O) & H, ge10 = (t - 10u * O) & H, ge14 = (t - 14u * O) & H, ge28 = (t - 28u * O) & H,
-                       ge33 = (t - 33u * O) & H;
         auto pack = [](uint64_t m) -> uint32_t {                        // the high bit of every byte -> one bit per byte
             const uint32_t l = ((((uint32_t)m >> 7) * 0x01020408u) >> 24) & 0xFu;
             const uint32_t h = ((((uint32_t)(m >> 32) >> 7) * 0x01020408u) >> 24) & 0xFu;
             return l | (h << 4);
         };
-        uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-        uint32_t wsm = pack((ge9 & ~ge14) | (ge28 & ~ge33)) & vm;
-        uint32_t nonws = ~wsm & vm;
-        uint32_t starts = nonws & ~((nonws << 1) | in_tok);
-        // the twelfth field starts in this word: phase 1 stops in front of it
-        const uint32_t cnt = (uint32_t)__popc(starts);
-        uint32_t stop = 8u;
-        if (n_tok + cnt > 11u) {
-            stop = nth_set(starts, 11u - n_tok);
-            p2 = wa + stop;
-            vm &= (1u << stop) - 1u;
-            wsm &= vm;
-            nonws &= vm;
-            starts &= vm;
+        auto eq = [&](uint32_t c) -> uint32_t {                         // bytes equal to c (exact zero-byte test of w ^ c)
+            const uint64_t x = w ^ (c * O), m7 = 0x7F7F7F7F7F7F7F7Full;
+            return pack(~(((x & m7) + m7) | x | m7));
+        };
+        // byte in [9, 13] or [28, 32]: Python's str.split() separators; byte == 9: the one '\t'.join() puts back
+        const uint64_t t = w | H;                                       // every byte >= 0x80: the subtractions do not borrow
+        const uint64_t ge9 = (t - 9u * O) & H, ge10 = (t - 10u * O) & H, ge14 = (t - 14u * O) & H, ge28 = (t - 28u * O) & H,
+                       ge33 = (t - 33u * O) & H;
+        const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        const uint32_t wsm = pack((ge9 & ~ge14) | (ge28 & ~ge33)) & vm, tabm = pack(ge9 & ~ge10) & vm;
+        const uint32_t nonws = ~wsm & vm;
+        const uint32_t pred = (nonws << 1) | in_tok;                    // bit b: the byte in front of b is part of a field
+        const uint32_t starts = nonws & ~pred;
+        uint32_t ends = wsm & pred;                                     // a field ends in front of these separators
+        // '\t'.join(fields) == line  <=>  exactly one '\t' between fields, nothing in front or behind
+        uint32_t bad = (wsm & ~tabm) | (wsm & ((wsm << 1) | prev_ws));
+        if (n_tok == 0u) bad |= wsm & ((starts ? (1u << ((uint32_t)__ffs((int)starts) - 1u)) : 256u) - 1u);
+        normal &= (uint32_t)(bad == 0u);
+        const uint32_t n_st = (uint32_t)__popc(starts);
+        if (n_tok == 0u && starts) name_off = wa + (uint32_t)__ffs((int)starts) - 1u;
+        if (n_tok <= 5u && n_tok + n_st > 5u) cig_b = wa + nth_set(starts, 5u - n_tok);
+        n_tok += n_st;
+        total += (uint32_t)__popc(nonws);
+        // the tag letters; a pair may straddle two words (never two fields: both bytes are part of one)
+        uint32_t as_hit = 0, xs_hit = 0, nm_hit = 0, colons = 0;
+        if (n_ends + (uint32_t)__popc(ends) + 1u > 11u) {               // an optional field touches this word
+            const uint32_t eS = eq('S') & vm, eA = eq('A') & vm, eX = eq(xtag0) & vm;
+            colons = eq(':') & vm;
+            xs_hit = eS & ((eX << 1) | pX);
+            pX = (eX >> 7) & 1u;
+            if (as_on) { as_hit = eS & ((eA << 1) | pA); pA = (eA >> 7) & 1u; }
+            if (nm_on) { const uint32_t eN = eq('N') & vm; nm_hit = (eq('M') & vm) & ((eN << 1) | pN); pN = (eN >> 7) & 1u; }
+        } else {
+            pA = pX = pN = 0u;
         }
-        if (vm) {
-            const uint32_t tabm = pack(ge9 & ~ge10) & vm;
-            const uint32_t pred = (nonws << 1) | in_tok;                // bit b: the byte in front of b is part of a field
-            const uint32_t ends = wsm & pred;                           // a field ends in front of these separators
-            // '\t'.join(fields) == line  <=>  exactly one '\t' between fields, nothing in front or behind
-            uint32_t bad = (wsm & ~tabm) | (wsm & ((wsm << 1) | prev_ws));
-            if (n_tok == 0u) bad |= wsm & ((starts ? (1u << ((uint32_t)__ffs((int)starts) - 1u)) : 256u) - 1u);
-            normal &= (uint32_t)(bad == 0u);
-            const uint32_t n_st = (uint32_t)__popc(starts), n_en = (uint32_t)__popc(ends);
-            if (n_tok == 0u && starts) name_off = wa + (uint32_t)__ffs((int)starts) - 1u;
-            if (n_tok <= 5u && n_tok + n_st > 5u) cig_b = wa + nth_set(starts, 5u - n_tok);
-            if (n_ends == 0u && ends) name_len = wa + (uint32_t)__ffs((int)ends) - 1u - name_off;
-            if (n_ends <= 5u && n_ends + n_en > 5u) cig_e = wa + nth_set(ends, 5u - n_ends);
-            n_tok += n_st;
-            n_ends += n_en;
-            total += (uint32_t)__popc(nonws);
-            const uint32_t last = 31u - (uint32_t)__clz((int)vm);
-            in_tok = (nonws >> last) & 1u;
-            prev_ws = (wsm >> last) & 1u;
-        }
-        return stop < 8u;
-    };
-    {
-        bool done = false;
-        for (uint32_t base = start & ~(STEP - 1u); base < end && !done; base += STEP) {
-            uint64_t ww[STEP / 8u];
-            load_step(text + base, ww);
-#pragma unroll
-            for (uint32_t j = 0; j < STEP / 8u; ++j) {
-                const uint32_t wa = base + 8u * j;
-                if (!done && wa + 8u > start && wa < end) done = phase1_word(wa, ww[j]);
+        // the fields that end in this word, in order; `from`: where the part of the field inside this word begins
+        uint32_t from = 0u, open = in_tok, rest = starts;
+        while (ends) {
+            const uint32_t e = (uint32_t)__ffs((int)ends) - 1u;
+            ends &= ends - 1u;
+            uint32_t ma = 0, mx = 0, mn = 0, colon = 0;
+            if (!open) {                                                // it began in this word
+                from = (uint32_t)__ffs((int)rest) - 1u;
+                rest &= rest - 1u;
+                colon = wa + from;
+            } else {
+                ma = o_ma; mx = o_mx; mn = o_mn; colon = o_colon;
             }
+            const uint32_t span = ((1u << e) - 1u) & ~((1u << from) - 1u);
+            ma |= (uint32_t)((as_hit & span) != 0u);
+            mx |= (uint32_t)((xs_hit & span) != 0u);
+            mn |= (uint32_t)((nm_hit & span) != 0u);
+            const uint32_t c = colons & span;
+            if (c) colon = wa + (32u - (uint32_t)__clz((int)c));         // behind the last ':' of the field
+            field_ends(wa + e, ma, mx, mn, colon);
+            open = 0u;
+            from = e;
         }
-    }
-    // Phase 2: fields[11:], where the tags are
-    uint32_t ma = 0, mx = 0, mn = 0, have_nm = 0, prevc = 0, last_colon = 0;
-    uint32_t n_a = 0, n_x = 0, a_b = 0, a_e = 0, x_b = 0, x_e = 0, nm_b = 0, nm_e = 0;
-    auto end_token = [&](uint32_t t_end, uint32_t p) {                 // an optional field ends in front of p (t_end: 0 / 1)
-        const uint32_t hit_a = t_end & ma, hit_x = t_end & mx, hit_n = t_end & mn & (have_nm ^ 1u);
-        const uint32_t first_a = hit_a & (uint32_t)(n_a == 0u), first_x = hit_x & (uint32_t)(n_x == 0u);
-        n_a += hit_a;
-        n_x += hit_x;
-        a_b = first_a ? last_colon : a_b;
-        a_e = first_a ? p : a_e;
-        x_b = first_x ? last_colon : x_b;
-        x_e = first_x ? p : x_e;
-        nm_b = hit_n ? last_colon : nm_b;                               // NM[0]: the first match, no duplicate rule
-        nm_e = hit_n ? p : nm_e;
-        have_nm |= hit_n;
-    };
-    auto phase2_word = [&](uint32_t wa, uint64_t w) {
-        const uint32_t lo = p2 > wa ? p2 - wa : 0u, hi = min(end - wa, 8u);
-#pragma unroll
-        for (uint32_t b = 0; b < 8u; ++b) {
-            const uint32_t c = (uint32_t)(w >> (8u * b)) & 0xFFu, p = wa + b;
-            const uint32_t valid = (uint32_t)(b >= lo) & (uint32_t)(b < hi);
-            const uint32_t ws = is_ws(c) ? 1u : 0u;
-            end_token(valid & ws & in_tok, p);
-            normal &= (valid & ws & ((uint32_t)(c != 9u) | prev_ws)) ^ 1u;
-            const uint32_t t_start = valid & (ws ^ 1u) & (in_tok ^ 1u);      // a field starts at p
-            last_colon = t_start ? p : last_colon;
-            ma = t_start ? 0u : ma;
-            mx = t_start ? 0u : mx;
-            mn = t_start ? 0u : mn;
-            prevc = t_start ? 0u : prevc;
-            n_tok += t_start;
-            const uint32_t nonws = valid & (ws ^ 1u);
-            total += nonws;
-            ma |= nonws & as_on & (uint32_t)(prevc == 'A') & (uint32_t)(c == 'S');
-            mx |= nonws & (uint32_t)(prevc == xtag0) & (uint32_t)(c == 'S');
-            mn |= nonws & nm_on & (uint32_t)(prevc == 'N') & (uint32_t)(c == 'M');
-            last_colon = (nonws & (uint32_t)(c == ':')) ? p + 1u : last_colon;
-            prevc = nonws ? c : prevc;
-            in_tok = valid ? (ws ^ 1u) : in_tok;
-            prev_ws = valid ? ws : prev_ws;
+        // what is left open at the end of the word
+        const uint32_t last = 31u - (uint32_t)__clz((int)vm);
+        in_tok = (nonws >> last) & 1u;
+        prev_ws = (wsm >> last) & 1u;
+        if (in_tok) {
+            if (!open) {                                                // the field began in this word
+                from = (uint32_t)__ffs((int)rest) - 1u;
+                o_ma = o_mx = o_mn = 0u;
+                o_colon = wa + from;
+            }
+            const uint32_t span = vm & ~((1u << from) - 1u);
+            o_ma |= (uint32_t)((as_hit & span) != 0u);
+            o_mx |= (uint32_t)((xs_hit & span) != 0u);
+            o_mn |= (uint32_t)((nm_hit & span) != 0u);
+            const uint32_t c = colons & span;
+            if (c) o_colon = wa + (32u - (uint32_t)__clz((int)c));
         }
     };
-    for (uint32_t base = p2 & ~(STEP - 1u); base < end; base += STEP) {
+    // STEP bytes per load step (16-byte loads, all in flight together): a word per step left the kernel waiting for memory --
+    // every step's load touches 64 different cache lines, one per lane
+    for (uint32_t base = start & ~(STEP - 1u); base < end; base += STEP) {
         uint64_t ww[STEP / 8u];
         load_step(text + base, ww);
 #pragma unroll
         for (uint32_t j = 0; j < STEP / 8u; ++j) {
             const uint32_t wa = base + 8u * j;
-            if (wa + 8u > p2 && wa < end) phase2_word(wa, ww[j]);
+            if (wa + 8u > start && wa < end) word(wa, ww[j]);
         }
     }
-    // the line ends: so does the field that is open
-    if (p2 < end) {
-        end_token(in_tok, end);
-    } else if (in_tok) {
-        if (n_ends == 0u) name_len = end - name_off;
-        if (n_ends == 5u) cig_e = end;
-    }
+    if (in_tok) field_ends(end, o_ma, o_mx, o_mn, o_colon);             // the line ends: so does the field that is open
     normal &= prev_ws ^ 1u;
     int32_t a = ABSENT, x = ABSENT, nm = ABSENT;
     uint32_t ex_a = 0, ex_x = 0, n_ops = 0;
