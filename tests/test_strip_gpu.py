@@ -291,3 +291,71 @@ def test_whole_file_path_with_either_stripper_writes_the_same_bytes(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     rep = json.loads(out.stdout.strip().splitlines()[-1])
     assert len(rep) == 4 and all(v["identical"] and v["units"] == 150000 for v in rep.values())
+
+
+def _unpack_cigar(cnt, ops):
+    """Packed CIGAR columns -> the operations of every record (xenomapper_hip.h: a count byte of 255 means "255 or more", the
+    record's operations are then followed by one trailer word n_ops << 4 | 15)."""
+    out, pos = [], 0
+    for c in cnt.tolist():
+        n = c
+        if c == 255:
+            while not ((int(ops[pos + n]) & 15) == 15 and (int(ops[pos + n]) >> 4) == n):
+                n += 1
+        out.append([int(v) for v in ops[pos:pos + n]])
+        pos += n + (1 if c == 255 else 0)
+    return out
+
+
+@settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "300")), deadline=None, suppress_health_check=list(HealthCheck))
+@given(texts=sam_pair(), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans(), skip=st.booleans())
+def test_gpu_stripper_agrees_with_the_oracle_directly(rig, texts, score_mode, paired, skip):
+    """Not through the host stripper: the oracle's restatement of getReadPairs and of the three plugins on the same text --
+    record count, walk outcome, unit mask, every score the kernels vouch for (a flag wherever they do not), line spans."""
+    import io
+    from tests.helpers import ORACLE, NEG
+    _ctx, s, _p = rig
+    t1, t2 = texts
+    b1, b2 = t1.encode("ascii"), t2.encode("ascii")
+    got = strip(s, 0, b1, b2, True, True, score_mode, paired, False, 1 << 12, skip)
+    pairs, err = [], None
+    try:
+        for pr in ORACLE.read_pairs(io.StringIO(t1, newline=None), io.StringIO(t2, newline=None), skip):
+            pairs.append(pr)
+    except AssertionError:
+        err = "mismatch"
+    assert got.n == len(pairs) and (got.mismatch_at >= 0) == (err == "mismatch")
+    if err != "mismatch":
+        assert got.ended
+    names = [p[0][0] for p in pairs]
+    cols = got.cols
+    flags = np.unpackbits(np.ascontiguousarray(cols[4] if len(cols) > 4 else got.unit_bits).view(np.uint8), bitorder="little")[:got.n].tolist()
+    assert flags == ([1] * len(pairs) if not paired else [int(i > 0 and names[i] == names[i - 1]) for i in range(len(names))])
+    scorer = [ORACLE.tag_score, ORACLE.tag_score_zs, ORACLE.cigar_score][score_mode]
+    exc = {(k, c) for k, c, _ in got.exc}
+    cig = [None, None]
+    if score_mode == 2 and got.n:
+        for f in (0, 1):
+            nm, cnt, _tile, ops = s.cigar_columns(0, f, got.n)
+            cig[f] = (nm, _unpack_cigar(cnt, ops))
+    raws = (b1, b2)
+    for k, (f1, f2) in enumerate(pairs):
+        for f, fields in enumerate((f1, f2)):
+            st0 = int(got.line_off[f][k])
+            assert raws[f][st0:st0 + int(got.line_len[f][k])].decode().split() == fields
+            assert int(got.norm_len[f][k]) == len("\t".join(fields))
+            for c, tag in ((2 * f, "AS"), (2 * f + 1, "XS")):
+                try:
+                    want, failed = scorer(fields, tag=tag), False
+                except Exception:
+                    want, failed = None, True
+                if (k, c) in exc:
+                    continue
+                assert not failed, (fields, tag)
+                if score_mode == 2 and tag == "AS":
+                    nm, ops = cig[f][0][k], cig[f][1][k]
+                    have = NEG if nm == -2**31 else -6 * int(nm) - sum(
+                        (5 + 3 * (v >> 4)) if (v & 15) in (1, 2) else (2 * (v >> 4) if (v & 15) == 4 else 0) for v in ops)
+                else:
+                    have = NEG if cols[c][k] == -2**31 else int(cols[c][k])
+                assert have == want, (fields, tag, have, want)
