@@ -282,7 +282,16 @@ def e2e_sam_text(pairs=4_000_000, to_files=True, gpu_strip=True):
             del os.environ["XENOMAPPER_GPU_STRIP"]
         else:
             os.environ["XENOMAPPER_GPU_STRIP"] = before
+    strip = None
+    if gpu_strip and r["phases"].get("strip_upload_ms"):
+        # the stripper's own roofline is the link: text bytes / device time from the first piece's upload to the last
+        strip = {"bound": "pcie", "upload_GBps": round(r["input_bytes"] / (r["phases"]["strip_upload_ms"] / 1e3) / 1e9, 2),
+                 "kernels_ms_total": round(r["phases"].get("strip_kernels_ms", 0.0), 2),
+                 "kernels_GBps_of_text": round(r["input_bytes"] / (max(r["phases"].get("strip_kernels_ms", 0.0), 1e-9) / 1e3) / 1e9, 1),
+                 "what": "SAM text uploaded piece by piece while the host threads read the next piece (compare e2e.pcie_ceiling."
+                         "h2d_pinned_GBps); the strip kernels run behind each window's upload"}
     return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"], "phases": r["phases"],
+            "strip": strip,
             "seconds": round(r["seconds"], 4), "outputs": r["outputs"], "output_bytes": r["output_bytes"],
             "text_bytes_in_per_pair": round(r["input_bytes"] / max(r["units"], 1), 1),
             "text_bytes_out_per_pair": round(r["output_bytes"] / max(r["units"], 1), 1),
