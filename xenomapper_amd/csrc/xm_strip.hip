@@ -485,15 +485,27 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
     }
 }
 
-// eight independent byte loads per side at a time (a loop with an exit after every byte waits a memory latency per byte)
+// 32 bytes per round as five aligned 8-byte words per side, all ten loads in flight together, shifted into place and compared
+// under a mask (a loop with an exit after every byte waits one memory latency per byte: 131 us for S6; eight byte loads per
+// side at a time: 73 us).  Reads up to 15 bytes past either string: the text buffers are padded.
 __device__ bool same_bytes(const uint8_t *a, const uint8_t *b, uint32_t n)
 {
-    for (uint32_t i = 0; i < n; i += 8u) {
-        uint32_t diff = 0;
+    for (uint32_t base = 0; base < n; base += 32u) {
+        const uint32_t m = min(n - base, 32u);
+        const uintptr_t pa = (uintptr_t)(a + base), pb = (uintptr_t)(b + base);
+        const uint64_t *qa = reinterpret_cast<const uint64_t *>(pa & ~(uintptr_t)7), *qb = reinterpret_cast<const uint64_t *>(pb & ~(uintptr_t)7);
+        const uint32_t sa = (uint32_t)(pa & 7u) * 8u, sb = (uint32_t)(pb & 7u) * 8u;
+        uint64_t wa[5], wb[5];
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) {
-            const uint32_t q = min(i + j, n - 1u);                   // past the end: the last byte again
-            diff |= (uint32_t)(a[q] ^ b[q]);
+        for (uint32_t j = 0; j < 5u; ++j) { wa[j] = qa[j]; wb[j] = qb[j]; }
+        uint64_t diff = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint64_t va = sa ? (wa[j] >> sa) | (wa[j + 1u] << (64u - sa)) : wa[j];
+            const uint64_t vb = sb ? (wb[j] >> sb) | (wb[j + 1u] << (64u - sb)) : wb[j];
+            const uint32_t have = m > 8u * j ? min(m - 8u * j, 8u) : 0u;      // bytes of this word that belong to the strings
+            const uint64_t mask = have >= 8u ? ~0ull : ((1ull << (8u * have)) - 1ull);
+            diff |= (va ^ vb) & mask;
         }
         if (diff) return false;
     }
