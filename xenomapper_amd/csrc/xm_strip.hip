@@ -39,10 +39,12 @@ namespace {
 constexpr int SB = 256;                               // lanes per workgroup
 constexpr uint32_t CHUNK = 1u << 16;                  // bytes of text per workgroup in S1 / S3
 constexpr uint32_t GROUPS = CHUNK / 16;               // 16-byte groups per chunk
+constexpr uint32_t WAVES = SB / 64;                    // waves per workgroup
 constexpr uint32_t ITER = GROUPS / SB;
 constexpr int32_t ABSENT = INT32_MIN;
 
-enum { ST_NTERM0 = 0, ST_NTERM1 = 1, ST_NONASCII = 2, ST_KSTOP = 3, ST_RUNS0 = 4, ST_RUNS1 = 5, ST_OPS0 = 6, ST_OPS1 = 7, ST_WORDS = 8 };
+enum { ST_NTERM0 = 0, ST_NTERM1 = 1, ST_NONASCII = 2, ST_KSTOP = 3, ST_RUNS0 = 4, ST_RUNS1 = 5, ST_OPS0 = 6, ST_OPS1 = 7, ST_HASCR0 = 8, ST_HASCR1 = 9,
+       ST_WORDS = 12 };
 enum { SUM_N = 0, SUM_CONS1, SUM_CONS2, SUM_CL1, SUM_CL2, SUM_ENDED, SUM_STARVED, SUM_MISMATCH, SUM_NONASCII, SUM_L1, SUM_L2,
        SUM_OVERFLOW, SUM_WORDS = 16 };
 
@@ -103,11 +105,13 @@ __global__ void __launch_bounds__(SB) mark_kernel(const Job job)
 {
     const FileView &f = job.f[blockIdx.y];
     if (blockIdx.x >= f.n_chunks) return;
-    __shared__ uint32_t red[SB / 64];
     const uint32_t n_groups = (f.len + 15u) / 16u;
-    uint32_t cnt = 0, hi = 0;
+    uint32_t cnt = 0, hi = 0, any_cr = 0;
+    // a wave owns a contiguous quarter of the chunk (16 KiB, 1 KiB per step): S3 then needs no barrier -- its waves take their
+    // own bases from the scan of these per-wave counts
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t it = 0; it < ITER; ++it) {
-        const uint32_t g = blockIdx.x * GROUPS + it * SB + threadIdx.x;
+        const uint32_t g = blockIdx.x * GROUPS + wave * (GROUPS / WAVES) + it * 64u + lane;
         if (g >= n_groups) break;
         const uint32_t p0 = g * 16u;
         const uint4 v = *reinterpret_cast<const uint4 *>(f.text + p0);       // the buffer is readable past len (padding)
@@ -127,6 +131,7 @@ __global__ void __launch_bounds__(SB) mark_kernel(const Job job)
         const uint32_t in_len = p0 + 16u <= f.len ? 0xFFFFu : (1u << (f.len - p0)) - 1u;           // p < len (p0 < len here)
         const uint32_t in_use = p0 + 16u <= f.usable ? 0xFFFFu : (p0 < f.usable ? (1u << (f.usable - p0)) - 1u : 0u);
         hi |= (him & in_len) ? 0x80u : 0u;
+        any_cr |= crm & in_len;
         // '\r' always ends a line (alone or as the first half of "\r\n"); '\n' unless it is that second half
         const uint32_t prev_cr = ((lfm & 1u) && p0 && f.text[p0 - 1u] == 13u) ? 1u : 0u;      // the byte in front of the group
         const uint32_t m = (crm | (lfm & ~((crm << 1) | prev_cr))) & in_use;
@@ -135,14 +140,9 @@ __global__ void __launch_bounds__(SB) mark_kernel(const Job job)
     }
     cnt = wave_sum(cnt);
     hi = __any((hi & 0x80808080u) != 0) ? 1u : 0u;
-    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int i = 0; i < SB / 64; ++i) t += red[i];
-        f.chunk_cnt[blockIdx.x] = t;
-    }
-    if (hi && (threadIdx.x & 63u) == 0) atomicOr(&job.state[ST_NONASCII], 1u);
+    if (lane == 0u) f.chunk_cnt[blockIdx.x * WAVES + wave] = cnt;
+    if (hi && lane == 0u) atomicOr(&job.state[ST_NONASCII], 1u);
+    if (__any(any_cr != 0u) && lane == 0u) atomicOr(&job.state[ST_HASCR0 + blockIdx.y], 1u);     // S3 looks at the text only then
 }
 
 // ---- S2: exclusive scan of the chunk counts, one workgroup per file ------------------------------------------------
@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(1024) chunk_scan_kernel(const Job job)
 {
     const FileView &f = job.f[blockIdx.x];
     __shared__ uint32_t ws[16];
-    const uint32_t per = (f.n_chunks + 1023u) / 1024u;
-    const uint32_t b = min(threadIdx.x * per, f.n_chunks), e = min(b + per, f.n_chunks);
+    const uint32_t n_cnt = f.n_chunks * WAVES;                     // one count per wave of S1
+    const uint32_t per = (n_cnt + 1023u) / 1024u;
+    const uint32_t b = min(threadIdx.x * per, n_cnt), e = min(b + per, n_cnt);
     uint32_t sum = 0;
     for (uint32_t c = b; c < e; ++c) sum += f.chunk_cnt[c];
     const uint32_t incl = wave_scan_incl(sum);
@@ -178,33 +179,26 @@ __global__ void __launch_bounds__(SB) fill_kernel(const Job job)
 {
     const FileView &f = job.f[blockIdx.y];
     if (blockIdx.x >= f.n_chunks) return;
-    __shared__ uint32_t ws[SB / 64];
     const uint32_t n_groups = (f.len + 15u) / 16u;
-    uint32_t run = f.chunk_base[blockIdx.x];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t run = f.chunk_base[blockIdx.x * WAVES + wave];            // lines in front of this wave's quarter of the chunk
+    const bool has_cr = job.state[ST_HASCR0 + blockIdx.y] != 0u;       // without a CR in the window every terminator is one LF
     for (uint32_t it = 0; it < ITER; ++it) {
-        const uint32_t g = blockIdx.x * GROUPS + it * SB + threadIdx.x;
+        const uint32_t g = blockIdx.x * GROUPS + wave * (GROUPS / WAVES) + it * 64u + lane;
         uint32_t m = g < n_groups ? (uint32_t)f.mask16[g] : 0u;
         const uint32_t c = (uint32_t)__popc(m), incl = wave_scan_incl(c);
-        if ((threadIdx.x & 63u) == 63u) ws[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint32_t wb = 0, tot = 0;
-        for (uint32_t i = 0; i < SB / 64; ++i) {
-            if (i < (threadIdx.x >> 6)) wb += ws[i];
-            tot += ws[i];
-        }
-        uint32_t j = run + wb + incl - c;
+        uint32_t j = run + incl - c;
         while (m) {
             const uint32_t p = g * 16u + (uint32_t)(__ffs((int)m) - 1);
             m &= m - 1u;
             if (j < job.cap_lines) {
-                const bool crlf = f.text[p] == 13u && p + 1u < f.len && f.text[p + 1u] == 10u;
+                const bool crlf = has_cr && f.text[p] == 13u && p + 1u < f.len && f.text[p + 1u] == 10u;
                 f.lend[j] = p;
                 f.lnext[j] = p + (crlf ? 2u : 1u);
             }
             ++j;
         }
-        run += tot;
-        __syncthreads();
+        run += (uint32_t)__shfl((int)incl, 63);
     }
 }
 
@@ -883,8 +877,8 @@ int grow_window(xm_strip *s, Slot &sl, uint64_t bytes)
         XMS_TRY(halloc(s, q.h_text, (size_t)cap));
         XMS_TRY(dalloc(s, q.d_text, (size_t)cap + 256));              // S1 / S4 read whole 16-byte words / load steps
         XMS_TRY(dalloc(s, q.d_mask, (size_t)cap / 16 + 16));
-        XMS_TRY(dalloc(s, q.d_chunk_cnt, n_chunks));
-        XMS_TRY(dalloc(s, q.d_chunk_base, n_chunks));
+        XMS_TRY(dalloc(s, q.d_chunk_cnt, n_chunks * WAVES));
+        XMS_TRY(dalloc(s, q.d_chunk_base, n_chunks * WAVES));
     }
     sl.window_cap = cap;
     return XM_OK;
