@@ -31,6 +31,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -803,6 +804,7 @@ struct xm_strip {
     xm_ctx *ctx = nullptr;
     int device = 0;
     Slot slot[XMS_SLOTS];
+    std::mutex error_lock;                             // the two slots are driven by two threads
     std::string last_error;
 };
 
@@ -812,7 +814,10 @@ int fail(xm_strip *s, hipError_t e, const char *what)
 {
     char buf[256];
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-    if (s) s->last_error = buf;
+    if (s) {
+        std::lock_guard<std::mutex> hold(s->error_lock);
+        s->last_error = buf;
+    }
     return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
 }
 
@@ -1171,6 +1176,7 @@ int xm_strip_classify(xm_strip *s, int slot, int mode, uint64_t n_records, int32
                                      min_score_floor, sl.d_code, sl.d_bins4, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
     }
     if (rc != XM_OK) {
+        std::lock_guard<std::mutex> hold(s->error_lock);
         s->last_error = xm_last_hip_error(s->ctx);
         return rc;
     }
