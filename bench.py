@@ -320,7 +320,7 @@ class Workload(object):
               "columns resident in HBM",
     }
 
-    def __init__(self, name, ctx, dev, n_pairs, rank, mode_name=None, n_slots=1, singletons_pct=0.0, shard=None):
+    def __init__(self, name, ctx, dev, n_pairs, rank, mode_name=None, n_slots=1, singletons_pct=0.0, shard=None, form=None):
         import numpy as np
         import torch
         from xenomapper_amd import _ffi, synth
@@ -333,6 +333,8 @@ class Workload(object):
         self.unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"        # A/B only: xm_classify_dev + xm_compact_dev
         self.shard = shard
         self.place = os.environ.get("XM_BENCH_PLACE") == "1" and name in ("cfg2", "cfg5", "se", "f64")   # A/B: the six-list form
+        # the segmented-lists form (xm_classify_runs*_dev, one launch): its own workload entry, and XM_BENCH_RUNS=1 for A/B runs
+        self.runs = (form == "runs" or os.environ.get("XM_BENCH_RUNS") == "1") and name in ("cfg2", "cfg5", "se", "f64") and not self.place
         self.layout = "strictly interleaved mates"
         n = 2 * n_pairs
         units = n_pairs
@@ -384,6 +386,16 @@ class Workload(object):
         if self.place:
             self.lists = [torch.empty(units + 64, dtype=torch.int32, device=dev) for _ in range(7 if name == "f64" else 6)]
             self.n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+        if self.runs:
+            # its OWN algorithmic bytes: the scores in, 2 B per unit of run entries + 16 B of counts per 2048 records out; no
+            # second pass (SURVEY 8d's 38 B/pair is the flat contract's figure and stays with the flat step)
+            g = _ffi.runs_granules(n)
+            self.runs16 = torch.empty(g * _ffi.RUNS_GRAN, dtype=torch.int16, device=dev)
+            self.gran_counts = torch.empty(g * 8, dtype=torch.int16, device=dev)
+            self.n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+            per_unit_in = self.bytes_classify - 1.0
+            self.bytes_classify = per_unit_in + 2.0 + 16.0 * g / max(units, 1)
+            self.bytes_compact = 0.0
         self.n_slots = max(n_slots, 1)
         self.step_counts = torch.zeros((self.n_slots, 64), dtype=torch.int64, device=dev)   # category_counts of every step of the job
         self.step_no = 0
@@ -431,6 +443,8 @@ class Workload(object):
                 "se": "single-end loop: 2 x %d reads/GPU (%s ignored)"}[self.name] % (self.n_pairs, self.mode_name)
 
     def step_short(self):
+        if self.runs:
+            return "xm_classify_runs%s_dev: classify+count+sort per granule, ONE launch (segmented lists)" % ("_f64" if self.dtype == "f64" else "")
         if self.place:
             return "xm_classify_place%s_dev: classify+count, scan, scatter into six lists" % ("_f64" if self.dtype == "f64" else "")
         if self.unfused:
@@ -444,6 +458,8 @@ class Workload(object):
         return self.DESCR[self.name] % (self.n_pairs, self.mode_name)
 
     def kernel_name(self):
+        if self.runs:
+            return "classify_runs_kernel<%s, %s>" % (self.dtype, "single" if self.name == "se" else "paired")
         if self.cigp is not None:
             return "classify_cigp_kernel<paired, counts, bins4>"
         if self.cig is not None:
@@ -451,6 +467,9 @@ class Workload(object):
         return "classify_kernel<%s, %s, counts>" % (self.dtype, "single" if self.name == "se" else "paired")
 
     def call_name(self):
+        if self.runs:
+            return "one xm_classify_runs%s_dev call: classify, count, sort by bin inside the granule (one launch + a 1-workgroup launch for the counts)" % (
+                "_f64" if self.dtype == "f64" else "")
         if self.place:
             return "one xm_classify_place%s_dev call: classify+count, scan, scatter into six lists" % ("_f64" if self.dtype == "f64" else "")
         if self.unfused:
@@ -471,7 +490,10 @@ class Workload(object):
         self.step_no += 1
         code = self.code if self.category_bytes else None
         bins4 = None if self.category_bytes else self.bins4
-        if self.place:
+        if self.runs:
+            ctx.classify_runs_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, self.runs16,
+                                  self.gran_counts, self.n_out, counts)
+        elif self.place:
             ctx.classify_place_dev(mode, c["as1"], c["xs1"], c["as2"], c["xs2"], c["unit_bits"], self.floor_min, self.lists[:6],
                                    self.n_out, counts, code_out=code, bins4=bins4,
                                    list_state6=self.lists[6] if len(self.lists) > 6 else None)
@@ -520,6 +542,19 @@ class Workload(object):
         want_code, want_counts = H.c_classify(mode, hc["as1"], hc["xs1"], hc["as2"], hc["xs2"], hc["unit_bits"], self.floor_min)
         want_idx, want_off = H.c_compact(mode, want_code)
         ok = True
+        if self.runs:
+            n_out = self.n_out.cpu().numpy().astype(np.uint64)
+            runs16 = self.runs16.cpu().numpy().view(np.uint16)
+            gcnt = self.gran_counts.cpu().numpy().view(np.uint16)
+            for b in range(7):
+                want = want_idx[int(want_off[b]):int(want_off[b + 1])]
+                ok &= int(n_out[b]) == want.shape[0]
+                got = _ffi.runs_expand(n, runs16, gcnt, b)
+                ok &= got.shape[0] == want.shape[0] and bool((got == want).all())
+            ok &= int(n_out[7]) == int(want_off[7]) == self.units_per_step
+            ok &= bool((self.counts.cpu().numpy().astype(np.uint64) == want_counts).all())
+            self.host_cols = hc
+            return ok
         if self.place:
             n_out = self.n_out.cpu().numpy().astype(np.uint64)
             for b in range(len(self.lists)):
@@ -706,6 +741,10 @@ def compact_line(full):
     if e is not None:          # [ms_per_step, read-pairs/s of the whole job, verified]: configs[3]'s input cut into N blocks with halo
         w["sharded"] = ([_r(e["ms_per_step"]), _r(e["value"], 6), e["verified_vs_oracle"]] if "error" not in e
                         else [None, None, str(e["error"])[:80]])
+    e = (full.get("workloads") or {}).get("runs")
+    if e is not None:          # [ms_per_step, median, frac by ms_per_step on its OWN bytes (34 B/pair), verified]: segmented lists, one launch
+        w["runs"] = ([_r(e["ms_per_step"]), _r(e.get("ms_per_step_median")), _r(e["roofline_step"]["frac_by_ms_per_step"], 4),
+                      e["verified_vs_oracle"]] if "error" not in e else [None, None, None, str(e["error"])[:80]])
     if w:
         line["workloads"] = w
     e2e = full.get("e2e")
@@ -736,7 +775,7 @@ def rooflines(wl, elapsed, steps, timing, timing_all, unit_name):
     step_achieved = step_bytes / (sum_ms * 1e-3) / 1e9
     ms_per_step = 1e3 * elapsed / steps
     traffic = step_traffic = source = None
-    if not (wl.unfused or wl.place or wl.category_bytes or wl.shard or "singletons" in wl.layout):
+    if not (wl.unfused or wl.place or wl.runs or wl.category_bytes or wl.shard or "singletons" in wl.layout):
         traffic, step_traffic, source = kernel_hash.load_traffic(wl.name, wl.n_pairs)
     roof = {"bound": "hbm", "kernel": wl.kernel_name(), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
@@ -954,7 +993,7 @@ def main():
     # the default command yields both curves of SURVEY 8d.  `value`/`config` stay configs[1].
     plain_default = (args.workload == "cfg2" and not args.no_extra_workloads and not args.sharded_input
                      and not args.singletons_pct and not args.strong_total and args.pairs == 50_000_000
-                     and not wl.unfused and not wl.place and os.environ.get("XM_BENCH_CATEGORY_BYTES") != "1")
+                     and not wl.unfused and not wl.place and not wl.runs and os.environ.get("XM_BENCH_CATEGORY_BYTES") != "1")
     default_run = world == 1 and plain_default
     extra = {}
     if plain_default:
@@ -990,6 +1029,23 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:                               # noqa: BLE001 -- reported, the headline line still goes out
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if default_run:
+        # the segmented-lists form of configs[1] (one launch, no scan / scatter): its own entry, its own algorithmic bytes
+        try:
+            w4 = Workload("cfg2", ctx, dev, n_pairs, rank, None, 20, form="runs")
+            el4, tm4, tma4 = time_steps(ctx, w4, 20, 5, fence)
+            med4 = median_step_ms(w4, 20)
+            ok4 = None if args.no_verify else bool(w4.verify())
+            r4, rs4, k4 = rooflines(w4, el4, 20, tm4, tma4, "read-pair")
+            extra["runs"] = {"workload": w4.describe(), "step": w4.call_name(), "steps": 20, "warmup": 5, "ms_per_step": 1e3 * el4 / 20,
+                             "ms_per_step_median": med4, "value": w4.units_per_step * 20 / el4, "unit": "read-pairs/s", "dtype": w4.dtype,
+                             "roofline": r4, "roofline_step": rs4, "kernel_ms": k4, "verified_vs_oracle": ok4,
+                             "note": "output contract = per-granule runs (2 B per unit) + counts, NOT the flat lists of SURVEY 8b (4): "
+                                     "bytes_per_unit is this form's own (32 in + 2 out + counts), `value`/`roofline_step` of the line stay flat"}
+            del w4
+            torch.cuda.empty_cache()
+        except Exception as e:                                   # noqa: BLE001
+            extra["runs"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if plain_default:
         try:
             total = 400_000_000 - 400_000_000 % (Workload.PARTS * 32)

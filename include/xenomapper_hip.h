@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XM_ABI_VERSION 4
+#define XM_ABI_VERSION 5
 
 #define XM_ABSENT   INT32_MIN
 #define XM_NO_UNIT  0xFFu
@@ -334,6 +334,45 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
                                        const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
                                        uint32_t *range_flag, uint32_t *const idx_out[6], uint64_t list_capacity,
                                        uint64_t *n_out, uint64_t *counts);
+
+/*
+ * The fused main loop (xenomapper.py:321-350, :398-452, :498-554) with SEGMENTED bin lists: ONE launch (plus a
+ * 1-workgroup launch for category_counts), no scan, no scatter, nothing written that is read again.  The records are taken
+ * in granules of XM_RUNS_GRAN = 2048; the workgroup that classifies a granule also sorts the granule's units by output bin
+ * (on chip) and writes
+ *   runs16       XM_RUNS16_ENTRIES(n_records) uint16: entries [2048 g, 2048 g + units(g)) = the units of granule g as record
+ *                numbers counted from the granule's first record (0..2047), sorted by bin, input order inside a bin;
+ *                entries past units(g) are not written
+ *   gran_counts  8 uint16 per granule: gran_counts[8 g + b] = units of granule g in bin b (b = 0..5 the six bins in the
+ *                priority order above, 6 = units holding state 6 (binary64 columns with NaN only), 7 = always 0)
+ *   n_out        8 device uint64: the six list lengths, units holding state 6, all units
+ *   counts       64 device uint64: category_counts
+ * so that list b in input order is, for g = 0, 1, ...: 2048 g + runs16[2048 g + s .. 2048 g + s + gran_counts[8 g + b]) with
+ * s = the granule's counts of the bins in front of b.  A consumer that emits per bin walks the granules once per bin
+ * (xm_runs_expand does exactly that into a flat list; the emission rule is xm_compact's).  Why this shape: a unit's place
+ * in a FLAT list needs the totals of all granules in front of it -- a prefix over the whole input, i.e. the scan and the
+ * second pass of xm_classify_compact_dev (a look-back inside one launch lost by 3-7x in round 4) -- while its
+ * place inside its own granule's run needs nothing from outside the workgroup.  Same one-in-flight rule (the count
+ * replicas belong to the context).  Columns 16-byte aligned (binary64: 32), runs16 and gran_counts 16-byte aligned.
+ */
+#define XM_RUNS_GRAN 2048u
+#define XM_RUNS_GRANULES(n_records) (((uint64_t)(n_records) + XM_RUNS_GRAN - 1u) / XM_RUNS_GRAN)
+#define XM_RUNS16_ENTRIES(n_records) (XM_RUNS_GRANULES(n_records) * XM_RUNS_GRAN)
+
+int xm_classify_runs_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                         const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                         const uint64_t *unit_bits, int32_t min_score_floor,
+                         uint16_t *runs16, uint16_t *gran_counts, uint64_t *n_out, uint64_t *counts);
+
+int xm_classify_runs_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records,
+                             const double *as1, const double *xs1, const double *as2, const double *xs2,
+                             const uint64_t *unit_bits, double min_score,
+                             uint16_t *runs16, uint16_t *gran_counts, uint64_t *n_out, uint64_t *counts);
+
+/* Host memory, no device: list `bin` (0..6) of the segmented form as a flat list of record indices in input order;
+ * *n_written = its length (entries past `capacity` are counted, not stored; idx_out may be NULL to count only). */
+int xm_runs_expand(uint64_t n_records, const uint16_t *runs16, const uint16_t *gran_counts, int bin,
+                   uint32_t *idx_out, uint64_t capacity, uint64_t *n_written);
 
 /*
  * Test aid: synchronises the device and reports (*clean = 1) whether the context's counting workspace -- the replicated

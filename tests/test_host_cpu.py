@@ -27,7 +27,7 @@ def test_hip_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_ffi.EXPORTED) == names
-    assert _ffi.lib().xm_abi_version() == 4 and _ffi.lib().xms_abi_version() == 1
+    assert _ffi.lib().xm_abi_version() == 5 and _ffi.lib().xms_abi_version() == 1
     assert b"gfx950" in _ffi.lib().xm_strerror(-2)
 
 
@@ -252,7 +252,7 @@ class _FakeParser(object):
 
 @pytest.mark.parametrize("err", ["ENOSPC", "EDQUOT", "EFBIG"])
 def test_mapped_writer_does_not_map_what_it_could_not_allocate(tmp_path, monkeypatch, err):
-    """posix_fallocate failing for lack of space (or quota, or the file size limit) must not be papered over with a
+    """fallocate failing for lack of space (or quota, or the file size limit) must not be papered over with a
     sparse ftruncate -- storing into pages that cannot be backed dies with SIGBUS.  The range is given back and the
     caller's ordinary write raises the real error, as the reference's print() would."""
     import errno
@@ -264,7 +264,7 @@ def test_mapped_writer_does_not_map_what_it_could_not_allocate(tmp_path, monkeyp
 
         def no_space(fd, off, length):
             raise OSError(getattr(errno, err), os.strerror(getattr(errno, err)))
-        monkeypatch.setattr(os, "posix_fallocate", no_space)
+        monkeypatch.setattr(xm, "_fallocate", no_space)
         fake = _FakeParser(4 << 20)
         assert xm._emit_into_file(fake, True, 0, None, sink) is False
         assert fake.calls == 0
@@ -281,7 +281,7 @@ def test_mapped_writer_falls_back_to_a_sparse_extension_only_where_preallocation
 
         def unsupported(fd, off, length):
             raise OSError(errno.EOPNOTSUPP, os.strerror(errno.EOPNOTSUPP))
-        monkeypatch.setattr(os, "posix_fallocate", unsupported)
+        monkeypatch.setattr(xm, "_fallocate", unsupported)
         fake = _FakeParser(2 << 20)
         assert xm._emit_into_file(fake, True, 0, None, sink) is True
         sink.write("tail\n")
@@ -313,6 +313,59 @@ def test_mapped_writer_extends_files_ahead_and_cuts_them_back(tmp_path):
     data = path.read_bytes()
     want = b"@HD\n" + b"x" * (2 << 20) + b"small\n" + b"x" * (2 << 20) + b"x" * (9 << 20) + b"tail\n"
     assert data == want
+
+
+def test_fallocate_is_the_system_call_and_reports_what_it_cannot_do(tmp_path):
+    """_fallocate is fallocate(2) itself: it allocates on a file system that can (tmp_path), and on one that cannot it must
+    fail with an errno instead of writing zeros block by block as glibc's posix_fallocate does (/proc: EBADF / EOPNOTSUPP /
+    ENODEV ... -- anything but success)."""
+    import os
+    from xenomapper_amd import xenomapper as xm
+    path = tmp_path / "f"
+    fd = os.open(path, os.O_RDWR | os.O_CREAT)
+    try:
+        xm._fallocate(fd, 0, 1 << 20)
+        assert os.fstat(fd).st_size == 1 << 20
+    finally:
+        os.close(fd)
+    fd = os.open("/proc/self/status", os.O_RDONLY)
+    try:
+        with pytest.raises(OSError):
+            xm._fallocate(fd, 0, 4096)
+    finally:
+        os.close(fd)
+
+
+def test_small_bins_wait_for_the_extension_running_ahead(tmp_path):
+    """A bin below the mapping threshold is written through the sink by the caller: _emit_into_file must first have waited
+    for the helper thread that is allocating further down the same file."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from xenomapper_amd import xenomapper as xm
+    path = tmp_path / "bin.sam"
+    ahead, pool = {}, ThreadPoolExecutor(max_workers=1)
+    gate = threading.Event()
+    with open(path, "wt") as sink:
+        sink.write("@HD\n")
+        fake = _FakeParser(2 << 20)
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True
+        state = ahead[id(sink)]
+        state.settle()
+        released = []
+
+        def slow():
+            gate.wait(5)
+            released.append(True)
+            return state.size
+        state.job = pool.submit(slow)                                # an extension that is still under way
+        fake.need = 100                                               # too small for the mapping
+        threading.Timer(0.2, gate.set).start()
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is False
+        assert released and state.job is None                        # it waited for the helper before handing back
+        sink.write("small\n")
+        state.finish(sink)
+    pool.shutdown()
+    assert path.read_bytes() == b"@HD\n" + b"x" * (2 << 20) + b"small\n"
 
 
 def test_mapped_writer_never_extends_an_append_mode_file_ahead(tmp_path):

@@ -12,11 +12,13 @@ import os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ("xenomapper_amd/csrc/xm_kernels.hip", "xenomapper_amd/csrc/xm_kernels.h", "xenomapper_amd/csrc/xm_api.hip",
                   "include/xenomapper_hip.h")
+# the strip kernels' PMC table (profiles/*_strip_pmc.json) is guarded the same way, by the sources IT was measured on
+STRIP_SOURCES = ("xenomapper_amd/csrc/xm_strip.hip", "include/xenomapper_strip.h")
 
 
-def kernel_src_sha256(repo=REPO, flags=None):
+def kernel_src_sha256(repo=REPO, flags=None, sources=None):
     h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
+    for rel in (sources or KERNEL_SOURCES):
         with open(os.path.join(repo, rel), "rb") as fh:
             h.update(rel.encode() + b"\0" + fh.read() + b"\0")
     flags = os.environ.get("XENOMAPPER_HIPCC_FLAGS", "") if flags is None else flags
@@ -43,5 +45,10 @@ def load_traffic(workload, n_pairs, repo=REPO, path=None):
     return ent.get("classify_hbm_bytes_per_launch"), ent.get("step_hbm_bytes"), src
 
 
+def strip_src_sha256(repo=REPO, flags=None):
+    return kernel_src_sha256(repo, flags, STRIP_SOURCES)
+
+
 if __name__ == "__main__":
-    print(kernel_src_sha256())
+    import sys
+    print(strip_src_sha256() if "--strip" in sys.argv else kernel_src_sha256())

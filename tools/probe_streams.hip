@@ -85,8 +85,76 @@ static void run_write(unsigned *buf, size_t bytes)
            NT ? "nt" : "plain", ms[ms.size() / 2] * 1e3, ms[0] * 1e3, (double)bytes / (ms[ms.size() / 2] * 1e-3) / 1e12);
 }
 
-int main()
+// The same bytes from a PERSISTENT grid (MI355X_MICROARCH.md's "plain stores of the same shape" row: one dword per lane,
+// 256 B per wave instruction, 8 waves per CU -> 6.0-6.2 TB/s): WAVES_PER_CU x 256 CUs waves, each wave writes 256-byte
+// (dword per lane) or 1-KiB (16 B per lane) pieces; ROWS: pieces of one wave are `nwaves` apart (a grid-stride loop);
+// otherwise every wave owns one contiguous chunk.  UNROLL stores are issued back to back.
+template <bool W4, bool ROWS, int UNROLL>
+__global__ void __launch_bounds__(256) write_loop(unsigned *out, size_t words, unsigned nwaves)
 {
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t piece_words = W4 ? 256 : 64;                      // words one wave instruction writes
+    const size_t pieces = words / piece_words;
+    const size_t per_wave = (pieces + nwaves - 1) / nwaves;
+    for (size_t k0 = 0; k0 < per_wave; k0 += UNROLL) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const size_t k = k0 + u;
+            const size_t piece = ROWS ? k * nwaves + wave : wave * per_wave + k;
+            if (k < per_wave && piece < pieces) {
+                const size_t i = piece * piece_words + lane * (W4 ? 4 : 1);
+                if (W4) { v4i v = {(int)i, (int)i + 1, (int)i + 2, (int)i + 3}; *reinterpret_cast<v4i *>(out + i) = v; }
+                else out[i] = (unsigned)i;
+            }
+        }
+    }
+}
+
+template <bool W4, bool ROWS, int UNROLL>
+static void run_write_loop(unsigned *buf, size_t bytes, int waves_per_cu)
+{
+    const size_t words = bytes / 4;
+    const unsigned nwaves = 256u * (unsigned)waves_per_cu;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    std::vector<float> ms;
+    for (int it = 0; it < 12; ++it) {
+        CK(hipEventRecord(a));
+        write_loop<W4, ROWS, UNROLL><<<nwaves / 4, 256>>>(buf, words, nwaves);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float t; CK(hipEventElapsedTime(&t, a, b));
+        if (it >= 2) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    printf("write-loop %5zu MB  %2d B/lane %2d waves/CU %-6s unroll %d  median %.1f us  min %.1f us  ->  %.2f TB/s (median)\n", bytes >> 20,
+           W4 ? 16 : 4, waves_per_cu, ROWS ? "rows" : "chunks", UNROLL, ms[ms.size() / 2] * 1e3, ms[0] * 1e3,
+           (double)bytes / (ms[ms.size() / 2] * 1e-3) / 1e12);
+}
+
+int main(int argc, char **argv)
+{
+    const bool writes_only = argc > 1 && argv[1][0] == 'w';
+    if (writes_only) {
+        unsigned *wb;
+        CK(hipMalloc(&wb, 2048ull << 20));
+        CK(hipMemset(wb, 1, 2048ull << 20));
+        for (size_t mb : {200, 2000}) {
+            run_write<false, false>(wb, mb << 20);
+            run_write<true, false>(wb, mb << 20);
+            for (int wpc : {8, 16, 32}) {
+                run_write_loop<false, true, 1>(wb, mb << 20, wpc);
+                run_write_loop<false, true, 4>(wb, mb << 20, wpc);
+                run_write_loop<false, false, 4>(wb, mb << 20, wpc);
+                run_write_loop<true, true, 1>(wb, mb << 20, wpc);
+                run_write_loop<true, true, 4>(wb, mb << 20, wpc);
+                run_write_loop<true, false, 4>(wb, mb << 20, wpc);
+            }
+        }
+        return 0;
+    }
+
     const size_t total = 2400ull << 20;                          // 2.4 GiB read per launch, whatever K
     v4i *buf; unsigned *out;
     CK(hipMalloc(&buf, total + (64u << 20)));

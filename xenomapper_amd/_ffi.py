@@ -116,6 +116,9 @@ def lib():
         "xm_classify_place_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, U64, P, P], I),
         "xm_classify_place_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P, U64, P, P], I),
         "xm_classify_place_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, U64, P, P], I),
+        "xm_classify_runs_dev": ([P, P, I, U64, P, P, P, P, P, I32, P, P, P, P], I),
+        "xm_classify_runs_f64_dev": ([P, P, I, U64, P, P, P, P, P, F64, P, P, P, P], I),
+        "xm_runs_expand": ([U64, P, P, I, P, U64, ctypes.POINTER(U64)], I),
         "xm_stream_probe_dev": ([P, P, U64, P, P, P, P, P], I),
         "xm_workspace_is_clean": ([P, ctypes.POINTER(I)], I),
         "xm_comm_unique_id": ([P], I),
@@ -155,7 +158,8 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
             "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister",
             "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev",
-            "xm_classify_place_cigar_packed_dev", "xm_stream_probe_dev", "xm_workspace_is_clean",
+            "xm_classify_place_cigar_packed_dev", "xm_classify_runs_dev", "xm_classify_runs_f64_dev", "xm_runs_expand",
+            "xm_stream_probe_dev", "xm_workspace_is_clean",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
@@ -169,6 +173,32 @@ def _np_ptr(a):
 def _as(a, dtype):
     a = np.ascontiguousarray(a, dtype=dtype)
     return a
+
+
+RUNS_GRAN = 2048
+
+
+def runs_granules(n_records):
+    """XM_RUNS_GRANULES: granules of 2048 records of the segmented bin lists (xm_classify_runs*_dev)."""
+    return (int(n_records) + RUNS_GRAN - 1) // RUNS_GRAN
+
+
+def runs_expand(n_records, runs16, gran_counts, bin):
+    """List `bin` (0..6) of the segmented form as a flat uint32 array of record indices in input order (xm_runs_expand;
+    host arrays, no device)."""
+    runs16 = _as(runs16, np.uint16)
+    gran_counts = _as(gran_counts, np.uint16)
+    n = int(n_records)
+    assert runs16.shape[0] >= runs_granules(n) * RUNS_GRAN and gran_counts.shape[0] >= runs_granules(n) * 8
+    L = lib()
+    k = ctypes.c_uint64()
+    rc = L.xm_runs_expand(n, _np_ptr(runs16), _np_ptr(gran_counts), int(bin), None, 0, ctypes.byref(k))
+    if rc == XM_OK:
+        out = np.empty(max(int(k.value), 1), dtype=np.uint32)
+        rc = L.xm_runs_expand(n, _np_ptr(runs16), _np_ptr(gran_counts), int(bin), _np_ptr(out), out.shape[0], ctypes.byref(k))
+    if rc != XM_OK:
+        raise _ERRORS.get(rc, RuntimeError)("xm_runs_expand: %s" % L.xm_strerror(rc).decode())
+    return out[:int(k.value)]
 
 
 def cigar_tiles(n_records):
@@ -532,6 +562,21 @@ class Context(object):
             opt(range_flag), arr, cap, opt(n_out), opt(counts))
         self._check(rc, "xm_classify_place_cigar_packed_dev")
 
+    def classify_runs_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, runs16, gran_counts, n_out, counts, stream=None):
+        """The fused main loop with SEGMENTED bin lists, one launch (xm_classify_runs*_dev): runs16 = int16 device tensor of
+        runs_granules(n) * 2048 entries, gran_counts = int16 device tensor of runs_granules(n) * 8, n_out 8 x int64,
+        counts 64 x int64.  Columns int32 or float64.  Asynchronous."""
+        n = as1.numel()
+        st = self._stream_handle(stream)
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (as1, xs1, as2, xs2, unit_bits)]
+        outs = [ctypes.c_void_p(t.data_ptr()) for t in (runs16, gran_counts, n_out, counts)]
+        assert runs16.numel() >= runs_granules(n) * RUNS_GRAN and gran_counts.numel() >= runs_granules(n) * 8
+        if as1.element_size() == 4:
+            rc = self._L.xm_classify_runs_dev(self._h, st, mode, n, *ptrs, int(min_score), *outs)
+        else:
+            rc = self._L.xm_classify_runs_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), *outs)
+        self._check(rc, "xm_classify_runs_dev")
+
     def workspace_is_clean(self):
         """Synchronises; True when the counting workspace is in its between-calls state (all zero)."""
         flag = ctypes.c_int(0)
@@ -697,6 +742,7 @@ class Stripper(object):
         have = self._cap[slot]
         if window_bytes > have[0] or max_records > have[1]:
             want = (max(window_bytes, have[0]), max(max_records, have[1]))
+            self._cap[slot] = (0, 0)             # a failed growth leaves the slot without buffers: never trust the old sizes
             self._check(self._L.xm_strip_reserve(self._h, slot, want[0], want[1]), "xm_strip_reserve")
             self._cap[slot] = want
 

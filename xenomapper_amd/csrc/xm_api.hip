@@ -30,7 +30,8 @@ struct xm_ctx {
     uint32_t *d_gran_off;           // [8 bins][granule]: K2b's exclusive scan of the above
     uint64_t *d_counts_rep;         // XM_COUNT_REPLICAS x 64 partial category_counts (all zero between calls), then 8 bin totals
     uint32_t *d_part_tot;           // [8][XM_PART_STRIDE]: per-part bin totals (K2b's first level)
-    // the stream the workspace was last used on: a call on another stream is ordered behind it (order_workspace)
+    // the stream the workspace was last used on (compared only) and the event recorded behind that call's last launch:
+    // a call on another stream waits for the event (order_workspace / workspace_done)
     hipStream_t ws_stream;
     bool ws_used;
     hipEvent_t ws_event;
@@ -157,26 +158,40 @@ void reset_count_state(xm_ctx *ctx, hipStream_t st)
 
 // The compaction workspace (per-granule counts and offsets, the count replicas, the part totals) belongs to the context:
 // calls that use it must not overlap.  Calls on one stream are ordered anyway; a call on ANOTHER stream than the previous
-// one is put behind everything enqueued on that stream so far (an event recorded there now, waited for here): no per-call
-// cost while one stream is used.  A capturing stream is left alone: the graph's own edges order its nodes, and events
-// cannot be mixed into a capture from outside.
-int order_workspace(xm_ctx *ctx, hipStream_t st)
+// one waits (hipStreamWaitEvent) for the event the previous call recorded behind its last launch (workspace_done).  The
+// event, not the previous stream, is what is kept: that stream may have been destroyed since (round 4 kept the handle and
+// recorded on it lazily -- a dangling handle once its owner, e.g. a Stripper, was closed).  A capturing stream is left
+// alone: the graph's own edges order its nodes, and events cannot be mixed into a capture from outside.
+bool capturing(hipStream_t st)
 {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
-    else if (cs != hipStreamCaptureStatusNone) return XM_OK;
-    if (ctx->ws_used && ctx->ws_stream != st) {
-        hipStreamCaptureStatus ps = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(ctx->ws_stream, &ps) != hipSuccess) { (void)hipGetLastError(); ps = hipStreamCaptureStatusNone; }
-        if (ps == hipStreamCaptureStatusNone) {
-            XM_HIP(ctx, hipEventRecord(ctx->ws_event, ctx->ws_stream));
-            XM_HIP(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
-        }
-    }
-    ctx->ws_stream = st;
-    ctx->ws_used = true;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+int order_workspace(xm_ctx *ctx, hipStream_t st)
+{
+    if (capturing(st)) return XM_OK;
+    if (ctx->ws_used && ctx->ws_stream != st) XM_HIP(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
     return XM_OK;
 }
+
+// behind the last launch of a call that used the workspace (also after a failed launch: whatever was enqueued counts)
+void workspace_done(xm_ctx *ctx, hipStream_t st)
+{
+    if (capturing(st)) return;
+    if (hipEventRecord(ctx->ws_event, st) != hipSuccess) { (void)hipGetLastError(); return; }
+    ctx->ws_stream = st;                 // only compared, never dereferenced
+    ctx->ws_used = true;
+}
+
+// runs workspace_done when the enclosing entry point returns, whichever way
+struct WorkspaceUse {
+    xm_ctx *ctx;
+    hipStream_t st;
+    WorkspaceUse(xm_ctx *c, hipStream_t s) : ctx(c), st(s) {}
+    ~WorkspaceUse() { workspace_done(ctx, st); }
+};
 
 }  // namespace
 
@@ -444,6 +459,7 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_
     const xm::CountPlan cp = count_plan(ctx, n);
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_HIST);
         xm::launch_hist(st, mode, n, code, cp);
@@ -470,6 +486,7 @@ int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     cp.bins4 = bins4;
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &cp);
@@ -494,6 +511,7 @@ int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     cp.bins4 = bins4;
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &cp);
@@ -553,6 +571,7 @@ int xm_classify_compact_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, ui
     const xm::CigCols s1 = {nm1, xs1, cnt1, tile1, ops1}, s2 = {nm2, xs2, cnt2, tile2, ops2};
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_cigp(st, mode, n, s1, s2, unit_bits, min_score_floor, code_out, range_flag, cp);
@@ -594,6 +613,7 @@ int xm_classify_place_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     xm::CountPlan cp = count_plan(ctx, n);
     cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &cp);
@@ -621,6 +641,7 @@ int xm_classify_place_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     xm::CountPlan cp = count_plan(ctx, n);
     cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &cp);
@@ -654,12 +675,88 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
     cp.bins4 = bins4;
     const xm::CigCols s1 = {nm1, xs1, cnt1, tile1, ops1}, s2 = {nm2, xs2, cnt2, tile2, ops2};
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_cigp(st, mode, n, s1, s2, unit_bits, min_score_floor, code_out, range_flag, cp);
     }
     if ((rc = check_launch(ctx, "classify_cigp_kernel")) != XM_OK) return rc;
     return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
+}
+
+/* ---- segmented bin lists: one launch, no scan, no scatter ------------------------------------------------------- */
+
+static int runs_common(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, size_t elem,
+                       const void *as1, const void *xs1, const void *as2, const void *xs2, const uint64_t *unit_bits,
+                       int32_t mi, double mf, uint16_t *runs16, uint16_t *gran_counts, uint64_t *n_out, uint64_t *counts)
+{
+    if (!ctx || bad_mode(mode) || n > XM_MAX_RECORDS || wrong_device(ctx)) return XM_ERR_INVALID_ARG;
+    if (!n_out || !counts) return XM_ERR_INVALID_ARG;
+    if (n == 0) return empty_compact(ctx, st, n_out, counts);
+    if (!as1 || !xs1 || !as2 || !xs2 || !unit_bits || !runs16 || !gran_counts) return XM_ERR_INVALID_ARG;
+    const uintptr_t col_mask = elem == 8 ? 31u : 15u;
+    if ((((uintptr_t)as1 | (uintptr_t)xs1 | (uintptr_t)as2 | (uintptr_t)xs2) & col_mask) ||
+        (((uintptr_t)runs16 | (uintptr_t)gran_counts) & 15u))
+        return XM_ERR_INVALID_ARG;
+    const xm::RunsOut ro = {runs16, gran_counts, ctx->d_counts_rep};
+    int rc;
+    if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, st);
+    {
+        Span span(ctx, st, XM_K_CLASSIFY);
+        if (elem == 4)
+            xm::launch_classify_runs_i32(st, mode, n, (const int32_t *)as1, (const int32_t *)xs1, (const int32_t *)as2,
+                                         (const int32_t *)xs2, unit_bits, mi, ro);
+        else
+            xm::launch_classify_runs_f64(st, mode, n, (const double *)as1, (const double *)xs1, (const double *)as2,
+                                         (const double *)xs2, unit_bits, mf, ro);
+    }
+    if ((rc = check_launch(ctx, "classify_runs_kernel")) != XM_OK) return rc;
+    {
+        Span span(ctx, st, XM_K_SCAN);
+        xm::launch_runs_finish(st, mode, ctx->d_counts_rep, counts, n_out);
+    }
+    if ((rc = check_launch(ctx, "runs_finish_kernel")) != XM_OK) reset_count_state(ctx, st);
+    return rc;
+}
+
+int xm_classify_runs_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                         const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                         const uint64_t *unit_bits, int32_t min_score_floor,
+                         uint16_t *runs16, uint16_t *gran_counts, uint64_t *n_out, uint64_t *counts)
+{
+    return runs_common(ctx, (hipStream_t)stream, mode, n, 4, as1, xs1, as2, xs2, unit_bits, min_score_floor, 0.0,
+                       runs16, gran_counts, n_out, counts);
+}
+
+int xm_classify_runs_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
+                             const double *as1, const double *xs1, const double *as2, const double *xs2,
+                             const uint64_t *unit_bits, double min_score,
+                             uint16_t *runs16, uint16_t *gran_counts, uint64_t *n_out, uint64_t *counts)
+{
+    return runs_common(ctx, (hipStream_t)stream, mode, n, 8, as1, xs1, as2, xs2, unit_bits, 0, min_score,
+                       runs16, gran_counts, n_out, counts);
+}
+
+/* Host side of the contract (no device needed): list `bin` of the segmented form as a flat list. */
+int xm_runs_expand(uint64_t n, const uint16_t *runs16, const uint16_t *gran_counts, int bin,
+                   uint32_t *idx_out, uint64_t capacity, uint64_t *n_written)
+{
+    if (n > XM_MAX_RECORDS || bin < 0 || bin > 6 || !n_written || (n && (!runs16 || !gran_counts))) return XM_ERR_INVALID_ARG;
+    const uint64_t n_gran = (n + XM_GRAN - 1) / XM_GRAN;
+    uint64_t w = 0;
+    for (uint64_t g = 0; g < n_gran; ++g) {
+        const uint16_t *c = gran_counts + g * 8;
+        uint32_t at = 0;
+        for (int b = 0; b < bin; ++b) at += c[b];
+        const uint32_t k = c[bin];
+        if (at + k > XM_GRAN) return XM_ERR_INVALID_ARG;                  // not counts the kernel wrote
+        const uint16_t *run = runs16 + g * XM_GRAN + at;
+        for (uint32_t i = 0; i < k; ++i, ++w)
+            if (idx_out && w < capacity) idx_out[w] = (uint32_t)(g * XM_GRAN) + run[i];
+    }
+    *n_written = w;
+    return XM_OK;
 }
 
 int xm_workspace_is_clean(xm_ctx *ctx, int *clean)
@@ -744,6 +841,7 @@ static int classify_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const v
     // category_counts come from the counting form of the kernel (+ K2b, which adds the replicas up)
     const xm::CountPlan cp = count_plan(ctx, n);
     if (counts && (rc = order_workspace(ctx, nullptr)) != XM_OK) return rc;
+    WorkspaceUse ws_use(ctx, nullptr);            // (also without counts: harmless)
     {
         Span span(ctx, nullptr, XM_K_CLASSIFY);
         if (elem == 4)

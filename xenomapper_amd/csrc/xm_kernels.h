@@ -52,6 +52,21 @@ struct ListOut {
     uint32_t cap;               // capacity of every list, in entries
 };
 
+// segmented bin lists (xm_classify_runs*): where the runs kernel leaves its results
+struct RunsOut {
+    uint16_t *runs16;           // [n_gran][XM_GRAN]: granule-local record numbers of the granule's units, sorted by bin
+    uint16_t *gran_counts16;    // [n_gran][8]: units per bin of every granule
+    uint64_t *counts_rep;       // the context's [XM_COUNT_REPLICAS][64], all zero between calls
+};
+void launch_classify_runs_i32(hipStream_t st, int mode, uint64_t n,
+                              const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                              const uint64_t *unit_bits, int32_t m, const RunsOut &ro);
+void launch_classify_runs_f64(hipStream_t st, int mode, uint64_t n,
+                              const double *as1, const double *xs1, const double *as2, const double *xs2,
+                              const uint64_t *unit_bits, double m, const RunsOut &ro);
+// adds up the category_counts replicas (left zeroed) and derives the eight list lengths
+void launch_runs_finish(hipStream_t st, int mode, uint64_t *counts_rep, uint64_t *counts, uint64_t *n_out);
+
 // cp != nullptr: the fused form, the kernel also counts (granule = its workgroup)
 void launch_classify_i32(hipStream_t st, int mode, uint64_t n,
                          const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,

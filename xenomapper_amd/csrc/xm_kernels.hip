@@ -823,6 +823,205 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1r: classify + SEGMENTED bin lists in one launch (xm_classify_runs*).  The six flat lists of K2 need a prefix over all
+// granules in front (K2b; a look-back inside one launch lost by 3-7x in round 4); segmented by
+// granule they need none: the workgroup = granule sorts its units by output bin inside an LDS slab (16-bit record numbers
+// counted from the granule's first record: ranks by ballot + mbcnt per wave, per-wave bin counts through LDS, one
+// barrier) and copies the slab out as it stands with 16-byte stores, next to the granule's eight bin counts.  List b in
+// input order = for every granule in order, its run of bin b.  2 bytes per unit written instead of 1/2 + 4, nothing read
+// twice, one launch (+ a 1-workgroup launch that adds up the category_counts replicas).
+// The reference code this replaces: the bodies of the three main loops, xenomapper.py:321-350, :398-452, :498-554.
+// ---------------------------------------------------------------------------------------------
+// LDS words: histogram [64][XM_HREP] | per-wave bin counts [8 waves][8] | slab XM_GRAN u16
+#define XM_RUNS_WCNT_AT (64 * XM_HREP)
+#define XM_RUNS_SLAB_AT (XM_RUNS_WCNT_AT + 64)
+#define XM_RUNS_LDS_WORDS (XM_RUNS_SLAB_AT + XM_GRAN / 2)
+
+struct RunsSink {
+    uint16_t *runs16;                    // [n_gran][XM_GRAN]
+    uint16_t *gran_counts16;             // [n_gran][8]
+    unsigned long long *counts_rep;      // [XM_COUNT_REPLICAS][64] (the context's; all zero between calls)
+};
+
+// ranks of the lane's units inside the wave, per bin: pos[j] = units of bin[j] in lower lanes and lower positions of this
+// lane; returns (lane b) the wave's units of bin b
+template <int SLOTS, int NB>
+__device__ __forceinline__ uint32_t runs_ranks(const uint32_t bin[4], uint32_t pos[4])
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t wc = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        uint64_t m[4], any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = ((SLOTS >> j) & 1) ? __ballot(bin[j] == (uint32_t)b) : 0ull;
+            any |= m[j];
+        }
+        if (any == 0ull) continue;                                        // wave-uniform
+        uint32_t t = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((SLOTS >> j) & 1) { t = mbcnt64(m[j], t); total += (uint32_t)__builtin_popcountll(m[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((SLOTS >> j) & 1) pos[j] = (bin[j] == (uint32_t)b) ? t : pos[j];
+        wc = (lane == (uint32_t)b) ? total : wc;
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < j; ++i)
+            if (((SLOTS >> j) & 1) && ((SLOTS >> i) & 1)) pos[j] += (bin[i] == bin[j]) ? 1u : 0u;
+    return wc;
+}
+
+template <typename T, bool PAIRED, bool NT, int BLOCK, bool FULL, int BINMODE>
+__device__ __forceinline__ void classify_runs_body(const T *__restrict__ as1, const T *__restrict__ xs1,
+                                                   const T *__restrict__ as2, const T *__restrict__ xs2,
+                                                   const uint8_t *__restrict__ unit_bits8, T m, uint64_t n,
+                                                   uint32_t *last_state, uint32_t *lds, const RunsSink &rs)
+{
+    static_assert(BLOCK == 512 && BLOCK * 4 == XM_GRAN, "eight waves, one granule");
+    constexpr bool HAS6 = sizeof(T) == 8;
+    constexpr int NB = HAS6 ? 7 : 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t g = blockIdx.x;
+    const uint64_t g4 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t r0 = g4 * 4;
+    T a1[4], x1[4], a2[4], x2[4];
+    load4<T, NT, FULL>(as1, r0, n, a1);
+    load4<T, NT, FULL>(xs1, r0, n, x1);
+    load4<T, NT, FULL>(as2, r0, n, a2);
+    load4<T, NT, FULL>(xs2, r0, n, x2);
+    uint32_t mb = 0;
+    if (FULL || r0 < n) mb = (uint32_t)(unit_bits8[g4 >> 1] >> ((g4 & 1u) * 4u)) & 0xFu;
+    if (!FULL && r0 + 4 > n) mb &= (r0 < n) ? ((1u << (uint32_t)(n - r0)) - 1u) : 0u;
+    uint32_t halo = 0;
+    if (PAIRED && threadIdx.x == 0) {
+        if (r0 > 0) {
+            const uint64_t h = r0 - 1;
+            halo = mapping_state<T>(as1[h], xs1[h], as2[h], xs2[h], m);
+        } else {
+            mb &= ~1u;                                                    // record 0 has no predecessor (:402)
+        }
+    }
+    uint32_t s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = mapping_state<T>(a1[j], x1[j], a2[j], x2[j], m);
+    uint32_t c[4], fwd[4] = {0, 0, 0, 0};
+    if (PAIRED) {
+        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[3], 0x138, 0xf, 0xf, false);
+        if (lane == 63) last_state[wave] = s[3];
+        __syncthreads();                                                  // also: the zeroed histogram is visible
+        if (lane == 0) prev = (wave == 0) ? halo : last_state[wave - 1];
+        c[0] = (mb & 1u) ? ((prev << 3) | s[0]) : XM_NO_UNIT;
+        c[1] = (mb & 2u) ? ((s[0] << 3) | s[1]) : XM_NO_UNIT;
+        c[2] = (mb & 4u) ? ((s[1] << 3) | s[2]) : XM_NO_UNIT;
+        c[3] = (mb & 8u) ? ((s[2] << 3) | s[3]) : XM_NO_UNIT;
+        fwd[0] = prev; fwd[1] = s[0]; fwd[2] = s[1]; fwd[3] = s[2];
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = ((mb >> j) & 1u) ? s[j] : XM_NO_UNIT;
+    }
+    uint32_t bin[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bin[j] = unit_bin_of<BINMODE, HAS6>(fwd[j], s[j], ((mb >> j) & 1u) != 0u);
+    {   // category_counts: the workgroup's histogram (as count_units)
+        const uint32_t rep = lane & (XM_HREP - 1u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool unit = c[j] != XM_NO_UNIT;
+            if (__ballot(unit) == 0ull) continue;
+            if (unit) atomicAdd(&lds[(c[j] & 63u) * XM_HREP + rep], 1u);
+        }
+    }
+    uint32_t pos[4] = {0, 0, 0, 0};
+    const bool inter = PAIRED && __ballot((mb & 5u) != 0u) == 0ull;     // strictly interleaved mates: positions 1 and 3 only
+    const uint32_t wc = inter ? runs_ranks<0xA, NB>(bin, pos) : runs_ranks<0xF, NB>(bin, pos);
+    uint32_t *wave_cnt = lds + XM_RUNS_WCNT_AT;
+    uint16_t *slab = reinterpret_cast<uint16_t *>(lds + XM_RUNS_SLAB_AT);
+    if (lane < 8u) wave_cnt[wave * 8u + lane] = wc;
+    __syncthreads();
+    uint32_t off, tot;                                                   // lane: bin lane & 7 -- units in the waves before / in all waves
+    {
+        const uint32_t v = wave_cnt[lane];                               // lane = 8 w + b
+        off = (lane >> 3) < wave ? v : 0u;
+        tot = v;
+        off += (uint32_t)__shfl_xor((int)off, 8, 64);  tot += (uint32_t)__shfl_xor((int)tot, 8, 64);
+        off += (uint32_t)__shfl_xor((int)off, 16, 64); tot += (uint32_t)__shfl_xor((int)tot, 16, 64);
+        off += (uint32_t)__shfl_xor((int)off, 32, 64); tot += (uint32_t)__shfl_xor((int)tot, 32, 64);
+    }
+    const uint32_t t8 = lane < 8u ? tot : 0u;                            // lanes 0..7: the granule's units per bin
+    const uint32_t incl8 = wave_scan_incl(t8);
+    const uint32_t where = incl8 - t8 + off;                             // lane b < 8: this wave's run of bin b in the slab
+    const uint32_t units = lane_value(incl8, 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t at = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) at = (bin[j] == (uint32_t)b) ? lane_value(where, b) : at;
+        if (bin[j] < 7u) slab[at + pos[j]] = (uint16_t)(threadIdx.x * 4u + (uint32_t)j);
+    }
+    __syncthreads();                                                     // the slab and the histogram are complete
+    // the slab as it stands: 16 bytes per thread (entries past the granule's units are not written)
+    if (threadIdx.x < (uint32_t)(XM_GRAN / 8) && threadIdx.x * 8u < units)
+        reinterpret_cast<uint4 *>(rs.runs16 + (uint64_t)g * XM_GRAN)[threadIdx.x] = reinterpret_cast<const uint4 *>(slab)[threadIdx.x];
+    if (wave == 0u) {
+        if (lane < 8u) rs.gran_counts16[(uint64_t)g * 8u + lane] = (uint16_t)tot;
+        const uint4 h0 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP);
+        const uint4 h1 = *reinterpret_cast<const uint4 *>(lds + lane * XM_HREP + 4);
+        const uint32_t sum = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
+        if (sum != 0u) atomicAdd(&rs.counts_rep[(g % XM_COUNT_REPLICAS) * 64u + lane], (unsigned long long)sum);
+    }
+}
+
+template <typename T, bool PAIRED, bool NT, int BLOCK, int BINMODE>
+__global__ void __launch_bounds__(BLOCK)
+classify_runs_kernel(const T *__restrict__ as1, const T *__restrict__ xs1, const T *__restrict__ as2, const T *__restrict__ xs2,
+                     const uint8_t *__restrict__ unit_bits8, T m, uint64_t n, RunsSink rs)
+{
+    __shared__ uint32_t last_state[BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[XM_RUNS_LDS_WORDS];
+    for (uint32_t q = threadIdx.x; q < 64u * XM_HREP; q += BLOCK) lds[q] = 0;
+    if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
+        classify_runs_body<T, PAIRED, NT, BLOCK, true, BINMODE>(as1, xs1, as2, xs2, unit_bits8, m, n, last_state, lds, rs);
+    else
+        classify_runs_body<T, PAIRED, NT, BLOCK, false, BINMODE>(as1, xs1, as2, xs2, unit_bits8, m, n, last_state, lds, rs);
+}
+
+// second, 1-workgroup launch: category_counts from the replicas (left zeroed), the eight list lengths from the counts
+__global__ void __launch_bounds__(256)
+runs_finish_kernel(unsigned long long *__restrict__ counts_rep, unsigned long long *__restrict__ counts,
+                   unsigned long long *__restrict__ n_out, int mode)
+{
+    __shared__ unsigned long long part[4][64];
+    __shared__ unsigned long long bins[8];
+    const uint32_t slot = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    unsigned long long acc = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < XM_COUNT_REPLICAS / 4u; ++r) {
+        acc += counts_rep[(q * (XM_COUNT_REPLICAS / 4u) + r) * 64u + slot];
+        counts_rep[(q * (XM_COUNT_REPLICAS / 4u) + r) * 64u + slot] = 0;
+    }
+    part[q][slot] = acc;
+    if (threadIdx.x < 8u) bins[threadIdx.x] = 0;
+    __syncthreads();
+    if (q == 0u) {
+        const unsigned long long v = part[0][slot] + part[1][slot] + part[2][slot] + part[3][slot];
+        counts[slot] = v;
+        if (v != 0ull) {
+            atomicAdd(&bins[bin_of_code(mode, slot)], v);                 // a counted slot is never 0xFF: bin <= 6
+            atomicAdd(&bins[7], v);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8u) n_out[threadIdx.x] = bins[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3: CIGAR-derived AS (one lane per record, CSR ops)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(XM_BLOCK)
@@ -1586,6 +1785,46 @@ void launch_classify_f64(hipStream_t st, int mode, uint64_t n,
                          const uint64_t *unit_bits, double m, uint8_t *code, const CountPlan *cp)
 {
     launch_classify_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, code, cp);
+}
+
+template <typename T>
+static void launch_classify_runs_t(hipStream_t st, int mode, uint64_t n,
+                                   const T *as1, const T *xs1, const T *as2, const T *xs2,
+                                   const uint64_t *unit_bits, T m, const RunsOut &ro)
+{
+    const uint64_t per_block = (uint64_t)XM_CLASSIFY_BLOCK * 4;
+    const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
+    const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
+    RunsSink rs;
+    rs.runs16 = ro.runs16;
+    rs.gran_counts16 = ro.gran_counts16;
+    rs.counts_rep = reinterpret_cast<unsigned long long *>(ro.counts_rep);
+#define XM_LAUNCH_RUNS(P, B) classify_runs_kernel<T, P, XM_CLASSIFY_NT, XM_CLASSIFY_BLOCK, B><<<grid, XM_CLASSIFY_BLOCK, 0, st>>>(as1, xs1, as2, xs2, bits8, m, n, rs)
+    if (mode == XM_MODE_SE) XM_LAUNCH_RUNS(false, XM_MODE_SE);
+    else if (mode == XM_MODE_PE_LIBERAL) XM_LAUNCH_RUNS(true, XM_MODE_PE_LIBERAL);
+    else XM_LAUNCH_RUNS(true, XM_MODE_PE_CONSERVATIVE);
+#undef XM_LAUNCH_RUNS
+}
+
+void launch_classify_runs_i32(hipStream_t st, int mode, uint64_t n,
+                              const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
+                              const uint64_t *unit_bits, int32_t m, const RunsOut &ro)
+{
+    launch_classify_runs_t<int32_t>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, ro);
+}
+
+void launch_classify_runs_f64(hipStream_t st, int mode, uint64_t n,
+                              const double *as1, const double *xs1, const double *as2, const double *xs2,
+                              const uint64_t *unit_bits, double m, const RunsOut &ro)
+{
+    launch_classify_runs_t<double>(st, mode, n, as1, xs1, as2, xs2, unit_bits, m, ro);
+}
+
+void launch_runs_finish(hipStream_t st, int mode, uint64_t *counts_rep, uint64_t *counts, uint64_t *n_out)
+{
+    runs_finish_kernel<<<1, 256, 0, st>>>(reinterpret_cast<unsigned long long *>(counts_rep),
+                                          reinterpret_cast<unsigned long long *>(counts),
+                                          reinterpret_cast<unsigned long long *>(n_out), mode);
 }
 
 void launch_classify_cigar(hipStream_t st, int mode, uint64_t n,

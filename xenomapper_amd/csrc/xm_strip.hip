@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(SB) parse_kernel(const Job job)
     };
     auto word = [&](uint32_t wa, uint64_t w) {
         const uint32_t lo = start > wa ? start - wa : 0u, hi = min(end - wa, 8u);
+        if (lo >= hi) return;                                           // an empty line inside this word: no valid byte (the shifts below need one)
         const uint64_t H = 0x8080808080808080ull, O = 0x0101010101010101ull;
         // a whole word inside a mandatory field without a byte below 0x21 (the input is ASCII, or the result is thrown away):
         // nothing to learn from it but its length
@@ -993,6 +994,11 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
     XMS_HIP(s, hipSetDevice(s->device));
     Slot &sl = s->slot[slot];
     XMS_HIP(s, hipStreamSynchronize(sl.stream));
+    // a window begins here: whatever an abandoned one (a read that failed half way, a run that was never issued) had
+    // sent is forgotten, or the next upload from offset 0 would be refused for ever
+    sl.uploaded[0] = sl.uploaded[1] = 0;
+    sl.upload_timed = false;
+    // a failed growth leaves the capacity at 0 and the pointers freed or null: the next reserve allocates afresh
     XMS_TRY(grow_window(s, sl, std::max<uint64_t>(window_bytes, 1)));
     XMS_TRY(grow_records(s, sl, max_records));
     return XM_OK;
@@ -1008,6 +1014,7 @@ int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t b
 {
     if (!s || slot < 0 || slot >= XMS_SLOTS || file < 0 || file > 1) return XM_ERR_INVALID_ARG;
     Slot &sl = s->slot[slot];
+    if (offset == 0) sl.uploaded[file] = 0;                 // a new window of this file (the previous one may have been abandoned)
     if (offset != sl.uploaded[file] || offset + bytes > sl.window_cap) return XM_ERR_INVALID_ARG;
     if (bytes == 0) return XM_OK;
     XMS_HIP(s, hipSetDevice(s->device));
@@ -1246,6 +1253,16 @@ int xm_strip_device_columns(xm_strip *s, int slot, void *ptrs[5])
     return XM_OK;
 }
 
-const char *xm_strip_last_error(const xm_strip *s) { return s ? s->last_error.c_str() : ""; }
+const char *xm_strip_last_error(const xm_strip *s)
+{
+    // the other slot's thread may be assigning the text: copied under the lock into a buffer of the calling thread
+    static thread_local std::string mine;
+    if (!s) return "";
+    {
+        std::lock_guard<std::mutex> hold(const_cast<xm_strip *>(s)->error_lock);
+        mine = s->last_error;
+    }
+    return mine.c_str();
+}
 
 }  // extern "C"

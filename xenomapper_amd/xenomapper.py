@@ -74,6 +74,15 @@ def set_context(ctx):
 _stripper = None
 
 
+def _forget_stripper(stripper):
+    """A stripper whose step failed (its buffers could not be allocated, a read into them failed) is dropped, so that the
+    next run starts from a fresh one instead of inheriting a half-staged window.  Not closed here: the block before the
+    failed one may still be classified from its other slot by the main thread; it closes itself with its last reference."""
+    global _stripper
+    if _stripper is stripper:
+        _stripper = None
+
+
 def default_stripper():
     """The process-wide GPU column stripper of the default context (its page-locked staging buffers are kept)."""
     global _stripper
@@ -678,10 +687,39 @@ AHEAD_FACTOR = int(os.environ.get("XENOMAPPER_AHEAD", "2"))      # output files 
 _EMIT_CLOCK = {}            # seconds inside _emit_into_file by step, since the run began (shown with the phases of the run)
 
 
+_libc_fallocate = None
+
+
+def _fallocate(fd, offset, length):
+    """fallocate(2) itself (mode 0), not glibc's posix_fallocate: on a file system that cannot preallocate the latter
+    silently falls back to writing a zero into every block, which races with anything else that writes to the file (the
+    ahead-extension runs beside the sink); the system call fails with EOPNOTSUPP instead and the caller extends sparsely."""
+    global _libc_fallocate
+    if _libc_fallocate is None:
+        import ctypes
+        try:
+            fn = ctypes.CDLL(None, use_errno=True).fallocate
+            fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
+            fn.restype = ctypes.c_int
+            _libc_fallocate = fn
+        except (OSError, AttributeError):
+            _libc_fallocate = False
+    if _libc_fallocate is False:
+        os.posix_fallocate(fd, offset, length)
+        return
+    import ctypes
+    while _libc_fallocate(fd, 0, offset, length) != 0:
+        e = ctypes.get_errno()
+        if e != errno.EINTR:
+            raise OSError(e, os.strerror(e))
+
+
 class _AheadFile(object):
-    """An output file that is kept LONGER than its content while a run is writing it: posix_fallocate is one kernel thread
+    """An output file that is kept LONGER than its content while a run is writing it: fallocate is one kernel thread
     zeroing pages (~18 GB/s on tmpfs) and used to sit in front of every bin of every block; extended in the background,
-    ahead of the writer, it is off the critical path.  finish() cuts the file back to its content."""
+    ahead of the writer, it is off the critical path.  finish() cuts the file back to its content.  Until then the file
+    ends in NUL bytes: a process killed between two blocks leaves them behind (the content in front of them is complete
+    lines); only finish() -- reached on every exit of the run, exceptions included -- truncates."""
 
     def __init__(self, fd2, size):
         self.fd2, self.size, self.job = fd2, size, None
@@ -699,7 +737,7 @@ class _AheadFile(object):
     def extend_later(self, pool, upto):
         if self.job is None and upto > self.size:
             def work(fd2=self.fd2, start=self.size, n=upto - self.size):
-                os.posix_fallocate(fd2, start, n)
+                _fallocate(fd2, start, n)              # EOPNOTSUPP: no extension ahead (settle() swallows it)
                 return start + n
             self.job = pool.submit(work)
 
@@ -730,10 +768,12 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
     t0 = time.perf_counter()
     idx, need = parser.emit_size(paired, b, seg)
     _EMIT_CLOCK["emit_size"] = _EMIT_CLOCK.get("emit_size", 0.0) + time.perf_counter() - t0
+    state = ahead.get(id(sink)) if ahead is not None else None
     if need < MMAP_EMIT_MIN_BYTES:
+        if state is not None:
+            state.settle()          # the caller writes through the sink: not while the helper thread is allocating in the same file
         return False
     t0 = time.perf_counter()
-    state = ahead.get(id(sink)) if ahead is not None else None
     fd2, pos, size, opened = None, 0, 0, False
     try:
         sink.flush()
@@ -751,7 +791,7 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
             fd2, size = state.fd2, state.settle()
         if pos + need > size:
             try:
-                os.posix_fallocate(fd2, size, pos + need - size)   # extends the file AND allocates its pages in one go: the
+                _fallocate(fd2, size, pos + need - size)           # extends the file AND allocates its pages in one go: the
             except OSError as e:                                   # threads then only copy (page by page faults cost 3x on tmpfs)
                 # Only a file system that cannot preallocate may be extended sparsely instead.  Anything else -- no space
                 # left, a quota, the file size limit -- must NOT be papered over: stores into a mapping whose pages cannot
@@ -1081,22 +1121,32 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             try:
                 stripper.reserve(which, max(w[2] for w in wins), records)
             except MemoryError:                                      # page-locked or device memory ran out: the host threads strip
+                _forget_stripper(stripper)
                 stripper = None
+        blk = None
         if stripper is not None and max(w[2] for w in wins) <= _ffi.STRIP_MAX_WINDOW:
-            with prof("stage"):
-                # read(2) into page-locked memory, piece by piece: the upload of one piece hides the read of the next; no page
-                # of the inputs is mapped, and the writer gathers its lines from the staging buffer
-                for f, w in enumerate(wins):
-                    base = stripper.staging_address(which, f)
-                    for at in range(0, w[2], STAGE_PIECE):
-                        piece = min(STAGE_PIECE, w[2] - at)
-                        parsers[which].pread(sources[f].fileno(), w[1] + at, base + at, piece)
-                        stripper.upload(which, f, at, piece)
-            with prof("strip"):
-                blk = stripper.run(which, wins[0][2], wins[0][3], wins[1][2], wins[1][3], score_mode, paired, skip_repeated, paired,
-                                   records)
-                prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_upload
-                prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
+            try:
+                with prof("stage"):
+                    # read(2) into page-locked memory, piece by piece: the upload of one piece hides the read of the next; no
+                    # page of the inputs is mapped, and the writer gathers its lines from the staging buffer
+                    for f, w in enumerate(wins):
+                        base = stripper.staging_address(which, f)
+                        for at in range(0, w[2], STAGE_PIECE):
+                            piece = min(STAGE_PIECE, w[2] - at)
+                            parsers[which].pread(sources[f].fileno(), w[1] + at, base + at, piece)
+                            stripper.upload(which, f, at, piece)
+                with prof("strip"):
+                    blk = stripper.run(which, wins[0][2], wins[0][3], wins[1][2], wins[1][3], score_mode, paired, skip_repeated,
+                                       paired, records)
+                    prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_upload
+                    prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
+            except (MemoryError, OSError):
+                # the --cigar_scores arrays did not fit (MemoryError from the run), or a read into the staging buffer failed
+                # half way: this window and the rest of the run go through the host stripper, and the half-staged stripper
+                # is not kept for later runs of the process
+                _forget_stripper(stripper)
+                stripper, blk = None, None
+        if blk is not None:
             if blk.non_ascii:
                 raise _host.NonAsciiInput()
             staged = [stripper.staging(which, f) for f in (0, 1)]
