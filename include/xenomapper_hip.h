@@ -224,8 +224,9 @@ int xm_mate_correlate_dev(xm_ctx *ctx, void *stream, uint64_t n, const double *t
  * The compaction workspace (per-granule counts and offsets, the count replicas, the part totals) belongs to the context:
  * ONE xm_compact_dev / xm_classify_compact*_dev / xm_classify_place*_dev call can be in flight per context at a time.
  * Calls on one stream are ordered anyway; a call issued on another stream than the previous one is put behind
- * everything enqueued on that stream so far by the library (an event); calls captured into graphs are ordered by the
- * graph's own edges only.  For real concurrency use one context per stream. */
+ * everything enqueued on that stream so far by the library (an event recorded there at that moment: the previous stream
+ * must still exist -- see xm_workspace_release); calls captured into graphs are ordered by the graph's own edges only.
+ * For real concurrency use one context per stream. */
 int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_records, const uint8_t *code,
                    uint32_t *idx_out, uint64_t *bin_offsets, uint64_t *counts);
 
@@ -373,6 +374,15 @@ int xm_classify_runs_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n_rec
  * *n_written = its length (entries past `capacity` are counted, not stored; idx_out may be NULL to count only). */
 int xm_runs_expand(uint64_t n_records, const uint16_t *runs16, const uint16_t *gran_counts, int bin,
                    uint32_t *idx_out, uint64_t capacity, uint64_t *n_written);
+
+/*
+ * Before a stream that xm_compact_dev / xm_classify_compact*_dev / xm_classify_place*_dev / xm_classify_runs*_dev were issued
+ * on is DESTROYED while the context lives on: tell the context.  The library orders workspace calls across streams lazily
+ * -- at the next call on another stream it records an event on the previous stream -- so it keeps that stream's handle;
+ * this call records the event now (the stream still exists) and forgets the handle.  Cheap, never blocks, harmless for a
+ * stream the context does not remember.  xm_strip_destroy does it for the stripper's own streams.
+ */
+int xm_workspace_release(xm_ctx *ctx, void *stream);
 
 /*
  * Test aid: synchronises the device and reports (*clean = 1) whether the context's counting workspace -- the replicated

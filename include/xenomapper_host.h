@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XMH_ABI_VERSION 3
+#define XMH_ABI_VERSION 4
 
 #define XMH_OK              0
 #define XMH_ERR_INVALID_ARG (-1)
@@ -169,10 +169,14 @@ int xmh_bam_read_pre(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int
                      xmh_pre *pre, uint64_t pre_cap, uint64_t *n_pre, uint32_t *ops, uint64_t ops_cap, uint64_t *n_ops);
 
 /* xmh_parse on windows of text that xmh_bam_read_pre wrote, without tokenising it again: pre1 / pre2 describe the lines
- * from the first byte of buf1 / buf2 on (entries past the window are ignored), ops1 / ops2 are the arrays their ops_at
- * refer to.  Same results as xmh_parse, or XMH_NEED_TEXT (nothing parsed) when a line is marked XMH_PRE_WEIRD. */
+ * from the first byte of buf1 / buf2 on (entries past the window are ignored), ops1 / ops2 are the arrays (n_ops1 / n_ops2
+ * words) their ops_at refer to.  Same results as xmh_parse, or XMH_NEED_TEXT (nothing parsed) when a line is marked
+ * XMH_PRE_WEIRD; XMH_ERR_INVALID_ARG when a description points outside its operation array (checked, since ABI 4: the
+ * arrays are rebased whenever windows are merged and cross the language boundary as raw pointers). */
 int xmh_parse_pre(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const xmh_pre *pre1, uint64_t n_pre1, const uint32_t *ops1,
+                  uint64_t n_ops1,
                   const char *buf2, uint64_t len2, int eof2, const xmh_pre *pre2, uint64_t n_pre2, const uint32_t *ops2,
+                  uint64_t n_ops2,
                   int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out);
 
 #ifdef __cplusplus

@@ -77,7 +77,7 @@ int xms_abi_version(void);
 
 /* ctx: the classifier context the columns will be classified with (same device).  Allocates nothing large. */
 int xm_strip_create(xm_ctx *ctx, int device_id, xm_strip **out);
-int xm_strip_destroy(xm_strip *s);
+int xm_strip_destroy(xm_strip *s);      /* while ctx is still alive: the slot streams are handed back to it (xm_workspace_release) */
 
 /* Make the slot's buffers hold windows of window_bytes per file and max_records records (grows only; not to be called
  * while the slot is in use).  XM_ERR_INVALID_ARG beyond XMS_MAX_WINDOW. */

@@ -10,6 +10,7 @@ import ctypes
 import importlib.util
 import os
 import sys
+import weakref
 
 import numpy as np
 
@@ -121,6 +122,7 @@ def lib():
         "xm_runs_expand": ([U64, P, P, I, P, U64, ctypes.POINTER(U64)], I),
         "xm_stream_probe_dev": ([P, P, U64, P, P, P, P, P], I),
         "xm_workspace_is_clean": ([P, ctypes.POINTER(I)], I),
+        "xm_workspace_release": ([P, P], I),
         "xm_comm_unique_id": ([P], I),
         "xm_comm_init": ([P, I, I, P], I),
         "xm_comm_destroy": ([P], I),
@@ -159,7 +161,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister",
             "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev",
             "xm_classify_place_cigar_packed_dev", "xm_classify_runs_dev", "xm_classify_runs_f64_dev", "xm_runs_expand",
-            "xm_stream_probe_dev", "xm_workspace_is_clean",
+            "xm_stream_probe_dev", "xm_workspace_is_clean", "xm_workspace_release",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
@@ -252,9 +254,12 @@ class Context(object):
                                                        self._L.xm_last_hip_error(None).decode()))
         self._h = h
         self.device = int(device)
+        self._strippers = weakref.WeakSet()       # closed with the context: xm_strip_destroy hands its streams back to it
 
     def close(self):
         if getattr(self, "_h", None):
+            for st in list(getattr(self, "_strippers", ())):
+                st.close()
             self._L.xm_ctx_destroy(self._h)
             self._h = None
 
@@ -577,6 +582,10 @@ class Context(object):
             rc = self._L.xm_classify_runs_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), *outs)
         self._check(rc, "xm_classify_runs_dev")
 
+    def workspace_release(self, stream):
+        """Call before destroying a stream the compaction calls were issued on while this context lives on."""
+        self._check(self._L.xm_workspace_release(self._h, self._stream_handle(stream)), "xm_workspace_release")
+
     def workspace_is_clean(self):
         """Synchronises; True when the counting workspace is in its between-calls state (all zero)."""
         flag = ctypes.c_int(0)
@@ -720,6 +729,7 @@ class Stripper(object):
             raise _ERRORS.get(rc, RuntimeError)("xm_strip_create: " + self._L.xm_strerror(rc).decode())
         self._h = h
         self._cap = [(0, 0)] * STRIP_SLOTS
+        ctx._strippers.add(self)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -77,8 +77,8 @@ def lib():
         L.xmh_bam_read_pre.argtypes = [_P, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int),
                                        _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), _P, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64)]
-        L.xmh_parse_pre.argtypes = [_P, _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P,
-                                    _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P,
+        L.xmh_parse_pre.argtypes = [_P, _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_uint64,
+                                    _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_uint64,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_Block)]
         L.xmh_copy.argtypes = [_P, _P, _P, ctypes.c_uint64]
         L.xmh_pread.argtypes = [_P, ctypes.c_int, ctypes.c_uint64, _P, ctypes.c_uint64]
@@ -164,9 +164,9 @@ class Parser(object):
         p1 = arr1.ctypes.data + pos1 if len1 else None
         p2 = arr2.ctypes.data + pos2 if len2 else None
         rc = self._L.xmh_parse_pre(self._h, p1, len1, int(eof1), pre1.ctypes.data if pre1.shape[0] else None, pre1.shape[0],
-                                   ops1.ctypes.data if ops1.shape[0] else None,
+                                   ops1.ctypes.data if ops1.shape[0] else None, ops1.shape[0],
                                    p2, len2, int(eof2), pre2.ctypes.data if pre2.shape[0] else None, pre2.shape[0],
-                                   ops2.ctypes.data if ops2.shape[0] else None,
+                                   ops2.ctypes.data if ops2.shape[0] else None, ops2.shape[0],
                                    score_mode, int(paired), int(skip_repeated), int(keep_halo), int(max_records), ctypes.byref(raw))
         if rc == NEED_TEXT:
             return None

@@ -30,10 +30,10 @@ struct xm_ctx {
     uint32_t *d_gran_off;           // [8 bins][granule]: K2b's exclusive scan of the above
     uint64_t *d_counts_rep;         // XM_COUNT_REPLICAS x 64 partial category_counts (all zero between calls), then 8 bin totals
     uint32_t *d_part_tot;           // [8][XM_PART_STRIDE]: per-part bin totals (K2b's first level)
-    // the stream the workspace was last used on (compared only) and the event recorded behind that call's last launch:
-    // a call on another stream waits for the event (order_workspace / workspace_done)
+    // the stream the workspace was last used on: a call on another stream is ordered behind it (order_workspace);
+    // ws_released: that stream's owner has let go of it (xm_workspace_release) -- ws_event marks the end of its work
     hipStream_t ws_stream;
-    bool ws_used;
+    bool ws_used, ws_released;
     hipEvent_t ws_event;
     // scratch of the host-buffer entry points (grown on demand, never inside *_dev calls)
     void *d_scratch[8];
@@ -158,10 +158,12 @@ void reset_count_state(xm_ctx *ctx, hipStream_t st)
 
 // The compaction workspace (per-granule counts and offsets, the count replicas, the part totals) belongs to the context:
 // calls that use it must not overlap.  Calls on one stream are ordered anyway; a call on ANOTHER stream than the previous
-// one waits (hipStreamWaitEvent) for the event the previous call recorded behind its last launch (workspace_done).  The
-// event, not the previous stream, is what is kept: that stream may have been destroyed since (round 4 kept the handle and
-// recorded on it lazily -- a dangling handle once its owner, e.g. a Stripper, was closed).  A capturing stream is left
-// alone: the graph's own edges order its nodes, and events cannot be mixed into a capture from outside.
+// one is put behind everything enqueued on that stream so far (an event recorded there now, waited for here): no per-call
+// cost while one stream is used (an event behind every call measured +5-7 us per 0.35 ms step, profiles/r05_ab_runs_first.txt).
+// The previous stream's handle is therefore kept -- and must still be alive at the next switch: whoever destroys a stream
+// that was used with this context calls xm_workspace_release first (xm_strip_destroy does, for its slot streams), which
+// records the event while the stream still exists and forgets the handle.  A capturing stream is left alone: the graph's
+// own edges order its nodes, and events cannot be mixed into a capture from outside.
 bool capturing(hipStream_t st)
 {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -172,26 +174,17 @@ bool capturing(hipStream_t st)
 int order_workspace(xm_ctx *ctx, hipStream_t st)
 {
     if (capturing(st)) return XM_OK;
-    if (ctx->ws_used && ctx->ws_stream != st) XM_HIP(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
+    if (ctx->ws_released) {                                   // the last user is gone; its event is what there is to wait for
+        XM_HIP(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
+        ctx->ws_released = false;
+    } else if (ctx->ws_used && ctx->ws_stream != st && !capturing(ctx->ws_stream)) {
+        XM_HIP(ctx, hipEventRecord(ctx->ws_event, ctx->ws_stream));
+        XM_HIP(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
+    }
+    ctx->ws_stream = st;
+    ctx->ws_used = true;
     return XM_OK;
 }
-
-// behind the last launch of a call that used the workspace (also after a failed launch: whatever was enqueued counts)
-void workspace_done(xm_ctx *ctx, hipStream_t st)
-{
-    if (capturing(st)) return;
-    if (hipEventRecord(ctx->ws_event, st) != hipSuccess) { (void)hipGetLastError(); return; }
-    ctx->ws_stream = st;                 // only compared, never dereferenced
-    ctx->ws_used = true;
-}
-
-// runs workspace_done when the enclosing entry point returns, whichever way
-struct WorkspaceUse {
-    xm_ctx *ctx;
-    hipStream_t st;
-    WorkspaceUse(xm_ctx *c, hipStream_t s) : ctx(c), st(s) {}
-    ~WorkspaceUse() { workspace_done(ctx, st); }
-};
 
 }  // namespace
 
@@ -243,6 +236,7 @@ int xm_ctx_create(int device_id, xm_ctx **out)
     ctx->d_part_tot = nullptr;
     ctx->ws_stream = nullptr;
     ctx->ws_used = false;
+    ctx->ws_released = false;
     ctx->ws_event = nullptr;
     for (int i = 0; i < 8; ++i) { ctx->d_scratch[i] = nullptr; ctx->scratch_bytes[i] = 0; }
     ctx->timing = false;
@@ -459,7 +453,6 @@ int xm_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n, const uint8_
     const xm::CountPlan cp = count_plan(ctx, n);
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_HIST);
         xm::launch_hist(st, mode, n, code, cp);
@@ -486,7 +479,6 @@ int xm_classify_compact_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     cp.bins4 = bins4;
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &cp);
@@ -511,7 +503,6 @@ int xm_classify_compact_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     cp.bins4 = bins4;
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &cp);
@@ -571,7 +562,6 @@ int xm_classify_compact_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, ui
     const xm::CigCols s1 = {nm1, xs1, cnt1, tile1, ops1}, s2 = {nm2, xs2, cnt2, tile2, ops2};
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_cigp(st, mode, n, s1, s2, unit_bits, min_score_floor, code_out, range_flag, cp);
@@ -613,7 +603,6 @@ int xm_classify_place_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     xm::CountPlan cp = count_plan(ctx, n);
     cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &cp);
@@ -641,7 +630,6 @@ int xm_classify_place_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     xm::CountPlan cp = count_plan(ctx, n);
     cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &cp);
@@ -675,7 +663,6 @@ int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint
     cp.bins4 = bins4;
     const xm::CigCols s1 = {nm1, xs1, cnt1, tile1, ops1}, s2 = {nm2, xs2, cnt2, tile2, ops2};
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         xm::launch_classify_cigp(st, mode, n, s1, s2, unit_bits, min_score_floor, code_out, range_flag, cp);
@@ -701,7 +688,6 @@ static int runs_common(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, size_t
     const xm::RunsOut ro = {runs16, gran_counts, ctx->d_counts_rep};
     int rc;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, st);
     {
         Span span(ctx, st, XM_K_CLASSIFY);
         if (elem == 4)
@@ -756,6 +742,18 @@ int xm_runs_expand(uint64_t n, const uint16_t *runs16, const uint16_t *gran_coun
             if (idx_out && w < capacity) idx_out[w] = (uint32_t)(g * XM_GRAN) + run[i];
     }
     *n_written = w;
+    return XM_OK;
+}
+
+int xm_workspace_release(xm_ctx *ctx, void *stream)
+{
+    if (!ctx) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx->ws_used || ctx->ws_released || ctx->ws_stream != st) return XM_OK;       // not the stream the workspace is waiting on
+    XM_HIP(ctx, hipSetDevice(ctx->device));
+    if (!capturing(st)) XM_HIP(ctx, hipEventRecord(ctx->ws_event, st));
+    ctx->ws_released = true;
+    ctx->ws_stream = nullptr;
     return XM_OK;
 }
 
@@ -841,7 +839,6 @@ static int classify_host(xm_ctx *ctx, int mode, uint64_t n, size_t elem, const v
     // category_counts come from the counting form of the kernel (+ K2b, which adds the replicas up)
     const xm::CountPlan cp = count_plan(ctx, n);
     if (counts && (rc = order_workspace(ctx, nullptr)) != XM_OK) return rc;
-    WorkspaceUse ws_use(ctx, nullptr);            // (also without counts: harmless)
     {
         Span span(ctx, nullptr, XM_K_CLASSIFY);
         if (elem == 4)

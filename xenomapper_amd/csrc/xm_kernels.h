@@ -17,6 +17,14 @@
 #define XM_CIGAR_BLOCK 256     // classify_cigar workgroup (128: 0.650, 256: 0.626, 512: 0.649, 1024: 0.754 ms per 50 M pairs)
 #endif
 #define XM_CIGP_BLOCK 512      // classify from packed CIGAR columns: workgroup = one granule (it counts)
+// K2c: at most this many waves per launch, each placing a run of consecutive granules.  Measured (profiles/r05_ab_k2c_waves.txt,
+// 50 M interleaved pairs = 48.8 k granules): one granule per wave 54.6 us, 16 k waves 58, 8 k 62, 4 k 70, 2 k 102 -- fewer, longer-
+// lived waves are SLOWER although a plain dword fill gains from exactly that shape (4.1 -> 6.0 TB/s, r05_probe_write_shapes.txt):
+// a granule is a chain of dependent phases (load, ballots, stores), and what hides it is the number of granules in flight.
+// So the default keeps one granule per wave up to 2^20 granules (2^31 records).
+#ifndef XM_SCATTER_WAVES
+#define XM_SCATTER_WAVES 1048576u
+#endif
 #define XM_CLASSIFY_NT true    // non-temporal loads of the score columns in classify
 
 namespace xm {

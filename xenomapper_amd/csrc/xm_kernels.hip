@@ -732,13 +732,18 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
 // costs them 2 us per 50 M pairs)
 // LISTS: the six-list output contract -- bin b's units go to lo.p[b] (positions count from the start of that list, so the
 // totals of the bins in front are not needed), bin_offsets receives the list lengths ([7] = all units).
+// Launch shape: a wave owns a RUN of `gran_per_wave` consecutive granules (the per-bin places carry over from granule to
+// granule in scalar registers: the scatter leaves base[b] advanced by the granule's units of bin b, so the scan's offsets
+// are read for the wave's first granule only).  Round 5 tried long-lived waves (a dense dword fill gains 4.1 -> 6.0 TB/s from
+// exactly that, tools/probe_streams.hip w) and measured the opposite for this kernel -- XM_SCATTER_WAVES in xm_kernels.h has
+// the numbers -- so gran_per_wave is 1 unless the input has more than 2^20 granules.
 template <int NSUB, bool WIDE, bool NIB, bool STAGE, bool LISTS>
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
                const uint32_t *__restrict__ gran_counts, const uint32_t *__restrict__ gran_off,
                const unsigned long long *__restrict__ bin_totals,
                unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ part_tot,
-               const ListOut lo)
+               const ListOut lo, uint32_t gran_per_wave)
 {
     constexpr bool CAN_STAGE = STAGE && XM_SCATTER_STAGED != 0 && NSUB * 256 == XM_GRAN;
     __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
@@ -751,74 +756,94 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
             part_tot[(i / n_parts) * XM_PART_STRIDE + i % n_parts] = 0u;
     }
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t g = blockIdx.x * (XM_BLOCK / 64) + wave;
-    if (g >= n_gran) return;                                              // wave-uniform; no barrier in this kernel
+    const uint32_t g0 = (blockIdx.x * (XM_BLOCK / 64) + wave) * gran_per_wave;
+    if (g0 >= n_gran) return;                                             // wave-uniform; no barrier in this kernel
+    const uint32_t g1 = g0 + gran_per_wave < n_gran ? g0 + gran_per_wave : n_gran;
     uint8_t *lut = lut_all[NIB ? 0 : wave];
     if (!NIB) lut[lane] = (uint8_t)bin_of_code(mode, lane == 63u ? XM_NO_UNIT : lane);
     uint64_t *lptr = lptr_all[LISTS ? wave : 0];
     if (LISTS && lane < 8u) lptr[lane] = lane < 7u ? (uint64_t)(uintptr_t)lo.p[lane] : 0ull;      // read back by this wave only
 
     // lane b < 8: where bin b starts in idx_out (exclusive prefix of the bin totals) plus what the granules before
-    // this one hold of it
+    // the wave's first one hold of it
     uint32_t lane_base, n_units;
     {
         const uint32_t tot = (lane < 8u) ? (uint32_t)bin_totals[lane] : 0u;
-        const uint32_t off = (lane < 7u) ? gran_off[(uint64_t)lane * gran_stride + g] : 0u;
+        const uint32_t off = (lane < 7u) ? gran_off[(uint64_t)lane * gran_stride + g0] : 0u;
         const uint32_t bin_start = wave_scan_incl(tot) - tot;
         lane_base = LISTS ? off : bin_start + off;
         n_units = LISTS ? lo.cap : lane_value(bin_start, 7);              // slot 7 counts nothing: the total
-        if (g == 0u && lane < 8u) bin_offsets[lane] = (LISTS && lane < 7u) ? tot : bin_start;
+        if (g0 == 0u && lane < 8u) bin_offsets[lane] = (LISTS && lane < 7u) ? tot : bin_start;
     }
-    // Staging pays where a granule holds many units (single-end input: 2048 of them; 117 against 166 us per 100 M reads)
-    // and costs where it holds few (strictly interleaved mates, 1024: 62 against 55 us): decided per launch (STAGE) and
-    // then per wave from the granule's unit count (what the counting side reported).
     uint16_t *slab = slab_all[CAN_STAGE ? wave : 0];
-    uint32_t run_start = 0, run_len = 0;
-    bool staged = false;
-    if (CAN_STAGE) {
-        // lane b < 7 lays out bin b's region of the slab: room for its units rounded up to 4, + 4, regions back to back;
-        // the run starts (its place in idx_out) mod 4 words into its region, so that 16-byte-aligned places of idx_out
-        // are 8-byte-aligned places of the slab
-        uint32_t cnt = (lane < 7u) ? gran_counts[(uint64_t)lane * gran_stride + g] : 0u;
-        const uint32_t room = (lane < 7u) ? ((cnt + 3u) & ~3u) + 4u : 0u;
-        const uint32_t incl_room = wave_scan_incl(room), incl_cnt = wave_scan_incl(cnt);
-        staged = lane_value(incl_cnt, 6) >= (uint32_t)XM_STAGE_MIN_UNITS;
-        run_start = incl_room - room + (lane_base & 3u);
-        // never past the number of units, never past the slab, whatever the counts hold
-        cnt = lane_base < n_units ? (cnt < n_units - lane_base ? cnt : n_units - lane_base) : 0u;
-        run_len = run_start < (uint32_t)XM_SLAB_U16 ? (cnt < XM_SLAB_U16 - run_start ? cnt : XM_SLAB_U16 - run_start) : 0u;
-    }
     uint32_t base[7];
 #pragma unroll
-    for (int b = 0; b < 7; ++b) base[b] = lane_value(staged ? run_start : lane_base, b);
+    for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
 
-    const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
-    uint32_t w[NSUB];
-    if (NIB) {
-        // 16 bits per lane and 256 records; whole granule blocks exist (records past the end read as 7)
-        const uint16_t *nib = reinterpret_cast<const uint16_t *>(code) + (rec_g >> 2) + lane;
+    auto load_granule = [&](uint32_t g, uint32_t w[NSUB]) {
+        const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
+        if (NIB) {
+            // 16 bits per lane and 256 records; whole granule blocks exist (records past the end read as 7)
+            const uint16_t *nib = reinterpret_cast<const uint16_t *>(code) + (rec_g >> 2) + lane;
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) w[s] = nib[s * 64];
-    } else if (rec_g + NSUB * 256u <= n) {
+            for (int s = 0; s < NSUB; ++s) w[s] = nib[s * 64];
+        } else if (rec_g + NSUB * 256u <= n) {
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) w[s] = *reinterpret_cast<const uint32_t *>(code + rec_g + s * 256u + lane * 4u);
-    } else {
+            for (int s = 0; s < NSUB; ++s) w[s] = *reinterpret_cast<const uint32_t *>(code + rec_g + s * 256u + lane * 4u);
+        } else {
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) w[s] = load_codes4_tail(code, rec_g + s * 256u + lane * 4u, n);
-    }
-    if (!NIB || LISTS) lds_settle();
-    if (CAN_STAGE && staged) {
-        scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lptr);
-        lds_settle();                                                     // the wave's slab is complete
-#pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            const uint32_t N = lane_value(run_len, b);
-            uint32_t *__restrict__ dst = LISTS ? lo.p[b] : idx_out;
-            if (N == 0u || dst == nullptr) continue;                      // wave-uniform
-            scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, dst);
+            for (int s = 0; s < NSUB; ++s) w[s] = load_codes4_tail(code, rec_g + s * 256u + lane * 4u, n);
         }
-    } else {
-        scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lptr);
+    };
+    uint32_t w[NSUB], wn[NSUB];
+    load_granule(g0, w);
+    if (!NIB || LISTS) lds_settle();
+    for (uint32_t g = g0; g < g1; ++g) {
+        if (g + 1u < g1) load_granule(g + 1u, wn);                        // in flight while this granule is placed
+        const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
+        // Staging pays where a granule holds many units (single-end input: 2048 of them; 117 against 166 us per 100 M reads)
+        // and costs where it holds few (strictly interleaved mates, 1024: 62 against 55 us): decided per launch (STAGE) and
+        // then per granule from its unit count (what the counting side reported).
+        bool staged = false;
+        uint32_t cnt_g = 0;
+        if (CAN_STAGE) {
+            // lane b < 7 lays out bin b's region of the slab: room for its units rounded up to 4, + 4, regions back to back;
+            // the run starts (its place in idx_out) mod 4 words into its region, so that 16-byte-aligned places of idx_out
+            // are 8-byte-aligned places of the slab
+            cnt_g = (lane < 7u) ? gran_counts[(uint64_t)lane * gran_stride + g] : 0u;
+            const uint32_t room = (lane < 7u) ? ((cnt_g + 3u) & ~3u) + 4u : 0u;
+            const uint32_t incl_room = wave_scan_incl(room), incl_cnt = wave_scan_incl(cnt_g);
+            staged = lane_value(incl_cnt, 6) >= (uint32_t)XM_STAGE_MIN_UNITS;
+            if (staged) {
+                const uint32_t run_start = incl_room - room + (lane_base & 3u);
+                // never past the number of units, never past the slab, whatever the counts hold
+                const uint32_t cnt = lane_base < n_units ? (cnt_g < n_units - lane_base ? cnt_g : n_units - lane_base) : 0u;
+                const uint32_t run_len = run_start < (uint32_t)XM_SLAB_U16 ? (cnt < XM_SLAB_U16 - run_start ? cnt : XM_SLAB_U16 - run_start) : 0u;
+                uint32_t sbase[7];
+#pragma unroll
+                for (int b = 0; b < 7; ++b) sbase[b] = lane_value(run_start, b);
+                scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, (uint32_t)rec_g, sbase, idx_out, n_units, slab, lptr);
+                lds_settle();                                             // the wave's slab is complete
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const uint32_t N = lane_value(run_len, b);
+                    uint32_t *__restrict__ dst = LISTS ? lo.p[b] : idx_out;
+                    if (N == 0u || dst == nullptr) continue;              // wave-uniform
+                    scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, dst);
+                }
+                lds_settle();                                             // the copy-out has read the slab: the next granule may fill it
+            }
+        }
+        if (!staged) {
+            if (CAN_STAGE) {
+#pragma unroll
+                for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
+            }
+            scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lptr);
+        }
+        if (CAN_STAGE) lane_base += cnt_g;                                // where the next granule's runs begin
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) w[s] = wn[s];
     }
 }
 
@@ -1884,11 +1909,14 @@ void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, con
 {
     const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
-    const uint32_t grid = (p.n_gran + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
+    // long-lived waves, each a run of consecutive granules (scatter_kernel): about XM_SCATTER_WAVES of them
+    const uint32_t gran_per_wave = (p.n_gran + XM_SCATTER_WAVES - 1u) / XM_SCATTER_WAVES;
+    const uint32_t n_waves = (p.n_gran + gran_per_wave - 1u) / gran_per_wave;
+    const uint32_t grid = (n_waves + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
     const bool stage = mode == XM_MODE_SE;
     const ListOut lo = lists ? *lists : ListOut{{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0u};
-#define XM_LAUNCH_SCT(W, NIB, STG, L) scatter_kernel<XM_GRAN / 256, W, NIB, STG, L><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot, lo)
+#define XM_LAUNCH_SCT(W, NIB, STG, L) scatter_kernel<XM_GRAN / 256, W, NIB, STG, L><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot, lo, gran_per_wave)
 #define XM_LAUNCH_SCT1(W, NIB, STG) do { if (lists) XM_LAUNCH_SCT(W, NIB, STG, true); else XM_LAUNCH_SCT(W, NIB, STG, false); } while (0)
 #define XM_LAUNCH_SCT2(W, NIB) do { if (stage) XM_LAUNCH_SCT1(W, NIB, true); else XM_LAUNCH_SCT1(W, NIB, false); } while (0)
     if (code_is_bins4) { if (wide) XM_LAUNCH_SCT2(true, true); else XM_LAUNCH_SCT2(false, true); }

@@ -392,9 +392,11 @@ int xmh_parser_destroy(xmh_parser *p)
 }
 
 // lines and records of one window from what the BAM decoder already knows about them (xmh_bam_read_pre): no byte of the
-// text is looked at.  false: a line the text rules might split differently -- the caller parses the text instead.
-static bool fill_from_pre(const xmh_pre *pre, uint64_t n_pre, const uint32_t *ops, uint64_t len, int score_mode, Pool &pool,
-                          FileParse &fp)
+// text is looked at.  XMH_NEED_TEXT: a line the text rules might split differently -- the caller parses the text instead.
+// XMH_ERR_INVALID_ARG: a description points outside the operation array it came with (n_ops words): these arrays cross
+// the language boundary as raw pointers and are rebased when windows are merged, so they are checked, never trusted.
+static int fill_from_pre(const xmh_pre *pre, uint64_t n_pre, const uint32_t *ops, uint64_t n_ops, uint64_t len, int score_mode,
+                         Pool &pool, FileParse &fp)
 {
     // the lines that lie in the window completely (every line of BAM text ends with '\n'): line starts = prefix sums of
     // the line lengths, in two parallel passes over the same slices
@@ -432,17 +434,22 @@ static bool fill_from_pre(const xmh_pre *pre, uint64_t n_pre, const uint32_t *op
     const bool cigar = score_mode == XMH_SCORE_CIGAR;
     auto &all_ops = fp.slots[0].ops;                 // one shared operation array: the records point into it
     all_ops.clear();
+    uint64_t ops_hi = 0;
     if (cigar && n) {
         const uint64_t lo = pre[0].ops_at, hi = (uint64_t)pre[n - 1].ops_at + pre[n - 1].n_ops;
+        if (lo > hi || hi > n_ops || (hi > lo && !ops)) return XMH_ERR_INVALID_ARG;
         all_ops.assign(ops + lo, ops + hi);
+        ops_hi = hi;
     }
     const uint32_t ops_base = (cigar && n) ? pre[0].ops_at : 0u;
+    std::vector<uint8_t> outside((size_t)pool.size() + 1, 0);
     parallel_for(pool, n, [&](int t, uint64_t b, uint64_t e) {
-        uint8_t w = 0;
+        uint8_t w = 0, bad = 0;
         for (uint64_t i = b; i < e; ++i) {
             const xmh_pre &q = pre[i];
             Rec &r = fp.recs[(size_t)i];
             w |= q.flags & XMH_PRE_WEIRD;
+            if (cigar) bad |= (uint8_t)(q.ops_at < ops_base || (uint64_t)q.ops_at + q.n_ops > ops_hi);
             r.name_off = 0;
             r.name_len = q.name_len;
             r.norm_len = q.line_len;                 // the decoder prints '\t'.join(fields)
@@ -463,15 +470,19 @@ static bool fill_from_pre(const xmh_pre *pre, uint64_t n_pre, const uint32_t *op
             }
         }
         weird[(size_t)t] = w;
+        outside[(size_t)t] = bad;
     });
+    for (uint8_t o : outside)
+        if (o) return XMH_ERR_INVALID_ARG;
     for (uint8_t w : weird)
-        if (w) return false;
-    return true;
+        if (w) return XMH_NEED_TEXT;
+    return XMH_OK;
 }
 
 static int parse_common(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const xmh_pre *pre1, uint64_t n_pre1, const uint32_t *pops1,
+                        uint64_t n_pops1,
                         const char *buf2, uint64_t len2, int eof2, const xmh_pre *pre2, uint64_t n_pre2, const uint32_t *pops2,
-                        bool from_pre, int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records,
+                        uint64_t n_pops2, bool from_pre, int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records,
                         xmh_block *out)
 {
     if (!p || !out || (!buf1 && len1) || (!buf2 && len2) || score_mode < 0 || score_mode > 2)
@@ -490,9 +501,9 @@ static int parse_common(xmh_parser *p, const char *buf1, uint64_t len1, int eof1
             for (int f = 0; f < 2; ++f) prefault(buf[f], len[f], *p->pool);
         const auto t0b = now();
         if (from_pre) {
-            if (!fill_from_pre(pre1, n_pre1, pops1, len1, score_mode, *p->pool, p->f[0]) ||
-                !fill_from_pre(pre2, n_pre2, pops2, len2, score_mode, *p->pool, p->f[1]))
-                return XMH_NEED_TEXT;
+            const int r1 = fill_from_pre(pre1, n_pre1, pops1, n_pops1, len1, score_mode, *p->pool, p->f[0]);
+            const int r2 = r1 == XMH_OK ? fill_from_pre(pre2, n_pre2, pops2, n_pops2, len2, score_mode, *p->pool, p->f[1]) : r1;
+            if (r2 != XMH_OK) return r2;                          // XMH_NEED_TEXT, or descriptions that do not fit their arrays
         } else {
             for (int f = 0; f < 2; ++f) {
                 index_lines(buf[f], len[f], eof[f] != 0, *p->pool, p->f[f]);
@@ -707,16 +718,18 @@ static int parse_common(xmh_parser *p, const char *buf1, uint64_t len1, int eof1
 int xmh_parse(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const char *buf2, uint64_t len2, int eof2,
               int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out)
 {
-    return parse_common(p, buf1, len1, eof1, nullptr, 0, nullptr, buf2, len2, eof2, nullptr, 0, nullptr, false, score_mode, paired,
+    return parse_common(p, buf1, len1, eof1, nullptr, 0, nullptr, 0, buf2, len2, eof2, nullptr, 0, nullptr, 0, false, score_mode, paired,
                         skip_repeated, keep_halo, max_records, out);
 }
 
 int xmh_parse_pre(xmh_parser *p, const char *buf1, uint64_t len1, int eof1, const xmh_pre *pre1, uint64_t n_pre1, const uint32_t *ops1,
+                  uint64_t n_ops1,
                   const char *buf2, uint64_t len2, int eof2, const xmh_pre *pre2, uint64_t n_pre2, const uint32_t *ops2,
+                  uint64_t n_ops2,
                   int score_mode, int paired, int skip_repeated, int keep_halo, uint64_t max_records, xmh_block *out)
 {
     if ((n_pre1 && !pre1) || (n_pre2 && !pre2)) return XMH_ERR_INVALID_ARG;
-    return parse_common(p, buf1, len1, eof1, pre1, n_pre1, ops1, buf2, len2, eof2, pre2, n_pre2, ops2, true, score_mode, paired,
+    return parse_common(p, buf1, len1, eof1, pre1, n_pre1, ops1, n_ops1, buf2, len2, eof2, pre2, n_pre2, ops2, n_ops2, true, score_mode, paired,
                         skip_repeated, keep_halo, max_records, out);
 }
 

@@ -974,7 +974,10 @@ int xm_strip_destroy(xm_strip *s)
     (void)hipSetDevice(s->device);
     for (int k = 0; k < XMS_SLOTS; ++k) {
         Slot &sl = s->slot[k];
-        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        if (sl.stream) {
+            (void)hipStreamSynchronize(sl.stream);
+            (void)xm_workspace_release(s->ctx, sl.stream);             // the context must not keep the handle of a dead stream
+        }
         free_slot(sl);
         dfree(sl.d_state); dfree(sl.d_range); dfree(sl.d_summary); dfree(sl.d_off_counts);
         hfree(sl.h_summary); hfree(sl.h_off_counts);
