@@ -145,6 +145,11 @@ def lib():
         "xm_strip_columns": ([P, I, U64, P, P, P, P, P], I),
         "xm_strip_device_columns": ([P, I, P], I),
         "xm_strip_last_error": ([P], ctypes.c_char_p),
+        # include/xenomapper_bgzf.h
+        "xm_bgzf_index": ([P, U64, U64, U64, P, P, U64, ctypes.POINTER(U64), ctypes.POINTER(U64), ctypes.POINTER(U64)], I),
+        "xm_bgzf_inflate_dev": ([P, P, P, P, U64, P, P, P], I),
+        "xm_bgzf_crc32_dev": ([P, P, P, P, U64, P], I),
+        "xm_bgzf_strerror": ([ctypes.c_uint32], ctypes.c_char_p),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -165,7 +170,8 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
-            "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error")
+            "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
+            "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror")
 
 
 def _np_ptr(a):
@@ -582,6 +588,22 @@ class Context(object):
             rc = self._L.xm_classify_runs_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), *outs)
         self._check(rc, "xm_classify_runs_dev")
 
+    def bgzf_inflate_dev(self, comp, blocks, out, status, work, stream=None):
+        """BGZF blocks inflated on the GPU (xm_bgzf_inflate_dev): comp = uint8 device tensor of the compressed image (+ BGZF_COMP_PAD
+        bytes behind the last block), blocks = device tensor holding a BGZF_BLOCK array (as uint8 / int64 bytes), out = uint8
+        device tensor, status = int32 tensor with one entry per block, work = int32 tensor with one entry.  Asynchronous."""
+        n = blocks.numel() * blocks.element_size() // 24
+        rc = self._L.xm_bgzf_inflate_dev(self._h, self._stream_handle(stream), ctypes.c_void_p(comp.data_ptr()),
+                                         ctypes.c_void_p(blocks.data_ptr()), n, ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(work.data_ptr()))
+        self._check(rc, "xm_bgzf_inflate_dev")
+
+    def bgzf_crc32_dev(self, out, blocks, crc_out, stream=None):
+        n = blocks.numel() * blocks.element_size() // 24
+        rc = self._L.xm_bgzf_crc32_dev(self._h, self._stream_handle(stream), ctypes.c_void_p(out.data_ptr()),
+                                       ctypes.c_void_p(blocks.data_ptr()), n, ctypes.c_void_p(crc_out.data_ptr()))
+        self._check(rc, "xm_bgzf_crc32_dev")
+
     def workspace_release(self, stream):
         """Call before destroying a stream the compaction calls were issued on while this context lives on."""
         self._check(self._L.xm_workspace_release(self._h, self._stream_handle(stream)), "xm_workspace_release")
@@ -634,6 +656,31 @@ class Context(object):
         launches = (ctypes.c_uint64 * len(KERNELS))()
         self._check(self._L.xm_timing_read(self._h, ms, launches), "xm_timing_read")
         return {k: {"ms": ms[i], "launches": int(launches[i])} for i, k in enumerate(KERNELS)}
+
+
+# ---- include/xenomapper_bgzf.h: BGZF blocks inflated on the GPU -----------------------------------------------------
+BGZF_BLOCK = np.dtype([("cdata_off", np.uint64), ("out_off", np.uint64), ("cdata_len", np.uint32), ("isize", np.uint32)])
+assert BGZF_BLOCK.itemsize == 24
+BGZF_COMP_PAD = 1024
+
+
+def bgzf_index(data, start=0, max_out=1 << 62, cap=None):
+    """Walk the BGZF member headers of a file image (uint8 array) from byte `start` (xm_bgzf_index; host only):
+    -> (blocks as a BGZF_BLOCK array, crc uint32 array, next byte, inflated bytes)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    n_max = int(cap) if cap is not None else max(16, (data.shape[0] - int(start)) // 28 + 16)    # an empty member is 28 bytes
+    blocks = np.zeros(n_max, dtype=BGZF_BLOCK)
+    crc = np.zeros(n_max, dtype=np.uint32)
+    n, nxt, total = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    rc = lib().xm_bgzf_index(ctypes.c_void_p(data.ctypes.data), data.shape[0], int(start), int(max_out), _np_ptr(blocks), _np_ptr(crc),
+                             n_max, ctypes.byref(n), ctypes.byref(nxt), ctypes.byref(total))
+    if rc != XM_OK:
+        raise ValueError("xm_bgzf_index: not a BGZF image (or a truncated one) at byte %d" % int(start))
+    return blocks[:n.value], crc[:n.value], int(nxt.value), int(total.value)
+
+
+def bgzf_strerror(status):
+    return lib().xm_bgzf_strerror(int(status)).decode()
 
 
 # ---- include/xenomapper_strip.h: the SAM column stripper on the GPU --------------------------------------------

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, "csrc")
 HIP_LIB = os.path.join(PKG, "libxenomapper_hip.so")
 HOST_LIB = os.path.join(PKG, "libxenomapper_host.so")
 
-HIP_SOURCES = ["xm_kernels.hip", "xm_api.hip", "xm_strip.hip"]
+HIP_SOURCES = ["xm_kernels.hip", "xm_api.hip", "xm_strip.hip", "xm_inflate.hip"]
 HOST_SOURCES = ["xm_sam.cpp", "xm_bam.cpp"]
 
 
@@ -35,8 +35,9 @@ def _stale(target, sources):
 
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "xm_kernels.h"), os.path.join(REPO, "include", "xenomapper_hip.h"),
-                   os.path.join(REPO, "include", "xenomapper_strip.h")]
+    deps = srcs + [os.path.join(CSRC, "xm_kernels.h"), os.path.join(CSRC, "xm_inflate_core.h"),
+                   os.path.join(REPO, "include", "xenomapper_hip.h"), os.path.join(REPO, "include", "xenomapper_strip.h"),
+                   os.path.join(REPO, "include", "xenomapper_bgzf.h")]
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB
     # XENOMAPPER_HIPCC_FLAGS: extra flags for tuning builds (e.g. -DXM_CIGAR_BLOCK=256); not used by the tests

@@ -1,0 +1,212 @@
+// xm_inflate.hip -- BGZF blocks inflated on the GPU (include/xenomapper_bgzf.h): the launch around xm_inflate_core.h, the
+// CRC-32 kernel, and the host-side walk over the member headers.
+//
+// Launch shape.  One workgroup = one wave = 64 / GS chains, each decoding one BGZF block at a time from a shared work
+// counter (a block takes 0.5 ms of a chain's time alone, ~18 ms on a full chip, and blocks differ, so a static split would
+// leave tails).  A chain's LDS footprint (xmi::ChainMem, ~5 KB) and the registers (95 VGPRs: 5 waves per SIMD) bound the
+// residency: 2 chains per wave = 10 KB, 16 waves per CU, ~8 000 blocks in flight on the chip -- a 1 GB window of BAM
+// (~16 000 blocks) is two rounds.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/xenomapper_bgzf.h"
+#include "xm_inflate_core.h"
+
+// Lanes per chain.  Measured on 16 802 blocks = 1.04 GB of inflated BAM (profiles/r05_inflate_first.txt): 64 lanes 22.8 GB/s,
+// 32 lanes 28.3, 16 lanes 26.2, 8 lanes 23.5 -- and the 8- and 4-lane builds WITHOUT the trace hooks did not come back at all
+// on a 4-block file (the same source with -DXMI_TRACE did, byte-exact; every loop has an exit the data cannot disable, so this
+// is not a decoding loop -- unresolved).  32 it is.
+#ifndef XM_INFLATE_GS
+#define XM_INFLATE_GS 32
+#endif
+#ifndef XM_INFLATE_WG_PER_CU
+#define XM_INFLATE_WG_PER_CU 16     // upper bound on resident waves per CU (the LDS of the chains usually binds first)
+#endif
+
+#ifdef XMI_TRACE
+__device__ uint32_t *xm_inflate_trace = nullptr;       // host-visible words, one per chain (tools/inflate_gpu_check.hip --trace)
+extern "C" int xm_bgzf_set_trace(uint32_t *host_visible_words)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(xm_inflate_trace), &host_visible_words, sizeof host_visible_words) == hipSuccess ? 0 : -3;
+}
+#endif
+
+namespace {
+
+template <int GS>
+__global__ void __launch_bounds__(64)
+inflate_kernel(const uint8_t *__restrict__ comp, const xm_bgzf_block *__restrict__ blocks, uint32_t n_blocks,
+               uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t *__restrict__ work)
+{
+    constexpr int G = 64 / GS;
+    __shared__ xmi::ChainMem mem[G];
+    const uint32_t lane = threadIdx.x, c = lane / GS, gl = lane % GS;
+    xmi::Chain<GS> chain;
+#ifdef XMI_TRACE
+    chain.trace = xm_inflate_trace ? xm_inflate_trace + (blockIdx.x * G + c) : nullptr;
+    chain.gl = gl;
+#endif
+    for (;;) {
+#ifdef XMI_TRACE
+        if (chain.trace && gl == 0u) __hip_atomic_store(chain.trace, 100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+        // the chain's next block: lane 0 takes a number, the others read it from LDS (every chain of every wave ends here
+        // once the counter has passed n_blocks: the grid always drains)
+        if (gl == 0u) mem[c].bcast = atomicAdd(work, 1u);
+        xmi::chain_sync();
+        const uint32_t b = mem[c].bcast;
+        xmi::chain_sync();
+        if (b >= n_blocks) break;
+#ifdef XMI_TRACE
+        if (chain.trace && gl == 0u) __hip_atomic_store(chain.trace, 101u + (b << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+        const xm_bgzf_block d = blocks[b];
+        int rc = xmi::OK;
+        if (d.isize != 0u) rc = chain.run(&mem[c], gl, comp, d.cdata_off, d.cdata_len, out, d.out_off, d.isize);
+        if (gl == 0u) status[b] = (uint32_t)rc;
+    }
+}
+
+// CRC-32 of one block per wave: lane l takes the l-th 64th of the block byte by byte (table in LDS), the pieces are
+// combined by multiplying with x^(8 * bytes behind the piece) modulo the polynomial (square-and-multiply over GF(2)).
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)       // reflected representation, as the CRC itself
+{
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        p ^= (b & 0x80000000u) ? a : 0u;                                    // bit 31 of b = x^0
+        a = (a >> 1) ^ ((a & 1u) ? 0xEDB88320u : 0u);                       // a *= x
+        b <<= 1;
+    }
+    return p;
+}
+
+__global__ void __launch_bounds__(256)
+crc32_kernel(const uint8_t *__restrict__ out, const xm_bgzf_block *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ crc_out)
+{
+    __shared__ uint32_t table[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+        table[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= n_blocks) return;
+    const xm_bgzf_block d = blocks[b];
+    const uint32_t piece = (d.isize + 63u) / 64u;
+    const uint32_t lo = min(lane * piece, d.isize), hi = min(lo + piece, d.isize);
+    const uint8_t *p = out + d.out_off;
+    // the ordinary CRC-32 of the piece (an empty piece: 0); CRC(A || B) = CRC(A) * x^(8 |B|) + CRC(B) over GF(2), so the block's
+    // CRC is the sum of every piece's CRC times x^(8 * bytes behind the piece)
+    uint32_t c = 0;
+    if (hi > lo) {
+        c = 0xFFFFFFFFu;
+        for (uint32_t i = lo; i < hi; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+        c ^= 0xFFFFFFFFu;
+    }
+    uint32_t n = d.isize - hi, pw = 0x80000000u /* x^0 */, sq = 0x00800000u /* x^8 */;
+    while (n) {
+        if (n & 1u) pw = gf2_mulmod(pw, sq);
+        sq = gf2_mulmod(sq, sq);
+        n >>= 1;
+    }
+    c = gf2_mulmod(c, pw);
+    c ^= __shfl_xor(c, 1, 64);  c ^= __shfl_xor(c, 2, 64);  c ^= __shfl_xor(c, 4, 64);
+    c ^= __shfl_xor(c, 8, 64);  c ^= __shfl_xor(c, 16, 64); c ^= __shfl_xor(c, 32, 64);
+    if (lane == 0u) crc_out[b] = c;
+}
+
+inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+}  // namespace
+
+extern "C" {
+
+int xm_bgzf_index(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_out, xm_bgzf_block *blocks, uint32_t *crc,
+                  uint64_t cap, uint64_t *n_blocks, uint64_t *next, uint64_t *out_bytes)
+{
+    if (!d || !blocks || !n_blocks || !next || !out_bytes || start > len) return XM_ERR_INVALID_ARG;
+    uint64_t p = start, n = 0, acc = 0;
+    while (p < len && n < cap && acc < max_out) {
+        if (p + 18 > len || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) return XM_ERR_INVALID_ARG;
+        const uint32_t xlen = le16(d + p + 10);
+        if (p + 12 + xlen > len) return XM_ERR_INVALID_ARG;
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const uint32_t slen = le16(d + q + 2);
+            if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2 && q + 6 <= len) { bsize = le16(d + q + 4); found = true; }
+            q += 4 + slen;
+        }
+        if (!found) return XM_ERR_INVALID_ARG;
+        const uint64_t total = (uint64_t)bsize + 1;
+        if (total < 12 + xlen + 8 || p + total > len) return XM_ERR_INVALID_ARG;
+        const uint32_t isize = le32(d + p + total - 4);
+        if (isize > 65536u) return XM_ERR_INVALID_ARG;
+        blocks[n].cdata_off = p + 12 + xlen;
+        blocks[n].cdata_len = (uint32_t)(total - 12 - xlen - 8);
+        blocks[n].isize = isize;
+        blocks[n].out_off = acc;
+        if (crc) crc[n] = le32(d + p + total - 8);
+        acc += isize;
+        ++n;
+        p += total;
+    }
+    *n_blocks = n;
+    *next = p;
+    *out_bytes = acc;
+    return XM_OK;
+}
+
+int xm_bgzf_inflate_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm_bgzf_block *blocks, uint64_t n_blocks,
+                        uint8_t *out, uint32_t *status, uint32_t *work)
+{
+    if (!ctx || n_blocks > 0x7FFFFFFFull) return XM_ERR_INVALID_ARG;
+    if (n_blocks == 0) return XM_OK;
+    if (!comp || !blocks || !out || !status || !work || ((uintptr_t)comp & 15u) || ((uintptr_t)blocks & 7u)) return XM_ERR_INVALID_ARG;
+    int n_cu = 0;
+    if (xm_ctx_device_info(ctx, &n_cu, nullptr, 0) != XM_OK || n_cu <= 0) return XM_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(work, 0, sizeof(uint32_t), st) != hipSuccess) return XM_ERR_HIP;
+    constexpr int G = 64 / XM_INFLATE_GS;
+    const uint64_t waves_needed = (n_blocks + G - 1) / G;
+    // resident waves per CU: what the chains' LDS allows (160 KB per CU), at most XM_INFLATE_WG_PER_CU
+    constexpr uint64_t by_lds = (160u * 1024u) / (G * sizeof(xmi::ChainMem));
+    uint64_t grid = (uint64_t)n_cu * (by_lds < XM_INFLATE_WG_PER_CU ? by_lds : XM_INFLATE_WG_PER_CU);
+    if (grid > waves_needed) grid = waves_needed;
+    inflate_kernel<XM_INFLATE_GS><<<(uint32_t)grid, 64, 0, st>>>(comp, blocks, (uint32_t)n_blocks, out, status, work);
+    return hipGetLastError() == hipSuccess ? XM_OK : XM_ERR_HIP;
+}
+
+int xm_bgzf_crc32_dev(xm_ctx *ctx, void *stream, const uint8_t *out, const xm_bgzf_block *blocks, uint64_t n_blocks, uint32_t *crc_out)
+{
+    if (!ctx || n_blocks > 0x7FFFFFFFull) return XM_ERR_INVALID_ARG;
+    if (n_blocks == 0) return XM_OK;
+    if (!out || !blocks || !crc_out) return XM_ERR_INVALID_ARG;
+    crc32_kernel<<<(uint32_t)((n_blocks + 3) / 4), 256, 0, (hipStream_t)stream>>>(out, blocks, (uint32_t)n_blocks, crc_out);
+    return hipGetLastError() == hipSuccess ? XM_OK : XM_ERR_HIP;
+}
+
+const char *xm_bgzf_strerror(uint32_t s)
+{
+    switch (s) {
+    case xmi::OK: return "ok";
+    case xmi::ERR_BTYPE: return "reserved DEFLATE block type";
+    case xmi::ERR_STORED: return "stored block: LEN / NLEN mismatch";
+    case xmi::ERR_LENGTHS: return "bad code-length sequence";
+    case xmi::ERR_OVERSUB: return "over-subscribed Huffman code";
+    case xmi::ERR_NO_EOB: return "no end-of-block code";
+    case xmi::ERR_CODE: return "bits that match no Huffman code";
+    case xmi::ERR_DIST: return "match distance beyond the start of the block";
+    case xmi::ERR_OUT: return "more output than the block's ISIZE";
+    case xmi::ERR_IN: return "DEFLATE stream runs past the block's compressed bytes";
+    case xmi::ERR_SHORT: return "DEFLATE stream ends before ISIZE bytes";
+    case xmi::ERR_LENSYM: return "invalid length symbol";
+    default: return "unknown block status";
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,500 @@
+// xm_inflate_core.h -- raw-DEFLATE decoder of one BGZF block, written for a GROUP of GS lanes of one wavefront ("a chain").
+//
+// What it replaces: the reference reads BAM by piping it through `samtools view` (getBamReadPairs / bam_lines /
+// get_bam_header, /root/reference/xenomapper/xenomapper.py:48-93), i.e. htslib's BGZF layer + zlib's inflate.  The format is
+// RFC 1951 (DEFLATE) inside RFC 1952 members with the BGZF extra field (SAM specification section 4.1); nothing here is
+// taken from zlib or htslib -- the decoder is restated from the RFC for the execution model below.
+//
+// Execution model.  DEFLATE is a serial chain per block (every symbol's position depends on the one before), so the
+// parallelism is ACROSS blocks: a chain = GS lanes of one wave decodes one BGZF block at a time; a wave runs 64 / GS chains
+// side by side (SIMT: every lane of a chain computes the chain's scalar state redundantly -- bit buffer, positions -- so no
+// cross-lane traffic is needed for it), and the lanes of a chain split what is data-parallel: filling decode tables, copying
+// matches (GS bytes per step), moving input and output between LDS and global memory in 16-byte pieces.  A chain never spans
+// waves and a wave executes in lockstep, so lanes of a chain communicate through LDS in program order: no barrier anywhere.
+//
+// Per chain, in LDS (ChainMem, ~5 KB): the two Huffman decoders (a root table indexed by the next ROOT bits -- entries
+// placed at bit-reversed codes, as the bits arrive LSB first -- plus the canonical (first code, limit, base) triples and the
+// sorted symbol list for the rare longer codes), an input ring refilled 128 bytes at a time with the next piece already in
+// flight, and an OUTPUT RING of 1 KiB: every produced byte goes there first; complete 16-byte lines are flushed to global
+// memory 128 bytes at a time (aligned 16-byte stores), and a match reads its source from the ring when it is recent and
+// from global memory when it is older than the flush before last (whose stores have been waited for since) -- so no store
+// is ever waited for right after it was issued.
+//
+// The same source compiles for the host with GS = 1 (tests/inflate_core_host.cpp: the decoder's LOGIC against zlib on this
+// CPU-only build container); that build is test infrastructure and is not part of any library.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define XMI_HD __device__ __forceinline__
+#define XMI_DEVICE 1
+#else
+#define XMI_HD inline
+#define XMI_DEVICE 0
+#endif
+
+namespace xmi {
+
+enum : int {
+    OK = 0,
+    ERR_BTYPE = 1,          // reserved block type
+    ERR_STORED = 2,         // LEN / NLEN mismatch
+    ERR_LENGTHS = 3,        // bad code-length sequence (repeat with no previous length, too many lengths)
+    ERR_OVERSUB = 4,        // over-subscribed Huffman code
+    ERR_NO_EOB = 5,         // no end-of-block code
+    ERR_CODE = 6,           // bits that match no code
+    ERR_DIST = 7,           // distance beyond the start of the block, or distance code 30 / 31
+    ERR_OUT = 8,            // more output than the block's ISIZE
+    ERR_IN = 9,             // ran past the end of the compressed data
+    ERR_SHORT = 10,         // stream ended with fewer bytes than ISIZE
+    ERR_LENSYM = 11,        // length symbol 286 / 287
+    ERR_GUARD = 12          // more decoding steps than any valid block of this size can take (the loops' own exit conditions
+                            // make this unreachable; it is the belt to their braces: a wave must always drain)
+};
+
+constexpr int LIT_ROOT = 10;            // bits of the literal/length root table
+constexpr int DIST_ROOT = 8;
+constexpr int CLC_ROOT = 7;             // the code-length code: lengths <= 7, the root table is complete
+constexpr uint32_t ORING = 1024;        // output ring bytes (power of two)
+constexpr uint32_t FLUSH = 128;         // bytes after which complete output lines are stored
+constexpr uint32_t IRING = 256;         // input ring bytes
+constexpr uint32_t ICHUNK = 128;        // input refill granule
+
+struct alignas(16) ChainMem {
+    uint8_t oring[ORING];
+    uint8_t iring[IRING];
+    uint16_t lit_root[1 << LIT_ROOT];   // (symbol << 4) | code length; 0: a longer code (or no code) starts with these bits
+    uint16_t dist_root[1 << DIST_ROOT]; // also holds the code-length code's root table while the lengths are read
+    uint16_t lit_sym[288];              // symbols in canonical order (by length, then value)
+    uint16_t dist_sym[32];
+    uint16_t lit_meta[3][16];           // per code length: first code, limit (first + count), index of its first symbol
+    uint16_t dist_meta[3][16];
+    uint32_t cnt[16];                   // symbols per length while a table is built, then the running index per length
+    uint32_t bcast;                     // one word handed from lane 0 to the chain
+    uint8_t cl[352];                    // code lengths: [0, 316) literal/length + distance, [320, 339) the code-length code
+};
+
+struct u128 { uint32_t w[4]; };
+
+XMI_HD uint32_t bitrev32(uint32_t v)
+{
+#if XMI_DEVICE
+    return __brev(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+
+XMI_HD void drain_stores()
+{
+#if XMI_DEVICE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// the lanes of a chain are about to read LDS another lane of the chain wrote (or the reverse): nothing to wait for -- a
+// wave's LDS operations execute in issue order -- but the compiler must not move accesses across this point
+XMI_HD void chain_sync()
+{
+#if XMI_DEVICE
+#ifdef XMI_SYNC_ASM
+    asm volatile("" ::: "memory");
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+XMI_HD u128 load16(const uint8_t *p)
+{
+    u128 v;
+#if XMI_DEVICE
+    const uint4 q = *reinterpret_cast<const uint4 *>(p);
+    v.w[0] = q.x; v.w[1] = q.y; v.w[2] = q.z; v.w[3] = q.w;
+#else
+    memcpy(&v, p, 16);
+#endif
+    return v;
+}
+
+XMI_HD void store16(uint8_t *p, const u128 &v)
+{
+#if XMI_DEVICE
+    *reinterpret_cast<uint4 *>(p) = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+#else
+    memcpy(p, &v, 16);
+#endif
+}
+
+XMI_HD void count_inc(uint32_t *p)
+{
+#if XMI_DEVICE
+    atomicAdd(p, 1u);
+#else
+    ++*p;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One chain's decoder state.  Everything here is identical in all lanes of the chain except `gl` and `pend`.
+// ---------------------------------------------------------------------------------------------------------------------
+// XMI_TRACE builds (tools/inflate_gpu_check.hip --trace): every chain leaves the number of the stage it has reached in a
+// host-visible word, so that a launch that does not come back can be read from outside
+#ifdef XMI_TRACE
+#define XMI_STAGE(code) do { if (trace && gl == 0u) __hip_atomic_store(trace, (uint32_t)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#elif defined(XMI_STAGE_BARRIER)
+#define XMI_STAGE(code) asm volatile("" ::: "memory")
+#else
+#define XMI_STAGE(code) do { } while (0)
+#endif
+
+template <int GS>
+struct Chain {
+    uint32_t *trace = nullptr;
+    static constexpr int NP = (8 + GS - 1) / GS;          // 16-byte pieces of an input granule per lane
+    ChainMem *m;
+    uint32_t gl;                 // lane within the chain
+    // input: positions relative to cbase (128-byte aligned, at or below the block's first byte)
+    const uint8_t *cbase;
+    uint32_t in_pos;             // next 4-byte word to take from the ring
+    uint32_t loaded;             // bytes [.., loaded) are in the ring; [loaded, loaded + 128) is in flight in `pend`
+    uint32_t cend;               // end of the block's compressed bytes
+    u128 pend[NP];
+    uint64_t bits;
+    uint32_t nbits;
+    // output: positions in "v-space" = offset from vbase, the 16-byte aligned address at or below the block's first byte
+    uint8_t *vbase;
+    uint32_t op, oend;           // next byte to produce, end of the block (start + ISIZE)
+    uint32_t ostart;             // first byte of the block
+    uint32_t flushed;            // bytes below this have been stored to global memory
+    uint32_t gsafe;              // bytes below this were stored AND waited for: readable from global memory
+    uint32_t budget;             // decoding steps left (every symbol, every block header costs one)
+    int err;
+
+    // ---- input ----
+    XMI_HD void issue_load()
+    {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const uint32_t piece = gl + (uint32_t)q * GS;
+            if (piece < 8u) pend[q] = load16(cbase + loaded + piece * 16u);
+        }
+    }
+    XMI_HD void land_load()
+    {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const uint32_t piece = gl + (uint32_t)q * GS;
+            if (piece < 8u) store16(m->iring + ((loaded + piece * 16u) & (IRING - 1u)), pend[q]);
+        }
+        loaded += ICHUNK;
+        chain_sync();
+    }
+    // start reading at byte `byte_pos` (relative to cbase): two granules land now, the third is in flight
+    XMI_HD void in_init(uint32_t byte_pos)
+    {
+        loaded = byte_pos & ~(ICHUNK - 1u);
+        issue_load(); land_load();
+        issue_load(); land_load();
+        issue_load();
+        in_pos = byte_pos & ~3u;
+        bits = 0; nbits = 0;
+        need32();
+        drop(8u * (byte_pos & 3u));
+    }
+    XMI_HD void need32()          // at least 32 valid bits (the tail of the stream is followed by padding)
+    {
+        if (nbits < 32u) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(m->iring + (in_pos & (IRING - 1u)));
+            bits |= (uint64_t)w << nbits;
+            nbits += 32u;
+            in_pos += 4u;
+            if (in_pos > cend + 12u) err = err ? err : ERR_IN;
+            if (loaded - in_pos < 64u) { land_load(); issue_load(); }
+        }
+    }
+    XMI_HD uint32_t peek(uint32_t n) const { return (uint32_t)bits & ((1u << n) - 1u); }       // n <= 16
+    XMI_HD void drop(uint32_t n) { bits >>= n; nbits -= n; }
+    XMI_HD uint32_t get(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+
+    // ---- output ----
+    XMI_HD void put_byte(uint32_t pos, uint32_t b) { m->oring[pos & (ORING - 1u)] = (uint8_t)b; }
+    // store ring bytes [lo, hi) to global memory: whole aligned 16-byte lines with one store, the rest byte by byte
+    XMI_HD void store_range(uint32_t lo, uint32_t hi)
+    {
+        for (uint32_t c = (lo & ~15u) + 16u * gl; c < hi; c += 16u * GS) {
+            if (c >= lo && c + 16u <= hi) {
+                store16(vbase + c, load16(m->oring + (c & (ORING - 1u))));
+            } else {
+                const uint32_t a = c > lo ? c : lo, b = c + 16u < hi ? c + 16u : hi;
+                for (uint32_t p = a; p < b; ++p) vbase[p] = m->oring[p & (ORING - 1u)];
+            }
+        }
+    }
+    XMI_HD void maybe_flush()
+    {
+        while (op - flushed >= FLUSH) {
+            chain_sync();
+            drain_stores();                     // the flush before this one: long complete
+            gsafe = flushed;
+            const uint32_t hi = op & ~15u;
+            store_range(flushed, hi);
+            flushed = hi;
+        }
+    }
+    XMI_HD void final_flush()
+    {
+        chain_sync();
+        store_range(flushed, op);
+        flushed = op;
+    }
+    XMI_HD uint32_t byte_at(uint32_t pos) const       // a byte produced earlier
+    {
+        return pos >= gsafe ? (uint32_t)m->oring[pos & (ORING - 1u)] : (uint32_t)vbase[pos];
+    }
+
+    // ---- Huffman tables ----
+    // code lengths cl[0 .. n) -> root table of RB bits, canonical triples, sorted symbols.  false: over-subscribed.
+    XMI_HD bool build(const uint8_t *cl, uint32_t n, uint16_t *root, uint32_t RB, uint16_t *sym, uint16_t (*meta)[16])
+    {
+        XMI_STAGE(40);
+        chain_sync();
+        for (uint32_t i = gl; i < 16u; i += GS) m->cnt[i] = 0u;
+        chain_sync();
+        for (uint32_t s = gl; s < n; s += GS) count_inc(&m->cnt[cl[s]]);
+        XMI_STAGE(41);
+        const u128 zero = {{0u, 0u, 0u, 0u}};
+        for (uint32_t i = gl * 8u; i < (1u << RB); i += GS * 8u) store16(reinterpret_cast<uint8_t *>(root + i), zero);
+        chain_sync();
+        uint32_t code = 0, idx = 0;
+        int32_t left = 1;
+        uint32_t first[16], base[16];
+        first[0] = base[0] = 0;
+#pragma unroll
+        for (uint32_t L = 1; L < 16u; ++L) {
+            const uint32_t c = m->cnt[L];
+            left = (left << 1) - (int32_t)c;
+            if (left < 0) return false;
+            first[L] = code; base[L] = idx;
+            if (gl == 0u) { meta[0][L] = (uint16_t)code; meta[1][L] = (uint16_t)(code + c); meta[2][L] = (uint16_t)idx; }
+            code = (code + c) << 1;
+            idx += c;
+        }
+        chain_sync();
+        for (uint32_t i = gl; i < 16u; i += GS) m->cnt[i] = 0u;          // now: symbols of each length placed so far
+        chain_sync();
+        XMI_STAGE(42);
+        for (uint32_t s = 0; s < n; ++s) {
+            const uint32_t L = cl[s];
+            if (L == 0u) continue;
+            const uint32_t k = m->cnt[L];
+            uint32_t f = 0, b = 0;
+#pragma unroll
+            for (uint32_t q = 1; q < 16u; ++q) { f = (L == q) ? first[q] : f; b = (L == q) ? base[q] : b; }
+            chain_sync();
+            if (gl == 0u) { m->cnt[L] = k + 1u; sym[b + k] = (uint16_t)s; }
+            if (L <= RB) {
+                const uint32_t r = bitrev32(f + k) >> (32u - L);           // the code as its bits arrive
+                const uint16_t e = (uint16_t)((s << 4) | L);
+                for (uint32_t j = gl; j < (1u << (RB - L)); j += GS) root[r + (j << L)] = e;
+            }
+            chain_sync();
+        }
+        return true;
+    }
+    // one symbol; at least 15 valid bits must be buffered (need32 before)
+    XMI_HD uint32_t decode(const uint16_t *root, uint32_t RB, const uint16_t *sym, const uint16_t (*meta)[16])
+    {
+        const uint32_t e = root[(uint32_t)bits & ((1u << RB) - 1u)];
+        const uint32_t L = e & 15u;
+        if (L) { drop(L); return e >> 4; }
+        const uint32_t rev = bitrev32((uint32_t)bits) >> 17;               // the next 15 bits, first bit on top
+        for (uint32_t q = RB + 1u; q <= 15u; ++q) {
+            const uint32_t c = rev >> (15u - q);
+            const uint32_t f = meta[0][q], lim = meta[1][q];
+            if (c >= f && c < lim) { drop(q); return sym[meta[2][q] + c - f]; }
+        }
+        err = err ? err : ERR_CODE;
+        return 256u;                                                        // ends the block
+    }
+
+    // ---- blocks ----
+    XMI_HD void stored_block()
+    {
+        drop(nbits & 7u);                                                   // to the next byte boundary
+        need32();
+        const uint32_t len = get(16u);
+        need32();
+        const uint32_t nlen = get(16u);
+        if ((len ^ 0xFFFFu) != nlen) { err = ERR_STORED; return; }
+        const uint32_t bp = in_pos - (nbits >> 3);                          // next unread byte of the input
+        if (bp + len > cend) { err = ERR_IN; return; }
+        if (op + len > oend) { err = ERR_OUT; return; }
+        for (uint32_t k0 = 0; k0 < len; k0 += GS) {
+            const uint32_t k = k0 + gl;
+            if (k < len) put_byte(op + gl, cbase[bp + k]);                  // op has advanced by k0 already
+            op += (len - k0 < (uint32_t)GS) ? len - k0 : (uint32_t)GS;
+            maybe_flush();
+        }
+        chain_sync();
+        in_init(bp + len);
+    }
+    XMI_HD bool fixed_tables()
+    {
+        for (uint32_t s = gl; s < 288u; s += GS) m->cl[s] = (uint8_t)(s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8);
+        for (uint32_t s = gl; s < 32u; s += GS) m->cl[288u + s] = 5;
+        chain_sync();
+        return build(m->cl, 288u, m->lit_root, LIT_ROOT, m->lit_sym, m->lit_meta) &&
+               build(m->cl + 288, 30u, m->dist_root, DIST_ROOT, m->dist_sym, m->dist_meta);
+    }
+    XMI_HD bool dynamic_tables()
+    {
+        need32();
+        const uint32_t hlit = get(5u) + 257u, hdist = get(5u) + 1u, hclen = get(4u) + 4u;
+        if (hlit > 286u || hdist > 30u) { err = ERR_LENGTHS; return false; }
+        for (uint32_t i = gl; i < 19u; i += GS) m->cl[320u + i] = 0;
+        chain_sync();
+        for (uint32_t i = 0; i < hclen; ++i) {
+            need32();
+            const uint32_t v = get(3u);
+            // the order of RFC 1951 3.2.7: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+            const uint32_t at = i < 3u ? 16u + i : i == 3u ? 0u : (i & 1u) ? (19u - i) >> 1 : 6u + (i >> 1);
+            if (gl == 0u) m->cl[320u + at] = (uint8_t)v;
+        }
+        chain_sync();
+        if (!build(m->cl + 320, 19u, m->dist_root, CLC_ROOT, m->dist_sym, m->dist_meta)) { err = ERR_OVERSUB; return false; }
+        XMI_STAGE(50);
+        uint32_t i = 0, prev = 0;
+        const uint32_t total = hlit + hdist;
+        while (i < total) {
+            if (budget-- == 0u) { err = ERR_GUARD; return false; }
+            need32();
+            const uint32_t s = decode(m->dist_root, CLC_ROOT, m->dist_sym, m->dist_meta);
+            if (err) return false;
+            if (s < 16u) {
+                if (gl == 0u) m->cl[i] = (uint8_t)s;
+                prev = s; ++i;
+                continue;
+            }
+            uint32_t rep, val = 0;
+            if (s == 16u) {
+                if (i == 0u) { err = ERR_LENGTHS; return false; }
+                rep = 3u + get(2u); val = prev;
+            } else if (s == 17u) {
+                rep = 3u + get(3u);
+            } else if (s == 18u) {
+                rep = 11u + get(7u);
+            } else { err = ERR_LENGTHS; return false; }
+            if (i + rep > total) { err = ERR_LENGTHS; return false; }
+            for (uint32_t k = gl; k < rep; k += GS) m->cl[i + k] = (uint8_t)val;
+            if (s != 16u) prev = 0;
+            i += rep;
+        }
+        chain_sync();
+        if (m->cl[256] == 0) { err = ERR_NO_EOB; return false; }
+        if (!build(m->cl, hlit, m->lit_root, LIT_ROOT, m->lit_sym, m->lit_meta) ||
+            !build(m->cl + hlit, hdist, m->dist_root, DIST_ROOT, m->dist_sym, m->dist_meta)) { err = ERR_OVERSUB; return false; }
+        return true;
+    }
+    XMI_HD void copy_match(uint32_t len, uint32_t dist)
+    {
+        if (dist >= (uint32_t)GS) {
+            for (uint32_t k0 = 0; k0 < len; k0 += GS) {
+                const uint32_t k = k0 + gl;
+                if (k < len) put_byte(op + k, byte_at(op + k - dist));
+                chain_sync();                                               // the next step may read what this one wrote
+            }
+        } else {
+            // the source period is shorter than a step: every byte of the match is one of the `dist` bytes in front of it
+            const uint32_t inv = 65536u / dist + 1u;                        // k / dist == (k * inv) >> 16 for k < 1024
+            for (uint32_t k0 = 0; k0 < len; k0 += GS) {
+                const uint32_t k = k0 + gl;
+                if (k < len) put_byte(op + k, byte_at(op - dist + (k - ((k * inv) >> 16) * dist)));
+            }
+            chain_sync();
+        }
+        op += len;
+    }
+    XMI_HD void huffman_block()
+    {
+        while (!err) {
+            if (budget-- == 0u) { err = ERR_GUARD; return; }
+            need32();
+            const uint32_t s = decode(m->lit_root, LIT_ROOT, m->lit_sym, m->lit_meta);
+            if (s < 256u) {
+                if (op >= oend) { err = ERR_OUT; return; }
+                if (gl == 0u) put_byte(op, s);
+                ++op;
+                maybe_flush();
+                continue;
+            }
+            if (s == 256u) return;
+            if (s > 285u) { err = ERR_LENSYM; return; }
+            uint32_t len;
+            if (s < 265u) len = s - 254u;
+            else if (s == 285u) len = 258u;
+            else { const uint32_t eb = (s - 261u) >> 2; len = ((4u + ((s - 261u) & 3u)) << eb) + 3u + get(eb); }
+            need32();
+            const uint32_t d = decode(m->dist_root, DIST_ROOT, m->dist_sym, m->dist_meta);
+            if (err) return;
+            if (d > 29u) { err = ERR_DIST; return; }
+            uint32_t dist;
+            if (d < 4u) dist = d + 1u;
+            else { const uint32_t eb = (d >> 1) - 1u; dist = ((2u + (d & 1u)) << eb) + 1u + get(eb); }
+            if (dist > op - ostart) { err = ERR_DIST; return; }
+            if (len > oend - op) { err = ERR_OUT; return; }
+            chain_sync();                                                   // literals written by lane 0 are in the ring
+            copy_match(len, dist);
+            maybe_flush();
+        }
+    }
+
+    // the whole BGZF block: comp + coff .. + clen -> out + ooff .. + isize.  Returns the status.
+    XMI_HD int run(ChainMem *mem, uint32_t lane_in_chain, const uint8_t *comp, uint64_t coff, uint32_t clen,
+                   uint8_t *out, uint64_t ooff, uint32_t isize)
+    {
+        m = mem; gl = lane_in_chain; err = OK;
+        const uint64_t cb = coff & ~(uint64_t)(ICHUNK - 1u);
+        cbase = comp + cb;
+        cend = (uint32_t)(coff - cb) + clen;
+        const uintptr_t oaddr = reinterpret_cast<uintptr_t>(out + ooff);
+        vbase = reinterpret_cast<uint8_t *>(oaddr & ~(uintptr_t)15);
+        ostart = (uint32_t)(oaddr & 15u);
+        op = flushed = gsafe = ostart;
+        oend = ostart + isize;
+        XMI_STAGE(1);
+        in_init((uint32_t)(coff - cb));
+        XMI_STAGE(2);
+        bool last = false;
+        budget = 8u * clen + isize + 4096u;          // a symbol costs at least one bit or yields at least one byte
+        while (!last && !err) {
+            if (budget-- == 0u) { err = ERR_GUARD; break; }
+            need32();
+            last = get(1u) != 0u;
+            const uint32_t type = get(2u);
+            XMI_STAGE(10u + type);
+            if (type == 0u) stored_block();
+            else if (type == 3u) err = ERR_BTYPE;
+            else {
+                const bool have = type == 1u ? fixed_tables() : dynamic_tables();
+                XMI_STAGE(20);
+                if (have) huffman_block();
+                else err = err ? err : ERR_OVERSUB;
+                XMI_STAGE(21);
+            }
+        }
+        if (!err && op != oend) err = ERR_SHORT;
+        if (!err && in_pos - (nbits >> 3) > cend) err = ERR_IN;
+        XMI_STAGE(30);
+        final_flush();
+        XMI_STAGE(31);
+        return err;
+    }
+};
+
+}  // namespace xmi
