@@ -19,6 +19,7 @@
 #define XENOMAPPER_BGZF_H
 
 #include "xenomapper_hip.h"
+#include "xenomapper_strip.h"     /* XMS_SCORE_*, XMS_LINE_* */
 
 #ifdef __cplusplus
 extern "C" {
@@ -66,6 +67,76 @@ int xm_bgzf_crc32_dev(xm_ctx *ctx, void *stream, const uint8_t *out, const xm_bg
                       uint32_t *crc_out);
 
 const char *xm_bgzf_strerror(uint32_t block_status);
+
+/* ---- BAM records -> the classifier's columns, on the device ------------------------------------------------------------
+ *
+ * xm_bamdev: the device half of BAM input for the lock-step walk of two files (getBamReadPairs, xenomapper.py:66-93, with
+ * getReadPairs' walk :95-118): per window and file the caller stages compressed BGZF blocks, the library inflates them
+ * (xm_bgzf_inflate_dev + the CRC check), finds the alignment records, reads AS / XS / ZS of every record with the plugins'
+ * rules applied to the typed fields (get_tag :176-191, get_tag_with_ZS_as_XS :193-206: a tag is matched by the field of
+ * that name and by any Z / H field whose printed text contains the two letters; two matches = the duplicate error;
+ * a match that is not an integer inside [-(2^31-1), 2^31-1] is flagged, never guessed), compares the names of the two
+ * files (:106) and of adjacent records (:402) and leaves the score columns and the unit mask IN HBM for the classify
+ * kernels.  What comes back to the host: the inflated bytes and the record table (the writer prints the SAM text of the
+ * records from them: xmh_bam_print), and per-record exception flags.
+ *
+ * Scope: the walk without skip_repeated_reads, score modes XMS_SCORE_AS_XS / XMS_SCORE_AS_ZS.  BGZF blocks must begin
+ * at a record boundary (what htslib / samtools write: bgzf_flush_try before every record); a file written otherwise is
+ * reported (`unaligned`) and goes through the host decoder of xenomapper_host.h, as do --cigar_scores, the skipping
+ * walk, and windows holding a record the text rules might split differently (`weird`: white space, control or non-ASCII
+ * bytes in a name, tag or string value, qualities above 93, CIGARs kept in a CG field).
+ */
+typedef struct xm_bamdev xm_bamdev;
+
+typedef struct {
+    uint64_t n_records;              /* record pairs yielded by the walk in this window                                          */
+    uint64_t consumed1, consumed2;   /* bytes of each window (carry included) the walk is finished with; with keep_halo the
+                                        last yielded record is NOT consumed                                                     */
+    uint64_t raw_len1, raw_len2;     /* inflated bytes in each window: carry + the blocks of this call                           */
+    uint64_t n_rec1, n_rec2;         /* complete records found in each window                                                    */
+    int32_t  ended, starved;         /* as xmh_block: a file ran out of records at its end / more input is needed                */
+    int64_t  mismatch_at;            /* first pair whose names differ (AssertionError, :106) or -1                               */
+    int32_t  bad_block;              /* != 0: a BGZF block failed (decoder status or CRC-32), a malformed record, or a file that
+                                        ends inside a record: nothing else is meaningful                                         */
+    int32_t  unaligned;              /* 1: a block does not begin with a record: no record table, use the host decoder           */
+    int32_t  weird;                  /* 1: a record the text rules might read differently: use the host decoder for this window  */
+    int32_t  reserved;
+    uint64_t n_exceptions;           /* pairs whose flags carry XMS_LINE_EX_A / _EX_X on either record                           */
+    const uint8_t  *raw1, *raw2;     /* page-locked host copies of the inflated windows (valid until the slot runs again)       */
+    const uint32_t *rec_off1, *rec_off2;   /* start of every record (its block_size word) in raw*: n_rec* entries              */
+    const uint8_t  *flags1, *flags2;       /* per yielded pair: XMS_LINE_NORMAL | exception bits (XMS_LINE_EX_A / _EX_X)        */
+    float ms_inflate, ms_kernels;    /* device time of the inflate + CRC launches, and of the record kernels (HIP events)       */
+} xm_bamdev_block;
+
+/* what one file contributes to a window */
+typedef struct {
+    uint64_t comp_len;               /* compressed bytes staged in xm_bamdev_staging(slot, file)                                */
+    const xm_bgzf_block *blocks;     /* host array: the blocks inside those bytes (cdata_off relative to the staging buffer,
+                                        out_off from 0 = behind the carry), with their trailer CRCs                              */
+    const uint32_t *crc;
+    uint64_t n_blocks;
+    int32_t  carry_slot;             /* bytes [carry_off, carry_off + carry_len) of this file's previous window (slot             */
+    uint64_t carry_off, carry_len;   /*   carry_slot) are put in front of the new bytes; carry_len 0: none                       */
+    int32_t  eof;                    /* no block of the file is left behind these                                                */
+    uint64_t skip;                   /* the first `skip` inflated bytes of the new blocks are not alignment records (the BAM
+                                        header: magic, text, reference list); less than the first block's ISIZE                   */
+} xm_bamdev_input;
+
+int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out);
+int xm_bamdev_destroy(xm_bamdev *b);                          /* while ctx is alive (its streams are handed back)                */
+/* room per slot and file for comp_bytes of compressed input, raw_bytes of inflated window, max_blocks, max_records */
+int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_bytes, uint64_t max_blocks, uint64_t max_records);
+uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file);
+/* inflate, find the records, strip, pair.  Blocking (the slot's own stream). */
+int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
+                  uint64_t max_records, xm_bamdev_block *out);
+/* the fused main loop on the slot's columns (as xm_strip_classify) */
+int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int32_t min_score_floor,
+                       const uint8_t **code, const uint32_t **idx, uint64_t bin_offsets[8], uint64_t counts[64]);
+/* the slot's score columns and unit mask copied to the host (records the caller must patch by the text rules) */
+int xm_bamdev_columns(xm_bamdev *b, int slot, uint64_t n_records, int32_t *as1, int32_t *xs1, int32_t *as2, int32_t *xs2,
+                      uint64_t *unit_bits);
+const char *xm_bamdev_last_error(const xm_bamdev *b);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,24 @@ typedef struct {
 int xmh_bam_read_pre(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof,
                      xmh_pre *pre, uint64_t pre_cap, uint64_t *n_pre, uint32_t *ops, uint64_t ops_cap, uint64_t *n_ops);
 
+/*
+ * The host half of BAM input decoded ON THE GPU (include/xenomapper_bgzf.h, xm_bamdev_*): the device inflates the blocks and
+ * strips the records; what the writer needs is the SAM text of the records, printed here from the inflated bytes.
+ * xmh_bam_records_start: inflated offset of the first alignment record (behind the magic, the header text and the
+ * reference list), right after xmh_bam_open.  xmh_bam_print: records rec_off[0 .. n) of `raw` (each offset is the record's
+ * block_size word) printed as `samtools view` prints them, back to back into dst (n lines, each ending in '\n'), in
+ * parallel; line_off / line_len (n entries each, caller arrays): where every line begins in dst and its length without
+ * the terminator.  *written = bytes the text takes; XMH_ERR_INVALID_ARG with *written set when cap is too small (or the
+ * text passes 4 GiB), XMH_ERR_BAD_BAM for a malformed record.  Reference names come from b's header.
+ */
+int xmh_bam_records_start(xmh_bam *b, uint64_t *inflated_offset);
+/* The record chain of an inflated window followed on the host (files whose BGZF blocks do not begin with a record: the
+ * device walks block by block and cannot): records whose block_size word begins at or behind `start` and that end inside
+ * the window; rec_off may be NULL (count only); *stop = first byte not covered by a complete record. */
+int xmh_bam_walk(const uint8_t *raw, uint64_t len, uint64_t start, uint32_t *rec_off, uint64_t cap, uint64_t *n_records, uint64_t *stop);
+int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, char *dst, uint64_t cap,
+                  uint32_t *line_off, uint32_t *line_len, uint64_t *written);
+
 /* xmh_parse on windows of text that xmh_bam_read_pre wrote, without tokenising it again: pre1 / pre2 describe the lines
  * from the first byte of buf1 / buf2 on (entries past the window are ignored), ops1 / ops2 are the arrays (n_ops1 / n_ops2
  * words) their ops_at refer to.  Same results as xmh_parse, or XMH_NEED_TEXT (nothing parsed) when a line is marked

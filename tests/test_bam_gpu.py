@@ -1,0 +1,197 @@
+"""BAM input decoded ON THE GPU (include/xenomapper_bgzf.h: xm_bamdev_* = inflate + CRC + record chain + stripper + pair kernel)
+against the text rules of the reference's plugins applied to the printed SAM text (the oracle's tag_score on the lines
+`samtools view` would print, restated by oracle/bam_oracle.py / the host decoder), and the whole file path with either
+BAM front end byte for byte.  The reference code this path replaces: getBamReadPairs / bam_lines, xenomapper.py:56-93, with
+get_tag / get_tag_with_ZS_as_XS :176-206 on the lines."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from tests import helpers as H
+from tests.test_host_fuzz import bam_file_pair
+
+pytestmark = pytest.mark.gpu
+
+DATA = os.path.join(H.REPO, "tests", "golden", "ref_data")
+sys.path.insert(0, os.path.join(H.REPO, "tools"))
+ABSENT = -2**31
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from xenomapper_amd import xenomapper as xm
+    return xm.default_context()
+
+
+def host_text(image):
+    """The SAM text of a BAM image through the host decoder (pinned to oracle/bam_oracle.py in test_host_fuzz)."""
+    from xenomapper_amd import _host
+    r = _host.BamReader(np.frombuffer(image, dtype=np.uint8), 2)
+    buf = np.empty(max(1 << 16, 8 * len(image) + (1 << 16)), dtype=np.uint8)
+    at = 0
+    while not r.eof:
+        got = r.read_into(buf, at)
+        assert got or r.eof
+        at += got
+    r.close()
+    return bytes(buf[:at])
+
+
+def expected_from_text(line, tag):
+    """What the device must report for one record and tag, from the printed line: (value or ABSENT, flag 0 / 1 NONINT / 2 DUP).
+    The plugins match a tag as a substring of any optional field (xenomapper.py:186) and raise on two matches (:189-190); the
+    device vouches for a value only when the ONE matching field is the tag's own integer-typed field inside int32."""
+    fields = line.split(b"\t")[11:]
+    hits = [x for x in fields if tag in x]
+    if not hits:
+        return ABSENT, 0
+    if len(hits) > 1:
+        return ABSENT, 2
+    parts = hits[0].split(b":")
+    if hits[0][:2] == tag and len(parts) == 3 and parts[1] == b"i":
+        v = int(parts[2])
+        if -(2**31 - 1) <= v <= 2**31 - 1:
+            return v, 0
+    return ABSENT, 1
+
+
+def run_whole_files(dev, images, score_mode, paired, halo=False):
+    from xenomapper_amd import _ffi, _host
+    inputs, readers = [], []
+    for f, image in enumerate(images):
+        data = np.frombuffer(image, dtype=np.uint8)
+        reader = _host.BamReader(data, 2)
+        at = reader.records_start()
+        blocks, crc, nxt, total = _ffi.bgzf_index(data)
+        ends = blocks["out_off"] + blocks["isize"]
+        j = int(np.searchsorted(ends, at, side="right"))
+        blocks, crc = blocks[j:].copy(), crc[j:]
+        skip = 0
+        comp_len = 0
+        if len(blocks):
+            skip = at - int(blocks["out_off"][0])
+            blocks["out_off"] -= blocks["out_off"][0]
+            c0 = int(blocks["cdata_off"][0])
+            comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1]) - c0
+            blocks["cdata_off"] -= np.uint64(c0)
+        inputs.append((c0 if len(blocks) else 0, comp_len, {"comp_len": comp_len, "blocks": blocks, "crc": crc, "eof": True, "skip": skip}))
+        readers.append(reader)
+    raw_cap = max(1 << 16, max(int(x[2]["blocks"]["isize"].sum()) if len(x[2]["blocks"]) else 0 for x in inputs) + 64)
+    dev.reserve(0, raw_cap + 4096, raw_cap, 4096, 1 << 16)
+    for f, (c0, comp_len, _x) in enumerate(inputs):
+        if comp_len:
+            dev.staging(0, f)[:comp_len] = np.frombuffer(images[f], dtype=np.uint8)[c0:c0 + comp_len]
+    blk = dev.run(0, [x[2] for x in inputs], score_mode, paired, halo, 1 << 16)
+    return blk, readers
+
+
+@settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "80")), deadline=None, suppress_health_check=list(HealthCheck))
+@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share")), score_mode=st.sampled_from([0, 1]), paired=st.booleans())
+def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mode, paired):
+    """Record by record: value and flag of AS and XS (or ZS) exactly as the printed text dictates (a flag must be justified and
+    a justified flag must be raised), names (unit mask, first mismatch), the walk's outcome, and `weird` exactly when a
+    line holds a byte the text rules could split at."""
+    from xenomapper_amd import _ffi
+    dev = _ffi.BamDev(ctx)
+    try:
+        blk, readers = run_whole_files(dev, images, score_mode, paired)
+        assert not blk.bad_block and not blk.unaligned
+        lines = [host_text(im).split(b"\n")[:-1] for im in images]
+        assert blk.n_rec == (len(lines[0]), len(lines[1]))
+        n_pairs = min(len(lines[0]), len(lines[1]))
+        names = [[l.split(b"\t")[0] for l in ls] for ls in lines]
+        mism = next((k for k in range(n_pairs) if names[0][k] != names[1][k]), -1)
+        assert blk.mismatch_at == mism
+        n = mism if mism >= 0 else n_pairs
+        assert blk.n == n
+        risky = any(any(c <= 0x20 and c != 9 or c >= 0x7F for c in l) or l.startswith(b"\t") or b"\t\t" in l
+                    for ls in lines for l in ls[:n_pairs])
+        assert blk.weird == risky
+        if mism < 0:
+            assert blk.ended and not blk.starved                   # whole files in one window
+        xtag = b"ZS" if score_mode == 1 else b"XS"
+        cols = blk.cols
+        flags = blk.line_flags
+        for k in range(n):
+            for f in (0, 1):
+                va, fa = expected_from_text(lines[f][k], b"AS")
+                vx, fx = expected_from_text(lines[f][k], xtag)
+                assert (int(cols[2 * f][k]), (int(flags[f][k]) >> 2) & 7) == (va, fa), (k, f, lines[f][k])
+                assert (int(cols[2 * f + 1][k]), (int(flags[f][k]) >> 5) & 3) == (vx, fx), (k, f, lines[f][k])
+        bits = np.unpackbits(blk.unit_bits.view(np.uint8), bitorder="little")[:n] if n else np.zeros(0, np.uint8)
+        want_bits = [(1 if (k > 0 and names[0][k] == names[0][k - 1]) else 0) if paired else 1 for k in range(n)]
+        assert bits.tolist() == want_bits
+        assert blk.n_exceptions == sum(1 for k in range(n) if (int(flags[0][k]) | int(flags[1][k])) & 0x7C)
+        # the printed text of the records is the host decoder's text
+        for f in (0, 1):
+            text = np.empty(max(1 << 16, 8 * len(images[f])), dtype=np.uint8)
+            loff, llen = np.empty(n + 1, dtype=np.uint32), np.empty(n + 1, dtype=np.uint32)
+            got = readers[f].print_records(blk.raw_addr[f], blk.rec_off_addr[f], n, text, loff, llen)
+            assert bytes(text[:got]) == b"".join(l + b"\n" for l in lines[f][:n])
+            assert [bytes(text[int(loff[k]):int(loff[k]) + int(llen[k])]) for k in range(n)] == lines[f][:n]
+        for r in readers:
+            r.close()
+    finally:
+        dev.close()
+
+
+def run_path(paths, gpu, conservative=False, tag="AS"):
+    """classify_sam_files(bam=True) with either BAM front end -> (six texts, counts) or the exception it raises."""
+    from xenomapper_amd import xenomapper as xm
+    os.environ["XENOMAPPER_GPU_BAM"] = "1" if gpu else "0"
+    sinks = [io.StringIO() for _ in range(6)]
+    try:
+        counts = xm.classify_sam_files(paths[0], paths[1], *sinks, paired=True, conservative=conservative, bam=True,
+                                       tag_func=xm.get_tag if tag == "AS" else xm.get_tag_with_ZS_as_XS)
+    except Exception as exc:                                        # noqa: BLE001
+        return type(exc).__name__, [s.getvalue() for s in sinks]
+    finally:
+        os.environ.pop("XENOMAPPER_GPU_BAM", None)
+    return dict(counts), [s.getvalue() for s in sinks]
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, monkeypatch, aligned):
+    """The tiled fixtures through the whole file path: GPU BAM front end (small windows: many windows, carried tails, halo
+    records) against the host decoder; record-aligned blocks (device record chain) and blocks that cut records (reported,
+    chain followed on the host)."""
+    import bench_bam
+    from xenomapper_amd import xenomapper as xm
+    paths = []
+    for tag in ("human", "mouse"):
+        p = str(tmp_path / ("%s.bam" % tag))
+        bench_bam.tiled_bam(os.path.join(DATA, "paired_end_testdata_%s.bam" % tag), p, 40, aligned=aligned)
+        paths.append(p)
+    want = run_path(paths, gpu=False)
+    monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 1 << 20)
+    for conservative in (False, True):
+        ref = run_path(paths, gpu=False, conservative=conservative) if conservative else want
+        got = run_path(paths, gpu=True, conservative=conservative)
+        assert got[0] == ref[0]
+        assert got[1] == ref[1]
+    assert sum(want[0].values()) == 40 * 238
+    prof = xm.LAST_FILE_PROFILE
+    assert prof.get("strip_kernels_ms", 0) > 0 or not aligned       # the device path really ran
+
+
+@settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "60")), deadline=None, suppress_health_check=list(HealthCheck))
+@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share"), bam_file_pair()), tag=st.sampled_from(["AS", "ZS"]),
+       conservative=st.booleans())
+def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, tag, conservative):
+    """Typed tags at the int32 edges, floats and characters under the tags' names, strings that merely contain the letters,
+    names with blanks, second files that end early: outputs, counts and exception types of the GPU front end equal the host
+    decoder's (which is pinned to the reference through the text rules)."""
+    d = tmp_path_factory.mktemp("bam")
+    paths = []
+    for f, im in enumerate(images):
+        p = str(d / ("f%d.bam" % f))
+        with open(p, "wb") as fh:
+            fh.write(im)
+        paths.append(p)
+    want = run_path(paths, gpu=False, conservative=conservative, tag=tag)
+    got = run_path(paths, gpu=True, conservative=conservative, tag=tag)
+    assert got == want

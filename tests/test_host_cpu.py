@@ -21,8 +21,8 @@ def _declared(header):
 def test_hip_library_exports_every_declared_symbol():
     from xenomapper_amd import _ffi, build
     build.build_hip()
-    names = sorted(_declared("xenomapper_hip.h") + _declared("xenomapper_strip.h"))
-    assert len(names) >= 17 + 10
+    names = sorted(_declared("xenomapper_hip.h") + _declared("xenomapper_strip.h") + _declared("xenomapper_bgzf.h"))
+    assert len(names) >= 17 + 10 + 12
     L = ctypes.CDLL(_ffi.LIB_PATH)
     for n in names:
         assert hasattr(L, n), n

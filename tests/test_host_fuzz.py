@@ -256,15 +256,27 @@ def score_tag(draw):
     return tag + b"H" + draw(st.text(alphabet="0123456789ABCDEF", max_size=6)).encode() + b"\0"
 
 
-def _bam_image_of(records, refs=("chr1", "chrX")):
+def _bam_image_of(records, refs=("chr1", "chrX"), aligned=False):
+    """aligned: every BGZF block begins with a record (what samtools writes); else blocks of 3000 bytes that cut records."""
     head = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", len(refs))
     for r in refs:
         rn = r.encode() + b"\0"
         head += struct.pack("<i", len(rn)) + rn + struct.pack("<i", 1000)
     payload = head + b"".join(records)
+    if aligned:
+        # "share": the header shares its block with the first records (the record chain then starts inside the block)
+        parts, cur = ([head], b"") if aligned != "share" else ([], head)
+        for rec in records:
+            if cur and len(cur) + len(rec) > 3000:
+                parts.append(cur)
+                cur = b""
+            cur += rec
+        parts.append(cur)
+        parts = [q for k, q in enumerate(parts) if q or k == 0] or [head]
+    else:
+        parts = [payload[at:at + 3000] for at in range(0, len(payload), 3000)]
     out = []
-    for at in range(0, len(payload), 3000):
-        part = payload[at:at + 3000]
+    for part in parts:
         comp = zlib.compressobj(1, zlib.DEFLATED, -15)
         body = comp.compress(part) + comp.flush()
         out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
@@ -273,7 +285,7 @@ def _bam_image_of(records, refs=("chr1", "chrX")):
 
 
 @st.composite
-def bam_file_pair(draw):
+def bam_file_pair(draw, aligned=False):
     n = draw(st.integers(0, 40))
     names = []
     for _ in range(n):
@@ -298,7 +310,7 @@ def bam_file_pair(draw):
             recs.append(struct.pack("<I", len(body)) + body)
         if f == 1 and recs and draw(st.integers(0, 5)) == 0:
             recs = recs[:draw(st.integers(0, len(recs)))]            # the second file ends early
-        images.append(_bam_image_of(recs))
+        images.append(_bam_image_of(recs, aligned=aligned))
     return images
 
 

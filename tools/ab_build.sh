@@ -8,7 +8,7 @@ mkdir -p build/ab
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  $HIPCC -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -I include $flags xenomapper_amd/csrc/xm_kernels.hip xenomapper_amd/csrc/xm_api.hip xenomapper_amd/csrc/xm_strip.hip xenomapper_amd/csrc/xm_inflate.hip -o build/ab/$name.so &
+  $HIPCC -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -I include $flags xenomapper_amd/csrc/xm_kernels.hip xenomapper_amd/csrc/xm_api.hip xenomapper_amd/csrc/xm_strip.hip xenomapper_amd/csrc/xm_inflate.hip xenomapper_amd/csrc/xm_bamdev.hip -o build/ab/$name.so &
 done
 wait
 ls -la build/ab

@@ -35,7 +35,25 @@ def bgzf_blocks(payload, level=6, chunk=0xff00):
 BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def tiled_bam(src, dst, copies):
+def record_aligned_blocks(payload, level=6, limit=0xff00):
+    """BGZF blocks that each begin with an alignment record, as htslib / samtools write them (bgzf_flush_try in front of every
+    record): the payload is cut at the last record boundary that keeps a block within `limit` bytes."""
+    cuts, at, start = [], 0, 0
+    while at < len(payload):
+        size, = struct.unpack_from("<i", payload, at)
+        nxt = at + 4 + size
+        if nxt - start > limit and at > start:
+            cuts.append((start, at))
+            start = at
+        at = nxt
+    cuts.append((start, len(payload)))
+    return b"".join(bgzf_blocks(payload[a:b], level, chunk=limit) for a, b in cuts)
+
+
+def tiled_bam(src, dst, copies, aligned=True):
+    """aligned: record-aligned blocks (what samtools writes; the GPU BAM path's record walk is parallel over such blocks);
+    False: blocks of a fixed size that cut through records (what htsjdk writes; the device reports them and the host
+    walks the chain)."""
     raw = gzip.decompress(open(src, "rb").read())
     assert raw[:4] == b"BAM\x01"
     l_text, = struct.unpack_from("<i", raw, 4)
@@ -45,7 +63,8 @@ def tiled_bam(src, dst, copies):
     for _ in range(n_ref):
         l_name, = struct.unpack_from("<i", raw, at)
         at += 4 + l_name + 4
-    head, records = bgzf_blocks(raw[:at]), bgzf_blocks(raw[at:])
+    head = bgzf_blocks(raw[:at])
+    records = record_aligned_blocks(raw[at:]) if aligned else bgzf_blocks(raw[at:])
     with open(dst, "wb") as fh:
         fh.write(head)
         for _ in range(copies):

@@ -150,6 +150,14 @@ def lib():
         "xm_bgzf_inflate_dev": ([P, P, P, P, U64, P, P, P], I),
         "xm_bgzf_crc32_dev": ([P, P, P, P, U64, P], I),
         "xm_bgzf_strerror": ([ctypes.c_uint32], ctypes.c_char_p),
+        "xm_bamdev_create": ([P, I, ctypes.POINTER(P)], I),
+        "xm_bamdev_destroy": ([P], I),
+        "xm_bamdev_reserve": ([P, I, U64, U64, U64, U64], I),
+        "xm_bamdev_staging": ([P, I, I], P),
+        "xm_bamdev_run": ([P, I, P, I, I, I, U64, P], I),
+        "xm_bamdev_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
+        "xm_bamdev_columns": ([P, I, U64, P, P, P, P, P], I),
+        "xm_bamdev_last_error": ([P], ctypes.c_char_p),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -171,7 +179,9 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
-            "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror")
+            "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
+            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_classify",
+            "xm_bamdev_columns", "xm_bamdev_last_error")
 
 
 def _np_ptr(a):
@@ -853,4 +863,146 @@ class Stripper(object):
         out = [np.empty(n, dtype=np.int32) for _ in range(4)] + [np.zeros((n + 63) // 64, dtype=np.uint64)]
         if n:
             self._check(self._L.xm_strip_columns(self._h, slot, n, *[_np_ptr(a) for a in out]), "xm_strip_columns")
+        return out
+
+
+# ---- include/xenomapper_bgzf.h: BAM records -> columns on the GPU (xm_bamdev_*) -----------------------------------------
+class _BamDevInput(ctypes.Structure):
+    _fields_ = [("comp_len", ctypes.c_uint64), ("blocks", ctypes.c_void_p), ("crc", ctypes.c_void_p), ("n_blocks", ctypes.c_uint64),
+                ("carry_slot", ctypes.c_int32), ("carry_off", ctypes.c_uint64), ("carry_len", ctypes.c_uint64),
+                ("eof", ctypes.c_int32), ("skip", ctypes.c_uint64)]
+
+
+class _BamDevBlock(ctypes.Structure):
+    _fields_ = [("n_records", ctypes.c_uint64), ("consumed1", ctypes.c_uint64), ("consumed2", ctypes.c_uint64),
+                ("raw_len1", ctypes.c_uint64), ("raw_len2", ctypes.c_uint64), ("n_rec1", ctypes.c_uint64), ("n_rec2", ctypes.c_uint64),
+                ("ended", ctypes.c_int32), ("starved", ctypes.c_int32), ("mismatch_at", ctypes.c_int64),
+                ("bad_block", ctypes.c_int32), ("unaligned", ctypes.c_int32), ("weird", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("n_exceptions", ctypes.c_uint64),
+                ("raw1", ctypes.c_void_p), ("raw2", ctypes.c_void_p), ("rec_off1", ctypes.c_void_p), ("rec_off2", ctypes.c_void_p),
+                ("flags1", ctypes.c_void_p), ("flags2", ctypes.c_void_p), ("ms_inflate", ctypes.c_float), ("ms_kernels", ctypes.c_float)]
+
+
+class BamDevBlock(object):
+    """One pair of BAM windows inflated and stripped on the GPU (xm_bamdev_block).  The score columns stay on the device; the
+    inflated bytes and the record tables are page-locked host memory of the slot (valid until the slot runs again).  The
+    caller prints the records' SAM text (set_text) before handing the block to the writer; then it looks like a StrippedBlock."""
+
+    def __init__(self, dev, slot, raw):
+        self.stripper, self.slot = dev, slot                     # `stripper`: whoever classifies the slot's columns
+        n = self.n = int(raw.n_records)
+        self.consumed = (int(raw.consumed1), int(raw.consumed2))
+        self.consumed_lines = (0, 0)
+        self.raw_len = (int(raw.raw_len1), int(raw.raw_len2))
+        self.n_rec = (int(raw.n_rec1), int(raw.n_rec2))
+        self.ended, self.starved, self.mismatch_at = bool(raw.ended), bool(raw.starved), int(raw.mismatch_at)
+        self.bad_block, self.unaligned, self.weird = int(raw.bad_block), bool(raw.unaligned), bool(raw.weird)
+        self.n_exceptions = int(raw.n_exceptions)
+        self.raw_addr = (raw.raw1, raw.raw2)
+        self.rec_off_addr = (raw.rec_off1, raw.rec_off2)
+        self.line_flags = [_host_view(raw.flags1, n, np.uint8), _host_view(raw.flags2, n, np.uint8)]
+        self.ms_inflate, self.ms_kernels = float(raw.ms_inflate), float(raw.ms_kernels)
+        self.non_ascii = self.overflow = False
+        self.csr = None
+        self._host_cols = None
+        self.line_off = self.line_len = self.norm_len = self.tables = None
+
+    def set_text(self, line_off, line_len):
+        """The line tables of the printed text (uint32 arrays per file): what the writer gathers from."""
+        self.line_off, self.line_len, self.norm_len = line_off, line_len, line_len
+        self.tables = (line_off[0].ctypes.data, line_len[0].ctypes.data, line_len[0].ctypes.data, self.line_flags[0].ctypes.data,
+                       line_off[1].ctypes.data, line_len[1].ctypes.data, line_len[1].ctypes.data, self.line_flags[1].ctypes.data)
+
+    def _download(self):
+        if self._host_cols is None:
+            self._host_cols = self.stripper.columns(self.slot, self.n)
+        return self._host_cols
+
+    @property
+    def cols(self):
+        return self._download()[:4]
+
+    @property
+    def unit_bits(self):
+        return self._download()[4]
+
+    exc = StrippedBlock.exc
+
+
+class BamDev(object):
+    """xm_bamdev: BGZF blocks of two BAM files -> score columns in HBM, inflated bytes + record tables on the host."""
+
+    def __init__(self, ctx):
+        self._L = lib()
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        rc = self._L.xm_bamdev_create(ctx._h, ctx.device, ctypes.byref(h))
+        if rc != XM_OK:
+            raise _ERRORS.get(rc, RuntimeError)("xm_bamdev_create: " + self._L.xm_strerror(rc).decode())
+        self._h = h
+        self._cap = [(0, 0, 0, 0)] * 2
+        ctx._strippers.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.xm_bamdev_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != XM_OK:
+            detail = self._L.xm_bamdev_last_error(self._h).decode()
+            raise _ERRORS.get(rc, RuntimeError)("%s: %s%s" % (what, self._L.xm_strerror(rc).decode(),
+                                                               " [" + detail + "]" if detail and rc in (-3, -4) else ""))
+
+    def reserve(self, slot, comp_bytes, raw_bytes, max_blocks, max_records):
+        have = self._cap[slot]
+        want = (max(comp_bytes, have[0]), max(raw_bytes, have[1]), max(max_blocks, have[2]), max(max_records, have[3]))
+        if want != have:
+            self._cap[slot] = (0, 0, 0, 0)
+            self._check(self._L.xm_bamdev_reserve(self._h, slot, *want), "xm_bamdev_reserve")
+            self._cap[slot] = want
+
+    def capacity(self, slot):
+        return self._cap[slot]
+
+    def staging(self, slot, file):
+        return _host_view(self._L.xm_bamdev_staging(self._h, slot, file), self._cap[slot][0], np.uint8)
+
+    def run(self, slot, inputs, score_mode, paired, keep_halo, max_records):
+        """inputs: two dicts {comp_len, blocks (BGZF_BLOCK array), crc (uint32 array), carry_slot, carry_off, carry_len, eof, skip}."""
+        arr = (_BamDevInput * 2)()
+        keep = []
+        for f, x in enumerate(inputs):
+            blocks = np.ascontiguousarray(x["blocks"])
+            crc = np.ascontiguousarray(x["crc"], dtype=np.uint32)
+            keep += [blocks, crc]
+            arr[f] = _BamDevInput(int(x["comp_len"]), blocks.ctypes.data if blocks.shape[0] else None,
+                                  crc.ctypes.data if crc.shape[0] else None, blocks.shape[0], int(x.get("carry_slot", 0)),
+                                  int(x.get("carry_off", 0)), int(x.get("carry_len", 0)), int(bool(x["eof"])), int(x.get("skip", 0)))
+        raw = _BamDevBlock()
+        rc = self._L.xm_bamdev_run(self._h, slot, ctypes.byref(arr), int(score_mode), int(bool(paired)), int(bool(keep_halo)),
+                                   int(max_records), ctypes.byref(raw))
+        self._check(rc, "xm_bamdev_run")
+        return BamDevBlock(self, slot, raw)
+
+    def classify(self, slot, mode, n_records, min_score_floor):
+        code, idx = ctypes.c_void_p(), ctypes.c_void_p()
+        off = np.zeros(8, dtype=np.uint64)
+        counts = np.zeros(64, dtype=np.uint64)
+        rc = self._L.xm_bamdev_classify(self._h, slot, int(mode), int(n_records), int(min_score_floor), ctypes.byref(code),
+                                        ctypes.byref(idx), _np_ptr(off), _np_ptr(counts))
+        self._check(rc, "xm_bamdev_classify")
+        return (_host_view(code.value, int(n_records), np.uint8), _host_view(idx.value, int(off[7]), np.uint32), off, counts)
+
+    def columns(self, slot, n_records):
+        n = int(n_records)
+        out = [np.empty(n, dtype=np.int32) for _ in range(4)] + [np.zeros((n + 63) // 64, dtype=np.uint64)]
+        if n:
+            self._check(self._L.xm_bamdev_columns(self._h, slot, n, *[_np_ptr(a) for a in out]), "xm_bamdev_columns")
         return out

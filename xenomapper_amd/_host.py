@@ -16,7 +16,7 @@ ERR_NON_ASCII = -3
 
 EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_default_threads", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
             "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read", "xmh_bam_read_pre", "xmh_parse_pre",
-            "xmh_copy", "xmh_pread", "xmh_adopt_lines")
+            "xmh_copy", "xmh_pread", "xmh_adopt_lines", "xmh_bam_records_start", "xmh_bam_print", "xmh_bam_walk")
 NEED_TEXT = 1
 # xmh_pre (include/xenomapper_host.h): what the BAM decoder knows about every line it prints
 PRE_DTYPE = np.dtype([("line_len", np.uint32), ("name_len", np.uint16), ("flags", np.uint8), ("ex_as", np.uint8),
@@ -80,6 +80,10 @@ def lib():
         L.xmh_parse_pre.argtypes = [_P, _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_uint64,
                                     _P, ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_uint64,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_Block)]
+        L.xmh_bam_records_start.argtypes = [_P, ctypes.POINTER(ctypes.c_uint64)]
+        L.xmh_bam_walk.argtypes = [_P, ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                   ctypes.POINTER(ctypes.c_uint64)]
+        L.xmh_bam_print.argtypes = [_P, _P, _P, ctypes.c_uint64, _P, ctypes.c_uint64, _P, _P, ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_copy.argtypes = [_P, _P, _P, ctypes.c_uint64]
         L.xmh_pread.argtypes = [_P, ctypes.c_int, ctypes.c_uint64, _P, ctypes.c_uint64]
         L.xmh_adopt_lines.argtypes = [_P, ctypes.c_uint64] + [_P] * 8
@@ -249,6 +253,16 @@ class Parser(object):
         return out
 
 
+def bam_walk(raw_address, length, start, rec_off):
+    """The record chain of an inflated window on the host (xmh_bam_walk) -> (records, stop); rec_off: uint32 array to fill."""
+    n, stop = ctypes.c_uint64(), ctypes.c_uint64()
+    rc = lib().xmh_bam_walk(_P(raw_address), int(length), int(start), rec_off.ctypes.data_as(_P), rec_off.shape[0],
+                            ctypes.byref(n), ctypes.byref(stop))
+    if rc != 0:
+        raise ValueError("xmh_bam_walk: " + lib().xmh_strerror(rc).decode())
+    return int(n.value), int(stop.value)
+
+
 class BamReader(object):
     """BAM file image -> SAM text, like `samtools view` (header via .header(), lines via .read_into())."""
 
@@ -278,6 +292,27 @@ class BamReader(object):
         text, n = _P(), ctypes.c_uint64()
         self._L.xmh_bam_header(self._h, ctypes.byref(text), ctypes.byref(n))
         return ctypes.string_at(text, n.value).decode("ascii") if n.value else ""
+
+    def records_start(self):
+        """Inflated offset of the first alignment record (right after opening: behind magic, header text, reference list)."""
+        v = ctypes.c_uint64()
+        rc = self._L.xmh_bam_records_start(self._h, ctypes.byref(v))
+        if rc != 0:
+            raise ValueError("xmh_bam_records_start: " + self._L.xmh_strerror(rc).decode())
+        return int(v.value)
+
+    def print_records(self, raw_address, rec_off_address, n, out, line_off, line_len):
+        """SAM text of records [0, n) of an inflated window (host addresses of the bytes and of the uint32 record table) into
+        the uint8 array `out`; fills the uint32 arrays line_off / line_len.  -> bytes written, or -needed when `out` is
+        too small."""
+        w = ctypes.c_uint64()
+        rc = self._L.xmh_bam_print(self._h, _P(raw_address), _P(rec_off_address), int(n), out.ctypes.data_as(_P), out.shape[0],
+                                   line_off.ctypes.data_as(_P), line_len.ctypes.data_as(_P), ctypes.byref(w))
+        if rc == -1 and w.value > out.shape[0]:
+            return -int(w.value)
+        if rc != 0:
+            raise ValueError("xmh_bam_print: " + self._L.xmh_strerror(rc).decode())
+        return int(w.value)
 
     def read_into_pre(self, out, start):
         """read_into() that also returns what the decoder knows about the lines it wrote:

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, "csrc")
 HIP_LIB = os.path.join(PKG, "libxenomapper_hip.so")
 HOST_LIB = os.path.join(PKG, "libxenomapper_host.so")
 
-HIP_SOURCES = ["xm_kernels.hip", "xm_api.hip", "xm_strip.hip", "xm_inflate.hip"]
+HIP_SOURCES = ["xm_kernels.hip", "xm_api.hip", "xm_strip.hip", "xm_inflate.hip", "xm_bamdev.hip"]
 HOST_SOURCES = ["xm_sam.cpp", "xm_bam.cpp"]
 
 

@@ -880,6 +880,83 @@ int xmh_bam_read(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eo
     return bam_read(b, dst, cap, written, eof, nullptr);
 }
 
+int xmh_bam_records_start(xmh_bam *b, uint64_t *inflated_offset)
+{
+    if (!b || !inflated_offset || !b->header_done) return XMH_ERR_INVALID_ARG;
+    // read_header leaves stream.pos behind the reference list, in a stream that began with the file's first block; nothing
+    // has been compacted yet when this is asked right after xmh_bam_open
+    *inflated_offset = b->stream.pos;
+    return XMH_OK;
+}
+
+int xmh_bam_walk(const uint8_t *raw, uint64_t len, uint64_t start, uint32_t *rec_off, uint64_t cap, uint64_t *n_records, uint64_t *stop)
+{
+    if (!n_records || !stop || start > len || len > 0xFFFFFFFFull || (len && !raw)) return XMH_ERR_INVALID_ARG;
+    uint64_t p = start, n = 0;
+    while (len - p >= 4) {
+        const uint64_t size = le32(raw + p);
+        if (size > len - p - 4) break;                               // the record continues behind the window
+        if (rec_off && n < cap) rec_off[n] = (uint32_t)p;
+        ++n;
+        p += 4 + size;
+    }
+    *n_records = n;
+    *stop = p;
+    return XMH_OK;
+}
+
+int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, char *dst, uint64_t cap,
+                  uint32_t *line_off, uint32_t *line_len, uint64_t *written)
+{
+    if (!b || !written || (n && (!raw || !rec_off || !line_off || !line_len))) return XMH_ERR_INVALID_ARG;
+    *written = 0;
+    if (n == 0) return XMH_OK;
+    try {
+        size_t longest_ref = 0;
+        for (auto &name : b->ref_names) longest_ref = std::max(longest_ref, name.size());
+        const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)b->pool->size(), (n + 255) / 256));
+        std::vector<uint64_t> first((size_t)nt + 1);
+        for (int t = 0; t <= nt; ++t) first[(size_t)t] = n * (uint64_t)t / (uint64_t)nt;
+        for (int t = 0; t < nt; ++t) { b->workers[(size_t)t].ok = true; b->workers[(size_t)t].text_len = 0; }
+        b->pool->run(nt, [&](int t) {
+            BamWorker &w = b->workers[(size_t)t];
+            const uint64_t lo = first[(size_t)t], hi = first[(size_t)t + 1];
+            if (lo == hi) return;
+            // the worst ratios are a B:c array element (1 byte -> "-128,"), a CIGAR operation (4 -> 11) and a packed base
+            // pair (1 -> 2), so 5x; the fixed fields add < 128 and two reference names
+            uint64_t bytes = 0;
+            for (uint64_t i = lo; i < hi; ++i) bytes += le32(raw + rec_off[i]);
+            const size_t room = 5 * (size_t)bytes + (size_t)(hi - lo) * (128 + 2 * longest_ref);
+            if (w.text_cap < room) { w.text.reset(new char[room]); w.text_cap = room; }
+            char *o = w.text.get();
+            for (uint64_t i = lo; i < hi; ++i) {
+                char *const line = o;
+                o = format_record(b, raw + rec_off[i] + 4, le32(raw + rec_off[i]), o);
+                if (!o) { w.ok = false; return; }
+                line_off[i] = (uint32_t)(line - w.text.get());                 // local: rebased below
+                line_len[i] = (uint32_t)(o - line - 1);                        // without the '\n'
+            }
+            w.text_len = (size_t)(o - w.text.get());
+        });
+        std::vector<uint64_t> at((size_t)nt + 1, 0);
+        for (int t = 0; t < nt; ++t) {
+            if (!b->workers[(size_t)t].ok) return XMH_ERR_BAD_BAM;
+            at[(size_t)t + 1] = at[(size_t)t] + b->workers[(size_t)t].text_len;
+        }
+        *written = at[(size_t)nt];
+        if (at[(size_t)nt] > cap || at[(size_t)nt] > 0xFFFFFFFFull || !dst) return XMH_ERR_INVALID_ARG;     // *written says what it takes
+        b->pool->run(nt, [&](int t) {
+            const BamWorker &w = b->workers[(size_t)t];
+            if (w.text_len) memcpy(dst + at[(size_t)t], w.text.get(), w.text_len);
+            const uint32_t shift = (uint32_t)at[(size_t)t];
+            for (uint64_t i = first[(size_t)t]; i < first[(size_t)t + 1]; ++i) line_off[i] += shift;
+        });
+        return XMH_OK;
+    } catch (const std::bad_alloc &) {
+        return XMH_ERR_OOM;
+    }
+}
+
 int xmh_bam_read_pre(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int *eof,
                      xmh_pre *pre, uint64_t pre_cap, uint64_t *n_pre, uint32_t *ops, uint64_t ops_cap, uint64_t *n_ops)
 {

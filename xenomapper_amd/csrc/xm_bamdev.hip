@@ -1,0 +1,715 @@
+// xm_bamdev.hip -- BAM records -> the classifier's columns on the GPU (include/xenomapper_bgzf.h, xm_bamdev_*).
+//
+// Per window and file:  compressed BGZF blocks (page-locked staging) --H2D--> inflate (xm_inflate.hip) + CRC-32 -->
+//   B1 walk_kernel   one lane per SEGMENT (the carried-over bytes, then every BGZF block): follows the block_size chain
+//                    from the segment's first byte, counts the records that begin in it, reports where the chain leaves
+//                    it.  The chain is serial, so the parallelism is the segments -- which only works when every block
+//                    begins with a record, as htslib / samtools write them (bgzf_flush_try in front of every record);
+//   B2 scan_kernel   one workgroup: checks exactly that (every segment's chain must land on the next segment's first
+//                    byte; else `unaligned` and the caller takes the host decoder), exclusive scan of the counts;
+//   B3 fill_kernel   the same walk again, now writing the record table;
+//   B4 parse_kernel  one lane per RECORD: the fixed fields, the name, the optional fields with the tag_func plugins' rules
+//                    on the TYPED fields (xm_bam.cpp's TagScan, restating get_tag xenomapper.py:176-191), everything the
+//                    text rules might read differently flagged;
+//   B5 pair_kernel   one lane per PAIR of records k of the two files: score columns, names compared (:106 across files,
+//                    :402 between neighbours -> unit mask by ballot), first mismatch by atomicMin.
+// The inflated bytes and the record table also go back to the host (page-locked), where the writer prints the SAM text of
+// the records (xmh_bam_print).  All byte / integer work, bound by memory latency per record, far from any roofline that
+// matters next to the inflate.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/xenomapper_bgzf.h"
+
+namespace {
+
+constexpr int32_t ABSENT = INT32_MIN;
+constexpr uint32_t R_EX_A_SHIFT = 0, R_EX_X_SHIFT = 2;     // per-record flag byte of B4: ex_a (2 bits), ex_x (2 bits),
+constexpr uint32_t R_WEIRD = 0x10u, R_BAD = 0x20u;         // weird, malformed
+
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// ---- B1 / B3: the record chain, one lane per segment --------------------------------------------------------------
+// seg_start[n_seg + 1]: first byte of every segment, seg_start[n_seg] = n_raw.  A record belongs to the segment its
+// block_size word begins in; a record that does not end inside the window ends the walk (it is the next window's).
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+walk_kernel(const uint8_t *__restrict__ raw, uint32_t n_raw, const uint32_t *__restrict__ seg_start, uint32_t n_seg,
+            uint32_t *__restrict__ cnt, uint32_t *__restrict__ exit_at, const uint32_t *__restrict__ base,
+            uint32_t *__restrict__ rec_off, uint32_t rec_cap)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n_seg) return;
+    const uint32_t lo = seg_start[s], hi = seg_start[s + 1];
+    uint32_t p = lo, n = 0;
+    const uint32_t b0 = FILL ? base[s] : 0u;
+    while (p < hi) {
+        if (n_raw - p < 4u) break;                                          // the size word itself is cut
+        const uint32_t size = ld32(raw + p);
+        if (size > n_raw - p - 4u) break;                                   // the record continues behind the window
+        if (FILL && b0 + n < rec_cap) rec_off[b0 + n] = p;
+        ++n;
+        p += 4u + size;                                                     // >= p + 4: the walk always advances
+    }
+    if (!FILL) { cnt[s] = n; exit_at[s] = p; }
+}
+
+// ---- B2: alignment check + exclusive scan of the per-segment counts (one workgroup) --------------------------------
+// summary: [0] records, [1] where the chain stopped (first byte not covered by a complete record), [2] aligned (1 / 0)
+__global__ void __launch_bounds__(1024)
+scan_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ exit_at, const uint32_t *__restrict__ seg_start,
+            uint32_t n_seg, uint32_t *__restrict__ base, uint32_t *__restrict__ summary)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t bad;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) bad = 0;
+    __syncthreads();
+    const uint32_t per = (n_seg + 1023u) / 1024u;
+    const uint32_t a = min(t * per, n_seg), b = min(a + per, n_seg);
+    uint32_t sum = 0, misaligned = 0;
+    for (uint32_t s = a; s < b; ++s) {
+        sum += cnt[s];
+        // the chain of segment s must land exactly on the first byte of segment s + 1; the last one may stop anywhere
+        // (an incomplete record at the end of the window) but must not have been cut short by a later segment's start
+        if (s + 1 < n_seg && exit_at[s] != seg_start[s + 1]) misaligned = 1;
+    }
+    part[t] = sum;
+    if (misaligned) atomicOr(&bad, 1u);
+    __syncthreads();
+    // Hillis-Steele over the 1024 partial sums
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t s = a; s < b; ++s) { base[s] = run; run += cnt[s]; }
+    if (t == 1023u) {
+        summary[0] = part[1023];
+        summary[1] = n_seg ? exit_at[n_seg - 1] : 0u;
+        summary[2] = bad ? 0u : 1u;
+    }
+}
+
+// ---- B4: one lane per record ----------------------------------------------------------------------------------------
+struct RecOut {
+    uint32_t *name_off;       // first byte of QNAME in raw
+    uint32_t *name_len;       // without the NUL
+    int32_t *a, *x;           // AS, and XS or ZS by mode; ABSENT = no match
+    uint8_t *flag;            // ex_a | ex_x << 2 | R_WEIRD | R_BAD
+};
+
+__device__ __forceinline__ bool odd_byte(uint32_t c) { return c <= 0x20u || c >= 0x7Fu; }
+
+__device__ __forceinline__ uint32_t elem_bytes(uint32_t t)
+{
+    switch (t) {
+    case 'A': case 'c': case 'C': return 1u;
+    case 's': case 'S': return 2u;
+    case 'i': case 'I': case 'f': return 4u;
+    case 'd': return 8u;
+    default: return 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+parse_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_off, uint32_t n, uint32_t x0 /* 'X' or 'Z' */, RecOut o)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t off = rec_off[i];
+    const uint32_t size = ld32(raw + off);
+    const uint8_t *r = raw + off + 4u;
+    uint32_t flag = 0, nl = 0;
+    uint32_t cnt_a = 0, cnt_x = 0, ex_a = 0, ex_x = 0;
+    int32_t va = ABSENT, vx = ABSENT;
+    bool ok = size >= 32u;
+    if (ok) {
+        const int32_t ref_id = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+        const uint32_t l_read_name = r[8], n_cigar = ld16(r + 12), l_seq = ld32(r + 16);
+        const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + ((uint64_t)l_seq + 1u) / 2u + l_seq;
+        ok = need <= size && l_read_name != 0u;
+        if (ok) {
+            bool weird = false;
+            // QNAME up to its NUL
+            while (nl < l_read_name && r[32u + nl] != 0u) { weird |= odd_byte(r[32u + nl]); ++nl; }
+            weird |= nl == 0u;
+            uint32_t p = 32u + l_read_name;
+            // a CIGAR that lives in a CG:B:I field (htslib moves it back when it prints): possible only with this placeholder
+            const bool cg_possible = n_cigar != 0u && ref_id >= 0 && pos >= 0 && (ld32(r + p) & 15u) == 4u && (ld32(r + p) >> 4) == l_seq;
+            p += 4u * n_cigar + (l_seq + 1u) / 2u;
+            // qualities: printed as byte + 33; above 93 the text is not ASCII any more
+            if (l_seq != 0u && r[p] != 0xFFu) {
+                uint32_t hi = 0;
+                for (uint32_t k = 0; k < l_seq; ++k) hi |= (r[p + k] + 33u) & 0xFFu;
+                weird |= (hi & 0x80u) != 0u;
+            }
+            p += l_seq;
+            // optional fields
+            while (ok && p + 3u <= size) {
+                const uint32_t t0 = r[p], t1 = r[p + 1], type = r[p + 2];
+                p += 3u;
+                weird |= odd_byte(t0) || odd_byte(t1);
+                weird |= cg_possible && t0 == 'C' && t1 == 'G';
+                const bool is_a = t0 == 'A' && t1 == 'S', is_x = t0 == x0 && t1 == 'S';
+                if (type == 'Z' || type == 'H') {
+                    // the printed field "TG:Z:value": matched by its name or by the two letters anywhere in the value
+                    bool in_a = is_a, in_x = is_x, end = false;
+                    uint32_t prev = 0;
+                    while (p < size) {
+                        const uint32_t c = r[p++];
+                        if (c == 0u) { end = true; break; }
+                        weird |= odd_byte(c);
+                        in_a |= prev == 'A' && c == 'S';
+                        in_x |= prev == x0 && c == 'S';
+                        prev = c;
+                    }
+                    ok = end;
+                    // a string value is never vouched for here: the text rules decide (the count still matters: duplicates)
+                    if (in_a) { if (cnt_a++ == 0u) ex_a = 1u; }
+                    if (in_x) { if (cnt_x++ == 0u) ex_x = 1u; }
+                    continue;
+                }
+                uint32_t bytes;
+                if (type == 'B') {
+                    if (p + 5u > size) { ok = false; break; }
+                    const uint32_t e = elem_bytes(r[p]);
+                    const uint64_t len = 5ull + (uint64_t)e * ld32(r + p + 1);
+                    if (e == 0u || p + len > size) { ok = false; break; }
+                    bytes = (uint32_t)len;
+                } else {
+                    bytes = elem_bytes(type);
+                    if (bytes == 0u || p + bytes > size) { ok = false; break; }
+                    if (type == 'A') weird |= odd_byte(r[p]);
+                }
+                if (is_a || is_x) {                                        // only the tag itself can hold the two letters
+                    long long v = 0;
+                    bool is_int = true;
+                    switch (type) {
+                    case 'c': v = (int8_t)r[p]; break;
+                    case 'C': v = r[p]; break;
+                    case 's': v = (int16_t)ld16(r + p); break;
+                    case 'S': v = ld16(r + p); break;
+                    case 'i': v = (int32_t)ld32(r + p); break;
+                    case 'I': v = ld32(r + p); break;
+                    default: is_int = false;                               // A, f, d, B by name: what its printed text says
+                    }
+                    const bool fits = is_int && v >= -2147483647ll && v <= 2147483647ll;
+                    if (is_a) { if (cnt_a++ == 0u) { if (fits) va = (int32_t)v; else ex_a = 1u; } }
+                    if (is_x) { if (cnt_x++ == 0u) { if (fits) vx = (int32_t)v; else ex_x = 1u; } }
+                }
+                p += bytes;
+            }
+            ok = ok && p == size;
+            if (weird) flag |= R_WEIRD;
+        }
+    }
+    if (!ok) flag |= R_BAD;
+    if (cnt_a > 1u) ex_a = 2u;
+    if (cnt_x > 1u) ex_x = 2u;
+    if (ex_a) va = ABSENT;
+    if (ex_x) vx = ABSENT;
+    o.name_off[i] = off + 36u;
+    o.name_len[i] = nl;
+    o.a[i] = va;
+    o.x[i] = vx;
+    o.flag[i] = (uint8_t)(flag | (ex_a << R_EX_A_SHIFT) | (ex_x << R_EX_X_SHIFT));
+}
+
+// ---- B5: one lane per pair --------------------------------------------------------------------------------------------
+struct FileRecs {
+    const uint8_t *raw;
+    const uint32_t *name_off, *name_len;
+    const int32_t *a, *x;
+    const uint8_t *flag;
+};
+
+__device__ __forceinline__ bool same_name(const uint8_t *p, const uint8_t *q, uint32_t n)
+{
+    uint32_t diff = 0;
+    for (uint32_t k = 0; k < n; ++k) diff |= (uint32_t)(p[k] ^ q[k]);
+    return diff == 0u;
+}
+
+// state: [0] first mismatch (atomicMin), [1] pairs with an exception, [2] weird | bad << 1
+__global__ void __launch_bounds__(256)
+pair_kernel(FileRecs f1, FileRecs f2, uint32_t n, int paired, int32_t *__restrict__ as1, int32_t *__restrict__ xs1,
+            int32_t *__restrict__ as2, int32_t *__restrict__ xs2, unsigned long long *__restrict__ unit_bits,
+            uint8_t *__restrict__ lflag1, uint8_t *__restrict__ lflag2, uint32_t *__restrict__ state)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    bool unit = false;
+    if (k < n) {
+        const uint32_t g1 = f1.flag[k], g2 = f2.flag[k];
+        as1[k] = f1.a[k]; xs1[k] = f1.x[k];
+        as2[k] = f2.a[k]; xs2[k] = f2.x[k];
+        const uint32_t n1 = f1.name_len[k], n2 = f2.name_len[k];
+        const uint8_t *p1 = f1.raw + f1.name_off[k], *p2 = f2.raw + f2.name_off[k];
+        if (n1 != n2 || !same_name(p1, p2, n1)) atomicMin(&state[0], k);
+        if (paired) {
+            if (k > 0u) {
+                const uint32_t n0 = f1.name_len[k - 1u];
+                unit = n0 == n1 && same_name(f1.raw + f1.name_off[k - 1u], p1, n1);
+            }
+        } else {
+            unit = true;
+        }
+        // per-pair line flags in the layout of xenomapper_strip.h: NORMAL | ex_a << 2 | ex_x << 5
+        const uint32_t e1a = (g1 >> R_EX_A_SHIFT) & 3u, e1x = (g1 >> R_EX_X_SHIFT) & 3u;
+        const uint32_t e2a = (g2 >> R_EX_A_SHIFT) & 3u, e2x = (g2 >> R_EX_X_SHIFT) & 3u;
+        lflag1[k] = (uint8_t)(XMS_LINE_NORMAL | (e1a << XMS_LINE_EX_A_SHIFT) | (e1x << XMS_LINE_EX_X_SHIFT));
+        lflag2[k] = (uint8_t)(XMS_LINE_NORMAL | (e2a << XMS_LINE_EX_A_SHIFT) | (e2x << XMS_LINE_EX_X_SHIFT));
+        if (e1a | e1x | e2a | e2x) atomicAdd(&state[1], 1u);
+        const uint32_t wb = (((g1 | g2) & R_WEIRD) ? 1u : 0u) | (((g1 | g2) & R_BAD) ? 2u : 0u);
+        if (wb) atomicOr(&state[2], wb);
+    }
+    const unsigned long long m = __ballot(unit);
+    if ((threadIdx.x & 63u) == 0u && (k & ~63u) < ((n + 63u) & ~63u)) unit_bits[k >> 6] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct PerFile {
+    uint8_t *h_comp = nullptr, *d_comp = nullptr;           // staged compressed bytes (+ XMB_COMP_PAD)
+    uint8_t *d_raw = nullptr, *h_raw = nullptr;             // the inflated window
+    xm_bgzf_block *h_blocks = nullptr, *d_blocks = nullptr;
+    uint32_t *d_status = nullptr, *h_status = nullptr, *d_crc = nullptr, *h_crc = nullptr;
+    uint32_t *h_seg = nullptr, *d_seg = nullptr, *d_cnt = nullptr, *d_exit = nullptr, *d_base = nullptr;
+    uint32_t *d_rec_off = nullptr, *h_rec_off = nullptr;
+    uint32_t *d_name_off = nullptr, *d_name_len = nullptr;
+    int32_t *d_a = nullptr, *d_x = nullptr;
+    uint8_t *d_rflag = nullptr, *d_lflag = nullptr, *h_lflag = nullptr;
+    uint32_t *d_summary = nullptr, *h_summary = nullptr, *d_work = nullptr;
+    uint64_t raw_len = 0;
+};
+
+struct Slot {
+    uint64_t comp_cap = 0, raw_cap = 0, block_cap = 0, record_cap = 0;
+    PerFile pf[2];
+    int32_t *d_col[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t *d_bits = nullptr;
+    uint32_t *d_state = nullptr, *h_state = nullptr;
+    uint8_t *d_code = nullptr, *d_bins4 = nullptr, *h_code = nullptr;
+    uint32_t *d_idx = nullptr, *h_idx = nullptr;
+    uint64_t *d_off_counts = nullptr, *h_off_counts = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool have_columns = false;
+};
+
+}  // namespace
+
+struct xm_bamdev {
+    xm_ctx *ctx = nullptr;
+    int device = 0;
+    Slot slot[2];
+    std::mutex error_lock;
+    std::string last_error;
+};
+
+namespace {
+
+int fail(xm_bamdev *b, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    if (b) {
+        std::lock_guard<std::mutex> hold(b->error_lock);
+        b->last_error = buf;
+    }
+    return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
+}
+
+#define XMB_HIP(b, call)                                   \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return fail((b), e_, #call); \
+    } while (0)
+#define XMB_TRY(expr)                  \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != XM_OK) return rc_;  \
+    } while (0)
+
+template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+template <typename T> void hfree(T *&p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+template <typename T> int dalloc(xm_bamdev *b, T *&p, size_t count)
+{
+    dfree(p);
+    XMB_HIP(b, hipMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T)));
+    return XM_OK;
+}
+template <typename T> int halloc(xm_bamdev *b, T *&p, size_t count)
+{
+    hfree(p);
+    XMB_HIP(b, hipHostMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T), hipHostMallocDefault));
+    return XM_OK;
+}
+
+void free_slot(Slot &sl)
+{
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        hfree(q.h_comp); dfree(q.d_comp); dfree(q.d_raw); hfree(q.h_raw);
+        hfree(q.h_blocks); dfree(q.d_blocks); dfree(q.d_status); hfree(q.h_status); dfree(q.d_crc); hfree(q.h_crc);
+        hfree(q.h_seg); dfree(q.d_seg); dfree(q.d_cnt); dfree(q.d_exit); dfree(q.d_base);
+        dfree(q.d_rec_off); hfree(q.h_rec_off); dfree(q.d_name_off); dfree(q.d_name_len); dfree(q.d_a); dfree(q.d_x);
+        dfree(q.d_rflag); dfree(q.d_lflag); hfree(q.h_lflag);
+    }
+    for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
+    dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx);
+    hfree(sl.h_code); hfree(sl.h_idx);
+    sl.comp_cap = sl.raw_cap = sl.block_cap = sl.record_cap = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
+{
+    if (!ctx || !out) return XM_ERR_INVALID_ARG;
+    xm_bamdev *b = new (std::nothrow) xm_bamdev();
+    if (!b) return XM_ERR_OOM;
+    b->ctx = ctx;
+    b->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        Slot &sl = b->slot[k];
+        e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, 16 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_state, 16 * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off_counts, 72 * sizeof(uint64_t), hipHostMallocDefault);
+        for (int f = 0; f < 2 && e == hipSuccess; ++f) {
+            PerFile &q = sl.pf[f];
+            e = hipMalloc((void **)&q.d_summary, 16 * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipHostMalloc((void **)&q.h_summary, 16 * sizeof(uint32_t), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void **)&q.d_work, 16 * sizeof(uint32_t));
+        }
+    }
+    if (e != hipSuccess) {
+        xm_bamdev_destroy(b);
+        return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
+    }
+    *out = b;
+    return XM_OK;
+}
+
+int xm_bamdev_destroy(xm_bamdev *b)
+{
+    if (!b) return XM_ERR_INVALID_ARG;
+    (void)hipSetDevice(b->device);
+    for (int k = 0; k < 2; ++k) {
+        Slot &sl = b->slot[k];
+        if (sl.stream) {
+            (void)hipStreamSynchronize(sl.stream);
+            (void)xm_workspace_release(b->ctx, sl.stream);
+        }
+        free_slot(sl);
+        dfree(sl.d_state); hfree(sl.h_state); dfree(sl.d_off_counts); hfree(sl.h_off_counts);
+        for (int f = 0; f < 2; ++f) { dfree(sl.pf[f].d_summary); hfree(sl.pf[f].h_summary); dfree(sl.pf[f].d_work); }
+        for (int i = 0; i < 3; ++i)
+            if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
+    delete b;
+    return XM_OK;
+}
+
+int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_bytes, uint64_t max_blocks, uint64_t max_records)
+{
+    if (!b || slot < 0 || slot > 1 || raw_bytes >= 0xFFFF0000ull || comp_bytes >= 0xFFFF0000ull || max_blocks == 0 || max_records == 0 ||
+        max_records >= 0xFFFFFF00ull || max_blocks >= 0x7FFFFF00ull)
+        return XM_ERR_INVALID_ARG;
+    XMB_HIP(b, hipSetDevice(b->device));
+    Slot &sl = b->slot[slot];
+    XMB_HIP(b, hipStreamSynchronize(sl.stream));
+    sl.have_columns = false;
+    if (comp_bytes > sl.comp_cap) {
+        sl.comp_cap = 0;
+        for (int f = 0; f < 2; ++f) {
+            XMB_TRY(halloc(b, sl.pf[f].h_comp, (size_t)comp_bytes));
+            XMB_TRY(dalloc(b, sl.pf[f].d_comp, (size_t)comp_bytes + XMB_COMP_PAD));
+            XMB_HIP(b, hipMemset(sl.pf[f].d_comp, 0, (size_t)comp_bytes + XMB_COMP_PAD));
+        }
+        sl.comp_cap = comp_bytes;
+    }
+    if (raw_bytes > sl.raw_cap) {
+        sl.raw_cap = 0;
+        for (int f = 0; f < 2; ++f) {
+            XMB_TRY(dalloc(b, sl.pf[f].d_raw, (size_t)raw_bytes + 64));
+            XMB_TRY(halloc(b, sl.pf[f].h_raw, (size_t)raw_bytes + 64));
+        }
+        sl.raw_cap = raw_bytes;
+    }
+    if (max_blocks > sl.block_cap) {
+        sl.block_cap = 0;
+        const size_t nb = (size_t)max_blocks + 2;
+        for (int f = 0; f < 2; ++f) {
+            PerFile &q = sl.pf[f];
+            XMB_TRY(halloc(b, q.h_blocks, nb)); XMB_TRY(dalloc(b, q.d_blocks, nb));
+            XMB_TRY(dalloc(b, q.d_status, nb)); XMB_TRY(halloc(b, q.h_status, nb));
+            XMB_TRY(dalloc(b, q.d_crc, nb)); XMB_TRY(halloc(b, q.h_crc, nb));
+            XMB_TRY(halloc(b, q.h_seg, nb + 2)); XMB_TRY(dalloc(b, q.d_seg, nb + 2));
+            XMB_TRY(dalloc(b, q.d_cnt, nb + 2)); XMB_TRY(dalloc(b, q.d_exit, nb + 2)); XMB_TRY(dalloc(b, q.d_base, nb + 2));
+        }
+        sl.block_cap = max_blocks;
+    }
+    if (max_records > sl.record_cap) {
+        sl.record_cap = 0;
+        const size_t n = (size_t)max_records + 64;
+        for (int f = 0; f < 2; ++f) {
+            PerFile &q = sl.pf[f];
+            XMB_TRY(dalloc(b, q.d_rec_off, n)); XMB_TRY(halloc(b, q.h_rec_off, n));
+            XMB_TRY(dalloc(b, q.d_name_off, n)); XMB_TRY(dalloc(b, q.d_name_len, n));
+            XMB_TRY(dalloc(b, q.d_a, n)); XMB_TRY(dalloc(b, q.d_x, n));
+            XMB_TRY(dalloc(b, q.d_rflag, n)); XMB_TRY(dalloc(b, q.d_lflag, n)); XMB_TRY(halloc(b, q.h_lflag, n));
+        }
+        for (int c = 0; c < 4; ++c) XMB_TRY(dalloc(b, sl.d_col[c], n));
+        XMB_TRY(dalloc(b, sl.d_bits, n / 64 + 2));
+        XMB_TRY(dalloc(b, sl.d_code, n));
+        XMB_TRY(dalloc(b, sl.d_bins4, (size_t)XM_BINS4_BYTES(max_records) + 16));
+        XMB_TRY(dalloc(b, sl.d_idx, n));
+        XMB_TRY(halloc(b, sl.h_code, n));
+        XMB_TRY(halloc(b, sl.h_idx, n));
+        sl.record_cap = max_records;
+    }
+    return XM_OK;
+}
+
+uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file)
+{
+    if (!b || slot < 0 || slot > 1 || file < 0 || file > 1) return nullptr;
+    return b->slot[slot].pf[file].h_comp;
+}
+
+int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
+                  uint64_t max_records, xm_bamdev_block *out)
+{
+    if (!b || !in || !out || slot < 0 || slot > 1 || (score_mode != XMS_SCORE_AS_XS && score_mode != XMS_SCORE_AS_ZS) || max_records == 0)
+        return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (max_records > sl.record_cap) return XM_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->mismatch_at = -1;
+    sl.have_columns = false;
+    XMB_HIP(b, hipSetDevice(b->device));
+    hipStream_t st = sl.stream;
+    uint64_t new_bytes[2] = {0, 0};
+    // ---- stage: carry, compressed bytes, block tables; inflate + CRC; the record chain --------------------------------
+    XMB_HIP(b, hipEventRecord(sl.ev[0], st));
+    for (int f = 0; f < 2; ++f) {
+        const xm_bamdev_input &x = in[f];
+        PerFile &q = sl.pf[f];
+        if (x.comp_len > sl.comp_cap || x.n_blocks > sl.block_cap || (x.n_blocks && (!x.blocks || !x.crc)) || x.carry_len > sl.raw_cap)
+            return XM_ERR_INVALID_ARG;
+        for (uint64_t k = 0; k < x.n_blocks; ++k) {
+            const xm_bgzf_block &d = x.blocks[k];
+            if (d.cdata_off + d.cdata_len > x.comp_len || d.isize > 65536u || d.out_off != new_bytes[f]) return XM_ERR_INVALID_ARG;
+            new_bytes[f] += d.isize;
+        }
+        if (x.carry_len + new_bytes[f] > sl.raw_cap) return XM_ERR_INVALID_ARG;
+        if (x.carry_len) {
+            if (x.carry_slot < 0 || x.carry_slot > 1) return XM_ERR_INVALID_ARG;
+            const PerFile &src = b->slot[x.carry_slot].pf[f];
+            if (x.carry_off + x.carry_len > b->slot[x.carry_slot].raw_cap) return XM_ERR_INVALID_ARG;
+            if (x.carry_slot == slot && x.carry_off < x.carry_len) return XM_ERR_INVALID_ARG;          // would overlap itself
+            // (the other slot's stream finished its window before the caller could know what to carry)
+            XMB_HIP(b, hipMemcpyAsync(q.d_raw, src.d_raw + x.carry_off, (size_t)x.carry_len, hipMemcpyDeviceToDevice, st));
+            memmove(q.h_raw, src.h_raw + x.carry_off, (size_t)x.carry_len);
+        }
+        q.raw_len = x.carry_len + new_bytes[f];
+        // segments: the carry (when there is one), then every block
+        uint32_t n_seg = 0;
+        if (x.carry_len) q.h_seg[n_seg++] = 0u;
+        if (x.skip && (x.carry_len || x.n_blocks == 0 || x.skip >= x.blocks[0].isize)) return XM_ERR_INVALID_ARG;
+        for (uint64_t k = 0; k < x.n_blocks; ++k) {
+            q.h_blocks[k] = x.blocks[k];
+            q.h_blocks[k].out_off += x.carry_len;
+            if (x.blocks[k].isize) q.h_seg[n_seg++] = (uint32_t)(q.h_blocks[k].out_off + (k == 0 ? x.skip : 0));
+        }
+        q.h_seg[n_seg] = (uint32_t)q.raw_len;
+        q.h_summary[8] = n_seg;
+        if (x.comp_len) XMB_HIP(b, hipMemcpyAsync(q.d_comp, q.h_comp, (size_t)x.comp_len, hipMemcpyHostToDevice, st));
+        if (x.n_blocks) XMB_HIP(b, hipMemcpyAsync(q.d_blocks, q.h_blocks, (size_t)x.n_blocks * sizeof(xm_bgzf_block), hipMemcpyHostToDevice, st));
+        XMB_HIP(b, hipMemcpyAsync(q.d_seg, q.h_seg, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
+        if (x.n_blocks) {
+            int rc = xm_bgzf_inflate_dev(b->ctx, st, q.d_comp, q.d_blocks, x.n_blocks, q.d_raw, q.d_status, q.d_work);
+            if (rc == XM_OK) rc = xm_bgzf_crc32_dev(b->ctx, st, q.d_raw, q.d_blocks, x.n_blocks, q.d_crc);
+            if (rc != XM_OK) return rc;
+            XMB_HIP(b, hipMemcpyAsync(q.h_status, q.d_status, (size_t)x.n_blocks * 4, hipMemcpyDeviceToHost, st));
+            XMB_HIP(b, hipMemcpyAsync(q.h_crc, q.d_crc, (size_t)x.n_blocks * 4, hipMemcpyDeviceToHost, st));
+        }
+    }
+    XMB_HIP(b, hipEventRecord(sl.ev[1], st));
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        const uint32_t n_seg = q.h_summary[8];
+        XMB_HIP(b, hipMemsetAsync(q.d_summary, 0, 8 * sizeof(uint32_t), st));
+        if (n_seg) {
+            walk_kernel<false><<<(n_seg + 255u) / 256u, 256, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, q.d_cnt, q.d_exit, nullptr, nullptr, 0u);
+            scan_kernel<<<1, 1024, 0, st>>>(q.d_cnt, q.d_exit, q.d_seg, n_seg, q.d_base, q.d_summary);
+            walk_kernel<true><<<(n_seg + 255u) / 256u, 256, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, nullptr, nullptr, q.d_base, q.d_rec_off,
+                                                                     (uint32_t)std::min<uint64_t>(sl.record_cap, 0xFFFFFFFFull));
+        }
+        XMB_HIP(b, hipMemcpyAsync(q.h_summary, q.d_summary, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        // the inflated window goes back for the writer while the record kernels run
+        if (new_bytes[f]) XMB_HIP(b, hipMemcpyAsync(q.h_raw + in[f].carry_len, q.d_raw + in[f].carry_len, (size_t)new_bytes[f], hipMemcpyDeviceToHost, st));
+    }
+    XMB_HIP(b, hipStreamSynchronize(st));
+    if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
+    // ---- what the device found ------------------------------------------------------------------------------------------
+    uint64_t n_rec[2], stop[2];
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        for (uint64_t k = 0; k < in[f].n_blocks; ++k)
+            if (q.h_status[k] != 0u || q.h_crc[k] != in[f].crc[k]) out->bad_block = 1;
+        const uint32_t n_seg = q.h_summary[8];
+        n_rec[f] = n_seg ? q.h_summary[0] : 0;
+        stop[f] = n_seg ? q.h_summary[1] : 0;
+        if (n_seg && q.h_summary[2] == 0u) out->unaligned = 1;
+        if (n_rec[f] > sl.record_cap) n_rec[f] = sl.record_cap;            // the caller's windows are sized so that this cannot bind
+        if (in[f].eof && stop[f] != q.raw_len && !out->unaligned) out->bad_block = 2;     // the file ends inside a record
+    }
+    out->raw_len1 = sl.pf[0].raw_len; out->raw_len2 = sl.pf[1].raw_len;
+    out->n_rec1 = n_rec[0]; out->n_rec2 = n_rec[1];
+    out->raw1 = sl.pf[0].h_raw; out->raw2 = sl.pf[1].h_raw;
+    out->rec_off1 = sl.pf[0].h_rec_off; out->rec_off2 = sl.pf[1].h_rec_off;
+    out->flags1 = sl.pf[0].h_lflag; out->flags2 = sl.pf[1].h_lflag;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]);
+    out->ms_inflate = ms;
+    if (out->bad_block || out->unaligned) return XM_OK;
+    uint64_t n = std::min(std::min(n_rec[0], n_rec[1]), max_records);
+    // ---- strip + pair ------------------------------------------------------------------------------------------------------
+    XMB_HIP(b, hipEventRecord(sl.ev[1], st));
+    sl.h_state[0] = 0xFFFFFFFFu; sl.h_state[1] = 0; sl.h_state[2] = 0;
+    XMB_HIP(b, hipMemcpyAsync(sl.d_state, sl.h_state, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (n) {
+        for (int f = 0; f < 2; ++f) {
+            PerFile &q = sl.pf[f];
+            const RecOut ro = {q.d_name_off, q.d_name_len, q.d_a, q.d_x, q.d_rflag};
+            parse_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(q.d_raw, q.d_rec_off, (uint32_t)n, score_mode == XMS_SCORE_AS_ZS ? 'Z' : 'X', ro);
+        }
+        const PerFile &a = sl.pf[0], &c = sl.pf[1];
+        const FileRecs f1 = {a.d_raw, a.d_name_off, a.d_name_len, a.d_a, a.d_x, a.d_rflag};
+        const FileRecs f2 = {c.d_raw, c.d_name_off, c.d_name_len, c.d_a, c.d_x, c.d_rflag};
+        pair_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(f1, f2, (uint32_t)n, paired ? 1 : 0, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3],
+                                                                   reinterpret_cast<unsigned long long *>(sl.d_bits), sl.pf[0].d_lflag, sl.pf[1].d_lflag, sl.d_state);
+        for (int f = 0; f < 2; ++f) {
+            PerFile &q = sl.pf[f];
+            XMB_HIP(b, hipMemcpyAsync(q.h_lflag, q.d_lflag, (size_t)n, hipMemcpyDeviceToHost, st));
+            XMB_HIP(b, hipMemcpyAsync(q.h_rec_off, q.d_rec_off, (size_t)std::min<uint64_t>(n_rec[f], n + 1) * 4, hipMemcpyDeviceToHost, st));
+        }
+    }
+    XMB_HIP(b, hipMemcpyAsync(sl.h_state, sl.d_state, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    XMB_HIP(b, hipEventRecord(sl.ev[2], st));
+    XMB_HIP(b, hipStreamSynchronize(st));
+    if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
+    (void)hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]);
+    out->ms_kernels = ms;
+    if (sl.h_state[2] & 2u) { out->bad_block = 3; return XM_OK; }          // a malformed record
+    if (sl.h_state[2] & 1u) out->weird = 1;
+    if (sl.h_state[0] != 0xFFFFFFFFu && sl.h_state[0] < n) {
+        out->mismatch_at = (int64_t)sl.h_state[0];
+        n = sl.h_state[0];                                                  // records at and behind it are not reported
+    }
+    out->n_exceptions = sl.h_state[1];
+    // the walk's outcome, as xmh_parse reports it: a file that has no record left AND no byte left at its end ends the walk
+    bool ended = false, starved = false;
+    if (out->mismatch_at < 0) {
+        for (int f = 0; f < 2; ++f) {
+            const bool exhausted = n == n_rec[f];                           // the window holds no further complete record
+            if (exhausted && in[f].eof && stop[f] == sl.pf[f].raw_len) ended = true;
+        }
+        if (!ended && n < max_records) starved = true;                      // a window ran out before the other file did
+    }
+    out->ended = ended ? 1 : 0;
+    out->starved = starved ? 1 : 0;
+    out->n_records = n;
+    for (int f = 0; f < 2; ++f) {
+        const PerFile &q = sl.pf[f];
+        uint64_t c = n < n_rec[f] ? q.h_rec_off[n] : stop[f];              // first byte behind the yielded records
+        if (keep_halo && n > 0 && !ended && out->mismatch_at < 0) c = q.h_rec_off[n - 1];
+        (f == 0 ? out->consumed1 : out->consumed2) = c;
+    }
+    sl.have_columns = true;
+    return XM_OK;
+}
+
+int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int32_t min_score_floor,
+                       const uint8_t **code, const uint32_t **idx, uint64_t bin_offsets[8], uint64_t counts[64])
+{
+    if (!b || slot < 0 || slot > 1 || !code || !idx || !bin_offsets || !counts) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (n_records > sl.record_cap || !sl.have_columns) return XM_ERR_INVALID_ARG;
+    *code = sl.h_code;
+    *idx = sl.h_idx;
+    memset(bin_offsets, 0, 8 * sizeof(uint64_t));
+    memset(counts, 0, 64 * sizeof(uint64_t));
+    if (n_records == 0) return XM_OK;
+    XMB_HIP(b, hipSetDevice(b->device));
+    hipStream_t st = sl.stream;
+    const int rc = xm_classify_compact_dev(b->ctx, st, mode, n_records, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3], sl.d_bits,
+                                           min_score_floor, sl.d_code, sl.d_bins4, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
+    if (rc != XM_OK) {
+        std::lock_guard<std::mutex> hold(b->error_lock);
+        b->last_error = xm_last_hip_error(b->ctx);
+        return rc;
+    }
+    XMB_HIP(b, hipMemcpyAsync(sl.h_code, sl.d_code, n_records, hipMemcpyDeviceToHost, st));
+    XMB_HIP(b, hipMemcpyAsync(sl.h_off_counts, sl.d_off_counts, 72 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    XMB_HIP(b, hipStreamSynchronize(st));
+    const uint64_t units = sl.h_off_counts[7];
+    if (units > n_records) return XM_ERR_HIP;
+    if (units) {
+        XMB_HIP(b, hipMemcpyAsync(sl.h_idx, sl.d_idx, units * 4, hipMemcpyDeviceToHost, st));
+        XMB_HIP(b, hipStreamSynchronize(st));
+    }
+    memcpy(bin_offsets, sl.h_off_counts, 8 * sizeof(uint64_t));
+    memcpy(counts, sl.h_off_counts + 8, 64 * sizeof(uint64_t));
+    return XM_OK;
+}
+
+int xm_bamdev_columns(xm_bamdev *b, int slot, uint64_t n_records, int32_t *as1, int32_t *xs1, int32_t *as2, int32_t *xs2,
+                      uint64_t *unit_bits)
+{
+    if (!b || slot < 0 || slot > 1) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (n_records > sl.record_cap || !sl.have_columns) return XM_ERR_INVALID_ARG;
+    if (n_records == 0) return XM_OK;
+    XMB_HIP(b, hipSetDevice(b->device));
+    int32_t *dst[4] = {as1, xs1, as2, xs2};
+    for (int c = 0; c < 4; ++c)
+        if (dst[c]) XMB_HIP(b, hipMemcpyAsync(dst[c], sl.d_col[c], n_records * 4, hipMemcpyDeviceToHost, sl.stream));
+    if (unit_bits) XMB_HIP(b, hipMemcpyAsync(unit_bits, sl.d_bits, (n_records + 63) / 64 * 8, hipMemcpyDeviceToHost, sl.stream));
+    XMB_HIP(b, hipStreamSynchronize(sl.stream));
+    return XM_OK;
+}
+
+const char *xm_bamdev_last_error(const xm_bamdev *b)
+{
+    static thread_local std::string mine;
+    if (!b) return "";
+    {
+        std::lock_guard<std::mutex> hold(const_cast<xm_bamdev *>(b)->error_lock);
+        mine = b->last_error;
+    }
+    return mine.c_str();
+}
+
+}  // extern "C"

@@ -83,6 +83,18 @@ def _forget_stripper(stripper):
         _stripper = None
 
 
+_bamdev = None
+
+
+def default_bamdev():
+    """The process-wide GPU BAM front end (xm_bamdev) of the default context."""
+    global _bamdev
+    ctx = default_context()
+    if _bamdev is None or _bamdev.ctx is not ctx or not _bamdev._h:
+        _bamdev = _ffi.BamDev(ctx)
+    return _bamdev
+
+
 def default_stripper():
     """The process-wide GPU column stripper of the default context (its page-locked staging buffers are kept)."""
     global _stripper
@@ -1076,6 +1088,88 @@ class _BamSource(object):
         self.reader.close()
 
 
+BAM_GPU_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_BAM_WINDOW_MB", "256")) << 20   # inflated bytes of each file per window
+
+
+class _GpuBamFile(object):
+    """One BAM file of the GPU BAM path (include/xenomapper_bgzf.h): a cursor over its BGZF blocks.  Per window the host only
+    walks the member headers of the next blocks (xm_bgzf_index) and reads their compressed bytes into the slot's page-locked
+    staging buffer; inflating, finding the records and stripping them is the device's (xm_bamdev_run).  The inflated tail a
+    window did not consume is carried into the next one on the device."""
+
+    def __init__(self, path, n_threads=0):
+        from . import _host
+        self.path = path
+        self.data = np.memmap(path, dtype=np.uint8, mode="r")
+        self.reader = _host.BamReader(self.data, n_threads)           # header, reference names, the printer's threads
+        at = self.reader.records_start()
+        # the block the first record lies in: members are walked from the start until their inflated sizes pass it
+        blocks, _crc, nxt, _total = _ffi.bgzf_index(self.data, 0, at + 1)
+        ends = blocks["out_off"] + blocks["isize"]
+        j = int(np.searchsorted(ends, at, side="right"))              # first block whose end lies behind the offset
+        if j < len(blocks):
+            self.cursor = int(blocks["cdata_off"][j]) - self._member_header(blocks, j)
+            self.skip = at - int(blocks["out_off"][j])
+        else:                                                        # no record at all
+            self.cursor, self.skip = nxt, 0
+        self.fd = os.open(path, os.O_RDONLY)
+        self.carry = (0, 0, 0)                                       # (slot, offset, bytes) of the previous window's tail
+        self.by_lines = None                                         # record table of a window parsed by the text rules
+        self.pending = None
+
+    def _member_header(self, blocks, j):
+        """Bytes between a member's first byte and its DEFLATE data: cdata_off of block j minus the end of block j - 1."""
+        if j == 0:
+            return int(blocks["cdata_off"][0])
+        prev_end = int(blocks["cdata_off"][j - 1]) + int(blocks["cdata_len"][j - 1]) + 8
+        return int(blocks["cdata_off"][j]) - prev_end
+
+    @property
+    def at_end(self):
+        return self.cursor >= self.data.shape[0]
+
+    def stage(self, dev, slot, file, parser, want_raw, max_blocks):
+        """Index the next blocks (about want_raw inflated bytes, less what is carried) and read their compressed bytes into the
+        slot's staging buffer -> the dict xm_bamdev_run takes.  The cursor moves only in commit()."""
+        carry_slot, carry_off, carry_len = self.carry
+        budget = max(want_raw - carry_len, 0)
+        blocks = np.zeros(0, dtype=_ffi.BGZF_BLOCK)
+        crc = np.zeros(0, dtype=np.uint32)
+        nxt, comp_len = self.cursor, 0
+        if budget and not self.at_end:
+            blocks, crc, nxt, _total = _ffi.bgzf_index(self.data, self.cursor, budget + self.skip, max_blocks)
+            if len(blocks):
+                c0 = int(blocks["cdata_off"][0])
+                comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1]) - c0
+                blocks = blocks.copy()
+                blocks["cdata_off"] -= np.uint64(c0)
+                parser.pread(self.fd, c0, dev._L.xm_bamdev_staging(dev._h, slot, file), comp_len)
+        self.pending = nxt
+        return {"comp_len": comp_len, "blocks": blocks, "crc": crc, "carry_slot": carry_slot, "carry_off": carry_off,
+                "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": self.skip if len(blocks) else 0}
+
+    def ran(self, slot, raw_len, rec_off=None, stop=None):
+        """What advance() needs to know about the window that was just run."""
+        self.last = (slot, raw_len, rec_off, stop)
+
+    def advance(self, consumed, lines=0):
+        """The window was processed: `consumed` of its inflated bytes are done (or, for a window that went through the text
+        rules, `lines` of its records), the rest is carried into the next window."""
+        slot, raw_len, rec_off, stop = self.last
+        if rec_off is not None:
+            consumed = int(rec_off[lines]) if lines < rec_off.shape[0] else stop
+        if self.pending is not None and self.pending != self.cursor:
+            self.cursor, self.skip = self.pending, 0
+        self.carry = (slot, int(consumed), raw_len - int(consumed))
+        self.pending = None
+
+    def close(self):
+        if self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
+        self.reader.close()
+
+
 def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_threads=0, bam=False, starts=None):
     """The three main loops on two SAM (or BAM) *files*: same results as _run(mode, getReadPairs(...)), with the
     text work done by the C++ stripper / writer.  Falls back to the Python reader when the input is not ASCII."""
@@ -1090,9 +1184,20 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     prof = _PhaseClock()
     _EMIT_CLOCK.clear()
     t_all = time.perf_counter()
+    # BAM on the GPU (include/xenomapper_bgzf.h): inflate + record chain + stripper on the device for the plain walk with the AS /
+    # XS / ZS plugins; --cigar_scores, the skipping walk and XENOMAPPER_GPU_BAM=0 keep the host decoder
+    bamdev = None
+    if (bam and not skip_repeated and not cigar_mode and min_score == min_score and os.environ.get("XENOMAPPER_GPU_BAM", "1") != "0"):
+        try:
+            bamdev = default_bamdev()
+        except MemoryError:
+            bamdev = None
     with prof("open"):
-        sources = [(_BamSource(path, n_threads) if bam else _SamSource(path, None if starts is None else starts[k]))
-                   for k, path in enumerate((path1, path2))]
+        if bamdev is not None:
+            sources = [_GpuBamFile(path, n_threads) for path in (path1, path2)]
+        else:
+            sources = [(_BamSource(path, n_threads) if bam else _SamSource(path, None if starts is None else starts[k]))
+                       for k, path in enumerate((path1, path2))]
         # Two parsers alternate so that the next window is decoded (BAM) and parsed in a helper thread -- the C++
         # code runs without the GIL -- while the GPU classifies and the writer emits the current one.
         parsers = [_host.Parser(n_threads), _host.Parser(n_threads)]
@@ -1111,8 +1216,71 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         except MemoryError:                                          # no room for its buffers: the host threads strip
             stripper = None
 
+    bam_text = {}                                                    # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
+
+    def print_records(which, f, raw_addr, rec_off_addr, n):
+        """SAM text of records [0, n) of a window decoded on the GPU -> (text array, line_off, line_len)."""
+        buf = bam_text.get((which, f))
+        if buf is None or buf[1].shape[0] < n:
+            text = buf[0] if buf is not None else np.empty(1 << 20, dtype=np.uint8)
+            buf = bam_text[(which, f)] = [text, np.empty(n + n // 4 + 64, dtype=np.uint32), np.empty(n + n // 4 + 64, dtype=np.uint32)]
+        while True:
+            got = sources[f].reader.print_records(raw_addr, rec_off_addr, n, buf[0], buf[1], buf[2])
+            if got >= 0:
+                return buf[0], buf[1], buf[2], got
+            buf[0] = np.empty(-got + (-got >> 3) + (1 << 16), dtype=np.uint8)
+
+    def parse_next_bamdev(which, want):
+        """One window of both BAM files on the GPU: stage compressed blocks, xm_bamdev_run (inflate, CRC, record chain, strip,
+        pair), print the records' text for the writer.  A window the device does not vouch for -- blocks that do not begin
+        with a record, a record the text rules might read differently -- is printed whole and stripped by the text rules."""
+        from . import _host
+        want = max(want, BAM_GPU_WINDOW_BYTES)
+        with prof("window"):
+            carried = max(src.carry[2] for src in sources)
+            raw_cap = want + carried + (1 << 20)
+            comp_cap = raw_cap                                   # DEFLATE never expands a block by more than a few bytes
+            max_blocks = raw_cap // 65536 + raw_cap // 4096 + 64
+            bamdev.reserve(which, comp_cap, raw_cap, max_blocks, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
+            inputs = [src.stage(bamdev, which, f, parsers[which], want + src.carry[2], max_blocks) for f, src in enumerate(sources)]
+        with prof("strip"):
+            blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
+            prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_inflate
+            prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
+        if blk.bad_block:
+            raise ValueError("corrupt BAM input: a BGZF block or an alignment record is damaged (%s, %s)" % (path1, path2))
+        eofs = [bool(x["eof"]) for x in inputs]
+        if blk.unaligned or blk.weird:
+            with prof("parse"):
+                # the whole windows as text, then the text rules (exactly the host path's semantics for this window)
+                texts, tables = [], []
+                for f in (0, 1):
+                    # the record chain followed on the host (the inflated bytes are here already): every complete record
+                    rec = np.empty(blk.raw_len[f] // 36 + 2, dtype=np.uint32)
+                    first = inputs[f]["skip"] if not inputs[f]["carry_len"] else 0
+                    n_rec, stop = _host.bam_walk(blk.raw_addr[f], blk.raw_len[f], first, rec)
+                    rec = rec[:n_rec]
+                    text, _loff, _llen, got = print_records(which, f, blk.raw_addr[f], rec.ctypes.data, n_rec)
+                    texts.append((text, got))
+                    tables.append((rec, stop))
+                    sources[f].ran(which, blk.raw_len[f], rec, stop)
+                whole = [eofs[f] and tables[f][1] == blk.raw_len[f] for f in (0, 1)]
+                hb = parsers[which].parse(texts[0][0], 0, texts[0][1], whole[0], texts[1][0], 0, texts[1][1], whole[1],
+                                          score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
+            return hb, [texts[0][0], texts[1][0]], [0, 0], eofs
+        with prof("parse"):
+            loffs, llens, texts = [], [], []
+            for f in (0, 1):
+                text, loff, llen, _got = print_records(which, f, blk.raw_addr[f], blk.rec_off_addr[f], blk.n)
+                texts.append(text); loffs.append(loff); llens.append(llen)
+                sources[f].ran(which, blk.raw_len[f])
+            blk.set_text(loffs, llens)
+        return blk, texts, [0, 0], eofs
+
     def parse_next(which, want):
         nonlocal stripper
+        if bamdev is not None:
+            return parse_next_bamdev(which, want)
         with prof("window"):
             wins = [src.window(want) for src in sources]
         if stripper is not None and max(w[2] for w in wins) <= _ffi.STRIP_MAX_WINDOW:
@@ -1175,7 +1343,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         """Classify one parsed block and hand its units to the sinks.  Returns the input error to raise once the
         units in front of it have been written (one found while resolving the stripper's exceptions comes first)."""
         n = block.n
-        on_device = isinstance(block, _ffi.StrippedBlock)
+        on_device = isinstance(block, (_ffi.StrippedBlock, _ffi.BamDevBlock))
         exc = block.exc
         patches, bad, err = {}, None, None
         if exc:
