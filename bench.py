@@ -969,11 +969,20 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import bench_bam
-                r = bench_bam.run(copies=4000, workdir="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+                wd = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+                r = bench_bam.run(copies=16000, workdir=wd)
                 e2e["bam"] = {"read_pairs_per_s": r["value"], "pairs": r["units"], "bam_GBps": r["bam_GBps"], "seconds": round(r["seconds"], 4),
                               "threads": r["threads"], "phases": r["phases"],
-                              "what": "two BAM files (the reference's fixtures tiled) -> BGZF/BAM decoder with line descriptions -> "
-                                      "lock-step walk -> fused pass -> six SAM outputs on /dev/null"}
+                              "what": "two BAM files (the reference's fixtures tiled 16 000 times, record-aligned BGZF blocks as samtools writes "
+                                      "them) -> BGZF blocks inflated, records found and stripped ON THE GPU (xm_bamdev), columns stay in HBM -> "
+                                      "fused pass -> the host prints the records' SAM text -> six SAM outputs on /dev/null"}
+                os.environ["XENOMAPPER_GPU_BAM"] = "0"
+                try:
+                    r0 = bench_bam.run(copies=16000, workdir=wd)
+                    e2e["bam_host_decoder"] = {"read_pairs_per_s": r0["value"], "seconds": round(r0["seconds"], 4), "phases": r0["phases"],
+                                               "what": "the same input through the host decoder (XENOMAPPER_GPU_BAM=0: inflate and printing on CPU threads)"}
+                finally:
+                    os.environ.pop("XENOMAPPER_GPU_BAM", None)
             except Exception as e:                               # noqa: BLE001
                 e2e["bam"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:

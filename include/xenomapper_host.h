@@ -177,6 +177,9 @@ int xmh_bam_read_pre(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int
  * parallel; line_off / line_len (n entries each, caller arrays): where every line begins in dst and its length without
  * the terminator.  *written = bytes the text takes; XMH_ERR_INVALID_ARG with *written set when cap is too small (or the
  * text passes 4 GiB), XMH_ERR_BAD_BAM for a malformed record.  Reference names come from b's header.
+ * sparse != 0: every thread prints straight into its own stretch of dst, sized for the worst case (5 x the record bytes):
+ * one pass, no copy -- the lines are where line_off says, with gaps between the threads' stretches (what the writer needs;
+ * a caller that wants the text itself takes sparse = 0); *written = the room that takes.
  */
 int xmh_bam_records_start(xmh_bam *b, uint64_t *inflated_offset);
 /* The record chain of an inflated window followed on the host (files whose BGZF blocks do not begin with a record: the
@@ -184,7 +187,7 @@ int xmh_bam_records_start(xmh_bam *b, uint64_t *inflated_offset);
  * the window; rec_off may be NULL (count only); *stop = first byte not covered by a complete record. */
 int xmh_bam_walk(const uint8_t *raw, uint64_t len, uint64_t start, uint32_t *rec_off, uint64_t cap, uint64_t *n_records, uint64_t *stop);
 int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, char *dst, uint64_t cap,
-                  uint32_t *line_off, uint32_t *line_len, uint64_t *written);
+                  uint32_t *line_off, uint32_t *line_len, int sparse, uint64_t *written);
 
 /* xmh_parse on windows of text that xmh_bam_read_pre wrote, without tokenising it again: pre1 / pre2 describe the lines
  * from the first byte of buf1 / buf2 on (entries past the window are ignored), ops1 / ops2 are the arrays (n_ops1 / n_ops2

@@ -906,6 +906,8 @@ class BamDevBlock(object):
         self.csr = None
         self._host_cols = None
         self.line_off = self.line_len = self.norm_len = self.tables = None
+        self.finish = None                                       # set by the file path: prints the records' text when called
+        self.classified = None                                   # (code, idx, bin_offsets, counts) when the fused pass has run already
 
     def set_text(self, line_off, line_len):
         """The line tables of the printed text (uint32 arrays per file): what the writer gathers from."""

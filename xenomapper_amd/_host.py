@@ -83,7 +83,8 @@ def lib():
         L.xmh_bam_records_start.argtypes = [_P, ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_bam_walk.argtypes = [_P, ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
                                    ctypes.POINTER(ctypes.c_uint64)]
-        L.xmh_bam_print.argtypes = [_P, _P, _P, ctypes.c_uint64, _P, ctypes.c_uint64, _P, _P, ctypes.POINTER(ctypes.c_uint64)]
+        L.xmh_bam_print.argtypes = [_P, _P, _P, ctypes.c_uint64, _P, ctypes.c_uint64, _P, _P, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_copy.argtypes = [_P, _P, _P, ctypes.c_uint64]
         L.xmh_pread.argtypes = [_P, ctypes.c_int, ctypes.c_uint64, _P, ctypes.c_uint64]
         L.xmh_adopt_lines.argtypes = [_P, ctypes.c_uint64] + [_P] * 8
@@ -301,13 +302,13 @@ class BamReader(object):
             raise ValueError("xmh_bam_records_start: " + self._L.xmh_strerror(rc).decode())
         return int(v.value)
 
-    def print_records(self, raw_address, rec_off_address, n, out, line_off, line_len):
+    def print_records(self, raw_address, rec_off_address, n, out, line_off, line_len, sparse=False):
         """SAM text of records [0, n) of an inflated window (host addresses of the bytes and of the uint32 record table) into
         the uint8 array `out`; fills the uint32 arrays line_off / line_len.  -> bytes written, or -needed when `out` is
-        too small."""
+        too small.  sparse: one pass, every thread into its own worst-case stretch of `out` (lines where line_off says)."""
         w = ctypes.c_uint64()
         rc = self._L.xmh_bam_print(self._h, _P(raw_address), _P(rec_off_address), int(n), out.ctypes.data_as(_P), out.shape[0],
-                                   line_off.ctypes.data_as(_P), line_len.ctypes.data_as(_P), ctypes.byref(w))
+                                   line_off.ctypes.data_as(_P), line_len.ctypes.data_as(_P), int(bool(sparse)), ctypes.byref(w))
         if rc == -1 and w.value > out.shape[0]:
             return -int(w.value)
         if rc != 0:

@@ -906,7 +906,7 @@ int xmh_bam_walk(const uint8_t *raw, uint64_t len, uint64_t start, uint32_t *rec
 }
 
 int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, char *dst, uint64_t cap,
-                  uint32_t *line_off, uint32_t *line_len, uint64_t *written)
+                  uint32_t *line_off, uint32_t *line_len, int sparse, uint64_t *written)
 {
     if (!b || !written || (n && (!raw || !rec_off || !line_off || !line_len))) return XMH_ERR_INVALID_ARG;
     *written = 0;
@@ -915,26 +915,51 @@ int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint6
         size_t longest_ref = 0;
         for (auto &name : b->ref_names) longest_ref = std::max(longest_ref, name.size());
         const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)b->pool->size(), (n + 255) / 256));
-        std::vector<uint64_t> first((size_t)nt + 1);
+        std::vector<uint64_t> first((size_t)nt + 1), room((size_t)nt + 1, 0);
         for (int t = 0; t <= nt; ++t) first[(size_t)t] = n * (uint64_t)t / (uint64_t)nt;
+        // text a record can grow to: the worst ratios are a B:c array element (1 byte -> "-128,"), a CIGAR operation (4 -> 11)
+        // and a packed base pair (1 -> 2), so 5x; the fixed fields add < 128 and two reference names
+        b->pool->run(nt, [&](int t) {
+            uint64_t bytes = 0;
+            for (uint64_t i = first[(size_t)t]; i < first[(size_t)t + 1]; ++i) bytes += le32(raw + rec_off[i]);
+            room[(size_t)t + 1] = (5 * bytes + (first[(size_t)t + 1] - first[(size_t)t]) * (128 + 2 * longest_ref) + 63) & ~(uint64_t)63;
+        });
         for (int t = 0; t < nt; ++t) { b->workers[(size_t)t].ok = true; b->workers[(size_t)t].text_len = 0; }
+        if (sparse) {
+            // every worker prints straight into its own stretch of dst, sized for the worst case: no second copy, the text is
+            // not contiguous (the line table says where every line is); untouched pages of dst cost nothing
+            for (int t = 0; t < nt; ++t) room[(size_t)t + 1] += room[(size_t)t];
+            *written = room[(size_t)nt];
+            if (room[(size_t)nt] > cap || room[(size_t)nt] > 0xFFFFFFFFull || !dst) return XMH_ERR_INVALID_ARG;
+            b->pool->run(nt, [&](int t) {
+                BamWorker &w = b->workers[(size_t)t];
+                char *const base = dst + room[(size_t)t];
+                char *o = base;
+                for (uint64_t i = first[(size_t)t]; i < first[(size_t)t + 1]; ++i) {
+                    char *const line = o;
+                    o = format_record(b, raw + rec_off[i] + 4, le32(raw + rec_off[i]), o);
+                    if (!o) { w.ok = false; return; }
+                    line_off[i] = (uint32_t)(line - dst);
+                    line_len[i] = (uint32_t)(o - line - 1);                    // without the '\n'
+                }
+            });
+            for (int t = 0; t < nt; ++t)
+                if (!b->workers[(size_t)t].ok) return XMH_ERR_BAD_BAM;
+            return XMH_OK;
+        }
         b->pool->run(nt, [&](int t) {
             BamWorker &w = b->workers[(size_t)t];
             const uint64_t lo = first[(size_t)t], hi = first[(size_t)t + 1];
             if (lo == hi) return;
-            // the worst ratios are a B:c array element (1 byte -> "-128,"), a CIGAR operation (4 -> 11) and a packed base
-            // pair (1 -> 2), so 5x; the fixed fields add < 128 and two reference names
-            uint64_t bytes = 0;
-            for (uint64_t i = lo; i < hi; ++i) bytes += le32(raw + rec_off[i]);
-            const size_t room = 5 * (size_t)bytes + (size_t)(hi - lo) * (128 + 2 * longest_ref);
-            if (w.text_cap < room) { w.text.reset(new char[room]); w.text_cap = room; }
+            const size_t need = (size_t)room[(size_t)t + 1];
+            if (w.text_cap < need) { w.text.reset(new char[need]); w.text_cap = need; }
             char *o = w.text.get();
             for (uint64_t i = lo; i < hi; ++i) {
                 char *const line = o;
                 o = format_record(b, raw + rec_off[i] + 4, le32(raw + rec_off[i]), o);
                 if (!o) { w.ok = false; return; }
                 line_off[i] = (uint32_t)(line - w.text.get());                 // local: rebased below
-                line_len[i] = (uint32_t)(o - line - 1);                        // without the '\n'
+                line_len[i] = (uint32_t)(o - line - 1);
             }
             w.text_len = (size_t)(o - w.text.get());
         });

@@ -18,9 +18,12 @@
 // matters next to the inflate.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -31,6 +34,7 @@
 namespace {
 
 constexpr int32_t ABSENT = INT32_MIN;
+constexpr uint64_t CARRY_SEG = 128;                         // records per segment of a carried tail
 constexpr uint32_t R_EX_A_SHIFT = 0, R_EX_X_SHIFT = 2;     // per-record flag byte of B4: ex_a (2 bits), ex_x (2 bits),
 constexpr uint32_t R_WEIRD = 0x10u, R_BAD = 0x20u;         // weird, malformed
 
@@ -282,22 +286,27 @@ pair_kernel(FileRecs f1, FileRecs f2, uint32_t n, int paired, int32_t *__restric
 
 // ---------------------------------------------------------------------------------------------------------------------
 struct PerFile {
-    uint8_t *h_comp = nullptr, *d_comp = nullptr;           // staged compressed bytes (+ XMB_COMP_PAD)
-    uint8_t *d_raw = nullptr, *h_raw = nullptr;             // the inflated window
-    xm_bgzf_block *h_blocks = nullptr, *d_blocks = nullptr;
-    uint32_t *d_status = nullptr, *h_status = nullptr, *d_crc = nullptr, *h_crc = nullptr;
+    uint8_t *h_comp = nullptr, *d_comp = nullptr;           // staged compressed bytes (+ XMB_COMP_PAD): d_comp = a half of Slot::d_comp_all
+    uint8_t *d_raw = nullptr, *h_raw = nullptr;             // the inflated window: d_raw = a half of Slot::d_raw_all
     uint32_t *h_seg = nullptr, *d_seg = nullptr, *d_cnt = nullptr, *d_exit = nullptr, *d_base = nullptr;
     uint32_t *d_rec_off = nullptr, *h_rec_off = nullptr;
     uint32_t *d_name_off = nullptr, *d_name_len = nullptr;
     int32_t *d_a = nullptr, *d_x = nullptr;
     uint8_t *d_rflag = nullptr, *d_lflag = nullptr, *h_lflag = nullptr;
-    uint32_t *d_summary = nullptr, *h_summary = nullptr, *d_work = nullptr;
+    uint32_t *d_summary = nullptr, *h_summary = nullptr;
     uint64_t raw_len = 0;
+    uint64_t table_len = 0;                 // entries of h_rec_off that are valid (the records of the slot's last window)
 };
 
 struct Slot {
     uint64_t comp_cap = 0, raw_cap = 0, block_cap = 0, record_cap = 0;
     PerFile pf[2];
+    // both files' blocks are inflated by ONE launch (a window of one file is only a third of the blocks the chip can hold):
+    // one compressed buffer and one output buffer, file 1's half behind file 0's; one block table, status and CRC array
+    uint8_t *d_comp_all = nullptr, *d_raw_all = nullptr;
+    uint64_t comp_stride = 0, raw_stride = 0;
+    xm_bgzf_block *h_blocks = nullptr, *d_blocks = nullptr;
+    uint32_t *d_status = nullptr, *h_status = nullptr, *d_crc = nullptr, *h_crc = nullptr, *d_work = nullptr;
     int32_t *d_col[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t *d_bits = nullptr;
     uint32_t *d_state = nullptr, *h_state = nullptr;
@@ -306,6 +315,8 @@ struct Slot {
     uint64_t *d_off_counts = nullptr, *h_off_counts = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_wait = nullptr;            // blocking-sync event: the waiting thread sleeps instead of spinning on a core the
+                                             // writer's printing threads need (16 of 16 CPUs print while the next window inflates)
     bool have_columns = false;
 };
 
@@ -362,12 +373,13 @@ void free_slot(Slot &sl)
 {
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
-        hfree(q.h_comp); dfree(q.d_comp); dfree(q.d_raw); hfree(q.h_raw);
-        hfree(q.h_blocks); dfree(q.d_blocks); dfree(q.d_status); hfree(q.h_status); dfree(q.d_crc); hfree(q.h_crc);
+        hfree(q.h_comp); q.d_comp = nullptr; q.d_raw = nullptr; hfree(q.h_raw);
         hfree(q.h_seg); dfree(q.d_seg); dfree(q.d_cnt); dfree(q.d_exit); dfree(q.d_base);
         dfree(q.d_rec_off); hfree(q.h_rec_off); dfree(q.d_name_off); dfree(q.d_name_len); dfree(q.d_a); dfree(q.d_x);
         dfree(q.d_rflag); dfree(q.d_lflag); hfree(q.h_lflag);
     }
+    dfree(sl.d_comp_all); dfree(sl.d_raw_all);
+    hfree(sl.h_blocks); dfree(sl.d_blocks); dfree(sl.d_status); hfree(sl.h_status); dfree(sl.d_crc); hfree(sl.h_crc);
     for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
     dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx);
     hfree(sl.h_code); hfree(sl.h_idx);
@@ -390,15 +402,16 @@ int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
         Slot &sl = b->slot[k];
         e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
         for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_wait, hipEventBlockingSync | hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, 16 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_state, 16 * sizeof(uint32_t), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off_counts, 72 * sizeof(uint64_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_work, 16 * sizeof(uint32_t));
         for (int f = 0; f < 2 && e == hipSuccess; ++f) {
             PerFile &q = sl.pf[f];
             e = hipMalloc((void **)&q.d_summary, 16 * sizeof(uint32_t));
             if (e == hipSuccess) e = hipHostMalloc((void **)&q.h_summary, 16 * sizeof(uint32_t), hipHostMallocDefault);
-            if (e == hipSuccess) e = hipMalloc((void **)&q.d_work, 16 * sizeof(uint32_t));
         }
     }
     if (e != hipSuccess) {
@@ -421,9 +434,11 @@ int xm_bamdev_destroy(xm_bamdev *b)
         }
         free_slot(sl);
         dfree(sl.d_state); hfree(sl.h_state); dfree(sl.d_off_counts); hfree(sl.h_off_counts);
-        for (int f = 0; f < 2; ++f) { dfree(sl.pf[f].d_summary); hfree(sl.pf[f].h_summary); dfree(sl.pf[f].d_work); }
+        dfree(sl.d_work);
+        for (int f = 0; f < 2; ++f) { dfree(sl.pf[f].d_summary); hfree(sl.pf[f].h_summary); }
         for (int i = 0; i < 3; ++i)
             if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
+        if (sl.ev_wait) (void)hipEventDestroy(sl.ev_wait);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     delete b;
@@ -441,17 +456,21 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
     sl.have_columns = false;
     if (comp_bytes > sl.comp_cap) {
         sl.comp_cap = 0;
+        sl.comp_stride = (comp_bytes + XMB_COMP_PAD + 255u) & ~(uint64_t)255;
+        XMB_TRY(dalloc(b, sl.d_comp_all, (size_t)(2 * sl.comp_stride)));
+        XMB_HIP(b, hipMemset(sl.d_comp_all, 0, (size_t)(2 * sl.comp_stride)));
         for (int f = 0; f < 2; ++f) {
             XMB_TRY(halloc(b, sl.pf[f].h_comp, (size_t)comp_bytes));
-            XMB_TRY(dalloc(b, sl.pf[f].d_comp, (size_t)comp_bytes + XMB_COMP_PAD));
-            XMB_HIP(b, hipMemset(sl.pf[f].d_comp, 0, (size_t)comp_bytes + XMB_COMP_PAD));
+            sl.pf[f].d_comp = sl.d_comp_all + f * sl.comp_stride;
         }
         sl.comp_cap = comp_bytes;
     }
     if (raw_bytes > sl.raw_cap) {
         sl.raw_cap = 0;
+        sl.raw_stride = (raw_bytes + 64u + 255u) & ~(uint64_t)255;
+        XMB_TRY(dalloc(b, sl.d_raw_all, (size_t)(2 * sl.raw_stride)));
         for (int f = 0; f < 2; ++f) {
-            XMB_TRY(dalloc(b, sl.pf[f].d_raw, (size_t)raw_bytes + 64));
+            sl.pf[f].d_raw = sl.d_raw_all + f * sl.raw_stride;
             XMB_TRY(halloc(b, sl.pf[f].h_raw, (size_t)raw_bytes + 64));
         }
         sl.raw_cap = raw_bytes;
@@ -459,13 +478,14 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
     if (max_blocks > sl.block_cap) {
         sl.block_cap = 0;
         const size_t nb = (size_t)max_blocks + 2;
+        XMB_TRY(halloc(b, sl.h_blocks, 2 * nb)); XMB_TRY(dalloc(b, sl.d_blocks, 2 * nb));
+        XMB_TRY(dalloc(b, sl.d_status, 2 * nb)); XMB_TRY(halloc(b, sl.h_status, 2 * nb));
+        XMB_TRY(dalloc(b, sl.d_crc, 2 * nb)); XMB_TRY(halloc(b, sl.h_crc, 2 * nb));
         for (int f = 0; f < 2; ++f) {
             PerFile &q = sl.pf[f];
-            XMB_TRY(halloc(b, q.h_blocks, nb)); XMB_TRY(dalloc(b, q.d_blocks, nb));
-            XMB_TRY(dalloc(b, q.d_status, nb)); XMB_TRY(halloc(b, q.h_status, nb));
-            XMB_TRY(dalloc(b, q.d_crc, nb)); XMB_TRY(halloc(b, q.h_crc, nb));
-            XMB_TRY(halloc(b, q.h_seg, nb + 2)); XMB_TRY(dalloc(b, q.d_seg, nb + 2));
-            XMB_TRY(dalloc(b, q.d_cnt, nb + 2)); XMB_TRY(dalloc(b, q.d_exit, nb + 2)); XMB_TRY(dalloc(b, q.d_base, nb + 2));
+            // segments: the blocks plus the pieces of a carried tail (at most as many again)
+            XMB_TRY(halloc(b, q.h_seg, 2 * nb + 4)); XMB_TRY(dalloc(b, q.d_seg, 2 * nb + 4));
+            XMB_TRY(dalloc(b, q.d_cnt, 2 * nb + 4)); XMB_TRY(dalloc(b, q.d_exit, 2 * nb + 4)); XMB_TRY(dalloc(b, q.d_base, 2 * nb + 4));
         }
         sl.block_cap = max_blocks;
     }
@@ -509,7 +529,12 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     sl.have_columns = false;
     XMB_HIP(b, hipSetDevice(b->device));
     hipStream_t st = sl.stream;
-    uint64_t new_bytes[2] = {0, 0};
+    static const bool profile = getenv("XM_BAMDEV_PROFILE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_staged = 0, t_issued = 0, t_sync1 = 0;
+    uint64_t new_bytes[2] = {0, 0}, first_block[2] = {0, 0}, n_all = 0;
+    if (in[0].n_blocks + in[1].n_blocks > 2 * sl.block_cap) return XM_ERR_INVALID_ARG;
     // ---- stage: carry, compressed bytes, block tables; inflate + CRC; the record chain --------------------------------
     XMB_HIP(b, hipEventRecord(sl.ev[0], st));
     for (int f = 0; f < 2; ++f) {
@@ -533,27 +558,46 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
             memmove(q.h_raw, src.h_raw + x.carry_off, (size_t)x.carry_len);
         }
         q.raw_len = x.carry_len + new_bytes[f];
-        // segments: the carry (when there is one), then every block
+        // segments: the carry (when there is one), then every block; the launch's block table holds both files
         uint32_t n_seg = 0;
-        if (x.carry_len) q.h_seg[n_seg++] = 0u;
+        if (x.carry_len) {
+            // The carried bytes are records of the previous window: ONE lane following their chain takes a microsecond a record
+            // (a 13 MB tail = 45 k records = 45 ms, and the tail of the file with the shorter records grows window by window),
+            // so the carry is cut into segments of CARRY_SEG records at boundaries the previous window's record table knows.
+            q.h_seg[n_seg++] = 0u;
+            const PerFile &src = b->slot[x.carry_slot].pf[f];
+            const uint32_t *tab = src.h_rec_off;
+            const uint64_t tn = src.table_len;
+            const uint32_t *at = std::lower_bound(tab, tab + tn, (uint32_t)x.carry_off);
+            if (tn && at != tab + tn && *at == x.carry_off) {
+                const uint64_t j0 = (uint64_t)(at - tab);
+                for (uint64_t j = j0 + CARRY_SEG; j < tn && n_seg + 2 < sl.block_cap; j += CARRY_SEG) q.h_seg[n_seg++] = tab[j] - (uint32_t)x.carry_off;
+            }
+        }
         if (x.skip && (x.carry_len || x.n_blocks == 0 || x.skip >= x.blocks[0].isize)) return XM_ERR_INVALID_ARG;
         for (uint64_t k = 0; k < x.n_blocks; ++k) {
-            q.h_blocks[k] = x.blocks[k];
-            q.h_blocks[k].out_off += x.carry_len;
-            if (x.blocks[k].isize) q.h_seg[n_seg++] = (uint32_t)(q.h_blocks[k].out_off + (k == 0 ? x.skip : 0));
+            xm_bgzf_block d = x.blocks[k];
+            const uint64_t out_in_file = d.out_off + x.carry_len;
+            if (d.isize) q.h_seg[n_seg++] = (uint32_t)(out_in_file + (k == 0 ? x.skip : 0));
+            d.cdata_off += (uint64_t)f * sl.comp_stride;
+            d.out_off = out_in_file + (uint64_t)f * sl.raw_stride;
+            sl.h_blocks[n_all + k] = d;
         }
         q.h_seg[n_seg] = (uint32_t)q.raw_len;
         q.h_summary[8] = n_seg;
+        first_block[f] = n_all;
+        n_all += x.n_blocks;
         if (x.comp_len) XMB_HIP(b, hipMemcpyAsync(q.d_comp, q.h_comp, (size_t)x.comp_len, hipMemcpyHostToDevice, st));
-        if (x.n_blocks) XMB_HIP(b, hipMemcpyAsync(q.d_blocks, q.h_blocks, (size_t)x.n_blocks * sizeof(xm_bgzf_block), hipMemcpyHostToDevice, st));
         XMB_HIP(b, hipMemcpyAsync(q.d_seg, q.h_seg, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
-        if (x.n_blocks) {
-            int rc = xm_bgzf_inflate_dev(b->ctx, st, q.d_comp, q.d_blocks, x.n_blocks, q.d_raw, q.d_status, q.d_work);
-            if (rc == XM_OK) rc = xm_bgzf_crc32_dev(b->ctx, st, q.d_raw, q.d_blocks, x.n_blocks, q.d_crc);
-            if (rc != XM_OK) return rc;
-            XMB_HIP(b, hipMemcpyAsync(q.h_status, q.d_status, (size_t)x.n_blocks * 4, hipMemcpyDeviceToHost, st));
-            XMB_HIP(b, hipMemcpyAsync(q.h_crc, q.d_crc, (size_t)x.n_blocks * 4, hipMemcpyDeviceToHost, st));
-        }
+    }
+    t_staged = since();
+    if (n_all) {
+        XMB_HIP(b, hipMemcpyAsync(sl.d_blocks, sl.h_blocks, (size_t)n_all * sizeof(xm_bgzf_block), hipMemcpyHostToDevice, st));
+        int rc = xm_bgzf_inflate_dev(b->ctx, st, sl.d_comp_all, sl.d_blocks, n_all, sl.d_raw_all, sl.d_status, sl.d_work);
+        if (rc == XM_OK) rc = xm_bgzf_crc32_dev(b->ctx, st, sl.d_raw_all, sl.d_blocks, n_all, sl.d_crc);
+        if (rc != XM_OK) return rc;
+        XMB_HIP(b, hipMemcpyAsync(sl.h_status, sl.d_status, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
+        XMB_HIP(b, hipMemcpyAsync(sl.h_crc, sl.d_crc, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
     }
     XMB_HIP(b, hipEventRecord(sl.ev[1], st));
     for (int f = 0; f < 2; ++f) {
@@ -570,14 +614,17 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         // the inflated window goes back for the writer while the record kernels run
         if (new_bytes[f]) XMB_HIP(b, hipMemcpyAsync(q.h_raw + in[f].carry_len, q.d_raw + in[f].carry_len, (size_t)new_bytes[f], hipMemcpyDeviceToHost, st));
     }
-    XMB_HIP(b, hipStreamSynchronize(st));
+    t_issued = since();
+    XMB_HIP(b, hipEventRecord(sl.ev_wait, st));
+    XMB_HIP(b, hipEventSynchronize(sl.ev_wait));
+    t_sync1 = since();
     if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
     // ---- what the device found ------------------------------------------------------------------------------------------
     uint64_t n_rec[2], stop[2];
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
         for (uint64_t k = 0; k < in[f].n_blocks; ++k)
-            if (q.h_status[k] != 0u || q.h_crc[k] != in[f].crc[k]) out->bad_block = 1;
+            if (sl.h_status[first_block[f] + k] != 0u || sl.h_crc[first_block[f] + k] != in[f].crc[k]) out->bad_block = 1;
         const uint32_t n_seg = q.h_summary[8];
         n_rec[f] = n_seg ? q.h_summary[0] : 0;
         stop[f] = n_seg ? q.h_summary[1] : 0;
@@ -593,6 +640,7 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     float ms = 0;
     (void)hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]);
     out->ms_inflate = ms;
+    sl.pf[0].table_len = sl.pf[1].table_len = 0;
     if (out->bad_block || out->unaligned) return XM_OK;
     uint64_t n = std::min(std::min(n_rec[0], n_rec[1]), max_records);
     // ---- strip + pair ------------------------------------------------------------------------------------------------------
@@ -613,12 +661,15 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         for (int f = 0; f < 2; ++f) {
             PerFile &q = sl.pf[f];
             XMB_HIP(b, hipMemcpyAsync(q.h_lflag, q.d_lflag, (size_t)n, hipMemcpyDeviceToHost, st));
-            XMB_HIP(b, hipMemcpyAsync(q.h_rec_off, q.d_rec_off, (size_t)std::min<uint64_t>(n_rec[f], n + 1) * 4, hipMemcpyDeviceToHost, st));
         }
     }
+    for (int f = 0; f < 2; ++f)                                            // the whole record table: the writer prints from it, and the next
+        if (n_rec[f])                                                      // window cuts its carried tail at boundaries it lists
+            XMB_HIP(b, hipMemcpyAsync(sl.pf[f].h_rec_off, sl.pf[f].d_rec_off, (size_t)n_rec[f] * 4, hipMemcpyDeviceToHost, st));
     XMB_HIP(b, hipMemcpyAsync(sl.h_state, sl.d_state, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     XMB_HIP(b, hipEventRecord(sl.ev[2], st));
-    XMB_HIP(b, hipStreamSynchronize(st));
+    XMB_HIP(b, hipEventRecord(sl.ev_wait, st));
+    XMB_HIP(b, hipEventSynchronize(sl.ev_wait));
     if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
     (void)hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]);
     out->ms_kernels = ms;
@@ -629,6 +680,11 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         n = sl.h_state[0];                                                  // records at and behind it are not reported
     }
     out->n_exceptions = sl.h_state[1];
+    if (out->mismatch_at >= 0) {                                            // the device counted the pairs behind the mismatch too
+        uint64_t e = 0;
+        for (uint64_t k = 0; k < n; ++k) e += ((sl.pf[0].h_lflag[k] | sl.pf[1].h_lflag[k]) & (XMS_LINE_EX_A | XMS_LINE_EX_X)) ? 1u : 0u;
+        out->n_exceptions = e;
+    }
     // the walk's outcome, as xmh_parse reports it: a file that has no record left AND no byte left at its end ends the walk
     bool ended = false, starved = false;
     if (out->mismatch_at < 0) {
@@ -638,9 +694,15 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         }
         if (!ended && n < max_records) starved = true;                      // a window ran out before the other file did
     }
+    if (profile)
+        fprintf(stderr, "xm_bamdev_run: staged %.1f ms (carry memmove, tables, copies queued), issued %.1f, first sync %.1f, done %.1f; "
+                        "device: inflate+crc+h2d %.1f ms, record kernels %.1f ms; %.1f + %.1f MB inflated\n",
+                t_staged, t_issued, t_sync1, since(), out->ms_inflate, out->ms_kernels, new_bytes[0] / 1e6, new_bytes[1] / 1e6);
     out->ended = ended ? 1 : 0;
     out->starved = starved ? 1 : 0;
     out->n_records = n;
+    sl.pf[0].table_len = n_rec[0];
+    sl.pf[1].table_len = n_rec[1];
     for (int f = 0; f < 2; ++f) {
         const PerFile &q = sl.pf[f];
         uint64_t c = n < n_rec[f] ? q.h_rec_off[n] : stop[f];              // first byte behind the yielded records

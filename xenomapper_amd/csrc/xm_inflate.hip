@@ -68,8 +68,8 @@ inflate_kernel(const uint8_t *__restrict__ comp, const xm_bgzf_block *__restrict
     }
 }
 
-// CRC-32 of one block per wave: lane l takes the l-th 64th of the block byte by byte (table in LDS), the pieces are
-// combined by multiplying with x^(8 * bytes behind the piece) modulo the polynomial (square-and-multiply over GF(2)).
+// CRC-32 of one block per workgroup (crc32_kernel below); the pieces' CRCs are combined by multiplying with
+// x^(8 * bytes behind the piece) modulo the polynomial (square-and-multiply over GF(2)).
 __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)       // reflected representation, as the CRC itself
 {
     uint32_t p = 0;
@@ -84,26 +84,42 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)       // 
 __global__ void __launch_bounds__(256)
 crc32_kernel(const uint8_t *__restrict__ out, const xm_bgzf_block *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ crc_out)
 {
-    __shared__ uint32_t table[256];
+    // one workgroup per block, thread t takes the t-th 256th of it (whole 4-byte words, the last thread the odd tail); four
+    // bytes per step through four tables ("slicing by 4": T[k][v] = CRC of byte v followed by k zero bytes)
+    __shared__ uint32_t T[4][256];
+    __shared__ uint32_t wave_x[4];
     {
         uint32_t c = threadIdx.x;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
-        table[threadIdx.x] = c;
+        T[0][threadIdx.x] = c;
+        uint32_t v = c;
+        for (int j = 1; j < 4; ++j) {
+            // one more zero byte behind: the register shifts by 8 through the byte table -- which is T[0], computable locally
+            uint32_t lo = v & 0xFFu, w = lo;
+            for (int k = 0; k < 8; ++k) w = (w >> 1) ^ ((w & 1u) ? 0xEDB88320u : 0u);
+            v = w ^ (v >> 8);
+            T[j][threadIdx.x] = v;
+        }
     }
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const xm_bgzf_block d = blocks[b];
-    const uint32_t piece = (d.isize + 63u) / 64u;
-    const uint32_t lo = min(lane * piece, d.isize), hi = min(lo + piece, d.isize);
+    const uint32_t t = threadIdx.x;
+    const uint32_t piece = ((d.isize + 255u) / 256u + 3u) & ~3u;
+    const uint32_t lo = min(t * piece, d.isize), hi = min(lo + piece, d.isize);
     const uint8_t *p = out + d.out_off;
     // the ordinary CRC-32 of the piece (an empty piece: 0); CRC(A || B) = CRC(A) * x^(8 |B|) + CRC(B) over GF(2), so the block's
     // CRC is the sum of every piece's CRC times x^(8 * bytes behind the piece)
     uint32_t c = 0;
     if (hi > lo) {
         c = 0xFFFFFFFFu;
-        for (uint32_t i = lo; i < hi; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+        uint32_t i = lo;
+        for (; i + 4u <= hi; i += 4u) {
+            c ^= (uint32_t)p[i] | ((uint32_t)p[i + 1] << 8) | ((uint32_t)p[i + 2] << 16) | ((uint32_t)p[i + 3] << 24);
+            c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
+        }
+        for (; i < hi; ++i) c = T[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
         c ^= 0xFFFFFFFFu;
     }
     uint32_t n = d.isize - hi, pw = 0x80000000u /* x^0 */, sq = 0x00800000u /* x^8 */;
@@ -115,7 +131,9 @@ crc32_kernel(const uint8_t *__restrict__ out, const xm_bgzf_block *__restrict__ 
     c = gf2_mulmod(c, pw);
     c ^= __shfl_xor(c, 1, 64);  c ^= __shfl_xor(c, 2, 64);  c ^= __shfl_xor(c, 4, 64);
     c ^= __shfl_xor(c, 8, 64);  c ^= __shfl_xor(c, 16, 64); c ^= __shfl_xor(c, 32, 64);
-    if (lane == 0u) crc_out[b] = c;
+    if ((t & 63u) == 0u) wave_x[t >> 6] = c;
+    __syncthreads();
+    if (t == 0u) crc_out[b] = wave_x[0] ^ wave_x[1] ^ wave_x[2] ^ wave_x[3];
 }
 
 inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -186,7 +204,7 @@ int xm_bgzf_crc32_dev(xm_ctx *ctx, void *stream, const uint8_t *out, const xm_bg
     if (!ctx || n_blocks > 0x7FFFFFFFull) return XM_ERR_INVALID_ARG;
     if (n_blocks == 0) return XM_OK;
     if (!out || !blocks || !crc_out) return XM_ERR_INVALID_ARG;
-    crc32_kernel<<<(uint32_t)((n_blocks + 3) / 4), 256, 0, (hipStream_t)stream>>>(out, blocks, (uint32_t)n_blocks, crc_out);
+    crc32_kernel<<<(uint32_t)n_blocks, 256, 0, (hipStream_t)stream>>>(out, blocks, (uint32_t)n_blocks, crc_out);
     return hipGetLastError() == hipSuccess ? XM_OK : XM_ERR_HIP;
 }
 

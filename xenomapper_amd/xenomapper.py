@@ -1088,7 +1088,13 @@ class _BamSource(object):
         self.reader.close()
 
 
-BAM_GPU_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_BAM_WINDOW_MB", "256")) << 20   # inflated bytes of each file per window
+# inflated bytes of each file per window of the GPU BAM path: both files' blocks go into ONE inflate launch, and ~16 000 blocks
+# (two 512 MB windows) are what keeps the chip's ~8 000 decoder chains busy for two rounds (256 MB: 5.0, 512 MB: 5.6 M pairs/s on
+# a 1.9 M-pair input, profiles/r05_bam_gpu_path.txt)
+BAM_GPU_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_BAM_WINDOW_MB", "512")) << 20
+# the text the writer prints per (slot, file): kept from run to run -- a fresh 1.4 GB buffer per window and file would be
+# page-faulted in again by every run (one run at a time uses them: the default context's BAM front end is one object)
+_BAM_TEXT_BUFFERS = {}
 
 
 class _GpuBamFile(object):
@@ -1114,6 +1120,8 @@ class _GpuBamFile(object):
             self.cursor, self.skip = nxt, 0
         self.fd = os.open(path, os.O_RDONLY)
         self.carry = (0, 0, 0)                                       # (slot, offset, bytes) of the previous window's tail
+        self.bytes_per_record = 0.0                                  # of the windows so far (0: not known yet)
+        self.seen = [0, 0]                                           # bytes and records consumed so far
         self.by_lines = None                                         # record table of a window parsed by the text rules
         self.pending = None
 
@@ -1148,9 +1156,13 @@ class _GpuBamFile(object):
         return {"comp_len": comp_len, "blocks": blocks, "crc": crc, "carry_slot": carry_slot, "carry_off": carry_off,
                 "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": self.skip if len(blocks) else 0}
 
-    def ran(self, slot, raw_len, rec_off=None, stop=None):
-        """What advance() needs to know about the window that was just run."""
+    def ran(self, slot, raw_len, rec_off=None, stop=None, consumed=0, records=0):
+        """What advance() needs to know about the window that was just run (and how many records its consumed bytes held)."""
         self.last = (slot, raw_len, rec_off, stop)
+        if records:
+            self.seen[0] += consumed - self.carry[1] * 0
+            self.seen[1] += records
+            self.bytes_per_record = self.seen[0] / self.seen[1]
 
     def advance(self, consumed, lines=0):
         """The window was processed: `consumed` of its inflated bytes are done (or, for a window that went through the text
@@ -1216,16 +1228,17 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         except MemoryError:                                          # no room for its buffers: the host threads strip
             stripper = None
 
-    bam_text = {}                                                    # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
+    bam_text = _BAM_TEXT_BUFFERS                                     # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
+    bam_windows = [0]                                                # windows run so far
 
-    def print_records(which, f, raw_addr, rec_off_addr, n):
+    def print_records(which, f, raw_addr, rec_off_addr, n, sparse=False):
         """SAM text of records [0, n) of a window decoded on the GPU -> (text array, line_off, line_len)."""
         buf = bam_text.get((which, f))
         if buf is None or buf[1].shape[0] < n:
             text = buf[0] if buf is not None else np.empty(1 << 20, dtype=np.uint8)
             buf = bam_text[(which, f)] = [text, np.empty(n + n // 4 + 64, dtype=np.uint32), np.empty(n + n // 4 + 64, dtype=np.uint32)]
         while True:
-            got = sources[f].reader.print_records(raw_addr, rec_off_addr, n, buf[0], buf[1], buf[2])
+            got = sources[f].reader.print_records(raw_addr, rec_off_addr, n, buf[0], buf[1], buf[2], sparse)
             if got >= 0:
                 return buf[0], buf[1], buf[2], got
             buf[0] = np.empty(-got + (-got >> 3) + (1 << 16), dtype=np.uint8)
@@ -1236,13 +1249,23 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         with a record, a record the text rules might read differently -- is printed whole and stripped by the text rules."""
         from . import _host
         want = max(want, BAM_GPU_WINDOW_BYTES)
+        # the first windows are small: nothing can be printed or written before the first window is through the GPU, so the
+        # pipeline is filled with a quarter and a half window before the full ones (which use the chip best) follow
+        if bam_windows[0] < 2 and want >= (64 << 20):
+            want = want >> (2 - bam_windows[0])
+        bam_windows[0] += 1
         with prof("window"):
             carried = max(src.carry[2] for src in sources)
             raw_cap = want + carried + (1 << 20)
             comp_cap = raw_cap                                   # DEFLATE never expands a block by more than a few bytes
             max_blocks = raw_cap // 65536 + raw_cap // 4096 + 64
             bamdev.reserve(which, comp_cap, raw_cap, max_blocks, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
-            inputs = [src.stage(bamdev, which, f, parsers[which], want + src.carry[2], max_blocks) for f, src in enumerate(sources)]
+            # the two files hold the same reads at different bytes per record: each gets a window in proportion, so that the
+            # windows hold about as many records and neither file drags a growing tail from window to window
+            per_rec = [src.bytes_per_record for src in sources]
+            scale = [p / max(per_rec) for p in per_rec] if min(per_rec) > 0 else [1.0, 1.0]
+            inputs = [src.stage(bamdev, which, f, parsers[which], int(want * scale[f]) + src.carry[2], max_blocks)
+                      for f, src in enumerate(sources)]
         with prof("strip"):
             blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
             prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_inflate
@@ -1268,13 +1291,26 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 hb = parsers[which].parse(texts[0][0], 0, texts[0][1], whole[0], texts[1][0], 0, texts[1][1], whole[1],
                                           score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
             return hb, [texts[0][0], texts[1][0]], [0, 0], eofs
-        with prof("parse"):
-            loffs, llens, texts = [], [], []
-            for f in (0, 1):
-                text, loff, llen, _got = print_records(which, f, blk.raw_addr[f], blk.rec_off_addr[f], blk.n)
-                texts.append(text); loffs.append(loff); llens.append(llen)
-                sources[f].ran(which, blk.raw_len[f])
-            blk.set_text(loffs, llens)
+        for f in (0, 1):
+            sources[f].ran(which, blk.raw_len[f], consumed=blk.consumed[f] - inputs[f]["skip"], records=max(blk.n - (1 if paired else 0), 0))
+        texts = [None, None]
+        if blk.n and not blk.n_exceptions:
+            # the fused pass right behind the strip kernels, on the slot's stream, BEFORE the next window's inflate launch is
+            # queued (issued later, from the main thread, it waits behind that launch: 25-30 ms a window)
+            with prof("classify"):
+                blk.classified = bamdev.classify(which, mode, blk.n, _floor_min_score(min_score))
+
+        def finish():
+            # the records' SAM text, printed by the host threads when the block is settled -- in the main thread, while the
+            # helper thread has the GPU inflate and strip the NEXT window (printing here instead would put the two in a row)
+            with prof("parse"):
+                loffs, llens = [], []
+                for f in (0, 1):
+                    text, loff, llen, _got = print_records(which, f, blk.raw_addr[f], blk.rec_off_addr[f], blk.n, sparse=True)
+                    texts[f] = text
+                    loffs.append(loff); llens.append(llen)
+                blk.set_text(loffs, llens)
+        blk.finish = finish
         return blk, texts, [0, 0], eofs
 
     def parse_next(which, want):
@@ -1342,6 +1378,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     def settle(block, raws, pos, parser, pending):
         """Classify one parsed block and hand its units to the sinks.  Returns the input error to raise once the
         units in front of it have been written (one found while resolving the stripper's exceptions comes first)."""
+        if getattr(block, "finish", None) is not None:
+            block.finish()                                       # GPU BAM path: print the records' text now
         n = block.n
         on_device = isinstance(block, (_ffi.StrippedBlock, _ffi.BamDevBlock))
         exc = block.exc
@@ -1360,7 +1398,9 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             parser.adopt_lines(raws[0], pos[0], raws[1], pos[1], block.n, block.tables)
         if n:
             with prof("classify"):          # one fused pass: category bytes, counts and the six bin lists
-                if on_device and not patches:                    # the columns never left the device
+                if on_device and not patches and n == block.n and getattr(block, "classified", None) is not None:
+                    code, idx, off, counts = block.classified        # classified right behind the strip kernels (GPU BAM path)
+                elif on_device and not patches:                  # the columns never left the device
                     code, idx, off, counts = block.stripper.classify(block.slot, mode, n, _floor_min_score(min_score))
                 else:
                     code, idx, off, counts = _classify_parsed(ctx, mode, block, n, patches, cigar_mode, min_score)
