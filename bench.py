@@ -749,7 +749,8 @@ def compact_line(full):
         line["workloads"] = w
     e2e = full.get("e2e")
     if e2e:                    # [G read-pairs/s host columns -> lists over PCIe (page-locked), M read-pairs/s SAM text -> six SAM files (GPU stripper),
-                               #  M pairs/s BAM -> files, M pairs/s SAM text -> files with the host stripper]
+                               #  M pairs/s BAM -> outputs (BAM front end on the GPU), M pairs/s SAM text -> files with the host stripper,
+                               #  M pairs/s BAM -> outputs with the host decoder, GB/s of inflated bytes of the GPU BGZF decoder]
         def rate(d, *path):
             for k in path:
                 d = d.get(k) if isinstance(d, dict) else None
@@ -757,7 +758,9 @@ def compact_line(full):
         line["e2e"] = [_r((rate(e2e, "h2d_inclusive", "registered_buffers", "read_pairs_per_s") or 0) / 1e9, 4),
                        _r((rate(e2e, "sam_text", "read_pairs_per_s") or 0) / 1e6, 4),
                        _r((rate(e2e, "bam", "read_pairs_per_s") or 0) / 1e6, 4),
-                       _r((rate(e2e, "sam_text_host_stripper", "read_pairs_per_s") or 0) / 1e6, 4)]
+                       _r((rate(e2e, "sam_text_host_stripper", "read_pairs_per_s") or 0) / 1e6, 4),
+                       _r((rate(e2e, "bam_host_decoder", "read_pairs_per_s") or 0) / 1e6, 4),
+                       _r(rate(e2e, "inflate", "value") or 0, 4)]
     line["full_record"] = full.get("full_record")
     return line
 
@@ -985,6 +988,12 @@ def main():
                     os.environ.pop("XENOMAPPER_GPU_BAM", None)
             except Exception as e:                               # noqa: BLE001
                 e2e["bam"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import bench_inflate
+                e2e["inflate"] = bench_inflate.run(out_gb=1.0, reps=5, ctx=ctx)
+            except Exception as e:                               # noqa: BLE001
+                e2e["inflate"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import bench_e2e

@@ -114,16 +114,18 @@ def test_printed_line_stays_short_enough_for_a_truncating_record():
             "cpu_baseline": {"value": 135060.123, "unit": "read-pairs/s", "cores": 1, "kind": "port", "sample": "s" * 300,
                              "sample_short": "82 x 20000-pair SAM text twin, parse+classify+write, 12 s"},
             "verified_vs_oracle": True, "n_ranks_seen": 8, "xm_allreduce_counts": {"ranks": 8, "matches_torch_distributed": True},
-            "workloads": {"configs[2]": sub, "configs[4]": sub,
+            "workloads": {"configs[2]": sub, "configs[4]": sub, "runs": dict(sub, ms_per_step_median=0.289412345),
                           "sharded_input": {"ms_per_step": 3.127712, "value": 127890123456.0, "verified_vs_oracle": True}},
             "e2e": {"h2d_inclusive": {"registered_buffers": {"read_pairs_per_s": 1.56e9}}, "sam_text": {"read_pairs_per_s": 6.869e6},
-                    "bam": {"read_pairs_per_s": 2.8e6}, "sam_text_host_stripper": {"read_pairs_per_s": 6.1e6}, "note": "n" * 500},
+                    "bam": {"read_pairs_per_s": 6.2e6}, "sam_text_host_stripper": {"read_pairs_per_s": 6.1e6},
+                    "bam_host_decoder": {"read_pairs_per_s": 3.5e6}, "inflate": {"value": 28.3312345}, "note": "n" * 500},
             "full_record": "gpurun_out/bench_full_8gpu_cfg2.json"}
     line = json.dumps(bench.compact_line(full), separators=(",", ":"))
     assert len(line) < 1900, len(line)
     rec = json.loads(line)
     assert rec["workloads"]["cfg3"][:3] == [0.51434, 0.7281, 0.6779] and rec["workloads"]["sharded"][2] is True
-    assert rec["roofline"]["frac"] == 0.7281 and rec["cpu_baseline"]["cores"] == 1 and rec["e2e"] == [1.56, 6.869, 2.8, 6.1]
+    assert rec["roofline"]["frac"] == 0.7281 and rec["cpu_baseline"]["cores"] == 1 and rec["e2e"] == [1.56, 6.869, 6.2, 6.1, 3.5, 28.33]
+    assert rec["workloads"]["runs"] == [0.51434, 0.28941, 0.6779, True]
     # an error in a side measurement is carried as text, the line still parses and stays short
     full["workloads"]["configs[2]"] = {"error": "RuntimeError: " + "e" * 500}
     full["xm_allreduce_counts"] = {"error": "watchdog: " + "h" * 500}

@@ -261,13 +261,18 @@ def test_bam_input_equals_sam_input(mode_case, via, tmp_path):
         assert hashlib.sha224(texts[name].encode("latin-1")).hexdigest() == exp["bins"][name]["sha224"], name
 
 
+@pytest.mark.parametrize("front_end", ["gpu", "host"])
 @pytest.mark.parametrize("window", [1500, 20000])
 @pytest.mark.parametrize("mode_case", ["ref_pe_liberal", "ref_pe_conservative_min99_5"])
-def test_bam_input_in_small_windows(mode_case, window, tmp_path, monkeypatch):
+def test_bam_input_in_small_windows(mode_case, window, front_end, tmp_path, monkeypatch):
     """Many windows per file: every refill moves the unread tail in front of the text the decoder thread has produced
     meanwhile, while the lines of the previous window are still being written (1500 bytes is a handful of lines: some
-    windows must grow, and a 64-byte head room never holds the tail)."""
+    windows must grow, and a 64-byte head room never holds the tail).  Both BAM front ends: the GPU one (blocks inflated and
+    stripped on the device; its windows are whole BGZF blocks, so the fixture's two record blocks come as two windows) and the
+    host decoder."""
     from xenomapper_amd import xenomapper as xm
+    monkeypatch.setenv("XENOMAPPER_GPU_BAM", "1" if front_end == "gpu" else "0")
+    monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", window)
     monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", window)
     monkeypatch.setattr(xm._BamSource, "HEAD", 64 if window == 1500 else 4096)
     case, counts, texts = _bam_case_outputs(xm, mode_case, tmp_path, "files")
@@ -463,3 +468,29 @@ def test_records_with_more_than_65535_cigar_operations_through_cigar_scores(via,
     for name, sink, w in zip(H.STATES, outs.values(), want_outs):
         sink.close()
         assert (tmp_path / (name + ".out")).read_text() == w.getvalue(), name
+
+
+def test_a_failed_read_into_the_staging_buffer_falls_back_and_the_next_run_is_clean(tmp_path, monkeypatch):
+    """a pread (or an upload) that fails half way through a window must not leave the process-wide GPU stripper with
+    a half-staged slot.  The run that hits it finishes through the host stripper with the right outputs; the next run gets a
+    fresh GPU stripper and uses it."""
+    from xenomapper_amd import _host, xenomapper as xm
+    case = next(c for c in G3 if c["name"] == "ref_pe_liberal")
+    real = _host.Parser.pread
+    calls = {"n": 0}
+
+    def flaky(self, fd, offset, dst, n):
+        calls["n"] += 1
+        if calls["n"] == 2:                                      # the second piece of the first window
+            raise OSError("injected: could not read %d bytes at offset %d" % (n, offset))
+        return real(self, fd, offset, dst, n)
+    monkeypatch.setattr(_host.Parser, "pread", flaky)
+    before = xm.default_stripper()
+    check(xm, case, tmp_path)                                    # correct outputs although the staging failed
+    assert calls["n"] >= 2
+    assert xm._stripper is not before                            # the half-staged stripper was dropped
+    monkeypatch.setattr(_host.Parser, "pread", real)
+    d2 = tmp_path / "again"
+    d2.mkdir()
+    check(xm, case, d2)
+    assert xm.LAST_FILE_PROFILE.get("strip_kernels_ms", 0) > 0   # and the next run strips on the GPU again

@@ -4,6 +4,7 @@ outcome, same score columns, unit mask, line tables and flagged values -- on ran
 in the middle of files, and on a large synthetic pair of files; then the fused classify pass on the device-resident
 columns against the same pass on the host stripper's columns."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -307,6 +308,38 @@ def _unpack_cigar(cnt, ops):
     return out
 
 
+_PLAIN_INT = re.compile(r"^[+-]?[0-9]{1,10}$")
+
+
+def _plain_int32(text):
+    return bool(_PLAIN_INT.match(text)) and int(text) <= 2**31 - 1 and int(text) >= -(2**31 - 1)
+
+
+def _flag_reason(fields, tag, score_mode):
+    """Why the stripper may (and must) decline to vouch for column `tag` of this line, from the text alone -- None: it must
+    deliver the value.  The plugins' rules (xenomapper.py:176-191, :193-206, :228-256): optional fields fields[11:] that CONTAIN
+    the tag; two of them raise; the value is what follows the last ':'.  The kernels vouch for plain int32 literals only."""
+    opt = fields[11:]
+    if score_mode == 2 and tag == "AS":                               # get_cigarbased_AS_tag: NM (first match) + fields[5]
+        nm = [x for x in opt if "NM" in x]
+        if not nm:
+            return None
+        if len(fields) < 6:
+            return "short"
+        if not _plain_int32(nm[0].split(":")[-1]):
+            return "nonint"
+        if any(int(n) >= 2**28 for n, _op in re.findall(r"([0-9]+)([MIDNSHPX=])", fields[5])):
+            return "biglen"
+        return None
+    name = "ZS" if (score_mode == 1 and tag == "XS") else tag
+    hits = [x for x in opt if name in x]
+    if not hits:
+        return None
+    if len(hits) > 1:
+        return "dup"
+    return None if _plain_int32(hits[0].split(":")[-1]) else "nonint"
+
+
 @settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "300")), deadline=None, suppress_health_check=list(HealthCheck))
 @given(texts=sam_pair(), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans(), skip=st.booleans())
 def test_gpu_stripper_agrees_with_the_oracle_directly(rig, texts, score_mode, paired, skip):
@@ -349,7 +382,13 @@ def test_gpu_stripper_agrees_with_the_oracle_directly(rig, texts, score_mode, pa
                     want, failed = scorer(fields, tag=tag), False
                 except Exception:
                     want, failed = None, True
+                # a flag must be JUSTIFIED by the text, and a justified flag must be there (an over-flagging stripper -- which the
+                # host path would quietly absorb by re-reading the line -- fails here)
+                why = _flag_reason(fields, tag, score_mode)
+                assert ((k, c) in exc) == (why is not None), (fields, tag, why)
                 if (k, c) in exc:
+                    if why in ("dup", "short"):
+                        assert failed, (fields, tag, why)               # the reference raises (ValueError :189-190 / IndexError)
                     continue
                 assert not failed, (fields, tag)
                 if score_mode == 2 and tag == "AS":
@@ -359,3 +398,43 @@ def test_gpu_stripper_agrees_with_the_oracle_directly(rig, texts, score_mode, pa
                 else:
                     have = NEG if cols[c][k] == -2**31 else int(cols[c][k])
                 assert have == want, (fields, tag, have, want)
+
+
+def test_closing_a_stripper_leaves_no_dangling_stream_in_the_context():
+    """the context orders workspace calls across streams and used to keep the handle of the last stream -- a closed
+    Stripper's slot stream.  xm_strip_destroy now hands the stream back (xm_workspace_release): a classify on another stream
+    afterwards must simply work."""
+    import torch
+    from xenomapper_amd import _ffi, synth
+    from tests import helpers as H
+    ctx = _ffi.Context(0)
+    try:
+        s = _ffi.Stripper(ctx)
+        t1, t2, _ = synth.sam_text_pair(n_pairs=300, seed=3, profile="bowtie2", paired=True, read_len=50)
+        bodies = []
+        for t in (t1, t2):
+            at = 0
+            while t[at] == "@":
+                at = t.index("\n", at) + 1
+            bodies.append(t[at:].encode("ascii"))
+        blk = strip(s, 0, bodies[0], bodies[1], True, True, 0, True, False, 1 << 12)
+        code, idx, off, counts = s.classify(0, _ffi.MODE_PE_LIBERAL, blk.n, _ffi.ABSENT)     # on the slot's own stream
+        want_counts = counts.copy()
+        cols = s.columns(0, blk.n)
+        s.close()                                                                           # destroys that stream
+        dev = torch.device("cuda:0")
+        d = [torch.from_numpy(c).to(dev) for c in cols[:4]] + [torch.from_numpy(cols[4].view(np.int64)).to(dev)]
+        n = blk.n
+        out_code = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+        out_idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        out_off = torch.zeros(8, dtype=torch.int64, device=dev)
+        out_counts = torch.zeros(64, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream()
+        for stream in (side, None):                                                          # another stream, then torch's own
+            ctx.classify_compact_dev(_ffi.MODE_PE_LIBERAL, *d, _ffi.ABSENT, out_code, out_idx, out_off, out_counts, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out_counts.cpu().numpy().astype(np.uint64), want_counts)
+            assert np.array_equal(out_off.cpu().numpy().astype(np.uint64), off)
+        assert ctx.workspace_is_clean()
+    finally:
+        ctx.close()

@@ -1213,6 +1213,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         # Two parsers alternate so that the next window is decoded (BAM) and parsed in a helper thread -- the C++
         # code runs without the GIL -- while the GPU classifies and the writer emits the current one.
         parsers = [_host.Parser(n_threads), _host.Parser(n_threads)]
+        # pread(2) into the page-locked staging buffers by a SMALL pool of its own (XENOMAPPER_PREAD_THREADS): with the stripper
+        # on the GPU the helper thread only copies, and sixteen readers beside the writer's sixteen gatherers oversubscribe the
+        # cores that feed the PCIe link
+        n_readers = int(os.environ.get("XENOMAPPER_PREAD_THREADS", "0"))
+        reader_pool = _host.Parser(n_readers) if n_readers > 0 else None
         pool = ThreadPoolExecutor(max_workers=1)
         ahead, ahead_pool = {}, ThreadPoolExecutor(max_workers=2)    # output files extended ahead of the writer, their pages unmapped behind it
     totals, key_order = Counter(), []
@@ -1337,7 +1342,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         base = stripper.staging_address(which, f)
                         for at in range(0, w[2], STAGE_PIECE):
                             piece = min(STAGE_PIECE, w[2] - at)
-                            parsers[which].pread(sources[f].fileno(), w[1] + at, base + at, piece)
+                            (reader_pool or parsers[which]).pread(sources[f].fileno(), w[1] + at, base + at, piece)
                             stripper.upload(which, f, at, piece)
                 with prof("strip"):
                     blk = stripper.run(which, wins[0][2], wins[0][3], wins[1][2], wins[1][3], score_mode, paired, skip_repeated,
@@ -1478,7 +1483,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         trouble = trouble or exc
             ahead_pool.shutdown(wait=True)
             pool.shutdown(wait=True)
-            for prs in parsers:
+            for prs in parsers + ([reader_pool] if reader_pool is not None else []):
                 prs.close()
             for src in sources:
                 src.close()
