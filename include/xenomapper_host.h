@@ -180,13 +180,16 @@ int xmh_bam_read_pre(xmh_bam *b, char *dst, uint64_t cap, uint64_t *written, int
  * sparse != 0: every thread prints straight into its own stretch of dst, sized for the worst case (5 x the record bytes):
  * one pass, no copy -- the lines are where line_off says, with gaps between the threads' stretches (what the writer needs;
  * a caller that wants the text itself takes sparse = 0); *written = the room that takes.
+ * wanted (may be NULL): one byte per record, 0 = do not print it (line_len 0).  The main loops print a unit's lines of ONE
+ * file only (primary bins file 1, secondary bins file 2, xenomapper.py:423-448) -- with the bins known before the text is
+ * printed, half the records need no text at all.
  */
 int xmh_bam_records_start(xmh_bam *b, uint64_t *inflated_offset);
 /* The record chain of an inflated window followed on the host (files whose BGZF blocks do not begin with a record: the
  * device walks block by block and cannot): records whose block_size word begins at or behind `start` and that end inside
  * the window; rec_off may be NULL (count only); *stop = first byte not covered by a complete record. */
 int xmh_bam_walk(const uint8_t *raw, uint64_t len, uint64_t start, uint32_t *rec_off, uint64_t cap, uint64_t *n_records, uint64_t *stop);
-int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, char *dst, uint64_t cap,
+int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, const uint8_t *wanted, char *dst, uint64_t cap,
                   uint32_t *line_off, uint32_t *line_len, int sparse, uint64_t *written);
 
 /* xmh_parse on windows of text that xmh_bam_read_pre wrote, without tokenising it again: pre1 / pre2 describe the lines

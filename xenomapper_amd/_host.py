@@ -83,7 +83,7 @@ def lib():
         L.xmh_bam_records_start.argtypes = [_P, ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_bam_walk.argtypes = [_P, ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
                                    ctypes.POINTER(ctypes.c_uint64)]
-        L.xmh_bam_print.argtypes = [_P, _P, _P, ctypes.c_uint64, _P, ctypes.c_uint64, _P, _P, ctypes.c_int,
+        L.xmh_bam_print.argtypes = [_P, _P, _P, ctypes.c_uint64, _P, _P, ctypes.c_uint64, _P, _P, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_copy.argtypes = [_P, _P, _P, ctypes.c_uint64]
         L.xmh_pread.argtypes = [_P, ctypes.c_int, ctypes.c_uint64, _P, ctypes.c_uint64]
@@ -302,12 +302,14 @@ class BamReader(object):
             raise ValueError("xmh_bam_records_start: " + self._L.xmh_strerror(rc).decode())
         return int(v.value)
 
-    def print_records(self, raw_address, rec_off_address, n, out, line_off, line_len, sparse=False):
+    def print_records(self, raw_address, rec_off_address, n, out, line_off, line_len, sparse=False, wanted=None):
         """SAM text of records [0, n) of an inflated window (host addresses of the bytes and of the uint32 record table) into
         the uint8 array `out`; fills the uint32 arrays line_off / line_len.  -> bytes written, or -needed when `out` is
-        too small.  sparse: one pass, every thread into its own worst-case stretch of `out` (lines where line_off says)."""
+        too small.  sparse: one pass, every thread into its own worst-case stretch of `out` (lines where line_off says).
+        wanted: uint8 per record, 0 = not printed (no sink takes it)."""
         w = ctypes.c_uint64()
-        rc = self._L.xmh_bam_print(self._h, _P(raw_address), _P(rec_off_address), int(n), out.ctypes.data_as(_P), out.shape[0],
+        rc = self._L.xmh_bam_print(self._h, _P(raw_address), _P(rec_off_address), int(n),
+                                   wanted.ctypes.data_as(_P) if wanted is not None else None, out.ctypes.data_as(_P), out.shape[0],
                                    line_off.ctypes.data_as(_P), line_len.ctypes.data_as(_P), int(bool(sparse)), ctypes.byref(w))
         if rc == -1 and w.value > out.shape[0]:
             return -int(w.value)

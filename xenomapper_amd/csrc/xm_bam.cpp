@@ -905,7 +905,7 @@ int xmh_bam_walk(const uint8_t *raw, uint64_t len, uint64_t start, uint32_t *rec
     return XMH_OK;
 }
 
-int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, char *dst, uint64_t cap,
+int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint64_t n, const uint8_t *wanted, char *dst, uint64_t cap,
                   uint32_t *line_off, uint32_t *line_len, int sparse, uint64_t *written)
 {
     if (!b || !written || (n && (!raw || !rec_off || !line_off || !line_len))) return XMH_ERR_INVALID_ARG;
@@ -920,9 +920,10 @@ int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint6
         // text a record can grow to: the worst ratios are a B:c array element (1 byte -> "-128,"), a CIGAR operation (4 -> 11)
         // and a packed base pair (1 -> 2), so 5x; the fixed fields add < 128 and two reference names
         b->pool->run(nt, [&](int t) {
-            uint64_t bytes = 0;
-            for (uint64_t i = first[(size_t)t]; i < first[(size_t)t + 1]; ++i) bytes += le32(raw + rec_off[i]);
-            room[(size_t)t + 1] = (5 * bytes + (first[(size_t)t + 1] - first[(size_t)t]) * (128 + 2 * longest_ref) + 63) & ~(uint64_t)63;
+            uint64_t bytes = 0, recs = 0;
+            for (uint64_t i = first[(size_t)t]; i < first[(size_t)t + 1]; ++i)
+                if (!wanted || wanted[i]) { bytes += le32(raw + rec_off[i]); ++recs; }
+            room[(size_t)t + 1] = (5 * bytes + recs * (128 + 2 * longest_ref) + 63) & ~(uint64_t)63;
         });
         for (int t = 0; t < nt; ++t) { b->workers[(size_t)t].ok = true; b->workers[(size_t)t].text_len = 0; }
         if (sparse) {
@@ -936,6 +937,7 @@ int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint6
                 char *const base = dst + room[(size_t)t];
                 char *o = base;
                 for (uint64_t i = first[(size_t)t]; i < first[(size_t)t + 1]; ++i) {
+                    if (wanted && !wanted[i]) { line_off[i] = 0; line_len[i] = 0; continue; }    // no sink takes this record
                     char *const line = o;
                     o = format_record(b, raw + rec_off[i] + 4, le32(raw + rec_off[i]), o);
                     if (!o) { w.ok = false; return; }
@@ -956,6 +958,7 @@ int xmh_bam_print(xmh_bam *b, const uint8_t *raw, const uint32_t *rec_off, uint6
             char *o = w.text.get();
             for (uint64_t i = lo; i < hi; ++i) {
                 char *const line = o;
+                if (wanted && !wanted[i]) { line_off[i] = (uint32_t)(line - w.text.get()); line_len[i] = 0; continue; }
                 o = format_record(b, raw + rec_off[i] + 4, le32(raw + rec_off[i]), o);
                 if (!o) { w.ok = false; return; }
                 line_off[i] = (uint32_t)(line - w.text.get());                 // local: rebased below

@@ -1236,14 +1236,14 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     bam_text = _BAM_TEXT_BUFFERS                                     # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
     bam_windows = [0]                                                # windows run so far
 
-    def print_records(which, f, raw_addr, rec_off_addr, n, sparse=False):
+    def print_records(which, f, raw_addr, rec_off_addr, n, sparse=False, wanted=None):
         """SAM text of records [0, n) of a window decoded on the GPU -> (text array, line_off, line_len)."""
         buf = bam_text.get((which, f))
         if buf is None or buf[1].shape[0] < n:
             text = buf[0] if buf is not None else np.empty(1 << 20, dtype=np.uint8)
             buf = bam_text[(which, f)] = [text, np.empty(n + n // 4 + 64, dtype=np.uint32), np.empty(n + n // 4 + 64, dtype=np.uint32)]
         while True:
-            got = sources[f].reader.print_records(raw_addr, rec_off_addr, n, buf[0], buf[1], buf[2], sparse)
+            got = sources[f].reader.print_records(raw_addr, rec_off_addr, n, buf[0], buf[1], buf[2], sparse, wanted)
             if got >= 0:
                 return buf[0], buf[1], buf[2], got
             buf[0] = np.empty(-got + (-got >> 3) + (1 << 16), dtype=np.uint8)
@@ -1310,8 +1310,23 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             # helper thread has the GPU inflate and strip the NEXT window (printing here instead would put the two in a row)
             with prof("parse"):
                 loffs, llens = [], []
+                # A unit's lines come from ONE file (primary bins: file 1, secondary bins: file 2, unresolved: both; :423-448),
+                # and a bin without a sink prints nothing: with the bins known already, only those records are printed
+                wanted = [None, None]
+                if blk.classified is not None:
+                    _code, idx, off, _counts = blk.classified
+                    wanted = [np.zeros(blk.n, dtype=np.uint8), np.zeros(blk.n, dtype=np.uint8)]
+                    for b in range(6):
+                        if not sinks[b]:
+                            continue
+                        seg = idx[int(off[b]):int(off[b + 1])]
+                        for f in ((0,) if b in (0, 2, 5) else (1,) if b in (1, 3) else (0, 1)):
+                            wanted[f][seg] = 1
+                            if paired:
+                                wanted[f][seg - 1] = 1               # a paired unit covers records idx - 1 and idx
                 for f in (0, 1):
-                    text, loff, llen, _got = print_records(which, f, blk.raw_addr[f], blk.rec_off_addr[f], blk.n, sparse=True)
+                    text, loff, llen, _got = print_records(which, f, blk.raw_addr[f], blk.rec_off_addr[f], blk.n, sparse=True,
+                                                           wanted=wanted[f])
                     texts[f] = text
                     loffs.append(loff); llens.append(llen)
                 blk.set_text(loffs, llens)
