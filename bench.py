@@ -332,7 +332,8 @@ class Workload(object):
         self.cigar_csr = os.environ.get("XM_BENCH_CIGAR_CSR") == "1"     # A/B only: the CSR-column kernel (K1c + stand-alone histogram)
         self.unfused = os.environ.get("XM_BENCH_UNFUSED") == "1"        # A/B only: xm_classify_dev + xm_compact_dev
         self.shard = shard
-        self.place = os.environ.get("XM_BENCH_PLACE") == "1" and name in ("cfg2", "cfg5", "se", "f64")   # A/B: the six-list form
+        # the six-list form (xm_classify_place*_dev): the sharded-input entry (large read blocks go through it in chunks), and XM_BENCH_PLACE=1 for A/B runs
+        self.place = (form == "place" or os.environ.get("XM_BENCH_PLACE") == "1") and name in ("cfg2", "cfg5", "se", "f64")
         # the segmented-lists form (xm_classify_runs*_dev, one launch): its own workload entry, and XM_BENCH_RUNS=1 for A/B runs
         self.runs = (form == "runs" or os.environ.get("XM_BENCH_RUNS") == "1") and name in ("cfg2", "cfg5", "se", "f64") and not self.place
         self.layout = "strictly interleaved mates"
@@ -1067,7 +1068,7 @@ def main():
     if plain_default:
         try:
             total = 400_000_000 - 400_000_000 % (Workload.PARTS * 32)
-            w3 = Workload("cfg2", ctx, dev, total // world, rank, None, 10, 0.0, (total, world))
+            w3 = Workload("cfg2", ctx, dev, total // world, rank, None, 10, 0.0, (total, world), form="place")
             el3, _, tma3 = time_steps(ctx, w3, 10, 3, fence)
             t3 = torch.tensor([el3], dtype=torch.float64, device=dev)
             el3 = float(allreduce(t3, dist.ReduceOp.MAX).item()) if world > 1 else el3
@@ -1079,7 +1080,10 @@ def main():
                 ok3 = bool(allreduce(f3, dist.ReduceOp.MIN).item()) if world > 1 else bool(f3.item())
             extra["sharded_input"] = {"total_pairs": total, "blocks": world, "steps": 10, "warmup": 3, "ms_per_step": 1e3 * el3 / 10,
                                       "value": units3 * 10 / el3, "unit": "read-pairs/s", "scaling": "strong", "units_per_step": units3,
-                                      "kernel_ms": {k: round(v["ms"] / max(1, v["launches"]), 5) for k, v in tma3.items() if v["launches"]},
+                                      "step": w3.call_name(),
+                                      # per STEP (a large read block takes several launches of each kernel: xm_api.hip place_steps)
+                                      "kernel_ms": {k: round(v["ms"] / 10, 5) for k, v in tma3.items() if v["launches"]},
+                                      "launches_per_step": {k: v["launches"] / 10 for k, v in tma3.items() if v["launches"]},
                                       "verified_vs_oracle": ok3}
             del w3
             torch.cuda.empty_cache()
@@ -1088,7 +1092,7 @@ def main():
     if rank == 0 and extra:
         line["workloads"] = extra
         line["workloads_note"] = ("timed in this process after the headline run, same protocol: configs[2] / configs[4] 5 warm-up + 20 "
-                                  "steps (one GPU only); sharded_input = configs[3]'s 400 M-pair input cut into N read blocks with halo, "
+                                  "steps (one GPU only); sharded_input = configs[3]'s 400 M-pair input cut into N read blocks with halo, six-list output (xm_classify_place_dev), "
                                   "3 warm-up + 10 steps, max over ranks")
 
     # The same reduction through the library's own RCCL communicator (xm_allreduce_counts, the C ABI's collective), on

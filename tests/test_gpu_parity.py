@@ -1041,6 +1041,67 @@ def test_six_list_form_on_the_device_every_mode_and_layout(ctx):
             assert np.array_equal(code[:n].cpu().numpy(), want_code)
 
 
+def test_six_lists_in_chunks_equal_the_one_pass_lists(ctx, monkeypatch):
+    """xm_classify_place*_dev goes over large inputs a chunk at a time (K1, K2b, K2c per chunk, running totals carried
+    through the part totals: xm_api.hip place_steps).  With the chunk cut down to one part (2 M records) a 9 M-record input
+    takes five chunks, the last one partial and ending off a part boundary: lists, lengths, category_counts, category
+    bytes and the workspace's between-calls state must be those of the one-pass order (= the oracle's), for every loop, both
+    scatter inputs, single-end staged granules, irregular unit masks and binary64 columns with the state-6 list; and a call
+    in one pass right after a chunked one must find the workspace as it expects it."""
+    import torch
+    from xenomapper_amd import _ffi
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4242)
+    n = 9_000_001
+    guard = 0x7FFFFFF0
+    for mode, p_unit, form in ((1, None, "bins4"), (2, 0.55, "bins4"), (0, 0.9, "bins4"), (1, 0.4, "code")):
+        cols = random_columns(rng, n)
+        bits = H.synth.interleaved_unit_bits(n) if p_unit is None else H.synth.pack_unit_bits(rng.random(n) < p_unit)
+        want_code, want_counts = H.c_classify(mode, *cols, bits, -2)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        d_cols = [torch.from_numpy(c).to(dev) for c in cols]
+        d_bits = torch.from_numpy(bits.view(np.int64)).to(dev)
+        for parts in ("1", "0"):                                    # chunked, then the one-pass order on the same context
+            monkeypatch.setenv("XM_PLACE_CHUNK_PARTS", parts)
+            lists = [torch.full((n + 8,), guard, dtype=torch.int32, device=dev) for _ in range(6)]
+            n_out = torch.full((8,), -1, dtype=torch.int64, device=dev)
+            counts = torch.full((64,), -1, dtype=torch.int64, device=dev)
+            code = torch.empty(n + 16, dtype=torch.uint8, device=dev) if form == "code" else None
+            bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev) if form == "bins4" else None
+            ctx.classify_place_dev(mode, *d_cols, d_bits, -2, lists, n_out, counts, code_out=code, bins4=bins4, capacity=n)
+            torch.cuda.synchronize()
+            _check_lists(lists, n_out.cpu().numpy(), want_idx, want_off)
+            assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts), (mode, parts)
+            for b, lst in enumerate(lists):
+                k = int(want_off[b + 1] - want_off[b])
+                assert bool((lst[k:] == guard).all()), (mode, parts, b)
+            if code is not None:
+                assert np.array_equal(code[:n].cpu().numpy(), want_code)
+            assert ctx.workspace_is_clean(), (mode, parts)
+            del lists
+        del d_cols, d_bits
+    # binary64 with NaN: the seventh list, chunked
+    nan = float("nan")
+    f = [rng.integers(-5, 6, n).astype(np.float64) for _ in range(4)]
+    f[0][rng.random(n) < 0.1] = nan
+    f[2][rng.random(n) < 0.05] = nan
+    bits = H.synth.pack_unit_bits(rng.random(n) < 0.7)
+    want_code, want_counts = H.c_classify(2, *f, bits, 0.5)
+    want_idx, want_off = H.c_compact(2, want_code)
+    d_cols = [torch.from_numpy(c).to(dev) for c in f]
+    d_bits = torch.from_numpy(bits.view(np.int64)).to(dev)
+    monkeypatch.setenv("XM_PLACE_CHUNK_PARTS", "1")
+    lists = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(7)]
+    n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(64, dtype=torch.int64, device=dev)
+    bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev)
+    ctx.classify_place_dev(2, *d_cols, d_bits, 0.5, lists[:6], n_out, counts, bins4=bins4, list_state6=lists[6])
+    torch.cuda.synchronize()
+    _check_lists(lists, n_out.cpu().numpy(), want_idx, want_off)
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+    assert ctx.workspace_is_clean()
+
+
 def test_two_streams_on_one_context_are_ordered_by_the_library(ctx):
     """The compaction workspace belongs to the context (include/xenomapper_hip.h): fused calls issued alternately on two
     streams, without any synchronisation by the caller, must still give each call its own right answer -- the library puts

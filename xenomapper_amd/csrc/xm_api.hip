@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <dlfcn.h>
@@ -417,7 +418,7 @@ static int compact_tail(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, const
     {
         Span span(ctx, st, XM_K_SCATTER);
         xm::launch_scatter(st, cp.plan, mode, n, from_bins4 ? cp.bins4 : code, from_bins4, cp.gran_counts, ctx->d_gran_off,
-                           bin_totals, bin_offsets, idx_out, ctx->d_part_tot, lists);
+                           bin_totals, bin_offsets, idx_out, ctx->d_part_tot, lists, cp.gran0, cp.gran1);
     }
     if ((rc = check_launch(ctx, "scatter_kernel")) != XM_OK) reset_count_state(ctx, st);      // K2c zeroes the part totals
     return rc;
@@ -585,6 +586,52 @@ static int list_out(uint32_t *const idx_out[6], uint32_t *idx_state6, uint64_t l
     return XM_OK;
 }
 
+/* Large inputs in chunks -- built, measured, and left OFF.  The six lists need, for every granule, the units of its bin in
+ * FRONT of it (running totals, not the bin totals), so K1, K2b and K2c can go over the input a chunk at a time: K1(c) leaves
+ * 1/2 byte per record of bins4 and the per-granule counts, K2b(c) takes its carry from the part totals of the chunks in
+ * front (left in place until the last chunk's K2c), K2c(c) reads what K1(c) wrote while it may still be in the 256 MB
+ * Infinity Cache; the last chunk's K2b adds up category_counts, its K2c publishes the list lengths.  The idea was that at
+ * 800 M records K2c (0.64 ms, against 8 x 0.06-0.07 at 100 M) loses by fetching 400 MB of bins4 from HBM again.  Measured
+ * on one box, same process, 400 M read pairs in one block (tools/ab_place_chunks.py, profiles/r05_ab_place_chunks.txt):
+ *     one pass 3.059 ms | chunks of 16 parts 3.413 | 32 parts 3.147 | 64 parts 3.120 | 128 parts 3.053
+ * K2c gains 0.04 ms at 32-64 parts (0.643 -> 0.600), K1 loses 0.08 (2.365 -> 2.44: every chunk launch has its own ramp and
+ * tail) and K2b 0.03-0.07 (every chunk's workgroups walk the part totals in front).  So the one-pass order stays the
+ * default; XM_PLACE_CHUNK_PARTS (environment, read per call) = parts of XM_PART_GRAN granules per chunk switches the
+ * chunked order on (inputs of more than two chunks), for A/B runs and tests/test_gpu_parity.py. */
+static uint32_t place_chunk_granules(void)
+{
+    const char *e = getenv("XM_PLACE_CHUNK_PARTS");
+    const long v = e && *e ? strtol(e, nullptr, 10) : 0;                   // off unless asked for (32 parts = 2^26 records = 32 MB of bins4)
+    return (uint32_t)(v < 0 ? 0 : v > 2048 ? 2048 : v) * (uint32_t)XM_PART_GRAN;
+}
+
+extern "C++" {
+template <typename LaunchK1>
+static int place_steps(xm_ctx *ctx, hipStream_t st, int mode, uint64_t n, xm::CountPlan &cp, uint8_t *code_out,
+                       const xm::ListOut &lo, uint64_t *n_out, uint64_t *counts, const char *k1_name, LaunchK1 k1)
+{
+    const uint32_t chunk = place_chunk_granules(), n_gran = cp.plan.n_gran;
+    const bool chunked = chunk != 0u && n_gran > 2u * chunk;
+    int rc;
+    for (uint32_t g0 = 0; g0 < n_gran; g0 += chunked ? chunk : n_gran) {
+        if (chunked) {
+            cp.gran0 = g0;
+            cp.gran1 = n_gran - g0 > chunk ? g0 + chunk : n_gran;
+        }
+        {
+            Span span(ctx, st, XM_K_CLASSIFY);
+            k1(cp);
+        }
+        if ((rc = check_launch(ctx, k1_name)) != XM_OK) {
+            if (g0) reset_count_state(ctx, st);                             // the chunks in front left their totals behind
+            return rc;
+        }
+        if ((rc = compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo)) != XM_OK) return rc;
+    }
+    return XM_OK;
+}
+}  // extern "C++"
+
 int xm_classify_place_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
                           const int32_t *as1, const int32_t *xs1, const int32_t *as2, const int32_t *xs2,
                           const uint64_t *unit_bits, int32_t min_score_floor, uint8_t *code_out, uint8_t *bins4,
@@ -603,12 +650,9 @@ int xm_classify_place_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     xm::CountPlan cp = count_plan(ctx, n);
     cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    {
-        Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &cp);
-    }
-    if ((rc = check_launch(ctx, "classify_kernel<int32, counts>")) != XM_OK) return rc;
-    return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
+    return place_steps(ctx, st, mode, n, cp, code_out, lo, n_out, counts, "classify_kernel<int32, counts>", [&](const xm::CountPlan &c) {
+        xm::launch_classify_i32(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score_floor, code_out, &c);
+    });
 }
 
 int xm_classify_place_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
@@ -630,12 +674,9 @@ int xm_classify_place_f64_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,
     xm::CountPlan cp = count_plan(ctx, n);
     cp.bins4 = bins4;
     if ((rc = order_workspace(ctx, st)) != XM_OK) return rc;
-    {
-        Span span(ctx, st, XM_K_CLASSIFY);
-        xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &cp);
-    }
-    if ((rc = check_launch(ctx, "classify_kernel<f64, counts>")) != XM_OK) return rc;
-    return compact_tail(ctx, st, mode, n, code_out, cp, nullptr, n_out, counts, &lo);
+    return place_steps(ctx, st, mode, n, cp, code_out, lo, n_out, counts, "classify_kernel<f64, counts>", [&](const xm::CountPlan &c) {
+        xm::launch_classify_f64(st, mode, n, as1, xs1, as2, xs2, unit_bits, min_score, code_out, &c);
+    });
 }
 
 int xm_classify_place_cigar_packed_dev(xm_ctx *ctx, void *stream, int mode, uint64_t n,

@@ -41,6 +41,9 @@ struct CountPlan {
     uint32_t *part_tot = nullptr;      // [XM_PART_REPLICAS][8][XM_PART_STRIDE]: K2b's first level (units per bin and part), all zero between calls
     uint8_t *bins4 = nullptr;          // where a counting classify kernel writes the compact category stream, or null
     uint64_t *counts_rep = nullptr;    // [XM_COUNT_REPLICAS][64], all zero between calls
+    // gran1 != 0: the launches cover the granules [gran0, gran1) only -- one chunk of a chunked xm_classify_place* call
+    // (gran0 a multiple of XM_PART_GRAN; the chunks are launched in order, the last one ends at plan.n_gran)
+    uint32_t gran0 = 0, gran1 = 0;
 };
 
 GranPlan plan_granules(uint64_t n);
@@ -95,7 +98,7 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
 // also zeroes the part totals K2b has consumed
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_counts, const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets,
-                    uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists = nullptr);
+                    uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists = nullptr, uint32_t gran0 = 0, uint32_t gran1 = 0);
 // memory shape of the classify kernel without arithmetic (bench.py: the box's streaming ceiling); n a multiple of 4
 void launch_stream_probe(hipStream_t st, uint64_t n, const int32_t *c0, const int32_t *c1, const int32_t *c2, const int32_t *c3,
                          uint8_t *out);

@@ -166,6 +166,7 @@ struct CountSink {
     uint8_t *bins4;                      // compact category stream (XM_GRAN / 2 bytes per granule) or null
     uint32_t gran_stride;
     int mode;                            // bin rule of the flush
+    uint32_t blk0;                       // a launch over part of the input (chunked xm_classify_place*): its first workgroup's number
 };
 
 // one wave adds up the group's histogram (lane = category slot) and publishes it
@@ -210,7 +211,7 @@ __device__ __forceinline__ void count_units(const uint32_t c[4], uint32_t *lds, 
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
     if (arrived != (uint32_t)(BLOCK / 64 - 1)) return;
     lds_settle();
-    count_flush(lds, blockIdx.x, sink);
+    count_flush(lds, blockIdx.x + sink.blk0, sink);
 }
 
 // Shared K1 epilogue: 4 states per lane -> forward mate's state (lane-1 / previous wave via LDS / halo) ->
@@ -319,7 +320,7 @@ __device__ __forceinline__ void classify_body(const T *__restrict__ as1, const T
                                               uint8_t *__restrict__ code, uint64_t n, uint32_t *last_state,
                                               uint32_t *count_lds, const CountSink &sink)
 {
-    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;       // group of 4 records
+    const uint64_t g = (uint64_t)(blockIdx.x + sink.blk0) * BLOCK + threadIdx.x;       // group of 4 records
     const uint64_t r0 = g * 4;
 
     T a1[4], x1[4], a2[4], x2[4];
@@ -364,7 +365,7 @@ classify_kernel(const T *__restrict__ as1, const T *__restrict__ xs1,
     __shared__ __attribute__((aligned(16))) uint32_t count_lds[COUNTS ? XM_COUNT_LDS_WORDS : 4];
     if (COUNTS) count_lds_clear<BLOCK>(count_lds);
     // every workgroup but possibly the last covers BLOCK*4 existing records: no bounds tests on that path
-    if (((uint64_t)blockIdx.x + 1) * (BLOCK * 4) <= n)
+    if (((uint64_t)blockIdx.x + sink.blk0 + 1) * (BLOCK * 4) <= n)
         classify_body<T, PAIRED, NT, BLOCK, true, COUNTS, BINMODE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
     else
         classify_body<T, PAIRED, NT, BLOCK, false, COUNTS, BINMODE>(as1, xs1, as2, xs2, unit_bits8, m, code, n, last_state, count_lds, sink);
@@ -485,13 +486,16 @@ __global__ void __launch_bounds__(XM_SCAN_THREADS)
 scan_kernel(const uint32_t *__restrict__ gran_counts, uint32_t n_gran, uint32_t gran_stride,
             const uint32_t *__restrict__ part_tot, uint32_t *__restrict__ gran_off,
             unsigned long long *__restrict__ bin_totals,
-            unsigned long long *__restrict__ counts_rep, unsigned long long *__restrict__ counts)
+            unsigned long long *__restrict__ counts_rep, unsigned long long *__restrict__ counts, uint32_t part0, uint32_t n_parts)
 {
+    // part0 / n_parts: a launch over the parts [part0, part0 + gridDim.x) of n_parts (chunked xm_classify_place*: the part
+    // totals of the chunks in front are still in place, so the carry below is the global one); the workgroups of the LAST
+    // part close the call: bin totals, and the category_counts replicas every counting launch of the call has added to
     __shared__ unsigned long long wsum[XM_SCAN_THREADS / 64];
     __shared__ uint32_t wtot[XM_SCAN_THREADS / 64];
-    const uint32_t p = blockIdx.x, b = blockIdx.y, n_parts = gridDim.x;
+    const uint32_t p = blockIdx.x + part0, b = blockIdx.y;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    if (p == 0u && t < 64u) {   // category_counts slots 8b..8b+7: 8 lanes per slot, 8 replicas each
+    if (p + 1u == n_parts && t < 64u) {   // category_counts slots 8b..8b+7: 8 lanes per slot, 8 replicas each
         const uint32_t slot = b * 8u + (t >> 3), part = t & 7u;
         unsigned long long acc = 0;
         for (uint32_t r = part; r < XM_COUNT_REPLICAS; r += 8u) {
@@ -743,20 +747,22 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
                const uint32_t *__restrict__ gran_counts, const uint32_t *__restrict__ gran_off,
                const unsigned long long *__restrict__ bin_totals,
                unsigned long long *__restrict__ bin_offsets, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ part_tot,
-               const ListOut lo, uint32_t gran_per_wave)
+               const ListOut lo, uint32_t gran_per_wave, uint32_t g_first, uint32_t last)
 {
+    // g_first / last: a launch over the granules [g_first, n_gran) of a chunked call (lists only: their places need the
+    // units in front, not the bin totals); the LAST launch of a call publishes the totals and zeroes the part totals
     constexpr bool CAN_STAGE = STAGE && XM_SCATTER_STAGED != 0 && NSUB * 256 == XM_GRAN;
     __shared__ uint8_t lut_all[NIB ? 1 : XM_BLOCK / 64][64];
     __shared__ uint64_t lptr_all[LISTS ? XM_BLOCK / 64 : 1][8];
     __shared__ __attribute__((aligned(16))) uint16_t slab_all[CAN_STAGE ? XM_BLOCK / 64 : 1][CAN_STAGE ? XM_SLAB_U16 : 4];
     const uint32_t lane = threadIdx.x & 63u;
-    {   // K2b has consumed the part totals: leave them zeroed for the next count (n_parts cells in each of the 8 x replicas rows)
+    if (last) {   // K2b has consumed the part totals: leave them zeroed for the next count (n_parts cells in each of the 8 x replicas rows)
         const uint32_t n_parts = (n_gran + XM_PART_GRAN - 1u) / XM_PART_GRAN, cells = 8u * XM_PART_REPLICAS * n_parts;
         for (uint32_t i = blockIdx.x * XM_BLOCK + threadIdx.x; i < cells; i += gridDim.x * XM_BLOCK)
             part_tot[(i / n_parts) * XM_PART_STRIDE + i % n_parts] = 0u;
     }
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t g0 = (blockIdx.x * (XM_BLOCK / 64) + wave) * gran_per_wave;
+    const uint32_t g0 = g_first + (blockIdx.x * (XM_BLOCK / 64) + wave) * gran_per_wave;
     if (g0 >= n_gran) return;                                             // wave-uniform; no barrier in this kernel
     const uint32_t g1 = g0 + gran_per_wave < n_gran ? g0 + gran_per_wave : n_gran;
     uint8_t *lut = lut_all[NIB ? 0 : wave];
@@ -773,7 +779,7 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
         const uint32_t bin_start = wave_scan_incl(tot) - tot;
         lane_base = LISTS ? off : bin_start + off;
         n_units = LISTS ? lo.cap : lane_value(bin_start, 7);              // slot 7 counts nothing: the total
-        if (g0 == 0u && lane < 8u) bin_offsets[lane] = (LISTS && lane < 7u) ? tot : bin_start;
+        if (g0 == g_first && last && lane < 8u) bin_offsets[lane] = (LISTS && lane < 7u) ? tot : bin_start;
     }
     uint16_t *slab = slab_all[CAN_STAGE ? wave : 0];
     uint32_t base[7];
@@ -1333,7 +1339,7 @@ __device__ __forceinline__ void classify_cigar_body(
     }
     // no fused counting here: the counting epilogue cost this kernel 36-45 us per 50 M pairs, more than the separate
     // histogram pass (30 us) it would save; K1p (packed columns) is the counting form of the --cigar_scores path
-    const CountSink none = {nullptr, nullptr, nullptr, nullptr, 0u, 0};
+    const CountSink none = {nullptr, nullptr, nullptr, nullptr, 0u, 0, 0u};
     classify_finish<int32_t, PAIRED, BLOCK, FULL, false, -1>(a1, x1, a2, x2, m, mb, halo, last_state, code, r0, n, nullptr, none);
 }
 
@@ -1774,6 +1780,7 @@ static CountSink make_sink(const CountPlan *cp, int mode)
     s.bins4 = cp ? cp->bins4 : nullptr;
     s.gran_stride = cp ? cp->plan.gran_stride : 0u;
     s.mode = mode;
+    s.blk0 = cp ? cp->gran0 : 0u;
     return s;
 }
 
@@ -1783,7 +1790,9 @@ static void launch_classify_t(hipStream_t st, int mode, uint64_t n,
                               const uint64_t *unit_bits, T m, uint8_t *code, const CountPlan *cp)
 {
     const uint64_t per_block = (uint64_t)XM_CLASSIFY_BLOCK * 4;
-    const uint32_t grid = (uint32_t)((n + per_block - 1) / per_block);
+    static_assert(XM_CLASSIFY_BLOCK * 4 == XM_GRAN, "a counting workgroup is a granule: CountPlan's chunk is in both");
+    const uint32_t all = (uint32_t)((n + per_block - 1) / per_block);
+    const uint32_t grid = (cp && cp->gran1) ? cp->gran1 - cp->gran0 : all;         // a chunk of the input, or all of it
     const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(unit_bits);
     const CountSink sink = make_sink(cp, mode);
     const bool paired = mode != XM_MODE_SE;
@@ -1899,24 +1908,30 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
     unsigned long long *bt = reinterpret_cast<unsigned long long *>(bin_totals);
     unsigned long long *rep = reinterpret_cast<unsigned long long *>(cp.counts_rep);
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(counts);
-    scan_kernel<<<dim3(n_parts, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.plan.n_gran, cp.plan.gran_stride, cp.part_tot,
-                                                             gran_off, bt, rep, cnt);
+    // a chunk [gran0, gran1) begins at a part boundary; the scan sees the granules up to the chunk's end
+    const uint32_t part0 = cp.gran1 ? cp.gran0 / XM_PART_GRAN : 0u;
+    const uint32_t part1 = cp.gran1 ? (cp.gran1 + XM_PART_GRAN - 1) / XM_PART_GRAN : n_parts;
+    scan_kernel<<<dim3(part1 - part0, 8), XM_SCAN_THREADS, 0, st>>>(cp.gran_counts, cp.gran1 ? cp.gran1 : cp.plan.n_gran, cp.plan.gran_stride,
+                                                                   cp.part_tot, gran_off, bt, rep, cnt, part0, n_parts);
 }
 
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_counts, const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets,
-                    uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists)
+                    uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists, uint32_t gran0, uint32_t gran1)
 {
     const unsigned long long *bt = reinterpret_cast<const unsigned long long *>(bin_totals);
     unsigned long long *bo = reinterpret_cast<unsigned long long *>(bin_offsets);
+    // [gran0, gran1): a chunk of a chunked call (lists only), gran1 == 0: the whole input
+    const uint32_t g_first = gran1 ? gran0 : 0u, g_end = gran1 ? gran1 : p.n_gran, span = g_end - g_first;
+    const uint32_t last = g_end == p.n_gran ? 1u : 0u;
     // long-lived waves, each a run of consecutive granules (scatter_kernel): about XM_SCATTER_WAVES of them
-    const uint32_t gran_per_wave = (p.n_gran + XM_SCATTER_WAVES - 1u) / XM_SCATTER_WAVES;
-    const uint32_t n_waves = (p.n_gran + gran_per_wave - 1u) / gran_per_wave;
+    const uint32_t gran_per_wave = (span + XM_SCATTER_WAVES - 1u) / XM_SCATTER_WAVES;
+    const uint32_t n_waves = (span + gran_per_wave - 1u) / gran_per_wave;
     const uint32_t grid = (n_waves + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
     const bool stage = mode == XM_MODE_SE;
     const ListOut lo = lists ? *lists : ListOut{{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0u};
-#define XM_LAUNCH_SCT(W, NIB, STG, L) scatter_kernel<XM_GRAN / 256, W, NIB, STG, L><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, p.n_gran, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot, lo, gran_per_wave)
+#define XM_LAUNCH_SCT(W, NIB, STG, L) scatter_kernel<XM_GRAN / 256, W, NIB, STG, L><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, g_end, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot, lo, gran_per_wave, g_first, last)
 #define XM_LAUNCH_SCT1(W, NIB, STG) do { if (lists) XM_LAUNCH_SCT(W, NIB, STG, true); else XM_LAUNCH_SCT(W, NIB, STG, false); } while (0)
 #define XM_LAUNCH_SCT2(W, NIB) do { if (stage) XM_LAUNCH_SCT1(W, NIB, true); else XM_LAUNCH_SCT1(W, NIB, false); } while (0)
     if (code_is_bins4) { if (wide) XM_LAUNCH_SCT2(true, true); else XM_LAUNCH_SCT2(false, true); }
