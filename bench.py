@@ -1000,7 +1000,8 @@ def main():
                 import bench_e2e
                 e2e["host_ceilings"] = bench_e2e.host_ceilings("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
                 e2e["host_ceilings"]["what"] = ("the file path's own rooflines on this box: memory copy (one core / all granted threads), "
-                                                "one write(2) stream into tmpfs, posix_fallocate alone, the writer gathering lines into a "
+                                                "one write(2) stream into tmpfs, posix_fallocate alone, pread(2) of a tmpfs file into page-locked memory by thread "
+                                                "count (what feeds the link in e2e.sam_text*.strip.upload_GBps), the writer gathering lines into a "
                                                 "mapped tmpfs file and into memory, the stripper's GB/s of SAM text against its thread count")
             except Exception as e:                               # noqa: BLE001
                 e2e["host_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -108,6 +108,28 @@ def host_ceilings(workdir="/dev/shm", mb=512, parse_mb=64):
                 os.posix_fallocate(fh.fileno(), 0, src.nbytes)
         out["tmpfs_one_write_stream_GBps"] = src.nbytes / best(one_stream) / 1e9
         out["tmpfs_fallocate_GBps"] = src.nbytes / best(allocate) / 1e9          # the kernel allocating (and zeroing) the pages, one thread
+        # what feeds the PCIe link in the SAM text path: pread(2) of a tmpfs file by k threads (xmh_pread, as the stage loop
+        # calls it) into page-locked memory when a GPU is here (else ordinary memory) -- compare e2e.pcie_ceiling.h2d_pinned_GBps
+        one_stream()
+        target, kind = dst, "ordinary memory"
+        try:
+            import torch
+            if torch.cuda.is_available():
+                pinned = torch.empty(src.nbytes, dtype=torch.uint8).pin_memory()
+                target, kind = pinned.numpy(), "page-locked memory"
+        except Exception:                                            # noqa: BLE001 -- the ordinary buffer then
+            pass
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            rates = {}
+            for k in sorted(set(t for t in (1, 4, 8, 16, 32, n_thr) if t <= 2 * max(n_thr, 1))):
+                reader = _host.Parser(k)
+                rates[str(k)] = round(src.nbytes / best(lambda: reader.pread(fd, 0, target.ctypes.data, src.nbytes)) / 1e9, 2)
+                reader.close()
+            out["tmpfs_pread_GBps_by_threads"] = rates
+            out["tmpfs_pread_into"] = kind
+        finally:
+            os.close(fd)
     finally:
         if os.path.exists(path):
             os.unlink(path)
