@@ -974,15 +974,15 @@ def main():
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import bench_bam
                 wd = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-                r = bench_bam.run(copies=16000, workdir=wd)
+                r = bench_bam.run(copies=48000, workdir=wd)
                 e2e["bam"] = {"read_pairs_per_s": r["value"], "pairs": r["units"], "bam_GBps": r["bam_GBps"], "seconds": round(r["seconds"], 4),
                               "threads": r["threads"], "phases": r["phases"],
-                              "what": "two BAM files (the reference's fixtures tiled 16 000 times, record-aligned BGZF blocks as samtools writes "
+                              "what": "two BAM files (the reference's fixtures tiled 48 000 times, record-aligned BGZF blocks as samtools writes "
                                       "them) -> BGZF blocks inflated, records found and stripped ON THE GPU (xm_bamdev), columns stay in HBM -> "
                                       "fused pass -> the host prints the records' SAM text -> six SAM outputs on /dev/null"}
                 os.environ["XENOMAPPER_GPU_BAM"] = "0"
                 try:
-                    r0 = bench_bam.run(copies=16000, workdir=wd)
+                    r0 = bench_bam.run(copies=48000, workdir=wd)
                     e2e["bam_host_decoder"] = {"read_pairs_per_s": r0["value"], "seconds": round(r0["seconds"], 4), "phases": r0["phases"],
                                                "what": "the same input through the host decoder (XENOMAPPER_GPU_BAM=0: inflate and printing on CPU threads)"}
                 finally:

@@ -102,7 +102,8 @@ typedef struct {
     int32_t  weird;                  /* 1: a record the text rules might read differently: use the host decoder for this window  */
     int32_t  reserved;
     uint64_t n_exceptions;           /* pairs whose flags carry XMS_LINE_EX_A / _EX_X on either record                           */
-    const uint8_t  *raw1, *raw2;     /* page-locked host copies of the inflated windows (valid until the slot runs again)       */
+    const uint8_t  *raw1, *raw2;     /* page-locked host copies of the inflated windows: complete once xm_bamdev_raw_wait(slot)
+                                        has returned (the copy runs beside the record kernels), valid until the slot runs again */
     const uint32_t *rec_off1, *rec_off2;   /* start of every record (its block_size word) in raw*: n_rec* entries              */
     const uint8_t  *flags1, *flags2;       /* per yielded pair: XMS_LINE_NORMAL | exception bits (XMS_LINE_EX_A / _EX_X)        */
     float ms_inflate, ms_kernels;    /* device time of the inflate + CRC launches, and of the record kernels (HIP events)       */
@@ -127,9 +128,12 @@ int xm_bamdev_destroy(xm_bamdev *b);                          /* while ctx is al
 /* room per slot and file for comp_bytes of compressed input, raw_bytes of inflated window, max_blocks, max_records */
 int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_bytes, uint64_t max_blocks, uint64_t max_records);
 uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file);
-/* inflate, find the records, strip, pair.  Blocking (the slot's own stream). */
+/* inflate, find the records, strip, pair.  Blocking (the slot's own stream) -- except for the copy of the inflated windows to
+ * raw1 / raw2, which may still be on its way when this returns. */
 int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
                   uint64_t max_records, xm_bamdev_block *out);
+/* blocks until the slot's last window has arrived in raw1 / raw2 (any thread; call it before reading them) */
+int xm_bamdev_raw_wait(xm_bamdev *b, int slot);
 /* the fused main loop on the slot's columns (as xm_strip_classify) */
 int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int32_t min_score_floor,
                        const uint8_t **code, const uint32_t **idx, uint64_t bin_offsets[8], uint64_t counts[64]);

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XMH_ABI_VERSION 4
+#define XMH_ABI_VERSION 5
 
 #define XMH_OK              0
 #define XMH_ERR_INVALID_ARG (-1)
@@ -136,6 +136,9 @@ int xmh_adopt_lines(xmh_parser *p, uint64_t n_records,
  * (xmh_parse / kernels / xmh_emit) applies unchanged.  `data` must stay valid while the reader is open. */
 typedef struct xmh_bam xmh_bam;
 int xmh_bam_open(const uint8_t *data, uint64_t len, int n_threads, xmh_bam **out);
+/* header, reference names, xmh_bam_records_start and xmh_bam_print only (the GPU BAM path walks the blocks itself): the file's
+ * blocks are not indexed, xmh_bam_read* on this handle return XMH_ERR_INVALID_ARG */
+int xmh_bam_open_header(const uint8_t *data, uint64_t len, int n_threads, xmh_bam **out);
 int xmh_bam_close(xmh_bam *b);
 /* The header as `samtools view -H` prints it (text owned by the reader, not NUL-terminated). */
 int xmh_bam_header(xmh_bam *b, const char **text, uint64_t *len);

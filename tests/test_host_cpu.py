@@ -383,3 +383,37 @@ def test_mapped_writer_never_extends_an_append_mode_file_ahead(tmp_path):
         sink.write("tail\n")
     pool.shutdown()
     assert path.read_bytes() == b"@HD\n" + b"x" * (2 << 20) + b"tail\n"
+
+
+def test_header_only_bam_handle_knows_the_header_and_refuses_to_read(tmp_path):
+    """xmh_bam_open_header (the GPU BAM path's handle: the file's blocks are not indexed): same header text and same start
+    of the records as the full handle -- also when the header spans more BGZF blocks than the first indexing step takes --
+    records printed from it equal the full reader's text, and reading through it is refused."""
+    import struct
+    import sys
+    import numpy as np
+    from xenomapper_amd import _host
+    sys.path.insert(0, os.path.join(H.REPO, "tools"))
+    import bench_bam
+    src = os.path.join(H.REPO, "tests", "golden", "ref_data", "paired_end_testdata_human.bam")
+    image = np.frombuffer(open(src, "rb").read(), dtype=np.uint8)
+    # a second image whose header text fills ~600 small blocks (the first indexing step takes 256)
+    import gzip
+    raw = gzip.decompress(image.tobytes())
+    l_text, = struct.unpack_from("<i", raw, 4)
+    filler = ("@CO\t" + "x" * 60 + "\n") * 3000
+    text = raw[8:8 + l_text].rstrip(b"\0") + filler.encode("ascii")
+    big = b"BAM\x01" + struct.pack("<i", len(text)) + text + raw[8 + l_text:]
+    big_image = np.frombuffer(bench_bam.bgzf_blocks(big, chunk=320) + bench_bam.BGZF_EOF, dtype=np.uint8)
+    for im in (image, big_image):
+        full, head = _host.BamReader(im, 2), _host.BamReader(im, 2, header_only=True)
+        try:
+            assert head.header() == full.header()
+            assert head.records_start() == full.records_start()
+            buf = np.empty(1 << 16, dtype=np.uint8)
+            with pytest.raises((ValueError, RuntimeError)):
+                head.read_into(buf, 0)
+            assert full.read_into(np.empty(1 << 22, dtype=np.uint8), 0) > 0
+        finally:
+            full.close()
+            head.close()

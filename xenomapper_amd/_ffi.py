@@ -155,6 +155,7 @@ def lib():
         "xm_bamdev_reserve": ([P, I, U64, U64, U64, U64], I),
         "xm_bamdev_staging": ([P, I, I], P),
         "xm_bamdev_run": ([P, I, P, I, I, I, U64, P], I),
+        "xm_bamdev_raw_wait": ([P, I], I),
         "xm_bamdev_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_bamdev_columns": ([P, I, U64, P, P, P, P, P], I),
         "xm_bamdev_last_error": ([P], ctypes.c_char_p),
@@ -180,7 +181,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
-            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_classify",
+            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_last_error")
 
 
@@ -976,8 +977,10 @@ class BamDev(object):
     def staging(self, slot, file):
         return _host_view(self._L.xm_bamdev_staging(self._h, slot, file), self._cap[slot][0], np.uint8)
 
-    def run(self, slot, inputs, score_mode, paired, keep_halo, max_records):
-        """inputs: two dicts {comp_len, blocks (BGZF_BLOCK array), crc (uint32 array), carry_slot, carry_off, carry_len, eof, skip}."""
+    def run(self, slot, inputs, score_mode, paired, keep_halo, max_records, wait_raw=True):
+        """inputs: two dicts {comp_len, blocks (BGZF_BLOCK array), crc (uint32 array), carry_slot, carry_off, carry_len, eof, skip}.
+        wait_raw=False: the inflated windows may still be on their way to the host when this returns -- call raw_wait(slot)
+        before reading them (the file path does, from the thread that prints the records)."""
         arr = (_BamDevInput * 2)()
         keep = []
         for f, x in enumerate(inputs):
@@ -991,7 +994,12 @@ class BamDev(object):
         rc = self._L.xm_bamdev_run(self._h, slot, ctypes.byref(arr), int(score_mode), int(bool(paired)), int(bool(keep_halo)),
                                    int(max_records), ctypes.byref(raw))
         self._check(rc, "xm_bamdev_run")
+        if wait_raw:
+            self.raw_wait(slot)
         return BamDevBlock(self, slot, raw)
+
+    def raw_wait(self, slot):
+        self._check(self._L.xm_bamdev_raw_wait(self._h, int(slot)), "xm_bamdev_raw_wait")
 
     def classify(self, slot, mode, n_records, min_score_floor):
         code, idx = ctypes.c_void_p(), ctypes.c_void_p()

@@ -15,7 +15,7 @@ EX_NONINT, EX_DUP, EX_SHORT, EX_BIGLEN = 1, 2, 3, 4
 ERR_NON_ASCII = -3
 
 EXPORTED = ("xmh_abi_version", "xmh_strerror", "xmh_default_threads", "xmh_parser_create", "xmh_parser_destroy", "xmh_parse", "xmh_emit",
-            "xmh_bam_open", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read", "xmh_bam_read_pre", "xmh_parse_pre",
+            "xmh_bam_open", "xmh_bam_open_header", "xmh_bam_close", "xmh_bam_header", "xmh_bam_read", "xmh_bam_read_pre", "xmh_parse_pre",
             "xmh_copy", "xmh_pread", "xmh_adopt_lines", "xmh_bam_records_start", "xmh_bam_print", "xmh_bam_walk")
 NEED_TEXT = 1
 # xmh_pre (include/xenomapper_host.h): what the BAM decoder knows about every line it prints
@@ -71,6 +71,8 @@ def lib():
         L.xmh_emit.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_uint64,
                                ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_bam_open.argtypes = [_P, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(_P)]
+        L.xmh_bam_open_header.argtypes = [_P, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(_P)]
+        L.xmh_bam_open_header.restype = ctypes.c_int
         L.xmh_bam_close.argtypes = [_P]
         L.xmh_bam_header.argtypes = [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]
         L.xmh_bam_read.argtypes = [_P, _P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
@@ -267,12 +269,13 @@ def bam_walk(raw_address, length, start, rec_off):
 class BamReader(object):
     """BAM file image -> SAM text, like `samtools view` (header via .header(), lines via .read_into())."""
 
-    def __init__(self, data, n_threads=0):
+    def __init__(self, data, n_threads=0, header_only=False):
+        """header_only: header(), records_start() and print_records() only (the GPU BAM path); the file is not indexed."""
         self._L = lib()
         self._data = np.ascontiguousarray(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         h = _P()
-        rc = self._L.xmh_bam_open(self._data.ctypes.data if self._data.shape[0] else None, self._data.shape[0],
-                                  int(n_threads), ctypes.byref(h))
+        opener = self._L.xmh_bam_open_header if header_only else self._L.xmh_bam_open
+        rc = opener(self._data.ctypes.data if self._data.shape[0] else None, self._data.shape[0], int(n_threads), ctypes.byref(h))
         if rc != 0:
             raise ValueError("xmh_bam_open: " + self._L.xmh_strerror(rc).decode())
         self._h = h

@@ -317,6 +317,12 @@ struct Slot {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_wait = nullptr;            // blocking-sync event: the waiting thread sleeps instead of spinning on a core the
                                              // writer's printing threads need (16 of 16 CPUs print while the next window inflates)
+    // the inflated window goes back to the host (the writer prints the records' text from it) on a stream of its own, behind
+    // the inflate launch only: the record kernels, the fused pass and the NEXT window's upload and inflate (other slot) run
+    // beside it.  ev_raw marks its end; whoever reads h_raw waits for it (xm_bamdev_raw_wait; a carried tail: the next run).
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_inflated = nullptr, ev_raw = nullptr;
+    bool raw_issued = false;                 // ev_raw has been recorded at least once (stays true: waiting for a past event costs nothing)
     bool have_columns = false;
 };
 
@@ -403,6 +409,9 @@ int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
         e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
         for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_wait, hipEventBlockingSync | hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_inflated, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_raw, hipEventBlockingSync | hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, 16 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_state, 16 * sizeof(uint32_t), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
@@ -432,6 +441,7 @@ int xm_bamdev_destroy(xm_bamdev *b)
             (void)hipStreamSynchronize(sl.stream);
             (void)xm_workspace_release(b->ctx, sl.stream);
         }
+        if (sl.copy_stream) (void)hipStreamSynchronize(sl.copy_stream);
         free_slot(sl);
         dfree(sl.d_state); hfree(sl.h_state); dfree(sl.d_off_counts); hfree(sl.h_off_counts);
         dfree(sl.d_work);
@@ -439,6 +449,9 @@ int xm_bamdev_destroy(xm_bamdev *b)
         for (int i = 0; i < 3; ++i)
             if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
         if (sl.ev_wait) (void)hipEventDestroy(sl.ev_wait);
+        if (sl.ev_inflated) (void)hipEventDestroy(sl.ev_inflated);
+        if (sl.ev_raw) (void)hipEventDestroy(sl.ev_raw);
+        if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     delete b;
@@ -453,6 +466,7 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
     XMB_HIP(b, hipSetDevice(b->device));
     Slot &sl = b->slot[slot];
     XMB_HIP(b, hipStreamSynchronize(sl.stream));
+    XMB_HIP(b, hipStreamSynchronize(sl.copy_stream));
     sl.have_columns = false;
     if (comp_bytes > sl.comp_cap) {
         sl.comp_cap = 0;
@@ -536,6 +550,8 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     uint64_t new_bytes[2] = {0, 0}, first_block[2] = {0, 0}, n_all = 0;
     if (in[0].n_blocks + in[1].n_blocks > 2 * sl.block_cap) return XM_ERR_INVALID_ARG;
     // ---- stage: carry, compressed bytes, block tables; inflate + CRC; the record chain --------------------------------
+    // this slot's previous window has left d_raw (its copy to the host ended long ago: the caller has printed from it)
+    if (sl.raw_issued) XMB_HIP(b, hipStreamWaitEvent(st, sl.ev_raw, 0));
     XMB_HIP(b, hipEventRecord(sl.ev[0], st));
     for (int f = 0; f < 2; ++f) {
         const xm_bamdev_input &x = in[f];
@@ -553,8 +569,10 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
             const PerFile &src = b->slot[x.carry_slot].pf[f];
             if (x.carry_off + x.carry_len > b->slot[x.carry_slot].raw_cap) return XM_ERR_INVALID_ARG;
             if (x.carry_slot == slot && x.carry_off < x.carry_len) return XM_ERR_INVALID_ARG;          // would overlap itself
-            // (the other slot's stream finished its window before the caller could know what to carry)
+            // (the other slot's stream finished its window before the caller could know what to carry; its copy of the window
+            // to the host may still be on its way)
             XMB_HIP(b, hipMemcpyAsync(q.d_raw, src.d_raw + x.carry_off, (size_t)x.carry_len, hipMemcpyDeviceToDevice, st));
+            if (b->slot[x.carry_slot].raw_issued) XMB_HIP(b, hipEventSynchronize(b->slot[x.carry_slot].ev_raw));
             memmove(q.h_raw, src.h_raw + x.carry_off, (size_t)x.carry_len);
         }
         q.raw_len = x.carry_len + new_bytes[f];
@@ -600,6 +618,15 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         XMB_HIP(b, hipMemcpyAsync(sl.h_crc, sl.d_crc, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
     }
     XMB_HIP(b, hipEventRecord(sl.ev[1], st));
+    // the inflated window goes back for the writer on the copy stream, behind the inflate launch (and the carry) only
+    XMB_HIP(b, hipEventRecord(sl.ev_inflated, st));
+    XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
+    for (int f = 0; f < 2; ++f)
+        if (new_bytes[f])
+            XMB_HIP(b, hipMemcpyAsync(sl.pf[f].h_raw + in[f].carry_len, sl.pf[f].d_raw + in[f].carry_len, (size_t)new_bytes[f],
+                                      hipMemcpyDeviceToHost, sl.copy_stream));
+    XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
+    sl.raw_issued = true;
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
         const uint32_t n_seg = q.h_summary[8];
@@ -611,8 +638,6 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
                                                                      (uint32_t)std::min<uint64_t>(sl.record_cap, 0xFFFFFFFFull));
         }
         XMB_HIP(b, hipMemcpyAsync(q.h_summary, q.d_summary, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        // the inflated window goes back for the writer while the record kernels run
-        if (new_bytes[f]) XMB_HIP(b, hipMemcpyAsync(q.h_raw + in[f].carry_len, q.d_raw + in[f].carry_len, (size_t)new_bytes[f], hipMemcpyDeviceToHost, st));
     }
     t_issued = since();
     XMB_HIP(b, hipEventRecord(sl.ev_wait, st));
@@ -710,6 +735,16 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         (f == 0 ? out->consumed1 : out->consumed2) = c;
     }
     sl.have_columns = true;
+    return XM_OK;
+}
+
+int xm_bamdev_raw_wait(xm_bamdev *b, int slot)
+{
+    if (!b || slot < 0 || slot > 1) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (!sl.raw_issued) return XM_OK;
+    XMB_HIP(b, hipSetDevice(b->device));
+    XMB_HIP(b, hipEventSynchronize(sl.ev_raw));
     return XM_OK;
 }
 

@@ -153,6 +153,12 @@ XMI_HD void count_inc(uint32_t *p)
 #define XMI_STAGE(code) do { } while (0)
 #endif
 
+// XMI_STAT_*: token statistics of the host build (tools: how many matches reach behind the output ring); nothing on the device
+#ifndef XMI_STAT_LITERAL
+#define XMI_STAT_LITERAL() do { } while (0)
+#define XMI_STAT_MATCH(len, dist, behind_ring) do { } while (0)
+#endif
+
 template <int GS>
 struct Chain {
     uint32_t *trace = nullptr;
@@ -255,7 +261,18 @@ struct Chain {
     }
     XMI_HD uint32_t byte_at(uint32_t pos) const       // a byte produced earlier
     {
+#if defined(XMI_GLOBAL_WINDOW) && XMI_DEVICE
+        uint32_t b;
+        if (pos >= gsafe) {
+            b = m->oring[pos & (ORING - 1u)];
+        } else {
+            b = vbase[pos];
+            asm volatile("" : "+v"(b));        // keeps the two loads apart (merged, they become one flat_load)
+        }
+        return b;
+#else
         return pos >= gsafe ? (uint32_t)m->oring[pos & (ORING - 1u)] : (uint32_t)vbase[pos];
+#endif
     }
 
     // ---- Huffman tables ----
@@ -429,6 +446,7 @@ struct Chain {
             if (s < 256u) {
                 if (op >= oend) { err = ERR_OUT; return; }
                 if (gl == 0u) put_byte(op, s);
+                XMI_STAT_LITERAL();
                 ++op;
                 maybe_flush();
                 continue;
@@ -449,6 +467,7 @@ struct Chain {
             if (dist > op - ostart) { err = ERR_DIST; return; }
             if (len > oend - op) { err = ERR_OUT; return; }
             chain_sync();                                                   // literals written by lane 0 are in the ring
+            XMI_STAT_MATCH(len, dist, op - dist < gsafe);
             copy_match(len, dist);
             maybe_flush();
         }
@@ -462,9 +481,15 @@ struct Chain {
         const uint64_t cb = coff & ~(uint64_t)(ICHUNK - 1u);
         cbase = comp + cb;
         cend = (uint32_t)(coff - cb) + clen;
-        const uintptr_t oaddr = reinterpret_cast<uintptr_t>(out + ooff);
-        vbase = reinterpret_cast<uint8_t *>(oaddr & ~(uintptr_t)15);
-        ostart = (uint32_t)(oaddr & 15u);
+        // The integer round trip makes the window accesses flat_* operations on the device (the address space is lost).
+        // XMI_GLOBAL_WINDOW (A/B): pointer arithmetic instead, global_load / global_store -- measured 3 % SLOWER on one box
+        // (38.9 against 40.0 ms per GB, profiles/r05_ab_inflate_variants.txt), so the flat form stays.
+        ostart = (uint32_t)(reinterpret_cast<uintptr_t>(out + ooff) & 15u);
+#ifdef XMI_GLOBAL_WINDOW
+        vbase = out + ooff - ostart;
+#else
+        vbase = reinterpret_cast<uint8_t *>(reinterpret_cast<uintptr_t>(out + ooff) & ~(uintptr_t)15);
+#endif
         op = flushed = gsafe = ostart;
         oend = ostart + isize;
         XMI_STAGE(1);

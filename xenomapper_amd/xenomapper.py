@@ -1107,7 +1107,7 @@ class _GpuBamFile(object):
         from . import _host
         self.path = path
         self.data = np.memmap(path, dtype=np.uint8, mode="r")
-        self.reader = _host.BamReader(self.data, n_threads)           # header, reference names, the printer's threads
+        self.reader = _host.BamReader(self.data, n_threads, header_only=True)   # header, reference names, the printer's threads
         at = self.reader.records_start()
         # the block the first record lies in: members are walked from the start until their inflated sizes pass it
         blocks, _crc, nxt, _total = _ffi.bgzf_index(self.data, 0, at + 1)
@@ -1272,7 +1272,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             inputs = [src.stage(bamdev, which, f, parsers[which], int(want * scale[f]) + src.carry[2], max_blocks)
                       for f, src in enumerate(sources)]
         with prof("strip"):
-            blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
+            blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2), wait_raw=False)
             prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_inflate
             prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
         if blk.bad_block:
@@ -1281,6 +1281,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         if blk.unaligned or blk.weird:
             with prof("parse"):
                 # the whole windows as text, then the text rules (exactly the host path's semantics for this window)
+                bamdev.raw_wait(which)                               # the inflated bytes must have arrived
                 texts, tables = [], []
                 for f in (0, 1):
                     # the record chain followed on the host (the inflated bytes are here already): every complete record
@@ -1309,6 +1310,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             # the records' SAM text, printed by the host threads when the block is settled -- in the main thread, while the
             # helper thread has the GPU inflate and strip the NEXT window (printing here instead would put the two in a row)
             with prof("parse"):
+                bamdev.raw_wait(which)                               # the copy of the window ran beside the kernels and the next window's inflate
                 loffs, llens = [], []
                 # A unit's lines come from ONE file (primary bins: file 1, secondary bins: file 2, unresolved: both; :423-448),
                 # and a bin without a sink prints nothing: with the bins known already, only those records are printed
