@@ -38,22 +38,28 @@ constexpr uint64_t CARRY_SEG = 128;                         // records per segme
 constexpr uint32_t R_EX_A_SHIFT = 0, R_EX_X_SHIFT = 2;     // per-record flag byte of B4: ex_a (2 bits), ex_x (2 bits),
 constexpr uint32_t R_WEIRD = 0x10u, R_BAD = 0x20u;         // weird, malformed
 
-__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-__device__ __forceinline__ uint32_t ld32(const uint8_t *p)
-{
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
+// little-endian fields at any byte offset: ONE access each (gfx950 reads unaligned words and dwords; byte-wise assembly made four
+// loads of every size word of the record chain)
+struct __attribute__((packed, aligned(1))) U32Unaligned { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U16Unaligned { uint16_t v; };
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return reinterpret_cast<const U16Unaligned *>(p)->v; }
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return reinterpret_cast<const U32Unaligned *>(p)->v; }
 
 // ---- B1 / B3: the record chain, one lane per segment --------------------------------------------------------------
 // seg_start[n_seg + 1]: first byte of every segment, seg_start[n_seg] = n_raw.  A record belongs to the segment its
 // block_size word begins in; a record that does not end inside the window ends the walk (it is the next window's).
+// Small workgroups, so that the few thousand lanes of a window -- one per block -- spread over all CUs.  What the walk costs is the
+// first touch of the freshly inflated window: 3.5 ms per file and window for whichever kernel reads it first, this one or --
+// when the inflating chains follow the record chain of their own block as they finish it and a gather builds the table (built
+// and measured in round 5, profiles/r05_bam_kernel_stats.csv) -- the parse kernel behind it; the sum stayed the same.
+constexpr uint32_t WALK_T = 64;
 template <bool FILL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WALK_T)
 walk_kernel(const uint8_t *__restrict__ raw, uint32_t n_raw, const uint32_t *__restrict__ seg_start, uint32_t n_seg,
             uint32_t *__restrict__ cnt, uint32_t *__restrict__ exit_at, const uint32_t *__restrict__ base,
             uint32_t *__restrict__ rec_off, uint32_t rec_cap)
 {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t s = blockIdx.x * WALK_T + threadIdx.x;
     if (s >= n_seg) return;
     const uint32_t lo = seg_start[s], hi = seg_start[s + 1];
     uint32_t p = lo, n = 0;
@@ -632,9 +638,9 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         const uint32_t n_seg = q.h_summary[8];
         XMB_HIP(b, hipMemsetAsync(q.d_summary, 0, 8 * sizeof(uint32_t), st));
         if (n_seg) {
-            walk_kernel<false><<<(n_seg + 255u) / 256u, 256, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, q.d_cnt, q.d_exit, nullptr, nullptr, 0u);
+            walk_kernel<false><<<(n_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, q.d_cnt, q.d_exit, nullptr, nullptr, 0u);
             scan_kernel<<<1, 1024, 0, st>>>(q.d_cnt, q.d_exit, q.d_seg, n_seg, q.d_base, q.d_summary);
-            walk_kernel<true><<<(n_seg + 255u) / 256u, 256, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, nullptr, nullptr, q.d_base, q.d_rec_off,
+            walk_kernel<true><<<(n_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, nullptr, nullptr, q.d_base, q.d_rec_off,
                                                                      (uint32_t)std::min<uint64_t>(sl.record_cap, 0xFFFFFFFFull));
         }
         XMB_HIP(b, hipMemcpyAsync(q.h_summary, q.d_summary, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
