@@ -31,6 +31,14 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
         if "classify_cigp_kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
+dur = []
+for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        if "classify_cigp_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+if dur and "GRBM_GUI_ACTIVE" in m:
+    dm = sum(dur) / len(dur)
+    print("under --pmc (launches apart): K1p %.1f us, shader clock = GRBM_GUI_ACTIVE / 8 / duration = %.3f GHz" % (dm / 1e3, m["GRBM_GUI_ACTIVE"] / 8 / dm))
 print("K1p counters per launch: " + "  ".join("%s %.4g" % (k, m[k]) for k in sorted(m)))
 if "GRBM_GUI_ACTIVE" in m and "SQ_WAVE_CYCLES" in m:
     print("  GRBM_GUI_ACTIVE / 8 XCDs = %.0f cycles; wave quad-cycles per wave %.0f; waiting %.2f of wave time" % (
