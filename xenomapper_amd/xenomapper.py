@@ -1124,6 +1124,8 @@ class _GpuBamFile(object):
         self.seen = [0, 0]                                           # bytes and records consumed so far
         self.by_lines = None                                         # record table of a window parsed by the text rules
         self.pending = None
+        self.ahead = None                                            # (staging address, file offset, bytes, the slot's capacities) read ahead for the next window
+        self.last_comp = 0                                           # compressed bytes of the last window staged
 
     def _member_header(self, blocks, j):
         """Bytes between a member's first byte and its DEFLATE data: cdata_off of block j minus the end of block j - 1."""
@@ -1151,10 +1153,38 @@ class _GpuBamFile(object):
                 comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1]) - c0
                 blocks = blocks.copy()
                 blocks["cdata_off"] -= np.uint64(c0)
-                parser.pread(self.fd, c0, dev._L.xm_bamdev_staging(dev._h, slot, file), comp_len)
+                dst = dev._L.xm_bamdev_staging(dev._h, slot, file)
+                have = 0
+                # read while the GPU had the window in front (read_ahead) -- into THIS allocation of the staging buffer (a
+                # buffer that has grown since may sit at the same address and holds nothing)
+                if self.ahead is not None and self.ahead[0] == dst and self.ahead[1] == c0 and self.ahead[3] == dev.capacity(slot):
+                    have = min(self.ahead[2], comp_len)
+                if have < comp_len:
+                    parser.pread(self.fd, c0 + have, dst + have, comp_len - have)
+                self.last_comp = comp_len
+        self.ahead = None
         self.pending = nxt
         return {"comp_len": comp_len, "blocks": blocks, "crc": crc, "carry_slot": carry_slot, "carry_off": carry_off,
                 "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": self.skip if len(blocks) else 0}
+
+    def read_ahead(self, dev, slot, file, reader):
+        """The compressed bytes of the NEXT window (from `pending`, where the window just staged ends) read into the other
+        slot's staging buffer -- by a thread of its own, while the GPU has the window just staged: stage() of the next window
+        then finds them in place.  The amount is a guess (what the last window took); stage() reads whatever is missing."""
+        self.ahead = None
+        at = self.pending
+        if at is None or at + 18 > self.data.shape[0] or not self.last_comp:
+            return
+        c0 = at + 12 + (int(self.data[at + 10]) | int(self.data[at + 11]) << 8)      # behind the member header (XLEN)
+        room = dev.capacity(slot)[0]
+        n = min(self.data.shape[0] - c0, self.last_comp + self.last_comp // 16 + (1 << 20), room)
+        if n <= 0:
+            return
+        dst = dev._L.xm_bamdev_staging(dev._h, slot, file)
+        if not dst:
+            return
+        reader.pread(self.fd, c0, dst, n)
+        self.ahead = (dst, c0, n, dev.capacity(slot))
 
     def ran(self, slot, raw_len, rec_off=None, stop=None, consumed=0, records=0):
         """What advance() needs to know about the window that was just run (and how many records its consumed bytes held)."""
@@ -1235,6 +1265,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
 
     bam_text = _BAM_TEXT_BUFFERS                                     # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
     bam_windows = [0]                                                # windows run so far
+    # the GPU BAM path reads the next window's compressed blocks while the GPU works on the current one (_GpuBamFile.read_ahead):
+    # a reader of its own (8 threads: pread into page-locked memory peaks there, e2e.host_ceilings) and one thread that drives it
+    bam_reader = _host.Parser(8) if bamdev is not None and os.environ.get("XENOMAPPER_BAM_READ_AHEAD", "1") != "0" else None
+    bam_ahead_pool = ThreadPoolExecutor(max_workers=1) if bam_reader is not None else None
+    bam_ahead = [None]                                               # the read-ahead in flight
 
     def print_records(which, f, raw_addr, rec_off_addr, n, sparse=False, wanted=None):
         """SAM text of records [0, n) of a window decoded on the GPU -> (text array, line_off, line_len)."""
@@ -1260,6 +1295,13 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             want = want >> (2 - bam_windows[0])
         bam_windows[0] += 1
         with prof("window"):
+            if bam_ahead[0] is not None:                             # the read-ahead into this slot's staging buffers has ended
+                try:
+                    bam_ahead[0].result()
+                except OSError:                                      # stage() reads what is missing
+                    for src in sources:
+                        src.ahead = None
+                bam_ahead[0] = None
             carried = max(src.carry[2] for src in sources)
             raw_cap = want + carried + (1 << 20)
             comp_cap = raw_cap                                   # DEFLATE never expands a block by more than a few bytes
@@ -1271,12 +1313,19 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             scale = [p / max(per_rec) for p in per_rec] if min(per_rec) > 0 else [1.0, 1.0]
             inputs = [src.stage(bamdev, which, f, parsers[which], int(want * scale[f]) + src.carry[2], max_blocks)
                       for f, src in enumerate(sources)]
+        if bam_reader is not None and not all(x["eof"] for x in inputs):
+            def ahead_job(slot=which ^ 1):
+                for f, src in enumerate(sources):
+                    src.read_ahead(bamdev, slot, f, bam_reader)
+            bam_ahead[0] = bam_ahead_pool.submit(ahead_job)
         with prof("strip"):
             blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2), wait_raw=False)
             prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_inflate
             prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
         if blk.bad_block:
-            raise ValueError("corrupt BAM input: a BGZF block or an alignment record is damaged (%s, %s)" % (path1, path2))
+            what = {1: "a BGZF block fails its decoder or its CRC-32", 2: "a file ends inside an alignment record",
+                    3: "a malformed alignment record"}.get(blk.bad_block, "damaged")
+            raise ValueError("corrupt BAM input: %s (%s, %s)" % (what, path1, path2))
         eofs = [bool(x["eof"]) for x in inputs]
         if blk.unaligned or blk.weird:
             with prof("parse"):
@@ -1500,6 +1549,9 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         trouble = trouble or exc
             ahead_pool.shutdown(wait=True)
             pool.shutdown(wait=True)
+            if bam_ahead_pool is not None:
+                bam_ahead_pool.shutdown(wait=True)
+                bam_reader.close()
             for prs in parsers + ([reader_pool] if reader_pool is not None else []):
                 prs.close()
             for src in sources:
