@@ -13,15 +13,24 @@
 #include "../../include/xenomapper_bgzf.h"
 #include "xm_inflate_core.h"
 
-// Lanes per chain.  Measured on 16 802 blocks = 1.04 GB of inflated BAM (profiles/r05_inflate_first.txt): 64 lanes 22.8 GB/s,
-// 32 lanes 28.3, 16 lanes 26.2, 8 lanes 23.5 -- and the 8- and 4-lane builds WITHOUT the trace hooks did not come back at all
-// on a 4-block file (the same source with -DXMI_TRACE did, byte-exact; every loop has an exit the data cannot disable, so this
-// is not a decoding loop -- unresolved).  32 it is.
+// Lanes per chain and waves per SIMD.  A chain's speed is its own serial instruction stream, so what counts is how many chains a CU
+// holds and how little they get in each other's way.  5.1 KB of LDS per chain allows 31 of them per CU, whatever their width.
+// Measured on 16 802 blocks = 1.04 GB of inflated BAM (profiles/r05_inflate_first.txt, r05_ab_inflate_variants.txt):
+//   as the compiler allocates (97 VGPRs = 5 waves per SIMD):  64 lanes 22.8-25.9 GB/s (20 chains per CU, one per wave),
+//       32 lanes 28.1-28.3 (31 chains, two per wave: they diverge, and a wave runs its chains' paths one after the other),
+//       16 lanes 26.2, 8 lanes 23.5;
+//   asked for 8 waves per SIMD (64 VGPRs, 16 dwords spilled outside the token loop):  64 lanes 31.0 GB/s -- 31 chains per CU again,
+//       each alone in its wave.  That is the shipped shape.
+// The 8- and 4-lane builds WITHOUT the trace hooks did not come back at all on a 4-block file (the same source with -DXMI_TRACE did,
+// byte-exact; every loop has an exit the data cannot disable, so this is not a decoding loop -- unresolved).
 #ifndef XM_INFLATE_GS
-#define XM_INFLATE_GS 32
+#define XM_INFLATE_GS 64
 #endif
 #ifndef XM_INFLATE_WG_PER_CU
-#define XM_INFLATE_WG_PER_CU 16     // upper bound on resident waves per CU (the LDS of the chains usually binds first)
+#define XM_INFLATE_WG_PER_CU 32     // upper bound on resident waves per CU (the LDS of the chains binds at 31-32)
+#endif
+#ifndef XM_INFLATE_WAVES_PER_EU
+#define XM_INFLATE_WAVES_PER_EU 8   // 0: leave the register budget to the compiler
 #endif
 
 #ifdef XMI_TRACE
@@ -34,8 +43,15 @@ extern "C" int xm_bgzf_set_trace(uint32_t *host_visible_words)
 
 namespace {
 
+// XM_INFLATE_WAVES_PER_EU: ask the compiler for that many waves per SIMD (8 = at most 64 VGPRs; what does not fit is spilled)
+#if XM_INFLATE_WAVES_PER_EU > 0
+#define XM_INFLATE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(XM_INFLATE_WAVES_PER_EU, XM_INFLATE_WAVES_PER_EU)))
+#else
+#define XM_INFLATE_OCCUPANCY
+#endif
+
 template <int GS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) XM_INFLATE_OCCUPANCY
 inflate_kernel(const uint8_t *__restrict__ comp, const xm_bgzf_block *__restrict__ blocks, uint32_t n_blocks,
                uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t *__restrict__ work)
 {
