@@ -439,8 +439,10 @@ struct Chain {
     }
     XMI_HD void huffman_block()
     {
+        // (no step budget in THIS loop, unlike the others: every pass drops at least one bit of the stream -- a code that matches
+        // nothing sets err -- and need32() sets err once the reading position is 12 bytes past the block's compressed bytes, so
+        // the loop ends after at most 8 x (compressed bytes + 16) passes whatever the data holds; the counter cost 4 % of the launch)
         while (!err) {
-            if (budget-- == 0u) { err = ERR_GUARD; return; }
             need32();
             const uint32_t s = decode(m->lit_root, LIT_ROOT, m->lit_sym, m->lit_meta);
             if (s < 256u) {
