@@ -232,6 +232,56 @@ def test_bam_decoder_agrees_with_the_spec_restatement(image, threads, cap):
     assert b"".join(parts).decode("latin-1") == "".join(l + "\n" for l in want_lines)
 
 
+@settings(max_examples=int(os.environ.get('XM_FUZZ_EXAMPLES', '200')), deadline=None, suppress_health_check=list(HealthCheck))
+@given(image=bam_image(), threads=st.sampled_from([1, 3, 8]), data=st.data())
+def test_record_printer_of_the_gpu_bam_path_prints_the_decoder_s_text(image, threads, data):
+    """xmh_bam_open_header + xmh_bam_walk + xmh_bam_print -- what the GPU BAM path leaves to the host: the record chain of an
+    inflated window and the SAM text of (some of) its records -- on the same random images: every record printed (dense and
+    sparse) is the line the oracle's restatement of the BAM layout prints, records no sink wants are skipped with an empty
+    table entry, a text buffer that is too small is reported with the size it takes and nothing is written behind it, and a
+    window cut anywhere yields exactly the complete records in front of the cut.  (CPU only: this file also runs under ASan.)"""
+    import gzip
+    from xenomapper_amd import _host
+    _want_header, want_lines = bam_oracle.bam_to_sam(image)
+    raw = np.frombuffer(gzip.decompress(image), dtype=np.uint8).copy() if image else np.zeros(0, np.uint8)
+    r = _host.BamReader(np.frombuffer(image, dtype=np.uint8), threads, header_only=True)
+    try:
+        start = r.records_start()
+        rec = np.empty(raw.shape[0] // 36 + 8, dtype=np.uint32)
+        n, stop = _host.bam_walk(raw.ctypes.data, raw.shape[0], start, rec)
+        assert n == len(want_lines) and stop == raw.shape[0]
+        # a window cut short: the complete records in front of the cut, and where the first incomplete one begins
+        cut = data.draw(st.integers(min_value=start, max_value=raw.shape[0]))
+        n_cut, stop_cut = _host.bam_walk(raw.ctypes.data, cut, start, rec.copy())
+        ends = [int(rec[k + 1]) if k + 1 < n else raw.shape[0] for k in range(n)]
+        assert n_cut == sum(1 for e in ends if e <= cut) and stop_cut == (int(rec[n_cut]) if n_cut < n else raw.shape[0])
+        want = [l.encode("latin-1") for l in want_lines]
+        loff, llen = np.empty(n + 1, dtype=np.uint32), np.empty(n + 1, dtype=np.uint32)
+        for sparse in (False, True):
+            mask = None
+            if data.draw(st.booleans()) and n:
+                mask = np.array(data.draw(st.lists(st.integers(0, 1), min_size=n, max_size=n)), dtype=np.uint8)
+            guard = 64
+            text = np.full(16, 0xEE, dtype=np.uint8)
+            got = r.print_records(raw.ctypes.data, rec.ctypes.data, n, text[:text.shape[0] - guard if text.shape[0] > guard else 0],
+                                  loff, llen, sparse, mask)
+            if n and (mask is None or mask.any()):
+                assert got < 0                                             # too small: the size it takes, nothing written
+                assert (text == 0xEE).all()
+                text = np.full(-got + guard, 0xEE, dtype=np.uint8)
+                got = r.print_records(raw.ctypes.data, rec.ctypes.data, n, text[:-guard], loff, llen, sparse, mask)
+            assert got >= 0 and (text[text.shape[0] - guard:] == 0xEE).all()
+            for k in range(n):
+                if mask is not None and not mask[k]:
+                    assert int(llen[k]) == 0
+                    continue
+                line = bytes(text[int(loff[k]):int(loff[k]) + int(llen[k])])
+                assert line == want[k], (k, sparse)
+                assert text[int(loff[k]) + int(llen[k])] == 0x0A
+    finally:
+        r.close()
+
+
 # ---- BAM line descriptions (xmh_bam_read_pre / xmh_parse_pre) against the text rules ------------------------------------
 
 _SCORE_TAGS = st.sampled_from(["AS", "XS", "ZS", "NM", "AS", "XS", "YS", "XA", "SA", "MN", "NH"])
