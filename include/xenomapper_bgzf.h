@@ -121,6 +121,7 @@ typedef struct {
     int32_t  eof;                    /* no block of the file is left behind these                                                */
     uint64_t skip;                   /* the first `skip` inflated bytes of the new blocks are not alignment records (the BAM
                                         header: magic, text, reference list); less than the first block's ISIZE                   */
+    uint64_t uploaded;               /* the first `uploaded` of the comp_len staged bytes went up with xm_bamdev_upload already   */
 } xm_bamdev_input;
 
 int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out);
@@ -128,6 +129,10 @@ int xm_bamdev_destroy(xm_bamdev *b);                          /* while ctx is al
 /* room per slot and file for comp_bytes of compressed input, raw_bytes of inflated window, max_blocks, max_records */
 int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_bytes, uint64_t max_blocks, uint64_t max_records);
 uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file);
+/* Send the first `bytes` of a file's staging buffer to the device now, on a stream of the slot's own -- from any thread, while
+ * the slot is idle (its last xm_bamdev_run has returned, the next has not begun): the next run, told so in `uploaded`, waits for
+ * the copy instead of making it.  A later xm_bamdev_reserve that grows the buffers forgets what was sent. */
+int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes);
 /* inflate, find the records, strip, pair.  Blocking (the slot's own stream) -- except for the copy of the inflated windows to
  * raw1 / raw2, which may still be on its way when this returns. */
 int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,

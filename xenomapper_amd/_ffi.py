@@ -156,6 +156,7 @@ def lib():
         "xm_bamdev_staging": ([P, I, I], P),
         "xm_bamdev_run": ([P, I, P, I, I, I, U64, P], I),
         "xm_bamdev_raw_wait": ([P, I], I),
+        "xm_bamdev_upload": ([P, I, I, U64], I),
         "xm_bamdev_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_bamdev_columns": ([P, I, U64, P, P, P, P, P], I),
         "xm_bamdev_last_error": ([P], ctypes.c_char_p),
@@ -181,7 +182,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
-            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_classify",
+            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_last_error")
 
 
@@ -871,7 +872,7 @@ class Stripper(object):
 class _BamDevInput(ctypes.Structure):
     _fields_ = [("comp_len", ctypes.c_uint64), ("blocks", ctypes.c_void_p), ("crc", ctypes.c_void_p), ("n_blocks", ctypes.c_uint64),
                 ("carry_slot", ctypes.c_int32), ("carry_off", ctypes.c_uint64), ("carry_len", ctypes.c_uint64),
-                ("eof", ctypes.c_int32), ("skip", ctypes.c_uint64)]
+                ("eof", ctypes.c_int32), ("skip", ctypes.c_uint64), ("uploaded", ctypes.c_uint64)]
 
 
 class _BamDevBlock(ctypes.Structure):
@@ -989,7 +990,8 @@ class BamDev(object):
             keep += [blocks, crc]
             arr[f] = _BamDevInput(int(x["comp_len"]), blocks.ctypes.data if blocks.shape[0] else None,
                                   crc.ctypes.data if crc.shape[0] else None, blocks.shape[0], int(x.get("carry_slot", 0)),
-                                  int(x.get("carry_off", 0)), int(x.get("carry_len", 0)), int(bool(x["eof"])), int(x.get("skip", 0)))
+                                  int(x.get("carry_off", 0)), int(x.get("carry_len", 0)), int(bool(x["eof"])), int(x.get("skip", 0)),
+                                  int(x.get("uploaded", 0)))
         raw = _BamDevBlock()
         rc = self._L.xm_bamdev_run(self._h, slot, ctypes.byref(arr), int(score_mode), int(bool(paired)), int(bool(keep_halo)),
                                    int(max_records), ctypes.byref(raw))
@@ -997,6 +999,10 @@ class BamDev(object):
         if wait_raw:
             self.raw_wait(slot)
         return BamDevBlock(self, slot, raw)
+
+    def upload(self, slot, file, nbytes):
+        """The first nbytes of the slot's staging buffer go to the device now (xm_bamdev_upload); the next run is told `uploaded`."""
+        self._check(self._L.xm_bamdev_upload(self._h, int(slot), int(file), int(nbytes)), "xm_bamdev_upload")
 
     def raw_wait(self, slot):
         self._check(self._L.xm_bamdev_raw_wait(self._h, int(slot)), "xm_bamdev_raw_wait")

@@ -328,6 +328,10 @@ struct Slot {
     // beside it.  ev_raw marks its end; whoever reads h_raw waits for it (xm_bamdev_raw_wait; a carried tail: the next run).
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_inflated = nullptr, ev_raw = nullptr;
+    // compressed bytes sent ahead (xm_bamdev_upload, from the thread that reads the next window while this slot is idle)
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
+    uint64_t up_len[2] = {0, 0};
     bool raw_issued = false;                 // ev_raw has been recorded at least once (stays true: waiting for a past event costs nothing)
     bool have_columns = false;
 };
@@ -418,6 +422,8 @@ int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_inflated, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_raw, hipEventBlockingSync | hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.up_stream, hipStreamNonBlocking);
+        for (int f = 0; f < 2 && e == hipSuccess; ++f) e = hipEventCreateWithFlags(&sl.ev_up[f], hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, 16 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_state, 16 * sizeof(uint32_t), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
@@ -448,6 +454,7 @@ int xm_bamdev_destroy(xm_bamdev *b)
             (void)xm_workspace_release(b->ctx, sl.stream);
         }
         if (sl.copy_stream) (void)hipStreamSynchronize(sl.copy_stream);
+        if (sl.up_stream) (void)hipStreamSynchronize(sl.up_stream);
         free_slot(sl);
         dfree(sl.d_state); hfree(sl.h_state); dfree(sl.d_off_counts); hfree(sl.h_off_counts);
         dfree(sl.d_work);
@@ -458,6 +465,9 @@ int xm_bamdev_destroy(xm_bamdev *b)
         if (sl.ev_inflated) (void)hipEventDestroy(sl.ev_inflated);
         if (sl.ev_raw) (void)hipEventDestroy(sl.ev_raw);
         if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
+        for (int f = 0; f < 2; ++f)
+            if (sl.ev_up[f]) (void)hipEventDestroy(sl.ev_up[f]);
+        if (sl.up_stream) (void)hipStreamDestroy(sl.up_stream);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     delete b;
@@ -473,9 +483,11 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
     Slot &sl = b->slot[slot];
     XMB_HIP(b, hipStreamSynchronize(sl.stream));
     XMB_HIP(b, hipStreamSynchronize(sl.copy_stream));
+    XMB_HIP(b, hipStreamSynchronize(sl.up_stream));
     sl.have_columns = false;
     if (comp_bytes > sl.comp_cap) {
         sl.comp_cap = 0;
+        sl.up_len[0] = sl.up_len[1] = 0;                                     // what was sent ahead went to the old buffer
         sl.comp_stride = (comp_bytes + XMB_COMP_PAD + 255u) & ~(uint64_t)255;
         XMB_TRY(dalloc(b, sl.d_comp_all, (size_t)(2 * sl.comp_stride)));
         XMB_HIP(b, hipMemset(sl.d_comp_all, 0, (size_t)(2 * sl.comp_stride)));
@@ -611,7 +623,13 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         q.h_summary[8] = n_seg;
         first_block[f] = n_all;
         n_all += x.n_blocks;
-        if (x.comp_len) XMB_HIP(b, hipMemcpyAsync(q.d_comp, q.h_comp, (size_t)x.comp_len, hipMemcpyHostToDevice, st));
+        // the part of the staged bytes that went up ahead of this call (xm_bamdev_upload) is waited for, the rest is sent now
+        const uint64_t up = x.uploaded < x.comp_len ? x.uploaded : x.comp_len;
+        if (up > sl.up_len[f]) return XM_ERR_INVALID_ARG;
+        if (up) XMB_HIP(b, hipStreamWaitEvent(st, sl.ev_up[f], 0));
+        if (x.comp_len > up)
+            XMB_HIP(b, hipMemcpyAsync(q.d_comp + up, q.h_comp + up, (size_t)(x.comp_len - up), hipMemcpyHostToDevice, st));
+        sl.up_len[f] = 0;
         XMB_HIP(b, hipMemcpyAsync(q.d_seg, q.h_seg, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
     }
     t_staged = since();
@@ -741,6 +759,20 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         (f == 0 ? out->consumed1 : out->consumed2) = c;
     }
     sl.have_columns = true;
+    return XM_OK;
+}
+
+int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes)
+{
+    if (!b || slot < 0 || slot > 1 || file < 0 || file > 1) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (bytes > sl.comp_cap) return XM_ERR_INVALID_ARG;
+    sl.up_len[file] = 0;
+    if (bytes == 0) return XM_OK;
+    XMB_HIP(b, hipSetDevice(b->device));
+    XMB_HIP(b, hipMemcpyAsync(sl.pf[file].d_comp, sl.pf[file].h_comp, (size_t)bytes, hipMemcpyHostToDevice, sl.up_stream));
+    XMB_HIP(b, hipEventRecord(sl.ev_up[file], sl.up_stream));
+    sl.up_len[file] = bytes;
     return XM_OK;
 }
 

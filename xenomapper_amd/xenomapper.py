@@ -1145,7 +1145,7 @@ class _GpuBamFile(object):
         budget = max(want_raw - carry_len, 0)
         blocks = np.zeros(0, dtype=_ffi.BGZF_BLOCK)
         crc = np.zeros(0, dtype=np.uint32)
-        nxt, comp_len = self.cursor, 0
+        nxt, comp_len, uploaded = self.cursor, 0, 0
         if budget and not self.at_end:
             blocks, crc, nxt, _total = _ffi.bgzf_index(self.data, self.cursor, budget + self.skip, max_blocks)
             if len(blocks):
@@ -1162,10 +1162,12 @@ class _GpuBamFile(object):
                 if have < comp_len:
                     parser.pread(self.fd, c0 + have, dst + have, comp_len - have)
                 self.last_comp = comp_len
+                uploaded = have                                      # read_ahead sent what it read to the device as well
         self.ahead = None
         self.pending = nxt
         return {"comp_len": comp_len, "blocks": blocks, "crc": crc, "carry_slot": carry_slot, "carry_off": carry_off,
-                "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": self.skip if len(blocks) else 0}
+                "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": self.skip if len(blocks) else 0,
+                "uploaded": uploaded}
 
     def read_ahead(self, dev, slot, file, reader):
         """The compressed bytes of the NEXT window (from `pending`, where the window just staged ends) read into the other
@@ -1184,6 +1186,7 @@ class _GpuBamFile(object):
         if not dst:
             return
         reader.pread(self.fd, c0, dst, n)
+        dev.upload(slot, file, n)                                    # and on to the device, beside the GPU's work on the current window
         self.ahead = (dst, c0, n, dev.capacity(slot))
 
     def ran(self, slot, raw_len, rec_off=None, stop=None, consumed=0, records=0):
@@ -1298,7 +1301,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             if bam_ahead[0] is not None:                             # the read-ahead into this slot's staging buffers has ended
                 try:
                     bam_ahead[0].result()
-                except OSError:                                      # stage() reads what is missing
+                except Exception:                                    # noqa: BLE001 -- a failed read or copy ahead: stage() does it all
                     for src in sources:
                         src.ahead = None
                 bam_ahead[0] = None
