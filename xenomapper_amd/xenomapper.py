@@ -1362,7 +1362,9 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             # the records' SAM text, printed by the host threads when the block is settled -- in the main thread, while the
             # helper thread has the GPU inflate and strip the NEXT window (printing here instead would put the two in a row)
             with prof("parse"):
+                t_w = time.perf_counter()
                 bamdev.raw_wait(which)                               # the copy of the window ran beside the kernels and the next window's inflate
+                prof["bam_wait_raw"] = prof.get("bam_wait_raw", 0.0) + time.perf_counter() - t_w
                 loffs, llens = [], []
                 # A unit's lines come from ONE file (primary bins: file 1, secondary bins: file 2, unresolved: both; :423-448),
                 # and a bin without a sink prints nothing: with the bins known already, only those records are printed
@@ -1378,11 +1380,13 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                             wanted[f][seg] = 1
                             if paired:
                                 wanted[f][seg - 1] = 1               # a paired unit covers records idx - 1 and idx
+                t_p = time.perf_counter()
                 for f in (0, 1):
                     text, loff, llen, _got = print_records(which, f, blk.raw_addr[f], blk.rec_off_addr[f], blk.n, sparse=True,
                                                            wanted=wanted[f])
                     texts[f] = text
                     loffs.append(loff); llens.append(llen)
+                prof["bam_print"] = prof.get("bam_print", 0.0) + time.perf_counter() - t_p
                 blk.set_text(loffs, llens)
         blk.finish = finish
         return blk, texts, [0, 0], eofs
@@ -1560,7 +1564,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             for src in sources:
                 src.close()
         total = time.perf_counter() - t_all
-        prof["other"] = total - sum(v for k, v in prof.items() if not k.endswith("_ms"))   # negative: helper-thread phases overlap the rest
+        prof["other"] = total - sum(v for k, v in prof.items() if not k.endswith("_ms") and not k.startswith("bam_"))   # negative: helper-thread phases overlap the rest
         LAST_FILE_PROFILE.clear()
         LAST_FILE_PROFILE.update(prof, total=total)
         LAST_FILE_PROFILE.update(_EMIT_CLOCK)
