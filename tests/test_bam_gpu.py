@@ -195,3 +195,60 @@ def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, t
     want = run_path(paths, gpu=False, conservative=conservative, tag=tag)
     got = run_path(paths, gpu=True, conservative=conservative, tag=tag)
     assert got == want
+
+
+def test_bytes_sent_ahead_are_the_bytes_the_run_would_have_sent(ctx, tmp_path):
+    """xm_bamdev_upload: part of a window's compressed bytes goes to the device before xm_bamdev_run (what the file path's read-ahead
+    thread does while the GPU has the other slot); the run told so (`uploaded`) must give what a run that sends everything itself
+    gives -- also when only a prefix went ahead, when nothing did, and after the staging buffers have grown in between (what was sent
+    is forgotten then: claiming it is refused)."""
+    import bench_bam
+    from xenomapper_amd import _ffi
+    paths = []
+    for tag in ("human", "mouse"):
+        p = str(tmp_path / ("%s.bam" % tag))
+        bench_bam.tiled_bam(os.path.join(DATA, "paired_end_testdata_%s.bam" % tag), p, 12)
+        paths.append(p)
+    images = [open(p, "rb").read() for p in paths]
+    dev = _ffi.BamDev(ctx)
+    try:
+        base, readers = run_whole_files(dev, images, 0, True)
+        want = (base.n, base.n_rec, base.mismatch_at, [c[:base.n].copy() for c in base.cols], base.unit_bits.copy())
+        for r in readers:
+            r.close()
+        # the same windows again, their compressed bytes (or a prefix) sent ahead
+        def again(fractions, grow=False):
+            inputs = []
+            for f, image in enumerate(images):
+                data = np.frombuffer(image, dtype=np.uint8)
+                from xenomapper_amd import _host
+                reader = _host.BamReader(data, 1, header_only=True)
+                at = reader.records_start()
+                reader.close()
+                blocks, crc, _nxt, _total = _ffi.bgzf_index(data)
+                ends = blocks["out_off"] + blocks["isize"]
+                j = int(np.searchsorted(ends, at, side="right"))
+                blocks, crc = blocks[j:].copy(), crc[j:]
+                skip = at - int(blocks["out_off"][0])
+                blocks["out_off"] -= blocks["out_off"][0]
+                c0 = int(blocks["cdata_off"][0])
+                comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1]) - c0
+                blocks["cdata_off"] -= np.uint64(c0)
+                dev.staging(0, f)[:comp_len] = data[c0:c0 + comp_len]
+                sent = int(comp_len * fractions[f])
+                dev.upload(0, f, sent)
+                inputs.append({"comp_len": comp_len, "blocks": blocks, "crc": crc, "eof": True, "skip": skip, "uploaded": sent})
+            if grow:
+                cap = dev.capacity(0)
+                dev.reserve(0, cap[0] * 2, cap[1], cap[2], cap[3])
+            return dev.run(0, inputs, 0, True, False, 1 << 16)
+        for fractions in ((1.0, 1.0), (0.5, 0.25), (0.0, 1.0)):
+            blk = again(fractions)
+            assert not blk.bad_block and not blk.unaligned
+            assert (blk.n, blk.n_rec, blk.mismatch_at) == want[:3]
+            assert all(np.array_equal(blk.cols[c][:blk.n], want[3][c]) for c in range(4))
+            assert np.array_equal(blk.unit_bits, want[4])
+        with pytest.raises(ValueError):
+            again((1.0, 1.0), grow=True)                                   # the buffers grew: nothing is on the device any more
+    finally:
+        dev.close()
