@@ -61,6 +61,29 @@ int xm_bgzf_index(const uint8_t *data, uint64_t len, uint64_t start, uint64_t ma
 int xm_bgzf_inflate_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm_bgzf_block *blocks, uint64_t n_blocks,
                         uint8_t *out, uint32_t *status, uint32_t *work);
 
+/* The same launch for windows of BAM: after a chain has written block k it also follows the alignment records' block_size chain
+ * through that block and reads what the classifier needs out of every record, while the block is still near the CU that wrote
+ * it (`out + raw_base` = first byte of the file's window, positions count from there): slots[0 .. *count) = where the records
+ * that begin in [start, end) begin; name_off / name_len / a / x / flag [0 .. *count) = the record fields of xm_bamdev's stripper
+ * (x0 = 'X' or 'Z': which tag plays XS; x0 = 0: record starts only); *exit_at = where the chain leaves the block (== end when the
+ * next block begins with a record; 0xFFFFFFFF: the block failed, or it holds more than slot_cap records); a record that does not
+ * end in front of n_raw (the window's end) ends the walk, and so does a size word cut by the block's end.  Entries with
+ * end <= start are skipped.  walk[] (device memory) has n_blocks entries; all arrays are device memory of slot_cap entries. */
+typedef struct {
+    uint64_t raw_base;
+    uint32_t start, end;             /* first byte to look at (the block's first, or behind the BAM header), the block's end     */
+    uint32_t n_raw;
+    uint32_t slot_cap;
+    uint32_t *count, *exit_at;
+    uint32_t *slots;
+    uint32_t *name_off, *name_len;
+    int32_t  *a, *x;
+    uint8_t  *flag;
+    uint32_t x0, reserved;
+} xm_bgzf_walk;
+int xm_bgzf_inflate_walk_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm_bgzf_block *blocks, uint64_t n_blocks,
+                             uint8_t *out, uint32_t *status, uint32_t *work, const xm_bgzf_walk *walk);
+
 /* CRC-32 (the gzip polynomial) of every block's inflated bytes, for the comparison with the member trailers:
  * crc_out[b] for b < n_blocks, on the device.  One wave per block. */
 int xm_bgzf_crc32_dev(xm_ctx *ctx, void *stream, const uint8_t *out, const xm_bgzf_block *blocks, uint64_t n_blocks,

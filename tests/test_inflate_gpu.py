@@ -160,3 +160,95 @@ def test_empty_input_and_empty_blocks(ctx):
     assert len(blocks) == 3 and total == 0 and nxt == len(image)
     out, status, got_crc = gpu_inflate(ctx, image, blocks, 0)
     assert (status == 0).all() and (out == 0xEE).all() and (got_crc == 0).all()
+
+
+def test_records_found_and_read_by_the_inflating_chains(ctx, tmp_path):
+    """xm_bgzf_inflate_walk_dev: every chain of lanes also follows the alignment records' block_size chain through the block it
+    wrote and reads the stripper's fields out of its records.  Record-aligned blocks (as samtools writes them): counts, record
+    starts and exits equal a plain walk of the inflated bytes on the host, block by block, the exits land on the next block's
+    first byte, the first block is entered behind the BAM header, a window that ends inside a record stops in front of it; the
+    fields (name position and length, AS, XS) are those the text of the record holds; blocks that cut records (fixed-size
+    blocks) report exits that are NOT the next block's start."""
+    import torch
+    import bench_bam
+    from xenomapper_amd import _ffi, _host
+    dev = torch.device("cuda:0")
+    for aligned in (True, False):
+        path = str(tmp_path / ("walk_%d.bam" % aligned))
+        bench_bam.tiled_bam(os.path.join(DATA, "paired_end_testdata_human.bam"), path, 40, aligned=aligned)
+        image = np.fromfile(path, dtype=np.uint8)
+        blocks, _crc, _nxt, total = _ffi.bgzf_index(image)
+        want = np.frombuffer(gzip.decompress(image.tobytes()), dtype=np.uint8)
+        reader = _host.BamReader(image, 1, header_only=True)
+        first = reader.records_start()
+        n_raw = total - 1000                                               # the window ends inside a record
+        comp = torch.zeros(image.shape[0] + _ffi.BGZF_COMP_PAD, dtype=torch.uint8, device=dev)
+        comp[:image.shape[0]] = torch.from_numpy(image).to(dev)
+        d_blocks = torch.from_numpy(blocks.view(np.uint8)).to(dev)
+        out = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+        nb = len(blocks)
+        status = torch.full((nb,), -1, dtype=torch.int32, device=dev)
+        work = torch.zeros(1, dtype=torch.int32, device=dev)
+        cnt = torch.full((nb,), -7, dtype=torch.int32, device=dev)
+        ext = torch.full((nb,), -7, dtype=torch.int32, device=dev)
+        cap = 65536 // 36 + 2
+        slots, name_off, name_len, a, x = (torch.full((nb * cap,), -1, dtype=torch.int32, device=dev) for _ in range(5))
+        flag = torch.full((nb * cap,), 0xEE, dtype=torch.uint8, device=dev)
+        walk = np.zeros(nb, dtype=_ffi.BGZF_WALK)
+        starts = blocks["out_off"].astype(np.int64).copy()
+        ends = starts + blocks["isize"].astype(np.int64)
+        j0 = int(np.searchsorted(ends, first, side="right"))             # the block the first record lies in
+        for k in range(nb):
+            if k < j0 or blocks["isize"][k] == 0:
+                continue                                                   # header blocks, the empty end-of-file block: no walk
+            at = 4 * cap * k
+            walk[k] = (0, max(int(starts[k]), first) if k == j0 else int(starts[k]), int(ends[k]), n_raw, cap,
+                       cnt.data_ptr() + 4 * k, ext.data_ptr() + 4 * k, slots.data_ptr() + at, name_off.data_ptr() + at,
+                       name_len.data_ptr() + at, a.data_ptr() + at, x.data_ptr() + at, flag.data_ptr() + cap * k, ord("X"), 0)
+        d_walk = torch.from_numpy(walk.view(np.uint8)).to(dev)
+        ctx.bgzf_inflate_dev(comp, d_blocks, out, status, work, walk=d_walk)
+        torch.cuda.synchronize()
+        assert (status.cpu().numpy() == 0).all()
+        assert np.array_equal(out[:total].cpu().numpy(), want)
+        h_cnt, h_ext = cnt.cpu().numpy(), ext.cpu().numpy().view(np.uint32)
+        h = [t.cpu().numpy().reshape(nb, cap) for t in (slots, name_off, name_len, a, x, flag)]
+        # the text of all records, to read names and tags from (the printer is pinned to the oracle in test_host_fuzz)
+        rec_all = np.empty(total // 36 + 8, dtype=np.uint32)
+        n_all, _stop = _host.bam_walk(want.ctypes.data, total, first, rec_all)
+        text = np.empty(8 * total, dtype=np.uint8)
+        loff, llen = np.empty(n_all + 1, dtype=np.uint32), np.empty(n_all + 1, dtype=np.uint32)
+        reader.print_records(want.ctypes.data, rec_all.ctypes.data, n_all, text, loff, llen)
+        line_of = {int(rec_all[i]): bytes(text[int(loff[i]):int(loff[i]) + int(llen[i])]) for i in range(n_all)}
+        reader.close()
+        lands = 0
+        for k in range(nb):
+            if not walk["end"][k]:
+                assert h_cnt[k] == -7                                      # skipped entries are not written
+                continue
+            p, hi, recs = int(walk["start"][k]), int(walk["end"][k]), []
+            while p < hi:                                                  # the host restatement of the walk (xm_bamdev.hip walk_kernel)
+                if hi - p < 4:
+                    break
+                size = int(want[p]) | int(want[p + 1]) << 8 | int(want[p + 2]) << 16 | int(want[p + 3]) << 24
+                if size > n_raw - p - 4:
+                    break
+                recs.append(p)
+                p += 4 + size
+            assert int(h_cnt[k]) == len(recs) and int(h_ext[k]) == p, (aligned, k)
+            assert h[0][k, :len(recs)].view(np.uint32).tolist() == recs
+            if aligned:                                                    # whole records inside the block: the fields are the text's
+                for i, r in enumerate(recs[:5] + recs[-3:]):
+                    i = recs.index(r)
+                    fields = line_of[r].split(b"\t")
+                    assert int(h[1][k, i]) == r + 36 and int(h[2][k, i]) == len(fields[0])
+                    tags = {f[:2]: f for f in fields[11:]}
+                    for col, tag in ((3, b"AS"), (4, b"XS")):
+                        wantv = int(tags[tag].split(b":")[2]) if tag in tags else -2**31
+                        assert int(h[col][k, i]) == wantv, (k, i, tag)
+                    assert int(h[5][k, i]) == 0
+            lands += int(k + 1 < nb and p == int(walk["end"][k]))
+        walked = int((walk["end"] > 0).sum())
+        if aligned:
+            assert lands >= walked - 2                                     # all but the block the window ends in (and the last)
+        else:
+            assert lands < walked // 2

@@ -148,6 +148,7 @@ def lib():
         # include/xenomapper_bgzf.h
         "xm_bgzf_index": ([P, U64, U64, U64, P, P, U64, ctypes.POINTER(U64), ctypes.POINTER(U64), ctypes.POINTER(U64)], I),
         "xm_bgzf_inflate_dev": ([P, P, P, P, U64, P, P, P], I),
+        "xm_bgzf_inflate_walk_dev": ([P, P, P, P, U64, P, P, P, P], I),
         "xm_bgzf_crc32_dev": ([P, P, P, P, U64, P], I),
         "xm_bgzf_strerror": ([ctypes.c_uint32], ctypes.c_char_p),
         "xm_bamdev_create": ([P, I, ctypes.POINTER(P)], I),
@@ -181,7 +182,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
-            "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
+            "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
             "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_last_error")
 
@@ -600,15 +601,20 @@ class Context(object):
             rc = self._L.xm_classify_runs_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), *outs)
         self._check(rc, "xm_classify_runs_dev")
 
-    def bgzf_inflate_dev(self, comp, blocks, out, status, work, stream=None):
+    def bgzf_inflate_dev(self, comp, blocks, out, status, work, stream=None, walk=None):
         """BGZF blocks inflated on the GPU (xm_bgzf_inflate_dev): comp = uint8 device tensor of the compressed image (+ BGZF_COMP_PAD
         bytes behind the last block), blocks = device tensor holding a BGZF_BLOCK array (as uint8 / int64 bytes), out = uint8
-        device tensor, status = int32 tensor with one entry per block, work = int32 tensor with one entry.  Asynchronous."""
+        device tensor, status = int32 tensor with one entry per block, work = int32 tensor with one entry.  walk: device tensor
+        holding a BGZF_WALK array, one entry per block (xm_bgzf_inflate_walk_dev: the records of every block found and read by
+        the chain that inflated it).  Asynchronous."""
         n = blocks.numel() * blocks.element_size() // 24
-        rc = self._L.xm_bgzf_inflate_dev(self._h, self._stream_handle(stream), ctypes.c_void_p(comp.data_ptr()),
-                                         ctypes.c_void_p(blocks.data_ptr()), n, ctypes.c_void_p(out.data_ptr()),
-                                         ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(work.data_ptr()))
-        self._check(rc, "xm_bgzf_inflate_dev")
+        if walk is not None:
+            assert walk.numel() * walk.element_size() == n * BGZF_WALK.itemsize
+        rc = self._L.xm_bgzf_inflate_walk_dev(self._h, self._stream_handle(stream), ctypes.c_void_p(comp.data_ptr()),
+                                              ctypes.c_void_p(blocks.data_ptr()), n, ctypes.c_void_p(out.data_ptr()),
+                                              ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(work.data_ptr()),
+                                              ctypes.c_void_p(walk.data_ptr()) if walk is not None else None)
+        self._check(rc, "xm_bgzf_inflate_walk_dev")
 
     def bgzf_crc32_dev(self, out, blocks, crc_out, stream=None):
         n = blocks.numel() * blocks.element_size() // 24
@@ -673,6 +679,10 @@ class Context(object):
 # ---- include/xenomapper_bgzf.h: BGZF blocks inflated on the GPU -----------------------------------------------------
 BGZF_BLOCK = np.dtype([("cdata_off", np.uint64), ("out_off", np.uint64), ("cdata_len", np.uint32), ("isize", np.uint32)])
 assert BGZF_BLOCK.itemsize == 24
+BGZF_WALK = np.dtype([("raw_base", np.uint64), ("start", np.uint32), ("end", np.uint32), ("n_raw", np.uint32), ("slot_cap", np.uint32),
+                      ("count", np.uint64), ("exit_at", np.uint64), ("slots", np.uint64), ("name_off", np.uint64), ("name_len", np.uint64),
+                      ("a", np.uint64), ("x", np.uint64), ("flag", np.uint64), ("x0", np.uint32), ("reserved", np.uint32)])
+assert BGZF_WALK.itemsize == 96                                     # xm_bgzf_walk (device addresses)
 BGZF_COMP_PAD = 1024
 
 

@@ -30,20 +30,14 @@
 #include <vector>
 
 #include "../../include/xenomapper_bgzf.h"
+#include "xm_bamrec.h"
 
 namespace {
 
-constexpr int32_t ABSENT = INT32_MIN;
 constexpr uint64_t CARRY_SEG = 128;                         // records per segment of a carried tail
-constexpr uint32_t R_EX_A_SHIFT = 0, R_EX_X_SHIFT = 2;     // per-record flag byte of B4: ex_a (2 bits), ex_x (2 bits),
-constexpr uint32_t R_WEIRD = 0x10u, R_BAD = 0x20u;         // weird, malformed
-
-// little-endian fields at any byte offset: ONE access each (gfx950 reads unaligned words and dwords; byte-wise assembly made four
-// loads of every size word of the record chain)
-struct __attribute__((packed, aligned(1))) U32Unaligned { uint32_t v; };
-struct __attribute__((packed, aligned(1))) U16Unaligned { uint16_t v; };
-__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return reinterpret_cast<const U16Unaligned *>(p)->v; }
-__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return reinterpret_cast<const U32Unaligned *>(p)->v; }
+using xmrec::ABSENT;
+using xmrec::R_EX_A_SHIFT; using xmrec::R_EX_X_SHIFT; using xmrec::R_WEIRD; using xmrec::R_BAD;
+using xmrec::ld16; using xmrec::ld32;
 
 // ---- B1 / B3: the record chain, one lane per segment --------------------------------------------------------------
 // seg_start[n_seg + 1]: first byte of every segment, seg_start[n_seg] = n_raw.  A record belongs to the segment its
@@ -73,6 +67,40 @@ walk_kernel(const uint8_t *__restrict__ raw, uint32_t n_raw, const uint32_t *__r
         p += 4u + size;                                                     // >= p + 4: the walk always advances
     }
     if (!FILL) { cnt[s] = n; exit_at[s] = p; }
+}
+
+// Where the records of the block that is segment s (counted among the BLOCK segments: k = s - carried pieces) are noted by the
+// inflate launch: a block of alignment records holds one per 36 bytes at most, so slot_of(start, k) = start / 36 + 2 k leaves every
+// block isize / 36 + 1 entries of its own.
+__host__ __device__ inline uint64_t slot_of(uint32_t start, uint32_t k) { return (uint64_t)start / 36u + 2ull * k; }
+
+struct SlotArrays {
+    const uint32_t *off, *name_off, *name_len;
+    const int32_t *a, *x;
+    const uint8_t *flag;
+};
+
+// B3 + B4 for the blocks: the record table and the per-record fields from the slots (one wave per segment), behind the scan's bases
+__global__ void __launch_bounds__(256)
+gather_kernel(SlotArrays sa, const uint32_t *__restrict__ seg_start, uint32_t n_carry_seg, uint32_t n_seg,
+              const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ base, uint32_t *__restrict__ rec_off,
+              uint32_t *__restrict__ name_off, uint32_t *__restrict__ name_len, int32_t *__restrict__ a, int32_t *__restrict__ x,
+              uint8_t *__restrict__ flag, uint32_t rec_cap)
+{
+    const uint32_t s = n_carry_seg + blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (s >= n_seg) return;
+    const uint32_t n = cnt[s], b0 = base[s];
+    const uint64_t so = slot_of(seg_start[s], s - n_carry_seg);
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t at = b0 + i;
+        if (at >= rec_cap) break;
+        rec_off[at] = sa.off[so + i];
+        name_off[at] = sa.name_off[so + i];
+        name_len[at] = sa.name_len[so + i];
+        a[at] = sa.a[so + i];
+        x[at] = sa.x[so + i];
+        flag[at] = sa.flag[so + i];
+    }
 }
 
 // ---- B2: alignment check + exclusive scan of the per-segment counts (one workgroup) --------------------------------
@@ -122,121 +150,20 @@ struct RecOut {
     uint8_t *flag;            // ex_a | ex_x << 2 | R_WEIRD | R_BAD
 };
 
-__device__ __forceinline__ bool odd_byte(uint32_t c) { return c <= 0x20u || c >= 0x7Fu; }
-
-__device__ __forceinline__ uint32_t elem_bytes(uint32_t t)
-{
-    switch (t) {
-    case 'A': case 'c': case 'C': return 1u;
-    case 's': case 'S': return 2u;
-    case 'i': case 'I': case 'f': return 4u;
-    case 'd': return 8u;
-    default: return 0u;
-    }
-}
-
+// n_dev: when not null, the number of records is read from there (at most n: the launch's upper bound)
 __global__ void __launch_bounds__(256)
-parse_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_off, uint32_t n, uint32_t x0 /* 'X' or 'Z' */, RecOut o)
+parse_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_off, uint32_t n, const uint32_t *__restrict__ n_dev,
+             uint32_t x0 /* 'X' or 'Z' */, RecOut o)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (n_dev != nullptr) { const uint32_t m = *n_dev; n = m < n ? m : n; }
     if (i >= n) return;
-    const uint32_t off = rec_off[i];
-    const uint32_t size = ld32(raw + off);
-    const uint8_t *r = raw + off + 4u;
-    uint32_t flag = 0, nl = 0;
-    uint32_t cnt_a = 0, cnt_x = 0, ex_a = 0, ex_x = 0;
-    int32_t va = ABSENT, vx = ABSENT;
-    bool ok = size >= 32u;
-    if (ok) {
-        const int32_t ref_id = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
-        const uint32_t l_read_name = r[8], n_cigar = ld16(r + 12), l_seq = ld32(r + 16);
-        const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + ((uint64_t)l_seq + 1u) / 2u + l_seq;
-        ok = need <= size && l_read_name != 0u;
-        if (ok) {
-            bool weird = false;
-            // QNAME up to its NUL
-            while (nl < l_read_name && r[32u + nl] != 0u) { weird |= odd_byte(r[32u + nl]); ++nl; }
-            weird |= nl == 0u;
-            uint32_t p = 32u + l_read_name;
-            // a CIGAR that lives in a CG:B:I field (htslib moves it back when it prints): possible only with this placeholder
-            const bool cg_possible = n_cigar != 0u && ref_id >= 0 && pos >= 0 && (ld32(r + p) & 15u) == 4u && (ld32(r + p) >> 4) == l_seq;
-            p += 4u * n_cigar + (l_seq + 1u) / 2u;
-            // qualities: printed as byte + 33; above 93 the text is not ASCII any more
-            if (l_seq != 0u && r[p] != 0xFFu) {
-                uint32_t hi = 0;
-                for (uint32_t k = 0; k < l_seq; ++k) hi |= (r[p + k] + 33u) & 0xFFu;
-                weird |= (hi & 0x80u) != 0u;
-            }
-            p += l_seq;
-            // optional fields
-            while (ok && p + 3u <= size) {
-                const uint32_t t0 = r[p], t1 = r[p + 1], type = r[p + 2];
-                p += 3u;
-                weird |= odd_byte(t0) || odd_byte(t1);
-                weird |= cg_possible && t0 == 'C' && t1 == 'G';
-                const bool is_a = t0 == 'A' && t1 == 'S', is_x = t0 == x0 && t1 == 'S';
-                if (type == 'Z' || type == 'H') {
-                    // the printed field "TG:Z:value": matched by its name or by the two letters anywhere in the value
-                    bool in_a = is_a, in_x = is_x, end = false;
-                    uint32_t prev = 0;
-                    while (p < size) {
-                        const uint32_t c = r[p++];
-                        if (c == 0u) { end = true; break; }
-                        weird |= odd_byte(c);
-                        in_a |= prev == 'A' && c == 'S';
-                        in_x |= prev == x0 && c == 'S';
-                        prev = c;
-                    }
-                    ok = end;
-                    // a string value is never vouched for here: the text rules decide (the count still matters: duplicates)
-                    if (in_a) { if (cnt_a++ == 0u) ex_a = 1u; }
-                    if (in_x) { if (cnt_x++ == 0u) ex_x = 1u; }
-                    continue;
-                }
-                uint32_t bytes;
-                if (type == 'B') {
-                    if (p + 5u > size) { ok = false; break; }
-                    const uint32_t e = elem_bytes(r[p]);
-                    const uint64_t len = 5ull + (uint64_t)e * ld32(r + p + 1);
-                    if (e == 0u || p + len > size) { ok = false; break; }
-                    bytes = (uint32_t)len;
-                } else {
-                    bytes = elem_bytes(type);
-                    if (bytes == 0u || p + bytes > size) { ok = false; break; }
-                    if (type == 'A') weird |= odd_byte(r[p]);
-                }
-                if (is_a || is_x) {                                        // only the tag itself can hold the two letters
-                    long long v = 0;
-                    bool is_int = true;
-                    switch (type) {
-                    case 'c': v = (int8_t)r[p]; break;
-                    case 'C': v = r[p]; break;
-                    case 's': v = (int16_t)ld16(r + p); break;
-                    case 'S': v = ld16(r + p); break;
-                    case 'i': v = (int32_t)ld32(r + p); break;
-                    case 'I': v = ld32(r + p); break;
-                    default: is_int = false;                               // A, f, d, B by name: what its printed text says
-                    }
-                    const bool fits = is_int && v >= -2147483647ll && v <= 2147483647ll;
-                    if (is_a) { if (cnt_a++ == 0u) { if (fits) va = (int32_t)v; else ex_a = 1u; } }
-                    if (is_x) { if (cnt_x++ == 0u) { if (fits) vx = (int32_t)v; else ex_x = 1u; } }
-                }
-                p += bytes;
-            }
-            ok = ok && p == size;
-            if (weird) flag |= R_WEIRD;
-        }
-    }
-    if (!ok) flag |= R_BAD;
-    if (cnt_a > 1u) ex_a = 2u;
-    if (cnt_x > 1u) ex_x = 2u;
-    if (ex_a) va = ABSENT;
-    if (ex_x) vx = ABSENT;
-    o.name_off[i] = off + 36u;
-    o.name_len[i] = nl;
-    o.a[i] = va;
-    o.x[i] = vx;
-    o.flag[i] = (uint8_t)(flag | (ex_a << R_EX_A_SHIFT) | (ex_x << R_EX_X_SHIFT));
+    const xmrec::RecFields f = xmrec::parse_record(raw, rec_off[i], x0);
+    o.name_off[i] = f.name_off;
+    o.name_len[i] = f.name_len;
+    o.a[i] = f.a;
+    o.x[i] = f.x;
+    o.flag[i] = (uint8_t)f.flag;
 }
 
 // ---- B5: one lane per pair --------------------------------------------------------------------------------------------
@@ -295,6 +222,11 @@ struct PerFile {
     uint8_t *h_comp = nullptr, *d_comp = nullptr;           // staged compressed bytes (+ XMB_COMP_PAD): d_comp = a half of Slot::d_comp_all
     uint8_t *d_raw = nullptr, *h_raw = nullptr;             // the inflated window: d_raw = a half of Slot::d_raw_all
     uint32_t *h_seg = nullptr, *d_seg = nullptr, *d_cnt = nullptr, *d_exit = nullptr, *d_base = nullptr;
+    // what the inflate launch notes per block (slot_of): record starts and the stripper's fields of every record
+    uint32_t *d_s_off = nullptr, *d_s_name_off = nullptr, *d_s_name_len = nullptr;
+    int32_t *d_s_a = nullptr, *d_s_x = nullptr;
+    uint8_t *d_s_flag = nullptr;
+    uint64_t slots_len = 0;
     uint32_t *d_rec_off = nullptr, *h_rec_off = nullptr;
     uint32_t *d_name_off = nullptr, *d_name_len = nullptr;
     int32_t *d_a = nullptr, *d_x = nullptr;
@@ -312,6 +244,7 @@ struct Slot {
     uint8_t *d_comp_all = nullptr, *d_raw_all = nullptr;
     uint64_t comp_stride = 0, raw_stride = 0;
     xm_bgzf_block *h_blocks = nullptr, *d_blocks = nullptr;
+    xm_bgzf_walk *h_walk = nullptr, *d_walk = nullptr;      // per block: where its record chain starts and where its results go
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_crc = nullptr, *h_crc = nullptr, *d_work = nullptr;
     int32_t *d_col[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t *d_bits = nullptr;
@@ -391,11 +324,13 @@ void free_slot(Slot &sl)
         PerFile &q = sl.pf[f];
         hfree(q.h_comp); q.d_comp = nullptr; q.d_raw = nullptr; hfree(q.h_raw);
         hfree(q.h_seg); dfree(q.d_seg); dfree(q.d_cnt); dfree(q.d_exit); dfree(q.d_base);
+        dfree(q.d_s_off); dfree(q.d_s_name_off); dfree(q.d_s_name_len); dfree(q.d_s_a); dfree(q.d_s_x); dfree(q.d_s_flag);
+        q.slots_len = 0;
         dfree(q.d_rec_off); hfree(q.h_rec_off); dfree(q.d_name_off); dfree(q.d_name_len); dfree(q.d_a); dfree(q.d_x);
         dfree(q.d_rflag); dfree(q.d_lflag); hfree(q.h_lflag);
     }
     dfree(sl.d_comp_all); dfree(sl.d_raw_all);
-    hfree(sl.h_blocks); dfree(sl.d_blocks); dfree(sl.d_status); hfree(sl.h_status); dfree(sl.d_crc); hfree(sl.h_crc);
+    hfree(sl.h_blocks); dfree(sl.d_blocks); hfree(sl.h_walk); dfree(sl.d_walk); dfree(sl.d_status); hfree(sl.h_status); dfree(sl.d_crc); hfree(sl.h_crc);
     for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
     dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx);
     hfree(sl.h_code); hfree(sl.h_idx);
@@ -511,6 +446,7 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
         sl.block_cap = 0;
         const size_t nb = (size_t)max_blocks + 2;
         XMB_TRY(halloc(b, sl.h_blocks, 2 * nb)); XMB_TRY(dalloc(b, sl.d_blocks, 2 * nb));
+        XMB_TRY(halloc(b, sl.h_walk, 2 * nb)); XMB_TRY(dalloc(b, sl.d_walk, 2 * nb));
         XMB_TRY(dalloc(b, sl.d_status, 2 * nb)); XMB_TRY(halloc(b, sl.h_status, 2 * nb));
         XMB_TRY(dalloc(b, sl.d_crc, 2 * nb)); XMB_TRY(halloc(b, sl.h_crc, 2 * nb));
         for (int f = 0; f < 2; ++f) {
@@ -539,6 +475,18 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
         XMB_TRY(halloc(b, sl.h_code, n));
         XMB_TRY(halloc(b, sl.h_idx, n));
         sl.record_cap = max_records;
+    }
+    // the slots the inflate launch notes records in: slot_of() of the largest window and block count
+    const uint64_t need_slots = sl.raw_cap / 36u + 2u * sl.block_cap + 64u;
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        if (need_slots > q.slots_len) {
+            q.slots_len = 0;
+            XMB_TRY(dalloc(b, q.d_s_off, (size_t)need_slots)); XMB_TRY(dalloc(b, q.d_s_name_off, (size_t)need_slots));
+            XMB_TRY(dalloc(b, q.d_s_name_len, (size_t)need_slots)); XMB_TRY(dalloc(b, q.d_s_a, (size_t)need_slots));
+            XMB_TRY(dalloc(b, q.d_s_x, (size_t)need_slots)); XMB_TRY(dalloc(b, q.d_s_flag, (size_t)need_slots));
+            q.slots_len = need_slots;
+        }
     }
     return XM_OK;
 }
@@ -611,10 +559,30 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
             }
         }
         if (x.skip && (x.carry_len || x.n_blocks == 0 || x.skip >= x.blocks[0].isize)) return XM_ERR_INVALID_ARG;
+        q.h_summary[9] = n_seg;                                             // segments of the carried tail: walked by walk_kernel
         for (uint64_t k = 0; k < x.n_blocks; ++k) {
             xm_bgzf_block d = x.blocks[k];
             const uint64_t out_in_file = d.out_off + x.carry_len;
-            if (d.isize) q.h_seg[n_seg++] = (uint32_t)(out_in_file + (k == 0 ? x.skip : 0));
+            // the block's records are found and read by the chain of lanes that inflates it (xm_bgzf_inflate_walk_dev)
+            xm_bgzf_walk w;
+            memset(&w, 0, sizeof w);
+            if (d.isize) {
+                const uint32_t kb = n_seg - q.h_summary[9];
+                w.raw_base = (uint64_t)f * sl.raw_stride;
+                w.start = (uint32_t)(out_in_file + (k == 0 ? x.skip : 0));
+                w.end = (uint32_t)(out_in_file + d.isize);
+                w.n_raw = (uint32_t)q.raw_len;
+                const uint64_t so = slot_of(w.start, kb);
+                w.slot_cap = (uint32_t)(slot_of(w.end, kb + 1u) - so);
+                w.count = q.d_cnt + n_seg;
+                w.exit_at = q.d_exit + n_seg;
+                w.slots = q.d_s_off + so;
+                w.name_off = q.d_s_name_off + so; w.name_len = q.d_s_name_len + so;
+                w.a = q.d_s_a + so; w.x = q.d_s_x + so; w.flag = q.d_s_flag + so;
+                w.x0 = score_mode == XMS_SCORE_AS_ZS ? 'Z' : 'X';
+                q.h_seg[n_seg++] = w.start;
+            }
+            sl.h_walk[n_all + k] = w;
             d.cdata_off += (uint64_t)f * sl.comp_stride;
             d.out_off = out_in_file + (uint64_t)f * sl.raw_stride;
             sl.h_blocks[n_all + k] = d;
@@ -635,7 +603,8 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     t_staged = since();
     if (n_all) {
         XMB_HIP(b, hipMemcpyAsync(sl.d_blocks, sl.h_blocks, (size_t)n_all * sizeof(xm_bgzf_block), hipMemcpyHostToDevice, st));
-        int rc = xm_bgzf_inflate_dev(b->ctx, st, sl.d_comp_all, sl.d_blocks, n_all, sl.d_raw_all, sl.d_status, sl.d_work);
+        XMB_HIP(b, hipMemcpyAsync(sl.d_walk, sl.h_walk, (size_t)n_all * sizeof(xm_bgzf_walk), hipMemcpyHostToDevice, st));
+        int rc = xm_bgzf_inflate_walk_dev(b->ctx, st, sl.d_comp_all, sl.d_blocks, n_all, sl.d_raw_all, sl.d_status, sl.d_work, sl.d_walk);
         if (rc == XM_OK) rc = xm_bgzf_crc32_dev(b->ctx, st, sl.d_raw_all, sl.d_blocks, n_all, sl.d_crc);
         if (rc != XM_OK) return rc;
         XMB_HIP(b, hipMemcpyAsync(sl.h_status, sl.d_status, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
@@ -656,10 +625,22 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         const uint32_t n_seg = q.h_summary[8];
         XMB_HIP(b, hipMemsetAsync(q.d_summary, 0, 8 * sizeof(uint32_t), st));
         if (n_seg) {
-            walk_kernel<false><<<(n_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, q.d_cnt, q.d_exit, nullptr, nullptr, 0u);
+            // counts, exits, record starts and fields of the blocks' segments came with the inflate launch; the pieces of the
+            // carried tail (bytes of the previous window) are walked here
+            const uint32_t n_carry_seg = q.h_summary[9];
+            const uint32_t rec_cap = (uint32_t)std::min<uint64_t>(sl.record_cap, 0xFFFFFFFFull);
+            if (n_carry_seg)
+                walk_kernel<false><<<(n_carry_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_carry_seg, q.d_cnt, q.d_exit,
+                                                                                          nullptr, nullptr, 0u);
             scan_kernel<<<1, 1024, 0, st>>>(q.d_cnt, q.d_exit, q.d_seg, n_seg, q.d_base, q.d_summary);
-            walk_kernel<true><<<(n_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_seg, nullptr, nullptr, q.d_base, q.d_rec_off,
-                                                                     (uint32_t)std::min<uint64_t>(sl.record_cap, 0xFFFFFFFFull));
+            if (n_carry_seg)
+                walk_kernel<true><<<(n_carry_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_carry_seg, nullptr, nullptr,
+                                                                                         q.d_base, q.d_rec_off, rec_cap);
+            if (n_seg > n_carry_seg) {
+                const SlotArrays sa = {q.d_s_off, q.d_s_name_off, q.d_s_name_len, q.d_s_a, q.d_s_x, q.d_s_flag};
+                gather_kernel<<<(n_seg - n_carry_seg + 3u) / 4u, 256, 0, st>>>(sa, q.d_seg, n_carry_seg, n_seg, q.d_cnt, q.d_base, q.d_rec_off, q.d_name_off,
+                                                                               q.d_name_len, q.d_a, q.d_x, q.d_rflag, rec_cap);
+            }
         }
         XMB_HIP(b, hipMemcpyAsync(q.h_summary, q.d_summary, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
@@ -698,9 +679,15 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     XMB_HIP(b, hipMemcpyAsync(sl.d_state, sl.h_state, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if (n) {
         for (int f = 0; f < 2; ++f) {
+            // the records of the carried tail (they come first): parsed here; the blocks' records came parsed with the inflate
+            // launch.  Their number is base[first block segment], known on the device only: lanes behind it leave at once.
             PerFile &q = sl.pf[f];
+            const uint32_t n_seg = q.h_summary[8], n_carry_seg = q.h_summary[9];
+            if (n_carry_seg == 0u) continue;
             const RecOut ro = {q.d_name_off, q.d_name_len, q.d_a, q.d_x, q.d_rflag};
-            parse_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(q.d_raw, q.d_rec_off, (uint32_t)n, score_mode == XMS_SCORE_AS_ZS ? 'Z' : 'X', ro);
+            const uint64_t upper = std::min<uint64_t>(n, in[f].carry_len / 36u + 1u);
+            parse_kernel<<<(uint32_t)((upper + 255) / 256), 256, 0, st>>>(q.d_raw, q.d_rec_off, (uint32_t)upper, n_carry_seg < n_seg ? q.d_base + n_carry_seg : nullptr,
+                                                                         score_mode == XMS_SCORE_AS_ZS ? 'Z' : 'X', ro);
         }
         const PerFile &a = sl.pf[0], &c = sl.pf[1];
         const FileRecs f1 = {a.d_raw, a.d_name_off, a.d_name_len, a.d_a, a.d_x, a.d_rflag};

@@ -12,6 +12,7 @@
 
 #include "../../include/xenomapper_bgzf.h"
 #include "xm_inflate_core.h"
+#include "xm_bamrec.h"
 
 // Lanes per chain and waves per SIMD.  A chain's speed is its own serial instruction stream, so what counts is how many chains a CU
 // holds and how little they get in each other's way.  5.1 KB of LDS per chain allows 31 of them per CU, whatever their width.
@@ -53,7 +54,8 @@ namespace {
 template <int GS>
 __global__ void __launch_bounds__(64) XM_INFLATE_OCCUPANCY
 inflate_kernel(const uint8_t *__restrict__ comp, const xm_bgzf_block *__restrict__ blocks, uint32_t n_blocks,
-               uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t *__restrict__ work)
+               uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t *__restrict__ work,
+               const xm_bgzf_walk *__restrict__ walk)
 {
     constexpr int G = 64 / GS;
     __shared__ xmi::ChainMem mem[G];
@@ -81,6 +83,44 @@ inflate_kernel(const uint8_t *__restrict__ comp, const xm_bgzf_block *__restrict
         int rc = xmi::OK;
         if (d.isize != 0u) rc = chain.run(&mem[c], gl, comp, d.cdata_off, d.cdata_len, out, d.out_off, d.isize);
         if (gl == 0u) status[b] = (uint32_t)rc;
+        // BAM windows (xm_bgzf_inflate_walk_dev): the chain follows the alignment records' block_size chain through the block it has
+        // just written and reads the classifier's fields out of its records -- while the block is still near this CU.  Kernels of
+        // their own doing the same over the whole window afterwards (a lane per block, a lane per record) cost 12 ms per window of
+        // dependent, uncoalesced reads (profiles/r05_bam_record_kernels.txt); here it is a fraction of a percent of the launch.
+        // Only bytes in front of the window's end are read, and only of records that begin in this block.
+        if (walk != nullptr) {
+            const xm_bgzf_walk w = walk[b];
+            if (w.end > w.start) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the block's last stores have left
+                const uint8_t *raw = out + w.raw_base;
+                uint32_t p = w.start, n = 0;
+                if (rc == xmi::OK) {
+                    while (p < w.end) {                                     // every lane of the chain the same walk
+                        if (w.end - p < 4u) break;                          // the size word is cut by the block's end (the window's: a tail)
+                        const uint32_t size = xmrec::ld32(raw + p);
+                        if (size > w.n_raw - p - 4u) break;                 // the record continues behind the window
+                        if (n >= w.slot_cap) { p = 0xFFFFFFFFu; break; }    // more records than bytes / 36: not alignment records
+                        if (gl == 0u) w.slots[n] = p;
+                        ++n;
+                        p += 4u + size;
+                    }
+                } else {
+                    p = 0xFFFFFFFFu;
+                }
+                if (gl == 0u) { *w.count = n; *w.exit_at = p; }
+                if (w.x0 != 0u && p != 0xFFFFFFFFu) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the record starts are where the other lanes read them
+                    for (uint32_t i = gl; i < n; i += GS) {
+                        const xmrec::RecFields f = xmrec::parse_record(raw, w.slots[i], w.x0);
+                        w.name_off[i] = f.name_off;
+                        w.name_len[i] = f.name_len;
+                        w.a[i] = f.a;
+                        w.x[i] = f.x;
+                        w.flag[i] = (uint8_t)f.flag;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -198,9 +238,16 @@ int xm_bgzf_index(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_o
 int xm_bgzf_inflate_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm_bgzf_block *blocks, uint64_t n_blocks,
                         uint8_t *out, uint32_t *status, uint32_t *work)
 {
+    return xm_bgzf_inflate_walk_dev(ctx, stream, comp, blocks, n_blocks, out, status, work, nullptr);
+}
+
+int xm_bgzf_inflate_walk_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm_bgzf_block *blocks, uint64_t n_blocks,
+                             uint8_t *out, uint32_t *status, uint32_t *work, const xm_bgzf_walk *walk)
+{
     if (!ctx || n_blocks > 0x7FFFFFFFull) return XM_ERR_INVALID_ARG;
     if (n_blocks == 0) return XM_OK;
     if (!comp || !blocks || !out || !status || !work || ((uintptr_t)comp & 15u) || ((uintptr_t)blocks & 7u)) return XM_ERR_INVALID_ARG;
+    if (walk && ((uintptr_t)walk & 7u)) return XM_ERR_INVALID_ARG;
     int n_cu = 0;
     if (xm_ctx_device_info(ctx, &n_cu, nullptr, 0) != XM_OK || n_cu <= 0) return XM_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -211,7 +258,7 @@ int xm_bgzf_inflate_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm
     constexpr uint64_t by_lds = (160u * 1024u) / (G * sizeof(xmi::ChainMem));
     uint64_t grid = (uint64_t)n_cu * (by_lds < XM_INFLATE_WG_PER_CU ? by_lds : XM_INFLATE_WG_PER_CU);
     if (grid > waves_needed) grid = waves_needed;
-    inflate_kernel<XM_INFLATE_GS><<<(uint32_t)grid, 64, 0, st>>>(comp, blocks, (uint32_t)n_blocks, out, status, work);
+    inflate_kernel<XM_INFLATE_GS><<<(uint32_t)grid, 64, 0, st>>>(comp, blocks, (uint32_t)n_blocks, out, status, work, walk);
     return hipGetLastError() == hipSuccess ? XM_OK : XM_ERR_HIP;
 }
 
