@@ -1,21 +1,23 @@
 // xm_bamdev.hip -- BAM records -> the classifier's columns on the GPU (include/xenomapper_bgzf.h, xm_bamdev_*).
 //
-// Per window and file:  compressed BGZF blocks (page-locked staging) --H2D--> inflate (xm_inflate.hip) + CRC-32 -->
-//   B1 walk_kernel   one lane per SEGMENT (the carried-over bytes, then every BGZF block): follows the block_size chain
-//                    from the segment's first byte, counts the records that begin in it, reports where the chain leaves
-//                    it.  The chain is serial, so the parallelism is the segments -- which only works when every block
-//                    begins with a record, as htslib / samtools write them (bgzf_flush_try in front of every record);
-//   B2 scan_kernel   one workgroup: checks exactly that (every segment's chain must land on the next segment's first
-//                    byte; else `unaligned` and the caller takes the host decoder), exclusive scan of the counts;
-//   B3 fill_kernel   the same walk again, now writing the record table;
-//   B4 parse_kernel  one lane per RECORD: the fixed fields, the name, the optional fields with the tag_func plugins' rules
-//                    on the TYPED fields (xm_bam.cpp's TagScan, restating get_tag xenomapper.py:176-191), everything the
-//                    text rules might read differently flagged;
+// Per window:  compressed BGZF blocks (page-locked staging) --H2D--> inflate (xm_inflate.hip) + CRC-32.  The inflate launch also does
+// the record work of the BLOCKS (xm_bgzf_inflate_walk_dev): the chain of lanes that has written a block follows the block_size chain
+// of the alignment records through it and reads the classifier's fields out of every record (xm_bamrec.h parse_record: the fixed
+// fields, the name, the optional fields with the tag_func plugins' rules on the TYPED fields -- xm_bam.cpp's TagScan, restating
+// get_tag xenomapper.py:176-191 -- everything the text rules might read differently flagged), into per-block slots.  The chain is
+// serial, so the parallelism is the blocks -- which only works when every block begins with a record, as htslib / samtools write
+// them (bgzf_flush_try in front of every record).  Then, per file:
+//   B1 walk_kernel   the pieces of the CARRIED tail (bytes of the previous window), a lane per piece: counts the records of each,
+//                    reports where its chain leaves it;
+//   B2 scan_kernel   one workgroup: checks that every segment's chain (pieces and blocks) lands on the next segment's first
+//                    byte -- else `unaligned` and the caller takes the host decoder --, exclusive scan of the counts;
+//   B3 walk_kernel   the pieces again, writing their part of the record table;  gather_kernel: the blocks' part of the table and
+//                    of the field arrays, from the slots (a wave per block);
+//   B4 parse_kernel  the carried tail's records, a lane per record (the same parse_record);
 //   B5 pair_kernel   one lane per PAIR of records k of the two files: score columns, names compared (:106 across files,
 //                    :402 between neighbours -> unit mask by ballot), first mismatch by atomicMin.
-// The inflated bytes and the record table also go back to the host (page-locked), where the writer prints the SAM text of
-// the records (xmh_bam_print).  All byte / integer work, bound by memory latency per record, far from any roofline that
-// matters next to the inflate.
+// The inflated bytes and the record table also go back to the host (page-locked, on a copy stream of the slot's own), where the
+// writer prints the SAM text of the records a sink takes (xmh_bam_print).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,10 +44,7 @@ using xmrec::ld16; using xmrec::ld32;
 // ---- B1 / B3: the record chain, one lane per segment --------------------------------------------------------------
 // seg_start[n_seg + 1]: first byte of every segment, seg_start[n_seg] = n_raw.  A record belongs to the segment its
 // block_size word begins in; a record that does not end inside the window ends the walk (it is the next window's).
-// Small workgroups, so that the few thousand lanes of a window -- one per block -- spread over all CUs.  What the walk costs is the
-// first touch of the freshly inflated window: 3.5 ms per file and window for whichever kernel reads it first, this one or --
-// when the inflating chains follow the record chain of their own block as they finish it and a gather builds the table (built
-// and measured in round 5, profiles/r05_bam_kernel_stats.csv) -- the parse kernel behind it; the sum stayed the same.
+// Since the blocks' records are found by the inflate launch, this kernel walks the carried tail's pieces only (a few hundred lanes).
 constexpr uint32_t WALK_T = 64;
 template <bool FILL>
 __global__ void __launch_bounds__(WALK_T)
