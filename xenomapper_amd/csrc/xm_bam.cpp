@@ -176,6 +176,42 @@ struct SeqTable {                      // one packed byte -> its two bases
 };
 const SeqTable SEQ;
 
+// SEQ, 16 packed bytes -> 32 bases at a time where the CPU has SSSE3 (both nibbles through one 16-entry shuffle table, interleaved);
+// the table loop for the rest and for other CPUs.  (Printing is what the file path's main thread does for BAM input on the GPU
+// front end: a third of a record's time went into this loop and the quality loop behind it.)
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("ssse3"))) static char *put_seq_ssse3(char *o, const uint8_t *packed, uint32_t l_seq)
+{
+    const __m128i lut = _mm_setr_epi8('=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N');
+    const __m128i low = _mm_set1_epi8(0x0F);
+    uint32_t k = 0;
+    for (; k + 32 <= l_seq; k += 32) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(packed + k / 2));
+        const __m128i hi = _mm_shuffle_epi8(lut, _mm_and_si128(_mm_srli_epi16(v, 4), low));
+        const __m128i lo = _mm_shuffle_epi8(lut, _mm_and_si128(v, low));
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k), _mm_unpacklo_epi8(hi, lo));
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k + 16), _mm_unpackhi_epi8(hi, lo));
+    }
+    for (; k + 1 < l_seq; k += 2) memcpy(o + k, SEQ.pair[packed[k / 2]], 2);
+    if (l_seq & 1) o[l_seq - 1] = SEQ.pair[packed[l_seq / 2]][0];
+    return o + l_seq;
+}
+static const bool HAVE_SSSE3 = __builtin_cpu_supports("ssse3");
+#else
+static const bool HAVE_SSSE3 = false;
+#endif
+
+inline char *put_seq(char *o, const uint8_t *packed, uint32_t l_seq)
+{
+#if defined(__x86_64__)
+    if (HAVE_SSSE3) return put_seq_ssse3(o, packed, l_seq);
+#endif
+    for (uint32_t k = 0; k + 1 < l_seq; k += 2) { memcpy(o, SEQ.pair[packed[k / 2]], 2); o += 2; }
+    if (l_seq & 1) *o++ = SEQ.pair[packed[l_seq / 2]][0];
+    return o;
+}
+
 }  // namespace
 
 // inflated bytes not yet consumed: [pos, end) of one reused, never zero-filled buffer (a std::vector would memset --
@@ -464,14 +500,26 @@ char *format_record(const xmh_bam *b, const uint8_t *r, uint32_t size, char *o, 
     *o++ = '\t'; o = put_int(o, tlen);
     *o++ = '\t';
     if (l_seq == 0) *o++ = '*';
-    for (uint32_t k = 0; k + 1 < l_seq; k += 2) { memcpy(o, SEQ.pair[r[p + k / 2]], 2); o += 2; }
-    if (l_seq & 1) *o++ = SEQ.pair[r[p + l_seq / 2]][0];
+    o = put_seq(o, r + p, l_seq);
     p += ((uint64_t)l_seq + 1) / 2;
     *o++ = '\t';
     if (l_seq == 0 || r[p] == 0xFF) *o++ = '*';
     else {
         uint8_t hi = 0;
-        for (uint32_t k = 0; k < l_seq; ++k) { const uint8_t c = (uint8_t)(r[p + k] + 33); o[k] = (char)c; hi |= c; }
+        uint32_t k = 0;
+#if defined(__x86_64__)
+        {   // 16 qualities at a time (SSE2 is part of x86-64)
+            __m128i acc = _mm_setzero_si128();
+            const __m128i add = _mm_set1_epi8(33);
+            for (; k + 16 <= l_seq; k += 16) {
+                const __m128i c = _mm_add_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(r + p + k)), add);
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(o + k), c);
+                acc = _mm_or_si128(acc, c);
+            }
+            hi = (uint8_t)(_mm_movemask_epi8(acc) ? 0x80 : 0);
+        }
+#endif
+        for (; k < l_seq; ++k) { const uint8_t c = (uint8_t)(r[p + k] + 33); o[k] = (char)c; hi |= c; }
         weird |= (hi & 0x80) != 0;                                   // a quality above 94: not ASCII any more
         o += l_seq;
     }
