@@ -47,6 +47,10 @@ typedef struct {
  */
 int xm_bgzf_index(const uint8_t *data, uint64_t len, uint64_t start, uint64_t max_out, xm_bgzf_block *blocks, uint32_t *crc,
                   uint64_t cap, uint64_t *n_blocks, uint64_t *next, uint64_t *out_bytes);
+/* the same over a buffer that may end inside a member (bytes read ahead of a file): stops in front of the member that is cut
+ * instead of refusing the buffer; *next = where that member begins */
+int xm_bgzf_index_prefix(const uint8_t *image, uint64_t len, uint64_t start, uint64_t max_out, xm_bgzf_block *blocks, uint32_t *crc,
+                         uint64_t cap, uint64_t *n_blocks, uint64_t *next, uint64_t *out_bytes);
 
 /*
  * Inflate n_blocks BGZF blocks.  comp: the compressed image on the device, 16-byte aligned, with at least

@@ -147,6 +147,7 @@ def lib():
         "xm_strip_last_error": ([P], ctypes.c_char_p),
         # include/xenomapper_bgzf.h
         "xm_bgzf_index": ([P, U64, U64, U64, P, P, U64, ctypes.POINTER(U64), ctypes.POINTER(U64), ctypes.POINTER(U64)], I),
+        "xm_bgzf_index_prefix": ([P, U64, U64, U64, P, P, U64, ctypes.POINTER(U64), ctypes.POINTER(U64), ctypes.POINTER(U64)], I),
         "xm_bgzf_inflate_dev": ([P, P, P, P, U64, P, P, P], I),
         "xm_bgzf_inflate_walk_dev": ([P, P, P, P, U64, P, P, P, P], I),
         "xm_bgzf_crc32_dev": ([P, P, P, P, U64, P], I),
@@ -182,7 +183,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
-            "xm_bgzf_index", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
+            "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
             "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_last_error")
 
@@ -686,16 +687,18 @@ assert BGZF_WALK.itemsize == 96                                     # xm_bgzf_wa
 BGZF_COMP_PAD = 1024
 
 
-def bgzf_index(data, start=0, max_out=1 << 62, cap=None):
+def bgzf_index(data, start=0, max_out=1 << 62, cap=None, prefix=False):
     """Walk the BGZF member headers of a file image (uint8 array) from byte `start` (xm_bgzf_index; host only):
-    -> (blocks as a BGZF_BLOCK array, crc uint32 array, next byte, inflated bytes)."""
+    -> (blocks as a BGZF_BLOCK array, crc uint32 array, next byte, inflated bytes).  prefix: the array may end inside a member
+    (bytes read ahead of a file): the walk stops in front of it (xm_bgzf_index_prefix)."""
     data = np.ascontiguousarray(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
     n_max = int(cap) if cap is not None else max(16, (data.shape[0] - int(start)) // 28 + 16)    # an empty member is 28 bytes
     blocks = np.zeros(n_max, dtype=BGZF_BLOCK)
     crc = np.zeros(n_max, dtype=np.uint32)
     n, nxt, total = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-    rc = lib().xm_bgzf_index(ctypes.c_void_p(data.ctypes.data), data.shape[0], int(start), int(max_out), _np_ptr(blocks), _np_ptr(crc),
-                             n_max, ctypes.byref(n), ctypes.byref(nxt), ctypes.byref(total))
+    fn = lib().xm_bgzf_index_prefix if prefix else lib().xm_bgzf_index
+    rc = fn(ctypes.c_void_p(data.ctypes.data), data.shape[0], int(start), int(max_out), _np_ptr(blocks), _np_ptr(crc),
+            n_max, ctypes.byref(n), ctypes.byref(nxt), ctypes.byref(total))
     if rc != XM_OK:
         raise ValueError("xm_bgzf_index: not a BGZF image (or a truncated one) at byte %d" % int(start))
     return blocks[:n.value], crc[:n.value], int(nxt.value), int(total.value)

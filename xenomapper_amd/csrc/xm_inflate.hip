@@ -199,15 +199,16 @@ inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 
 extern "C" {
 
-int xm_bgzf_index(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_out, xm_bgzf_block *blocks, uint32_t *crc,
-                  uint64_t cap, uint64_t *n_blocks, uint64_t *next, uint64_t *out_bytes)
+static int index_members(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_out, xm_bgzf_block *blocks, uint32_t *crc,
+                         uint64_t cap, uint64_t *n_blocks, uint64_t *next, uint64_t *out_bytes, bool prefix)
 {
     if (!d || !blocks || !n_blocks || !next || !out_bytes || start > len) return XM_ERR_INVALID_ARG;
     uint64_t p = start, n = 0, acc = 0;
     while (p < len && n < cap && acc < max_out) {
-        if (p + 18 > len || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) return XM_ERR_INVALID_ARG;
+        if (p + 18 > len) { if (prefix) break; return XM_ERR_INVALID_ARG; }           // (prefix: the buffer ends inside a header)
+        if (d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) return XM_ERR_INVALID_ARG;
         const uint32_t xlen = le16(d + p + 10);
-        if (p + 12 + xlen > len) return XM_ERR_INVALID_ARG;
+        if (p + 12 + xlen > len) { if (prefix) break; return XM_ERR_INVALID_ARG; }
         uint32_t bsize = 0;
         bool found = false;
         for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
@@ -217,7 +218,8 @@ int xm_bgzf_index(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_o
         }
         if (!found) return XM_ERR_INVALID_ARG;
         const uint64_t total = (uint64_t)bsize + 1;
-        if (total < 12 + xlen + 8 || p + total > len) return XM_ERR_INVALID_ARG;
+        if (total < 12 + xlen + 8) return XM_ERR_INVALID_ARG;
+        if (p + total > len) { if (prefix) break; return XM_ERR_INVALID_ARG; }      // a member cut by the end of the buffer
         const uint32_t isize = le32(d + p + total - 4);
         if (isize > 65536u) return XM_ERR_INVALID_ARG;
         blocks[n].cdata_off = p + 12 + xlen;
@@ -233,6 +235,18 @@ int xm_bgzf_index(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_o
     *next = p;
     *out_bytes = acc;
     return XM_OK;
+}
+
+int xm_bgzf_index(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_out, xm_bgzf_block *blocks, uint32_t *crc,
+                  uint64_t cap, uint64_t *n_blocks, uint64_t *next, uint64_t *out_bytes)
+{
+    return index_members(d, len, start, max_out, blocks, crc, cap, n_blocks, next, out_bytes, false);
+}
+
+int xm_bgzf_index_prefix(const uint8_t *d, uint64_t len, uint64_t start, uint64_t max_out, xm_bgzf_block *blocks, uint32_t *crc,
+                         uint64_t cap, uint64_t *n_blocks, uint64_t *next, uint64_t *out_bytes)
+{
+    return index_members(d, len, start, max_out, blocks, crc, cap, n_blocks, next, out_bytes, true);
 }
 
 int xm_bgzf_inflate_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm_bgzf_block *blocks, uint64_t n_blocks,

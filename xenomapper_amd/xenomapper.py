@@ -1124,7 +1124,7 @@ class _GpuBamFile(object):
         self.seen = [0, 0]                                           # bytes and records consumed so far
         self.by_lines = None                                         # record table of a window parsed by the text rules
         self.pending = None
-        self.ahead = None                                            # (staging address, file offset, bytes, the slot's capacities) read ahead for the next window
+        self.ahead = None                                            # (staging address, file offset, bytes, the slot's capacities, blocks, CRCs, indexed bytes) read ahead for the next window
         self.last_comp = 0                                           # compressed bytes of the last window staged
 
     def _member_header(self, blocks, j):
@@ -1146,6 +1146,28 @@ class _GpuBamFile(object):
         blocks = np.zeros(0, dtype=_ffi.BGZF_BLOCK)
         crc = np.zeros(0, dtype=np.uint32)
         nxt, comp_len, uploaded = self.cursor, 0, 0
+        dst = dev._L.xm_bamdev_staging(dev._h, slot, file)
+        ahead = self.ahead
+        if (budget and not self.at_end and ahead is not None and ahead[0] == dst and ahead[1] == self.cursor
+                and ahead[3] == dev.capacity(slot) and not self.skip):
+            # The window's bytes are in the staging buffer (read_ahead read them from the cursor while the GPU had the window in
+            # front -- into THIS allocation of the buffer: one that has grown since may sit at the same address and holds
+            # nothing) and their members are indexed already, in that thread, from the buffer: walking the headers through the
+            # file's mapping costs a page fault per block, 5 - 10 ms per file and window in the thread the GPU waits for.
+            a_blocks, a_crc, a_end = ahead[4], ahead[5], ahead[6]
+            ends = np.cumsum(a_blocks["isize"], dtype=np.uint64)
+            k = min(int(np.searchsorted(ends, budget, side="left")) + 1, len(a_blocks), max_blocks)
+            whole = k == len(a_blocks) and self.cursor + a_end >= self.data.shape[0]       # the file ends with the last block indexed
+            if k and (int(ends[k - 1]) >= budget or whole):
+                blocks, crc = a_blocks[:k].copy(), a_crc[:k].copy()
+                comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1])
+                nxt = self.cursor + comp_len + 8                       # behind the last member's CRC-32 and ISIZE
+                self.last_comp = comp_len
+                uploaded = min(ahead[2], comp_len)                     # read_ahead sent what it read to the device as well
+                self.ahead = None
+                self.pending = nxt
+                return {"comp_len": comp_len, "blocks": blocks, "crc": crc, "carry_slot": carry_slot, "carry_off": carry_off,
+                        "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": 0, "uploaded": uploaded}
         if budget and not self.at_end:
             blocks, crc, nxt, _total = _ffi.bgzf_index(self.data, self.cursor, budget + self.skip, max_blocks)
             if len(blocks):
@@ -1153,16 +1175,8 @@ class _GpuBamFile(object):
                 comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1]) - c0
                 blocks = blocks.copy()
                 blocks["cdata_off"] -= np.uint64(c0)
-                dst = dev._L.xm_bamdev_staging(dev._h, slot, file)
-                have = 0
-                # read while the GPU had the window in front (read_ahead) -- into THIS allocation of the staging buffer (a
-                # buffer that has grown since may sit at the same address and holds nothing)
-                if self.ahead is not None and self.ahead[0] == dst and self.ahead[1] == c0 and self.ahead[3] == dev.capacity(slot):
-                    have = min(self.ahead[2], comp_len)
-                if have < comp_len:
-                    parser.pread(self.fd, c0 + have, dst + have, comp_len - have)
+                parser.pread(self.fd, c0, dst, comp_len)
                 self.last_comp = comp_len
-                uploaded = have                                      # read_ahead sent what it read to the device as well
         self.ahead = None
         self.pending = nxt
         return {"comp_len": comp_len, "blocks": blocks, "crc": crc, "carry_slot": carry_slot, "carry_off": carry_off,
@@ -1177,17 +1191,19 @@ class _GpuBamFile(object):
         at = self.pending
         if at is None or at + 18 > self.data.shape[0] or not self.last_comp:
             return
-        c0 = at + 12 + (int(self.data[at + 10]) | int(self.data[at + 11]) << 8)      # behind the member header (XLEN)
         room = dev.capacity(slot)[0]
-        n = min(self.data.shape[0] - c0, self.last_comp + self.last_comp // 16 + (1 << 20), room)
+        n = min(self.data.shape[0] - at, self.last_comp + self.last_comp // 16 + (1 << 20), room)
         if n <= 0:
             return
         dst = dev._L.xm_bamdev_staging(dev._h, slot, file)
         if not dst:
             return
-        reader.pread(self.fd, c0, dst, n)
+        reader.pread(self.fd, at, dst, n)                            # from the member's first byte: the headers come along
         dev.upload(slot, file, n)                                    # and on to the device, beside the GPU's work on the current window
-        self.ahead = (dst, c0, n, dev.capacity(slot))
+        # the members of what was read, indexed here and from the buffer (stage() takes as many as its window holds)
+        view = _ffi._host_view(dst, n, np.uint8)
+        blocks, crc, end, _total = _ffi.bgzf_index(view, 0, 1 << 62, n // 2048 + 1024, prefix=True)   # (a file of tiny members: stage() indexes itself)
+        self.ahead = (dst, at, n, dev.capacity(slot), blocks, crc, end)
 
     def ran(self, slot, raw_len, rec_off=None, stop=None, consumed=0, records=0):
         """What advance() needs to know about the window that was just run (and how many records its consumed bytes held)."""
