@@ -129,8 +129,9 @@ typedef struct {
     int32_t  weird;                  /* 1: a record the text rules might read differently: use the host decoder for this window  */
     int32_t  reserved;
     uint64_t n_exceptions;           /* pairs whose flags carry XMS_LINE_EX_A / _EX_X on either record                           */
-    const uint8_t  *raw1, *raw2;     /* page-locked host copies of the inflated windows: complete once xm_bamdev_raw_wait(slot)
-                                        has returned (the copy runs beside the record kernels), valid until the slot runs again */
+    const uint8_t  *raw1, *raw2;     /* page-locked host copies of the inflated windows -- filled only when asked for
+                                        (xm_bamdev_fetch_raw), complete once xm_bamdev_raw_wait(slot) has returned, valid until
+                                        the slot runs again                                                                       */
     const uint32_t *rec_off1, *rec_off2;   /* start of every record (its block_size word) in raw*: n_rec* entries              */
     const uint8_t  *flags1, *flags2;       /* per yielded pair: XMS_LINE_NORMAL | exception bits (XMS_LINE_EX_A / _EX_X)        */
     float ms_inflate, ms_kernels;    /* device time of the inflate + CRC launches, and of the record kernels (HIP events)       */
@@ -160,11 +161,22 @@ uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file);
  * the slot is idle (its last xm_bamdev_run has returned, the next has not begun): the next run, told so in `uploaded`, waits for
  * the copy instead of making it.  A later xm_bamdev_reserve that grows the buffers forgets what was sent. */
 int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes);
-/* inflate, find the records, strip, pair.  Blocking (the slot's own stream) -- except for the copy of the inflated windows to
- * raw1 / raw2, which may still be on its way when this returns. */
+/* inflate, find the records, strip, pair.  Blocking (the slot's own stream).  The inflated windows stay on the device: what the
+ * writer needs of them is asked for afterwards, one of */
 int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
                   uint64_t max_records, xm_bamdev_block *out);
-/* blocks until the slot's last window has arrived in raw1 / raw2 (any thread; call it before reading them) */
+/* (a) the whole windows into raw1 / raw2 (a window the host has to walk or print whole: unaligned, weird, exceptions) */
+int xm_bamdev_fetch_raw(xm_bamdev *b, int slot);
+/* (b) after xm_bamdev_classify: only the records a sink takes -- a unit's lines come from one file (primary bins: file 1, secondary
+ * bins: file 2, unresolved: both; xenomapper.py:423-448), sink_mask bit b = sink b is given -- packed next to each other:
+ * raw1 / raw2 = the packed records, off1 / off2[i] = where record i went (0xFFFFFFFF: no sink takes it), bytes1 / bytes2 */
+typedef struct {
+    const uint8_t  *raw1, *raw2;
+    const uint32_t *off1, *off2;
+    uint64_t bytes1, bytes2;
+} xm_bamdev_text;
+int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_text *out);
+/* both copies run on a stream of their own; this blocks until the one asked for last has arrived (any thread) */
 int xm_bamdev_raw_wait(xm_bamdev *b, int slot);
 /* the fused main loop on the slot's columns (as xm_strip_classify) */
 int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int32_t min_score_floor,

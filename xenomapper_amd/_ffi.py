@@ -158,6 +158,8 @@ def lib():
         "xm_bamdev_staging": ([P, I, I], P),
         "xm_bamdev_run": ([P, I, P, I, I, I, U64, P], I),
         "xm_bamdev_raw_wait": ([P, I], I),
+        "xm_bamdev_fetch_raw": ([P, I], I),
+        "xm_bamdev_fetch_wanted": ([P, I, U64, I, ctypes.c_uint32, P], I),
         "xm_bamdev_upload": ([P, I, I, U64], I),
         "xm_bamdev_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_bamdev_columns": ([P, I, U64, P, P, P, P, P], I),
@@ -184,7 +186,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
-            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_upload", "xm_bamdev_classify",
+            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_last_error")
 
 
@@ -888,6 +890,11 @@ class _BamDevInput(ctypes.Structure):
                 ("eof", ctypes.c_int32), ("skip", ctypes.c_uint64), ("uploaded", ctypes.c_uint64)]
 
 
+class _BamDevText(ctypes.Structure):
+    _fields_ = [("raw1", ctypes.c_void_p), ("raw2", ctypes.c_void_p), ("off1", ctypes.c_void_p), ("off2", ctypes.c_void_p),
+                ("bytes1", ctypes.c_uint64), ("bytes2", ctypes.c_uint64)]
+
+
 class _BamDevBlock(ctypes.Structure):
     _fields_ = [("n_records", ctypes.c_uint64), ("consumed1", ctypes.c_uint64), ("consumed2", ctypes.c_uint64),
                 ("raw_len1", ctypes.c_uint64), ("raw_len2", ctypes.c_uint64), ("n_rec1", ctypes.c_uint64), ("n_rec2", ctypes.c_uint64),
@@ -921,6 +928,7 @@ class BamDevBlock(object):
         self.csr = None
         self._host_cols = None
         self.line_off = self.line_len = self.norm_len = self.tables = None
+        self.packed = None                                       # fetch_wanted()'s result when only the wanted records came back
         self.finish = None                                       # set by the file path: prints the records' text when called
         self.classified = None                                   # (code, idx, bin_offsets, counts) when the fused pass has run already
 
@@ -993,8 +1001,8 @@ class BamDev(object):
 
     def run(self, slot, inputs, score_mode, paired, keep_halo, max_records, wait_raw=True):
         """inputs: two dicts {comp_len, blocks (BGZF_BLOCK array), crc (uint32 array), carry_slot, carry_off, carry_len, eof, skip}.
-        wait_raw=False: the inflated windows may still be on their way to the host when this returns -- call raw_wait(slot)
-        before reading them (the file path does, from the thread that prints the records)."""
+        wait_raw=False: the inflated windows stay on the device -- the file path then asks for what the writer needs
+        (fetch_wanted after classify, or fetch_raw) and waits for it (raw_wait) in the thread that prints the records."""
         arr = (_BamDevInput * 2)()
         keep = []
         for f, x in enumerate(inputs):
@@ -1009,9 +1017,24 @@ class BamDev(object):
         rc = self._L.xm_bamdev_run(self._h, slot, ctypes.byref(arr), int(score_mode), int(bool(paired)), int(bool(keep_halo)),
                                    int(max_records), ctypes.byref(raw))
         self._check(rc, "xm_bamdev_run")
-        if wait_raw:
+        if wait_raw:                                                 # the whole inflated windows on the host (tests; windows the host walks)
+            self.fetch_raw(slot)
             self.raw_wait(slot)
         return BamDevBlock(self, slot, raw)
+
+    def fetch_raw(self, slot):
+        """Ask for the whole inflated windows in raw1 / raw2 of the slot's block (complete after raw_wait)."""
+        self._check(self._L.xm_bamdev_fetch_raw(self._h, int(slot)), "xm_bamdev_fetch_raw")
+
+    def fetch_wanted(self, slot, n_records, paired, sink_mask):
+        """After classify(): only the records a sink takes, packed (xm_bamdev_fetch_wanted) -> ((address of file 1's packed
+        records, of file 2's), (uint32 views: where record i went, 0xFFFFFFFF = no sink takes it), (bytes1, bytes2));
+        complete after raw_wait."""
+        t = _BamDevText()
+        rc = self._L.xm_bamdev_fetch_wanted(self._h, int(slot), int(n_records), int(bool(paired)), int(sink_mask), ctypes.byref(t))
+        self._check(rc, "xm_bamdev_fetch_wanted")
+        n = int(n_records)
+        return ((t.raw1, t.raw2), (_host_view(t.off1, n, np.uint32), _host_view(t.off2, n, np.uint32)), (int(t.bytes1), int(t.bytes2)))
 
     def upload(self, slot, file, nbytes):
         """The first nbytes of the slot's staging buffer go to the device now (xm_bamdev_upload); the next run is told `uploaded`."""

@@ -165,6 +165,98 @@ parse_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_o
     o.flag[i] = (uint8_t)f.flag;
 }
 
+// ---- the records a sink takes, packed for the way back ---------------------------------------------------------------------
+// The writer prints SAM text only for records whose unit goes to a sink that was given, and a unit's lines come from ONE file
+// (primary bins: file 1, secondary bins: file 2, unresolved: both; xenomapper.py:423-448) -- about half of every window.  With the
+// bins known on the device (the compact category stream of the fused pass), only those records go back over PCIe: W1 marks
+// them and notes their sizes, W2 scans the sizes (three small launches), W3 copies the records next to each other.
+constexpr uint32_t NO_RECORD = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t files_of_bin(uint32_t bin, uint32_t sink_mask)     // bit 0: file 1's line, bit 1: file 2's
+{
+    if (bin > 5u || ((sink_mask >> bin) & 1u) == 0u) return 0u;
+    return bin == 4u ? 3u : (bin == 1u || bin == 3u) ? 2u : 1u;
+}
+
+__global__ void __launch_bounds__(256)
+want_kernel(const uint8_t *__restrict__ raw1, const uint8_t *__restrict__ raw2, const uint32_t *__restrict__ rec_off1,
+            const uint32_t *__restrict__ rec_off2, const uint8_t *__restrict__ bins4, uint32_t n, int paired, uint32_t sink_mask,
+            uint32_t *__restrict__ wsize1, uint32_t *__restrict__ wsize2)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w = files_of_bin((bins4[i >> 1] >> ((i & 1u) * 4u)) & 15u, sink_mask);
+    if (paired && i + 1u < n) w |= files_of_bin((bins4[(i + 1u) >> 1] >> (((i + 1u) & 1u) * 4u)) & 15u, sink_mask);   // a pair covers records i - 1 and i
+    wsize1[i] = (w & 1u) ? 4u + ld32(raw1 + rec_off1[i]) : 0u;
+    wsize2[i] = (w & 2u) ? 4u + ld32(raw2 + rec_off2[i]) : 0u;
+}
+
+constexpr uint32_t SCAN_ITEMS = 16, SCAN_TILE = 256 * SCAN_ITEMS;
+__global__ void __launch_bounds__(256)
+size_sum_kernel(const uint32_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ part)
+{
+    __shared__ uint32_t ws[4];
+    const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) s += (i0 + k < n) ? v[i0 + k] : 0u;
+    for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63u) == 0u) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0u) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void __launch_bounds__(1024)
+part_scan_kernel(uint32_t *__restrict__ part, uint32_t n_part, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t sh[1024];
+    const uint32_t t = threadIdx.x, per = (n_part + 1023u) / 1024u;
+    const uint32_t a = min(t * per, n_part), e = min(a + per, n_part);
+    uint32_t s = 0;
+    for (uint32_t k = a; k < e; ++k) s += part[k];
+    sh[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t x = t >= d ? sh[t - d] : 0u;
+        __syncthreads();
+        sh[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - s;
+    for (uint32_t k = a; k < e; ++k) { const uint32_t x = part[k]; part[k] = run; run += x; }
+    if (t == 1023u) *total = sh[1023];
+}
+
+__global__ void __launch_bounds__(256)
+size_place_kernel(const uint32_t *__restrict__ v, uint32_t n, const uint32_t *__restrict__ part, uint32_t *__restrict__ place)
+{
+    __shared__ uint32_t ws[4];
+    const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t x[SCAN_ITEMS], s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) { x[k] = (i0 + k < n) ? v[i0 + k] : 0u; s += x[k]; }
+    uint32_t incl = s;                                                      // inclusive scan of the lanes' sums inside the wave
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += y; }
+    if (lane == 63u) ws[wave] = incl;
+    __syncthreads();
+    uint32_t base = part[blockIdx.x] + incl - s;
+    for (uint32_t w = 0; w < wave; ++w) base += ws[w];
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+        if (i0 + k < n) { place[i0 + k] = x[k] ? base : NO_RECORD; base += x[k]; }
+}
+
+// W3: a wave per record
+__global__ void __launch_bounds__(256)
+pack_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ wsize,
+            const uint32_t *__restrict__ place, uint32_t n, uint8_t *__restrict__ packed)
+{
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= n) return;
+    const uint32_t size = wsize[i];
+    if (size == 0u) return;
+    const uint8_t *src = raw + rec_off[i];
+    uint8_t *dst = packed + place[i];
+    for (uint32_t k = lane; k < size; k += 64u) dst[k] = src[k];
+}
+
 // ---- B5: one lane per pair --------------------------------------------------------------------------------------------
 struct FileRecs {
     const uint8_t *raw;
@@ -222,6 +314,9 @@ struct PerFile {
     uint8_t *d_raw = nullptr, *h_raw = nullptr;             // the inflated window: d_raw = a half of Slot::d_raw_all
     uint32_t *h_seg = nullptr, *d_seg = nullptr, *d_cnt = nullptr, *d_exit = nullptr, *d_base = nullptr;
     // what the inflate launch notes per block (slot_of): record starts and the stripper's fields of every record
+    // the records a sink takes, packed (xm_bamdev_fetch_wanted): bytes, and per record where it went (NO_RECORD: not taken)
+    uint8_t *d_packed = nullptr, *h_packed = nullptr;
+    uint32_t *d_wsize = nullptr, *d_place = nullptr, *h_place = nullptr, *d_part = nullptr;
     uint32_t *d_s_off = nullptr, *d_s_name_off = nullptr, *d_s_name_len = nullptr;
     int32_t *d_s_a = nullptr, *d_s_x = nullptr;
     uint8_t *d_s_flag = nullptr;
@@ -266,6 +361,7 @@ struct Slot {
     uint64_t up_len[2] = {0, 0};
     bool raw_issued = false;                 // ev_raw has been recorded at least once (stays true: waiting for a past event costs nothing)
     bool have_columns = false;
+    bool classified = false;                 // the fused pass has run on the slot's columns (its compact category stream is in d_bins4)
 };
 
 }  // namespace
@@ -322,6 +418,7 @@ void free_slot(Slot &sl)
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
         hfree(q.h_comp); q.d_comp = nullptr; q.d_raw = nullptr; hfree(q.h_raw);
+        dfree(q.d_packed); hfree(q.h_packed); dfree(q.d_wsize); dfree(q.d_place); hfree(q.h_place); dfree(q.d_part);
         hfree(q.h_seg); dfree(q.d_seg); dfree(q.d_cnt); dfree(q.d_exit); dfree(q.d_base);
         dfree(q.d_s_off); dfree(q.d_s_name_off); dfree(q.d_s_name_len); dfree(q.d_s_a); dfree(q.d_s_x); dfree(q.d_s_flag);
         q.slots_len = 0;
@@ -438,6 +535,7 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
         for (int f = 0; f < 2; ++f) {
             sl.pf[f].d_raw = sl.d_raw_all + f * sl.raw_stride;
             XMB_TRY(halloc(b, sl.pf[f].h_raw, (size_t)raw_bytes + 64));
+            XMB_TRY(dalloc(b, sl.pf[f].d_packed, (size_t)raw_bytes + 64)); XMB_TRY(halloc(b, sl.pf[f].h_packed, (size_t)raw_bytes + 64));
         }
         sl.raw_cap = raw_bytes;
     }
@@ -465,6 +563,8 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
             XMB_TRY(dalloc(b, q.d_name_off, n)); XMB_TRY(dalloc(b, q.d_name_len, n));
             XMB_TRY(dalloc(b, q.d_a, n)); XMB_TRY(dalloc(b, q.d_x, n));
             XMB_TRY(dalloc(b, q.d_rflag, n)); XMB_TRY(dalloc(b, q.d_lflag, n)); XMB_TRY(halloc(b, q.h_lflag, n));
+            XMB_TRY(dalloc(b, q.d_wsize, n)); XMB_TRY(dalloc(b, q.d_place, n)); XMB_TRY(halloc(b, q.h_place, n));
+            XMB_TRY(dalloc(b, q.d_part, n / SCAN_TILE + 8));
         }
         for (int c = 0; c < 4; ++c) XMB_TRY(dalloc(b, sl.d_col[c], n));
         XMB_TRY(dalloc(b, sl.d_bits, n / 64 + 2));
@@ -506,6 +606,7 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     memset(out, 0, sizeof *out);
     out->mismatch_at = -1;
     sl.have_columns = false;
+    sl.classified = false;
     XMB_HIP(b, hipSetDevice(b->device));
     hipStream_t st = sl.stream;
     static const bool profile = getenv("XM_BAMDEV_PROFILE") != nullptr;
@@ -537,8 +638,6 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
             // (the other slot's stream finished its window before the caller could know what to carry; its copy of the window
             // to the host may still be on its way)
             XMB_HIP(b, hipMemcpyAsync(q.d_raw, src.d_raw + x.carry_off, (size_t)x.carry_len, hipMemcpyDeviceToDevice, st));
-            if (b->slot[x.carry_slot].raw_issued) XMB_HIP(b, hipEventSynchronize(b->slot[x.carry_slot].ev_raw));
-            memmove(q.h_raw, src.h_raw + x.carry_off, (size_t)x.carry_len);
         }
         q.raw_len = x.carry_len + new_bytes[f];
         // segments: the carry (when there is one), then every block; the launch's block table holds both files
@@ -610,15 +709,7 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         XMB_HIP(b, hipMemcpyAsync(sl.h_crc, sl.d_crc, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
     }
     XMB_HIP(b, hipEventRecord(sl.ev[1], st));
-    // the inflated window goes back for the writer on the copy stream, behind the inflate launch (and the carry) only
-    XMB_HIP(b, hipEventRecord(sl.ev_inflated, st));
-    XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
-    for (int f = 0; f < 2; ++f)
-        if (new_bytes[f])
-            XMB_HIP(b, hipMemcpyAsync(sl.pf[f].h_raw + in[f].carry_len, sl.pf[f].d_raw + in[f].carry_len, (size_t)new_bytes[f],
-                                      hipMemcpyDeviceToHost, sl.copy_stream));
-    XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
-    sl.raw_issued = true;
+    // (what of the inflated window goes back for the writer is asked for afterwards: xm_bamdev_fetch_wanted / _fetch_raw)
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
         const uint32_t n_seg = q.h_summary[8];
@@ -762,6 +853,62 @@ int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes)
     return XM_OK;
 }
 
+int xm_bamdev_fetch_raw(xm_bamdev *b, int slot)
+{
+    if (!b || slot < 0 || slot > 1) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    XMB_HIP(b, hipSetDevice(b->device));
+    XMB_HIP(b, hipEventRecord(sl.ev_inflated, sl.stream));
+    XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
+    for (int f = 0; f < 2; ++f)
+        if (sl.pf[f].raw_len)
+            XMB_HIP(b, hipMemcpyAsync(sl.pf[f].h_raw, sl.pf[f].d_raw, (size_t)sl.pf[f].raw_len, hipMemcpyDeviceToHost, sl.copy_stream));
+    XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
+    sl.raw_issued = true;
+    return XM_OK;
+}
+
+int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_text *out)
+{
+    if (!b || slot < 0 || slot > 1 || !out) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (n_records > sl.record_cap || n_records > 0xFFFFFFF0ull || !sl.have_columns || !sl.classified) return XM_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->raw1 = sl.pf[0].h_packed; out->raw2 = sl.pf[1].h_packed;
+    out->off1 = sl.pf[0].h_place; out->off2 = sl.pf[1].h_place;
+    XMB_HIP(b, hipSetDevice(b->device));
+    hipStream_t st = sl.stream;
+    const uint32_t n = (uint32_t)n_records;
+    if (n) {
+        const uint32_t n_part = (n + SCAN_TILE - 1u) / SCAN_TILE;
+        want_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(sl.pf[0].d_raw, sl.pf[1].d_raw, sl.pf[0].d_rec_off, sl.pf[1].d_rec_off, sl.d_bins4, n, paired ? 1 : 0,
+                                                       sink_mask, sl.pf[0].d_wsize, sl.pf[1].d_wsize);
+        for (int f = 0; f < 2; ++f) {
+            PerFile &q = sl.pf[f];
+            size_sum_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part);
+            part_scan_kernel<<<1, 1024, 0, st>>>(q.d_part, n_part, sl.d_state + 8 + f);
+            size_place_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part, q.d_place);
+            pack_kernel<<<(n + 3u) / 4u, 256, 0, st>>>(q.d_raw, q.d_rec_off, q.d_wsize, q.d_place, n, q.d_packed);
+        }
+        XMB_HIP(b, hipMemcpyAsync(sl.h_state + 8, sl.d_state + 8, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        XMB_HIP(b, hipEventRecord(sl.ev_wait, st));
+        XMB_HIP(b, hipEventSynchronize(sl.ev_wait));
+        if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
+        out->bytes1 = sl.h_state[8]; out->bytes2 = sl.h_state[9];
+        if (out->bytes1 > sl.raw_cap || out->bytes2 > sl.raw_cap) return XM_ERR_HIP;
+    }
+    // the packed records and the table of where each went, on the copy stream (the kernels above have finished)
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        const uint64_t bytes = f == 0 ? out->bytes1 : out->bytes2;
+        if (bytes) XMB_HIP(b, hipMemcpyAsync(q.h_packed, q.d_packed, (size_t)bytes, hipMemcpyDeviceToHost, sl.copy_stream));
+        if (n) XMB_HIP(b, hipMemcpyAsync(q.h_place, q.d_place, (size_t)n * 4, hipMemcpyDeviceToHost, sl.copy_stream));
+    }
+    XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
+    sl.raw_issued = true;
+    return XM_OK;
+}
+
 int xm_bamdev_raw_wait(xm_bamdev *b, int slot)
 {
     if (!b || slot < 0 || slot > 1) return XM_ERR_INVALID_ARG;
@@ -782,7 +929,7 @@ int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int
     *idx = sl.h_idx;
     memset(bin_offsets, 0, 8 * sizeof(uint64_t));
     memset(counts, 0, 64 * sizeof(uint64_t));
-    if (n_records == 0) return XM_OK;
+    if (n_records == 0) { sl.classified = true; return XM_OK; }
     XMB_HIP(b, hipSetDevice(b->device));
     hipStream_t st = sl.stream;
     const int rc = xm_classify_compact_dev(b->ctx, st, mode, n_records, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3], sl.d_bits,
@@ -803,6 +950,7 @@ int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int
     }
     memcpy(bin_offsets, sl.h_off_counts, 8 * sizeof(uint64_t));
     memcpy(counts, sl.h_off_counts + 8, 64 * sizeof(uint64_t));
+    sl.classified = true;
     return XM_OK;
 }
 

@@ -1349,6 +1349,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         if blk.unaligned or blk.weird:
             with prof("parse"):
                 # the whole windows as text, then the text rules (exactly the host path's semantics for this window)
+                bamdev.fetch_raw(which)
                 bamdev.raw_wait(which)                               # the inflated bytes must have arrived
                 texts, tables = [], []
                 for f in (0, 1):
@@ -1373,6 +1374,10 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             # queued (issued later, from the main thread, it waits behind that launch: 25-30 ms a window)
             with prof("classify"):
                 blk.classified = bamdev.classify(which, mode, blk.n, _floor_min_score(min_score))
+                # the bins are on the device: only the records a sink takes come back, packed (half of a window)
+                blk.packed = bamdev.fetch_wanted(which, blk.n, paired, sum(1 << b for b in range(6) if sinks[b]))
+        else:
+            bamdev.fetch_raw(which)                                  # values the text rules must decide, or nothing: the whole windows
 
         def finish():
             # the records' SAM text, printed by the host threads when the block is settled -- in the main thread, while the
@@ -1383,22 +1388,17 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 prof["bam_wait_raw"] = prof.get("bam_wait_raw", 0.0) + time.perf_counter() - t_w
                 loffs, llens = [], []
                 # A unit's lines come from ONE file (primary bins: file 1, secondary bins: file 2, unresolved: both; :423-448),
-                # and a bin without a sink prints nothing: with the bins known already, only those records are printed
+                # and a bin without a sink prints nothing: with the bins known on the device, only those records came back
+                # (packed; their table says where each went), and only those are printed
                 wanted = [None, None]
-                if blk.classified is not None:
-                    _code, idx, off, _counts = blk.classified
-                    wanted = [np.zeros(blk.n, dtype=np.uint8), np.zeros(blk.n, dtype=np.uint8)]
-                    for b in range(6):
-                        if not sinks[b]:
-                            continue
-                        seg = idx[int(off[b]):int(off[b + 1])]
-                        for f in ((0,) if b in (0, 2, 5) else (1,) if b in (1, 3) else (0, 1)):
-                            wanted[f][seg] = 1
-                            if paired:
-                                wanted[f][seg - 1] = 1               # a paired unit covers records idx - 1 and idx
+                raw_addr, off_addr = blk.raw_addr, blk.rec_off_addr
+                if blk.packed is not None:
+                    raw_addr, places, _bytes = blk.packed
+                    off_addr = [places[0].ctypes.data if blk.n else 0, places[1].ctypes.data if blk.n else 0]
+                    wanted = [(places[f] != 0xFFFFFFFF).view(np.uint8) for f in (0, 1)]
                 t_p = time.perf_counter()
                 for f in (0, 1):
-                    text, loff, llen, _got = print_records(which, f, blk.raw_addr[f], blk.rec_off_addr[f], blk.n, sparse=True,
+                    text, loff, llen, _got = print_records(which, f, raw_addr[f], off_addr[f], blk.n, sparse=True,
                                                            wanted=wanted[f])
                     texts[f] = text
                     loffs.append(loff); llens.append(llen)
