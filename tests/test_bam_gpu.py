@@ -3,6 +3,7 @@ against the text rules of the reference's plugins applied to the printed SAM tex
 `samtools view` would print, restated by oracle/bam_oracle.py / the host decoder), and the whole file path with either
 BAM front end byte for byte.  The reference code this path replaces: getBamReadPairs / bam_lines, xenomapper.py:56-93, with
 get_tag / get_tag_with_ZS_as_XS :176-206 on the lines."""
+import ctypes
 import io
 import os
 import sys
@@ -250,5 +251,60 @@ def test_bytes_sent_ahead_are_the_bytes_the_run_would_have_sent(ctx, tmp_path):
             assert np.array_equal(blk.unit_bits, want[4])
         with pytest.raises(ValueError):
             again((1.0, 1.0), grow=True)                                   # the buffers grew: nothing is on the device any more
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("paired,mode", [(True, 1), (True, 2), (False, 0)])
+def test_only_the_records_a_sink_takes_come_back(ctx, tmp_path, paired, mode):
+    """xm_bamdev_fetch_wanted: with the bins on the device, the records that go back to the host are exactly those of units whose
+    bin has a sink -- file 1's records for bins 0, 2, 5, file 2's for bins 1, 3, both for bin 4 (xenomapper.py:423-448; a paired
+    unit = records i - 1 and i) -- packed next to each other, byte for byte the records of the whole window, in input order; every
+    other record's table entry says so.  All sink masks with one or two sinks missing, and none / all."""
+    import struct
+    import bench_bam
+    from xenomapper_amd import _ffi
+    paths = []
+    for tag in ("human", "mouse"):
+        p = str(tmp_path / ("%s.bam" % tag))
+        bench_bam.tiled_bam(os.path.join(DATA, "paired_end_testdata_%s.bam" % tag), p, 6)
+        paths.append(p)
+    images = [open(p, "rb").read() for p in paths]
+    dev = _ffi.BamDev(ctx)
+    try:
+        blk, readers = run_whole_files(dev, images, 0, paired)           # the whole windows on the host as well (wait_raw)
+        for r in readers:
+            r.close()
+        n = blk.n
+        assert n > 1000 and not blk.n_exceptions
+        raws = [np.ctypeslib.as_array((ctypes.c_uint8 * blk.raw_len[f]).from_address(blk.raw_addr[f])).copy() for f in (0, 1)]
+        rec = [np.ctypeslib.as_array((ctypes.c_uint32 * blk.n_rec[f]).from_address(blk.rec_off_addr[f])).copy() for f in (0, 1)]
+        code, idx, off, _counts = dev.classify(0, mode, n, -2**31)
+        idx, off = idx.copy(), off.copy()
+        masks = [0, 0b111111, 0b000001, 0b010010, 0b101101, 0b011111, 0b110111]
+        for sink_mask in masks:
+            want = [np.zeros(n, dtype=bool), np.zeros(n, dtype=bool)]
+            for b in range(6):
+                if not (sink_mask >> b) & 1:
+                    continue
+                seg = idx[int(off[b]):int(off[b + 1])].astype(np.int64)
+                for f in ((0,) if b in (0, 2, 5) else (1,) if b in (1, 3) else (0, 1)):
+                    want[f][seg] = True
+                    if paired:
+                        want[f][seg - 1] = True
+            addrs, places, nbytes = dev.fetch_wanted(0, n, paired, sink_mask)
+            dev.raw_wait(0)
+            for f in (0, 1):
+                place = places[f].copy()
+                assert np.array_equal(place != 0xFFFFFFFF, want[f]), (sink_mask, f)
+                packed = np.ctypeslib.as_array((ctypes.c_uint8 * max(nbytes[f], 1)).from_address(addrs[f]))[:nbytes[f]]
+                at = 0
+                for i in np.flatnonzero(want[f]).tolist():
+                    o = int(rec[f][i])
+                    size = 4 + struct.unpack_from("<I", raws[f], o)[0]
+                    assert int(place[i]) == at, (sink_mask, f, i)
+                    assert bytes(packed[at:at + size]) == bytes(raws[f][o:o + size])
+                    at += size
+                assert at == nbytes[f]
     finally:
         dev.close()
