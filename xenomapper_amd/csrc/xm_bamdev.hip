@@ -16,8 +16,11 @@
 //   B4 parse_kernel  the carried tail's records, a lane per record (the same parse_record);
 //   B5 pair_kernel   one lane per PAIR of records k of the two files: score columns, names compared (:106 across files,
 //                    :402 between neighbours -> unit mask by ballot), first mismatch by atomicMin.
-// The inflated bytes and the record table also go back to the host (page-locked, on a copy stream of the slot's own), where the
-// writer prints the SAM text of the records a sink takes (xmh_bam_print).
+// Then the fused pass on the columns (xm_bamdev_classify), and with the bins on the device:
+//   W1 want_kernel   marks the records a sink takes (a unit's lines come from one file: :423-448) and notes their sizes;
+//   W2 size_sum / part_scan / size_place: where each goes;   W3 pack_kernel: the records next to each other.
+// Those records, the table of where each went and the record table go back to the host (page-locked, on a copy stream of the
+// slot's own), where the writer prints their SAM text (xmh_bam_print); the whole windows only on request (xm_bamdev_fetch_raw).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
