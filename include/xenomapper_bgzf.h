@@ -68,8 +68,9 @@ int xm_bgzf_inflate_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm
 /* The same launch for windows of BAM: after a chain has written block k it also follows the alignment records' block_size chain
  * through that block and reads what the classifier needs out of every record, while the block is still near the CU that wrote
  * it (`out + raw_base` = first byte of the file's window, positions count from there): slots[0 .. *count) = where the records
- * that begin in [start, end) begin; name_off / name_len / a / x / flag [0 .. *count) = the record fields of xm_bamdev's stripper
- * (x0 = 'X' or 'Z': which tag plays XS; x0 = 0: record starts only); *exit_at = where the chain leaves the block (== end when the
+ * that begin in [start, end) begin; name_off / name_len / a / x / flag / n_cigar / cig_at [0 .. *count) = the record fields of
+ * xm_bamdev's stripper (tags: which tags are read -- 'X' | 'A' << 8 | 'S' << 16: AS and XS; 'Z' | ...: AS and ZS;
+ * 'X' | 'N' << 8 | 'M' << 16 | 1 << 24: NM, first match, and XS, the --cigar_scores plugin -- 0: record starts only); *exit_at = where the chain leaves the block (== end when the
  * next block begins with a record; 0xFFFFFFFF: the block failed, or it holds more than slot_cap records); a record that does not
  * end in front of n_raw (the window's end) ends the walk, and so does a size word cut by the block's end.  Entries with
  * end <= start are skipped.  walk[] (device memory) has n_blocks entries; all arrays are device memory of slot_cap entries. */
@@ -83,7 +84,8 @@ typedef struct {
     uint32_t *name_off, *name_len;
     int32_t  *a, *x;
     uint8_t  *flag;
-    uint32_t x0, reserved;
+    uint32_t *n_cigar, *cig_at;      /* the records' CIGAR operations: how many, where in the window (may both be null)          */
+    uint32_t tags, reserved;
 } xm_bgzf_walk;
 int xm_bgzf_inflate_walk_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm_bgzf_block *blocks, uint64_t n_blocks,
                              uint8_t *out, uint32_t *status, uint32_t *work, const xm_bgzf_walk *walk);
@@ -161,7 +163,10 @@ uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file);
  * the slot is idle (its last xm_bamdev_run has returned, the next has not begun): the next run, told so in `uploaded`, waits for
  * the copy instead of making it.  A later xm_bamdev_reserve that grows the buffers forgets what was sent. */
 int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes);
-/* inflate, find the records, strip, pair.  Blocking (the slot's own stream).  The inflated windows stay on the device: what the
+/* inflate, find the records, strip, pair.  score_mode: XMS_SCORE_AS_XS, XMS_SCORE_AS_ZS, or XMS_SCORE_CIGAR (get_cigarbased_AS_tag,
+ * xenomapper.py:228-256: column "AS" then holds NM -- the FIRST optional field that holds the letters decides, :247-250 -- and
+ * xm_bamdev_classify makes the packed CIGAR columns of the records' CIGAR words and runs xm_classify_compact_cigar_packed_dev).
+ * Blocking (the slot's own stream).  The inflated windows stay on the device: what the
  * writer needs of them is asked for afterwards, one of */
 int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
                   uint64_t max_records, xm_bamdev_block *out);
@@ -184,6 +189,11 @@ int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int
 /* the slot's score columns and unit mask copied to the host (records the caller must patch by the text rules) */
 int xm_bamdev_columns(xm_bamdev *b, int slot, uint64_t n_records, int32_t *as1, int32_t *xs1, int32_t *as2, int32_t *xs2,
                       uint64_t *unit_bits);
+/* After a XMS_SCORE_CIGAR run: the packed CIGAR columns (include/xenomapper_hip.h) the device made of one file's first n_records
+ * records -- NM, and the records' own CIGAR words (BAM stores them as the kernel reads them: len << 4 | op) -- copied to the host;
+ * arguments as xm_strip_cigar_columns.  For tests and for callers that want the columns themselves. */
+int xm_bamdev_cigar_columns(xm_bamdev *b, int slot, int file, uint64_t n_records, int32_t *nm, uint8_t *cig_cnt, uint32_t *cig_tile,
+                            uint32_t *cig_ops, uint64_t ops_capacity, uint64_t *n_ops);
 const char *xm_bamdev_last_error(const xm_bamdev *b);
 
 #ifdef __cplusplus

@@ -42,15 +42,16 @@ def host_text(image):
     return bytes(buf[:at])
 
 
-def expected_from_text(line, tag):
+def expected_from_text(line, tag, first_decides=False):
     """What the device must report for one record and tag, from the printed line: (value or ABSENT, flag 0 / 1 NONINT / 2 DUP).
     The plugins match a tag as a substring of any optional field (xenomapper.py:186) and raise on two matches (:189-190); the
-    device vouches for a value only when the ONE matching field is the tag's own integer-typed field inside int32."""
+    device vouches for a value only when the ONE matching field is the tag's own integer-typed field inside int32.
+    first_decides: NM as get_cigarbased_AS_tag reads it (:247-250) -- the first matching field, however many follow."""
     fields = line.split(b"\t")[11:]
     hits = [x for x in fields if tag in x]
     if not hits:
         return ABSENT, 0
-    if len(hits) > 1:
+    if len(hits) > 1 and not first_decides:
         return ABSENT, 2
     parts = hits[0].split(b":")
     if hits[0][:2] == tag and len(parts) == 3 and parts[1] == b"i":
@@ -91,11 +92,12 @@ def run_whole_files(dev, images, score_mode, paired, halo=False):
 
 
 @settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "80")), deadline=None, suppress_health_check=list(HealthCheck))
-@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share")), score_mode=st.sampled_from([0, 1]), paired=st.booleans())
+@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share")), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans())
 def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mode, paired):
     """Record by record: value and flag of AS and XS (or ZS) exactly as the printed text dictates (a flag must be justified and
     a justified flag must be raised), names (unit mask, first mismatch), the walk's outcome, and `weird` exactly when a
-    line holds a byte the text rules could split at."""
+    line holds a byte the text rules could split at.  score_mode 2 (--cigar_scores): NM in place of AS by the first-field rule,
+    and the packed CIGAR columns the device makes of the records' CIGAR words against xm_cigar_pack of the printed CIGARs."""
     from xenomapper_amd import _ffi
     dev = _ffi.BamDev(ctx)
     try:
@@ -119,7 +121,7 @@ def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mod
         flags = blk.line_flags
         for k in range(n):
             for f in (0, 1):
-                va, fa = expected_from_text(lines[f][k], b"AS")
+                va, fa = expected_from_text(lines[f][k], b"NM", True) if score_mode == 2 else expected_from_text(lines[f][k], b"AS")
                 vx, fx = expected_from_text(lines[f][k], xtag)
                 assert (int(cols[2 * f][k]), (int(flags[f][k]) >> 2) & 7) == (va, fa), (k, f, lines[f][k])
                 assert (int(cols[2 * f + 1][k]), (int(flags[f][k]) >> 5) & 3) == (vx, fx), (k, f, lines[f][k])
@@ -127,6 +129,23 @@ def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mod
         want_bits = [(1 if (k > 0 and names[0][k] == names[0][k - 1]) else 0) if paired else 1 for k in range(n)]
         assert bits.tolist() == want_bits
         assert blk.n_exceptions == sum(1 for k in range(n) if (int(flags[0][k]) | int(flags[1][k])) & 0x7C)
+        if score_mode == 2 and n:
+            import re
+            letters = {c: k for k, c in enumerate("MIDNSHP=X")}
+            for f in (0, 1):
+                nm, cnt, tile, ops = dev.cigar_columns(0, f, n)
+                assert (nm == cols[2 * f][:n]).all()
+                assert int(cnt.max()) < 255                         # (records with 255 operations and more: the test below)
+                ends = np.cumsum(cnt.astype(np.int64))
+                assert int(ends[-1]) == ops.shape[0] == int(tile[-1])
+                assert (tile[:-1] == (ends - cnt)[::256]).all()
+                for k in range(n):
+                    # operation codes above 8 print as letters the reference's pattern (:251) skips; the device keeps such words
+                    # and the kernel scores I, D and S only
+                    mine = [int(w) for w in ops[int(ends[k]) - int(cnt[k]):int(ends[k])] if (int(w) & 15) <= 8]
+                    text = [(int(ln) << 4) | letters[op]
+                            for ln, op in re.findall(r"([0-9]+)([MIDNSHPX=])", lines[f][k].split(b"\t")[5].decode("latin-1"))]
+                    assert mine == text, (f, k, lines[f][k])
         # the printed text of the records is the host decoder's text
         for f in (0, 1):
             text = np.empty(max(1 << 16, 8 * len(images[f])), dtype=np.uint8)
@@ -141,13 +160,14 @@ def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mod
 
 
 def run_path(paths, gpu, conservative=False, tag="AS"):
+    """tag: "AS" get_tag, "ZS" get_tag_with_ZS_as_XS, "NM" get_cigarbased_AS_tag."""
     """classify_sam_files(bam=True) with either BAM front end -> (six texts, counts) or the exception it raises."""
     from xenomapper_amd import xenomapper as xm
     os.environ["XENOMAPPER_GPU_BAM"] = "1" if gpu else "0"
     sinks = [io.StringIO() for _ in range(6)]
     try:
         counts = xm.classify_sam_files(paths[0], paths[1], *sinks, paired=True, conservative=conservative, bam=True,
-                                       tag_func=xm.get_tag if tag == "AS" else xm.get_tag_with_ZS_as_XS)
+                                       tag_func={"AS": xm.get_tag, "ZS": xm.get_tag_with_ZS_as_XS, "NM": xm.get_cigarbased_AS_tag}[tag])
     except Exception as exc:                                        # noqa: BLE001
         return type(exc).__name__, [s.getvalue() for s in sinks]
     finally:
@@ -169,9 +189,9 @@ def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, m
         paths.append(p)
     want = run_path(paths, gpu=False)
     monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 1 << 20)
-    for conservative in (False, True):
-        ref = run_path(paths, gpu=False, conservative=conservative) if conservative else want
-        got = run_path(paths, gpu=True, conservative=conservative)
+    for conservative, tag in ((False, "AS"), (True, "AS"), (False, "NM")):
+        ref = run_path(paths, gpu=False, conservative=conservative, tag=tag) if (conservative or tag != "AS") else want
+        got = run_path(paths, gpu=True, conservative=conservative, tag=tag)
         assert got[0] == ref[0]
         assert got[1] == ref[1]
     assert sum(want[0].values()) == 40 * 238
@@ -180,7 +200,7 @@ def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, m
 
 
 @settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "60")), deadline=None, suppress_health_check=list(HealthCheck))
-@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share"), bam_file_pair()), tag=st.sampled_from(["AS", "ZS"]),
+@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share"), bam_file_pair()), tag=st.sampled_from(["AS", "ZS", "NM"]),
        conservative=st.booleans())
 def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, tag, conservative):
     """Typed tags at the int32 edges, floats and characters under the tags' names, strings that merely contain the letters,
@@ -196,6 +216,74 @@ def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, t
     want = run_path(paths, gpu=False, conservative=conservative, tag=tag)
     got = run_path(paths, gpu=True, conservative=conservative, tag=tag)
     assert got == want
+
+
+def _cigar_bam(n, seed, n_ops_of):
+    """n records, mates r0 r0 r1 r1 .., with NM and XS tags; record k has n_ops_of(k) CIGAR operations (M / I / D / S / N mixed)."""
+    import struct
+    from tests.test_host_fuzz import _bam_image_of
+    rng = np.random.default_rng(seed)
+    recs = []
+    for k in range(n):
+        name = b"r%d\0" % (k // 2)
+        c = n_ops_of(k)
+        words = (rng.integers(1, 40, size=c).astype(np.uint32) << 4) | rng.choice(np.array([0, 0, 1, 2, 4, 3], dtype=np.uint32), size=c)
+        tags = b""
+        if k % 7 != 3:
+            tags += b"NMC" + bytes([int(rng.integers(0, 9))])
+        if k % 5 == 1:
+            tags += b"XSc" + struct.pack("<b", int(rng.integers(-60, 0)))
+        core = struct.pack("<iiBBHHHIiii", 0, 100 + k, len(name), 30, 4680, c, 0, 0, -1, -1, 0)
+        body = core + name + words.astype("<u4").tobytes() + tags
+        recs.append(struct.pack("<I", len(body)) + body)
+    return _bam_image_of(recs, aligned=True)
+
+
+def test_cigar_columns_made_on_the_device_with_255_operations_and_more(ctx, tmp_path):
+    """--cigar_scores on the GPU BAM front end: records with 0, 254, 255, 256 and 3000 CIGAR operations (count byte 255 + trailer
+    word), more than one tile of 256 records: the device's packed CIGAR columns equal xm_cigar_pack of the files' own CIGAR words,
+    and the whole file path equals the host decoder's (which is pinned to the reference's text rule, xenomapper.py:228-256)."""
+    from xenomapper_amd import _ffi
+    import struct
+    sizes = {5: 254, 6: 255, 7: 256, 300: 3000, 511: 255, 512: 0, 513: 700}
+    images = [_cigar_bam(700, 11, lambda k: sizes.get(k, k % 6)), _cigar_bam(700, 12, lambda k: sizes.get(k + 1, (k + 2) % 5))]
+    dev = _ffi.BamDev(ctx)
+    try:
+        blk, readers = run_whole_files(dev, images, 2, False)
+        assert not blk.bad_block and not blk.unaligned and not blk.weird and blk.n == 700 and blk.n_exceptions == 0
+        for f in (0, 1):
+            raw = __import__("gzip").decompress(images[f])
+            at = readers[f].records_start()
+            per, nms = [], []
+            while at < len(raw):
+                size, = struct.unpack_from("<I", raw, at)
+                l_name, n_cig = raw[at + 12], struct.unpack_from("<H", raw, at + 16)[0]
+                p = at + 36 + l_name
+                per.append(np.frombuffer(raw, dtype="<u4", count=n_cig, offset=p))
+                tags = raw[p + 4 * n_cig:at + 4 + size]
+                nms.append(tags[3] if tags[:2] == b"NM" else ABSENT)
+                at += 4 + size
+            off = np.cumsum([0] + [x.shape[0] for x in per]).astype(np.uint32)
+            w_cnt, w_tile, w_ops = _ffi.cigar_pack(off, np.concatenate(per).astype(np.uint32))
+            nm, cnt, tile, ops = dev.cigar_columns(0, f, blk.n)
+            assert nm.tolist() == nms
+            assert (cnt == w_cnt).all() and (tile == w_tile).all() and (ops == w_ops).all()
+        for r in readers:
+            r.close()
+    finally:
+        dev.close()
+    paths = []
+    for f, im in enumerate(images):
+        paths.append(str(tmp_path / ("c%d.bam" % f)))
+        with open(paths[-1], "wb") as fh:
+            fh.write(im)
+    for conservative in (False, True):
+        want = run_path(paths, gpu=False, conservative=conservative, tag="NM")
+        got = run_path(paths, gpu=True, conservative=conservative, tag="NM")
+        assert isinstance(want[0], dict) and sum(want[0].values()) == 350
+        assert got == want
+    from xenomapper_amd import xenomapper as xm
+    assert xm.LAST_FILE_PROFILE.get("strip_kernels_ms", 0) > 0      # the device path really ran
 
 
 def test_bytes_sent_ahead_are_the_bytes_the_run_would_have_sent(ctx, tmp_path):

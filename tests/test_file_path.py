@@ -263,7 +263,7 @@ def test_bam_input_equals_sam_input(mode_case, via, tmp_path):
 
 @pytest.mark.parametrize("front_end", ["gpu", "host"])
 @pytest.mark.parametrize("window", [1500, 20000])
-@pytest.mark.parametrize("mode_case", ["ref_pe_liberal", "ref_pe_conservative_min99_5"])
+@pytest.mark.parametrize("mode_case", ["ref_pe_liberal", "ref_pe_conservative_min99_5", "ref_pe_liberal_cigar"])
 def test_bam_input_in_small_windows(mode_case, window, front_end, tmp_path, monkeypatch):
     """Many windows per file: every refill moves the unread tail in front of the text the decoder thread has produced
     meanwhile, while the lines of the previous window are still being written (1500 bytes is a handful of lines: some

@@ -192,7 +192,7 @@ def test_records_found_and_read_by_the_inflating_chains(ctx, tmp_path):
         cnt = torch.full((nb,), -7, dtype=torch.int32, device=dev)
         ext = torch.full((nb,), -7, dtype=torch.int32, device=dev)
         cap = 65536 // 36 + 2
-        slots, name_off, name_len, a, x = (torch.full((nb * cap,), -1, dtype=torch.int32, device=dev) for _ in range(5))
+        slots, name_off, name_len, a, x, ncig, cig_at = (torch.full((nb * cap,), -1, dtype=torch.int32, device=dev) for _ in range(7))
         flag = torch.full((nb * cap,), 0xEE, dtype=torch.uint8, device=dev)
         walk = np.zeros(nb, dtype=_ffi.BGZF_WALK)
         starts = blocks["out_off"].astype(np.int64).copy()
@@ -204,14 +204,15 @@ def test_records_found_and_read_by_the_inflating_chains(ctx, tmp_path):
             at = 4 * cap * k
             walk[k] = (0, max(int(starts[k]), first) if k == j0 else int(starts[k]), int(ends[k]), n_raw, cap,
                        cnt.data_ptr() + 4 * k, ext.data_ptr() + 4 * k, slots.data_ptr() + at, name_off.data_ptr() + at,
-                       name_len.data_ptr() + at, a.data_ptr() + at, x.data_ptr() + at, flag.data_ptr() + cap * k, ord("X"), 0)
+                       name_len.data_ptr() + at, a.data_ptr() + at, x.data_ptr() + at, flag.data_ptr() + cap * k,
+                       ncig.data_ptr() + at, cig_at.data_ptr() + at, _ffi.BGZF_TAGS_AS_XS, 0)
         d_walk = torch.from_numpy(walk.view(np.uint8)).to(dev)
         ctx.bgzf_inflate_dev(comp, d_blocks, out, status, work, walk=d_walk)
         torch.cuda.synchronize()
         assert (status.cpu().numpy() == 0).all()
         assert np.array_equal(out[:total].cpu().numpy(), want)
         h_cnt, h_ext = cnt.cpu().numpy(), ext.cpu().numpy().view(np.uint32)
-        h = [t.cpu().numpy().reshape(nb, cap) for t in (slots, name_off, name_len, a, x, flag)]
+        h = [t.cpu().numpy().reshape(nb, cap) for t in (slots, name_off, name_len, a, x, flag, ncig, cig_at)]
         # the text of all records, to read names and tags from (the printer is pinned to the oracle in test_host_fuzz)
         rec_all = np.empty(total // 36 + 8, dtype=np.uint32)
         n_all, _stop = _host.bam_walk(want.ctypes.data, total, first, rec_all)
@@ -246,6 +247,9 @@ def test_records_found_and_read_by_the_inflating_chains(ctx, tmp_path):
                         wantv = int(tags[tag].split(b":")[2]) if tag in tags else -2**31
                         assert int(h[col][k, i]) == wantv, (k, i, tag)
                     assert int(h[5][k, i]) == 0
+                    # the CIGAR words where the record says they are, as many as its header says
+                    n_cigar = int(want[r + 4 + 12]) | int(want[r + 4 + 13]) << 8
+                    assert int(h[6][k, i]) == n_cigar and int(h[7][k, i]) == r + 36 + int(want[r + 4 + 8])
             lands += int(k + 1 < nb and p == int(walk["end"][k]))
         walked = int((walk["end"] > 0).sum())
         if aligned:

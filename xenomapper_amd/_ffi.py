@@ -163,6 +163,7 @@ def lib():
         "xm_bamdev_upload": ([P, I, I, U64], I),
         "xm_bamdev_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_bamdev_columns": ([P, I, U64, P, P, P, P, P], I),
+        "xm_bamdev_cigar_columns": ([P, I, I, U64, P, P, P, P, U64, ctypes.POINTER(ctypes.c_uint64)], I),
         "xm_bamdev_last_error": ([P], ctypes.c_char_p),
     }
     for name, (args, res) in sig.items():
@@ -187,7 +188,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
             "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_upload", "xm_bamdev_classify",
-            "xm_bamdev_columns", "xm_bamdev_last_error")
+            "xm_bamdev_columns", "xm_bamdev_cigar_columns", "xm_bamdev_last_error")
 
 
 def _np_ptr(a):
@@ -684,8 +685,12 @@ BGZF_BLOCK = np.dtype([("cdata_off", np.uint64), ("out_off", np.uint64), ("cdata
 assert BGZF_BLOCK.itemsize == 24
 BGZF_WALK = np.dtype([("raw_base", np.uint64), ("start", np.uint32), ("end", np.uint32), ("n_raw", np.uint32), ("slot_cap", np.uint32),
                       ("count", np.uint64), ("exit_at", np.uint64), ("slots", np.uint64), ("name_off", np.uint64), ("name_len", np.uint64),
-                      ("a", np.uint64), ("x", np.uint64), ("flag", np.uint64), ("x0", np.uint32), ("reserved", np.uint32)])
-assert BGZF_WALK.itemsize == 96                                     # xm_bgzf_walk (device addresses)
+                      ("a", np.uint64), ("x", np.uint64), ("flag", np.uint64), ("n_cigar", np.uint64), ("cig_at", np.uint64),
+                      ("tags", np.uint32), ("reserved", np.uint32)])
+assert BGZF_WALK.itemsize == 112                                    # xm_bgzf_walk (device addresses)
+BGZF_TAGS_AS_XS = ord("X") | ord("A") << 8 | ord("S") << 16
+BGZF_TAGS_AS_ZS = ord("Z") | ord("A") << 8 | ord("S") << 16
+BGZF_TAGS_NM_XS = ord("X") | ord("N") << 8 | ord("M") << 16 | 1 << 24
 BGZF_COMP_PAD = 1024
 
 
@@ -1058,3 +1063,17 @@ class BamDev(object):
         if n:
             self._check(self._L.xm_bamdev_columns(self._h, slot, n, *[_np_ptr(a) for a in out]), "xm_bamdev_columns")
         return out
+
+    def cigar_columns(self, slot, file, n_records):
+        """After a SCORE_CIGAR run: (nm int32, cig_cnt uint8, cig_tile uint32, cig_ops uint32) of one file, made on the device."""
+        n = int(n_records)
+        nm = np.empty(n, dtype=np.int32)
+        cnt = np.empty(n, dtype=np.uint8)
+        tile = np.zeros(cigar_tiles(n) + 1, dtype=np.uint32)
+        n_ops = ctypes.c_uint64()
+        self._check(self._L.xm_bamdev_cigar_columns(self._h, slot, file, n, _np_ptr(nm), _np_ptr(cnt), _np_ptr(tile), None, 0,
+                                                    ctypes.byref(n_ops)), "xm_bamdev_cigar_columns")
+        ops = np.zeros(max(int(n_ops.value), 1), dtype=np.uint32)
+        self._check(self._L.xm_bamdev_cigar_columns(self._h, slot, file, n, None, None, None, _np_ptr(ops), ops.shape[0],
+                                                    ctypes.byref(n_ops)), "xm_bamdev_cigar_columns")
+        return nm, cnt, tile, ops[:int(n_ops.value)]

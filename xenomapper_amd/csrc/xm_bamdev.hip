@@ -80,6 +80,7 @@ struct SlotArrays {
     const uint32_t *off, *name_off, *name_len;
     const int32_t *a, *x;
     const uint8_t *flag;
+    const uint32_t *n_cigar, *cig_at;        // --cigar_scores runs only (else null)
 };
 
 // B3 + B4 for the blocks: the record table and the per-record fields from the slots (one wave per segment), behind the scan's bases
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256)
 gather_kernel(SlotArrays sa, const uint32_t *__restrict__ seg_start, uint32_t n_carry_seg, uint32_t n_seg,
               const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ base, uint32_t *__restrict__ rec_off,
               uint32_t *__restrict__ name_off, uint32_t *__restrict__ name_len, int32_t *__restrict__ a, int32_t *__restrict__ x,
-              uint8_t *__restrict__ flag, uint32_t rec_cap)
+              uint8_t *__restrict__ flag, uint32_t *__restrict__ n_cigar, uint32_t *__restrict__ cig_at, uint32_t rec_cap)
 {
     const uint32_t s = n_carry_seg + blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (s >= n_seg) return;
@@ -102,6 +103,7 @@ gather_kernel(SlotArrays sa, const uint32_t *__restrict__ seg_start, uint32_t n_
         a[at] = sa.a[so + i];
         x[at] = sa.x[so + i];
         flag[at] = sa.flag[so + i];
+        if (sa.n_cigar != nullptr) { n_cigar[at] = sa.n_cigar[so + i]; cig_at[at] = sa.cig_at[so + i]; }
     }
 }
 
@@ -150,22 +152,24 @@ struct RecOut {
     uint32_t *name_len;       // without the NUL
     int32_t *a, *x;           // AS, and XS or ZS by mode; ABSENT = no match
     uint8_t *flag;            // ex_a | ex_x << 2 | R_WEIRD | R_BAD
+    uint32_t *n_cigar, *cig_at;   // --cigar_scores runs only (else null)
 };
 
 // n_dev: when not null, the number of records is read from there (at most n: the launch's upper bound)
 __global__ void __launch_bounds__(256)
 parse_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_off, uint32_t n, const uint32_t *__restrict__ n_dev,
-             uint32_t x0 /* 'X' or 'Z' */, RecOut o)
+             uint32_t tags /* xmrec::TAGS_* */, RecOut o)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (n_dev != nullptr) { const uint32_t m = *n_dev; n = m < n ? m : n; }
     if (i >= n) return;
-    const xmrec::RecFields f = xmrec::parse_record(raw, rec_off[i], x0);
+    const xmrec::RecFields f = xmrec::parse_record(raw, rec_off[i], tags);
     o.name_off[i] = f.name_off;
     o.name_len[i] = f.name_len;
     o.a[i] = f.a;
     o.x[i] = f.x;
     o.flag[i] = (uint8_t)f.flag;
+    if (o.n_cigar != nullptr) { o.n_cigar[i] = f.n_cigar; o.cig_at[i] = f.cig_at; }
 }
 
 // ---- the records a sink takes, packed for the way back ---------------------------------------------------------------------
@@ -229,6 +233,7 @@ part_scan_kernel(uint32_t *__restrict__ part, uint32_t n_part, uint32_t *__restr
     if (t == 1023u) *total = sh[1023];
 }
 
+template <bool ALL>          // ALL: every item gets its place (an empty one that of the next); else empty items get NO_RECORD
 __global__ void __launch_bounds__(256)
 size_place_kernel(const uint32_t *__restrict__ v, uint32_t n, const uint32_t *__restrict__ part, uint32_t *__restrict__ place)
 {
@@ -243,7 +248,7 @@ size_place_kernel(const uint32_t *__restrict__ v, uint32_t n, const uint32_t *__
     uint32_t base = part[blockIdx.x] + incl - s;
     for (uint32_t w = 0; w < wave; ++w) base += ws[w];
     for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
-        if (i0 + k < n) { place[i0 + k] = x[k] ? base : NO_RECORD; base += x[k]; }
+        if (i0 + k < n) { place[i0 + k] = (ALL || x[k]) ? base : NO_RECORD; base += x[k]; }
 }
 
 // W3: a wave per record
@@ -258,6 +263,36 @@ pack_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_of
     const uint8_t *src = raw + rec_off[i];
     uint8_t *dst = packed + place[i];
     for (uint32_t k = lane; k < size; k += 64u) dst[k] = src[k];
+}
+
+// ---- --cigar_scores: the records' CIGAR words as the packed CIGAR columns K1p reads (include/xenomapper_hip.h) ------------------
+// BAM holds the operations as the kernel wants them (len << 4 | op); what is left to do is what xm_cigar_pack does on the host:
+// a count byte per record (255 = "255 or more": a trailer word n_ops << 4 | 15 behind the operations), the operations back to
+// back, and where every 256th record's operations begin.  C1 sizes, the size scan of W2, C2 copies.
+__global__ void __launch_bounds__(256)
+cig_size_kernel(const uint32_t *__restrict__ n_cigar, uint32_t n, uint8_t *__restrict__ cnt8, uint32_t *__restrict__ words)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = n_cigar[i];
+    cnt8[i] = (uint8_t)(c < 255u ? c : 255u);
+    words[i] = c + (c >= 255u ? 1u : 0u);
+}
+
+__global__ void __launch_bounds__(256)
+cig_fill_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ n_cigar, const uint32_t *__restrict__ cig_at,
+                const uint32_t *__restrict__ place, const uint32_t *__restrict__ total, uint32_t n, uint32_t *__restrict__ tile,
+                uint32_t *__restrict__ ops, uint32_t ops_cap)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u) tile[(n + 255u) / 256u] = *total;
+    if (i >= n) return;
+    const uint32_t c = n_cigar[i], pos = place[i];
+    if ((i & 255u) == 0u) tile[i >> 8] = pos;
+    if (pos + c + (c >= 255u ? 1u : 0u) > ops_cap) return;                 // cannot happen: the words are a part of the window
+    const uint8_t *src = raw + cig_at[i];
+    for (uint32_t k = 0; k < c; ++k) ops[pos + k] = ld32(src + 4u * k);
+    if (c >= 255u) ops[pos + c] = (c << 4) | 15u;
 }
 
 // ---- B5: one lane per pair --------------------------------------------------------------------------------------------
@@ -320,7 +355,11 @@ struct PerFile {
     // the records a sink takes, packed (xm_bamdev_fetch_wanted): bytes, and per record where it went (NO_RECORD: not taken)
     uint8_t *d_packed = nullptr, *h_packed = nullptr;
     uint32_t *d_wsize = nullptr, *d_place = nullptr, *h_place = nullptr, *d_part = nullptr;
-    uint32_t *d_s_off = nullptr, *d_s_name_off = nullptr, *d_s_name_len = nullptr;
+    uint32_t *d_s_off = nullptr, *d_s_name_off = nullptr, *d_s_name_len = nullptr, *d_s_ncig = nullptr, *d_s_cig_at = nullptr;
+    // --cigar_scores: per record how many CIGAR words and where, and the packed CIGAR columns made of them (ensure_cigar)
+    uint32_t *d_ncig = nullptr, *d_cig_at = nullptr, *d_cig_tile = nullptr, *d_cig_ops = nullptr;
+    uint8_t *d_cig_cnt = nullptr;
+    uint64_t ops_cap = 0, cig_records = 0, cig_slots = 0;
     int32_t *d_s_a = nullptr, *d_s_x = nullptr;
     uint8_t *d_s_flag = nullptr;
     uint64_t slots_len = 0;
@@ -362,6 +401,7 @@ struct Slot {
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr};
     uint64_t up_len[2] = {0, 0};
+    int last_score_mode = XMS_SCORE_AS_XS;   // of the last run: which columns xm_bamdev_classify reads
     bool raw_issued = false;                 // ev_raw has been recorded at least once (stays true: waiting for a past event costs nothing)
     bool have_columns = false;
     bool classified = false;                 // the fused pass has run on the slot's columns (its compact category stream is in d_bins4)
@@ -424,7 +464,8 @@ void free_slot(Slot &sl)
         dfree(q.d_packed); hfree(q.h_packed); dfree(q.d_wsize); dfree(q.d_place); hfree(q.h_place); dfree(q.d_part);
         hfree(q.h_seg); dfree(q.d_seg); dfree(q.d_cnt); dfree(q.d_exit); dfree(q.d_base);
         dfree(q.d_s_off); dfree(q.d_s_name_off); dfree(q.d_s_name_len); dfree(q.d_s_a); dfree(q.d_s_x); dfree(q.d_s_flag);
-        q.slots_len = 0;
+        dfree(q.d_s_ncig); dfree(q.d_s_cig_at); dfree(q.d_ncig); dfree(q.d_cig_at); dfree(q.d_cig_tile); dfree(q.d_cig_ops); dfree(q.d_cig_cnt);
+        q.slots_len = 0; q.ops_cap = q.cig_records = q.cig_slots = 0;
         dfree(q.d_rec_off); hfree(q.h_rec_off); dfree(q.d_name_off); dfree(q.d_name_len); dfree(q.d_a); dfree(q.d_x);
         dfree(q.d_rflag); dfree(q.d_lflag); hfree(q.h_lflag);
     }
@@ -437,6 +478,50 @@ void free_slot(Slot &sl)
 }
 
 }  // namespace
+
+// --cigar_scores: the arrays only such a run needs, made when the first one comes (and again when reserve() has grown the rest)
+static int ensure_cigar(xm_bamdev *b, Slot &sl)
+{
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        if (q.cig_slots < q.slots_len) {
+            q.cig_slots = 0;
+            XMB_TRY(dalloc(b, q.d_s_ncig, (size_t)q.slots_len)); XMB_TRY(dalloc(b, q.d_s_cig_at, (size_t)q.slots_len));
+            q.cig_slots = q.slots_len;
+        }
+        if (q.cig_records < sl.record_cap) {
+            q.cig_records = 0;
+            const size_t n = (size_t)sl.record_cap + 64;
+            XMB_TRY(dalloc(b, q.d_ncig, n)); XMB_TRY(dalloc(b, q.d_cig_at, n)); XMB_TRY(dalloc(b, q.d_cig_cnt, n));
+            XMB_TRY(dalloc(b, q.d_cig_tile, n / 256 + 8));
+            q.cig_records = sl.record_cap;
+        }
+        // the operations are words of the window; a record with 255 or more of them has one trailer word behind them
+        const uint64_t need_ops = sl.raw_cap / 4u + sl.raw_cap / 1020u + 64u;
+        if (q.ops_cap < need_ops) {
+            q.ops_cap = 0;
+            XMB_TRY(dalloc(b, q.d_cig_ops, (size_t)need_ops));
+            q.ops_cap = need_ops;
+        }
+    }
+    return XM_OK;
+}
+
+// the packed CIGAR columns of one file's first n records, queued on the slot's stream (C1, the size scan, C2)
+static int pack_cigar(Slot &sl, int f, uint32_t n)
+{
+    PerFile &q = sl.pf[f];
+    if (q.cig_records < n || q.ops_cap == 0 || n == 0) return XM_ERR_INVALID_ARG;
+    hipStream_t st = sl.stream;
+    const uint32_t n_part = (n + SCAN_TILE - 1u) / SCAN_TILE;
+    cig_size_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_ncig, n, q.d_cig_cnt, q.d_wsize);
+    size_sum_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part);
+    part_scan_kernel<<<1, 1024, 0, st>>>(q.d_part, n_part, sl.d_state + 10 + f);
+    size_place_kernel<true><<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part, q.d_place);
+    cig_fill_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_raw, q.d_ncig, q.d_cig_at, q.d_place, sl.d_state + 10 + f, n, q.d_cig_tile, q.d_cig_ops,
+                                                      (uint32_t)std::min<uint64_t>(q.ops_cap, 0xFFFFFFFFull));
+    return XM_OK;
+}
 
 extern "C" {
 
@@ -602,15 +687,19 @@ uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file)
 int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
                   uint64_t max_records, xm_bamdev_block *out)
 {
-    if (!b || !in || !out || slot < 0 || slot > 1 || (score_mode != XMS_SCORE_AS_XS && score_mode != XMS_SCORE_AS_ZS) || max_records == 0)
+    if (!b || !in || !out || slot < 0 || slot > 1 || (score_mode != XMS_SCORE_AS_XS && score_mode != XMS_SCORE_AS_ZS && score_mode != XMS_SCORE_CIGAR) || max_records == 0)
         return XM_ERR_INVALID_ARG;
     Slot &sl = b->slot[slot];
     if (max_records > sl.record_cap) return XM_ERR_INVALID_ARG;
+    const bool cigar = score_mode == XMS_SCORE_CIGAR;
+    const uint32_t tags = cigar ? xmrec::TAGS_NM_XS : score_mode == XMS_SCORE_AS_ZS ? xmrec::TAGS_AS_ZS : xmrec::TAGS_AS_XS;
+    sl.last_score_mode = score_mode;
     memset(out, 0, sizeof *out);
     out->mismatch_at = -1;
     sl.have_columns = false;
     sl.classified = false;
     XMB_HIP(b, hipSetDevice(b->device));
+    if (cigar) XMB_TRY(ensure_cigar(b, sl));
     hipStream_t st = sl.stream;
     static const bool profile = getenv("XM_BAMDEV_PROFILE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -680,7 +769,8 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
                 w.slots = q.d_s_off + so;
                 w.name_off = q.d_s_name_off + so; w.name_len = q.d_s_name_len + so;
                 w.a = q.d_s_a + so; w.x = q.d_s_x + so; w.flag = q.d_s_flag + so;
-                w.x0 = score_mode == XMS_SCORE_AS_ZS ? 'Z' : 'X';
+                w.tags = tags;
+                if (cigar) { w.n_cigar = q.d_s_ncig + so; w.cig_at = q.d_s_cig_at + so; }
                 q.h_seg[n_seg++] = w.start;
             }
             sl.h_walk[n_all + k] = w;
@@ -730,9 +820,10 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
                 walk_kernel<true><<<(n_carry_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_carry_seg, nullptr, nullptr,
                                                                                          q.d_base, q.d_rec_off, rec_cap);
             if (n_seg > n_carry_seg) {
-                const SlotArrays sa = {q.d_s_off, q.d_s_name_off, q.d_s_name_len, q.d_s_a, q.d_s_x, q.d_s_flag};
+                const SlotArrays sa = {q.d_s_off, q.d_s_name_off, q.d_s_name_len, q.d_s_a, q.d_s_x, q.d_s_flag,
+                                       cigar ? q.d_s_ncig : nullptr, cigar ? q.d_s_cig_at : nullptr};
                 gather_kernel<<<(n_seg - n_carry_seg + 3u) / 4u, 256, 0, st>>>(sa, q.d_seg, n_carry_seg, n_seg, q.d_cnt, q.d_base, q.d_rec_off, q.d_name_off,
-                                                                               q.d_name_len, q.d_a, q.d_x, q.d_rflag, rec_cap);
+                                                                               q.d_name_len, q.d_a, q.d_x, q.d_rflag, q.d_ncig, q.d_cig_at, rec_cap);
             }
         }
         XMB_HIP(b, hipMemcpyAsync(q.h_summary, q.d_summary, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -777,10 +868,10 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
             PerFile &q = sl.pf[f];
             const uint32_t n_seg = q.h_summary[8], n_carry_seg = q.h_summary[9];
             if (n_carry_seg == 0u) continue;
-            const RecOut ro = {q.d_name_off, q.d_name_len, q.d_a, q.d_x, q.d_rflag};
+            const RecOut ro = {q.d_name_off, q.d_name_len, q.d_a, q.d_x, q.d_rflag, cigar ? q.d_ncig : nullptr, cigar ? q.d_cig_at : nullptr};
             const uint64_t upper = std::min<uint64_t>(n, in[f].carry_len / 36u + 1u);
             parse_kernel<<<(uint32_t)((upper + 255) / 256), 256, 0, st>>>(q.d_raw, q.d_rec_off, (uint32_t)upper, n_carry_seg < n_seg ? q.d_base + n_carry_seg : nullptr,
-                                                                         score_mode == XMS_SCORE_AS_ZS ? 'Z' : 'X', ro);
+                                                                         tags, ro);
         }
         const PerFile &a = sl.pf[0], &c = sl.pf[1];
         const FileRecs f1 = {a.d_raw, a.d_name_off, a.d_name_len, a.d_a, a.d_x, a.d_rflag};
@@ -890,7 +981,7 @@ int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paire
             PerFile &q = sl.pf[f];
             size_sum_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part);
             part_scan_kernel<<<1, 1024, 0, st>>>(q.d_part, n_part, sl.d_state + 8 + f);
-            size_place_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part, q.d_place);
+            size_place_kernel<false><<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part, q.d_place);
             pack_kernel<<<(n + 3u) / 4u, 256, 0, st>>>(q.d_raw, q.d_rec_off, q.d_wsize, q.d_place, n, q.d_packed);
         }
         XMB_HIP(b, hipMemcpyAsync(sl.h_state + 8, sl.d_state + 8, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -935,8 +1026,20 @@ int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int
     if (n_records == 0) { sl.classified = true; return XM_OK; }
     XMB_HIP(b, hipSetDevice(b->device));
     hipStream_t st = sl.stream;
-    const int rc = xm_classify_compact_dev(b->ctx, st, mode, n_records, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3], sl.d_bits,
-                                           min_score_floor, sl.d_code, sl.d_bins4, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
+    const bool cigar = sl.last_score_mode == XMS_SCORE_CIGAR;
+    int rc;
+    if (cigar) {
+        // the records' CIGAR words as packed CIGAR columns (col 0 / 2 hold NM), then the kernel that makes AS of them
+        for (int f = 0; f < 2; ++f) XMB_TRY(pack_cigar(sl, f, (uint32_t)n_records));
+        XMB_HIP(b, hipMemsetAsync(sl.d_state + 12, 0, sizeof(uint32_t), st));
+        const PerFile &a = sl.pf[0], &c = sl.pf[1];
+        rc = xm_classify_compact_cigar_packed_dev(b->ctx, st, mode, n_records, sl.d_col[0], a.d_cig_cnt, a.d_cig_tile, a.d_cig_ops, sl.d_col[1],
+                                                  sl.d_col[2], c.d_cig_cnt, c.d_cig_tile, c.d_cig_ops, sl.d_col[3], sl.d_bits, min_score_floor,
+                                                  sl.d_code, sl.d_bins4, sl.d_state + 12, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
+    } else {
+        rc = xm_classify_compact_dev(b->ctx, st, mode, n_records, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3], sl.d_bits,
+                                     min_score_floor, sl.d_code, sl.d_bins4, sl.d_idx, sl.d_off_counts, sl.d_off_counts + 8);
+    }
     if (rc != XM_OK) {
         std::lock_guard<std::mutex> hold(b->error_lock);
         b->last_error = xm_last_hip_error(b->ctx);
@@ -944,7 +1047,9 @@ int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int
     }
     XMB_HIP(b, hipMemcpyAsync(sl.h_code, sl.d_code, n_records, hipMemcpyDeviceToHost, st));
     XMB_HIP(b, hipMemcpyAsync(sl.h_off_counts, sl.d_off_counts, 72 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (cigar) XMB_HIP(b, hipMemcpyAsync(sl.h_state + 12, sl.d_state + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     XMB_HIP(b, hipStreamSynchronize(st));
+    if (cigar && sl.h_state[12] != 0u) return XM_ERR_RANGE;               // a score left int32: the caller's text rules decide
     const uint64_t units = sl.h_off_counts[7];
     if (units > n_records) return XM_ERR_HIP;
     if (units) {
@@ -970,6 +1075,33 @@ int xm_bamdev_columns(xm_bamdev *b, int slot, uint64_t n_records, int32_t *as1, 
         if (dst[c]) XMB_HIP(b, hipMemcpyAsync(dst[c], sl.d_col[c], n_records * 4, hipMemcpyDeviceToHost, sl.stream));
     if (unit_bits) XMB_HIP(b, hipMemcpyAsync(unit_bits, sl.d_bits, (n_records + 63) / 64 * 8, hipMemcpyDeviceToHost, sl.stream));
     XMB_HIP(b, hipStreamSynchronize(sl.stream));
+    return XM_OK;
+}
+
+int xm_bamdev_cigar_columns(xm_bamdev *b, int slot, int file, uint64_t n_records, int32_t *nm, uint8_t *cig_cnt, uint32_t *cig_tile,
+                            uint32_t *cig_ops, uint64_t ops_capacity, uint64_t *n_ops)
+{
+    if (!b || slot < 0 || slot > 1 || file < 0 || file > 1 || !n_ops) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (n_records > sl.record_cap || !sl.have_columns || sl.last_score_mode != XMS_SCORE_CIGAR) return XM_ERR_INVALID_ARG;
+    *n_ops = 0;
+    if (n_records == 0) { if (cig_tile) cig_tile[0] = 0; return XM_OK; }
+    XMB_HIP(b, hipSetDevice(b->device));
+    hipStream_t st = sl.stream;
+    const PerFile &q = sl.pf[file];
+    XMB_TRY(pack_cigar(sl, file, (uint32_t)n_records));
+    XMB_HIP(b, hipMemcpyAsync(sl.h_state + 10 + file, sl.d_state + 10 + file, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (nm) XMB_HIP(b, hipMemcpyAsync(nm, sl.d_col[2 * file], n_records * 4, hipMemcpyDeviceToHost, st));
+    if (cig_cnt) XMB_HIP(b, hipMemcpyAsync(cig_cnt, q.d_cig_cnt, n_records, hipMemcpyDeviceToHost, st));
+    if (cig_tile) XMB_HIP(b, hipMemcpyAsync(cig_tile, q.d_cig_tile, (XM_CIG_TILES(n_records) + 1) * 4, hipMemcpyDeviceToHost, st));
+    XMB_HIP(b, hipStreamSynchronize(st));
+    *n_ops = sl.h_state[10 + file];
+    if (*n_ops > q.ops_cap) return XM_ERR_HIP;
+    if (cig_ops) {
+        if (ops_capacity < *n_ops) return XM_ERR_INVALID_ARG;
+        if (*n_ops) XMB_HIP(b, hipMemcpyAsync(cig_ops, q.d_cig_ops, *n_ops * 4, hipMemcpyDeviceToHost, st));
+        XMB_HIP(b, hipStreamSynchronize(st));
+    }
     return XM_OK;
 }
 

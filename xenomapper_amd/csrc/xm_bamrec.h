@@ -34,13 +34,24 @@ __device__ __forceinline__ uint32_t elem_bytes(uint32_t t)
 struct RecFields {
     uint32_t name_off;        // first byte of QNAME in raw
     uint32_t name_len;        // without the NUL
-    int32_t a, x;             // AS, and XS or ZS by mode; ABSENT = no match
+    int32_t a, x;             // AS (or NM in --cigar_scores mode), and XS or ZS by mode; ABSENT = no match
     uint32_t flag;            // ex_a | ex_x << 2 | R_WEIRD | R_BAD
+    uint32_t n_cigar, cig_at; // the CIGAR operations (BAM words, len << 4 | op) of the record: how many, where in raw
 };
 
-// the record whose block_size word is at raw + off; x0 = 'X' or 'Z' (which tag plays XS)
-__device__ __forceinline__ RecFields parse_record(const uint8_t *__restrict__ raw, uint32_t off, uint32_t x0)
+// Which tags are read: x0 = 'X' or 'Z' (which tag plays XS: get_tag / get_tag_with_ZS_as_XS, :176-206); tags >> 8 = the two letters
+// of the first value ('A' | 'S' << 8: AS, with the duplicate rule; 'N' | 'M' << 8 with bit 16 set: NM as get_cigarbased_AS_tag
+// reads it, :247-250 -- the FIRST field that holds the letters decides, later ones do not matter).
+constexpr uint32_t TAGS_AS_XS = 'X' | ('A' << 8) | ('S' << 16);
+constexpr uint32_t TAGS_AS_ZS = 'Z' | ('A' << 8) | ('S' << 16);
+constexpr uint32_t TAGS_NM_XS = 'X' | ('N' << 8) | ('M' << 16) | (1u << 24);
+
+// the record whose block_size word is at raw + off
+__device__ __forceinline__ RecFields parse_record(const uint8_t *__restrict__ raw, uint32_t off, uint32_t tags)
 {
+    const uint32_t x0 = tags & 0xFFu, a0 = (tags >> 8) & 0xFFu, a1 = (tags >> 16) & 0xFFu;
+    const bool a_first_only = (tags >> 24) != 0u;
+    uint32_t n_cig = 0, cig_at = 0;
     const uint32_t size = ld32(raw + off);
     const uint8_t *r = raw + off + 4u;
     uint32_t flag = 0, nl = 0;
@@ -54,6 +65,8 @@ __device__ __forceinline__ RecFields parse_record(const uint8_t *__restrict__ ra
         ok = need <= size && l_read_name != 0u;
         if (ok) {
             bool weird = false;
+            n_cig = n_cigar;
+            cig_at = off + 36u + l_read_name;
             // QNAME up to its NUL
             while (nl < l_read_name && r[32u + nl] != 0u) { weird |= odd_byte(r[32u + nl]); ++nl; }
             weird |= nl == 0u;
@@ -74,7 +87,7 @@ __device__ __forceinline__ RecFields parse_record(const uint8_t *__restrict__ ra
                 p += 3u;
                 weird |= odd_byte(t0) || odd_byte(t1);
                 weird |= cg_possible && t0 == 'C' && t1 == 'G';
-                const bool is_a = t0 == 'A' && t1 == 'S', is_x = t0 == x0 && t1 == 'S';
+                const bool is_a = t0 == a0 && t1 == a1, is_x = t0 == x0 && t1 == 'S';
                 if (type == 'Z' || type == 'H') {
                     // the printed field "TG:Z:value": matched by its name or by the two letters anywhere in the value
                     bool in_a = is_a, in_x = is_x, end = false;
@@ -83,7 +96,7 @@ __device__ __forceinline__ RecFields parse_record(const uint8_t *__restrict__ ra
                         const uint32_t c = r[p++];
                         if (c == 0u) { end = true; break; }
                         weird |= odd_byte(c);
-                        in_a |= prev == 'A' && c == 'S';
+                        in_a |= prev == a0 && c == a1;
                         in_x |= prev == x0 && c == 'S';
                         prev = c;
                     }
@@ -128,7 +141,7 @@ __device__ __forceinline__ RecFields parse_record(const uint8_t *__restrict__ ra
         }
     }
     if (!ok) flag |= R_BAD;
-    if (cnt_a > 1u) ex_a = 2u;
+    if (cnt_a > 1u && !a_first_only) ex_a = 2u;
     if (cnt_x > 1u) ex_x = 2u;
     if (ex_a) va = ABSENT;
     if (ex_x) vx = ABSENT;
@@ -138,6 +151,8 @@ __device__ __forceinline__ RecFields parse_record(const uint8_t *__restrict__ ra
     f.a = va;
     f.x = vx;
     f.flag = flag | (ex_a << R_EX_A_SHIFT) | (ex_x << R_EX_X_SHIFT);
+    f.n_cigar = n_cig;
+    f.cig_at = cig_at;
     return f;
 }
 

@@ -108,15 +108,16 @@ inflate_kernel(const uint8_t *__restrict__ comp, const xm_bgzf_block *__restrict
                     p = 0xFFFFFFFFu;
                 }
                 if (gl == 0u) { *w.count = n; *w.exit_at = p; }
-                if (w.x0 != 0u && p != 0xFFFFFFFFu) {
+                if (w.tags != 0u && p != 0xFFFFFFFFu) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the record starts are where the other lanes read them
                     for (uint32_t i = gl; i < n; i += GS) {
-                        const xmrec::RecFields f = xmrec::parse_record(raw, w.slots[i], w.x0);
+                        const xmrec::RecFields f = xmrec::parse_record(raw, w.slots[i], w.tags);
                         w.name_off[i] = f.name_off;
                         w.name_len[i] = f.name_len;
                         w.a[i] = f.a;
                         w.x[i] = f.x;
                         w.flag[i] = (uint8_t)f.flag;
+                        if (w.n_cigar != nullptr) { w.n_cigar[i] = f.n_cigar; w.cig_at[i] = f.cig_at; }
                     }
                 }
             }

@@ -1245,10 +1245,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     prof = _PhaseClock()
     _EMIT_CLOCK.clear()
     t_all = time.perf_counter()
-    # BAM on the GPU (include/xenomapper_bgzf.h): inflate + record chain + stripper on the device for the plain walk with the AS /
-    # XS / ZS plugins; --cigar_scores, the skipping walk and XENOMAPPER_GPU_BAM=0 keep the host decoder
+    # BAM on the GPU (include/xenomapper_bgzf.h): inflate + record chain + stripper on the device for the plain walk with the three
+    # plugins (--cigar_scores: NM and the records' CIGAR words become the packed CIGAR columns on the device); the skipping walk
+    # and XENOMAPPER_GPU_BAM=0 keep the host decoder
     bamdev = None
-    if (bam and not skip_repeated and not cigar_mode and min_score == min_score and os.environ.get("XENOMAPPER_GPU_BAM", "1") != "0"):
+    if (bam and not skip_repeated and min_score == min_score and os.environ.get("XENOMAPPER_GPU_BAM", "1") != "0"):
         try:
             bamdev = default_bamdev()
         except MemoryError:
@@ -1346,7 +1347,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     3: "a malformed alignment record"}.get(blk.bad_block, "damaged")
             raise ValueError("corrupt BAM input: %s (%s, %s)" % (what, path1, path2))
         eofs = [bool(x["eof"]) for x in inputs]
-        if blk.unaligned or blk.weird:
+        if blk.unaligned or blk.weird or (cigar_mode and blk.n_exceptions):
+            # (--cigar_scores: an NM or XS value the kernels do not vouch for sends the window the same way, as on the SAM path)
             with prof("parse"):
                 # the whole windows as text, then the text rules (exactly the host path's semantics for this window)
                 bamdev.fetch_raw(which)
