@@ -74,6 +74,9 @@ int xm_bgzf_inflate_dev(xm_ctx *ctx, void *stream, const uint8_t *comp, const xm
  * next block begins with a record; 0xFFFFFFFF: the block failed, or it holds more than slot_cap records); a record that does not
  * end in front of n_raw (the window's end) ends the walk, and so does a size word cut by the block's end.  Entries with
  * end <= start are skipped.  walk[] (device memory) has n_blocks entries; all arrays are device memory of slot_cap entries. */
+#define XM_BGZF_TAGS_AS_XS ((uint32_t)'X' | (uint32_t)'A' << 8 | (uint32_t)'S' << 16)             /* get_tag, xenomapper.py:176-191 */
+#define XM_BGZF_TAGS_AS_ZS ((uint32_t)'Z' | (uint32_t)'A' << 8 | (uint32_t)'S' << 16)             /* get_tag_with_ZS_as_XS, :193-206 */
+#define XM_BGZF_TAGS_NM_XS ((uint32_t)'X' | (uint32_t)'N' << 8 | (uint32_t)'M' << 16 | 1u << 24)  /* get_cigarbased_AS_tag, :228-256 */
 typedef struct {
     uint64_t raw_base;
     uint32_t start, end;             /* first byte to look at (the block's first, or behind the BAM header), the block's end     */

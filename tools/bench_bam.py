@@ -73,8 +73,9 @@ def tiled_bam(src, dst, copies, aligned=True):
     return len(raw) - at
 
 
-def run(copies=4000, threads=0, workdir="/dev/shm"):
-    """One warm-up and one timed pass over the tiled fixtures; returns the result record (also bench.py's `e2e.bam`)."""
+def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False):
+    """One warm-up and one timed pass over the tiled fixtures; returns the result record (also bench.py's `e2e.bam`).
+    cigar_scores: the --cigar_scores plugin (AS made of NM + CIGAR) instead of the AS / XS tags."""
     import types
     a = types.SimpleNamespace(copies=copies, threads=threads, dir=workdir)
     from xenomapper_amd import _host, xenomapper as xm
@@ -90,11 +91,12 @@ def run(copies=4000, threads=0, workdir="/dev/shm"):
         xm.default_context()
         for _warm in (True, False):
             t0 = time.perf_counter()
-            counts = xm.classify_sam_files(paths[0], paths[1], paired=True, n_threads=a.threads, bam=True, **sinks)
+            counts = xm.classify_sam_files(paths[0], paths[1], paired=True, n_threads=a.threads, bam=True,
+                                           tag_func=xm.get_cigarbased_AS_tag if cigar_scores else xm.get_tag, **sinks)
             el = time.perf_counter() - t0
         units = sum(counts.values())
         return {"metric": "end-to-end read-pairs/s (BAM in, six SAM files out)", "value": units / el,
-                "units": units, "seconds": el, "bam_bytes": size, "bam_GBps": size / el / 1e9,
+                "plugin": "get_cigarbased_AS_tag" if cigar_scores else "get_tag", "units": units, "seconds": el, "bam_bytes": size, "bam_GBps": size / el / 1e9,
                 "threads": a.threads or _host.lib().xmh_default_threads(),
                 "phases": {k: round(v, 4) for k, v in xm.LAST_FILE_PROFILE.items()}}
     finally:
@@ -107,8 +109,9 @@ def main():
     ap.add_argument("--copies", type=int, default=4000)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--cigar_scores", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.copies, a.threads, a.dir)))
+    print(json.dumps(run(a.copies, a.threads, a.dir, a.cigar_scores)))
 
 
 if __name__ == "__main__":
