@@ -169,9 +169,13 @@ int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes);
 /* inflate, find the records, strip, pair.  score_mode: XMS_SCORE_AS_XS, XMS_SCORE_AS_ZS, or XMS_SCORE_CIGAR (get_cigarbased_AS_tag,
  * xenomapper.py:228-256: column "AS" then holds NM -- the FIRST optional field that holds the letters decides, :247-250 -- and
  * xm_bamdev_classify makes the packed CIGAR columns of the records' CIGAR words and runs xm_classify_compact_cigar_packed_dev).
+ * skip_repeated: the skipping walk of getReadPairs (xenomapper.py:110-117; what the command line does for single-end input, :691):
+ * each file is cut into runs of adjacent records with one name, pair k = the first record of run k of both files; a run that
+ * reaches the end of a window whose file goes on is not yielded (starved: it may go on in the next window); rec_off1/2 then list
+ * the yielded records only, and consumed1/2 lie behind the records skipped.
  * Blocking (the slot's own stream).  The inflated windows stay on the device: what the
  * writer needs of them is asked for afterwards, one of */
-int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
+int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int skip_repeated, int keep_halo,
                   uint64_t max_records, xm_bamdev_block *out);
 /* (a) the whole windows into raw1 / raw2 (a window the host has to walk or print whole: unaligned, weird, exceptions) */
 int xm_bamdev_fetch_raw(xm_bamdev *b, int slot);

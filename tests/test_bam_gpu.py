@@ -61,7 +61,7 @@ def expected_from_text(line, tag, first_decides=False):
     return ABSENT, 1
 
 
-def run_whole_files(dev, images, score_mode, paired, halo=False):
+def run_whole_files(dev, images, score_mode, paired, halo=False, skip_repeated=False):
     from xenomapper_amd import _ffi, _host
     inputs, readers = [], []
     for f, image in enumerate(images):
@@ -87,32 +87,40 @@ def run_whole_files(dev, images, score_mode, paired, halo=False):
     for f, (c0, comp_len, _x) in enumerate(inputs):
         if comp_len:
             dev.staging(0, f)[:comp_len] = np.frombuffer(images[f], dtype=np.uint8)[c0:c0 + comp_len]
-    blk = dev.run(0, [x[2] for x in inputs], score_mode, paired, halo, 1 << 16)
+    blk = dev.run(0, [x[2] for x in inputs], score_mode, paired, halo, 1 << 16, skip_repeated=skip_repeated)
     return blk, readers
 
 
 @settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "80")), deadline=None, suppress_health_check=list(HealthCheck))
-@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share")), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans())
-def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mode, paired):
+@given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share")), score_mode=st.sampled_from([0, 1, 2]), paired=st.booleans(), skip=st.booleans())
+def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mode, paired, skip):
     """Record by record: value and flag of AS and XS (or ZS) exactly as the printed text dictates (a flag must be justified and
     a justified flag must be raised), names (unit mask, first mismatch), the walk's outcome, and `weird` exactly when a
     line holds a byte the text rules could split at.  score_mode 2 (--cigar_scores): NM in place of AS by the first-field rule,
-    and the packed CIGAR columns the device makes of the records' CIGAR words against xm_cigar_pack of the printed CIGARs."""
+    and the packed CIGAR columns the device makes of the records' CIGAR words against xm_cigar_pack of the printed CIGARs.
+    skip: the skipping walk (getReadPairs :110-117) -- pair k is the first record of the k-th run of equal names of either file."""
     from xenomapper_amd import _ffi
     dev = _ffi.BamDev(ctx)
     try:
-        blk, readers = run_whole_files(dev, images, score_mode, paired)
+        blk, readers = run_whole_files(dev, images, score_mode, paired, skip_repeated=skip)
         assert not blk.bad_block and not blk.unaligned
-        lines = [host_text(im).split(b"\n")[:-1] for im in images]
-        assert blk.n_rec == (len(lines[0]), len(lines[1]))
+        every = [host_text(im).split(b"\n")[:-1] for im in images]
+        assert blk.n_rec == (len(every[0]), len(every[1]))
+        odd = lambda l: any(c <= 0x20 and c != 9 or c >= 0x7F for c in l) or l.startswith(b"\t") or b"\t\t" in l   # noqa: E731
+        if skip:
+            # the records the walk can yield: the first of every run of equal names (a record the text rules might read
+            # differently could cut the runs differently wherever it lies: `weird` looks at every record then)
+            lines = [[l for i, l in enumerate(ls) if i == 0 or l.split(b"\t")[0] != ls[i - 1].split(b"\t")[0]] for ls in every]
+            risky = min(len(every[0]), len(every[1])) > 0 and any(odd(l) for ls in every for l in ls)
+        else:
+            lines = every
+            risky = any(odd(l) for ls in lines for l in ls[:min(len(lines[0]), len(lines[1]))])
         n_pairs = min(len(lines[0]), len(lines[1]))
         names = [[l.split(b"\t")[0] for l in ls] for ls in lines]
         mism = next((k for k in range(n_pairs) if names[0][k] != names[1][k]), -1)
         assert blk.mismatch_at == mism
         n = mism if mism >= 0 else n_pairs
         assert blk.n == n
-        risky = any(any(c <= 0x20 and c != 9 or c >= 0x7F for c in l) or l.startswith(b"\t") or b"\t\t" in l
-                    for ls in lines for l in ls[:n_pairs])
         assert blk.weird == risky
         if mism < 0:
             assert blk.ended and not blk.starved                   # whole files in one window
@@ -159,14 +167,14 @@ def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mod
         dev.close()
 
 
-def run_path(paths, gpu, conservative=False, tag="AS"):
-    """tag: "AS" get_tag, "ZS" get_tag_with_ZS_as_XS, "NM" get_cigarbased_AS_tag."""
+def run_path(paths, gpu, conservative=False, tag="AS", paired=True, skip=None):
+    """tag: "AS" get_tag, "ZS" get_tag_with_ZS_as_XS, "NM" get_cigarbased_AS_tag; skip None: as the command line (not paired)."""
     """classify_sam_files(bam=True) with either BAM front end -> (six texts, counts) or the exception it raises."""
     from xenomapper_amd import xenomapper as xm
     os.environ["XENOMAPPER_GPU_BAM"] = "1" if gpu else "0"
     sinks = [io.StringIO() for _ in range(6)]
     try:
-        counts = xm.classify_sam_files(paths[0], paths[1], *sinks, paired=True, conservative=conservative, bam=True,
+        counts = xm.classify_sam_files(paths[0], paths[1], *sinks, paired=paired, conservative=conservative, bam=True, skip_repeated_reads=skip,
                                        tag_func={"AS": xm.get_tag, "ZS": xm.get_tag_with_ZS_as_XS, "NM": xm.get_cigarbased_AS_tag}[tag])
     except Exception as exc:                                        # noqa: BLE001
         return type(exc).__name__, [s.getvalue() for s in sinks]
@@ -189,20 +197,21 @@ def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, m
         paths.append(p)
     want = run_path(paths, gpu=False)
     monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 1 << 20)
-    for conservative, tag in ((False, "AS"), (True, "AS"), (False, "NM")):
-        ref = run_path(paths, gpu=False, conservative=conservative, tag=tag) if (conservative or tag != "AS") else want
-        got = run_path(paths, gpu=True, conservative=conservative, tag=tag)
+    for conservative, tag, paired in ((False, "AS", True), (True, "AS", True), (False, "NM", True), (False, "AS", False), (False, "NM", False)):
+        # (not paired: the skipping walk, as the command line runs single-end input -- the mates' runs of two cross the windows)
+        ref = run_path(paths, gpu=False, conservative=conservative, tag=tag, paired=paired) if (conservative or tag != "AS" or not paired) else want
+        got = run_path(paths, gpu=True, conservative=conservative, tag=tag, paired=paired)
         assert got[0] == ref[0]
         assert got[1] == ref[1]
+        prof = xm.LAST_FILE_PROFILE
+        assert prof.get("strip_kernels_ms", 0) > 0 or not aligned   # the device path really ran
     assert sum(want[0].values()) == 40 * 238
-    prof = xm.LAST_FILE_PROFILE
-    assert prof.get("strip_kernels_ms", 0) > 0 or not aligned       # the device path really ran
 
 
 @settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "60")), deadline=None, suppress_health_check=list(HealthCheck))
 @given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share"), bam_file_pair()), tag=st.sampled_from(["AS", "ZS", "NM"]),
-       conservative=st.booleans())
-def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, tag, conservative):
+       conservative=st.booleans(), walk=st.sampled_from(["paired", "paired", "single", "paired skipping"]))
+def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, tag, conservative, walk):
     """Typed tags at the int32 edges, floats and characters under the tags' names, strings that merely contain the letters,
     names with blanks, second files that end early: outputs, counts and exception types of the GPU front end equal the host
     decoder's (which is pinned to the reference through the text rules)."""
@@ -213,9 +222,49 @@ def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, t
         with open(p, "wb") as fh:
             fh.write(im)
         paths.append(p)
-    want = run_path(paths, gpu=False, conservative=conservative, tag=tag)
-    got = run_path(paths, gpu=True, conservative=conservative, tag=tag)
+    kw = {"paired": walk != "single", "skip": True if walk == "paired skipping" else None}
+    want = run_path(paths, gpu=False, conservative=conservative, tag=tag, **kw)
+    got = run_path(paths, gpu=True, conservative=conservative, tag=tag, **kw)
     assert got == want
+
+
+def test_runs_of_equal_names_longer_than_a_window(tmp_path, monkeypatch):
+    """The skipping walk over files whose runs of equal names differ between the files and cross the windows -- one run longer
+    than several windows (the window has to grow), runs that end exactly with a BGZF block, a file whose last run reaches its
+    end: GPU front end against the host decoder, single-end (the command line's walk) and paired with skipping."""
+    import struct
+    from tests.test_host_fuzz import _bam_image_of
+    from xenomapper_amd import xenomapper as xm
+    rng = np.random.default_rng(3)
+    names = 400
+    lens = [rng.integers(1, 6, size=names), rng.integers(1, 6, size=names)]
+    lens[0][37], lens[1][37] = 9000, 3                               # ~ 450 KB of one name in file 1
+    lens[1][200] = 2500
+    lens[0][names - 1] = 40                                          # the last run reaches the end of the file
+    images = []
+    for f in (0, 1):
+        recs = []
+        for k in range(names):
+            for j in range(int(lens[f][k])):
+                name = b"read%d\0" % k
+                tags = b"ASc" + struct.pack("<b", -int(rng.integers(0, 40))) + (b"XSc" + struct.pack("<b", -int(rng.integers(0, 60))) if (k + j) % 3 else b"")
+                core = struct.pack("<iiBBHHHIiii", 0, 100 + k, len(name), 30, 4680, 1, 0, 4, -1, -1, 0)
+                body = core + name + struct.pack("<I", (4 << 4) | 0) + b"\x12\x48" + b"\x1e\x1e\x1e\x1e" + tags
+                recs.append(struct.pack("<I", len(body)) + body)
+        images.append(_bam_image_of(recs, aligned=True))
+    paths = []
+    for f, im in enumerate(images):
+        paths.append(str(tmp_path / ("r%d.bam" % f)))
+        with open(paths[-1], "wb") as fh:
+            fh.write(im)
+    monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 1 << 16)
+    monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 1 << 16)
+    for paired, skip in ((False, None), (True, True)):
+        want = run_path(paths, gpu=False, paired=paired, skip=skip)
+        got = run_path(paths, gpu=True, paired=paired, skip=skip)
+        assert isinstance(want[0], dict) and sum(want[0].values()) == (names if not paired else 0)
+        assert got == want
+        assert xm.LAST_FILE_PROFILE.get("strip_kernels_ms", 0) > 0   # the device path really ran
 
 
 def _cigar_bam(n, seed, n_ops_of):

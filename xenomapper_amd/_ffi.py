@@ -156,7 +156,7 @@ def lib():
         "xm_bamdev_destroy": ([P], I),
         "xm_bamdev_reserve": ([P, I, U64, U64, U64, U64], I),
         "xm_bamdev_staging": ([P, I, I], P),
-        "xm_bamdev_run": ([P, I, P, I, I, I, U64, P], I),
+        "xm_bamdev_run": ([P, I, P, I, I, I, I, U64, P], I),
         "xm_bamdev_raw_wait": ([P, I], I),
         "xm_bamdev_fetch_raw": ([P, I], I),
         "xm_bamdev_fetch_wanted": ([P, I, U64, I, ctypes.c_uint32, P], I),
@@ -1004,8 +1004,9 @@ class BamDev(object):
     def staging(self, slot, file):
         return _host_view(self._L.xm_bamdev_staging(self._h, slot, file), self._cap[slot][0], np.uint8)
 
-    def run(self, slot, inputs, score_mode, paired, keep_halo, max_records, wait_raw=True):
+    def run(self, slot, inputs, score_mode, paired, keep_halo, max_records, wait_raw=True, skip_repeated=False):
         """inputs: two dicts {comp_len, blocks (BGZF_BLOCK array), crc (uint32 array), carry_slot, carry_off, carry_len, eof, skip}.
+        skip_repeated: the skipping walk of getReadPairs (pair k = the first record of run k of either file).
         wait_raw=False: the inflated windows stay on the device -- the file path then asks for what the writer needs
         (fetch_wanted after classify, or fetch_raw) and waits for it (raw_wait) in the thread that prints the records."""
         arr = (_BamDevInput * 2)()
@@ -1019,8 +1020,8 @@ class BamDev(object):
                                   int(x.get("carry_off", 0)), int(x.get("carry_len", 0)), int(bool(x["eof"])), int(x.get("skip", 0)),
                                   int(x.get("uploaded", 0)))
         raw = _BamDevBlock()
-        rc = self._L.xm_bamdev_run(self._h, slot, ctypes.byref(arr), int(score_mode), int(bool(paired)), int(bool(keep_halo)),
-                                   int(max_records), ctypes.byref(raw))
+        rc = self._L.xm_bamdev_run(self._h, slot, ctypes.byref(arr), int(score_mode), int(bool(paired)), int(bool(skip_repeated)),
+                                   int(bool(keep_halo)), int(max_records), ctypes.byref(raw))
         self._check(rc, "xm_bamdev_run")
         if wait_raw:                                                 # the whole inflated windows on the host (tests; windows the host walks)
             self.fetch_raw(slot)

@@ -295,6 +295,55 @@ cig_fill_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ n_
     if (c >= 255u) ops[pos + c] = (c << 4) | 15u;
 }
 
+// ---- skip_repeated_reads (getReadPairs, xenomapper.py:110-117): a file is cut into runs of adjacent records with one name; pair k
+// is the first record of run k of both files.  R1 marks the run starts, the size scan of W2 ranks them, R2 moves the fields of
+// the run starts next to each other -- behind it the pair kernel and everything after it see a file of run starts only.
+struct RecCols {
+    uint32_t *rec_off, *name_off, *name_len;
+    int32_t *a, *x;
+    uint8_t *flag;
+    uint32_t *n_cigar, *cig_at;                 // --cigar_scores runs only (else null)
+};
+
+__global__ void __launch_bounds__(256)
+run_start_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ name_off, const uint32_t *__restrict__ name_len,
+                 const uint8_t *__restrict__ flag, uint32_t n, uint32_t *__restrict__ is_start, uint32_t *__restrict__ state)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    // a record the text rules might read differently may cut the runs differently, yielded or not (state[2] as the pair kernel's)
+    const uint32_t g = flag[i], wb = ((g & R_WEIRD) ? 1u : 0u) | ((g & R_BAD) ? 2u : 0u);
+    if (wb) atomicOr(&state[2], wb);
+    bool st = i == 0u;
+    if (!st) {
+        const uint32_t l = name_len[i];
+        st = l != name_len[i - 1u];
+        if (!st) {
+            const uint8_t *p = raw + name_off[i], *q = raw + name_off[i - 1u];
+            uint32_t diff = 0;
+            for (uint32_t k = 0; k < l; ++k) diff |= (uint32_t)(p[k] ^ q[k]);
+            st = diff != 0u;
+        }
+    }
+    is_start[i] = st ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+run_select_kernel(RecCols from, const uint32_t *__restrict__ place, uint32_t n, RecCols to)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = place[i];
+    if (j == 0xFFFFFFFFu) return;
+    to.rec_off[j] = from.rec_off[i];
+    to.name_off[j] = from.name_off[i];
+    to.name_len[j] = from.name_len[i];
+    to.a[j] = from.a[i];
+    to.x[j] = from.x[i];
+    to.flag[j] = from.flag[i];
+    if (from.n_cigar != nullptr) { to.n_cigar[j] = from.n_cigar[i]; to.cig_at[j] = from.cig_at[i]; }
+}
+
 // ---- B5: one lane per pair --------------------------------------------------------------------------------------------
 struct FileRecs {
     const uint8_t *raw;
@@ -310,13 +359,22 @@ __device__ __forceinline__ bool same_name(const uint8_t *p, const uint8_t *q, ui
     return diff == 0u;
 }
 
-// state: [0] first mismatch (atomicMin), [1] pairs with an exception, [2] weird | bad << 1
+// state: [0] first mismatch (atomicMin), [1] pairs with an exception, [2] weird | bad << 1, [3] first open run (atomicMin);
+// runs (the skipping walk; else null): runs[f] = run starts of file f (the most it can pair), open bit f = the file goes on behind
+// its window, so its last run may go on too and must not be yielded yet
 __global__ void __launch_bounds__(256)
-pair_kernel(FileRecs f1, FileRecs f2, uint32_t n, int paired, int32_t *__restrict__ as1, int32_t *__restrict__ xs1,
+pair_kernel(FileRecs f1, FileRecs f2, uint32_t n_launch, int paired, const uint32_t *__restrict__ runs, uint32_t open,
+            int32_t *__restrict__ as1, int32_t *__restrict__ xs1,
             int32_t *__restrict__ as2, int32_t *__restrict__ xs2, unsigned long long *__restrict__ unit_bits,
             uint8_t *__restrict__ lflag1, uint8_t *__restrict__ lflag2, uint32_t *__restrict__ state)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    uint32_t n = n_launch;
+    if (runs != nullptr) {
+        const uint32_t r1 = runs[0], r2 = runs[1];
+        n = min(n, min(r1, r2));
+        if (k < n && (((open & 1u) && k + 1u == r1) || ((open & 2u) && k + 1u == r2))) atomicMin(&state[3], k);
+    }
     bool unit = false;
     if (k < n) {
         const uint32_t g1 = f1.flag[k], g2 = f2.flag[k];
@@ -343,7 +401,7 @@ pair_kernel(FileRecs f1, FileRecs f2, uint32_t n, int paired, int32_t *__restric
         if (wb) atomicOr(&state[2], wb);
     }
     const unsigned long long m = __ballot(unit);
-    if ((threadIdx.x & 63u) == 0u && (k & ~63u) < ((n + 63u) & ~63u)) unit_bits[k >> 6] = m;
+    if ((threadIdx.x & 63u) == 0u && (k & ~63u) < ((n_launch + 63u) & ~63u)) unit_bits[k >> 6] = m;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -367,6 +425,13 @@ struct PerFile {
     uint32_t *d_name_off = nullptr, *d_name_len = nullptr;
     int32_t *d_a = nullptr, *d_x = nullptr;
     uint8_t *d_rflag = nullptr, *d_lflag = nullptr, *h_lflag = nullptr;
+    // the skipping walk: the fields of the run starts, next to each other (ensure_skip), and their record starts on the host
+    uint32_t *d_r_rec_off = nullptr, *d_r_name_off = nullptr, *d_r_name_len = nullptr, *d_r_ncig = nullptr, *d_r_cig_at = nullptr, *h_pair_off = nullptr;
+    int32_t *d_r_a = nullptr, *d_r_x = nullptr;
+    uint8_t *d_r_flag = nullptr;
+    uint64_t skip_records = 0, skip_cig_records = 0;
+    // what the pair kernel and everything behind it read: the records of the window, or its run starts
+    const uint32_t *v_rec_off = nullptr, *v_ncig = nullptr, *v_cig_at = nullptr;
     uint32_t *d_summary = nullptr, *h_summary = nullptr;
     uint64_t raw_len = 0;
     uint64_t table_len = 0;                 // entries of h_rec_off that are valid (the records of the slot's last window)
@@ -468,6 +533,9 @@ void free_slot(Slot &sl)
         q.slots_len = 0; q.ops_cap = q.cig_records = q.cig_slots = 0;
         dfree(q.d_rec_off); hfree(q.h_rec_off); dfree(q.d_name_off); dfree(q.d_name_len); dfree(q.d_a); dfree(q.d_x);
         dfree(q.d_rflag); dfree(q.d_lflag); hfree(q.h_lflag);
+        dfree(q.d_r_rec_off); dfree(q.d_r_name_off); dfree(q.d_r_name_len); dfree(q.d_r_ncig); dfree(q.d_r_cig_at); hfree(q.h_pair_off);
+        dfree(q.d_r_a); dfree(q.d_r_x); dfree(q.d_r_flag);
+        q.skip_records = q.skip_cig_records = 0;
     }
     dfree(sl.d_comp_all); dfree(sl.d_raw_all);
     hfree(sl.h_blocks); dfree(sl.d_blocks); hfree(sl.h_walk); dfree(sl.d_walk); dfree(sl.d_status); hfree(sl.h_status); dfree(sl.d_crc); hfree(sl.h_crc);
@@ -507,6 +575,28 @@ static int ensure_cigar(xm_bamdev *b, Slot &sl)
     return XM_OK;
 }
 
+// skip_repeated_reads: the arrays only the skipping walk needs
+static int ensure_skip(xm_bamdev *b, Slot &sl, bool cigar)
+{
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        const size_t n = (size_t)sl.record_cap + 64;
+        if (q.skip_records < sl.record_cap) {
+            q.skip_records = 0;
+            XMB_TRY(dalloc(b, q.d_r_rec_off, n)); XMB_TRY(dalloc(b, q.d_r_name_off, n)); XMB_TRY(dalloc(b, q.d_r_name_len, n));
+            XMB_TRY(dalloc(b, q.d_r_a, n)); XMB_TRY(dalloc(b, q.d_r_x, n)); XMB_TRY(dalloc(b, q.d_r_flag, n));
+            XMB_TRY(halloc(b, q.h_pair_off, n));
+            q.skip_records = sl.record_cap;
+        }
+        if (cigar && q.skip_cig_records < sl.record_cap) {
+            q.skip_cig_records = 0;
+            XMB_TRY(dalloc(b, q.d_r_ncig, n)); XMB_TRY(dalloc(b, q.d_r_cig_at, n));
+            q.skip_cig_records = sl.record_cap;
+        }
+    }
+    return XM_OK;
+}
+
 // the packed CIGAR columns of one file's first n records, queued on the slot's stream (C1, the size scan, C2)
 static int pack_cigar(Slot &sl, int f, uint32_t n)
 {
@@ -514,11 +604,11 @@ static int pack_cigar(Slot &sl, int f, uint32_t n)
     if (q.cig_records < n || q.ops_cap == 0 || n == 0) return XM_ERR_INVALID_ARG;
     hipStream_t st = sl.stream;
     const uint32_t n_part = (n + SCAN_TILE - 1u) / SCAN_TILE;
-    cig_size_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_ncig, n, q.d_cig_cnt, q.d_wsize);
+    cig_size_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.v_ncig, n, q.d_cig_cnt, q.d_wsize);
     size_sum_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part);
     part_scan_kernel<<<1, 1024, 0, st>>>(q.d_part, n_part, sl.d_state + 10 + f);
     size_place_kernel<true><<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part, q.d_place);
-    cig_fill_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_raw, q.d_ncig, q.d_cig_at, q.d_place, sl.d_state + 10 + f, n, q.d_cig_tile, q.d_cig_ops,
+    cig_fill_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_raw, q.v_ncig, q.v_cig_at, q.d_place, sl.d_state + 10 + f, n, q.d_cig_tile, q.d_cig_ops,
                                                       (uint32_t)std::min<uint64_t>(q.ops_cap, 0xFFFFFFFFull));
     return XM_OK;
 }
@@ -684,7 +774,7 @@ uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file)
     return b->slot[slot].pf[file].h_comp;
 }
 
-int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int keep_halo,
+int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int skip_repeated, int keep_halo,
                   uint64_t max_records, xm_bamdev_block *out)
 {
     if (!b || !in || !out || slot < 0 || slot > 1 || (score_mode != XMS_SCORE_AS_XS && score_mode != XMS_SCORE_AS_ZS && score_mode != XMS_SCORE_CIGAR) || max_records == 0)
@@ -700,6 +790,8 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     sl.classified = false;
     XMB_HIP(b, hipSetDevice(b->device));
     if (cigar) XMB_TRY(ensure_cigar(b, sl));
+    const bool skip = skip_repeated != 0;
+    if (skip) XMB_TRY(ensure_skip(b, sl, cigar));
     hipStream_t st = sl.stream;
     static const bool profile = getenv("XM_BAMDEV_PROFILE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -849,7 +941,7 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     out->raw_len1 = sl.pf[0].raw_len; out->raw_len2 = sl.pf[1].raw_len;
     out->n_rec1 = n_rec[0]; out->n_rec2 = n_rec[1];
     out->raw1 = sl.pf[0].h_raw; out->raw2 = sl.pf[1].h_raw;
-    out->rec_off1 = sl.pf[0].h_rec_off; out->rec_off2 = sl.pf[1].h_rec_off;
+    out->rec_off1 = skip ? sl.pf[0].h_pair_off : sl.pf[0].h_rec_off; out->rec_off2 = skip ? sl.pf[1].h_pair_off : sl.pf[1].h_rec_off;
     out->flags1 = sl.pf[0].h_lflag; out->flags2 = sl.pf[1].h_lflag;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]);
@@ -857,10 +949,20 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     sl.pf[0].table_len = sl.pf[1].table_len = 0;
     if (out->bad_block || out->unaligned) return XM_OK;
     uint64_t n = std::min(std::min(n_rec[0], n_rec[1]), max_records);
+    const bool by_runs = skip && n > 0;                                    // the run kernels ran (a file without a record has no run either)
     // ---- strip + pair ------------------------------------------------------------------------------------------------------
     XMB_HIP(b, hipEventRecord(sl.ev[1], st));
-    sl.h_state[0] = 0xFFFFFFFFu; sl.h_state[1] = 0; sl.h_state[2] = 0;
-    XMB_HIP(b, hipMemcpyAsync(sl.d_state, sl.h_state, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    sl.h_state[0] = 0xFFFFFFFFu; sl.h_state[1] = 0; sl.h_state[2] = 0; sl.h_state[3] = 0xFFFFFFFFu;
+    sl.h_state[4] = sl.h_state[5] = sl.h_state[6] = sl.h_state[7] = 0;
+    XMB_HIP(b, hipMemcpyAsync(sl.d_state, sl.h_state, 8 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    bool whole[2];
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        whole[f] = in[f].eof && stop[f] == q.raw_len;                      // no record of the file lies behind this window
+        q.v_rec_off = skip ? q.d_r_rec_off : q.d_rec_off;
+        q.v_ncig = skip ? q.d_r_ncig : q.d_ncig;
+        q.v_cig_at = skip ? q.d_r_cig_at : q.d_cig_at;
+    }
     if (n) {
         for (int f = 0; f < 2; ++f) {
             // the records of the carried tail (they come first): parsed here; the blocks' records came parsed with the inflate
@@ -869,24 +971,41 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
             const uint32_t n_seg = q.h_summary[8], n_carry_seg = q.h_summary[9];
             if (n_carry_seg == 0u) continue;
             const RecOut ro = {q.d_name_off, q.d_name_len, q.d_a, q.d_x, q.d_rflag, cigar ? q.d_ncig : nullptr, cigar ? q.d_cig_at : nullptr};
-            const uint64_t upper = std::min<uint64_t>(n, in[f].carry_len / 36u + 1u);
+            const uint64_t upper = std::min<uint64_t>(skip ? n_rec[f] : n, in[f].carry_len / 36u + 1u);     // (the skipping walk reads every name)
             parse_kernel<<<(uint32_t)((upper + 255) / 256), 256, 0, st>>>(q.d_raw, q.d_rec_off, (uint32_t)upper, n_carry_seg < n_seg ? q.d_base + n_carry_seg : nullptr,
                                                                          tags, ro);
         }
+        for (int f = 0; f < 2 && skip; ++f) {
+            // the run starts of the file's records, their fields next to each other; how many: d_state[4 + f]
+            PerFile &q = sl.pf[f];
+            const uint32_t nf = (uint32_t)n_rec[f], n_part = (nf + SCAN_TILE - 1u) / SCAN_TILE;
+            run_start_kernel<<<(nf + 255u) / 256u, 256, 0, st>>>(q.d_raw, q.d_name_off, q.d_name_len, q.d_rflag, nf, q.d_wsize, sl.d_state);
+            size_sum_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, nf, q.d_part);
+            part_scan_kernel<<<1, 1024, 0, st>>>(q.d_part, n_part, sl.d_state + 4 + f);
+            size_place_kernel<false><<<n_part, 256, 0, st>>>(q.d_wsize, nf, q.d_part, q.d_place);
+            const RecCols from = {q.d_rec_off, q.d_name_off, q.d_name_len, q.d_a, q.d_x, q.d_rflag, cigar ? q.d_ncig : nullptr, cigar ? q.d_cig_at : nullptr};
+            const RecCols to = {q.d_r_rec_off, q.d_r_name_off, q.d_r_name_len, q.d_r_a, q.d_r_x, q.d_r_flag, q.d_r_ncig, q.d_r_cig_at};
+            run_select_kernel<<<(nf + 255u) / 256u, 256, 0, st>>>(from, q.d_place, nf, to);
+        }
         const PerFile &a = sl.pf[0], &c = sl.pf[1];
-        const FileRecs f1 = {a.d_raw, a.d_name_off, a.d_name_len, a.d_a, a.d_x, a.d_rflag};
-        const FileRecs f2 = {c.d_raw, c.d_name_off, c.d_name_len, c.d_a, c.d_x, c.d_rflag};
-        pair_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(f1, f2, (uint32_t)n, paired ? 1 : 0, sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3],
+        const FileRecs f1 = skip ? FileRecs{a.d_raw, a.d_r_name_off, a.d_r_name_len, a.d_r_a, a.d_r_x, a.d_r_flag}
+                                 : FileRecs{a.d_raw, a.d_name_off, a.d_name_len, a.d_a, a.d_x, a.d_rflag};
+        const FileRecs f2 = skip ? FileRecs{c.d_raw, c.d_r_name_off, c.d_r_name_len, c.d_r_a, c.d_r_x, c.d_r_flag}
+                                 : FileRecs{c.d_raw, c.d_name_off, c.d_name_len, c.d_a, c.d_x, c.d_rflag};
+        pair_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(f1, f2, (uint32_t)n, paired ? 1 : 0, skip ? sl.d_state + 4 : nullptr,
+                                                                   (whole[0] ? 0u : 1u) | (whole[1] ? 0u : 2u), sl.d_col[0], sl.d_col[1], sl.d_col[2], sl.d_col[3],
                                                                    reinterpret_cast<unsigned long long *>(sl.d_bits), sl.pf[0].d_lflag, sl.pf[1].d_lflag, sl.d_state);
         for (int f = 0; f < 2; ++f) {
             PerFile &q = sl.pf[f];
             XMB_HIP(b, hipMemcpyAsync(q.h_lflag, q.d_lflag, (size_t)n, hipMemcpyDeviceToHost, st));
+            if (skip)                                                      // where the run starts' records begin: entry n too, when there is one
+                XMB_HIP(b, hipMemcpyAsync(q.h_pair_off, q.d_r_rec_off, (size_t)std::min<uint64_t>(n + 1, n_rec[f]) * 4, hipMemcpyDeviceToHost, st));
         }
     }
     for (int f = 0; f < 2; ++f)                                            // the whole record table: the writer prints from it, and the next
         if (n_rec[f])                                                      // window cuts its carried tail at boundaries it lists
             XMB_HIP(b, hipMemcpyAsync(sl.pf[f].h_rec_off, sl.pf[f].d_rec_off, (size_t)n_rec[f] * 4, hipMemcpyDeviceToHost, st));
-    XMB_HIP(b, hipMemcpyAsync(sl.h_state, sl.d_state, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    XMB_HIP(b, hipMemcpyAsync(sl.h_state, sl.d_state, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     XMB_HIP(b, hipEventRecord(sl.ev[2], st));
     XMB_HIP(b, hipEventRecord(sl.ev_wait, st));
     XMB_HIP(b, hipEventSynchronize(sl.ev_wait));
@@ -895,12 +1014,26 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     out->ms_kernels = ms;
     if (sl.h_state[2] & 2u) { out->bad_block = 3; return XM_OK; }          // a malformed record
     if (sl.h_state[2] & 1u) out->weird = 1;
+    // what each file can pair: its records, or (the skipping walk) its runs
+    uint64_t n_can[2] = {n_rec[0], n_rec[1]};
+    if (by_runs) {
+        n_can[0] = sl.h_state[4]; n_can[1] = sl.h_state[5];
+        if (n_can[0] > n_rec[0] || n_can[1] > n_rec[1]) return XM_ERR_HIP;
+        n = std::min(n, std::min(n_can[0], n_can[1]));
+    }
+    bool cut = false, open_run = false;
     if (sl.h_state[0] != 0xFFFFFFFFu && sl.h_state[0] < n) {
         out->mismatch_at = (int64_t)sl.h_state[0];
         n = sl.h_state[0];                                                  // records at and behind it are not reported
+        cut = true;
+    }
+    if (by_runs && sl.h_state[3] < n) {                                        // a run that may go on in the next window comes first
+        out->mismatch_at = -1;
+        n = sl.h_state[3];
+        cut = open_run = true;
     }
     out->n_exceptions = sl.h_state[1];
-    if (out->mismatch_at >= 0) {                                            // the device counted the pairs behind the mismatch too
+    if (cut) {                                                              // the device counted the pairs behind the stop too
         uint64_t e = 0;
         for (uint64_t k = 0; k < n; ++k) e += ((sl.pf[0].h_lflag[k] | sl.pf[1].h_lflag[k]) & (XMS_LINE_EX_A | XMS_LINE_EX_X)) ? 1u : 0u;
         out->n_exceptions = e;
@@ -908,9 +1041,9 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     // the walk's outcome, as xmh_parse reports it: a file that has no record left AND no byte left at its end ends the walk
     bool ended = false, starved = false;
     if (out->mismatch_at < 0) {
-        for (int f = 0; f < 2; ++f) {
-            const bool exhausted = n == n_rec[f];                           // the window holds no further complete record
-            if (exhausted && in[f].eof && stop[f] == sl.pf[f].raw_len) ended = true;
+        for (int f = 0; f < 2 && !open_run; ++f) {
+            const bool exhausted = n == n_can[f];                           // the window holds no further complete record (or run)
+            if (exhausted && whole[f]) ended = true;
         }
         if (!ended && n < max_records) starved = true;                      // a window ran out before the other file did
     }
@@ -925,8 +1058,9 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     sl.pf[1].table_len = n_rec[1];
     for (int f = 0; f < 2; ++f) {
         const PerFile &q = sl.pf[f];
-        uint64_t c = n < n_rec[f] ? q.h_rec_off[n] : stop[f];              // first byte behind the yielded records
-        if (keep_halo && n > 0 && !ended && out->mismatch_at < 0) c = q.h_rec_off[n - 1];
+        const uint32_t *table = by_runs ? q.h_pair_off : q.h_rec_off;
+        uint64_t c = n < n_can[f] ? table[n] : stop[f];                    // first byte behind the yielded records (and the ones skipped)
+        if (keep_halo && n > 0 && !ended && out->mismatch_at < 0) c = table[n - 1];
         (f == 0 ? out->consumed1 : out->consumed2) = c;
     }
     sl.have_columns = true;
@@ -975,14 +1109,14 @@ int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paire
     const uint32_t n = (uint32_t)n_records;
     if (n) {
         const uint32_t n_part = (n + SCAN_TILE - 1u) / SCAN_TILE;
-        want_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(sl.pf[0].d_raw, sl.pf[1].d_raw, sl.pf[0].d_rec_off, sl.pf[1].d_rec_off, sl.d_bins4, n, paired ? 1 : 0,
+        want_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(sl.pf[0].d_raw, sl.pf[1].d_raw, sl.pf[0].v_rec_off, sl.pf[1].v_rec_off, sl.d_bins4, n, paired ? 1 : 0,
                                                        sink_mask, sl.pf[0].d_wsize, sl.pf[1].d_wsize);
         for (int f = 0; f < 2; ++f) {
             PerFile &q = sl.pf[f];
             size_sum_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part);
             part_scan_kernel<<<1, 1024, 0, st>>>(q.d_part, n_part, sl.d_state + 8 + f);
             size_place_kernel<false><<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part, q.d_place);
-            pack_kernel<<<(n + 3u) / 4u, 256, 0, st>>>(q.d_raw, q.d_rec_off, q.d_wsize, q.d_place, n, q.d_packed);
+            pack_kernel<<<(n + 3u) / 4u, 256, 0, st>>>(q.d_raw, q.v_rec_off, q.d_wsize, q.d_place, n, q.d_packed);
         }
         XMB_HIP(b, hipMemcpyAsync(sl.h_state + 8, sl.d_state + 8, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         XMB_HIP(b, hipEventRecord(sl.ev_wait, st));

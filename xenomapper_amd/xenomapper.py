@@ -1245,11 +1245,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     prof = _PhaseClock()
     _EMIT_CLOCK.clear()
     t_all = time.perf_counter()
-    # BAM on the GPU (include/xenomapper_bgzf.h): inflate + record chain + stripper on the device for the plain walk with the three
-    # plugins (--cigar_scores: NM and the records' CIGAR words become the packed CIGAR columns on the device); the skipping walk
-    # and XENOMAPPER_GPU_BAM=0 keep the host decoder
+    # BAM on the GPU (include/xenomapper_bgzf.h): inflate + record chain + stripper on the device, either walk, the three plugins
+    # (--cigar_scores: NM and the records' CIGAR words become the packed CIGAR columns on the device); XENOMAPPER_GPU_BAM=0 keeps
+    # the host decoder
     bamdev = None
-    if (bam and not skip_repeated and min_score == min_score and os.environ.get("XENOMAPPER_GPU_BAM", "1") != "0"):
+    if (bam and min_score == min_score and os.environ.get("XENOMAPPER_GPU_BAM", "1") != "0"):
         try:
             bamdev = default_bamdev()
         except MemoryError:
@@ -1339,7 +1339,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     src.read_ahead(bamdev, slot, f, bam_reader)
             bam_ahead[0] = bam_ahead_pool.submit(ahead_job)
         with prof("strip"):
-            blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2), wait_raw=False)
+            blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2), wait_raw=False,
+                             skip_repeated=skip_repeated)
             prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_inflate
             prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
         if blk.bad_block:
