@@ -73,9 +73,10 @@ def tiled_bam(src, dst, copies, aligned=True):
     return len(raw) - at
 
 
-def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False):
+def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False, single_end=False):
     """One warm-up and one timed pass over the tiled fixtures; returns the result record (also bench.py's `e2e.bam`).
-    cigar_scores: the --cigar_scores plugin (AS made of NM + CIGAR) instead of the AS / XS tags."""
+    cigar_scores: the --cigar_scores plugin (AS made of NM + CIGAR) instead of the AS / XS tags.  single_end: the files as
+    single-end input, as the command line runs it: the skipping walk (every run of equal names yields its first record)."""
     import types
     a = types.SimpleNamespace(copies=copies, threads=threads, dir=workdir)
     from xenomapper_amd import _host, xenomapper as xm
@@ -91,11 +92,11 @@ def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False):
         xm.default_context()
         for _warm in (True, False):
             t0 = time.perf_counter()
-            counts = xm.classify_sam_files(paths[0], paths[1], paired=True, n_threads=a.threads, bam=True,
+            counts = xm.classify_sam_files(paths[0], paths[1], paired=not single_end, n_threads=a.threads, bam=True,
                                            tag_func=xm.get_cigarbased_AS_tag if cigar_scores else xm.get_tag, **sinks)
             el = time.perf_counter() - t0
         units = sum(counts.values())
-        return {"metric": "end-to-end read-pairs/s (BAM in, six SAM files out)", "value": units / el,
+        return {"metric": "end-to-end %s/s (BAM in, six SAM files out)" % ("reads" if single_end else "read-pairs"), "value": units / el,
                 "plugin": "get_cigarbased_AS_tag" if cigar_scores else "get_tag", "units": units, "seconds": el, "bam_bytes": size, "bam_GBps": size / el / 1e9,
                 "threads": a.threads or _host.lib().xmh_default_threads(),
                 "phases": {k: round(v, 4) for k, v in xm.LAST_FILE_PROFILE.items()}}
@@ -110,8 +111,9 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--cigar_scores", action="store_true")
+    ap.add_argument("--single_end", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.copies, a.threads, a.dir, a.cigar_scores)))
+    print(json.dumps(run(a.copies, a.threads, a.dir, a.cigar_scores, a.single_end)))
 
 
 if __name__ == "__main__":
