@@ -437,43 +437,174 @@ struct Chain {
         }
         op += len;
     }
-    XMI_HD void huffman_block()
+    // one token through the bit reader: a literal, a match, or the end of the block (true: the block goes on)
+    XMI_HD bool serial_token()
+    {
+        need32();
+        const uint32_t s = decode(m->lit_root, LIT_ROOT, m->lit_sym, m->lit_meta);
+        if (s < 256u) {
+            if (op >= oend) { err = ERR_OUT; return false; }
+            if (gl == 0u) put_byte(op, s);
+            XMI_STAT_LITERAL();
+            ++op;
+            maybe_flush();
+            return true;
+        }
+        if (s == 256u) return false;
+        if (s > 285u) { err = ERR_LENSYM; return false; }
+        uint32_t len;
+        if (s < 265u) len = s - 254u;
+        else if (s == 285u) len = 258u;
+        else { const uint32_t eb = (s - 261u) >> 2; len = ((4u + ((s - 261u) & 3u)) << eb) + 3u + get(eb); }
+        need32();
+        const uint32_t d = decode(m->dist_root, DIST_ROOT, m->dist_sym, m->dist_meta);
+        if (err) return false;
+        if (d > 29u) { err = ERR_DIST; return false; }
+        uint32_t dist;
+        if (d < 4u) dist = d + 1u;
+        else { const uint32_t eb = (d >> 1) - 1u; dist = ((2u + (d & 1u)) << eb) + 1u + get(eb); }
+        if (dist > op - ostart) { err = ERR_DIST; return false; }
+        if (len > oend - op) { err = ERR_OUT; return false; }
+        chain_sync();                                                   // literals written by lane 0 are in the ring
+        XMI_STAT_MATCH(len, dist, op - dist < gsafe);
+        copy_match(len, dist);
+        maybe_flush();
+        return true;
+    }
+    XMI_HD void huffman_block_serial()
     {
         // (no step budget in THIS loop, unlike the others: every pass drops at least one bit of the stream -- a code that matches
         // nothing sets err -- and need32() sets err once the reading position is 12 bytes past the block's compressed bytes, so
         // the loop ends after at most 8 x (compressed bytes + 16) passes whatever the data holds; the counter cost 4 % of the launch)
-        while (!err) {
-            need32();
-            const uint32_t s = decode(m->lit_root, LIT_ROOT, m->lit_sym, m->lit_meta);
-            if (s < 256u) {
-                if (op >= oend) { err = ERR_OUT; return; }
-                if (gl == 0u) put_byte(op, s);
-                XMI_STAT_LITERAL();
-                ++op;
-                maybe_flush();
-                continue;
-            }
-            if (s == 256u) return;
-            if (s > 285u) { err = ERR_LENSYM; return; }
-            uint32_t len;
-            if (s < 265u) len = s - 254u;
-            else if (s == 285u) len = 258u;
-            else { const uint32_t eb = (s - 261u) >> 2; len = ((4u + ((s - 261u) & 3u)) << eb) + 3u + get(eb); }
-            need32();
-            const uint32_t d = decode(m->dist_root, DIST_ROOT, m->dist_sym, m->dist_meta);
-            if (err) return;
-            if (d > 29u) { err = ERR_DIST; return; }
-            uint32_t dist;
-            if (d < 4u) dist = d + 1u;
-            else { const uint32_t eb = (d >> 1) - 1u; dist = ((2u + (d & 1u)) << eb) + 1u + get(eb); }
-            if (dist > op - ostart) { err = ERR_DIST; return; }
-            if (len > oend - op) { err = ERR_OUT; return; }
-            chain_sync();                                                   // literals written by lane 0 are in the ring
-            XMI_STAT_MATCH(len, dist, op - dist < gsafe);
-            copy_match(len, dist);
-            maybe_flush();
-        }
+        while (!err && serial_token()) { }
     }
+
+#if XMI_DEVICE && defined(XMI_WIDE_TOKENS)
+    // ---- the wide token loop (one chain = one whole wave): an A/B build, NOT what ships --------------------------------------
+    // Byte-exact on every block of the 1 GB check, and exactly as fast as the serial loop (30.5 against 30.6 ms, profiles/
+    // r05_ab_inflate_variants.txt): the literals' decoding moves to the scalar unit, but the matches' copies and the loop around
+    // them keep the VECTOR instructions per token where they were (~40; a wave64 instruction holds its SIMD for 4 cycles, 8 waves
+    // a SIMD: that is the launch's bound).  Kept as the base of the step that would pay: producing a window's bytes in parallel.
+    // The serial loop above computes every token in all 64 lanes alike: ~90 instructions a token.  Here the lanes do different work: lane i decodes the WHOLE token that would
+    // begin at bit P + i of the stream -- literal, or length + extra bits + distance + extra bits (at most 48 bits: each lane
+    // reads its own 64) -- with both root-table lookups, branch-free; which lanes really begin a token is then found by walking
+    // from lane 0 (bit P begins one) with the scalar unit: read the lane's packed token, act, step on by its bit count.  A
+    // window of 64 bits holds about six tokens of BAM data; the walk costs a dozen scalar instructions a token.  Literals are
+    // not written one by one: the walk notes their lanes in a mask, and they go to the ring together (their positions follow
+    // from their rank in the mask) before anything reads the ring (a match, a flush, the end).  A lane whose bits need the long-code path (codes beyond the root
+    // tables: rare) or hold no valid token is marked; when the walk reaches one, the serial reader takes that one token.
+    static constexpr uint32_t K_LIT = 0u, K_MATCH = 1u, K_EOB = 2u, K_SLOW = 3u;
+    XMI_HD void seek_bits(uint32_t bitpos)            // the serial reader continues at this bit of the stream
+    {
+        in_pos = (bitpos >> 5) << 2;
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(m->iring + (in_pos & (IRING - 1u)));
+        bits = (uint64_t)w;
+        nbits = 32u;
+        in_pos += 4u;
+        drop(bitpos & 31u);
+    }
+    XMI_HD uint32_t window_tokens(uint32_t bitpos) const
+    {
+        const uint32_t b = bitpos + gl, w0 = (b >> 5) << 2, sh = b & 31u;
+        const uint32_t a0 = *reinterpret_cast<const uint32_t *>(m->iring + (w0 & (IRING - 1u)));
+        const uint32_t a1 = *reinterpret_cast<const uint32_t *>(m->iring + ((w0 + 4u) & (IRING - 1u)));
+        const uint32_t a2 = *reinterpret_cast<const uint32_t *>(m->iring + ((w0 + 8u) & (IRING - 1u)));
+        const uint32_t x0 = __builtin_amdgcn_alignbit(a1, a0, sh), x1 = __builtin_amdgcn_alignbit(a2, a1, sh);
+        const uint32_t e = m->lit_root[x0 & ((1u << LIT_ROOT) - 1u)];
+        const uint32_t L = e & 15u, sym = e >> 4;
+        // as a length symbol
+        const uint32_t ls = sym - 257u;
+        const uint32_t leb = (ls < 8u || ls >= 28u) ? 0u : (ls - 4u) >> 2;
+        const uint32_t lbase = ls < 8u ? ls + 3u : ls == 28u ? 258u : ((4u + ((ls - 4u) & 3u)) << leb) + 3u;
+        const uint32_t len = lbase + ((x0 >> L) & ((1u << leb) - 1u));
+        const uint32_t o2 = L + leb;                                        // <= 20
+        const uint32_t y = __builtin_amdgcn_alignbit(x1, x0, o2);
+        const uint32_t de = m->dist_root[y & ((1u << DIST_ROOT) - 1u)];
+        const uint32_t DL = de & 15u, d = de >> 4;
+        const uint32_t deb = d < 4u ? 0u : (d >> 1) - 1u;
+        const uint32_t dbase = d < 4u ? d + 1u : ((2u + (d & 1u)) << deb) + 1u;
+        const uint32_t dist = dbase + ((y >> DL) & ((1u << deb) - 1u));
+        const bool is_lit = sym < 256u, is_eob = sym == 256u;
+        const bool bad = L == 0u || (!is_lit && !is_eob && (ls > 28u || DL == 0u || d > 29u));
+        const uint32_t kind = bad ? K_SLOW : is_lit ? K_LIT : is_eob ? K_EOB : K_MATCH;
+        const uint32_t total = (is_lit || is_eob) ? L : o2 + DL + deb;      // <= 48
+        const uint32_t val = is_lit ? sym : len;
+        return total | (kind << 6) | (val << 8) | (((dist - 1u) & 0x7FFFu) << 17);
+    }
+    // the noted literals are the last popcount(lits) bytes in front of `ops`, in lane order (nothing else was produced since
+    // the last call: a match writes them first)
+    XMI_HD void put_literals(uint64_t lits, uint32_t ops, uint32_t info)
+    {
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u));
+        if ((lits >> gl) & 1ull) put_byte(ops - (uint32_t)__popcll(lits) + below, info >> 8);
+    }
+    XMI_HD void huffman_block()
+    {
+        if (GS != 64) { huffman_block_serial(); return; }
+        uint32_t P = in_pos * 8u - nbits;                                   // the stream's next bit
+        bool more = true;
+        while (more && !err) {
+            const uint32_t bytepos = P >> 3;
+            if (bytepos > cend + 12u) { err = ERR_IN; break; }
+            if (loaded - bytepos < 64u) { land_load(); issue_load(); }
+            const uint32_t info = window_tokens(P);
+            uint32_t s = 0;
+            while (s < 64u) {
+                // the scalar unit's part: the run of literals from lane s on -- as many as fit in front of the next flush and
+                // the block's end -- noted in a mask; it stops at the first token of another kind (t, at lane s)
+                const uint32_t left = oend - op, to_flush = FLUSH - (op - flushed);
+                const uint32_t room = __builtin_amdgcn_readfirstlane(left < to_flush ? left : to_flush);
+                uint32_t ss = __builtin_amdgcn_readfirstlane(s), n = 0, t;
+                uint64_t lits = 0;
+                for (;;) {
+                    t = __builtin_amdgcn_readlane(info, ss);
+                    if ((t & 0xC0u) != (K_LIT << 6) || n >= room) break;
+                    lits |= 1ull << ss;
+                    ++n;
+                    ss += t & 63u;
+                    if (ss >= 64u) break;
+                }
+                if (n) {
+                    op += n;
+                    put_literals(lits, op, info);
+                }
+                s = ss;
+                if (s >= 64u) break;
+                const uint32_t kind = (t >> 6) & 3u;
+                if (kind == K_LIT) {                                        // the run stopped for want of room
+                    if (op >= oend) { err = ERR_OUT; more = false; break; }
+                    chain_sync();
+                    maybe_flush();
+                } else if (kind == K_MATCH) {
+                    const uint32_t len = (t >> 8) & 0x1FFu, dist = (t >> 17) + 1u;
+                    if (dist > op - ostart) { err = ERR_DIST; more = false; break; }
+                    if (len > oend - op) { err = ERR_OUT; more = false; break; }
+                    chain_sync();
+                    copy_match(len, dist);
+                    maybe_flush();
+                    s += t & 63u;
+                } else if (kind == K_EOB) {
+                    s += t & 63u;
+                    more = false;
+                    break;
+                } else {
+                    // a token for the serial reader (a code beyond the root tables, or no valid code)
+                    chain_sync();
+                    seek_bits(P + s);
+                    more = serial_token();
+                    P = in_pos * 8u - nbits;
+                    s = 0xFFFFFFFFu;                                        // P is set: a new window
+                    break;
+                }
+            }
+            if (s != 0xFFFFFFFFu) P += s;
+        }
+        chain_sync();
+        seek_bits(P);
+    }
+#else
+    XMI_HD void huffman_block() { huffman_block_serial(); }
+#endif
 
     // the whole BGZF block: comp + coff .. + clen -> out + ooff .. + isize.  Returns the status.
     XMI_HD int run(ChainMem *mem, uint32_t lane_in_chain, const uint8_t *comp, uint64_t coff, uint32_t clen,
