@@ -479,21 +479,26 @@ struct Chain {
         while (!err && serial_token()) { }
     }
 
-#if XMI_DEVICE && defined(XMI_WIDE_TOKENS)
-    // ---- the wide token loop (one chain = one whole wave): an A/B build, NOT what ships --------------------------------------
-    // Byte-exact on every block of the 1 GB check, and exactly as fast as the serial loop (30.5 against 30.6 ms, profiles/
-    // r05_ab_inflate_variants.txt): the literals' decoding moves to the scalar unit, but the matches' copies and the loop around
-    // them keep the VECTOR instructions per token where they were (~40; a wave64 instruction holds its SIMD for 4 cycles, 8 waves
-    // a SIMD: that is the launch's bound).  Kept as the base of the step that would pay: producing a window's bytes in parallel.
-    // The serial loop above computes every token in all 64 lanes alike: ~90 instructions a token.  Here the lanes do different work: lane i decodes the WHOLE token that would
-    // begin at bit P + i of the stream -- literal, or length + extra bits + distance + extra bits (at most 48 bits: each lane
-    // reads its own 64) -- with both root-table lookups, branch-free; which lanes really begin a token is then found by walking
-    // from lane 0 (bit P begins one) with the scalar unit: read the lane's packed token, act, step on by its bit count.  A
-    // window of 64 bits holds about six tokens of BAM data; the walk costs a dozen scalar instructions a token.  Literals are
-    // not written one by one: the walk notes their lanes in a mask, and they go to the ring together (their positions follow
-    // from their rank in the mask) before anything reads the ring (a match, a flush, the end).  A lane whose bits need the long-code path (codes beyond the root
-    // tables: rare) or hold no valid token is marked; when the walk reaches one, the serial reader takes that one token.
-    static constexpr uint32_t K_LIT = 0u, K_MATCH = 1u, K_EOB = 2u, K_SLOW = 3u;
+#if XMI_DEVICE && !defined(XMI_SERIAL_TOKENS)
+    // ---- the wide token loop (one chain = one whole wave): what ships; -DXMI_SERIAL_TOKENS builds the loop above instead ----------
+    // The serial loop above computes every token in all 64 lanes alike: ~90 instructions a token, and instruction issue is what
+    // the launch is bound by (a wave64 vector instruction holds its SIMD for four cycles, eight waves a SIMD; the CU's one scalar
+    // unit is as full).  Here the lanes do different work, twice over -- 30.7 -> 20.0 ms per GB of BAM, profiles/
+    // r05_ab_inflate_variants.txt.
+    // DECODING: lane i decodes the WHOLE token that would begin at bit P + i of the stream -- literal, or length + extra bits +
+    // distance + extra bits (at most 48 bits: each lane reads its own 64) -- with both root-table lookups, branch-free; which
+    // lanes really begin a token is found by walking from lane 0 (bit P begins one) with the scalar unit: read the lane's packed
+    // token (v_readlane), step on by its bit count.  A window of 64 bits holds about six tokens of BAM data.
+    // PRODUCING: the walk does not copy.  It deals the tokens out over the lanes of a BATCH of up to 64 output bytes -- lane j
+    // learns what byte j of the batch is made of: a literal, or "the byte `dist` in front of me" (a match longer than the batch's
+    // rest goes on in the next batch: the same rule) -- and emit_batch() makes all of them at once: sources in front of the batch
+    // come from the ring or from memory as ever, sources INSIDE the batch (overlapping matches, a match that copies a token of
+    // the same batch) are chased lane to lane (ds_bpermute pointer jumping: a chain of references halves every round).
+    // A lane whose bits need the long-code path (codes beyond the root tables: rare) or hold no valid token is marked; when the
+    // walk reaches one, the serial reader takes that one token.
+    // Packed token: bits 0-5 its length in bits, 6-14 the bytes it makes (0: not a token the walk can deal out -- then bits 15..
+    // say which: T_EOB, T_SLOW), 15-31 what they are made of: V_LIT | byte, or the distance.
+    static constexpr uint32_t V_LIT = 0x10000u, T_EOB = 1u, T_SLOW = 2u;
     XMI_HD void seek_bits(uint32_t bitpos)            // the serial reader continues at this bit of the stream
     {
         in_pos = (bitpos >> 5) << 2;
@@ -526,22 +531,42 @@ struct Chain {
         const uint32_t dist = dbase + ((y >> DL) & ((1u << deb) - 1u));
         const bool is_lit = sym < 256u, is_eob = sym == 256u;
         const bool bad = L == 0u || (!is_lit && !is_eob && (ls > 28u || DL == 0u || d > 29u));
-        const uint32_t kind = bad ? K_SLOW : is_lit ? K_LIT : is_eob ? K_EOB : K_MATCH;
         const uint32_t total = (is_lit || is_eob) ? L : o2 + DL + deb;      // <= 48
-        const uint32_t val = is_lit ? sym : len;
-        return total | (kind << 6) | (val << 8) | (((dist - 1u) & 0x7FFFu) << 17);
+        const uint32_t n = (bad || is_eob) ? 0u : is_lit ? 1u : len;
+        const uint32_t v = bad ? T_SLOW : is_eob ? T_EOB : is_lit ? (V_LIT | sym) : dist;
+        return total | (n << 6) | (v << 15);
     }
-    // the noted literals are the last popcount(lits) bytes in front of `ops`, in lane order (nothing else was produced since
-    // the last call: a match writes them first)
-    XMI_HD void put_literals(uint64_t lits, uint32_t ops, uint32_t info)
+    // bytes [op, op + T) from what the lanes of the batch hold
+    XMI_HD void emit_batch(uint32_t lane_val, uint32_t T)
     {
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u));
-        if ((lits >> gl) & 1ull) put_byte(ops - (uint32_t)__popcll(lits) + below, info >> 8);
+        if (T > oend - op) { err = ERR_OUT; return; }
+        const uint32_t pos = op + gl;
+        const bool active = gl < T, is_lit = (lane_val & V_LIT) != 0u;
+        const uint32_t dist = lane_val & 0xFFFFu;
+        const bool copies = active && !is_lit;
+        if (__builtin_amdgcn_ballot_w64(copies && dist > pos - ostart) != 0ull) { err = ERR_DIST; return; }
+        const uint32_t src = pos - dist;
+        const bool inside = copies && src >= op;
+        uint32_t ref = inside ? src - op : gl;
+        uint32_t byte = lane_val & 0xFFu;
+        if (copies && !inside) byte = byte_at(src);
+        for (;;) {                                                          // ref[j] = ref[ref[j]] until nothing moves
+            const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ref << 2), (int)ref);
+            const bool moved = r2 != ref;
+            ref = r2;
+            if (__builtin_amdgcn_ballot_w64(moved) == 0ull) break;
+        }
+        byte = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ref << 2), (int)byte);
+        if (active) put_byte(pos, byte);
+        op += T;
+        chain_sync();
+        maybe_flush();
     }
     XMI_HD void huffman_block()
     {
         if (GS != 64) { huffman_block_serial(); return; }
         uint32_t P = in_pos * 8u - nbits;                                   // the stream's next bit
+        uint32_t lane_val = 0, fill = 0;                                    // the open batch: what each byte is made of, bytes dealt out
         bool more = true;
         while (more && !err) {
             const uint32_t bytepos = P >> 3;
@@ -549,46 +574,27 @@ struct Chain {
             if (loaded - bytepos < 64u) { land_load(); issue_load(); }
             const uint32_t info = window_tokens(P);
             uint32_t s = 0;
-            while (s < 64u) {
-                // the scalar unit's part: the run of literals from lane s on -- as many as fit in front of the next flush and
-                // the block's end -- noted in a mask; it stops at the first token of another kind (t, at lane s)
-                const uint32_t left = oend - op, to_flush = FLUSH - (op - flushed);
-                const uint32_t room = __builtin_amdgcn_readfirstlane(left < to_flush ? left : to_flush);
-                uint32_t ss = __builtin_amdgcn_readfirstlane(s), n = 0, t;
-                uint64_t lits = 0;
+            while (more && !err) {
+                // the scalar unit's part: tokens that fit the open batch whole are dealt out; it stops at the window's end
+                // (ss >= 64) or at the first token that needs more than that (t, at lane ss)
+                uint32_t ss = __builtin_amdgcn_readfirstlane(s), ff = __builtin_amdgcn_readfirstlane(fill), t;
                 for (;;) {
                     t = __builtin_amdgcn_readlane(info, ss);
-                    if ((t & 0xC0u) != (K_LIT << 6) || n >= room) break;
-                    lits |= 1ull << ss;
-                    ++n;
+                    const uint32_t n = (t >> 6) & 0x1FFu;
+                    if (n == 0u || ff + n > 64u) break;
+                    lane_val = (gl - ff < n) ? (t >> 15) : lane_val;
+                    ff += n;
                     ss += t & 63u;
                     if (ss >= 64u) break;
                 }
-                if (n) {
-                    op += n;
-                    put_literals(lits, op, info);
-                }
-                s = ss;
+                s = ss; fill = ff;
                 if (s >= 64u) break;
-                const uint32_t kind = (t >> 6) & 3u;
-                if (kind == K_LIT) {                                        // the run stopped for want of room
-                    if (op >= oend) { err = ERR_OUT; more = false; break; }
-                    chain_sync();
-                    maybe_flush();
-                } else if (kind == K_MATCH) {
-                    const uint32_t len = (t >> 8) & 0x1FFu, dist = (t >> 17) + 1u;
-                    if (dist > op - ostart) { err = ERR_DIST; more = false; break; }
-                    if (len > oend - op) { err = ERR_OUT; more = false; break; }
-                    chain_sync();
-                    copy_match(len, dist);
-                    maybe_flush();
-                    s += t & 63u;
-                } else if (kind == K_EOB) {
-                    s += t & 63u;
-                    more = false;
-                    break;
-                } else {
-                    // a token for the serial reader (a code beyond the root tables, or no valid code)
+                uint32_t n = (t >> 6) & 0x1FFu;
+                const uint32_t v = t >> 15;
+                if (n == 0u) {                                              // the end of the block, or a token for the serial reader
+                    if (fill) { emit_batch(lane_val, fill); fill = 0; }
+                    if (v == T_EOB) { s += t & 63u; more = false; break; }
+                    if (err) break;
                     chain_sync();
                     seek_bits(P + s);
                     more = serial_token();
@@ -596,9 +602,20 @@ struct Chain {
                     s = 0xFFFFFFFFu;                                        // P is set: a new window
                     break;
                 }
+                // a token longer than the batch's rest: batch after batch
+                while (n && !err) {
+                    const uint32_t room = 64u - fill, take = n < room ? n : room;
+                    lane_val = (gl - fill < take) ? v : lane_val;
+                    fill += take;
+                    n -= take;
+                    if (fill == 64u) { emit_batch(lane_val, 64u); fill = 0; }
+                }
+                s += t & 63u;
+                if (s >= 64u) break;
             }
             if (s != 0xFFFFFFFFu) P += s;
         }
+        if (fill && !err) emit_batch(lane_val, fill);
         chain_sync();
         seek_bits(P);
     }
