@@ -568,52 +568,61 @@ struct Chain {
         uint32_t P = in_pos * 8u - nbits;                                   // the stream's next bit
         uint32_t lane_val = 0, fill = 0;                                    // the open batch: what each byte is made of, bytes dealt out
         bool more = true;
+        // Every pass of this loop ends the block (more = false, err) or moves on: it refills the ring (only while P is within 64
+        // bytes of `loaded`, and P never passes cend + 13 bytes), or P advances -- a pass that refills nothing and raises no
+        // error has P below `stop`, so at least one window is looked at, and its first token either is dealt out (its bit count
+        // is >= 1), or is handed to emit_batch / the serial reader below, which consume it or set err.
         while (more && !err) {
-            const uint32_t bytepos = P >> 3;
-            if (bytepos > cend + 12u) { err = ERR_IN; break; }
-            if (loaded - bytepos < 64u) { land_load(); issue_load(); }
-            const uint32_t info = window_tokens(P);
-            uint32_t s = 0;
-            while (more && !err) {
-                // the scalar unit's part: tokens that fit the open batch whole are dealt out; it stops at the window's end
-                // (ss >= 64) or at the first token that needs more than that (t, at lane ss)
-                uint32_t ss = __builtin_amdgcn_readfirstlane(s), ff = __builtin_amdgcn_readfirstlane(fill), t;
+            if ((P >> 3) > cend + 12u) { err = ERR_IN; break; }
+            if (loaded - (P >> 3) < 64u) { land_load(); issue_load(); }
+            // The scalar unit's part, window after window while the input ring holds what a window reads (bits below `stop`):
+            // tokens that fit the open batch whole are dealt out; it ends at `stop` (t = 0) or at the first token that needs
+            // more than that: t, the token at bit pp.  Every value that steers these loops comes out of v_readfirstlane /
+            // v_readlane, so that the compiler keeps them, and the branches on them, on the scalar unit.
+            // (a window at byte b reads the ring up to b + 20: b <= loaded - 64, the same margin as the refill above; b <= cend + 12)
+            const uint32_t cut = cend + 13u < loaded - 63u ? cend + 13u : loaded - 63u;
+            const uint32_t stop = __builtin_amdgcn_readfirstlane(cut * 8u);
+            uint32_t pp = __builtin_amdgcn_readfirstlane(P), ff = __builtin_amdgcn_readfirstlane(fill), t = 0;
+            while (pp < stop) {
+                const uint32_t info = window_tokens(pp);
+                uint32_t ss = 0;
+                bool out = false;
                 for (;;) {
                     t = __builtin_amdgcn_readlane(info, ss);
                     const uint32_t n = (t >> 6) & 0x1FFu;
-                    if (n == 0u || ff + n > 64u) break;
+                    if (n == 0u || ff + n > 64u) { out = true; break; }
                     lane_val = (gl - ff < n) ? (t >> 15) : lane_val;
                     ff += n;
                     ss += t & 63u;
                     if (ss >= 64u) break;
                 }
-                s = ss; fill = ff;
-                if (s >= 64u) break;
-                uint32_t n = (t >> 6) & 0x1FFu;
-                const uint32_t v = t >> 15;
-                if (n == 0u) {                                              // the end of the block, or a token for the serial reader
-                    if (fill) { emit_batch(lane_val, fill); fill = 0; }
-                    if (v == T_EOB) { s += t & 63u; more = false; break; }
-                    if (err) break;
-                    chain_sync();
-                    seek_bits(P + s);
-                    more = serial_token();
-                    P = in_pos * 8u - nbits;
-                    s = 0xFFFFFFFFu;                                        // P is set: a new window
-                    break;
-                }
-                // a token longer than the batch's rest: batch after batch
-                while (n && !err) {
-                    const uint32_t room = 64u - fill, take = n < room ? n : room;
-                    lane_val = (gl - fill < take) ? v : lane_val;
-                    fill += take;
-                    n -= take;
-                    if (fill == 64u) { emit_batch(lane_val, 64u); fill = 0; }
-                }
-                s += t & 63u;
-                if (s >= 64u) break;
+                pp += ss;
+                if (out) break;
+                t = 0;
             }
-            if (s != 0xFFFFFFFFu) P += s;
+            P = pp; fill = ff;
+            if (t == 0u) continue;                                          // the ring needs input (or the stream has run out)
+            uint32_t n = (t >> 6) & 0x1FFu;
+            const uint32_t v = t >> 15;
+            if (n == 0u) {                                                  // the end of the block, or a token for the serial reader
+                if (fill) { emit_batch(lane_val, fill); fill = 0; }
+                if (v == T_EOB) { P += t & 63u; more = false; break; }
+                if (err) break;
+                chain_sync();
+                seek_bits(P);
+                more = serial_token();
+                P = in_pos * 8u - nbits;
+                continue;
+            }
+            // a token longer than the batch's rest: batch after batch
+            while (n && !err) {
+                const uint32_t room = 64u - fill, take = n < room ? n : room;
+                lane_val = (gl - fill < take) ? v : lane_val;
+                fill += take;
+                n -= take;
+                if (fill == 64u) { emit_batch(lane_val, 64u); fill = 0; }
+            }
+            P += t & 63u;
         }
         if (fill && !err) emit_batch(lane_val, fill);
         chain_sync();
