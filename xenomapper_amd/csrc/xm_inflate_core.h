@@ -589,10 +589,28 @@ struct Chain {
                 bool out = false;
                 for (;;) {
                     t = __builtin_amdgcn_readlane(info, ss);
-                    const uint32_t n = (t >> 6) & 0x1FFu;
-                    if (n == 0u || ff + n > 64u) { out = true; break; }
-                    lane_val = (gl - ff < n) ? (t >> 15) : lane_val;
-                    ff += n;
+                    uint32_t n = (t >> 6) & 0x1FFu;
+                    if (n == 0u) { out = true; break; }
+                    if (ff + n > 64u) {
+                        // a token longer than the batch's rest: batch after batch, and on in this window
+                        const uint32_t v = t >> 15;
+                        bool failed = false;
+                        do {
+                            const uint32_t room = 64u - ff, take = n < room ? n : room;
+                            lane_val = (gl - ff < take) ? v : lane_val;
+                            ff += take;
+                            n -= take;
+                            if (ff == 64u) {
+                                emit_batch(lane_val, 64u);
+                                ff = 0;
+                                failed = __builtin_amdgcn_readfirstlane((uint32_t)err) != 0u;
+                            }
+                        } while (n && !failed);
+                        if (failed) { out = true; break; }
+                    } else {
+                        lane_val = (gl - ff < n) ? (t >> 15) : lane_val;
+                        ff += n;
+                    }
                     ss += t & 63u;
                     if (ss >= 64u) break;
                 }
@@ -601,28 +619,16 @@ struct Chain {
                 t = 0;
             }
             P = pp; fill = ff;
-            if (t == 0u) continue;                                          // the ring needs input (or the stream has run out)
-            uint32_t n = (t >> 6) & 0x1FFu;
-            const uint32_t v = t >> 15;
-            if (n == 0u) {                                                  // the end of the block, or a token for the serial reader
-                if (fill) { emit_batch(lane_val, fill); fill = 0; }
-                if (v == T_EOB) { P += t & 63u; more = false; break; }
-                if (err) break;
-                chain_sync();
-                seek_bits(P);
-                more = serial_token();
-                P = in_pos * 8u - nbits;
-                continue;
-            }
-            // a token longer than the batch's rest: batch after batch
-            while (n && !err) {
-                const uint32_t room = 64u - fill, take = n < room ? n : room;
-                lane_val = (gl - fill < take) ? v : lane_val;
-                fill += take;
-                n -= take;
-                if (fill == 64u) { emit_batch(lane_val, 64u); fill = 0; }
-            }
-            P += t & 63u;
+            if (t == 0u || err) continue;                                   // the ring needs input (or the stream has run out)
+            // the end of the block, or a token for the serial reader
+            if (fill) { emit_batch(lane_val, fill); fill = 0; }
+            if ((t >> 15) == T_EOB) { P += t & 63u; more = false; break; }
+            if (err) break;
+            chain_sync();
+            seek_bits(P);
+            more = serial_token();
+            P = in_pos * 8u - nbits;
+            continue;
         }
         if (fill && !err) emit_batch(lane_val, fill);
         chain_sync();
