@@ -130,6 +130,59 @@ def test_zlib_streams_every_level_and_strategy(ctx):
     assert n == 400 and total == sum(len(r) for r in raws)
 
 
+def test_periods_around_the_batch_width_and_codes_beyond_the_root_tables(ctx):
+    """What the wide token loop (xm_inflate_core.h: a lane per bit offset decodes, a lane per output byte produces, 64 bytes a
+    batch) has edges of its own for: repeating units of 1 .. 66, 127 .. 130 and 257 .. 260 bytes (matches that overlap themselves,
+    matches whose source is a token of the same batch, matches of 258 bytes that run over five batches), short literal / match
+    mixes, and alphabets skewed enough for codes longer than the 10 / 8 bits of the root tables (tokens the serial reader takes
+    in the middle of a window); every level that changes zlib's parsing, dynamic and fixed codes."""
+    rng = np.random.default_rng(99)
+    members, raws = [], []
+
+    def add(raw, level, strategy=zlib.Z_DEFAULT_STRATEGY):
+        d = deflate_raw(raw, level, strategy)
+        assert len(d) + 26 <= 65536
+        members.append(bgzf_member(d, raw))
+        raws.append(raw)
+
+    for period in list(range(1, 67)) + [127, 128, 129, 130, 257, 258, 259, 260]:
+        unit = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+        n = int(rng.integers(300, 3000))
+        raw = bytearray((unit * (n // period + 1))[:n])
+        for k in range(0, n, int(rng.integers(40, 400))):                                 # a literal now and then breaks the runs
+            raw[k] = int(rng.integers(0, 256))
+        for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED)):
+            add(bytes(raw), level, strategy)
+    # geometric symbol frequencies: code lengths up to 15 bits in the literal / length code, long distance codes too
+    for k in range(40):
+        n = int(rng.integers(2000, 60000))
+        ranks = np.minimum(rng.geometric(0.5 if k % 2 else 0.3, n) - 1, 255).astype(np.uint8)
+        perm = rng.permutation(256).astype(np.uint8)
+        raw = bytearray(perm[ranks].tobytes())
+        for _ in range(int(rng.integers(0, 200))):                                        # copies at skewed distances
+            ln, src = int(rng.integers(3, 259)), int(rng.integers(0, max(n - 300, 1)))
+            dst = min(n - ln, src + int(min(rng.geometric(0.002), 32000)))
+            if dst > src and dst + ln <= n:
+                raw[dst:dst + ln] = raw[src:src + ln]
+        add(bytes(raw), int(rng.choice([1, 6, 9])), zlib.Z_HUFFMAN_ONLY if k % 5 == 0 else zlib.Z_DEFAULT_STRATEGY)
+    image = np.frombuffer(b"".join(members), dtype=np.uint8)
+    n, total = check_image(ctx, image)
+    assert n == len(members) and total == sum(len(r) for r in raws)
+    # ... and every one of those streams cut short or with a flipped bit ends with a status or a CRC mismatch, inside its block
+    from xenomapper_amd import _ffi
+    blocks, crc, _nxt, total = _ffi.bgzf_index(image)
+    damaged = bytearray(image.tobytes())
+    for b in range(len(blocks)):
+        at = int(blocks["cdata_off"][b]) + int(rng.integers(0, int(blocks["cdata_len"][b])))
+        damaged[at] ^= 1 << int(rng.integers(0, 8))
+    out, status, got_crc = gpu_inflate(ctx, np.frombuffer(bytes(damaged), dtype=np.uint8), blocks, total)
+    assert (out[:64] == 0xEE).all() and (out[64 + total:] == 0xEE).all()
+    want = np.frombuffer(b"".join(raws), dtype=np.uint8)
+    for b in range(len(blocks)):
+        o, nb = int(blocks["out_off"][b]), int(blocks["isize"][b])
+        assert status[b] != 0 or got_crc[b] != crc[b] or np.array_equal(out[64 + o:64 + o + nb], want[o:o + nb]), b
+
+
 def test_damaged_streams_end_with_a_status_and_stay_inside_their_block(ctx):
     from xenomapper_amd import _ffi
     rng = np.random.default_rng(7)

@@ -11,6 +11,9 @@
 // cross-lane traffic is needed for it), and the lanes of a chain split what is data-parallel: filling decode tables, copying
 // matches (GS bytes per step), moving input and output between LDS and global memory in 16-byte pieces.  A chain never spans
 // waves and a wave executes in lockstep, so lanes of a chain communicate through LDS in program order: no barrier anywhere.
+// With GS = 64 (what ships: a chain is a whole wave) the token loop of a Huffman block is WIDE instead: lane i decodes the
+// token that would begin at bit P + i, the scalar unit walks from token to token, and a batch of up to 64 output bytes is
+// produced a lane per byte (huffman_block() below; the serial loop remains for GS < 64, the host build and -DXMI_SERIAL_TOKENS).
 //
 // Per chain, in LDS (ChainMem, ~5 KB): the two Huffman decoders (a root table indexed by the next ROOT bits -- entries
 // placed at bit-reversed codes, as the bits arrive LSB first -- plus the canonical (first code, limit, base) triples and the
