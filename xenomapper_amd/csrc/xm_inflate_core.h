@@ -520,21 +520,26 @@ struct Chain {
         const uint32_t x0 = __builtin_amdgcn_alignbit(a1, a0, sh), x1 = __builtin_amdgcn_alignbit(a2, a1, sh);
         const uint32_t e = m->lit_root[x0 & ((1u << LIT_ROOT) - 1u)];
         const uint32_t L = e & 15u, sym = e >> 4;
-        // as a length symbol
+        // as a length symbol: RFC 1951's table as arithmetic -- symbols 257 + ls, ls < 4: lengths 3 + ls; from ls = 4 on, four
+        // symbols share a count of extra bits, (ls >> 2) - 1, and lengths ((4 | ls & 3) << extra) + 3 + the extra bits' value
+        // (which is ls + 3 again for ls = 4 .. 7); 285 is 258 with no extra bits where the rule would say 259 and six
         const uint32_t ls = sym - 257u;
-        const uint32_t leb = (ls < 8u || ls >= 28u) ? 0u : (ls - 4u) >> 2;
-        const uint32_t lbase = ls < 8u ? ls + 3u : ls == 28u ? 258u : ((4u + ((ls - 4u) & 3u)) << leb) + 3u;
-        const uint32_t len = lbase + ((x0 >> L) & ((1u << leb) - 1u));
+        const bool top = ls == 28u;
+        const uint32_t leb0 = (ls >> 2) > 1u ? (ls >> 2) - 1u : 0u;
+        const uint32_t leb = top ? 0u : leb0;
+        const uint32_t lman = ls < 4u ? ls : (4u | (ls & 3u));
+        const uint32_t len = (lman << leb0) + 3u - (top ? 1u : 0u) + __builtin_amdgcn_ubfe(x0, L, leb);
         const uint32_t o2 = L + leb;                                        // <= 20
         const uint32_t y = __builtin_amdgcn_alignbit(x1, x0, o2);
         const uint32_t de = m->dist_root[y & ((1u << DIST_ROOT) - 1u)];
         const uint32_t DL = de & 15u, d = de >> 4;
-        const uint32_t deb = d < 4u ? 0u : (d >> 1) - 1u;
-        const uint32_t dbase = d < 4u ? d + 1u : ((2u + (d & 1u)) << deb) + 1u;
-        const uint32_t dist = dbase + ((y >> DL) & ((1u << deb) - 1u));
+        // distance symbols the same way: d < 2: 1 + d; from 2 on, two symbols share (d >> 1) - 1 extra bits, ((2 | d & 1) << extra) + 1
+        const uint32_t deb = (d >> 1) > 1u ? (d >> 1) - 1u : 0u;
+        const uint32_t dman = d < 2u ? d : (2u | (d & 1u));
+        const uint32_t dist = (dman << deb) + 1u + __builtin_amdgcn_ubfe(y, DL, deb);
         const bool is_lit = sym < 256u, is_eob = sym == 256u;
-        const bool bad = L == 0u || (!is_lit && !is_eob && (ls > 28u || DL == 0u || d > 29u));
-        const uint32_t total = (is_lit || is_eob) ? L : o2 + DL + deb;      // <= 48
+        const bool bad = L == 0u || (sym > 256u && (ls > 28u || DL == 0u || d > 29u));
+        const uint32_t total = sym > 256u ? o2 + DL + deb : L;              // <= 48
         const uint32_t n = (bad || is_eob) ? 0u : is_lit ? 1u : len;
         const uint32_t v = bad ? T_SLOW : is_eob ? T_EOB : is_lit ? (V_LIT | sym) : dist;
         return total | (n << 6) | (v << 15);
