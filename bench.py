@@ -980,6 +980,12 @@ def main():
                               "what": "two BAM files (the reference's fixtures tiled 48 000 times, record-aligned BGZF blocks as samtools writes "
                                       "them) -> BGZF blocks inflated, records found and stripped ON THE GPU (xm_bamdev), columns stay in HBM -> "
                                       "fused pass -> the host prints the records' SAM text -> six SAM outputs on /dev/null"}
+                for key, kw, what in (("bam_cigar_scores", {"cigar_scores": True}, "the same input with the --cigar_scores plugin (NM + the records' CIGAR "
+                                                                              "words packed into the CIGAR columns on the device)"),
+                                      ("bam_single_end", {"single_end": True}, "the same files as single-end input: the skipping walk, as the "
+                                                                          "command line runs it (reads/s)")):
+                    rk = bench_bam.run(copies=48000, workdir=wd, **kw)
+                    e2e[key] = {"per_s": rk["value"], "units": rk["units"], "seconds": round(rk["seconds"], 4), "what": what}
                 os.environ["XENOMAPPER_GPU_BAM"] = "0"
                 try:
                     r0 = bench_bam.run(copies=48000, workdir=wd)
