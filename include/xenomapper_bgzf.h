@@ -188,6 +188,20 @@ typedef struct {
     uint64_t bytes1, bytes2;
 } xm_bamdev_text;
 int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_text *out);
+/* (c) after xm_bamdev_classify: the SAM TEXT of the records a sink takes, printed on the device -- the lines `samtools view` would
+ * print (the reference reads BAM through it: getBamReadPairs / bam_lines, xenomapper.py:56-93), next to each other in text1 / text2,
+ * line_off*[i] / line_len*[i] = where record i's line is and how long (without its '\n'; 0 / 0: no sink takes it).  Needs the
+ * files' reference names (xm_bamdev_set_refs: the names back to back, at[n_refs + 1] positions; once per pair of files).
+ * status 0: the text is on its way (xm_bamdev_raw_wait); 1: a record holds a floating-point field (printf("%g") is the host
+ * printer's), 2: more text than the slot's buffers hold -- nothing was copied then: ask for (b) and print on the host. */
+typedef struct {
+    const uint8_t  *text1, *text2;
+    const uint32_t *line_off1, *line_off2, *line_len1, *line_len2;
+    uint64_t bytes1, bytes2;
+    int32_t  status, reserved;
+} xm_bamdev_lines;
+int xm_bamdev_set_refs(xm_bamdev *b, int file, const uint8_t *names, const uint32_t *at, uint32_t n_refs);
+int xm_bamdev_fetch_text(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_lines *out);
 /* both copies run on a stream of their own; this blocks until the one asked for last has arrived (any thread) */
 int xm_bamdev_raw_wait(xm_bamdev *b, int slot);
 /* the fused main loop on the slot's columns (as xm_strip_classify) */

@@ -4,8 +4,10 @@ against the text rules of the reference's plugins applied to the printed SAM tex
 BAM front end byte for byte.  The reference code this path replaces: getBamReadPairs / bam_lines, xenomapper.py:56-93, with
 get_tag / get_tag_with_ZS_as_XS :176-206 on the lines."""
 import ctypes
+import gzip
 import io
 import os
+import re
 import sys
 
 import numpy as np
@@ -40,6 +42,22 @@ def host_text(image):
         at += got
     r.close()
     return bytes(buf[:at])
+
+
+def host_text_header_refs(image):
+    """The reference names of a BAM image, in order (SAM specification 4.2)."""
+    import struct
+    raw = gzip.decompress(image)
+    l_text, = struct.unpack_from("<i", raw, 4)
+    at = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, at)
+    at += 4
+    names = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, at)
+        names.append(raw[at + 4:at + 4 + l_name].split(b"\0", 1)[0])
+        at += 4 + l_name + 4
+    return names
 
 
 def expected_from_text(line, tag, first_decides=False):
@@ -138,7 +156,6 @@ def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mod
         assert bits.tolist() == want_bits
         assert blk.n_exceptions == sum(1 for k in range(n) if (int(flags[0][k]) | int(flags[1][k])) & 0x7C)
         if score_mode == 2 and n:
-            import re
             letters = {c: k for k, c in enumerate("MIDNSHP=X")}
             for f in (0, 1):
                 nm, cnt, tile, ops = dev.cigar_columns(0, f, n)
@@ -161,6 +178,28 @@ def test_device_stripper_reports_what_the_text_rules_read(ctx, images, score_mod
             got = readers[f].print_records(blk.raw_addr[f], blk.rec_off_addr[f], n, text, loff, llen)
             assert bytes(text[:got]) == b"".join(l + b"\n" for l in lines[f][:n])
             assert [bytes(text[int(loff[k]):int(loff[k]) + int(llen[k])]) for k in range(n)] == lines[f][:n]
+        # the device printer (xm_bamdev_fetch_text) on the same records: every line it prints is the host printer's; it declines
+        # (status 1) exactly when a record a sink takes holds a floating-point field
+        if n:
+            for f in (0, 1):
+                dev.set_refs(f, host_text_header_refs(images[f]))
+            try:
+                dev.classify(0, _ffi.MODE_PE_LIBERAL if paired else _ffi.MODE_SE, n, -2**31)
+                status, dtext, dloff, dllen = dev.fetch_text(0, n, paired, 0b111111)
+            except OverflowError:                                    # --cigar_scores: a synthesised score left int32
+                status = -1
+            floats = re.compile(rb"\t[^\t]{2}:(f|d|B:f)[:,]?")
+            if status == -1:
+                pass
+            elif status == 0:
+                dev.raw_wait(0)
+                for f in (0, 1):
+                    for k in range(n):
+                        if int(dllen[f][k]) or int(dloff[f][k]):
+                            a = int(dloff[f][k])
+                            assert bytes(dtext[f][a:a + int(dllen[f][k]) + 1]) == lines[f][k] + b"\n", (f, k, lines[f][k])
+            else:
+                assert status == 1 and any(floats.search(l) for f in (0, 1) for l in lines[f][:n])
         for r in readers:
             r.close()
     finally:
@@ -410,10 +449,19 @@ def test_only_the_records_a_sink_takes_come_back(ctx, tmp_path, paired, mode):
     dev = _ffi.BamDev(ctx)
     try:
         blk, readers = run_whole_files(dev, images, 0, paired)           # the whole windows on the host as well (wait_raw)
-        for r in readers:
-            r.close()
         n = blk.n
         assert n > 1000 and not blk.n_exceptions
+        # the host printer's text of every record, and the files' reference names for the device printer
+        host_lines = []
+        for f in (0, 1):
+            text = np.empty(8 * len(images[f]) + (1 << 16), dtype=np.uint8)
+            loff, llen = np.empty(n + 1, dtype=np.uint32), np.empty(n + 1, dtype=np.uint32)
+            readers[f].print_records(blk.raw_addr[f], blk.rec_off_addr[f], n, text, loff, llen)
+            host_lines.append([bytes(text[int(loff[k]):int(loff[k]) + int(llen[k])]) for k in range(n)])
+            head = host_text_header_refs(images[f])
+            dev.set_refs(f, head)
+        for r in readers:
+            r.close()
         raws = [np.ctypeslib.as_array((ctypes.c_uint8 * blk.raw_len[f]).from_address(blk.raw_addr[f])).copy() for f in (0, 1)]
         rec = [np.ctypeslib.as_array((ctypes.c_uint32 * blk.n_rec[f]).from_address(blk.rec_off_addr[f])).copy() for f in (0, 1)]
         code, idx, off, _counts = dev.classify(0, mode, n, -2**31)
@@ -443,5 +491,19 @@ def test_only_the_records_a_sink_takes_come_back(ctx, tmp_path, paired, mode):
                     assert bytes(packed[at:at + size]) == bytes(raws[f][o:o + size])
                     at += size
                 assert at == nbytes[f]
+            # (c) xm_bamdev_fetch_text: the same records as SAM text printed on the device = the host printer's lines, next to
+            # each other in input order, with the line table the writer gathers from
+            status, text, loff, llen = dev.fetch_text(0, n, paired, sink_mask)
+            assert status == 0
+            dev.raw_wait(0)
+            for f in (0, 1):
+                at = 0
+                lo, ll = loff[f].copy(), llen[f].copy()
+                for i in range(n):
+                    if not want[f][i]:
+                        assert lo[i] == 0 and ll[i] == 0
+                        continue
+                    assert int(lo[i]) == at and bytes(text[f][at:at + int(ll[i]) + 1]) == host_lines[f][i] + b"\n", (sink_mask, f, i)
+                    at += int(ll[i]) + 1
     finally:
         dev.close()

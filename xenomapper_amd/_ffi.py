@@ -161,6 +161,8 @@ def lib():
         "xm_bamdev_fetch_raw": ([P, I], I),
         "xm_bamdev_fetch_wanted": ([P, I, U64, I, ctypes.c_uint32, P], I),
         "xm_bamdev_upload": ([P, I, I, U64], I),
+        "xm_bamdev_set_refs": ([P, I, P, P, ctypes.c_uint32], I),
+        "xm_bamdev_fetch_text": ([P, I, U64, I, ctypes.c_uint32, P], I),
         "xm_bamdev_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_bamdev_columns": ([P, I, U64, P, P, P, P, P], I),
         "xm_bamdev_cigar_columns": ([P, I, I, U64, P, P, P, P, U64, ctypes.POINTER(ctypes.c_uint64)], I),
@@ -187,7 +189,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
-            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_upload", "xm_bamdev_classify",
+            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_fetch_text", "xm_bamdev_set_refs", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_cigar_columns", "xm_bamdev_last_error")
 
 
@@ -900,6 +902,12 @@ class _BamDevText(ctypes.Structure):
                 ("bytes1", ctypes.c_uint64), ("bytes2", ctypes.c_uint64)]
 
 
+class _BamDevLines(ctypes.Structure):
+    _fields_ = [("text1", ctypes.c_void_p), ("text2", ctypes.c_void_p), ("line_off1", ctypes.c_void_p), ("line_off2", ctypes.c_void_p),
+                ("line_len1", ctypes.c_void_p), ("line_len2", ctypes.c_void_p), ("bytes1", ctypes.c_uint64), ("bytes2", ctypes.c_uint64),
+                ("status", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class _BamDevBlock(ctypes.Structure):
     _fields_ = [("n_records", ctypes.c_uint64), ("consumed1", ctypes.c_uint64), ("consumed2", ctypes.c_uint64),
                 ("raw_len1", ctypes.c_uint64), ("raw_len2", ctypes.c_uint64), ("n_rec1", ctypes.c_uint64), ("n_rec2", ctypes.c_uint64),
@@ -1041,6 +1049,28 @@ class BamDev(object):
         self._check(rc, "xm_bamdev_fetch_wanted")
         n = int(n_records)
         return ((t.raw1, t.raw2), (_host_view(t.off1, n, np.uint32), _host_view(t.off2, n, np.uint32)), (int(t.bytes1), int(t.bytes2)))
+
+    def set_refs(self, file, names):
+        """The file's reference names (a list of bytes, in reference-id order): what the device printer writes in RNAME / RNEXT."""
+        blob = np.frombuffer(b"".join(names) or b"\0", dtype=np.uint8)
+        at = np.zeros(len(names) + 1, dtype=np.uint32)
+        if names:
+            at[1:] = np.cumsum([len(x) for x in names], dtype=np.uint64).astype(np.uint32)
+        self._check(self._L.xm_bamdev_set_refs(self._h, int(file), _np_ptr(blob), _np_ptr(at), len(names)), "xm_bamdev_set_refs")
+
+    def fetch_text(self, slot, n_records, paired, sink_mask):
+        """After classify(): the SAM text of the records a sink takes, printed on the device (xm_bamdev_fetch_text) ->
+        (status, (text1, text2 uint8 views), (line_off1, line_off2), (line_len1, line_len2)); status 0: on its way, complete after
+        raw_wait; 1 / 2: the host has to print this window (a floating-point field / more text than the buffers hold)."""
+        t = _BamDevLines()
+        rc = self._L.xm_bamdev_fetch_text(self._h, int(slot), int(n_records), int(bool(paired)), int(sink_mask), ctypes.byref(t))
+        self._check(rc, "xm_bamdev_fetch_text")
+        n = int(n_records)
+        if t.status != 0 or n == 0:
+            return int(t.status), None, None, None
+        return (0, (_host_view(t.text1, max(int(t.bytes1), 1), np.uint8), _host_view(t.text2, max(int(t.bytes2), 1), np.uint8)),
+                (_host_view(t.line_off1, n, np.uint32), _host_view(t.line_off2, n, np.uint32)),
+                (_host_view(t.line_len1, n, np.uint32), _host_view(t.line_len2, n, np.uint32)))
 
     def upload(self, slot, file, nbytes):
         """The first nbytes of the slot's staging buffer go to the device now (xm_bamdev_upload); the next run is told `uploaded`."""

@@ -265,6 +265,172 @@ pack_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_of
     for (uint32_t k = lane; k < size; k += 64u) dst[k] = src[k];
 }
 
+// ---- T: the SAM text of the records a sink takes, printed ON the device -------------------------------------------------------
+// What `samtools view` prints for an alignment record (the reference reads BAM through it: getBamReadPairs / bam_lines,
+// /root/reference/xenomapper/xenomapper.py:56-93), restated as csrc/xm_bam.cpp's format_record restates it for the host -- the two are
+// compared byte for byte in tests/test_bam_gpu.py.  One lane prints one record, twice: first into a sink that only counts (T1; the
+// size scan of W2 places the lines), then into the text (T2).  Fields with a floating-point value (types f, d, B:f) are not
+// printed here: such a record raises a flag and the host printer takes the window, as it does for every window the device does
+// not vouch for (a CIGAR in a CG:B,I field: `weird`).
+struct RefTable {
+    const uint8_t *names;        // the reference names back to back
+    const uint32_t *at;          // n + 1 positions in `names`
+    uint32_t n;
+};
+
+struct CountChars {
+    uint32_t n = 0;
+    __device__ __forceinline__ void ch(uint32_t) { ++n; }
+    __device__ __forceinline__ void bytes(const uint8_t *, uint32_t len) { n += len; }
+    __device__ __forceinline__ void seq(const uint8_t *, uint32_t len) { n += len; }
+    __device__ __forceinline__ void qual(const uint8_t *, uint32_t len) { n += len; }
+};
+
+struct WriteChars {
+    uint8_t *o;
+    __device__ __forceinline__ void ch(uint32_t c) { *o++ = (uint8_t)c; }
+    __device__ __forceinline__ void bytes(const uint8_t *p, uint32_t len) { for (uint32_t k = 0; k < len; ++k) o[k] = p[k]; o += len; }
+    __device__ __forceinline__ void seq(const uint8_t *p, uint32_t len)
+    {
+        // "=ACMGRSVTWYHKDBN", eight letters a word
+        const unsigned long long lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;
+        for (uint32_t k = 0; k < len; ++k) {
+            const uint32_t code = (p[k >> 1] >> ((k & 1u) ? 0u : 4u)) & 15u;
+            o[k] = (uint8_t)(((code < 8u ? lo : hi) >> (8u * (code & 7u))) & 0xFFu);
+        }
+        o += len;
+    }
+    __device__ __forceinline__ void qual(const uint8_t *p, uint32_t len) { for (uint32_t k = 0; k < len; ++k) o[k] = (uint8_t)(p[k] + 33u); o += len; }
+};
+
+template <typename S> __device__ __forceinline__ void put_u64(S &s, unsigned long long v)
+{
+    uint8_t d[20];
+    uint32_t k = 0;
+    do { d[k++] = (uint8_t)('0' + (uint32_t)(v % 10ull)); v /= 10ull; } while (v);
+    while (k) s.ch(d[--k]);
+}
+template <typename S> __device__ __forceinline__ void put_u32(S &s, uint32_t v)
+{
+    uint8_t d[10];
+    uint32_t k = 0;
+    do { d[k++] = (uint8_t)('0' + v % 10u); v /= 10u; } while (v);
+    while (k) s.ch(d[--k]);
+}
+template <typename S> __device__ __forceinline__ void put_i64(S &s, long long v)
+{
+    if (v < 0) { s.ch('-'); put_u64(s, (unsigned long long)(-(v + 1)) + 1ull); } else put_u64(s, (unsigned long long)v);
+}
+template <typename S> __device__ __forceinline__ void put_i32(S &s, int32_t v)
+{
+    if (v < 0) { s.ch('-'); put_u32(s, (uint32_t)(-(v + 1)) + 1u); } else put_u32(s, (uint32_t)v);
+}
+
+// one value of type t at r + p (inside the record: parse_record has walked the fields): false = a type this printer leaves to the host
+template <typename S> __device__ __forceinline__ bool put_scalar(S &s, const uint8_t *r, uint32_t &p, uint32_t t)
+{
+    switch (t) {
+    case 'A': s.ch(r[p]); p += 1u; return true;
+    case 'c': put_i32(s, (int8_t)r[p]); p += 1u; return true;
+    case 'C': put_u32(s, r[p]); p += 1u; return true;
+    case 's': put_i32(s, (int16_t)ld16(r + p)); p += 2u; return true;
+    case 'S': put_u32(s, ld16(r + p)); p += 2u; return true;
+    case 'i': put_i32(s, (int32_t)ld32(r + p)); p += 4u; return true;
+    case 'I': put_u32(s, ld32(r + p)); p += 4u; return true;
+    default: return false;
+    }
+}
+
+// the record whose block_size word is at raw + off -> its SAM line with the '\n'; false: leave the record to the host printer
+template <typename S> __device__ bool sam_line(const uint8_t *__restrict__ raw, uint32_t off, const RefTable refs, S &s)
+{
+    const uint32_t size = ld32(raw + off);
+    const uint8_t *r = raw + off + 4u;
+    const int32_t ref_id = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+    const uint32_t l_read_name = r[8], mapq = r[9], n_cigar = ld16(r + 12), flag = ld16(r + 14), l_seq = ld32(r + 16);
+    const int32_t next_ref = (int32_t)ld32(r + 20), next_pos = (int32_t)ld32(r + 24), tlen = (int32_t)ld32(r + 28);
+    uint32_t p = 32u, nl = 0;
+    while (nl < l_read_name && r[p + nl] != 0u) ++nl;
+    s.bytes(r + p, nl);
+    p += l_read_name;
+    s.ch('\t'); put_u32(s, flag);
+    s.ch('\t');
+    if (ref_id < 0 || (uint32_t)ref_id >= refs.n) s.ch('*');
+    else s.bytes(refs.names + refs.at[ref_id], refs.at[ref_id + 1] - refs.at[ref_id]);
+    s.ch('\t'); put_i64(s, (long long)pos + 1);
+    s.ch('\t'); put_u32(s, mapq);
+    s.ch('\t');
+    if (n_cigar == 0u) s.ch('*');
+    for (uint32_t k = 0; k < n_cigar; ++k) {
+        const uint32_t v = ld32(r + p + 4u * k);
+        put_u32(s, v >> 4);
+        const unsigned long long lo = 0x3D5048534E44494Dull, hi = 0x3F3F3F3F3F3F4258ull;               // "MIDNSHP=" "XB??????"
+        s.ch((uint32_t)((((v & 8u) ? hi : lo) >> (8u * (v & 7u))) & 0xFFu));
+    }
+    p += 4u * n_cigar;
+    s.ch('\t');
+    if (next_ref < 0 || (uint32_t)next_ref >= refs.n) s.ch('*');
+    else if (next_ref == ref_id) s.ch('=');
+    else s.bytes(refs.names + refs.at[next_ref], refs.at[next_ref + 1] - refs.at[next_ref]);
+    s.ch('\t'); put_i64(s, (long long)next_pos + 1);
+    s.ch('\t'); put_i32(s, tlen);
+    s.ch('\t');
+    if (l_seq == 0u) s.ch('*');
+    s.seq(r + p, l_seq);
+    p += (l_seq + 1u) / 2u;
+    s.ch('\t');
+    if (l_seq == 0u || r[p] == 0xFFu) s.ch('*'); else s.qual(r + p, l_seq);
+    p += l_seq;
+    while (p + 3u <= size) {
+        const uint32_t type = r[p + 2];
+        s.ch('\t'); s.ch(r[p]); s.ch(r[p + 1]); s.ch(':');
+        p += 3u;
+        if (type == 'A') { s.ch('A'); s.ch(':'); put_scalar(s, r, p, 'A'); }
+        else if (type == 'c' || type == 'C' || type == 's' || type == 'S' || type == 'i' || type == 'I') { s.ch('i'); s.ch(':'); put_scalar(s, r, p, type); }
+        else if (type == 'Z' || type == 'H') {
+            s.ch(type); s.ch(':');
+            uint32_t l = 0;
+            while (p + l < size && r[p + l] != 0u) ++l;
+            s.bytes(r + p, l);
+            p += l + 1u;
+        } else if (type == 'B') {
+            const uint32_t sub = r[p], cnt = ld32(r + p + 1);
+            p += 5u;
+            s.ch('B'); s.ch(':'); s.ch(sub);
+            for (uint32_t k = 0; k < cnt; ++k) { s.ch(','); if (!put_scalar(s, r, p, sub)) return false; }
+        } else return false;                                                 // f, d: the host prints what printf("%g") would
+    }
+    s.ch('\n');
+    return true;
+}
+
+// T1: wsize[i] (want_kernel: the record's bytes when a sink takes it, else 0) becomes the length of its line; state[13] != 0: a
+// record for the host printer
+__global__ void __launch_bounds__(256)
+text_size_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_off, uint32_t n, const RefTable refs,
+                 uint32_t *__restrict__ wsize, uint32_t *__restrict__ state)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || wsize[i] == 0u) return;
+    CountChars c;
+    if (!sam_line(raw, rec_off[i], refs, c)) atomicOr(&state[13], 1u);
+    wsize[i] = c.n;
+}
+
+// T2: the lines themselves; place[i] / wsize[i] become the line table the writer gathers from (position; length without '\n')
+__global__ void __launch_bounds__(256)
+text_fill_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_off, uint32_t n, const RefTable refs,
+                 uint32_t *__restrict__ wsize, uint32_t *__restrict__ place, uint8_t *__restrict__ text, uint32_t text_cap)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t len = wsize[i], at = place[i];
+    if (len == 0u || at == NO_RECORD || at + len > text_cap) { wsize[i] = 0u; place[i] = 0u; return; }
+    WriteChars w = {text + at};
+    (void)sam_line(raw, rec_off[i], refs, w);
+    wsize[i] = len - 1u;
+}
+
 // ---- --cigar_scores: the records' CIGAR words as the packed CIGAR columns K1p reads (include/xenomapper_hip.h) ------------------
 // BAM holds the operations as the kernel wants them (len << 4 | op); what is left to do is what xm_cigar_pack does on the host:
 // a count byte per record (255 = "255 or more": a trailer word n_ops << 4 | 15 behind the operations), the operations back to
@@ -425,6 +591,10 @@ struct PerFile {
     uint32_t *d_name_off = nullptr, *d_name_len = nullptr;
     int32_t *d_a = nullptr, *d_x = nullptr;
     uint8_t *d_rflag = nullptr, *d_lflag = nullptr, *h_lflag = nullptr;
+    // the device printer: the file's reference names (xm_bamdev_set_refs: the same for both slots), the line lengths on the host
+    uint8_t *d_ref_names = nullptr;
+    uint32_t *d_ref_at = nullptr, n_refs = 0, *h_llen = nullptr;
+    uint64_t llen_records = 0;
     // the skipping walk: the fields of the run starts, next to each other (ensure_skip), and their record starts on the host
     uint32_t *d_r_rec_off = nullptr, *d_r_name_off = nullptr, *d_r_name_len = nullptr, *d_r_ncig = nullptr, *d_r_cig_at = nullptr, *h_pair_off = nullptr;
     int32_t *d_r_a = nullptr, *d_r_x = nullptr;
@@ -535,7 +705,8 @@ void free_slot(Slot &sl)
         dfree(q.d_rflag); dfree(q.d_lflag); hfree(q.h_lflag);
         dfree(q.d_r_rec_off); dfree(q.d_r_name_off); dfree(q.d_r_name_len); dfree(q.d_r_ncig); dfree(q.d_r_cig_at); hfree(q.h_pair_off);
         dfree(q.d_r_a); dfree(q.d_r_x); dfree(q.d_r_flag);
-        q.skip_records = q.skip_cig_records = 0;
+        dfree(q.d_ref_names); dfree(q.d_ref_at); hfree(q.h_llen);
+        q.skip_records = q.skip_cig_records = q.llen_records = 0; q.n_refs = 0;
     }
     dfree(sl.d_comp_all); dfree(sl.d_raw_all);
     hfree(sl.h_blocks); dfree(sl.d_blocks); hfree(sl.h_walk); dfree(sl.d_walk); dfree(sl.d_status); hfree(sl.h_status); dfree(sl.d_crc); hfree(sl.h_crc);
@@ -1131,6 +1302,88 @@ int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paire
         const uint64_t bytes = f == 0 ? out->bytes1 : out->bytes2;
         if (bytes) XMB_HIP(b, hipMemcpyAsync(q.h_packed, q.d_packed, (size_t)bytes, hipMemcpyDeviceToHost, sl.copy_stream));
         if (n) XMB_HIP(b, hipMemcpyAsync(q.h_place, q.d_place, (size_t)n * 4, hipMemcpyDeviceToHost, sl.copy_stream));
+    }
+    XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
+    sl.raw_issued = true;
+    return XM_OK;
+}
+
+int xm_bamdev_set_refs(xm_bamdev *b, int file, const uint8_t *names, const uint32_t *at, uint32_t n_refs)
+{
+    if (!b || file < 0 || file > 1 || (n_refs && (!names || !at))) return XM_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < n_refs; ++k)
+        if (at[k + 1] < at[k]) return XM_ERR_INVALID_ARG;
+    XMB_HIP(b, hipSetDevice(b->device));
+    XMB_HIP(b, hipDeviceSynchronize());
+    for (int slot = 0; slot < 2; ++slot) {                                  // a copy per slot: the slots' streams share nothing
+        PerFile &q = b->slot[slot].pf[file];
+        q.n_refs = 0;
+        const size_t bytes = n_refs ? at[n_refs] : 0;
+        XMB_TRY(dalloc(b, q.d_ref_names, bytes + 16)); XMB_TRY(dalloc(b, q.d_ref_at, (size_t)n_refs + 1));
+        if (n_refs) {
+            if (bytes) XMB_HIP(b, hipMemcpy(q.d_ref_names, names, bytes, hipMemcpyHostToDevice));
+            XMB_HIP(b, hipMemcpy(q.d_ref_at, at, ((size_t)n_refs + 1) * 4, hipMemcpyHostToDevice));
+        }
+        q.n_refs = n_refs;
+    }
+    return XM_OK;
+}
+
+int xm_bamdev_fetch_text(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_lines *out)
+{
+    if (!b || slot < 0 || slot > 1 || !out) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (n_records > sl.record_cap || n_records > 0xFFFFFFF0ull || !sl.have_columns || !sl.classified) return XM_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    XMB_HIP(b, hipSetDevice(b->device));
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        if (q.llen_records < sl.record_cap) {
+            q.llen_records = 0;
+            XMB_TRY(halloc(b, q.h_llen, (size_t)sl.record_cap + 64));
+            q.llen_records = sl.record_cap;
+        }
+    }
+    out->text1 = sl.pf[0].h_packed; out->text2 = sl.pf[1].h_packed;
+    out->line_off1 = sl.pf[0].h_place; out->line_off2 = sl.pf[1].h_place;
+    out->line_len1 = sl.pf[0].h_llen; out->line_len2 = sl.pf[1].h_llen;
+    hipStream_t st = sl.stream;
+    const uint32_t n = (uint32_t)n_records;
+    if (n == 0) return XM_OK;
+    const uint32_t n_part = (n + SCAN_TILE - 1u) / SCAN_TILE;
+    const uint32_t text_cap = (uint32_t)std::min<uint64_t>(sl.raw_cap, 0xFFFFFFF0ull);      // the packed-record buffers hold the text
+    XMB_HIP(b, hipMemsetAsync(sl.d_state + 13, 0, sizeof(uint32_t), st));
+    want_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(sl.pf[0].d_raw, sl.pf[1].d_raw, sl.pf[0].v_rec_off, sl.pf[1].v_rec_off, sl.d_bins4, n, paired ? 1 : 0,
+                                                   sink_mask, sl.pf[0].d_wsize, sl.pf[1].d_wsize);
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        const RefTable refs = {q.d_ref_names, q.d_ref_at, q.n_refs};
+        text_size_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_raw, q.v_rec_off, n, refs, q.d_wsize, sl.d_state);
+        size_sum_kernel<<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part);
+        part_scan_kernel<<<1, 1024, 0, st>>>(q.d_part, n_part, sl.d_state + 8 + f);
+        size_place_kernel<false><<<n_part, 256, 0, st>>>(q.d_wsize, n, q.d_part, q.d_place);
+    }
+    XMB_HIP(b, hipMemcpyAsync(sl.h_state + 8, sl.d_state + 8, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    XMB_HIP(b, hipEventRecord(sl.ev_wait, st));
+    XMB_HIP(b, hipEventSynchronize(sl.ev_wait));
+    if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
+    out->bytes1 = sl.h_state[8]; out->bytes2 = sl.h_state[9];
+    if (sl.h_state[13] != 0u) { out->status = 1; return XM_OK; }            // a field the host prints (floating point)
+    if (out->bytes1 > text_cap || out->bytes2 > text_cap) { out->status = 2; return XM_OK; }     // more text than the buffers hold
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        const RefTable refs = {q.d_ref_names, q.d_ref_at, q.n_refs};
+        text_fill_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_raw, q.v_rec_off, n, refs, q.d_wsize, q.d_place, q.d_packed, text_cap);
+    }
+    // the text and its line table, on the copy stream behind the kernels
+    XMB_HIP(b, hipEventRecord(sl.ev_inflated, st));
+    XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        const uint64_t bytes = f == 0 ? out->bytes1 : out->bytes2;
+        if (bytes) XMB_HIP(b, hipMemcpyAsync(q.h_packed, q.d_packed, (size_t)bytes, hipMemcpyDeviceToHost, sl.copy_stream));
+        XMB_HIP(b, hipMemcpyAsync(q.h_place, q.d_place, (size_t)n * 4, hipMemcpyDeviceToHost, sl.copy_stream));
+        XMB_HIP(b, hipMemcpyAsync(q.h_llen, q.d_wsize, (size_t)n * 4, hipMemcpyDeviceToHost, sl.copy_stream));
     }
     XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
     sl.raw_issued = true;

@@ -1118,6 +1118,7 @@ class _GpuBamFile(object):
             self.skip = at - int(blocks["out_off"][j])
         else:                                                        # no record at all
             self.cursor, self.skip = nxt, 0
+        self.ref_names = self._reference_names(blocks, at)           # for the device printer (None: could not be read)
         self.fd = os.open(path, os.O_RDONLY)
         self.carry = (0, 0, 0)                                       # (slot, offset, bytes) of the previous window's tail
         self.bytes_per_record = 0.0                                  # of the windows so far (0: not known yet)
@@ -1126,6 +1127,33 @@ class _GpuBamFile(object):
         self.pending = None
         self.ahead = None                                            # (staging address, file offset, bytes, the slot's capacities, blocks, CRCs, indexed bytes) read ahead for the next window
         self.last_comp = 0                                           # compressed bytes of the last window staged
+
+    def _reference_names(self, blocks, at):
+        """The reference names of the BAM header (SAM specification 4.2: magic, l_text, text, n_ref, then l_name, name, l_ref per
+        reference), from the inflated bytes in front of the first record."""
+        import zlib
+        try:
+            head = bytearray()
+            for blk in blocks:
+                if len(head) >= at:
+                    break
+                c0, cl = int(blk["cdata_off"]), int(blk["cdata_len"])
+                head += zlib.decompress(bytes(self.data[c0:c0 + cl]), -15)
+            if len(head) < at or head[:4] != b"BAM\x01":
+                return None
+            l_text = int.from_bytes(head[4:8], "little")
+            p = 8 + l_text
+            n_ref = int.from_bytes(head[p:p + 4], "little")
+            p += 4
+            names = []
+            for _ in range(n_ref):
+                l_name = int.from_bytes(head[p:p + 4], "little")
+                name = bytes(head[p + 4:p + 4 + l_name])
+                names.append(name.split(b"\0", 1)[0])
+                p += 4 + l_name + 4
+            return names if p == at else None
+        except Exception:                                            # noqa: BLE001 -- the host printer does not need them
+            return None
 
     def _member_header(self, blocks, j):
         """Bytes between a member's first byte and its DEFLATE data: cdata_off of block j minus the end of block j - 1."""
@@ -1285,6 +1313,13 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
 
     bam_text = _BAM_TEXT_BUFFERS                                     # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
     bam_windows = [0]                                                # windows run so far
+    # the records' SAM text is printed on the device when the reference names could be read (XENOMAPPER_GPU_BAM_TEXT=0: by the
+    # host threads, from the packed records; a window with floating-point fields is printed that way in any case)
+    bam_text_on_device = False
+    if bamdev is not None and os.environ.get("XENOMAPPER_GPU_BAM_TEXT", "1") != "0" and all(src.ref_names is not None for src in sources):
+        for f, src in enumerate(sources):
+            bamdev.set_refs(f, src.ref_names)
+        bam_text_on_device = True
     # the GPU BAM path reads the next window's compressed blocks while the GPU works on the current one (_GpuBamFile.read_ahead):
     # a reader of its own (8 threads: pread into page-locked memory peaks there, e2e.host_ceilings) and one thread that drives it
     bam_reader = _host.Parser(8) if bamdev is not None and os.environ.get("XENOMAPPER_BAM_READ_AHEAD", "1") != "0" else None
@@ -1378,7 +1413,14 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             with prof("classify"):
                 blk.classified = bamdev.classify(which, mode, blk.n, _floor_min_score(min_score))
                 # the bins are on the device: only the records a sink takes come back, packed (half of a window)
-                blk.packed = bamdev.fetch_wanted(which, blk.n, paired, sum(1 << b for b in range(6) if sinks[b]))
+                mask = sum(1 << b for b in range(6) if sinks[b])
+                blk.lines = None
+                if bam_text_on_device:
+                    lines = bamdev.fetch_text(which, blk.n, paired, mask)
+                    if lines[0] == 0:
+                        blk.lines = lines
+                if blk.lines is None:
+                    blk.packed = bamdev.fetch_wanted(which, blk.n, paired, mask)
         else:
             bamdev.fetch_raw(which)                                  # values the text rules must decide, or nothing: the whole windows
 
@@ -1389,6 +1431,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 t_w = time.perf_counter()
                 bamdev.raw_wait(which)                               # the copy of the window ran beside the kernels and the next window's inflate
                 prof["bam_wait_raw"] = prof.get("bam_wait_raw", 0.0) + time.perf_counter() - t_w
+                if getattr(blk, "lines", None) is not None:         # printed on the device: the text and its line table are here
+                    _st, text, loff, llen = blk.lines
+                    texts[0], texts[1] = text[0], text[1]
+                    blk.set_text(list(loff), list(llen))
+                    return
                 loffs, llens = [], []
                 # A unit's lines come from ONE file (primary bins: file 1, secondary bins: file 2, unresolved: both; :423-448),
                 # and a bin without a sink prints nothing: with the bins known on the device, only those records came back
