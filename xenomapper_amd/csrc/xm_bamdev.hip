@@ -286,21 +286,60 @@ struct CountChars {
     __device__ __forceinline__ void qual(const uint8_t *, uint32_t len) { n += len; }
 };
 
+struct __attribute__((packed, aligned(1))) U32Store { uint32_t v; };
+// bytes gathered four at a time: a lane's line is written with (unaligned) dword stores -- a store instruction of 64 lanes touches 64
+// cache lines whatever its width
 struct WriteChars {
     uint8_t *o;
-    __device__ __forceinline__ void ch(uint32_t c) { *o++ = (uint8_t)c; }
-    __device__ __forceinline__ void bytes(const uint8_t *p, uint32_t len) { for (uint32_t k = 0; k < len; ++k) o[k] = p[k]; o += len; }
+    unsigned long long acc = 0;
+    uint32_t k = 0;                              // bytes waiting in acc (< 4 between calls)
+    __device__ __forceinline__ void word(uint32_t w, uint32_t n_bytes)          // n_bytes <= 4, the bytes above them zero
+    {
+        acc |= (unsigned long long)w << (8u * k);
+        k += n_bytes;
+        if (k >= 4u) {
+            reinterpret_cast<U32Store *>(o)->v = (uint32_t)acc;
+            o += 4;
+            acc >>= 32;
+            k -= 4u;
+        }
+    }
+    __device__ __forceinline__ void ch(uint32_t c) { word(c & 0xFFu, 1u); }
+    __device__ __forceinline__ void bytes(const uint8_t *p, uint32_t len)
+    {
+        uint32_t j = 0;
+        for (; j + 4u <= len; j += 4u) word(ld32(p + j), 4u);
+        for (; j < len; ++j) word(p[j], 1u);
+    }
     __device__ __forceinline__ void seq(const uint8_t *p, uint32_t len)
     {
-        // "=ACMGRSVTWYHKDBN", eight letters a word
+        // "=ACMGRSVTWYHKDBN", eight letters a word; two bases a byte, the first in the high nibble
         const unsigned long long lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;
-        for (uint32_t k = 0; k < len; ++k) {
-            const uint32_t code = (p[k >> 1] >> ((k & 1u) ? 0u : 4u)) & 15u;
-            o[k] = (uint8_t)(((code < 8u ? lo : hi) >> (8u * (code & 7u))) & 0xFFu);
+        uint32_t j = 0;
+        for (; j + 4u <= len; j += 4u) {
+            const uint32_t two = ld16(p + (j >> 1));
+            uint32_t w = 0;
+            for (uint32_t q = 0; q < 4u; ++q) {
+                const uint32_t code = (two >> (8u * (q >> 1) + ((q & 1u) ? 0u : 4u))) & 15u;
+                w |= (uint32_t)(((code < 8u ? lo : hi) >> (8u * (code & 7u))) & 0xFFu) << (8u * q);
+            }
+            word(w, 4u);
         }
-        o += len;
+        for (; j < len; ++j) {
+            const uint32_t code = (p[j >> 1] >> ((j & 1u) ? 0u : 4u)) & 15u;
+            word((uint32_t)(((code < 8u ? lo : hi) >> (8u * (code & 7u))) & 0xFFu), 1u);
+        }
     }
-    __device__ __forceinline__ void qual(const uint8_t *p, uint32_t len) { for (uint32_t k = 0; k < len; ++k) o[k] = (uint8_t)(p[k] + 33u); o += len; }
+    __device__ __forceinline__ void qual(const uint8_t *p, uint32_t len)
+    {
+        uint32_t j = 0;
+        for (; j + 4u <= len; j += 4u) {
+            const uint32_t q4 = ld32(p + j);
+            word(((q4 & 0x7F7F7F7Fu) + 0x21212121u) ^ (q4 & 0x80808080u), 4u);          // + 33 in every byte, no carry across bytes
+        }
+        for (; j < len; ++j) word((p[j] + 33u) & 0xFFu, 1u);
+    }
+    __device__ __forceinline__ void finish() { for (uint32_t j = 0; j < k; ++j) o[j] = (uint8_t)(acc >> (8u * j)); }
 };
 
 template <typename S> __device__ __forceinline__ void put_u64(S &s, unsigned long long v)
@@ -426,8 +465,10 @@ text_fill_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ r
     if (i >= n) return;
     const uint32_t len = wsize[i], at = place[i];
     if (len == 0u || at == NO_RECORD || at + len > text_cap) { wsize[i] = 0u; place[i] = 0u; return; }
-    WriteChars w = {text + at};
+    WriteChars w;
+    w.o = text + at;
     (void)sam_line(raw, rec_off[i], refs, w);
+    w.finish();
     wsize[i] = len - 1u;
 }
 
