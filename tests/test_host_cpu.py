@@ -417,3 +417,40 @@ def test_header_only_bam_handle_knows_the_header_and_refuses_to_read(tmp_path):
         finally:
             full.close()
             head.close()
+
+
+def test_gpu_bam_cursor_reads_the_reference_names(tmp_path):
+    """_GpuBamFile (the GPU BAM path's cursor over a file's BGZF blocks) reads the reference names the device printer writes in
+    RNAME / RNEXT from the inflated bytes in front of the first record: the names of the reference's fixtures as the SAM header
+    lists them (@SQ SN), also when the header spans hundreds of small blocks, and None -- the host printer then -- for a file
+    whose header it cannot follow."""
+    import gzip
+    import struct
+    import sys
+    from xenomapper_amd import xenomapper as xm
+    sys.path.insert(0, os.path.join(H.REPO, "tools"))
+    import bench_bam
+    for tag in ("human", "mouse"):
+        src = os.path.join(H.REPO, "tests", "golden", "ref_data", "paired_end_testdata_%s.bam" % tag)
+        raw = gzip.decompress(open(src, "rb").read())
+        l_text, = struct.unpack_from("<i", raw, 4)
+        text = raw[8:8 + l_text]
+        want = [f[3:] for line in text.split(b"\n") if line.startswith(b"@SQ") for f in line.split(b"\t") if f.startswith(b"SN:")]
+        assert len(want) > 1
+        g = xm._GpuBamFile(src, 2)
+        try:
+            assert g.ref_names == want
+        finally:
+            g.close()
+        # the same file with a header text that fills hundreds of small blocks
+        filler = ("@CO\t" + "x" * 60 + "\n") * 2000
+        big_text = text.rstrip(b"\0") + filler.encode("ascii")
+        big = b"BAM\x01" + struct.pack("<i", len(big_text)) + big_text + raw[8 + l_text:]
+        path = str(tmp_path / ("big_%s.bam" % tag))
+        with open(path, "wb") as fh:
+            fh.write(bench_bam.bgzf_blocks(big, chunk=320) + bench_bam.BGZF_EOF)
+        g = xm._GpuBamFile(path, 2)
+        try:
+            assert g.ref_names == want
+        finally:
+            g.close()
