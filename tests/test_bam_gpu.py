@@ -267,6 +267,24 @@ def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, t
     assert got == want
 
 
+def test_more_text_than_the_buffers_hold_goes_to_the_host_printer(tmp_path, monkeypatch):
+    """The same file on both sides: every pair is unresolved, every record of both files is wanted, and their SAM text (1.6 x the
+    records) does not fit the slot's packed-record buffers in windows of 8 MB -- xm_bamdev_fetch_text declines (status 2) and the
+    window is printed by the host from the packed records; a smaller mask of sinks fits and is printed on the device.  Outputs equal
+    the host decoder's either way."""
+    import bench_bam
+    from xenomapper_amd import xenomapper as xm
+    p = str(tmp_path / "same.bam")
+    bench_bam.tiled_bam(os.path.join(DATA, "paired_end_testdata_human.bam"), p, 100)
+    monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 8 << 20)
+    monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 8 << 20)
+    want = run_path([p, p], gpu=False)
+    got = run_path([p, p], gpu=True)
+    assert isinstance(want[0], dict) and got == want
+    assert len(got[1][4]) > 0 and not any(got[1][b] for b in (0, 1, 2, 3))     # all unresolved (or unassigned)
+    assert xm.LAST_FILE_PROFILE.get("bam_print", 0) > 0                        # the host printed
+
+
 def test_runs_of_equal_names_longer_than_a_window(tmp_path, monkeypatch):
     """The skipping walk over files whose runs of equal names differ between the files and cross the windows -- one run longer
     than several windows (the window has to grow), runs that end exactly with a BGZF block, a file whose last run reaches its
