@@ -1391,6 +1391,9 @@ int xm_bamdev_fetch_text(xm_bamdev *b, int slot, uint64_t n_records, int paired,
     hipStream_t st = sl.stream;
     const uint32_t n = (uint32_t)n_records;
     if (n == 0) return XM_OK;
+    // the line lengths are summed in 32 bits: a record's text is at most five times its bytes (xm_bam.cpp: a B:c element, 1 -> "-128,"),
+    // so windows beyond 2^32 / 5 bytes are the host printer's
+    if (sl.pf[0].raw_len > 0x30000000ull || sl.pf[1].raw_len > 0x30000000ull) { out->status = 2; return XM_OK; }
     const uint32_t n_part = (n + SCAN_TILE - 1u) / SCAN_TILE;
     const uint32_t text_cap = (uint32_t)std::min<uint64_t>(sl.raw_cap, 0xFFFFFFF0ull);      // the packed-record buffers hold the text
     XMB_HIP(b, hipMemsetAsync(sl.d_state + 13, 0, sizeof(uint32_t), st));
