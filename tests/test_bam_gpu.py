@@ -279,7 +279,11 @@ def test_more_text_than_the_buffers_hold_goes_to_the_host_printer(tmp_path, monk
     monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 8 << 20)
     monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 8 << 20)
     want = run_path([p, p], gpu=False)
+    if xm._bamdev is not None:                                       # a front end of its own: the process-wide one keeps the
+        xm._bamdev.close()                                           # largest buffers any earlier run asked for
+    monkeypatch.setattr(xm, "_bamdev", None)
     got = run_path([p, p], gpu=True)
+    xm._bamdev.close()
     assert isinstance(want[0], dict) and got == want
     assert len(got[1][4]) > 0 and not any(got[1][b] for b in (0, 1, 2, 3))     # all unresolved (or unassigned)
     assert xm.LAST_FILE_PROFILE.get("bam_print", 0) > 0                        # the host printed
