@@ -191,7 +191,8 @@ int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paire
 /* (c) after xm_bamdev_classify: the SAM TEXT of the records a sink takes, printed on the device -- the lines `samtools view` would
  * print (the reference reads BAM through it: getBamReadPairs / bam_lines, xenomapper.py:56-93), next to each other in text1 / text2,
  * line_off*[i] / line_len*[i] = where record i's line is and how long (without its '\n'; 0 / 0: no sink takes it).  Needs the
- * files' reference names (xm_bamdev_set_refs: the names back to back, at[n_refs + 1] positions; once per pair of files).
+ * files' reference names (xm_bamdev_set_refs: the names back to back, at[n_refs + 1] positions; once per pair of files;
+ * XM_ERR_INVALID_ARG without them).
  * status 0: the text is on its way (xm_bamdev_raw_wait); 1: a record holds a floating-point field (printf("%g") is the host
  * printer's), 2: more text than the slot's buffers hold -- nothing was copied then: ask for (b) and print on the host. */
 typedef struct {

@@ -473,6 +473,10 @@ def test_only_the_records_a_sink_takes_come_back(ctx, tmp_path, paired, mode):
         blk, readers = run_whole_files(dev, images, 0, paired)           # the whole windows on the host as well (wait_raw)
         n = blk.n
         assert n > 1000 and not blk.n_exceptions
+        if mode == 1:                                                     # the device printer needs the reference names
+            dev.classify(0, mode, n, -2**31)
+            with pytest.raises(ValueError):
+                dev.fetch_text(0, n, paired, 0b111111)
         # the host printer's text of every record, and the files' reference names for the device printer
         host_lines = []
         for f in (0, 1):

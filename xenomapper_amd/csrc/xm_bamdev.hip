@@ -635,6 +635,7 @@ struct PerFile {
     // the device printer: the file's reference names (xm_bamdev_set_refs: the same for both slots), the line lengths on the host
     uint8_t *d_ref_names = nullptr;
     uint32_t *d_ref_at = nullptr, n_refs = 0, *h_llen = nullptr;
+    bool refs_set = false;
     uint64_t llen_records = 0;
     // the skipping walk: the fields of the run starts, next to each other (ensure_skip), and their record starts on the host
     uint32_t *d_r_rec_off = nullptr, *d_r_name_off = nullptr, *d_r_name_len = nullptr, *d_r_ncig = nullptr, *d_r_cig_at = nullptr, *h_pair_off = nullptr;
@@ -747,6 +748,7 @@ void free_slot(Slot &sl)
         dfree(q.d_r_rec_off); dfree(q.d_r_name_off); dfree(q.d_r_name_len); dfree(q.d_r_ncig); dfree(q.d_r_cig_at); hfree(q.h_pair_off);
         dfree(q.d_r_a); dfree(q.d_r_x); dfree(q.d_r_flag);
         dfree(q.d_ref_names); dfree(q.d_ref_at); hfree(q.h_llen);
+        q.refs_set = false;
         q.skip_records = q.skip_cig_records = q.llen_records = 0; q.n_refs = 0;
     }
     dfree(sl.d_comp_all); dfree(sl.d_raw_all);
@@ -1359,6 +1361,7 @@ int xm_bamdev_set_refs(xm_bamdev *b, int file, const uint8_t *names, const uint3
     for (int slot = 0; slot < 2; ++slot) {                                  // a copy per slot: the slots' streams share nothing
         PerFile &q = b->slot[slot].pf[file];
         q.n_refs = 0;
+        q.refs_set = false;
         const size_t bytes = n_refs ? at[n_refs] : 0;
         XMB_TRY(dalloc(b, q.d_ref_names, bytes + 16)); XMB_TRY(dalloc(b, q.d_ref_at, (size_t)n_refs + 1));
         if (n_refs) {
@@ -1366,6 +1369,7 @@ int xm_bamdev_set_refs(xm_bamdev *b, int file, const uint8_t *names, const uint3
             XMB_HIP(b, hipMemcpy(q.d_ref_at, at, ((size_t)n_refs + 1) * 4, hipMemcpyHostToDevice));
         }
         q.n_refs = n_refs;
+        q.refs_set = true;
     }
     return XM_OK;
 }
@@ -1375,6 +1379,7 @@ int xm_bamdev_fetch_text(xm_bamdev *b, int slot, uint64_t n_records, int paired,
     if (!b || slot < 0 || slot > 1 || !out) return XM_ERR_INVALID_ARG;
     Slot &sl = b->slot[slot];
     if (n_records > sl.record_cap || n_records > 0xFFFFFFF0ull || !sl.have_columns || !sl.classified) return XM_ERR_INVALID_ARG;
+    if (!sl.pf[0].refs_set || !sl.pf[1].refs_set) return XM_ERR_INVALID_ARG;          // RNAME / RNEXT need xm_bamdev_set_refs
     memset(out, 0, sizeof *out);
     XMB_HIP(b, hipSetDevice(b->device));
     for (int f = 0; f < 2; ++f) {
