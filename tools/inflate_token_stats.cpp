@@ -9,6 +9,8 @@ static uint64_t g_lit, g_match, g_match_bytes, g_far, g_far_bytes, g_dist_le[16]
 #define XMI_STAT_MATCH(len, dist, behind) do { ++g_match; g_match_bytes += (len); if (behind) { ++g_far; g_far_bytes += (len); } \
     for (int k_ = 0; k_ < 16; ++k_) if ((dist) <= (1u << k_)) { ++g_dist_le[k_]; break; } \
     for (int k_ = 0; k_ < 10; ++k_) if ((len) <= (1u << k_)) { ++g_len_le[k_]; break; } } while (0)
+static uint64_t g_long[16];
+#define XMI_STAT_LONG_CODE(root_bits) (++g_long[(root_bits) & 15])
 #include "../xenomapper_amd/csrc/xm_inflate_core.h"
 
 #include <cstdlib>
@@ -54,6 +56,8 @@ int main(int argc, char **argv)
     for (int k = 0; k < 16; ++k) printf(" %.1f", 100.0 * g_dist_le[k] / g_match);
     printf("\nlength <= 2^k, k = 0..9 (%% of matches):");
     for (int k = 0; k < 10; ++k) printf(" %.1f", 100.0 * g_len_le[k] / g_match);
-    printf("\n");
+    printf("\ncodes beyond the root tables (the wide token loop hands these tokens to the serial reader): literal/length %.2f %% of tokens, "
+           "distance %.2f %% of matches (code-length code: %llu)\n", 100.0 * g_long[xmi::LIT_ROOT] / tok, 100.0 * g_long[xmi::DIST_ROOT] / g_match,
+           (unsigned long long)g_long[xmi::CLC_ROOT]);
     return 0;
 }

@@ -161,6 +161,9 @@ XMI_HD void count_inc(uint32_t *p)
 #define XMI_STAT_LITERAL() do { } while (0)
 #define XMI_STAT_MATCH(len, dist, behind_ring) do { } while (0)
 #endif
+#ifndef XMI_STAT_LONG_CODE
+#define XMI_STAT_LONG_CODE(root_bits) do { } while (0)      // a code beyond a root table (the wide loop hands such a token to the serial reader)
+#endif
 
 template <int GS>
 struct Chain {
@@ -333,6 +336,7 @@ struct Chain {
         const uint32_t e = root[(uint32_t)bits & ((1u << RB) - 1u)];
         const uint32_t L = e & 15u;
         if (L) { drop(L); return e >> 4; }
+        XMI_STAT_LONG_CODE(RB);
         const uint32_t rev = bitrev32((uint32_t)bits) >> 17;               // the next 15 bits, first bit on top
         for (uint32_t q = RB + 1u; q <= 15u; ++q) {
             const uint32_t c = rev >> (15u - q);
@@ -497,8 +501,9 @@ struct Chain {
     // rest goes on in the next batch: the same rule) -- and emit_batch() makes all of them at once: sources in front of the batch
     // come from the ring or from memory as ever, sources INSIDE the batch (overlapping matches, a match that copies a token of
     // the same batch) are chased lane to lane (ds_bpermute pointer jumping: a chain of references halves every round).
-    // A lane whose bits need the long-code path (codes beyond the root tables: rare) or hold no valid token is marked; when the
-    // walk reaches one, the serial reader takes that one token.
+    // A lane whose bits need a code beyond the root tables (4 % of BAM's tokens) or hold no valid token is marked; when the walk
+    // reaches one, long_token() decodes that one token with the canonical walk, all lanes alike, and the walk goes on; only what
+    // is no token at all goes to the serial reader, which names the error.
     // Packed token: bits 0-5 its length in bits, 6-14 the bytes it makes (0: not a token the walk can deal out -- then bits 15..
     // say which: T_EOB, T_SLOW), 15-31 what they are made of: V_LIT | byte, or the distance.
     static constexpr uint32_t V_LIT = 0x10000u, T_EOB = 1u, T_SLOW = 2u;
@@ -543,6 +548,56 @@ struct Chain {
         const uint32_t n = (bad || is_eob) ? 0u : is_lit ? 1u : len;
         const uint32_t v = bad ? T_SLOW : is_eob ? T_EOB : is_lit ? (V_LIT | sym) : dist;
         return total | (n << 6) | (v << 15);
+    }
+    // The token at one bit of the stream with the codes BEYOND the root tables decoded too (the canonical first-code / limit walk of
+    // decode()), computed by all lanes alike, in the packed form of window_tokens -- for the lane the walk has reached and found
+    // marked: 4 % of the tokens of BAM data (tools/inflate_token_stats.cpp: literal / length codes longer than 10 bits, distance
+    // codes longer than 8), too many to hand each to the serial reader, which needs the open batch written first and a fresh
+    // window behind it.  T_SLOW again: no valid token here (the serial reader then names the error).
+    XMI_HD uint32_t long_token(uint32_t bitpos) const
+    {
+        const uint32_t w0 = (bitpos >> 5) << 2, sh = bitpos & 31u;
+        const uint32_t a0 = *reinterpret_cast<const uint32_t *>(m->iring + (w0 & (IRING - 1u)));
+        const uint32_t a1 = *reinterpret_cast<const uint32_t *>(m->iring + ((w0 + 4u) & (IRING - 1u)));
+        const uint32_t a2 = *reinterpret_cast<const uint32_t *>(m->iring + ((w0 + 8u) & (IRING - 1u)));
+        const uint32_t x0 = __builtin_amdgcn_alignbit(a1, a0, sh), x1 = __builtin_amdgcn_alignbit(a2, a1, sh);
+        const uint32_t slow = T_SLOW << 15;
+        const uint32_t e = m->lit_root[x0 & ((1u << LIT_ROOT) - 1u)];
+        uint32_t L = e & 15u, sym = e >> 4;
+        if (L == 0u) {
+            const uint32_t rev = bitrev32(x0) >> 17;                        // the next 15 bits, first bit on top
+            for (uint32_t q = LIT_ROOT + 1u; q <= 15u; ++q) {
+                const uint32_t c = rev >> (15u - q), f = m->lit_meta[0][q], lim = m->lit_meta[1][q];
+                if (c >= f && c < lim) { L = q; sym = m->lit_sym[m->lit_meta[2][q] + c - f]; break; }
+            }
+            if (L == 0u) return slow;
+        }
+        if (sym < 256u) return L | (1u << 6) | ((V_LIT | sym) << 15);
+        if (sym == 256u) return L | (T_EOB << 15);
+        const uint32_t ls = sym - 257u;
+        if (ls > 28u) return slow;
+        const bool top = ls == 28u;
+        const uint32_t leb0 = (ls >> 2) > 1u ? (ls >> 2) - 1u : 0u;
+        const uint32_t leb = top ? 0u : leb0;
+        const uint32_t lman = ls < 4u ? ls : (4u | (ls & 3u));
+        const uint32_t len = (lman << leb0) + 3u - (top ? 1u : 0u) + __builtin_amdgcn_ubfe(x0, L, leb);
+        const uint32_t o2 = L + leb;                                        // <= 20
+        const uint32_t y = __builtin_amdgcn_alignbit(x1, x0, o2);
+        const uint32_t de = m->dist_root[y & ((1u << DIST_ROOT) - 1u)];
+        uint32_t DL = de & 15u, d = de >> 4;
+        if (DL == 0u) {
+            const uint32_t rev = bitrev32(y) >> 17;
+            for (uint32_t q = DIST_ROOT + 1u; q <= 15u; ++q) {
+                const uint32_t c = rev >> (15u - q), f = m->dist_meta[0][q], lim = m->dist_meta[1][q];
+                if (c >= f && c < lim) { DL = q; d = m->dist_sym[m->dist_meta[2][q] + c - f]; break; }
+            }
+            if (DL == 0u) return slow;
+        }
+        if (d > 29u) return slow;
+        const uint32_t deb = (d >> 1) > 1u ? (d >> 1) - 1u : 0u;
+        const uint32_t dman = d < 2u ? d : (2u | (d & 1u));
+        const uint32_t dist = (dman << deb) + 1u + __builtin_amdgcn_ubfe(y, DL, deb);
+        return (o2 + DL + deb) | (len << 6) | (dist << 15);
     }
     // bytes [op, op + T) from what the lanes of the batch hold
     XMI_HD void emit_batch(uint32_t lane_val, uint32_t T)
@@ -598,7 +653,13 @@ struct Chain {
                 for (;;) {
                     t = __builtin_amdgcn_readlane(info, ss);
                     uint32_t n = (t >> 6) & 0x1FFu;
-                    if (n == 0u) { out = true; break; }
+                    if (n == 0u) {
+                        if ((t >> 15) == T_SLOW) {                          // a code beyond the root tables, most likely
+                            t = __builtin_amdgcn_readfirstlane(long_token(pp + ss));
+                            n = (t >> 6) & 0x1FFu;
+                        }
+                        if (n == 0u) { out = true; break; }                 // the end of the block, or no token at all
+                    }
                     if (ff + n > 64u) {
                         // a token longer than the batch's rest: batch after batch, and on in this window
                         const uint32_t v = t >> 15;
