@@ -9,7 +9,8 @@ static uint64_t g_lit, g_match, g_match_bytes, g_far, g_far_bytes, g_dist_le[16]
 #define XMI_STAT_MATCH(len, dist, behind) do { ++g_match; g_match_bytes += (len); if (behind) { ++g_far; g_far_bytes += (len); } \
     for (int k_ = 0; k_ < 16; ++k_) if ((dist) <= (1u << k_)) { ++g_dist_le[k_]; break; } \
     for (int k_ = 0; k_ < 10; ++k_) if ((len) <= (1u << k_)) { ++g_len_le[k_]; break; } } while (0)
-static uint64_t g_long[16];
+static uint64_t g_long[16], g_blocks[4];
+#define XMI_STAT_BLOCK(type) (++g_blocks[(type) & 3])
 #define XMI_STAT_LONG_CODE(root_bits) (++g_long[(root_bits) & 15])
 #include "../xenomapper_amd/csrc/xm_inflate_core.h"
 
@@ -59,5 +60,7 @@ int main(int argc, char **argv)
     printf("\ncodes beyond the root tables (the wide token loop hands these tokens to the serial reader): literal/length %.2f %% of tokens, "
            "distance %.2f %% of matches (code-length code: %llu)\n", 100.0 * g_long[xmi::LIT_ROOT] / tok, 100.0 * g_long[xmi::DIST_ROOT] / g_match,
            (unsigned long long)g_long[xmi::CLC_ROOT]);
+    printf("DEFLATE blocks: %llu stored, %llu fixed, %llu dynamic = %.2f per BGZF block\n", (unsigned long long)g_blocks[0], (unsigned long long)g_blocks[1],
+           (unsigned long long)g_blocks[2], (double)(g_blocks[0] + g_blocks[1] + g_blocks[2]) / (double)blocks);
     return 0;
 }

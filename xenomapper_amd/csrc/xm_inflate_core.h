@@ -161,6 +161,9 @@ XMI_HD void count_inc(uint32_t *p)
 #define XMI_STAT_LITERAL() do { } while (0)
 #define XMI_STAT_MATCH(len, dist, behind_ring) do { } while (0)
 #endif
+#ifndef XMI_STAT_BLOCK
+#define XMI_STAT_BLOCK(type) do { } while (0)               // a DEFLATE block of this type begins
+#endif
 #ifndef XMI_STAT_LONG_CODE
 #define XMI_STAT_LONG_CODE(root_bits) do { } while (0)      // a code beyond a root table (the wide loop hands such a token to the serial reader)
 #endif
@@ -737,6 +740,7 @@ struct Chain {
             last = get(1u) != 0u;
             const uint32_t type = get(2u);
             XMI_STAGE(10u + type);
+            XMI_STAT_BLOCK(type);
             if (type == 0u) stored_block();
             else if (type == 3u) err = ERR_BTYPE;
             else {
