@@ -1315,11 +1315,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     bam_windows = [0]                                                # windows run so far
     # the records' SAM text is printed on the device when the reference names could be read (XENOMAPPER_GPU_BAM_TEXT=0: by the
     # host threads, from the packed records; a window with floating-point fields is printed that way in any case)
-    bam_text_on_device = False
+    bam_text_on_device = [False]
     if bamdev is not None and os.environ.get("XENOMAPPER_GPU_BAM_TEXT", "1") != "0" and all(src.ref_names is not None for src in sources):
         for f, src in enumerate(sources):
             bamdev.set_refs(f, src.ref_names)
-        bam_text_on_device = True
+        bam_text_on_device[0] = True
     # the GPU BAM path reads the next window's compressed blocks while the GPU works on the current one (_GpuBamFile.read_ahead):
     # a reader of its own (8 threads: pread into page-locked memory peaks there, e2e.host_ceilings) and one thread that drives it
     bam_reader = _host.Parser(8) if bamdev is not None and os.environ.get("XENOMAPPER_BAM_READ_AHEAD", "1") != "0" else None
@@ -1415,10 +1415,12 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 # the bins are on the device: only the records a sink takes come back, packed (half of a window)
                 mask = sum(1 << b for b in range(6) if sinks[b])
                 blk.lines = None
-                if bam_text_on_device:
+                if bam_text_on_device[0]:
                     lines = bamdev.fetch_text(which, blk.n, paired, mask)
                     if lines[0] == 0:
                         blk.lines = lines
+                    elif lines[0] == 1:                              # files whose records carry floating-point fields (e.g. de:f):
+                        bam_text_on_device[0] = False                # the host prints the rest of the run without asking again
                 if blk.lines is None:
                     blk.packed = bamdev.fetch_wanted(which, blk.n, paired, mask)
         else:
