@@ -312,6 +312,41 @@ struct Chain {
             idx += c;
         }
         chain_sync();
+#if XMI_DEVICE && !defined(XMI_SERIAL_BUILD)
+        if (GS == 64) {
+            // A lane per symbol, a lane per root entry (the loop below places one symbol at a time, all lanes alike: 22 k
+            // instructions for a literal / length table, 4.5 % of the launch).  Symbols in canonical order: among the symbols of
+            // one length a symbol's place is the number of smaller ones -- the lanes in front of it in its chunk of 64 (a ballot's
+            // bits below the lane) plus the chunks in front.  Root entries: every entry looks for the code that begins its index
+            // (the canonical first-code / limit test per length; a prefix code matches at one length at most).
+            uint32_t Lc[5];
+#pragma unroll
+            for (uint32_t c = 0; c < 5u; ++c) { const uint32_t sy = c * 64u + gl; Lc[c] = sy < n ? cl[sy] : 0u; }
+            for (uint32_t q = 1; q <= 15u; ++q) {
+                const uint32_t b = meta[2][q];
+                uint32_t run = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < 5u; ++c) {
+                    if (c * 64u >= n) break;
+                    const bool mine = Lc[c] == q;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
+                    if (mine) sym[b + run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint16_t)(c * 64u + gl);
+                    run += (uint32_t)__popcll(mask);
+                }
+            }
+            chain_sync();
+            for (uint32_t q = 1; q <= RB; ++q) {
+                const uint32_t f = meta[0][q], lim = meta[1][q], b = meta[2][q];
+                if (f == lim) continue;
+                for (uint32_t i = gl; i < (1u << RB); i += 64u) {
+                    const uint32_t c = (bitrev32(i) >> (32u - RB)) >> (RB - q);          // the first q bits of the index, first bit on top
+                    if (c >= f && c < lim) root[i] = (uint16_t)((sym[b + c - f] << 4) | q);
+                }
+            }
+            chain_sync();
+            return true;
+        }
+#endif
         for (uint32_t i = gl; i < 16u; i += GS) m->cnt[i] = 0u;          // now: symbols of each length placed so far
         chain_sync();
         XMI_STAGE(42);
