@@ -789,6 +789,16 @@ static int ensure_cigar(xm_bamdev *b, Slot &sl)
     return XM_OK;
 }
 
+// The inflate launch reads the compressed blocks where the host staged them -- page-locked memory the device has mapped -- instead of
+// a copy in HBM: every chain keeps one 128-byte piece of its block in flight, 8192 chains hide the link's latency, and the copy
+// that is not made is a shader kernel that does not run beside the inflate launch (host <-> device copies are blit kernels on this
+// pool): 20.4-20.7 against 18.5-19.8 M pairs/s end to end (profiles/r05_bam_device_text.txt).  XM_BAMDEV_ZEROCOPY=0: upload first.
+static bool zero_copy_input()
+{
+    static const bool on = [] { const char *v = getenv("XM_BAMDEV_ZEROCOPY"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
 // skip_repeated_reads: the arrays only the skipping walk needs
 static int ensure_skip(xm_bamdev *b, Slot &sl, bool cigar)
 {
@@ -915,7 +925,7 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
         XMB_TRY(dalloc(b, sl.d_comp_all, (size_t)(2 * sl.comp_stride)));
         XMB_HIP(b, hipMemset(sl.d_comp_all, 0, (size_t)(2 * sl.comp_stride)));
         for (int f = 0; f < 2; ++f) {
-            XMB_TRY(halloc(b, sl.pf[f].h_comp, (size_t)comp_bytes));
+            XMB_TRY(halloc(b, sl.pf[f].h_comp, (size_t)comp_bytes + XMB_COMP_PAD));      // (+ pad: the inflate launch reads it in place)
             sl.pf[f].d_comp = sl.d_comp_all + f * sl.comp_stride;
         }
         sl.comp_cap = comp_bytes;
@@ -1008,6 +1018,7 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     if (skip) XMB_TRY(ensure_skip(b, sl, cigar));
     hipStream_t st = sl.stream;
     static const bool profile = getenv("XM_BAMDEV_PROFILE") != nullptr;
+    const bool zero_copy = zero_copy_input();
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     double t_staged = 0, t_issued = 0, t_sync1 = 0;
@@ -1080,7 +1091,8 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
                 q.h_seg[n_seg++] = w.start;
             }
             sl.h_walk[n_all + k] = w;
-            d.cdata_off += (uint64_t)f * sl.comp_stride;
+            if (zero_copy) d.cdata_off += (uint64_t)(reinterpret_cast<uintptr_t>(q.h_comp) - reinterpret_cast<uintptr_t>(sl.pf[0].h_comp));
+            else d.cdata_off += (uint64_t)f * sl.comp_stride;
             d.out_off = out_in_file + (uint64_t)f * sl.raw_stride;
             sl.h_blocks[n_all + k] = d;
         }
@@ -1091,8 +1103,8 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         // the part of the staged bytes that went up ahead of this call (xm_bamdev_upload) is waited for, the rest is sent now
         const uint64_t up = x.uploaded < x.comp_len ? x.uploaded : x.comp_len;
         if (up > sl.up_len[f]) return XM_ERR_INVALID_ARG;
-        if (up) XMB_HIP(b, hipStreamWaitEvent(st, sl.ev_up[f], 0));
-        if (x.comp_len > up)
+        if (up && !zero_copy) XMB_HIP(b, hipStreamWaitEvent(st, sl.ev_up[f], 0));
+        if (x.comp_len > up && !zero_copy)
             XMB_HIP(b, hipMemcpyAsync(q.d_comp + up, q.h_comp + up, (size_t)(x.comp_len - up), hipMemcpyHostToDevice, st));
         sl.up_len[f] = 0;
         XMB_HIP(b, hipMemcpyAsync(q.d_seg, q.h_seg, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
@@ -1101,7 +1113,7 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     if (n_all) {
         XMB_HIP(b, hipMemcpyAsync(sl.d_blocks, sl.h_blocks, (size_t)n_all * sizeof(xm_bgzf_block), hipMemcpyHostToDevice, st));
         XMB_HIP(b, hipMemcpyAsync(sl.d_walk, sl.h_walk, (size_t)n_all * sizeof(xm_bgzf_walk), hipMemcpyHostToDevice, st));
-        int rc = xm_bgzf_inflate_walk_dev(b->ctx, st, sl.d_comp_all, sl.d_blocks, n_all, sl.d_raw_all, sl.d_status, sl.d_work, sl.d_walk);
+        int rc = xm_bgzf_inflate_walk_dev(b->ctx, st, zero_copy ? sl.pf[0].h_comp : sl.d_comp_all, sl.d_blocks, n_all, sl.d_raw_all, sl.d_status, sl.d_work, sl.d_walk);
         if (rc == XM_OK) rc = xm_bgzf_crc32_dev(b->ctx, st, sl.d_raw_all, sl.d_blocks, n_all, sl.d_crc);
         if (rc != XM_OK) return rc;
         XMB_HIP(b, hipMemcpyAsync(sl.h_status, sl.d_status, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
@@ -1289,6 +1301,7 @@ int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes)
     sl.up_len[file] = 0;
     if (bytes == 0) return XM_OK;
     XMB_HIP(b, hipSetDevice(b->device));
+    if (zero_copy_input()) { sl.up_len[file] = bytes; return XM_OK; }       // nothing to send: the inflate launch reads the staging buffer
     XMB_HIP(b, hipMemcpyAsync(sl.pf[file].d_comp, sl.pf[file].h_comp, (size_t)bytes, hipMemcpyHostToDevice, sl.up_stream));
     XMB_HIP(b, hipEventRecord(sl.ev_up[file], sl.up_stream));
     sl.up_len[file] = bytes;
