@@ -166,6 +166,9 @@ uint8_t *xm_bamdev_staging(xm_bamdev *b, int slot, int file);
  * the slot is idle (its last xm_bamdev_run has returned, the next has not begun): the next run, told so in `uploaded`, waits for
  * the copy instead of making it.  A later xm_bamdev_reserve that grows the buffers forgets what was sent. */
 int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes);
+/* (By default the inflate launch of xm_bamdev_run reads the staging buffers where they are -- page-locked, device-mapped host memory --
+ * and nothing is uploaded at all: xm_bamdev_upload then only notes the count.  XM_BAMDEV_ZEROCOPY=0 in the environment restores the
+ * copy into HBM, ahead of the run or inside it.) */
 /* inflate, find the records, strip, pair.  score_mode: XMS_SCORE_AS_XS, XMS_SCORE_AS_ZS, or XMS_SCORE_CIGAR (get_cigarbased_AS_tag,
  * xenomapper.py:228-256: column "AS" then holds NM -- the FIRST optional field that holds the letters decides, :247-250 -- and
  * xm_bamdev_classify makes the packed CIGAR columns of the records' CIGAR words and runs xm_classify_compact_cigar_packed_dev).
