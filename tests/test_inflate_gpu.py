@@ -205,6 +205,37 @@ def test_damaged_streams_end_with_a_status_and_stay_inside_their_block(ctx):
             assert status[b] != 0 or got_crc[b] != crc[b] or np.array_equal(out[o:o + n], clean[o - 64:o - 64 + n])
 
 
+def test_random_bytes_as_deflate_data_end_with_a_status(ctx):
+    """BGZF members whose DEFLATE data are random bytes, or a valid stream cut short, or a valid stream with a wrong ISIZE: every
+    loop of the decoder ends whatever the data holds (the wide token loop's own argument is written at its head), every such
+    block ends with a status or a CRC that does not match, and nothing is written outside the blocks' own output."""
+    from xenomapper_amd import _ffi
+    rng = np.random.default_rng(31)
+    members, sizes = [], []
+    good = deflate_raw(make_payload(rng, 1, 30000), 6, zlib.Z_DEFAULT_STRATEGY)
+    for k in range(600):
+        kind = k % 4
+        if kind == 0:
+            d = rng.integers(0, 256, int(rng.integers(1, 4000)), dtype=np.uint8).tobytes()
+        elif kind == 1:                                                                   # a dynamic-block header, then noise
+            d = bytes([0b101]) + rng.integers(0, 256, int(rng.integers(8, 3000)), dtype=np.uint8).tobytes()
+        elif kind == 2:
+            d = good[:int(rng.integers(1, len(good)))]                                    # cut short
+        else:
+            d = good
+        isize = int(rng.integers(0, 65537)) if kind != 3 else int(rng.choice([0, 1, 29999, 30001, 65536]))
+        members.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d +
+                       struct.pack("<II", 0xDEADBEEF, isize))
+        sizes.append(isize)
+    image = np.frombuffer(b"".join(members), dtype=np.uint8)
+    blocks, crc, nxt, total = _ffi.bgzf_index(image)
+    assert len(blocks) == 600 and nxt == image.shape[0] and total == sum(sizes)
+    out, status, got_crc = gpu_inflate(ctx, image, blocks, total)
+    assert (out[:64] == 0xEE).all() and (out[64 + total:] == 0xEE).all()
+    assert all(status[b] != 0 or got_crc[b] != 0xDEADBEEF for b in range(600) if sizes[b])
+    assert int((status != 0).sum()) > 400
+
+
 def test_empty_input_and_empty_blocks(ctx):
     from xenomapper_amd import _ffi
     eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
