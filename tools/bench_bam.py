@@ -90,14 +90,16 @@ def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False, single_e
                                                   "secondary_multi", "unassigned", "unresolved")}
     try:
         xm.default_context()
+        first = None
         for _warm in (True, False):
             t0 = time.perf_counter()
             counts = xm.classify_sam_files(paths[0], paths[1], paired=not single_end, n_threads=a.threads, bam=True,
                                            tag_func=xm.get_cigarbased_AS_tag if cigar_scores else xm.get_tag, **sinks)
             el = time.perf_counter() - t0
+            first = el if first is None else first
         units = sum(counts.values())
         return {"metric": "end-to-end %s/s (BAM in, six SAM files out)" % ("reads" if single_end else "read-pairs"), "value": units / el,
-                "plugin": "get_cigarbased_AS_tag" if cigar_scores else "get_tag", "units": units, "seconds": el, "bam_bytes": size, "bam_GBps": size / el / 1e9,
+                "plugin": "get_cigarbased_AS_tag" if cigar_scores else "get_tag", "units": units, "seconds": el, "first_run_seconds": first, "bam_bytes": size, "bam_GBps": size / el / 1e9,
                 "threads": a.threads or _host.lib().xmh_default_threads(),
                 "phases": {k: round(v, 4) for k, v in xm.LAST_FILE_PROFILE.items()}}
     finally:
