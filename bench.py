@@ -221,14 +221,9 @@ def e2e_h2d_inclusive(ctx, mode, host_cols, pairs, reps=3):
     try:
         idx_buf[0] = np.zeros(n, dtype=np.uint32)
         t0 = time.perf_counter()
-        for a in cols + [bits, idx_buf[0]]:
-            ctx.host_register(a)
-        reg = time.perf_counter() - t0
-        try:
+        with ctx.registered(*(cols + [bits, idx_buf[0]])):           # unlocks what it locked, also when locking stops half way
+            reg = time.perf_counter() - t0
             pinned, units = timed()
-        finally:
-            for a in cols + [bits, idx_buf[0]]:
-                ctx.host_unregister(a)
         out["registered_buffers"] = {"read_pairs_per_s": units / pinned, "GBps_over_pcie": moved / pinned / 1e9,
                                      "seconds": round(pinned, 4), "register_seconds_once": round(reg, 4),
                                      "what": "the same call with the five input arrays and the index output page-locked "

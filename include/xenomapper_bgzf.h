@@ -196,8 +196,10 @@ int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paire
  * line_off*[i] / line_len*[i] = where record i's line is and how long (without its '\n'; 0 / 0: no sink takes it).  Needs the
  * files' reference names (xm_bamdev_set_refs: the names back to back, at[n_refs + 1] positions; once per pair of files;
  * XM_ERR_INVALID_ARG without them).
- * status 0: the text is on its way (xm_bamdev_raw_wait); 1: a record holds a floating-point field (printf("%g") is the host
- * printer's), 2: more text than the slot's buffers hold -- nothing was copied then: ask for (b) and print on the host. */
+ * Floating-point fields of the specification's types (f, B:f) are printed as printf("%g") prints them (exact: csrc/xm_fmtg.h).
+ * status 0: the text is on its way (xm_bamdev_raw_wait); 1: a record of THIS window holds a binary64 field (type d: htslib
+ * accepts it, the specification does not have it; its "%g" is the host printer's), 2: more text than the slot's buffers hold --
+ * nothing was copied then: ask for (b) and print this window on the host; the next window may be printed here again. */
 typedef struct {
     const uint8_t  *text1, *text2;
     const uint32_t *line_off1, *line_off2, *line_len1, *line_len2;

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XM_ABI_VERSION 5
+#define XM_ABI_VERSION 6
 
 #define XM_ABSENT   INT32_MIN
 #define XM_NO_UNIT  0xFFu
@@ -187,6 +187,15 @@ int xm_mate_correlate(xm_ctx *ctx, uint64_t n, const double *track, uint64_t m, 
  */
 int xm_host_register(xm_ctx *ctx, void *ptr, size_t bytes);
 int xm_host_unregister(xm_ctx *ctx, void *ptr);
+/*
+ * The page-locked host memory this library holds right now, process-wide (ABI 6): `allocated` = what the front ends
+ * (xm_strip_*, xm_bamdev_*: staging windows, inflated copies, line tables, text) got from hipHostMalloc and have not given
+ * back, `registered` = caller memory locked through xm_host_register and not yet unregistered, `peak` = the largest sum of
+ * the two so far.  Any pointer may be NULL.  xm_strip_destroy / xm_bamdev_destroy give everything of theirs back; a process
+ * that keeps front ends alive between jobs (the Python package's process-wide ones: xenomapper_amd.xenomapper.
+ * release_buffers()) reads here what that costs.
+ */
+int xm_pinned_bytes(uint64_t *allocated, uint64_t *registered, uint64_t *peak);
 
 /* ---- device-resident entry points (asynchronous on `stream`) -------------------------- */
 /*

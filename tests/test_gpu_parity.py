@@ -672,18 +672,38 @@ def test_host_buffer_calls_from_registered_memory(ctx):
     bits = H.synth.pack_unit_bits(rng.random(n) < 0.55)
     want_code, want_counts = H.c_classify(1, *cols, bits, ABSENT)
     want_idx, want_off = H.c_compact(1, want_code)
-    for a in cols + [bits]:
-        ctx.host_register(a)
-    try:
+    from xenomapper_amd import _ffi
+    before = _ffi.pinned_bytes()["registered"]
+    with ctx.registered(*(cols + [bits])):
+        assert _ffi.pinned_bytes()["registered"] == before + sum(a.nbytes for a in cols + [bits])
         for _ in range(2):
             code, idx, off, counts = ctx.classify_compact(1, *cols, bits, ABSENT)
             assert np.array_equal(code, want_code) and np.array_equal(counts, want_counts)
             assert np.array_equal(off, want_off) and np.array_equal(idx, want_idx)
-    finally:
-        for a in cols + [bits]:
-            ctx.host_unregister(a)
+        with pytest.raises(ValueError):                               # a second registration of the same memory is refused
+            ctx.host_register(cols[0])
+    assert _ffi.pinned_bytes()["registered"] == before                # nothing stays locked behind the block
     code, idx, off, counts = ctx.classify_compact(1, *cols, bits, ABSENT)
     assert np.array_equal(code, want_code) and np.array_equal(idx, want_idx)
+    # locking fails half way (the third "array" is not memory the process owns): the two before it are unlocked again
+    with pytest.raises(Exception):
+        with ctx.registered(cols[0], cols[1], _FakeArray(0x10, 4096)):
+            pass
+    assert _ffi.pinned_bytes()["registered"] == before
+
+
+class _FakeArray(object):
+    """Quacks like a NumPy array for host_register: an address that is not mapped."""
+    def __init__(self, address, nbytes):
+        import ctypes
+
+        class _C(object):
+            data = address
+
+            @staticmethod
+            def data_as(_t):
+                return ctypes.c_void_p(address)
+        self.ctypes, self.nbytes = _C(), nbytes
 
 
 def test_classify_cigar_range_error(ctx):
@@ -1100,6 +1120,57 @@ def test_six_lists_in_chunks_equal_the_one_pass_lists(ctx, monkeypatch):
     _check_lists(lists, n_out.cpu().numpy(), want_idx, want_off)
     assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
     assert ctx.workspace_is_clean()
+
+
+def test_scatter_runs_of_granules_equal_one_granule_per_wave(ctx, monkeypatch):
+    """K2c's second launch shape (scatter_kernel MULTI: a wave places a RUN of consecutive granules, the per-bin places carried
+    from granule to granule) is what inputs beyond XM_SCATTER_WAVES granules take -- 2^31 records in the shipped build, which
+    no test reaches.  The environment variable of the same name lowers the wave count: with 7 and 100 waves a 1.2 M-record
+    input gives runs of 84 and 6 granules (the last run short, the last granule partial).  Packed output and six lists, every
+    loop, compact stream and category bytes, staged single-end granules beside unstaged ones: all equal to the oracle's
+    split, as the one-granule shape is, with guard words behind the lists."""
+    import torch
+    from xenomapper_amd import _ffi
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(777)
+    n = 1_200_003
+    guard = 0x7FFFFFF0
+    for mode, p_unit in ((1, None), (2, 0.55), (0, 1.0), (0, 0.8), (1, 0.3)):
+        cols = random_columns(rng, n)
+        if p_unit is None:
+            bits = H.synth.interleaved_unit_bits(n)
+        else:
+            flags = rng.random(n) < p_unit
+            if mode == 0 and p_unit < 1.0:
+                flags[: n // 2] = True                              # staged granules in front, unstaged ones behind
+            bits = H.synth.pack_unit_bits(flags)
+        want_code, want_counts = H.c_classify(mode, *cols, bits, -2)
+        want_idx, want_off = H.c_compact(mode, want_code)
+        d_cols = [torch.from_numpy(c).to(dev) for c in cols]
+        d_bits = torch.from_numpy(bits.view(np.int64)).to(dev)
+        for waves in ("7", "100", ""):
+            monkeypatch.setenv("XM_SCATTER_WAVES", waves)
+            for form in ("bins4", "code"):
+                code = torch.empty(n + 16, dtype=torch.uint8, device=dev) if form == "code" else None
+                bins4 = torch.empty(_ffi.bins4_bytes(n), dtype=torch.uint8, device=dev) if form == "bins4" else None
+                idx = torch.full((n + 8,), guard, dtype=torch.int32, device=dev)
+                off = torch.zeros(8, dtype=torch.int64, device=dev)
+                counts = torch.zeros(64, dtype=torch.int64, device=dev)
+                ctx.classify_compact_dev(mode, *d_cols, d_bits, -2, code, idx, off, counts, bins4=bins4)
+                torch.cuda.synchronize()
+                assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off), (mode, waves, form)
+                assert np.array_equal(counts.cpu().numpy().astype(np.uint64), want_counts)
+                assert np.array_equal(idx[:int(want_off[7])].cpu().numpy().view(np.uint32), want_idx), (mode, waves, form)
+                assert bool((idx[int(want_off[7]):] == guard).all())
+                lists = [torch.full((n + 8,), guard, dtype=torch.int32, device=dev) for _ in range(6)]
+                n_out = torch.zeros(8, dtype=torch.int64, device=dev)
+                counts.zero_()
+                ctx.classify_place_dev(mode, *d_cols, d_bits, -2, lists, n_out, counts, code_out=code, bins4=bins4, capacity=n)
+                torch.cuda.synchronize()
+                _check_lists(lists, n_out.cpu().numpy(), want_idx, want_off)
+                for b, lst in enumerate(lists):
+                    assert bool((lst[int(want_off[b + 1] - want_off[b]):] == guard).all()), (mode, waves, form, b)
+                assert ctx.workspace_is_clean()
 
 
 def test_two_streams_on_one_context_are_ordered_by_the_library(ctx):

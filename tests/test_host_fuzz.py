@@ -282,6 +282,39 @@ def test_record_printer_of_the_gpu_bam_path_prints_the_decoder_s_text(image, thr
         r.close()
 
 
+def test_sparse_printing_falls_back_to_two_passes_when_its_estimate_passes_4_gib():
+    """xmh_bam_print(sparse) reserves every thread's worst case (5 x record bytes + per record 128 + two reference names) and
+    addresses its text with 32 bits: a window whose ESTIMATE passes 4 GiB used to end in 'ValueError: xmh_bam_print' (ADVICE r5;
+    a large carried tail, XENOMAPPER_BAM_WINDOW_MB >= ~800).  Here the estimate is driven up by a 600 KB reference name that no
+    record uses: 4 000 records estimate 4.8 GB, their real text is 200 KB -- the binding prints in two passes instead, and the
+    lines are the oracle's."""
+    import gzip
+    from xenomapper_amd import _host
+    long_ref = "r" * 600_000
+    recs = []
+    for k in range(4_000):
+        name = ("q%05d" % k).encode() + b"\0"
+        body = struct.pack("<iiBBHHHIiii", 0, k, len(name), 30, 4680, 1, 0, 4, -1, -1, 0) + name + struct.pack("<I", (4 << 4)) + \
+            bytes([0x12, 0x48]) + bytes([30, 31, 32, 33]) + b"ASi" + struct.pack("<i", -k)
+        recs.append(struct.pack("<I", len(body)) + body)
+    image = _bam_image_of(recs, refs=("chr1", long_ref), aligned=True)
+    _header, want_lines = bam_oracle.bam_to_sam(image)
+    raw = np.frombuffer(gzip.decompress(image), dtype=np.uint8).copy()
+    r = _host.BamReader(np.frombuffer(image, dtype=np.uint8), 4, header_only=True)
+    try:
+        rec = np.empty(len(recs) + 8, dtype=np.uint32)
+        n, stop = _host.bam_walk(raw.ctypes.data, raw.shape[0], r.records_start(), rec)
+        assert n == len(recs) and stop == raw.shape[0]
+        loff, llen = np.empty(n + 1, dtype=np.uint32), np.empty(n + 1, dtype=np.uint32)
+        text = np.empty(1 << 20, dtype=np.uint8)
+        got = r.print_records(raw.ctypes.data, rec.ctypes.data, n, text, loff, llen, True, None)
+        assert 0 < got <= text.shape[0]
+        for k in (0, 1, n // 2, n - 1):
+            assert bytes(text[int(loff[k]):int(loff[k]) + int(llen[k])]) == want_lines[k].encode("latin-1")
+    finally:
+        r.close()
+
+
 # ---- BAM line descriptions (xmh_bam_read_pre / xmh_parse_pre) against the text rules ------------------------------------
 
 _SCORE_TAGS = st.sampled_from(["AS", "XS", "ZS", "NM", "AS", "XS", "YS", "XA", "SA", "MN", "NH"])

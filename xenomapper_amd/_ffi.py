@@ -6,10 +6,13 @@ host-buffer entry points, torch device tensors through the *_dev entry points.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import functools
 import importlib.util
 import os
 import sys
+import threading
 import weakref
 
 import numpy as np
@@ -110,6 +113,7 @@ def lib():
         "xm_classify_compact_cigar_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P], I),
         "xm_host_register": ([P, P, ctypes.c_size_t], I),
         "xm_host_unregister": ([P, P], I),
+        "xm_pinned_bytes": ([P, P, P], I),
         "xm_cigar_pack": ([U64, P, P, P, P, P, U64, ctypes.POINTER(U64)], I),
         "xm_classify_compact_cigar_packed_dev": ([P, P, I, U64, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P], I),
         "xm_classify_place": ([P, I, U64, P, P, P, P, P, I32, P, P, U64, P, P], I),
@@ -180,7 +184,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_ctx_device_info", "xm_classify", "xm_classify_f64", "xm_cigar_scores", "xm_classify_cigar",
             "xm_compact", "xm_classify_compact", "xm_classify_compact_f64", "xm_classify_compact_cigar", "xm_mate_correlate", "xm_mate_correlate_dev", "xm_classify_dev", "xm_classify_f64_dev", "xm_classify_cigar_dev", "xm_cigar_scores_dev",
             "xm_compact_dev", "xm_classify_compact_dev", "xm_classify_compact_f64_dev", "xm_classify_compact_cigar_dev",
-            "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister",
+            "xm_cigar_pack", "xm_classify_compact_cigar_packed_dev", "xm_host_register", "xm_host_unregister", "xm_pinned_bytes",
             "xm_classify_place", "xm_classify_place_f64", "xm_classify_place_dev", "xm_classify_place_f64_dev",
             "xm_classify_place_cigar_packed_dev", "xm_classify_runs_dev", "xm_classify_runs_f64_dev", "xm_runs_expand",
             "xm_stream_probe_dev", "xm_workspace_is_clean", "xm_workspace_release",
@@ -195,6 +199,14 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
 
 def _np_ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def pinned_bytes():
+    """xm_pinned_bytes: {"allocated": page-locked bytes the front ends hold, "registered": caller memory locked through
+    host_register, "peak": the largest sum so far} -- process-wide."""
+    a, r, pk = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    lib().xm_pinned_bytes(ctypes.byref(a), ctypes.byref(r), ctypes.byref(pk))
+    return {"allocated": int(a.value), "registered": int(r.value), "peak": int(pk.value)}
 
 
 def _as(a, dtype):
@@ -266,6 +278,20 @@ def comm_unique_id():
     return buf.raw
 
 
+def _one_call_per_context(method):
+    """include/xenomapper_hip.h allows ONE call in flight per context (the compaction workspace -- granule counts, part totals,
+    count replicas, the stream it was last used on -- belongs to the context and has no lock of its own in C).  The file path
+    runs two threads on the process-wide context (the helper thread's fused pass behind the GPU front end of window k + 1 beside
+    the main thread settling window k, which classifies again when the window had exception records), so every Python entry
+    point that launches on the workspace takes the context's lock for the length of the C call."""
+    @functools.wraps(method)
+    def locked(self, *args, **kwargs):
+        ctx = self if isinstance(self, Context) else self.ctx
+        with ctx.call_lock:
+            return method(self, *args, **kwargs)
+    return locked
+
+
 class Context(object):
     """One classifier context on one GPU (xm_ctx)."""
 
@@ -280,11 +306,18 @@ class Context(object):
         self._h = h
         self.device = int(device)
         self._strippers = weakref.WeakSet()       # closed with the context: xm_strip_destroy hands its streams back to it
+        self.call_lock = threading.RLock()        # one workspace call at a time (_one_call_per_context)
+        self._registered = {}                     # address -> array page-locked through host_register
 
     def close(self):
         if getattr(self, "_h", None):
             for st in list(getattr(self, "_strippers", ())):
                 st.close()
+            for array in list(getattr(self, "_registered", {}).values()):
+                try:
+                    self.host_unregister(array)
+                except Exception:                                    # noqa: BLE001 -- closing goes on
+                    pass
             self._L.xm_ctx_destroy(self._h)
             self._h = None
 
@@ -311,13 +344,31 @@ class Context(object):
 
     def host_register(self, array):
         """Page-lock a NumPy array that will be handed to the host-buffer calls repeatedly (direct DMA instead of the
-        runtime's staging copies).  Call host_unregister(array) before the array is freed."""
+        runtime's staging copies).  Call host_unregister(array) before the array is freed; the context keeps the array alive
+        until then, and close() unregisters what is left -- pages of memory that NumPy has given back to the allocator must
+        not stay locked under whoever gets the address next.  `with ctx.registered(a, b, ...)` does both ends."""
         rc = self._L.xm_host_register(self._h, _np_ptr(array), array.nbytes)
         self._check(rc, "xm_host_register")
+        self._registered[array.ctypes.data] = array
 
     def host_unregister(self, array):
         rc = self._L.xm_host_unregister(self._h, _np_ptr(array))
         self._check(rc, "xm_host_unregister")
+        self._registered.pop(array.ctypes.data, None)
+
+    @contextlib.contextmanager
+    def registered(self, *arrays):
+        """Page-lock the arrays for the length of the block; whatever was locked when the block ends (or when locking one of
+        them fails half way) is unlocked again."""
+        done = []
+        try:
+            for a in arrays:
+                self.host_register(a)
+                done.append(a)
+            yield
+        finally:
+            for a in done:
+                self.host_unregister(a)
 
     def device_info(self):
         n_cu = ctypes.c_int()
@@ -326,6 +377,7 @@ class Context(object):
         return {"n_cu": n_cu.value, "name": buf.value.decode()}
 
     # ---- host-buffer entry points (NumPy) --------------------------------------------------
+    @_one_call_per_context
     def classify(self, mode, as1, xs1, as2, xs2, unit_bits, min_score_floor):
         cols = [_as(c, np.int32) for c in (as1, xs1, as2, xs2)]
         n = cols[0].shape[0]
@@ -338,6 +390,7 @@ class Context(object):
         self._check(rc, "xm_classify")
         return code, counts
 
+    @_one_call_per_context
     def classify_f64(self, mode, as1, xs1, as2, xs2, unit_bits, min_score):
         cols = [_as(c, np.float64) for c in (as1, xs1, as2, xs2)]
         n = cols[0].shape[0]
@@ -363,6 +416,7 @@ class Context(object):
         self._check(rc, "xm_cigar_scores")
         return out
 
+    @_one_call_per_context
     def classify_cigar(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor):
         """The --cigar_scores path: AS from NM + CIGAR inside the classify kernel."""
         a = [_as(nm1, np.int32), _as(off1, np.uint32), _as(ops1, np.uint32), _as(xs1, np.int32),
@@ -380,6 +434,7 @@ class Context(object):
         self._check(rc, "xm_classify_cigar")
         return code, counts
 
+    @_one_call_per_context
     def compact(self, mode, code):
         code = _as(code, np.uint8)
         n = code.shape[0]
@@ -390,6 +445,7 @@ class Context(object):
         self._check(rc, "xm_compact")
         return idx[:int(off[7])], off, counts
 
+    @_one_call_per_context
     def classify_compact(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, want_code=True, idx_out=None):
         """One fused pass: classify + count + stable split.  Columns int32 (min_score = int floor) or float64
         (min_score = float).  -> (code or None, idx, bin_offsets[8], counts[64]).  idx_out: a uint32 array of at least
@@ -414,6 +470,7 @@ class Context(object):
         self._check(rc, "xm_classify_compact")
         return code, idx[:int(off[7])], off, counts
 
+    @_one_call_per_context
     def classify_compact_cigar(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
                                want_code=True):
         a = [_as(nm1, np.int32), _as(off1, np.uint32), _as(ops1, np.uint32), _as(xs1, np.int32),
@@ -434,6 +491,7 @@ class Context(object):
         self._check(rc, "xm_classify_compact_cigar")
         return code, idx[:int(off[7])], off, counts
 
+    @_one_call_per_context
     def classify_place(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, want_code=True, capacity=None):
         """One main loop, six lists out (xm_classify_place / _f64: SURVEY 8b (4)).  -> (code or None, lists, n_out[8],
         counts[64]); lists = six uint32 arrays (seven for float64 columns: the last holds the units with state 6)."""
@@ -484,6 +542,7 @@ class Context(object):
             return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         return ctypes.c_void_p(getattr(stream, "cuda_stream", stream))
 
+    @_one_call_per_context
     def classify_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, code_out, stream=None):
         """Columns int32 (min_score = int floor) or float64 (min_score = float).  Asynchronous."""
         n = as1.numel()
@@ -497,6 +556,7 @@ class Context(object):
                                              ctypes.c_void_p(code_out.data_ptr()))
         self._check(rc, "xm_classify_dev")
 
+    @_one_call_per_context
     def classify_cigar_dev(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
                            code_out, range_flag=None, stream=None):
         ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits)]
@@ -514,6 +574,7 @@ class Context(object):
             ctypes.c_void_p(range_flag.data_ptr()) if range_flag is not None else None)
         self._check(rc, "xm_cigar_scores_dev")
 
+    @_one_call_per_context
     def compact_dev(self, mode, code, idx_out, bin_offsets, counts, stream=None):
         rc = self._L.xm_compact_dev(
             self._h, self._stream_handle(stream), mode, code.numel(), ctypes.c_void_p(code.data_ptr()),
@@ -521,6 +582,7 @@ class Context(object):
             ctypes.c_void_p(counts.data_ptr()))
         self._check(rc, "xm_compact_dev")
 
+    @_one_call_per_context
     def classify_compact_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, code_out, idx_out, bin_offsets,
                              counts, bins4=None, stream=None):
         """The fused main loop on device-resident columns (int32 or float64): classify + count in one kernel, then
@@ -536,6 +598,7 @@ class Context(object):
             rc = self._L.xm_classify_compact_f64_dev(self._h, st, mode, n, *ptrs, float(min_score), *outs)
         self._check(rc, "xm_classify_compact_dev")
 
+    @_one_call_per_context
     def classify_compact_cigar_dev(self, mode, nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits, min_score_floor,
                                    code_out, idx_out, bin_offsets, counts, range_flag=None, stream=None):
         ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (nm1, off1, ops1, xs1, nm2, off2, ops2, xs2, unit_bits)]
@@ -547,6 +610,7 @@ class Context(object):
             ctypes.c_void_p(counts.data_ptr()))
         self._check(rc, "xm_classify_compact_cigar_dev")
 
+    @_one_call_per_context
     def classify_compact_cigar_packed_dev(self, mode, nm1, cnt1, tile1, ops1, xs1, nm2, cnt2, tile2, ops2, xs2, unit_bits,
                                           min_score_floor, code_out, idx_out, bin_offsets, counts, bins4=None,
                                           range_flag=None, stream=None):
@@ -559,6 +623,7 @@ class Context(object):
             opt(range_flag), opt(idx_out), opt(bin_offsets), opt(counts))
         self._check(rc, "xm_classify_compact_cigar_packed_dev")
 
+    @_one_call_per_context
     def classify_place_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, lists, n_out, counts, code_out=None,
                            bins4=None, list_state6=None, capacity=None, stream=None):
         """The fused main loop with the six-list output contract: `lists` = six uint32 device tensors,
@@ -579,6 +644,7 @@ class Context(object):
                                                    opt(list_state6), cap, opt(n_out), opt(counts))
         self._check(rc, "xm_classify_place_dev")
 
+    @_one_call_per_context
     def classify_place_cigar_packed_dev(self, mode, nm1, cnt1, tile1, ops1, xs1, nm2, cnt2, tile2, ops2, xs2, unit_bits,
                                         min_score_floor, lists, n_out, counts, code_out=None, bins4=None, range_flag=None,
                                         capacity=None, stream=None):
@@ -592,6 +658,7 @@ class Context(object):
             opt(range_flag), arr, cap, opt(n_out), opt(counts))
         self._check(rc, "xm_classify_place_cigar_packed_dev")
 
+    @_one_call_per_context
     def classify_runs_dev(self, mode, as1, xs1, as2, xs2, unit_bits, min_score, runs16, gran_counts, n_out, counts, stream=None):
         """The fused main loop with SEGMENTED bin lists, one launch (xm_classify_runs*_dev): runs16 = int16 device tensor of
         runs_granules(n) * 2048 entries, gran_counts = int16 device tensor of runs_granules(n) * 8, n_out 8 x int64,
@@ -628,10 +695,12 @@ class Context(object):
                                        ctypes.c_void_p(blocks.data_ptr()), n, ctypes.c_void_p(crc_out.data_ptr()))
         self._check(rc, "xm_bgzf_crc32_dev")
 
+    @_one_call_per_context
     def workspace_release(self, stream):
         """Call before destroying a stream the compaction calls were issued on while this context lives on."""
         self._check(self._L.xm_workspace_release(self._h, self._stream_handle(stream)), "xm_workspace_release")
 
+    @_one_call_per_context
     def workspace_is_clean(self):
         """Synchronises; True when the counting workspace is in its between-calls state (all zero)."""
         flag = ctypes.c_int(0)
@@ -856,6 +925,7 @@ class Stripper(object):
         self._check(rc, "xm_strip_run")
         return StrippedBlock(self, slot, raw)
 
+    @_one_call_per_context
     def classify(self, slot, mode, n_records, min_score_floor):
         """The fused pass on the slot's device columns -> (code, idx, bin_offsets, counts); code / idx are views of
         page-locked arrays, valid until the next classify on the slot."""
@@ -1061,7 +1131,7 @@ class BamDev(object):
     def fetch_text(self, slot, n_records, paired, sink_mask):
         """After classify(): the SAM text of the records a sink takes, printed on the device (xm_bamdev_fetch_text) ->
         (status, (text1, text2 uint8 views), (line_off1, line_off2), (line_len1, line_len2)); status 0: on its way, complete after
-        raw_wait; 1 / 2: the host has to print this window (a floating-point field / more text than the buffers hold)."""
+        raw_wait; 1 / 2: the host has to print this window (a binary64 field / more text than the buffers hold)."""
         t = _BamDevLines()
         rc = self._L.xm_bamdev_fetch_text(self._h, int(slot), int(n_records), int(bool(paired)), int(sink_mask), ctypes.byref(t))
         self._check(rc, "xm_bamdev_fetch_text")
@@ -1079,6 +1149,7 @@ class BamDev(object):
     def raw_wait(self, slot):
         self._check(self._L.xm_bamdev_raw_wait(self._h, int(slot)), "xm_bamdev_raw_wait")
 
+    @_one_call_per_context
     def classify(self, slot, mode, n_records, min_score_floor):
         code, idx = ctypes.c_void_p(), ctypes.c_void_p()
         off = np.zeros(8, dtype=np.uint64)

@@ -314,6 +314,11 @@ class BamReader(object):
         rc = self._L.xmh_bam_print(self._h, _P(raw_address), _P(rec_off_address), int(n),
                                    wanted.ctypes.data_as(_P) if wanted is not None else None, out.ctypes.data_as(_P), out.shape[0],
                                    line_off.ctypes.data_as(_P), line_len.ctypes.data_as(_P), int(bool(sparse)), ctypes.byref(w))
+        if rc == -1 and sparse and w.value > 0xFFFFFFFF:
+            # the one-pass form reserves every thread's WORST case (five times the record bytes) and its line table is 32-bit: a
+            # window whose estimate passes 4 GiB (a large carried tail, XENOMAPPER_BAM_WINDOW_MB >= ~800) is printed in two
+            # passes instead, which needs the real size only
+            return self.print_records(raw_address, rec_off_address, n, out, line_off, line_len, False, wanted)
         if rc == -1 and w.value > out.shape[0]:
             return -int(w.value)
         if rc != 0:

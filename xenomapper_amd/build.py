@@ -36,13 +36,36 @@ def _stale(target, sources):
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, "xm_kernels.h"), os.path.join(CSRC, "xm_inflate_core.h"),
+                   os.path.join(CSRC, "xm_bamrec.h"), os.path.join(CSRC, "xm_fmtg.h"), os.path.join(CSRC, "xm_pinned.h"),
                    os.path.join(REPO, "include", "xenomapper_hip.h"), os.path.join(REPO, "include", "xenomapper_strip.h"),
                    os.path.join(REPO, "include", "xenomapper_bgzf.h")]
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB
     # XENOMAPPER_HIPCC_FLAGS: extra flags for tuning builds (e.g. -DXM_CIGAR_BLOCK=256); not used by the tests
-    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-           "-I", os.path.join(REPO, "include")] + os.environ.get("XENOMAPPER_HIPCC_FLAGS", "").split() + srcs + ["-o", HIP_LIB]
+    # One object per source, compiled side by side (the five translation units share no device code), objects kept under
+    # build/obj and reused while neither their source nor any header is newer; then one link.
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-I", os.path.join(REPO, "include")] + \
+        os.environ.get("XENOMAPPER_HIPCC_FLAGS", "").split()
+    obj_dir = os.path.join(REPO, "build", "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    tag = os.path.join(obj_dir, "flags.txt")
+    same_flags = os.path.exists(tag) and open(tag).read() == " ".join(flags)
+    headers = deps[len(srcs):]
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not same_flags or _stale(obj, [src] + headers):
+            cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    with open(tag, "w") as fh:
+        fh.write(" ".join(flags))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>          // types only: the library is looked up at run time (xm_comm_init), not linked
 
 #include "xm_kernels.h"
+#include "xm_pinned.h"
 
 struct TimedSpan {
     int kernel;
@@ -62,6 +63,7 @@ int fail_hip(xm_ctx *ctx, hipError_t e, const char *what)
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
     if (ctx) ctx->last_error = buf;
     else g_create_error = buf;
+    (void)hipGetLastError();        // reported here: the next check_launch() on this thread must not find it again
     return (e == hipErrorOutOfMemory) ? XM_ERR_OOM : XM_ERR_HIP;
 }
 
@@ -1255,8 +1257,10 @@ int xm_classify_place_f64(xm_ctx *ctx, int mode, uint64_t n,
 int xm_host_register(xm_ctx *ctx, void *ptr, size_t bytes)
 {
     if (!ctx || !ptr || !bytes) return XM_ERR_INVALID_ARG;
+    if (xmpin::is_registered(ptr)) return XM_ERR_INVALID_ARG;             // twice: the second unregister would leave the first's pages locked
     XM_HIP(ctx, hipSetDevice(ctx->device));
     XM_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    xmpin::note_registered(ptr, bytes);
     return XM_OK;
 }
 
@@ -1265,6 +1269,17 @@ int xm_host_unregister(xm_ctx *ctx, void *ptr)
     if (!ctx || !ptr) return XM_ERR_INVALID_ARG;
     XM_HIP(ctx, hipSetDevice(ctx->device));
     XM_HIP(ctx, hipHostUnregister(ptr));
+    xmpin::note_unregistered(ptr);
+    return XM_OK;
+}
+
+int xm_pinned_bytes(uint64_t *allocated, uint64_t *registered, uint64_t *peak)
+{
+    xmpin::Book &b = xmpin::book();
+    std::lock_guard<std::mutex> hold(b.lock);
+    if (allocated) *allocated = b.allocated_bytes;
+    if (registered) *registered = b.registered_bytes;
+    if (peak) *peak = b.peak_bytes;
     return XM_OK;
 }
 

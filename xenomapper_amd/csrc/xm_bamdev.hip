@@ -36,6 +36,8 @@
 
 #include "../../include/xenomapper_bgzf.h"
 #include "xm_bamrec.h"
+#include "xm_fmtg.h"
+#include "xm_pinned.h"
 
 namespace {
 
@@ -269,9 +271,10 @@ pack_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ rec_of
 // What `samtools view` prints for an alignment record (the reference reads BAM through it: getBamReadPairs / bam_lines,
 // /root/reference/xenomapper/xenomapper.py:56-93), restated as csrc/xm_bam.cpp's format_record restates it for the host -- the two are
 // compared byte for byte in tests/test_bam_gpu.py.  One lane prints one record, twice: first into a sink that only counts (T1; the
-// size scan of W2 places the lines), then into the text (T2).  Fields with a floating-point value (types f, d, B:f) are not
-// printed here: such a record raises a flag and the host printer takes the window, as it does for every window the device does
-// not vouch for (a CIGAR in a CG:B,I field: `weird`).
+// size scan of W2 places the lines), then into the text (T2).  Floating-point fields of the specification's types (f, B:f) are
+// printed as printf("%g") prints them, exactly (xm_fmtg.h, round 6); a binary64 field (type d, which the specification does not
+// have and htslib accepts) raises a flag and the host printer takes THAT window, as it does for every window the device does not
+// vouch for (a CIGAR in a CG:B,I field: `weird`).
 struct RefTable {
     const uint8_t *names;        // the reference names back to back
     const uint32_t *at;          // n + 1 positions in `names`
@@ -376,7 +379,13 @@ template <typename S> __device__ __forceinline__ bool put_scalar(S &s, const uin
     case 'S': put_u32(s, ld16(r + p)); p += 2u; return true;
     case 'i': put_i32(s, (int32_t)ld32(r + p)); p += 4u; return true;
     case 'I': put_u32(s, ld32(r + p)); p += 4u; return true;
-    default: return false;
+    case 'f': {                                  // printf("%g") of the value, exact (xm_fmtg.h)
+        const xmfmt::Text16 t = xmfmt::fmt_g_f32(ld32(r + p));
+        for (uint32_t k = 0; k < t.n; ++k) s.ch(t.at(k));
+        p += 4u;
+        return true;
+    }
+    default: return false;                       // d (binary64; not a type of the BAM specification, htslib accepts it): the host
     }
 }
 
@@ -426,6 +435,7 @@ template <typename S> __device__ bool sam_line(const uint8_t *__restrict__ raw, 
         p += 3u;
         if (type == 'A') { s.ch('A'); s.ch(':'); put_scalar(s, r, p, 'A'); }
         else if (type == 'c' || type == 'C' || type == 's' || type == 'S' || type == 'i' || type == 'I') { s.ch('i'); s.ch(':'); put_scalar(s, r, p, type); }
+        else if (type == 'f') { s.ch('f'); s.ch(':'); put_scalar(s, r, p, 'f'); }
         else if (type == 'Z' || type == 'H') {
             s.ch(type); s.ch(':');
             uint32_t l = 0;
@@ -437,7 +447,7 @@ template <typename S> __device__ bool sam_line(const uint8_t *__restrict__ raw, 
             p += 5u;
             s.ch('B'); s.ch(':'); s.ch(sub);
             for (uint32_t k = 0; k < cnt; ++k) { s.ch(','); if (!put_scalar(s, r, p, sub)) return false; }
-        } else return false;                                                 // f, d: the host prints what printf("%g") would
+        } else return false;                                                 // d: the host prints what printf("%g") would
     }
     s.ch('\n');
     return true;
@@ -704,6 +714,7 @@ int fail(xm_bamdev *b, hipError_t e, const char *what)
         std::lock_guard<std::mutex> hold(b->error_lock);
         b->last_error = buf;
     }
+    (void)hipGetLastError();        // reported here: a later launch check on this thread must not find it again
     return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
 }
 
@@ -719,7 +730,7 @@ int fail(xm_bamdev *b, hipError_t e, const char *what)
     } while (0)
 
 template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
-template <typename T> void hfree(T *&p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+template <typename T> void hfree(T *&p) { if (p) { (void)xmpin::host_free(p); p = nullptr; } }
 template <typename T> int dalloc(xm_bamdev *b, T *&p, size_t count)
 {
     dfree(p);
@@ -729,7 +740,7 @@ template <typename T> int dalloc(xm_bamdev *b, T *&p, size_t count)
 template <typename T> int halloc(xm_bamdev *b, T *&p, size_t count)
 {
     hfree(p);
-    XMB_HIP(b, hipHostMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T), hipHostMallocDefault));
+    XMB_HIP(b, xmpin::host_malloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T)));
     return XM_OK;
 }
 
@@ -858,14 +869,14 @@ int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.up_stream, hipStreamNonBlocking);
         for (int f = 0; f < 2 && e == hipSuccess; ++f) e = hipEventCreateWithFlags(&sl.ev_up[f], hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, 16 * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_state, 16 * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_state, 16 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off_counts, 72 * sizeof(uint64_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_off_counts, 72 * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_work, 16 * sizeof(uint32_t));
         for (int f = 0; f < 2 && e == hipSuccess; ++f) {
             PerFile &q = sl.pf[f];
             e = hipMalloc((void **)&q.d_summary, 16 * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipHostMalloc((void **)&q.h_summary, 16 * sizeof(uint32_t), hipHostMallocDefault);
+            if (e == hipSuccess) e = xmpin::host_malloc((void **)&q.h_summary, 16 * sizeof(uint32_t));
         }
     }
     if (e != hipSuccess) {
@@ -1430,7 +1441,7 @@ int xm_bamdev_fetch_text(xm_bamdev *b, int slot, uint64_t n_records, int paired,
     XMB_HIP(b, hipEventSynchronize(sl.ev_wait));
     if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
     out->bytes1 = sl.h_state[8]; out->bytes2 = sl.h_state[9];
-    if (sl.h_state[13] != 0u) { out->status = 1; return XM_OK; }            // a field the host prints (floating point)
+    if (sl.h_state[13] != 0u) { out->status = 1; return XM_OK; }            // a field the host prints (binary64)
     if (out->bytes1 > text_cap || out->bytes2 > text_cap) { out->status = 2; return XM_OK; }     // more text than the buffers hold
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];

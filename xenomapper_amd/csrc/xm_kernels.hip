@@ -18,6 +18,7 @@
 //   get_cigarbased_AS_tag :228-256.  The oracle (oracle/) is the checker; nothing here calls it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "xm_kernels.h"
 
@@ -736,12 +737,15 @@ __device__ __forceinline__ void scatter_granule(const uint32_t w[NSUB], const ui
 // costs them 2 us per 50 M pairs)
 // LISTS: the six-list output contract -- bin b's units go to lo.p[b] (positions count from the start of that list, so the
 // totals of the bins in front are not needed), bin_offsets receives the list lengths ([7] = all units).
-// Launch shape: a wave owns a RUN of `gran_per_wave` consecutive granules (the per-bin places carry over from granule to
-// granule in scalar registers: the scatter leaves base[b] advanced by the granule's units of bin b, so the scan's offsets
-// are read for the wave's first granule only).  Round 5 tried long-lived waves (a dense dword fill gains 4.1 -> 6.0 TB/s from
-// exactly that, tools/probe_streams.hip w) and measured the opposite for this kernel -- XM_SCATTER_WAVES in xm_kernels.h has
-// the numbers -- so gran_per_wave is 1 unless the input has more than 2^20 granules.
-template <int NSUB, bool WIDE, bool NIB, bool STAGE, bool LISTS>
+// Launch shape: one granule per wave (MULTI = false, what every input up to 2^20 granules runs: the body below is the
+// round-4 kernel, whose loads of the granule's counts and of its categories are in flight together and which has no loop
+// state to carry).  MULTI: a wave owns a RUN of `gran_per_wave` consecutive granules (the per-bin places carry over from
+// granule to granule in scalar registers: the scatter leaves base[b] advanced by the granule's units of bin b, so the scan's
+// offsets are read for the wave's first granule only).  Round 5 tried long-lived waves for every input (a dense dword fill
+// gains 4.1 -> 6.0 TB/s from exactly that, tools/probe_streams.hip w) and measured the opposite for this kernel --
+// XM_SCATTER_WAVES in xm_kernels.h has the numbers -- and compiling the one-granule case through the loop cost the staged
+// single-end form 13 % (133.7 against 118.6 us per 100 M reads, profiles/r05_se_kernel_stats.csv): hence the template flag.
+template <int NSUB, bool WIDE, bool NIB, bool STAGE, bool LISTS, bool MULTI>
 __global__ void __launch_bounds__(XM_BLOCK)
 scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t n_gran, uint32_t gran_stride,
                const uint32_t *__restrict__ gran_counts, const uint32_t *__restrict__ gran_off,
@@ -762,9 +766,8 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
             part_tot[(i / n_parts) * XM_PART_STRIDE + i % n_parts] = 0u;
     }
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t g0 = g_first + (blockIdx.x * (XM_BLOCK / 64) + wave) * gran_per_wave;
+    const uint32_t g0 = g_first + (blockIdx.x * (XM_BLOCK / 64) + wave) * (MULTI ? gran_per_wave : 1u);
     if (g0 >= n_gran) return;                                             // wave-uniform; no barrier in this kernel
-    const uint32_t g1 = g0 + gran_per_wave < n_gran ? g0 + gran_per_wave : n_gran;
     uint8_t *lut = lut_all[NIB ? 0 : wave];
     if (!NIB) lut[lane] = (uint8_t)bin_of_code(mode, lane == 63u ? XM_NO_UNIT : lane);
     uint64_t *lptr = lptr_all[LISTS ? wave : 0];
@@ -782,9 +785,6 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
         if (g0 == g_first && last && lane < 8u) bin_offsets[lane] = (LISTS && lane < 7u) ? tot : bin_start;
     }
     uint16_t *slab = slab_all[CAN_STAGE ? wave : 0];
-    uint32_t base[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
 
     auto load_granule = [&](uint32_t g, uint32_t w[NSUB]) {
         const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
@@ -801,42 +801,78 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
             for (int s = 0; s < NSUB; ++s) w[s] = load_codes4_tail(code, rec_g + s * 256u + lane * 4u, n);
         }
     };
+    // Staging pays where a granule holds many units (single-end input: 2048 of them; 117 against 166 us per 100 M reads)
+    // and costs where it holds few (strictly interleaved mates, 1024: 62 against 55 us): decided per launch (STAGE) and
+    // then per granule from its unit count (what the counting side reported).
+    // lane b < 7 lays out bin b's region of the slab: room for its units rounded up to 4, + 4, regions back to back;
+    // the run starts (its place in idx_out) mod 4 words into its region, so that 16-byte-aligned places of idx_out
+    // are 8-byte-aligned places of the slab; never past the number of units, never past the slab, whatever the counts hold
+    auto slab_layout = [&](uint32_t cnt_g, uint32_t &run_start, uint32_t &run_len) -> bool {
+        const uint32_t room = (lane < 7u) ? ((cnt_g + 3u) & ~3u) + 4u : 0u;
+        const uint32_t incl_room = wave_scan_incl(room), incl_cnt = wave_scan_incl(cnt_g);
+        run_start = incl_room - room + (lane_base & 3u);
+        const uint32_t cnt = lane_base < n_units ? (cnt_g < n_units - lane_base ? cnt_g : n_units - lane_base) : 0u;
+        run_len = run_start < (uint32_t)XM_SLAB_U16 ? (cnt < XM_SLAB_U16 - run_start ? cnt : XM_SLAB_U16 - run_start) : 0u;
+        return lane_value(incl_cnt, 6) >= (uint32_t)XM_STAGE_MIN_UNITS;
+    };
+    auto copy_runs_out = [&](uint32_t run_start, uint32_t run_len, uint32_t rec_g) {
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const uint32_t N = lane_value(run_len, b);
+            uint32_t *__restrict__ dst = LISTS ? lo.p[b] : idx_out;
+            if (N == 0u || dst == nullptr) continue;                      // wave-uniform
+            scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, rec_g, dst);
+        }
+    };
+
+    if (!MULTI) {
+        const uint32_t g = g0;
+        uint32_t run_start = 0, run_len = 0;
+        bool staged = false;
+        if (CAN_STAGE) {
+            const uint32_t cnt_g = (lane < 7u) ? gran_counts[(uint64_t)lane * gran_stride + g] : 0u;
+            staged = slab_layout(cnt_g, run_start, run_len);
+        }
+        uint32_t base[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) base[b] = lane_value(staged ? run_start : lane_base, b);
+        const uint32_t rec_g = (uint32_t)((uint64_t)g * (NSUB * 256u));
+        uint32_t w[NSUB];
+        load_granule(g, w);
+        if (!NIB || LISTS) lds_settle();
+        if (CAN_STAGE && staged) {
+            scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, rec_g, base, idx_out, n_units, slab, lptr);
+            lds_settle();                                                 // the wave's slab is complete
+            copy_runs_out(run_start, run_len, rec_g);
+        } else {
+            scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, rec_g, base, idx_out, n_units, slab, lptr);
+        }
+        return;
+    }
+
+    const uint32_t g1 = g0 + gran_per_wave < n_gran ? g0 + gran_per_wave : n_gran;
+    uint32_t base[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
     uint32_t w[NSUB], wn[NSUB];
     load_granule(g0, w);
     if (!NIB || LISTS) lds_settle();
     for (uint32_t g = g0; g < g1; ++g) {
         if (g + 1u < g1) load_granule(g + 1u, wn);                        // in flight while this granule is placed
-        const uint64_t rec_g = (uint64_t)g * (NSUB * 256u);
-        // Staging pays where a granule holds many units (single-end input: 2048 of them; 117 against 166 us per 100 M reads)
-        // and costs where it holds few (strictly interleaved mates, 1024: 62 against 55 us): decided per launch (STAGE) and
-        // then per granule from its unit count (what the counting side reported).
+        const uint32_t rec_g = (uint32_t)((uint64_t)g * (NSUB * 256u));
         bool staged = false;
         uint32_t cnt_g = 0;
         if (CAN_STAGE) {
-            // lane b < 7 lays out bin b's region of the slab: room for its units rounded up to 4, + 4, regions back to back;
-            // the run starts (its place in idx_out) mod 4 words into its region, so that 16-byte-aligned places of idx_out
-            // are 8-byte-aligned places of the slab
             cnt_g = (lane < 7u) ? gran_counts[(uint64_t)lane * gran_stride + g] : 0u;
-            const uint32_t room = (lane < 7u) ? ((cnt_g + 3u) & ~3u) + 4u : 0u;
-            const uint32_t incl_room = wave_scan_incl(room), incl_cnt = wave_scan_incl(cnt_g);
-            staged = lane_value(incl_cnt, 6) >= (uint32_t)XM_STAGE_MIN_UNITS;
+            uint32_t run_start, run_len;
+            staged = slab_layout(cnt_g, run_start, run_len);
             if (staged) {
-                const uint32_t run_start = incl_room - room + (lane_base & 3u);
-                // never past the number of units, never past the slab, whatever the counts hold
-                const uint32_t cnt = lane_base < n_units ? (cnt_g < n_units - lane_base ? cnt_g : n_units - lane_base) : 0u;
-                const uint32_t run_len = run_start < (uint32_t)XM_SLAB_U16 ? (cnt < XM_SLAB_U16 - run_start ? cnt : XM_SLAB_U16 - run_start) : 0u;
                 uint32_t sbase[7];
 #pragma unroll
                 for (int b = 0; b < 7; ++b) sbase[b] = lane_value(run_start, b);
-                scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, (uint32_t)rec_g, sbase, idx_out, n_units, slab, lptr);
+                scatter_granule<NSUB, WIDE, NIB, true, LISTS>(w, lut, rec_g, sbase, idx_out, n_units, slab, lptr);
                 lds_settle();                                             // the wave's slab is complete
-#pragma unroll
-                for (int b = 0; b < 7; ++b) {
-                    const uint32_t N = lane_value(run_len, b);
-                    uint32_t *__restrict__ dst = LISTS ? lo.p[b] : idx_out;
-                    if (N == 0u || dst == nullptr) continue;              // wave-uniform
-                    scatter_copy_out<WIDE>(slab, lane_value(run_start, b), lane_value(lane_base, b), N, (uint32_t)rec_g, dst);
-                }
+                copy_runs_out(run_start, run_len, rec_g);
                 lds_settle();                                             // the copy-out has read the slab: the next granule may fill it
             }
         }
@@ -845,7 +881,7 @@ scatter_kernel(const uint8_t *__restrict__ code, uint64_t n, int mode, uint32_t 
 #pragma unroll
                 for (int b = 0; b < 7; ++b) base[b] = lane_value(lane_base, b);
             }
-            scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, (uint32_t)rec_g, base, idx_out, n_units, slab, lptr);
+            scatter_granule<NSUB, WIDE, NIB, false, LISTS>(w, lut, rec_g, base, idx_out, n_units, slab, lptr);
         }
         if (CAN_STAGE) lane_base += cnt_g;                                // where the next granule's runs begin
 #pragma unroll
@@ -1915,6 +1951,15 @@ void launch_scan(hipStream_t st, const CountPlan &cp, uint32_t *gran_off, uint64
                                                                    cp.part_tot, gran_off, bt, rep, cnt, part0, n_parts);
 }
 
+// XM_SCATTER_WAVES (xm_kernels.h) waves at most; the environment variable of the same name (read per call, like
+// XM_PLACE_CHUNK_PARTS) lowers it so that tests reach the run-of-granules form without 2^31 records
+static uint32_t scatter_waves()
+{
+    const char *e = getenv("XM_SCATTER_WAVES");
+    const long v = e && *e ? strtol(e, nullptr, 10) : 0;
+    return v >= 1 && v < (long)XM_SCATTER_WAVES ? (uint32_t)v : (uint32_t)XM_SCATTER_WAVES;
+}
+
 void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, const uint8_t *code, bool code_is_bins4,
                     const uint32_t *gran_counts, const uint32_t *gran_off, const uint64_t *bin_totals, uint64_t *bin_offsets,
                     uint32_t *idx_out, uint32_t *part_tot, const ListOut *lists, uint32_t gran0, uint32_t gran1)
@@ -1924,20 +1969,24 @@ void launch_scatter(hipStream_t st, const GranPlan &p, int mode, uint64_t n, con
     // [gran0, gran1): a chunk of a chunked call (lists only), gran1 == 0: the whole input
     const uint32_t g_first = gran1 ? gran0 : 0u, g_end = gran1 ? gran1 : p.n_gran, span = g_end - g_first;
     const uint32_t last = g_end == p.n_gran ? 1u : 0u;
-    // long-lived waves, each a run of consecutive granules (scatter_kernel): about XM_SCATTER_WAVES of them
-    const uint32_t gran_per_wave = (span + XM_SCATTER_WAVES - 1u) / XM_SCATTER_WAVES;
-    const uint32_t n_waves = (span + gran_per_wave - 1u) / gran_per_wave;
+    // one granule per wave; beyond scatter_waves() granules a wave takes a run of consecutive ones (scatter_kernel, MULTI)
+    const uint32_t max_waves = scatter_waves();
+    const uint32_t gran_per_wave = (span + max_waves - 1u) / max_waves;
+    const bool multi = gran_per_wave > 1u;
+    const uint32_t n_waves = multi ? (span + gran_per_wave - 1u) / gran_per_wave : span;
     const uint32_t grid = (n_waves + (XM_BLOCK / 64) - 1) / (XM_BLOCK / 64);
     const bool wide = n > (1ull << 30);                 // unit positions * 4 bytes may pass 2^32
     const bool stage = mode == XM_MODE_SE;
     const ListOut lo = lists ? *lists : ListOut{{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0u};
-#define XM_LAUNCH_SCT(W, NIB, STG, L) scatter_kernel<XM_GRAN / 256, W, NIB, STG, L><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, g_end, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot, lo, gran_per_wave, g_first, last)
-#define XM_LAUNCH_SCT1(W, NIB, STG) do { if (lists) XM_LAUNCH_SCT(W, NIB, STG, true); else XM_LAUNCH_SCT(W, NIB, STG, false); } while (0)
+#define XM_LAUNCH_SCT(W, NIB, STG, L, M) scatter_kernel<XM_GRAN / 256, W, NIB, STG, L, M><<<grid, XM_BLOCK, 0, st>>>(code, n, mode, g_end, p.gran_stride, gran_counts, gran_off, bt, bo, idx_out, part_tot, lo, gran_per_wave, g_first, last)
+#define XM_LAUNCH_SCT0(W, NIB, STG, L) do { if (multi) XM_LAUNCH_SCT(W, NIB, STG, L, true); else XM_LAUNCH_SCT(W, NIB, STG, L, false); } while (0)
+#define XM_LAUNCH_SCT1(W, NIB, STG) do { if (lists) XM_LAUNCH_SCT0(W, NIB, STG, true); else XM_LAUNCH_SCT0(W, NIB, STG, false); } while (0)
 #define XM_LAUNCH_SCT2(W, NIB) do { if (stage) XM_LAUNCH_SCT1(W, NIB, true); else XM_LAUNCH_SCT1(W, NIB, false); } while (0)
     if (code_is_bins4) { if (wide) XM_LAUNCH_SCT2(true, true); else XM_LAUNCH_SCT2(false, true); }
     else               { if (wide) XM_LAUNCH_SCT2(true, false); else XM_LAUNCH_SCT2(false, false); }
 #undef XM_LAUNCH_SCT2
 #undef XM_LAUNCH_SCT1
+#undef XM_LAUNCH_SCT0
 #undef XM_LAUNCH_SCT
 }
 

@@ -35,6 +35,8 @@
 #include <new>
 #include <string>
 
+#include "xm_pinned.h"
+
 namespace {
 
 constexpr int SB = 256;                               // lanes per workgroup
@@ -819,6 +821,7 @@ int fail(xm_strip *s, hipError_t e, const char *what)
         std::lock_guard<std::mutex> hold(s->error_lock);
         s->last_error = buf;
     }
+    (void)hipGetLastError();        // reported here: a later launch check on this thread must not find it again
     return e == hipErrorOutOfMemory ? XM_ERR_OOM : XM_ERR_HIP;
 }
 
@@ -835,7 +838,7 @@ int fail(xm_strip *s, hipError_t e, const char *what)
     } while (0)
 
 template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
-template <typename T> void hfree(T *&p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+template <typename T> void hfree(T *&p) { if (p) { (void)xmpin::host_free(p); p = nullptr; } }
 
 template <typename T> int dalloc(xm_strip *s, T *&p, size_t count)
 {
@@ -846,7 +849,7 @@ template <typename T> int dalloc(xm_strip *s, T *&p, size_t count)
 template <typename T> int halloc(xm_strip *s, T *&p, size_t count)
 {
     hfree(p);
-    XMS_HIP(s, hipHostMalloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T), hipHostMallocDefault));
+    XMS_HIP(s, xmpin::host_malloc((void **)&p, std::max<size_t>(count, 16) * sizeof(T)));
     return XM_OK;
 }
 
@@ -956,9 +959,9 @@ int xm_strip_create(xm_ctx *ctx, int device_id, xm_strip **out)
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, ST_WORDS * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_range, 4 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_summary, SUM_WORDS * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_summary, SUM_WORDS * sizeof(uint64_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_summary, SUM_WORDS * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off_counts, 74 * sizeof(uint64_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_off_counts, 74 * sizeof(uint64_t));
     }
     if (e != hipSuccess) {
         xm_strip_destroy(s);

@@ -104,6 +104,24 @@ def default_stripper():
     return _stripper
 
 
+def release_buffers():
+    """Give back what the process-wide GPU front ends hold between jobs: default_stripper() and default_bamdev() keep the largest
+    page-locked staging / text / table buffers and device buffers any run so far asked for (two slots x two files each: several
+    GB after one large BAM pair), so that the next run does not pay for allocating and page-locking them again.  A process that
+    classifies now and then calls this in between: both front ends are destroyed (their slot streams handed back to the context,
+    xm_workspace_release), the host-side text buffers of the BAM path dropped; the next file run builds fresh ones.  Not while a
+    file run is in progress in another thread.  -> _ffi.pinned_bytes() afterwards."""
+    global _stripper, _bamdev
+    if _bamdev is not None:
+        _bamdev.close()
+        _bamdev = None
+    if _stripper is not None:
+        _stripper.close()
+        _stripper = None
+    _BAM_TEXT_BUFFERS.clear()
+    return _ffi.pinned_bytes()
+
+
 # --------------------------------------------------------------------------------------------
 # SAM input / headers (host text work)
 # --------------------------------------------------------------------------------------------
@@ -1383,7 +1401,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     3: "a malformed alignment record"}.get(blk.bad_block, "damaged")
             raise ValueError("corrupt BAM input: %s (%s, %s)" % (what, path1, path2))
         eofs = [bool(x["eof"]) for x in inputs]
+        # which way each window went, for the profile (and the tests: tests/test_file_path.py, test_bam_gpu.py): "raw" = the whole
+        # inflated windows came back for the host to walk or print, "device_text" / "host_text" = who printed the wanted records
+        prof["bam_windows"] = prof.get("bam_windows", 0) + 1
         if blk.unaligned or blk.weird or (cigar_mode and blk.n_exceptions):
+            prof["bam_windows_raw"] = prof.get("bam_windows_raw", 0) + 1
             # (--cigar_scores: an NM or XS value the kernels do not vouch for sends the window the same way, as on the SAM path)
             with prof("parse"):
                 # the whole windows as text, then the text rules (exactly the host path's semantics for this window)
@@ -1419,11 +1441,14 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     lines = bamdev.fetch_text(which, blk.n, paired, mask)
                     if lines[0] == 0:
                         blk.lines = lines
-                    elif lines[0] == 1:                              # files whose records carry floating-point fields (e.g. de:f):
-                        bam_text_on_device[0] = False                # the host prints the rest of the run without asking again
+                    # (status 1: a binary64 field -- f and B:f are printed on the device since round 6 --, 2: more text than the
+                    # slot's buffers hold: the host prints THIS window; the next one is offered to the device again)
                 if blk.lines is None:
                     blk.packed = bamdev.fetch_wanted(which, blk.n, paired, mask)
+                key = "bam_windows_device_text" if blk.lines is not None else "bam_windows_host_text"
+                prof[key] = prof.get(key, 0) + 1
         else:
+            prof["bam_windows_raw"] = prof.get("bam_windows_raw", 0) + 1
             bamdev.fetch_raw(which)                                  # values the text rules must decide, or nothing: the whole windows
 
         def finish():
