@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define XMB_ABI_VERSION 1
+#define XMB_ABI_VERSION 2   /* 2: xm_bamdev_fetch_bins; f and B:f fields printed on the device */
 
 /* One BGZF block of the compressed image (24 bytes; the layout the kernels read). */
 typedef struct {
@@ -208,7 +208,21 @@ typedef struct {
 } xm_bamdev_lines;
 int xm_bamdev_set_refs(xm_bamdev *b, int file, const uint8_t *names, const uint32_t *at, uint32_t n_refs);
 int xm_bamdev_fetch_text(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_lines *out);
-/* both copies run on a stream of their own; this blocks until the one asked for last has arrived (any thread) */
+/* (d) after xm_bamdev_classify: the six OUTPUTS themselves, gathered on the device (XMB_ABI_VERSION 2) -- the text of every bin whose
+ * sink is given (sink_mask bit b), i.e. for the bin's units in input order the lines the reference's loop prints for them
+ * (xenomapper.py:332-350, :423-448, :521-550: primary bins file 1's line(s), secondary bins file 2's, `unresolved` file 1's
+ * then file 2's; a paired unit is records i - 1 and i), as `samtools view` prints them (as (c)).  One page-locked stream:
+ * bin b's text = text[bin_off[b] .. bin_off[b + 1]), b = 0..5 in the state order PS, SS, PM, SM, unresolved, unassigned
+ * (bin_off[6] = bin_off[7] = all of it: the seventh list, state 6, cannot occur for int32 columns).  Needs the reference
+ * names as (c).  The caller writes six contiguous byte ranges per window; nothing else of the window crosses the link.
+ * status as (c): 0 on its way (xm_bamdev_raw_wait), 1 a binary64 field, 2 more text than the slot's buffers hold. */
+typedef struct {
+    const uint8_t *text;
+    uint64_t bin_off[8];
+    int32_t  status, reserved;
+} xm_bamdev_bins;
+int xm_bamdev_fetch_bins(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_bins *out);
+/* the copies run on a stream of their own; this blocks until the one asked for last has arrived (any thread) */
 int xm_bamdev_raw_wait(xm_bamdev *b, int slot);
 /* the fused main loop on the slot's columns (as xm_strip_classify) */
 int xm_bamdev_classify(xm_bamdev *b, int slot, int mode, uint64_t n_records, int32_t min_score_floor,

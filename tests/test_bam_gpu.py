@@ -247,13 +247,16 @@ def oracle_path(images, conservative=False, tag="AS", paired=True, skip=None):
     return dict(res.named_counts(paired)), [outs[k].getvalue() for k in order]
 
 
+@pytest.mark.parametrize("bins", ["1", "0"])
 @pytest.mark.parametrize("aligned", [True, False])
-def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, monkeypatch, aligned):
+def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, monkeypatch, aligned, bins):
     """The tiled fixtures through the whole file path: GPU BAM front end (small windows: many windows, carried tails, halo
     records) against the host decoder; record-aligned blocks (device record chain) and blocks that cut records (reported,
-    chain followed on the host)."""
+    chain followed on the host).  bins: the six outputs gathered on the device (xm_bamdev_fetch_bins, the default) or the
+    records' text printed on the device and gathered by the host (xm_bamdev_fetch_text)."""
     import bench_bam
     from xenomapper_amd import xenomapper as xm
+    monkeypatch.setenv("XENOMAPPER_GPU_BAM_BINS", bins)
     paths = []
     for tag in ("human", "mouse"):
         p = str(tmp_path / ("%s.bam" % tag))
@@ -269,6 +272,9 @@ def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, m
         assert got[1] == ref[1]
         prof = xm.LAST_FILE_PROFILE
         assert prof.get("strip_kernels_ms", 0) > 0 or not aligned   # the device path really ran
+        if aligned:
+            assert (prof.get("bam_windows_device_bins", 0) > 0) == (bins == "1"), dict(prof)
+            assert prof.get("bam_windows_device_text", 0) == prof["bam_windows"] - prof.get("bam_windows_raw", 0), dict(prof)
     assert sum(want[0].values()) == 40 * 238
 
 
@@ -300,13 +306,17 @@ def test_adversarial_bam_pairs_through_the_file_path(tmp_path_factory, images, t
     assert got[1] == ref[1]
 
 
-def test_more_text_than_the_buffers_hold_goes_to_the_host_printer(tmp_path, monkeypatch):
+@pytest.mark.parametrize("bins", ["0", "1"])
+def test_more_text_than_the_buffers_hold_goes_to_the_host_printer(tmp_path, monkeypatch, bins):
     """The same file on both sides: every pair is unresolved, every record of both files is wanted, and their SAM text (1.6 x the
     records) does not fit the slot's packed-record buffers in windows of 8 MB -- xm_bamdev_fetch_text declines (status 2) and the
     window is printed by the host from the packed records; a smaller mask of sinks fits and is printed on the device.  Outputs equal
     the host decoder's either way."""
     import bench_bam
     from xenomapper_amd import xenomapper as xm
+    # bins "0": the text printed per file (xm_bamdev_fetch_text), what the paragraph above describes; "1": the outputs gathered on
+    # the device (xm_bamdev_fetch_bins), whose one stream may use both files' buffers -- here it fits, so nothing is declined
+    monkeypatch.setenv("XENOMAPPER_GPU_BAM_BINS", bins)
     p = str(tmp_path / "same.bam")
     bench_bam.tiled_bam(os.path.join(DATA, "paired_end_testdata_human.bam"), p, 100)
     monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 8 << 20)
@@ -319,7 +329,10 @@ def test_more_text_than_the_buffers_hold_goes_to_the_host_printer(tmp_path, monk
     xm._bamdev.close()
     assert isinstance(want[0], dict) and got == want
     assert len(got[1][4]) > 0 and not any(got[1][b] for b in (0, 1, 2, 3))     # all unresolved (or unassigned)
-    assert xm.LAST_FILE_PROFILE.get("bam_print", 0) > 0                        # the host printed
+    if bins == "0":
+        assert xm.LAST_FILE_PROFILE.get("bam_print", 0) > 0                    # the host printed
+    else:
+        assert xm.LAST_FILE_PROFILE.get("bam_windows_device_bins", 0) + xm.LAST_FILE_PROFILE.get("bam_print", 0) > 0
 
 
 def test_runs_of_equal_names_longer_than_a_window(tmp_path, monkeypatch):

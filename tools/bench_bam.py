@@ -73,7 +73,7 @@ def tiled_bam(src, dst, copies, aligned=True):
     return len(raw) - at
 
 
-def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False, single_end=False):
+def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False, single_end=False, to_files=False):
     """One warm-up and one timed pass over the tiled fixtures; returns the result record (also bench.py's `e2e.bam`).
     cigar_scores: the --cigar_scores plugin (AS made of NM + CIGAR) instead of the AS / XS tags.  single_end: the files as
     single-end input, as the command line runs it: the skipping walk (every run of equal names yields its first record)."""
@@ -86,12 +86,17 @@ def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False, single_e
         tiled_bam(os.path.join(DATA, "paired_end_testdata_%s.bam" % tag), path, a.copies)
         paths.append(path)
     size = sum(os.path.getsize(p) for p in paths)
-    sinks = {k: open(os.devnull, "wt") for k in ("primary_specific", "secondary_specific", "primary_multi",
-                                                  "secondary_multi", "unassigned", "unresolved")}
+    names = ("primary_specific", "secondary_specific", "primary_multi", "secondary_multi", "unassigned", "unresolved")
+    out_paths = [os.path.join(a.dir, "xm_bam_out_%s_%d.sam" % (k, os.getpid())) for k in names] if to_files else []
+    sinks = {k: open(os.devnull, "wt") for k in names}
     try:
         xm.default_context()
         first = None
         for _warm in (True, False):
+            if to_files:                                              # real files (tmpfs): every pass starts from empty ones
+                for s_ in sinks.values():
+                    s_.close()
+                sinks = {k: open(p_, "wt") for k, p_ in zip(names, out_paths)}
             t0 = time.perf_counter()
             counts = xm.classify_sam_files(paths[0], paths[1], paired=not single_end, n_threads=a.threads, bam=True,
                                            tag_func=xm.get_cigarbased_AS_tag if cigar_scores else xm.get_tag, **sinks)
@@ -103,8 +108,11 @@ def run(copies=4000, threads=0, workdir="/dev/shm", cigar_scores=False, single_e
                 "threads": a.threads or _host.lib().xmh_default_threads(),
                 "phases": {k: round(v, 4) for k, v in xm.LAST_FILE_PROFILE.items()}}
     finally:
-        for p in paths:
-            os.unlink(p)
+        for s_ in sinks.values():
+            s_.close()
+        for p in paths + out_paths:
+            if os.path.exists(p):
+                os.unlink(p)
 
 
 def main():
@@ -114,8 +122,9 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--cigar_scores", action="store_true")
     ap.add_argument("--single_end", action="store_true")
+    ap.add_argument("--files", action="store_true", help="six real output files in --dir instead of /dev/null")
     a = ap.parse_args()
-    print(json.dumps(run(a.copies, a.threads, a.dir, a.cigar_scores, a.single_end)))
+    print(json.dumps(run(a.copies, a.threads, a.dir, a.cigar_scores, a.single_end, a.files)))
 
 
 if __name__ == "__main__":

@@ -167,6 +167,7 @@ def lib():
         "xm_bamdev_upload": ([P, I, I, U64], I),
         "xm_bamdev_set_refs": ([P, I, P, P, ctypes.c_uint32], I),
         "xm_bamdev_fetch_text": ([P, I, U64, I, ctypes.c_uint32, P], I),
+        "xm_bamdev_fetch_bins": ([P, I, U64, I, ctypes.c_uint32, P], I),
         "xm_bamdev_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
         "xm_bamdev_columns": ([P, I, U64, P, P, P, P, P], I),
         "xm_bamdev_cigar_columns": ([P, I, I, U64, P, P, P, P, U64, ctypes.POINTER(ctypes.c_uint64)], I),
@@ -193,7 +194,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
-            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_fetch_text", "xm_bamdev_set_refs", "xm_bamdev_upload", "xm_bamdev_classify",
+            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_fetch_text", "xm_bamdev_fetch_bins", "xm_bamdev_set_refs", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_cigar_columns", "xm_bamdev_last_error")
 
 
@@ -972,6 +973,10 @@ class _BamDevText(ctypes.Structure):
                 ("bytes1", ctypes.c_uint64), ("bytes2", ctypes.c_uint64)]
 
 
+class _BamDevBins(ctypes.Structure):
+    _fields_ = [("text", ctypes.c_void_p), ("bin_off", ctypes.c_uint64 * 8), ("status", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class _BamDevLines(ctypes.Structure):
     _fields_ = [("text1", ctypes.c_void_p), ("text2", ctypes.c_void_p), ("line_off1", ctypes.c_void_p), ("line_off2", ctypes.c_void_p),
                 ("line_len1", ctypes.c_void_p), ("line_len2", ctypes.c_void_p), ("bytes1", ctypes.c_uint64), ("bytes2", ctypes.c_uint64),
@@ -1141,6 +1146,19 @@ class BamDev(object):
         return (0, (_host_view(t.text1, max(int(t.bytes1), 1), np.uint8), _host_view(t.text2, max(int(t.bytes2), 1), np.uint8)),
                 (_host_view(t.line_off1, n, np.uint32), _host_view(t.line_off2, n, np.uint32)),
                 (_host_view(t.line_len1, n, np.uint32), _host_view(t.line_len2, n, np.uint32)))
+
+    def fetch_bins(self, slot, n_records, paired, sink_mask):
+        """After classify(): the six outputs themselves, gathered on the device (xm_bamdev_fetch_bins) -> (status, text, bin_off):
+        bin b's text = text[bin_off[b]:bin_off[b + 1]] (a view of a page-locked buffer, valid after raw_wait and until the next
+        run on the slot); status 1 / 2: this window is the host's (a binary64 field / more text than the buffers hold)."""
+        t = _BamDevBins()
+        rc = self._L.xm_bamdev_fetch_bins(self._h, int(slot), int(n_records), int(bool(paired)), int(sink_mask), ctypes.byref(t))
+        self._check(rc, "xm_bamdev_fetch_bins")
+        if t.status != 0:
+            return int(t.status), None, None
+        off = [int(v) for v in t.bin_off]
+        text = _host_view(t.text, off[7], np.uint8) if off[7] else np.zeros(0, dtype=np.uint8)
+        return 0, text, off
 
     def upload(self, slot, file, nbytes):
         """The first nbytes of the slot's staging buffer go to the device now (xm_bamdev_upload); the next run is told `uploaded`."""

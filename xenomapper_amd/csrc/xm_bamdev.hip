@@ -482,6 +482,97 @@ text_fill_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ r
     wsize[i] = len - 1u;
 }
 
+// ---- G: the six outputs themselves, gathered ON the device (xm_bamdev_fetch_bins; SURVEY f-2's gather kernel) ----
+// With the bins' unit lists (d_idx: unit indices sorted by bin, input order inside a bin; d_off_counts[0..7]: where each bin begins)
+// and the wanted records' line lengths (T1) on the device, the text of every output file is a pure function of device data:
+// bin b's text = for its units in order, the unit's lines (xenomapper.py:332-350, :423-448, :521-550: primary bins print file 1's
+// line(s), secondary bins file 2's, `unresolved` file 1's then file 2's; a paired unit is records i - 1 and i).  G1 sizes every
+// unit, the size scan places it -- the units are in bin order, so the scan IS the layout of the six texts back to back --, G2
+// prints every line where it belongs (the same sam_line as T2), G3 moves the stream to the host's page-locked buffer in aligned
+// 16-byte pieces.  The host then writes six contiguous byte ranges per window instead of gathering a million lines.
+__device__ __forceinline__ uint32_t bin_of_place(uint32_t p, const unsigned long long *__restrict__ off)
+{
+    uint32_t b = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 7u; ++k) b += (off[k] <= (unsigned long long)p) ? 1u : 0u;
+    return b;
+}
+
+__global__ void __launch_bounds__(256)
+unit_size_kernel(const uint32_t *__restrict__ idx, const unsigned long long *__restrict__ off, uint32_t n_units, uint32_t n_records, int paired,
+                 uint32_t sink_mask, const uint32_t *__restrict__ ws1, const uint32_t *__restrict__ ws2, uint32_t *__restrict__ usize,
+                 unsigned long long *__restrict__ total64)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    uint32_t s = 0;
+    if (p < n_units) {
+        const uint32_t i = idx[p], files = files_of_bin(bin_of_place(p, off), sink_mask);
+        if (i < n_records && (!paired || i > 0u)) {
+            if (files & 1u) s += ws1[i] + (paired ? ws1[i - 1u] : 0u);
+            if (files & 2u) s += ws2[i] + (paired ? ws2[i - 1u] : 0u);
+        }
+        usize[p] = s;
+    }
+    // the places are 32-bit; whether all the text fits them (and the buffers) is decided on a 64-bit total
+    unsigned long long t = s;
+    for (int d = 32; d; d >>= 1) t += __shfl_xor(t, d, 64);
+    if ((threadIdx.x & 63u) == 0u && t) atomicAdd(total64, t);
+}
+
+// G2: a lane per (unit, line of the unit): paired units have two lines per file, single-end units one
+__global__ void __launch_bounds__(256)
+line_fill_kernel(const uint8_t *__restrict__ raw1, const uint8_t *__restrict__ raw2, const uint32_t *__restrict__ rec_off1,
+                 const uint32_t *__restrict__ rec_off2, const RefTable refs1, const RefTable refs2,
+                 const uint32_t *__restrict__ idx, const unsigned long long *__restrict__ off, uint32_t n_units, uint32_t n_records, int paired,
+                 uint32_t sink_mask, const uint32_t *__restrict__ ws1, const uint32_t *__restrict__ ws2,
+                 const uint32_t *__restrict__ usize, const uint32_t *__restrict__ uplace, uint8_t *__restrict__ out, uint32_t out_cap)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t p = paired ? g >> 1 : g, j = paired ? g & 1u : 0u;
+    if (p >= n_units) return;
+    const uint32_t size = usize[p];
+    if (size == 0u) return;
+    const uint32_t i = idx[p], files = files_of_bin(bin_of_place(p, off), sink_mask);
+    if (i >= n_records || (paired && i == 0u)) return;
+    const uint32_t r = paired ? i - 1u + j : i;
+    uint32_t at = uplace[p];
+    if (at > out_cap || size > out_cap - at) return;                              // (the total was checked before the launch)
+    for (uint32_t f = 0; f < 2u; ++f) {
+        if (((files >> f) & 1u) == 0u) continue;
+        const uint32_t *ws = f ? ws2 : ws1;
+        const uint32_t first = paired ? ws[i - 1u] : 0u, mine = ws[r];
+        if (mine != 0u) {
+            WriteChars w;
+            w.o = out + at + (j ? first : 0u);
+            (void)sam_line(f ? raw2 : raw1, (f ? rec_off2 : rec_off1)[r], f ? refs2 : refs1, w);
+            w.finish();
+        }
+        at += first + ws[i];                                                       // behind file 1's lines of the unit: file 2's
+    }
+}
+
+// where bin b's text begins (b = 0..6; [7] = the total), and whether the 32-bit places wrapped (the sizes summed again in 64 bits)
+__global__ void __launch_bounds__(64)
+bin_start_kernel(const uint32_t *__restrict__ uplace, const unsigned long long *__restrict__ off, uint32_t n_units,
+                 uint32_t *__restrict__ total_and_wrapped, uint32_t *__restrict__ starts)
+{
+    const uint32_t k = threadIdx.x;
+    const uint32_t total = total_and_wrapped[0];
+    if (k < 8u) starts[k] = (k < 7u && off[k] < (unsigned long long)n_units) ? uplace[off[k]] : total;
+}
+
+// G3: the stream to the host's page-locked buffer (device-mapped), 16 bytes per lane and step, both sides 16-byte aligned.  Its own
+// kernel instead of hipMemcpyAsync, whose shader blit takes whatever share of the chip it likes beside the next window's inflate
+// launch: this one is a fixed, small number of workgroups (XM_BAMDEV_COPY_WG), each streaming its contiguous share.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+out_copy_kernel(const v4u32 *__restrict__ src, v4u32 *__restrict__ dst, uint64_t n16)
+{
+    const uint64_t per = (n16 + gridDim.x - 1u) / gridDim.x;
+    const uint64_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+    for (uint64_t k = lo + threadIdx.x; k < hi; k += 256u) dst[k] = __builtin_nontemporal_load(src + k);
+}
+
 // ---- --cigar_scores: the records' CIGAR words as the packed CIGAR columns K1p reads (include/xenomapper_hip.h) ------------------
 // BAM holds the operations as the kernel wants them (len << 4 | op); what is left to do is what xm_cigar_pack does on the host:
 // a count byte per record (255 = "255 or more": a trailer word n_ops << 4 | 15 behind the operations), the operations back to
@@ -666,6 +757,11 @@ struct Slot {
     // one compressed buffer and one output buffer, file 1's half behind file 0's; one block table, status and CRC array
     uint8_t *d_comp_all = nullptr, *d_raw_all = nullptr;
     uint64_t comp_stride = 0, raw_stride = 0;
+    // the packed-record / text buffers of the two files are halves of ONE allocation each (pf[f].d_packed, pf[f].h_packed):
+    // xm_bamdev_fetch_bins prints the six outputs into them as one stream
+    uint8_t *d_packed_all = nullptr, *h_packed_all = nullptr;
+    uint64_t packed_stride = 0;
+    uint32_t *d_usize = nullptr, *d_uplace = nullptr, *d_upart = nullptr;      // per unit: bytes of its lines, where they go (fetch_bins)
     xm_bgzf_block *h_blocks = nullptr, *d_blocks = nullptr;
     xm_bgzf_walk *h_walk = nullptr, *d_walk = nullptr;      // per block: where its record chain starts and where its results go
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_crc = nullptr, *h_crc = nullptr, *d_work = nullptr;
@@ -749,7 +845,7 @@ void free_slot(Slot &sl)
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
         hfree(q.h_comp); q.d_comp = nullptr; q.d_raw = nullptr; hfree(q.h_raw);
-        dfree(q.d_packed); hfree(q.h_packed); dfree(q.d_wsize); dfree(q.d_place); hfree(q.h_place); dfree(q.d_part);
+        q.d_packed = nullptr; q.h_packed = nullptr; dfree(q.d_wsize); dfree(q.d_place); hfree(q.h_place); dfree(q.d_part);
         hfree(q.h_seg); dfree(q.d_seg); dfree(q.d_cnt); dfree(q.d_exit); dfree(q.d_base);
         dfree(q.d_s_off); dfree(q.d_s_name_off); dfree(q.d_s_name_len); dfree(q.d_s_a); dfree(q.d_s_x); dfree(q.d_s_flag);
         dfree(q.d_s_ncig); dfree(q.d_s_cig_at); dfree(q.d_ncig); dfree(q.d_cig_at); dfree(q.d_cig_tile); dfree(q.d_cig_ops); dfree(q.d_cig_cnt);
@@ -762,7 +858,8 @@ void free_slot(Slot &sl)
         q.refs_set = false;
         q.skip_records = q.skip_cig_records = q.llen_records = 0; q.n_refs = 0;
     }
-    dfree(sl.d_comp_all); dfree(sl.d_raw_all);
+    dfree(sl.d_comp_all); dfree(sl.d_raw_all); dfree(sl.d_packed_all); hfree(sl.h_packed_all);
+    dfree(sl.d_usize); dfree(sl.d_uplace); dfree(sl.d_upart);
     hfree(sl.h_blocks); dfree(sl.d_blocks); hfree(sl.h_walk); dfree(sl.d_walk); dfree(sl.d_status); hfree(sl.h_status); dfree(sl.d_crc); hfree(sl.h_crc);
     for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
     dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx);
@@ -868,8 +965,8 @@ int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_raw, hipEventBlockingSync | hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.up_stream, hipStreamNonBlocking);
         for (int f = 0; f < 2 && e == hipSuccess; ++f) e = hipEventCreateWithFlags(&sl.ev_up[f], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, 16 * sizeof(uint32_t));
-        if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_state, 16 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, 32 * sizeof(uint32_t));
+        if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_state, 32 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
         if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_off_counts, 72 * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_work, 16 * sizeof(uint32_t));
@@ -948,7 +1045,12 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
         for (int f = 0; f < 2; ++f) {
             sl.pf[f].d_raw = sl.d_raw_all + f * sl.raw_stride;
             XMB_TRY(halloc(b, sl.pf[f].h_raw, (size_t)raw_bytes + 64));
-            XMB_TRY(dalloc(b, sl.pf[f].d_packed, (size_t)raw_bytes + 64)); XMB_TRY(halloc(b, sl.pf[f].h_packed, (size_t)raw_bytes + 64));
+        }
+        sl.packed_stride = (raw_bytes + 64u + 255u) & ~(uint64_t)255;
+        XMB_TRY(dalloc(b, sl.d_packed_all, (size_t)(2 * sl.packed_stride))); XMB_TRY(halloc(b, sl.h_packed_all, (size_t)(2 * sl.packed_stride)));
+        for (int f = 0; f < 2; ++f) {
+            sl.pf[f].d_packed = sl.d_packed_all + f * sl.packed_stride;
+            sl.pf[f].h_packed = sl.h_packed_all + f * sl.packed_stride;
         }
         sl.raw_cap = raw_bytes;
     }
@@ -984,6 +1086,7 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
         XMB_TRY(dalloc(b, sl.d_code, n));
         XMB_TRY(dalloc(b, sl.d_bins4, (size_t)XM_BINS4_BYTES(max_records) + 16));
         XMB_TRY(dalloc(b, sl.d_idx, n));
+        XMB_TRY(dalloc(b, sl.d_usize, n)); XMB_TRY(dalloc(b, sl.d_uplace, n)); XMB_TRY(dalloc(b, sl.d_upart, n / SCAN_TILE + 8));
         XMB_TRY(halloc(b, sl.h_code, n));
         XMB_TRY(halloc(b, sl.h_idx, n));
         sl.record_cap = max_records;
@@ -1460,6 +1563,82 @@ int xm_bamdev_fetch_text(xm_bamdev *b, int slot, uint64_t n_records, int paired,
     }
     XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
     sl.raw_issued = true;
+    return XM_OK;
+}
+
+static uint32_t out_copy_workgroups()
+{
+    static const uint32_t wg = [] {
+        const char *v = getenv("XM_BAMDEV_COPY_WG");                             // 0: hipMemcpyAsync (the runtime's blit) instead
+        const long n = v && *v ? strtol(v, nullptr, 10) : 64;
+        return (uint32_t)(n < 0 ? 0 : n > 4096 ? 4096 : n);
+    }();
+    return wg;
+}
+
+int xm_bamdev_fetch_bins(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_bins *out)
+{
+    if (!b || slot < 0 || slot > 1 || !out) return XM_ERR_INVALID_ARG;
+    Slot &sl = b->slot[slot];
+    if (n_records > sl.record_cap || n_records > 0xFFFFFFF0ull || !sl.have_columns || !sl.classified) return XM_ERR_INVALID_ARG;
+    if (!sl.pf[0].refs_set || !sl.pf[1].refs_set) return XM_ERR_INVALID_ARG;          // RNAME / RNEXT need xm_bamdev_set_refs
+    memset(out, 0, sizeof *out);
+    out->text = sl.h_packed_all;
+    const uint32_t n = (uint32_t)n_records;
+    const uint64_t units64 = sl.h_off_counts[7];                                    // of the slot's last xm_bamdev_classify
+    if (n == 0 || units64 == 0) return XM_OK;
+    if (units64 > n_records) return XM_ERR_INVALID_ARG;
+    const uint32_t n_units = (uint32_t)units64;
+    XMB_HIP(b, hipSetDevice(b->device));
+    hipStream_t st = sl.stream;
+    // line lengths and the places of the units are summed in 32 bits (as in xm_bamdev_fetch_text)
+    if (sl.pf[0].raw_len > 0x30000000ull || sl.pf[1].raw_len > 0x30000000ull) { out->status = 2; return XM_OK; }
+    const uint64_t out_cap = std::min<uint64_t>(2 * sl.packed_stride - 64u, 0xFFFFFFF0ull);
+    const uint32_t n_part = (n_units + SCAN_TILE - 1u) / SCAN_TILE;
+    const unsigned long long *d_off = reinterpret_cast<const unsigned long long *>(sl.d_off_counts);
+    XMB_HIP(b, hipMemsetAsync(sl.d_state + 13, 0, 13 * sizeof(uint32_t), st));
+    want_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(sl.pf[0].d_raw, sl.pf[1].d_raw, sl.pf[0].v_rec_off, sl.pf[1].v_rec_off, sl.d_bins4, n, paired ? 1 : 0,
+                                                   sink_mask, sl.pf[0].d_wsize, sl.pf[1].d_wsize);
+    RefTable refs[2];
+    for (int f = 0; f < 2; ++f) {
+        PerFile &q = sl.pf[f];
+        refs[f] = RefTable{q.d_ref_names, q.d_ref_at, q.n_refs};
+        text_size_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(q.d_raw, q.v_rec_off, n, refs[f], q.d_wsize, sl.d_state);
+    }
+    unit_size_kernel<<<(n_units + 255u) / 256u, 256, 0, st>>>(sl.d_idx, d_off, n_units, n, paired ? 1 : 0, sink_mask, sl.pf[0].d_wsize, sl.pf[1].d_wsize,
+                                                             sl.d_usize, reinterpret_cast<unsigned long long *>(sl.d_state + 24));
+    size_sum_kernel<<<n_part, 256, 0, st>>>(sl.d_usize, n_units, sl.d_upart);
+    part_scan_kernel<<<1, 1024, 0, st>>>(sl.d_upart, n_part, sl.d_state + 14);
+    size_place_kernel<true><<<n_part, 256, 0, st>>>(sl.d_usize, n_units, sl.d_upart, sl.d_uplace);
+    // where each bin's text begins: the place of its first unit (state[16..23]; [14] the total, [13] the printer's flag)
+    bin_start_kernel<<<1, 64, 0, st>>>(sl.d_uplace, d_off, n_units, sl.d_state + 14, sl.d_state + 16);
+    XMB_HIP(b, hipMemcpyAsync(sl.h_state + 13, sl.d_state + 13, 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    XMB_HIP(b, hipEventRecord(sl.ev_wait, st));
+    XMB_HIP(b, hipEventSynchronize(sl.ev_wait));
+    if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
+    if (sl.h_state[13] != 0u) { out->status = 1; return XM_OK; }            // a field the host prints (binary64)
+    uint64_t total = 0;
+    memcpy(&total, sl.h_state + 24, sizeof total);                          // summed in 64 bits: the 32-bit places hold only if this fits
+    if (total > out_cap) { out->status = 2; return XM_OK; }                 // more text than the buffers hold
+    for (int k = 0; k < 8; ++k) out->bin_off[k] = sl.h_state[16 + k];
+    line_fill_kernel<<<((paired ? 2u : 1u) * n_units + 255u) / 256u, 256, 0, st>>>(
+        sl.pf[0].d_raw, sl.pf[1].d_raw, sl.pf[0].v_rec_off, sl.pf[1].v_rec_off, refs[0], refs[1], sl.d_idx, d_off, n_units, n, paired ? 1 : 0, sink_mask,
+        sl.pf[0].d_wsize, sl.pf[1].d_wsize, sl.d_usize, sl.d_uplace, sl.d_packed_all, (uint32_t)out_cap);
+    // the stream goes to the host on the copy stream behind the kernels (beside the next window's inflate launch on the other slot)
+    XMB_HIP(b, hipEventRecord(sl.ev_inflated, st));
+    XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
+    if (total) {
+        const uint32_t wg = out_copy_workgroups();
+        if (wg == 0u) XMB_HIP(b, hipMemcpyAsync(sl.h_packed_all, sl.d_packed_all, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+        else {
+            const uint64_t n16 = (total + 15u) / 16u;                       // (the buffers end 64 bytes behind out_cap)
+            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(wg, (n16 + 255u) / 256u), 256, 0, sl.copy_stream>>>(
+                reinterpret_cast<const v4u32 *>(sl.d_packed_all), reinterpret_cast<v4u32 *>(sl.h_packed_all), n16);
+        }
+    }
+    XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
+    sl.raw_issued = true;
+    if (hipGetLastError() != hipSuccess) return XM_ERR_HIP;
     return XM_OK;
 }
 

@@ -21,12 +21,16 @@
 //       32 lanes 28.1-28.3 (31 chains, two per wave: they diverge, and a wave runs its chains' paths one after the other),
 //       16 lanes 26.2, 8 lanes 23.5;
 //   asked for 8 waves per SIMD (64 VGPRs, 16 dwords spilled outside the token loop):  64 lanes 31.0 GB/s -- 31 chains per CU again,
-//       each alone in its wave.  That is the shipped shape.
-// The 8- and 4-lane builds WITHOUT the trace hooks did not come back at all on a 4-block file (the same source with -DXMI_TRACE did,
-// byte-exact; every loop has an exit the data cannot disable, so this is not a decoding loop -- unresolved).
-#ifndef XM_INFLATE_GS
-#define XM_INFLATE_GS 64
-#endif
+//       each alone in its wave.  That is the shipped shape, and since round 6 the ONLY one the device build accepts: the 8- and
+//       4-lane builds without the trace hooks did not come back from a 4-block file in round 5 (the same source with -DXMI_TRACE
+//       did, byte-exact; every loop has an exit the data cannot disable; the two ISA listings differ in control-flow layout only).
+//       Several chains in one wave run under divergent exec masks and hand words from lane to lane through LDS in "program order"
+//       -- an order the compiler is free to lay out per branch; a whole-wave chain has no such hand-off between diverged lanes (its
+//       lanes take every branch together, the steering values come out of v_readfirstlane / v_readlane).  The cause was not
+//       isolated (doing so means launching the hanging build on a shared GPU again), so the configuration is gone instead of
+//       offered: xmi::Chain<GS> is instantiated with 64 lanes on the device and with 1 lane on the host (tests), nothing else.
+constexpr int XM_INFLATE_GS = 64;
+static_assert(XM_INFLATE_GS == 64, "a chain is a whole wave (xm_inflate.hip: narrower chains hung in round 5)");
 #ifndef XM_INFLATE_WG_PER_CU
 #define XM_INFLATE_WG_PER_CU 32     // upper bound on resident waves per CU (the LDS of the chains binds at 31-32)
 #endif

@@ -13,7 +13,9 @@
 // waves and a wave executes in lockstep, so lanes of a chain communicate through LDS in program order: no barrier anywhere.
 // With GS = 64 (what ships: a chain is a whole wave) the token loop of a Huffman block is WIDE instead: lane i decodes the
 // token that would begin at bit P + i, the scalar unit walks from token to token, and a batch of up to 64 output bytes is
-// produced a lane per byte (huffman_block() below; the serial loop remains for GS < 64, the host build and -DXMI_SERIAL_TOKENS).
+// produced a lane per byte (huffman_block() below; the serial loop remains for the host build, GS = 1, and -DXMI_SERIAL_TOKENS).
+// GS is 64 on the device and 1 on the host, nothing else (static_assert in Chain): widths in between shared a wave between chains
+// and hung in round 5 (xm_inflate.hip has the record).
 //
 // Per chain, in LDS (ChainMem, ~5 KB): the two Huffman decoders (a root table indexed by the next ROOT bits -- entries
 // placed at bit-reversed codes, as the bits arrive LSB first -- plus the canonical (first code, limit, base) triples and the
@@ -170,6 +172,11 @@ XMI_HD void count_inc(uint32_t *p)
 
 template <int GS>
 struct Chain {
+#if XMI_DEVICE
+    static_assert(GS == 64, "device build: a chain is a whole wave (narrower chains are not supported: xm_inflate.hip)");
+#else
+    static_assert(GS == 1, "host build (tests): a chain of one lane");
+#endif
     uint32_t *trace = nullptr;
     static constexpr int NP = (8 + GS - 1) / GS;          // 16-byte pieces of an input granule per lane
     ChainMem *m;

@@ -780,7 +780,7 @@ class _AheadFile(object):
             os.close(self.fd2)
 
 
-def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
+def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, ready=None):
     """The text of one bin's units written by the writer's threads STRAIGHT into the output file: the file is extended,
     its new pages are mapped, and xmh_emit gathers the lines into them in parallel -- no intermediate buffer and no
     single write(2) stream (which tops out at ~5 GB/s on one file and made the file path write-bound).  Only for a
@@ -788,7 +788,9 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
     False = not handled (the caller writes through the sink as before).  XENOMAPPER_MMAP_EMIT=0 switches it off.
     ahead: {id(sink): _AheadFile} of the run -- with it the file stays extended past its content between calls (twice the
     bytes of the last call, allocated by ahead_pool's thread while the next block is classified); the run cuts the files
-    back when it ends (_AheadFile.finish)."""
+    back when it ends (_AheadFile.finish).
+    ready: the bin's text as it stands (uint8 array: the GPU BAM path gathers the outputs on the device, xm_bamdev_fetch_bins) --
+    then the threads only copy it into the file's pages."""
     if os.environ.get("XENOMAPPER_MMAP_EMIT") == "0":
         return False
     raw = getattr(sink, "buffer", None)
@@ -796,7 +798,10 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
     if raw is None or enc not in _ASCII_SUPERSETS:
         return False
     t0 = time.perf_counter()
-    idx, need = parser.emit_size(paired, b, seg)
+    if ready is not None:
+        idx, need = None, int(ready.shape[0])
+    else:
+        idx, need = parser.emit_size(paired, b, seg)
     _EMIT_CLOCK["emit_size"] = _EMIT_CLOCK.get("emit_size", 0.0) + time.perf_counter() - t0
     state = ahead.get(id(sink)) if ahead is not None else None
     if need < MMAP_EMIT_MIN_BYTES:
@@ -848,7 +853,11 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None):
     try:
         view = np.frombuffer(mm, dtype=np.uint8)
         try:
-            wrote = parser.emit_to(paired, b, idx, view.ctypes.data + (pos - start), need)
+            if ready is not None:
+                parser.copy(view.ctypes.data + (pos - start), ready, 0, need)
+                wrote = need
+            else:
+                wrote = parser.emit_to(paired, b, idx, view.ctypes.data + (pos - start), need)
         finally:
             del view
         assert wrote == need
@@ -1338,6 +1347,10 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         for f, src in enumerate(sources):
             bamdev.set_refs(f, src.ref_names)
         bam_text_on_device[0] = True
+    # ... and gathered there into the six outputs (xm_bamdev_fetch_bins: the host writes six byte ranges per window instead of
+    # gathering the lines; needs every bin to have a sink of its own -- two bins sharing one are written unit by unit, _emit_shared).
+    # XENOMAPPER_GPU_BAM_BINS=0: the device prints, the host gathers (round 5's form)
+    bam_bins_on_device = [bam_text_on_device[0] and distinct and os.environ.get("XENOMAPPER_GPU_BAM_BINS", "1") != "0"]
     # the GPU BAM path reads the next window's compressed blocks while the GPU works on the current one (_GpuBamFile.read_ahead):
     # a reader of its own (8 threads: pread into page-locked memory peaks there, e2e.host_ceilings) and one thread that drives it
     bam_reader = _host.Parser(8) if bamdev is not None and os.environ.get("XENOMAPPER_BAM_READ_AHEAD", "1") != "0" else None
@@ -1437,15 +1450,23 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 # the bins are on the device: only the records a sink takes come back, packed (half of a window)
                 mask = sum(1 << b for b in range(6) if sinks[b])
                 blk.lines = None
-                if bam_text_on_device[0]:
+                blk.bins = None
+                if bam_bins_on_device[0]:
+                    # the six outputs themselves, gathered on the device: what comes back is what the sinks get
+                    bins = bamdev.fetch_bins(which, blk.n, paired, mask)
+                    if bins[0] == 0:
+                        blk.bins = bins
+                if blk.bins is not None:
+                    prof["bam_windows_device_bins"] = prof.get("bam_windows_device_bins", 0) + 1
+                elif bam_text_on_device[0]:
                     lines = bamdev.fetch_text(which, blk.n, paired, mask)
                     if lines[0] == 0:
                         blk.lines = lines
                     # (status 1: a binary64 field -- f and B:f are printed on the device since round 6 --, 2: more text than the
                     # slot's buffers hold: the host prints THIS window; the next one is offered to the device again)
-                if blk.lines is None:
+                if blk.lines is None and blk.bins is None:
                     blk.packed = bamdev.fetch_wanted(which, blk.n, paired, mask)
-                key = "bam_windows_device_text" if blk.lines is not None else "bam_windows_host_text"
+                key = "bam_windows_device_text" if (blk.lines is not None or blk.bins is not None) else "bam_windows_host_text"
                 prof[key] = prof.get(key, 0) + 1
         else:
             prof["bam_windows_raw"] = prof.get("bam_windows_raw", 0) + 1
@@ -1458,6 +1479,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 t_w = time.perf_counter()
                 bamdev.raw_wait(which)                               # the copy of the window ran beside the kernels and the next window's inflate
                 prof["bam_wait_raw"] = prof.get("bam_wait_raw", 0.0) + time.perf_counter() - t_w
+                if getattr(blk, "bins", None) is not None:          # gathered on the device: the outputs themselves are here
+                    return
                 if getattr(blk, "lines", None) is not None:         # printed on the device: the text and its line table are here
                     _st, text, loff, llen = blk.lines
                     texts[0], texts[1] = text[0], text[1]
@@ -1565,7 +1588,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             patches, bad, err = _resolve_exceptions(block, raws, pos, needed, tag_func, cigar_mode)
         if err is not None:
             n, pending = bad, err                                # units closing at index >= bad are not reached
-        if on_device and block.n:
+        ready = getattr(block, "bins", None) if (not exc and err is None) else None
+        if on_device and block.n and ready is None:
             parser.adopt_lines(raws[0], pos[0], raws[1], pos[1], block.n, block.tables)
         if n:
             with prof("classify"):          # one fused pass: category bytes, counts and the six bin lists
@@ -1584,7 +1608,20 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     fields = _fields_of(raws[f], block, f, j, pos[f])
                     shown += [tag_func(fields, tag="AS"), tag_func(fields, tag="XS")]
                 state_error = RuntimeError("Error in processing logic with values {0} ".format(tuple(shown)))
-            for b in (range(6) if distinct else ()):
+            if ready is not None and limit is not None:          # (state 6 needs a NaN: not on the int32 columns of this path)
+                raise RuntimeError("a unit fell through every branch on the GPU BAM path")
+            if ready is not None and limit is None:
+                # the outputs were gathered on the device (xm_bamdev_fetch_bins): six byte ranges, written as they stand
+                _st, text, boff = ready
+                for b in range(6):
+                    if sinks[b] and boff[b + 1] > boff[b]:
+                        piece = text[boff[b]:boff[b + 1]]
+                        with prof("emit"):
+                            done = _emit_into_file(parser, paired, b, None, sinks[b], ahead, ahead_pool, ready=piece)
+                        if not done:
+                            with prof("write"):
+                                _write_bytes(sinks[b], piece)
+            for b in (range(6) if (distinct and (ready is None or limit is not None)) else ()):
                 if sinks[b]:
                     seg = idx[int(off[b]):int(off[b + 1])]
                     if limit is not None:
