@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define XMS_ABI_VERSION 1
+#define XMS_ABI_VERSION 2   /* 2: xm_strip_fetch_bins / xm_strip_out_wait */
 #define XMS_SLOTS 2
 #define XMS_MAX_WINDOW 0xFFFF0000ull
 
@@ -107,6 +107,25 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
  */
 int xm_strip_classify(xm_strip *s, int slot, int mode, uint64_t n_records, int32_t min_score_floor,
                       const uint8_t **code, const uint32_t **idx, uint64_t bin_offsets[8], uint64_t counts[64]);
+
+/*
+ * After xm_strip_classify: the six OUTPUTS themselves, gathered on the device (ABI 2) -- for every bin whose sink is given
+ * (sink_mask bit b) the lines the reference's loop prints for the bin's units, in input order (xenomapper.py:332-350, :423-448,
+ * :521-550: primary bins file 1's line(s), secondary bins file 2's, `unresolved` file 1's then file 2's; a paired unit is
+ * records i - 1 and i), each as '\t'.join(fields) + '\n'.  One page-locked stream owned by the stripper, valid after
+ * xm_strip_out_wait and until the next call on the slot: bin b's text = text[bin_off[b] .. bin_off[b + 1]), b = 0..5 in the state
+ * order PS, SS, PM, SM, unresolved, unassigned.  The copy to the host runs on a stream of the slot's own, beside the next
+ * window's upload and kernels.  status 0: on its way; 2: more text than the buffers hold (units that overlap); 3: a wanted
+ * line is not '\t'.join(fields) as it stands (mixed white space) -- then nothing was copied: write this window with xmh_emit
+ * from the line tables of xm_strip_run.
+ */
+typedef struct {
+    const uint8_t *text;
+    uint64_t bin_off[8];
+    int32_t  status, reserved;
+} xm_strip_bins;
+int xm_strip_fetch_bins(xm_strip *s, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_strip_bins *out);
+int xm_strip_out_wait(xm_strip *s, int slot);      /* blocks until the stream asked for last has arrived (any thread) */
 
 /* Bring the first n_records of the slot's score columns and ceil(n/64) words of the unit mask to the host (for records
  * the caller must patch by the text rules).  Any pointer may be NULL. */

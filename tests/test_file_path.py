@@ -68,9 +68,14 @@ def test_golden_files(case, tmp_path):
 @pytest.mark.parametrize("name", ["ref_pe_liberal", "ref_se_skip_repeated", "all36_conservative", "all36_se_skip",
                                    "cfg1_se_cli", "cfg2_pe_liberal", "cfg3_pe_cigar", "cfg5_pe_zs_conservative"])
 @pytest.mark.parametrize("window", [700, 4096, 65536])
-def test_small_windows(name, window, tmp_path):
+@pytest.mark.parametrize("bins", ["1", "0"])
+def test_small_windows(name, window, bins, tmp_path, monkeypatch):
+    """bins: the six outputs gathered on the device (xm_strip_fetch_bins, the default) or by the host writer from the line tables."""
     from xenomapper_amd import xenomapper as xm
+    monkeypatch.setenv("XENOMAPPER_GPU_SAM_BINS", bins)
     check(xm, {c["name"]: c for c in G3}[name], tmp_path, window=window)
+    if bins == "0":
+        assert xm.LAST_FILE_PROFILE.get("sam_windows_device_bins", 0) == 0
 
 
 @pytest.mark.parametrize("name", ["ref_pe_liberal", "ref_se_skip_repeated", "all36_conservative", "cfg3_pe_cigar",

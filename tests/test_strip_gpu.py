@@ -438,3 +438,47 @@ def test_closing_a_stripper_leaves_no_dangling_stream_in_the_context():
         assert ctx.workspace_is_clean()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["pe", "pe_conservative", "se"])
+def test_outputs_gathered_on_the_device_equal_the_oracle_and_the_host_writer(tmp_path, monkeypatch, mode):
+    """xm_strip_fetch_bins through the file path (windows of 1 MB: ~25 windows): the six outputs gathered on the device equal the
+    oracle's and the host writer's (XENOMAPPER_GPU_SAM_BINS=0) byte for byte, every window took the device route for plain
+    tab-separated text -- and with a sprinkling of lines whose fields are separated by mixed white space (the reference re-joins
+    them with tabs, xenomapper.py:103 + the print calls) the windows that hold a wanted one fall back to the host writer while
+    the others stay on the device, outputs still equal."""
+    import io
+    from tests import helpers as H
+    from tests.test_file_fuzz_gpu import oracle_run, SCORERS
+    from xenomapper_amd import xenomapper as xm
+    monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 1 << 20)
+    paired = mode != "se"
+    for mixed in (0.0, 0.0002):
+        t1, t2, _info = H.synth.sam_text_pair(n_pairs=30_000, seed=17, profile="bowtie2", paired=paired, read_len=100, mixed_ws=mixed,
+                                              irregular=0.01, header_pg=False)
+        bodies = []
+        for k, text in enumerate((t1, t2)):
+            at = 0
+            while text[at] == "@":
+                at = text.index("\n", at) + 1
+            bodies.append(text[at:])
+            (tmp_path / ("g%d.sam" % k)).write_text(text)
+        paths = [str(tmp_path / "g0.sam"), str(tmp_path / "g1.sam")]
+        want_texts, want_counts, want_err = oracle_run(bodies[0], bodies[1], mode, SCORERS["get_tag"], H.NEG, not paired)
+        assert want_err is None
+        got = {}
+        for bins in ("1", "0"):
+            monkeypatch.setenv("XENOMAPPER_GPU_SAM_BINS", bins)
+            outs = {name: io.StringIO() for name in H.STATES}
+            counts = xm.classify_sam_files(paths[0], paths[1], paired=paired, conservative=mode == "pe_conservative", **outs)
+            prof = dict(xm.LAST_FILE_PROFILE)
+            assert dict(counts) == dict(want_counts)
+            got[bins] = [outs[name].getvalue() for name in H.STATES]
+            assert got[bins] == want_texts, (mode, mixed, bins)
+            assert prof.get("sam_windows", 0) >= 5
+            if bins == "0":
+                assert prof.get("sam_windows_device_bins", 0) == 0
+            elif mixed == 0.0:
+                assert prof.get("sam_windows_device_bins", 0) == prof["sam_windows"], prof
+            else:
+                assert 0 < prof.get("sam_windows_device_bins", 0) < prof["sam_windows"], prof

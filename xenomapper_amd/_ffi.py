@@ -146,6 +146,8 @@ def lib():
         "xm_strip_run": ([P, I, U64, I, U64, I, I, I, I, I, U64, P], I),
         "xm_strip_cigar_columns": ([P, I, I, U64, P, P, P, P, U64, ctypes.POINTER(U64)], I),
         "xm_strip_classify": ([P, I, I, U64, I32, ctypes.POINTER(P), ctypes.POINTER(P), P, P], I),
+        "xm_strip_fetch_bins": ([P, I, U64, I, ctypes.c_uint32, P], I),
+        "xm_strip_out_wait": ([P, I], I),
         "xm_strip_columns": ([P, I, U64, P, P, P, P, P], I),
         "xm_strip_device_columns": ([P, I, P], I),
         "xm_strip_last_error": ([P], ctypes.c_char_p),
@@ -192,7 +194,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
-            "xm_strip_classify", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
+            "xm_strip_classify", "xm_strip_fetch_bins", "xm_strip_out_wait", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
             "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_fetch_text", "xm_bamdev_fetch_bins", "xm_bamdev_set_refs", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_cigar_columns", "xm_bamdev_last_error")
@@ -794,6 +796,10 @@ STRIP_SLOTS = 2
 STRIP_MAX_WINDOW = 0xFFFF0000
 
 
+class _BamDevBins(ctypes.Structure):          # xm_bamdev_bins and xm_strip_bins
+    _fields_ = [("text", ctypes.c_void_p), ("bin_off", ctypes.c_uint64 * 8), ("status", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class _StripBlock(ctypes.Structure):
     _fields_ = [("n_records", ctypes.c_uint64), ("consumed1", ctypes.c_uint64), ("consumed2", ctypes.c_uint64),
                 ("consumed_lines1", ctypes.c_uint64), ("consumed_lines2", ctypes.c_uint64),
@@ -938,6 +944,23 @@ class Stripper(object):
         self._check(rc, "xm_strip_classify")
         return (_host_view(code.value, int(n_records), np.uint8), _host_view(idx.value, int(off[7]), np.uint32), off, counts)
 
+    def fetch_bins(self, slot, n_records, paired, sink_mask):
+        """After classify(): the six outputs themselves, gathered on the device (xm_strip_fetch_bins) -> (status, text, bin_off):
+        bin b's text = text[bin_off[b]:bin_off[b + 1]] (a view of a page-locked buffer, valid after out_wait() and until the
+        next fetch on the slot); status 2 / 3: this window is the host writer's (more text than the buffers hold / a wanted line
+        that needs its white space re-joined)."""
+        t = _BamDevBins()                                               # (xm_strip_bins has the same layout)
+        rc = self._L.xm_strip_fetch_bins(self._h, int(slot), int(n_records), int(bool(paired)), int(sink_mask), ctypes.byref(t))
+        self._check(rc, "xm_strip_fetch_bins")
+        if t.status != 0:
+            return int(t.status), None, None
+        off = [int(v) for v in t.bin_off]
+        text = _host_view(t.text, off[7], np.uint8) if off[7] else np.zeros(0, dtype=np.uint8)
+        return 0, text, off
+
+    def out_wait(self, slot):
+        self._check(self._L.xm_strip_out_wait(self._h, int(slot)), "xm_strip_out_wait")
+
     def cigar_columns(self, slot, file, n_records):
         """After a CIGAR-mode run: (nm int32, cig_cnt uint8, cig_tile uint32, cig_ops uint32) of one file, on the host."""
         n = int(n_records)
@@ -971,10 +994,6 @@ class _BamDevInput(ctypes.Structure):
 class _BamDevText(ctypes.Structure):
     _fields_ = [("raw1", ctypes.c_void_p), ("raw2", ctypes.c_void_p), ("off1", ctypes.c_void_p), ("off2", ctypes.c_void_p),
                 ("bytes1", ctypes.c_uint64), ("bytes2", ctypes.c_uint64)]
-
-
-class _BamDevBins(ctypes.Structure):
-    _fields_ = [("text", ctypes.c_void_p), ("bin_off", ctypes.c_uint64 * 8), ("status", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class _BamDevLines(ctypes.Structure):

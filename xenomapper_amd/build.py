@@ -36,7 +36,7 @@ def _stale(target, sources):
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, "xm_kernels.h"), os.path.join(CSRC, "xm_inflate_core.h"),
-                   os.path.join(CSRC, "xm_bamrec.h"), os.path.join(CSRC, "xm_fmtg.h"), os.path.join(CSRC, "xm_pinned.h"),
+                   os.path.join(CSRC, "xm_bamrec.h"), os.path.join(CSRC, "xm_fmtg.h"), os.path.join(CSRC, "xm_pinned.h"), os.path.join(CSRC, "xm_gather.h"),
                    os.path.join(REPO, "include", "xenomapper_hip.h"), os.path.join(REPO, "include", "xenomapper_strip.h"),
                    os.path.join(REPO, "include", "xenomapper_bgzf.h")]
     if not force and not _stale(HIP_LIB, deps):

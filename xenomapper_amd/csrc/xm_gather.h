@@ -1,0 +1,118 @@
+// Pieces both device front ends use when they gather the six OUTPUTS on the device (xm_bamdev_fetch_bins, xm_strip_fetch_bins;
+// SURVEY f-2's gather kernel): which file a bin prints from, the bin of a place in the packed unit list, the size scan (three small
+// launches over a uint32 array), where each bin's text begins, and the copy of the finished stream into the host's page-locked,
+// device-mapped buffer.  Every kernel lives in an anonymous namespace: each translation unit that includes this gets its own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr uint32_t NO_RECORD = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t files_of_bin(uint32_t bin, uint32_t sink_mask)     // bit 0: file 1's line, bit 1: file 2's
+{
+    if (bin > 5u || ((sink_mask >> bin) & 1u) == 0u) return 0u;
+    return bin == 4u ? 3u : (bin == 1u || bin == 3u) ? 2u : 1u;
+}
+
+constexpr uint32_t SCAN_ITEMS = 16, SCAN_TILE = 256 * SCAN_ITEMS;
+__global__ void __launch_bounds__(256)
+size_sum_kernel(const uint32_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ part)
+{
+    __shared__ uint32_t ws[4];
+    const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) s += (i0 + k < n) ? v[i0 + k] : 0u;
+    for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63u) == 0u) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0u) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void __launch_bounds__(1024)
+part_scan_kernel(uint32_t *__restrict__ part, uint32_t n_part, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t sh[1024];
+    const uint32_t t = threadIdx.x, per = (n_part + 1023u) / 1024u;
+    const uint32_t a = min(t * per, n_part), e = min(a + per, n_part);
+    uint32_t s = 0;
+    for (uint32_t k = a; k < e; ++k) s += part[k];
+    sh[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t x = t >= d ? sh[t - d] : 0u;
+        __syncthreads();
+        sh[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - s;
+    for (uint32_t k = a; k < e; ++k) { const uint32_t x = part[k]; part[k] = run; run += x; }
+    if (t == 1023u) *total = sh[1023];
+}
+
+template <bool ALL>          // ALL: every item gets its place (an empty one that of the next); else empty items get NO_RECORD
+__global__ void __launch_bounds__(256)
+size_place_kernel(const uint32_t *__restrict__ v, uint32_t n, const uint32_t *__restrict__ part, uint32_t *__restrict__ place)
+{
+    __shared__ uint32_t ws[4];
+    const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t x[SCAN_ITEMS], s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) { x[k] = (i0 + k < n) ? v[i0 + k] : 0u; s += x[k]; }
+    uint32_t incl = s;                                                      // inclusive scan of the lanes' sums inside the wave
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += y; }
+    if (lane == 63u) ws[wave] = incl;
+    __syncthreads();
+    uint32_t base = part[blockIdx.x] + incl - s;
+    for (uint32_t w = 0; w < wave; ++w) base += ws[w];
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+        if (i0 + k < n) { place[i0 + k] = (ALL || x[k]) ? base : NO_RECORD; base += x[k]; }
+}
+
+__device__ __forceinline__ uint32_t bin_of_place(uint32_t p, const unsigned long long *__restrict__ off)
+{
+    uint32_t b = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 7u; ++k) b += (off[k] <= (unsigned long long)p) ? 1u : 0u;
+    return b;
+}
+
+// where bin b's text begins (b = 0..6; [7] = the total), and whether the 32-bit places wrapped (the sizes summed again in 64 bits)
+__global__ void __launch_bounds__(64)
+bin_start_kernel(const uint32_t *__restrict__ uplace, const unsigned long long *__restrict__ off, uint32_t n_units,
+                 uint32_t *__restrict__ total_and_wrapped, uint32_t *__restrict__ starts)
+{
+    const uint32_t k = threadIdx.x;
+    const uint32_t total = total_and_wrapped[0];
+    if (k < 8u) starts[k] = (k < 7u && off[k] < (unsigned long long)n_units) ? uplace[off[k]] : total;
+}
+
+// G3: the stream to the host's page-locked buffer (device-mapped), 16 bytes per lane and step, both sides 16-byte aligned.  Its own
+// kernel instead of hipMemcpyAsync, whose shader blit takes whatever share of the chip it likes beside the next window's inflate
+// launch: this one is a fixed, small number of workgroups (XM_BAMDEV_COPY_WG), each streaming its contiguous share.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+out_copy_kernel(const v4u32 *__restrict__ src, v4u32 *__restrict__ dst, uint64_t n16)
+{
+    const uint64_t per = (n16 + gridDim.x - 1u) / gridDim.x;
+    const uint64_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+    for (uint64_t k = lo + threadIdx.x; k < hi; k += 256u) dst[k] = __builtin_nontemporal_load(src + k);
+}
+
+// Workgroups of out_copy_kernel.  Measured on the BAM path (4.5 GB of BAM -> 9.8 GB of text to /dev/null, same box, two runs each,
+// profiles/r06_ab_bam_bins.txt): the runtime's blit 22.6-23.0 M pairs/s, 256 workgroups 26.2-26.7, 64: 25.6-27.5, 32: 27.9-28.7,
+// 16: 28.6-30.2, 8: 27.3-28.7, 4: 25.8-26.0 (the link no longer full), 2: 18.2 -- the fewer wave slots the copy holds, the less
+// the inflate launch beside it is slowed, down to where the copy itself cannot keep the link busy.  XM_BAMDEV_COPY_WG overrides
+// (0: hipMemcpyAsync instead).
+static uint32_t out_copy_workgroups()
+{
+    static const uint32_t wg = [] {
+        const char *v = getenv("XM_BAMDEV_COPY_WG");
+        const long n = v && *v ? strtol(v, nullptr, 10) : 16;
+        return (uint32_t)(n < 0 ? 0 : n > 4096 ? 4096 : n);
+    }();
+    return wg;
+}
+
+}  // namespace

@@ -35,6 +35,7 @@
 #include <new>
 #include <string>
 
+#include "xm_gather.h"
 #include "xm_pinned.h"
 
 namespace {
@@ -760,6 +761,75 @@ __global__ void summary_kernel(const Job job)
     s[SUM_OVERFLOW] = overflow;
 }
 
+// ---- G: the six outputs gathered on the device (xm_strip_fetch_bins; the BAM path's twin is in xm_bamdev.hip) -------------------
+// With the window's text, the line table and the bins' unit lists all on the device, the text of every output file is a function of
+// device data: for the bin's units in input order, the unit's lines (xenomapper.py:332-350, :423-448, :521-550) -- each line as the
+// reference prints it, '\t'.join(fields) + '\n', which IS the input line without its terminator whenever the line already has
+// single tabs between its fields (XMS_LINE_NORMAL: nearly every line of real SAM; a window with a wanted line that needs re-joining
+// is left to the host writer, status 3).  G1 sizes every unit, the size scan places it (units are in bin order: the scan is the
+// layout of the six texts back to back), G2 copies the lines, G3 (xm_gather.h) moves the stream to page-locked memory.
+__global__ void __launch_bounds__(256)
+sam_unit_size_kernel(const uint32_t *__restrict__ idx, const unsigned long long *__restrict__ off, uint32_t n_units, uint32_t n_records, int paired,
+                     uint32_t sink_mask, const uint32_t *__restrict__ llen1, const uint32_t *__restrict__ llen2,
+                     const uint8_t *__restrict__ lflag1, const uint8_t *__restrict__ lflag2, uint32_t *__restrict__ usize,
+                     unsigned long long *__restrict__ total64, uint32_t *__restrict__ not_normal)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    uint32_t s = 0, odd = 0;
+    if (p < n_units) {
+        const uint32_t i = idx[p], files = files_of_bin(bin_of_place(p, off), sink_mask);
+        if (i < n_records && (!paired || i > 0u)) {
+            if (files & 1u) {
+                s += llen1[i] + 1u; odd |= ~(uint32_t)lflag1[i] & XMS_LINE_NORMAL;
+                if (paired) { s += llen1[i - 1u] + 1u; odd |= ~(uint32_t)lflag1[i - 1u] & XMS_LINE_NORMAL; }
+            }
+            if (files & 2u) {
+                s += llen2[i] + 1u; odd |= ~(uint32_t)lflag2[i] & XMS_LINE_NORMAL;
+                if (paired) { s += llen2[i - 1u] + 1u; odd |= ~(uint32_t)lflag2[i - 1u] & XMS_LINE_NORMAL; }
+            }
+        }
+        usize[p] = s;
+    }
+    unsigned long long t = s;
+    for (int d = 32; d; d >>= 1) t += __shfl_xor(t, d, 64);
+    if ((threadIdx.x & 63u) == 0u && t) atomicAdd(total64, t);
+    if (__any(odd != 0u) && (threadIdx.x & 63u) == 0u) atomicOr(not_normal, 1u);
+}
+
+struct __attribute__((packed, aligned(1))) U64Any { uint64_t v; };
+
+// G2: a wave per (unit, line of the unit); the lanes copy the line eight bytes each per step (neither side is aligned), lane 0 adds '\n'
+__global__ void __launch_bounds__(256)
+sam_line_copy_kernel(const uint8_t *__restrict__ text1, const uint8_t *__restrict__ text2, const uint32_t *__restrict__ loff1,
+                     const uint32_t *__restrict__ loff2, const uint32_t *__restrict__ llen1, const uint32_t *__restrict__ llen2,
+                     const uint32_t *__restrict__ idx, const unsigned long long *__restrict__ off, uint32_t n_units, uint32_t n_records, int paired,
+                     uint32_t sink_mask, const uint32_t *__restrict__ usize, const uint32_t *__restrict__ uplace,
+                     uint8_t *__restrict__ out, uint32_t out_cap)
+{
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t p = paired ? w >> 1 : w, j = paired ? w & 1u : 0u;
+    if (p >= n_units) return;
+    const uint32_t size = usize[p];
+    if (size == 0u) return;
+    const uint32_t i = idx[p], files = files_of_bin(bin_of_place(p, off), sink_mask);
+    if (i >= n_records || (paired && i == 0u)) return;
+    const uint32_t r = paired ? i - 1u + j : i;
+    uint32_t at = uplace[p];
+    if (at > out_cap || size > out_cap - at) return;                              // (the total was checked before the launch)
+    for (uint32_t f = 0; f < 2u; ++f) {
+        if (((files >> f) & 1u) == 0u) continue;
+        const uint32_t *ll = f ? llen2 : llen1;
+        const uint32_t first = paired ? ll[i - 1u] + 1u : 0u, len = ll[r];
+        const uint8_t *src = (f ? text2 : text1) + (f ? loff2 : loff1)[r];
+        uint8_t *dst = out + at + (j ? first : 0u);
+        uint32_t k = lane * 8u;
+        for (; k + 8u <= len; k += 512u) reinterpret_cast<U64Any *>(dst + k)->v = reinterpret_cast<const U64Any *>(src + k)->v;
+        if (k < len) for (uint32_t q = k; q < len && q < k + 8u; ++q) dst[q] = src[q];
+        if (lane == 0u) dst[len] = (uint8_t)'\n';
+        at += first + ll[i] + 1u;                                                    // behind file 1's lines of the unit: file 2's
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 struct PerFile {
     char *h_text = nullptr;                            // page-locked staging
@@ -794,6 +864,14 @@ struct Slot {
     uint64_t *d_off_counts = nullptr, *h_off_counts = nullptr;     // 8 + 64 words (+ the range flag's word on the host side)
     uint32_t *d_state = nullptr;
     uint64_t *d_summary = nullptr, *h_summary = nullptr;
+    // xm_strip_fetch_bins: per unit the bytes of its lines and where they go, the six outputs as one stream on the device and in
+    // page-locked host memory, a few words of state; its copy to the host runs on a stream of its own
+    uint32_t *d_usize = nullptr, *d_uplace = nullptr, *d_upart = nullptr, *d_gstate = nullptr, *h_gstate = nullptr;
+    uint8_t *d_out = nullptr, *h_out = nullptr;
+    uint64_t out_cap = 0, out_records = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_filled = nullptr, ev_out = nullptr;
+    bool out_issued = false, classified = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     uint64_t uploaded[2] = {0, 0};                     // bytes of the staged windows already on their way (xm_strip_upload)
@@ -870,6 +948,8 @@ void free_slot(Slot &sl)
     for (int c = 0; c < 4; ++c) dfree(sl.d_col[c]);
     dfree(sl.d_bits); dfree(sl.d_code); dfree(sl.d_bins4); dfree(sl.d_idx);
     hfree(sl.h_code); hfree(sl.h_idx);
+    dfree(sl.d_usize); dfree(sl.d_uplace); dfree(sl.d_upart); dfree(sl.d_out); hfree(sl.h_out);
+    sl.out_cap = sl.out_records = 0;
     sl.window_cap = sl.record_cap = 0;
     sl.cigar_ready = false;
 }
@@ -962,6 +1042,11 @@ int xm_strip_create(xm_ctx *ctx, int device_id, xm_strip **out)
         if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_summary, SUM_WORDS * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_off_counts, 72 * sizeof(uint64_t));
         if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_off_counts, 74 * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_gstate, 16 * sizeof(uint32_t));
+        if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_gstate, 16 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_filled, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_out, hipEventBlockingSync | hipEventDisableTiming);
     }
     if (e != hipSuccess) {
         xm_strip_destroy(s);
@@ -981,9 +1066,14 @@ int xm_strip_destroy(xm_strip *s)
             (void)hipStreamSynchronize(sl.stream);
             (void)xm_workspace_release(s->ctx, sl.stream);             // the context must not keep the handle of a dead stream
         }
+        if (sl.copy_stream) (void)hipStreamSynchronize(sl.copy_stream);
         free_slot(sl);
         dfree(sl.d_state); dfree(sl.d_range); dfree(sl.d_summary); dfree(sl.d_off_counts);
         hfree(sl.h_summary); hfree(sl.h_off_counts);
+        dfree(sl.d_gstate); hfree(sl.h_gstate);
+        if (sl.ev_filled) (void)hipEventDestroy(sl.ev_filled);
+        if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
+        if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
         for (int i = 0; i < 3; ++i)
             if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1000,6 +1090,7 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
     XMS_HIP(s, hipSetDevice(s->device));
     Slot &sl = s->slot[slot];
     XMS_HIP(s, hipStreamSynchronize(sl.stream));
+    XMS_HIP(s, hipStreamSynchronize(sl.copy_stream));
     // a window begins here: whatever an abandoned one (a read that failed half way, a run that was never issued) had
     // sent is forgotten, or the next upload from offset 0 would be refused for ever
     sl.uploaded[0] = sl.uploaded[1] = 0;
@@ -1045,6 +1136,7 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
     sl.uploaded[0] = sl.uploaded[1] = 0;
     sl.upload_timed = false;
     sl.last_score_mode = -1;
+    sl.classified = false;
     if (len1 > sl.window_cap || len2 > sl.window_cap || max_records == 0 || max_records > sl.record_cap || sent[0] > len1 ||
         sent[1] > len2)
         return XM_ERR_INVALID_ARG;
@@ -1206,6 +1298,87 @@ int xm_strip_classify(xm_strip *s, int slot, int mode, uint64_t n_records, int32
     }
     std::memcpy(bin_offsets, sl.h_off_counts, 8 * sizeof(uint64_t));
     std::memcpy(counts, sl.h_off_counts + 8, 64 * sizeof(uint64_t));
+    sl.classified = true;
+    return XM_OK;
+}
+
+int xm_strip_fetch_bins(xm_strip *s, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_strip_bins *out)
+{
+    if (!s || slot < 0 || slot >= XMS_SLOTS || !out) return XM_ERR_INVALID_ARG;
+    Slot &sl = s->slot[slot];
+    if (n_records > sl.record_cap || n_records > 0xFFFFFFF0ull || sl.last_score_mode < 0 || !sl.classified) return XM_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const uint32_t n = (uint32_t)n_records;
+    const uint64_t units64 = sl.h_off_counts[7];                                    // of the slot's last xm_strip_classify
+    if (n == 0 || units64 == 0) return XM_OK;
+    if (units64 > n_records) return XM_ERR_INVALID_ARG;
+    const uint32_t n_units = (uint32_t)units64;
+    XMS_HIP(s, hipSetDevice(s->device));
+    // the stream of the six outputs: both windows' text at most (+ a '\n' per line that had none), unless units overlap
+    const uint64_t want_cap = std::min<uint64_t>(2 * sl.window_cap + 4096, 0xFFFFFFF0ull);
+    if (sl.out_cap < want_cap) {
+        XMS_HIP(s, hipStreamSynchronize(sl.copy_stream));
+        sl.out_cap = 0;
+        XMS_TRY(dalloc(s, sl.d_out, (size_t)want_cap + 64)); XMS_TRY(halloc(s, sl.h_out, (size_t)want_cap + 64));
+        sl.out_cap = want_cap;
+    }
+    if (sl.out_records < sl.record_cap) {
+        sl.out_records = 0;
+        const size_t nr = (size_t)sl.record_cap + 64;
+        XMS_TRY(dalloc(s, sl.d_usize, nr)); XMS_TRY(dalloc(s, sl.d_uplace, nr)); XMS_TRY(dalloc(s, sl.d_upart, nr / SCAN_TILE + 8));
+        sl.out_records = sl.record_cap;
+    }
+    out->text = sl.h_out;
+    hipStream_t st = sl.stream;
+    if (sl.out_issued) XMS_HIP(s, hipStreamWaitEvent(st, sl.ev_out, 0));            // the previous window's stream has left d_out
+    const uint32_t n_part = (n_units + SCAN_TILE - 1u) / SCAN_TILE;
+    const unsigned long long *d_off = reinterpret_cast<const unsigned long long *>(sl.d_off_counts);
+    const PerFile &a = sl.pf[0], &b = sl.pf[1];
+    XMS_HIP(s, hipMemsetAsync(sl.d_gstate, 0, 16 * sizeof(uint32_t), st));
+    // gstate: [0] a wanted line that is not '\t'.join(fields) as it stands, [1] the scan's 32-bit total, [2..3] the 64-bit total,
+    // [4..11] where each bin's text begins
+    sam_unit_size_kernel<<<(n_units + 255u) / 256u, 256, 0, st>>>(sl.d_idx, d_off, n_units, n, paired ? 1 : 0, sink_mask, a.d_llen, b.d_llen,
+                                                                 a.d_lflag, b.d_lflag, sl.d_usize,
+                                                                 reinterpret_cast<unsigned long long *>(sl.d_gstate + 2), sl.d_gstate + 0);
+    size_sum_kernel<<<n_part, 256, 0, st>>>(sl.d_usize, n_units, sl.d_upart);
+    part_scan_kernel<<<1, 1024, 0, st>>>(sl.d_upart, n_part, sl.d_gstate + 1);
+    size_place_kernel<true><<<n_part, 256, 0, st>>>(sl.d_usize, n_units, sl.d_upart, sl.d_uplace);
+    bin_start_kernel<<<1, 64, 0, st>>>(sl.d_uplace, d_off, n_units, sl.d_gstate + 1, sl.d_gstate + 4);
+    XMS_HIP(s, hipMemcpyAsync(sl.h_gstate, sl.d_gstate, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    XMS_HIP(s, hipStreamSynchronize(st));
+    XMS_HIP(s, hipGetLastError());
+    if (sl.h_gstate[0] != 0u) { out->status = 3; return XM_OK; }            // a line the writer has to re-join: the host's window
+    uint64_t total = 0;
+    std::memcpy(&total, sl.h_gstate + 2, sizeof total);
+    if (total > sl.out_cap) { out->status = 2; return XM_OK; }              // more text than the buffers hold (overlapping units)
+    for (int k = 0; k < 8; ++k) out->bin_off[k] = sl.h_gstate[4 + k];
+    sam_line_copy_kernel<<<((paired ? 2u : 1u) * n_units + 3u) / 4u, 256, 0, st>>>(
+        a.d_text, b.d_text, a.d_loff, b.d_loff, a.d_llen, b.d_llen, sl.d_idx, d_off, n_units, n, paired ? 1 : 0, sink_mask, sl.d_usize, sl.d_uplace,
+        sl.d_out, (uint32_t)sl.out_cap);
+    XMS_HIP(s, hipEventRecord(sl.ev_filled, st));
+    XMS_HIP(s, hipStreamWaitEvent(sl.copy_stream, sl.ev_filled, 0));
+    if (total) {
+        const uint32_t wg = out_copy_workgroups();
+        if (wg == 0u) XMS_HIP(s, hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+        else {
+            const uint64_t n16 = (total + 15u) / 16u;
+            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(wg, (n16 + 255u) / 256u), 256, 0, sl.copy_stream>>>(
+                reinterpret_cast<const v4u32 *>(sl.d_out), reinterpret_cast<v4u32 *>(sl.h_out), n16);
+        }
+    }
+    XMS_HIP(s, hipEventRecord(sl.ev_out, sl.copy_stream));
+    sl.out_issued = true;
+    XMS_HIP(s, hipGetLastError());
+    return XM_OK;
+}
+
+int xm_strip_out_wait(xm_strip *s, int slot)
+{
+    if (!s || slot < 0 || slot >= XMS_SLOTS) return XM_ERR_INVALID_ARG;
+    Slot &sl = s->slot[slot];
+    if (!sl.out_issued) return XM_OK;
+    XMS_HIP(s, hipSetDevice(s->device));
+    XMS_HIP(s, hipEventSynchronize(sl.ev_out));
     return XM_OK;
 }
 

@@ -789,8 +789,11 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
     ahead: {id(sink): _AheadFile} of the run -- with it the file stays extended past its content between calls (twice the
     bytes of the last call, allocated by ahead_pool's thread while the next block is classified); the run cuts the files
     back when it ends (_AheadFile.finish).
-    ready: the bin's text as it stands (uint8 array: the GPU BAM path gathers the outputs on the device, xm_bamdev_fetch_bins) --
-    then the threads only copy it into the file's pages."""
+    ready: the bin's text as it stands (uint8 array: the outputs of the window were gathered on the device, xm_bamdev_fetch_bins /
+    xm_strip_fetch_bins) -- then the threads only copy it into the file's pages.  (Positional writes of the same ranges instead --
+    one stream per file, or 8 MB chunks over 6 / 16 / 32 threads -- take 3.4 GB in 0.18 s when nothing else runs on the box
+    (tools/probe_tmpfs_write.py) but 0.47-0.92 s inside a run, beside the readers and the link, where this route takes 0.28-0.39:
+    profiles/r06_ab_sam_bins.txt.)"""
     if os.environ.get("XENOMAPPER_MMAP_EMIT") == "0":
         return False
     raw = getattr(sink, "buffer", None)
@@ -1324,7 +1327,9 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         n_readers = int(os.environ.get("XENOMAPPER_PREAD_THREADS", "0"))
         reader_pool = _host.Parser(n_readers) if n_readers > 0 else None
         pool = ThreadPoolExecutor(max_workers=1)
-        ahead, ahead_pool = {}, ThreadPoolExecutor(max_workers=2)    # output files extended ahead of the writer, their pages unmapped behind it
+        # output files extended ahead of the writer, their pages unmapped behind it (more helper threads than two measured no
+        # better: profiles/r06_ab_sam_bins.txt)
+        ahead, ahead_pool = {}, ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("XENOMAPPER_AHEAD_THREADS", "2"))))
     totals, key_order = Counter(), []
     window = FILE_WINDOW_BYTES
     active = [s for s in sinks if s]
@@ -1338,6 +1343,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         except MemoryError:                                          # no room for its buffers: the host threads strip
             stripper = None
 
+    # SAM text: the outputs gathered on the device as well (every bin needs a sink of its own; XENOMAPPER_GPU_SAM_BINS=0: the host gathers)
+    sam_bins_on_device = stripper is not None and distinct and os.environ.get("XENOMAPPER_GPU_SAM_BINS", "1") != "0"
     bam_text = _BAM_TEXT_BUFFERS                                     # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
     bam_windows = [0]                                                # windows run so far
     # the records' SAM text is printed on the device when the reference names could be read (XENOMAPPER_GPU_BAM_TEXT=0: by the
@@ -1547,6 +1554,24 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         if blk is not None:
             if blk.non_ascii:
                 raise _host.NonAsciiInput()
+            if (sam_bins_on_device and blk.n and not blk.n_exceptions and not blk.overflow):
+                # the fused pass right behind the strip kernels, then the six outputs gathered on the device and sent back as one
+                # stream (xm_strip_fetch_bins): the main thread writes six byte ranges instead of gathering the lines.  A window
+                # with a wanted line that needs re-joining, or with more text than the buffers hold, is written as before.
+                with prof("classify"):
+                    blk.classified = stripper.classify(which, mode, blk.n, _floor_min_score(min_score))
+                    mask = sum(1 << b for b in range(6) if sinks[b])
+                    bins = stripper.fetch_bins(which, blk.n, paired, mask)
+                if bins[0] == 0:
+                    blk.bins = bins
+                    prof["sam_windows_device_bins"] = prof.get("sam_windows_device_bins", 0) + 1
+
+                    def finish(strip=stripper, slot=which):
+                        t_w = time.perf_counter()
+                        strip.out_wait(slot)
+                        prof["sam_wait_out"] = prof.get("sam_wait_out", 0.0) + time.perf_counter() - t_w
+                    blk.finish = finish
+            prof["sam_windows"] = prof.get("sam_windows", 0) + 1
             staged = [stripper.staging(which, f) for f in (0, 1)]
             if blk.overflow or (cigar_mode and blk.n_exceptions):
                 # more lines than the device tables hold, or a --cigar_scores block with a value the kernels do not vouch for:
@@ -1611,7 +1636,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             if ready is not None and limit is not None:          # (state 6 needs a NaN: not on the int32 columns of this path)
                 raise RuntimeError("a unit fell through every branch on the GPU BAM path")
             if ready is not None and limit is None:
-                # the outputs were gathered on the device (xm_bamdev_fetch_bins): six byte ranges, written as they stand
+                # the outputs were gathered on the device (xm_bamdev_fetch_bins / xm_strip_fetch_bins): six byte ranges, written
+                # as they stand (into a regular file's pages by the writer's threads, else through the sink)
                 _st, text, boff = ready
                 for b in range(6):
                     if sinks[b] and boff[b + 1] > boff[b]:
@@ -1694,7 +1720,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             for src in sources:
                 src.close()
         total = time.perf_counter() - t_all
-        prof["other"] = total - sum(v for k, v in prof.items() if not k.endswith("_ms") and not k.startswith("bam_"))   # negative: helper-thread phases overlap the rest
+        prof["other"] = total - sum(v for k, v in prof.items() if not k.endswith("_ms") and not k.startswith("bam_") and not k.startswith("sam_"))   # negative: helper-thread phases overlap the rest
         LAST_FILE_PROFILE.clear()
         LAST_FILE_PROFILE.update(prof, total=total)
         LAST_FILE_PROFILE.update(_EMIT_CLOCK)
