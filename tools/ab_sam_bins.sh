@@ -14,8 +14,11 @@ print('%-22s %6.2f M pairs/s  %.3f s | stage %.3f upload_ms %.0f (%.1f GB/s) str
 }
 for EXTRA in "" "--out-dir /dev/shm"; do
   echo "== outputs: ${EXTRA:-/dev/null}"
-  one "host gathers" XENOMAPPER_GPU_SAM_BINS=0 XENOMAPPER_AHEAD_THREADS=2
-  one "device bins" XENOMAPPER_GPU_SAM_BINS=1
+  one "host gathers" XENOMAPPER_GPU_SAM_BINS=0 XM_STRIP_ZEROCOPY=0
+  one "device bins" XENOMAPPER_GPU_SAM_BINS=1 XM_STRIP_ZEROCOPY=0
+  one "bins + zero-copy S1" XENOMAPPER_GPU_SAM_BINS=1 XM_STRIP_ZEROCOPY=1
+  one "bins + zc, 256 MB" XENOMAPPER_GPU_SAM_BINS=1 XM_STRIP_ZEROCOPY=1 XENOMAPPER_WINDOW_MB=256
+  one "bins + zc, 64 MB" XENOMAPPER_GPU_SAM_BINS=1 XM_STRIP_ZEROCOPY=1 XENOMAPPER_WINDOW_MB=64
 
 
 

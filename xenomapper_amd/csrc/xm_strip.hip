@@ -105,20 +105,33 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 // ---- S1: terminator masks, terminators per chunk, non-ASCII --------------------------------------------------------
-__global__ void __launch_bounds__(SB) mark_kernel(const Job job)
+// src: where the text is read -- the window's copy in HBM, or (zero-copy, the default since round 6) the host's page-locked staging
+// buffer itself, read over the link 16 bytes per lane, 1 KiB per wave instruction; then `copy` is the HBM copy S3-S7 read and this
+// kernel writes it beside its masks: the upload IS this kernel, and there is no copy engine launch per piece of a window.
+struct MarkArgs {
+    const uint8_t *src;
+    uint8_t *copy;                                    // null: src is the HBM copy already
+    uint16_t *mask16;
+    uint32_t *chunk_cnt;
+    uint32_t *state;
+    uint32_t len, usable, file, chunk0, n_chunks;     // chunks [chunk0, chunk0 + n_chunks) of a window of `len` bytes
+};
+
+__global__ void __launch_bounds__(SB) mark_kernel(const MarkArgs a)
 {
-    const FileView &f = job.f[blockIdx.y];
-    if (blockIdx.x >= f.n_chunks) return;
-    const uint32_t n_groups = (f.len + 15u) / 16u;
+    if (blockIdx.x >= a.n_chunks) return;
+    const uint32_t chunk = a.chunk0 + blockIdx.x;
+    const uint32_t n_groups = (a.len + 15u) / 16u;
     uint32_t cnt = 0, hi = 0, any_cr = 0;
     // a wave owns a contiguous quarter of the chunk (16 KiB, 1 KiB per step): S3 then needs no barrier -- its waves take their
     // own bases from the scan of these per-wave counts
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t it = 0; it < ITER; ++it) {
-        const uint32_t g = blockIdx.x * GROUPS + wave * (GROUPS / WAVES) + it * 64u + lane;
+        const uint32_t g = chunk * GROUPS + wave * (GROUPS / WAVES) + it * 64u + lane;
         if (g >= n_groups) break;
         const uint32_t p0 = g * 16u;
-        const uint4 v = *reinterpret_cast<const uint4 *>(f.text + p0);       // the buffer is readable past len (padding)
+        const uint4 v = *reinterpret_cast<const uint4 *>(a.src + p0);         // the buffer is readable past len (padding)
+        if (a.copy != nullptr) *reinterpret_cast<uint4 *>(a.copy + p0) = v;
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         // bytes equal to '\r' / '\n' as 16-bit masks, without a branch (nearly every wave holds a line end somewhere, so a
         // byte loop behind a test ran for all of them): exact zero-byte test of w ^ c, high bits gathered by a multiply
@@ -132,21 +145,21 @@ __global__ void __launch_bounds__(SB) mark_kernel(const Job job)
             lfm |= ((((zn >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * q);
             him |= (((((w[q] & 0x80808080u) >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * q);
         }
-        const uint32_t in_len = p0 + 16u <= f.len ? 0xFFFFu : (1u << (f.len - p0)) - 1u;           // p < len (p0 < len here)
-        const uint32_t in_use = p0 + 16u <= f.usable ? 0xFFFFu : (p0 < f.usable ? (1u << (f.usable - p0)) - 1u : 0u);
+        const uint32_t in_len = p0 + 16u <= a.len ? 0xFFFFu : (1u << (a.len - p0)) - 1u;           // p < len (p0 < len here)
+        const uint32_t in_use = p0 + 16u <= a.usable ? 0xFFFFu : (p0 < a.usable ? (1u << (a.usable - p0)) - 1u : 0u);
         hi |= (him & in_len) ? 0x80u : 0u;
         any_cr |= crm & in_len;
         // '\r' always ends a line (alone or as the first half of "\r\n"); '\n' unless it is that second half
-        const uint32_t prev_cr = ((lfm & 1u) && p0 && f.text[p0 - 1u] == 13u) ? 1u : 0u;      // the byte in front of the group
+        const uint32_t prev_cr = ((lfm & 1u) && p0 && a.src[p0 - 1u] == 13u) ? 1u : 0u;      // the byte in front of the group
         const uint32_t m = (crm | (lfm & ~((crm << 1) | prev_cr))) & in_use;
-        f.mask16[g] = (uint16_t)m;
+        a.mask16[g] = (uint16_t)m;
         cnt += (uint32_t)__popc(m);
     }
     cnt = wave_sum(cnt);
     hi = __any((hi & 0x80808080u) != 0) ? 1u : 0u;
-    if (lane == 0u) f.chunk_cnt[blockIdx.x * WAVES + wave] = cnt;
-    if (hi && lane == 0u) atomicOr(&job.state[ST_NONASCII], 1u);
-    if (__any(any_cr != 0u) && lane == 0u) atomicOr(&job.state[ST_HASCR0 + blockIdx.y], 1u);     // S3 looks at the text only then
+    if (lane == 0u) a.chunk_cnt[chunk * WAVES + wave] = cnt;
+    if (hi && lane == 0u) atomicOr(&a.state[ST_NONASCII], 1u);
+    if (__any(any_cr != 0u) && lane == 0u) atomicOr(&a.state[ST_HASCR0 + a.file], 1u);     // S3 looks at the text only then
 }
 
 // ---- S2: exclusive scan of the chunk counts, one workgroup per file ------------------------------------------------
@@ -875,6 +888,8 @@ struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     uint64_t uploaded[2] = {0, 0};                     // bytes of the staged windows already on their way (xm_strip_upload)
+    uint32_t marked[2] = {0, 0};                       // zero-copy: chunks of the window S1 has been launched for already
+    bool state_cleared = false;                        // the window's state words were zeroed (before its first S1 launch)
     bool upload_timed = false;
     int last_score_mode = -1;                          // of the block the slot holds
 };
@@ -1018,6 +1033,36 @@ int ensure_cigar(xm_strip *s, Slot &sl)
     return XM_OK;
 }
 
+// The text crosses the link inside S1 (mark_kernel reads the page-locked staging buffer and writes the HBM copy) instead of by a copy
+// of its own per piece.  XM_STRIP_ZEROCOPY=0: hipMemcpyAsync per piece, S1 on the copy (rounds 4 and 5).
+bool zero_copy_text()
+{
+    static const bool on = [] { const char *v = getenv("XM_STRIP_ZEROCOPY"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
+// S1 for chunks [marked, upto_chunk) of one file's window, with `len` / `usable` as the kernel is to see them; last: upto_chunk is
+// the window's chunk count (else the chunk holding the last staged byte is left for later)
+int mark_chunks(xm_strip *s, Slot &sl, int file, uint64_t len, uint64_t usable, uint32_t upto_chunk, bool last)
+{
+    if (!last && upto_chunk > 0) --upto_chunk;
+    if (upto_chunk <= sl.marked[file]) return XM_OK;
+    if (!sl.state_cleared) {
+        XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), sl.stream));
+        sl.state_cleared = true;
+    }
+    PerFile &q = sl.pf[file];
+    MarkArgs a;
+    a.src = zero_copy_text() ? reinterpret_cast<const uint8_t *>(q.h_text) : q.d_text;
+    a.copy = zero_copy_text() ? q.d_text : nullptr;
+    a.mask16 = q.d_mask; a.chunk_cnt = q.d_chunk_cnt; a.state = sl.d_state;
+    a.len = (uint32_t)len; a.usable = (uint32_t)usable; a.file = (uint32_t)file;
+    a.chunk0 = sl.marked[file]; a.n_chunks = upto_chunk - sl.marked[file];
+    mark_kernel<<<a.n_chunks, SB, 0, sl.stream>>>(a);
+    sl.marked[file] = upto_chunk;
+    return XM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1094,6 +1139,8 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
     // a window begins here: whatever an abandoned one (a read that failed half way, a run that was never issued) had
     // sent is forgotten, or the next upload from offset 0 would be refused for ever
     sl.uploaded[0] = sl.uploaded[1] = 0;
+    sl.marked[0] = sl.marked[1] = 0;
+    sl.state_cleared = false;
     sl.upload_timed = false;
     // a failed growth leaves the capacity at 0 and the pointers freed or null: the next reserve allocates afresh
     XMS_TRY(grow_window(s, sl, std::max<uint64_t>(window_bytes, 1)));
@@ -1120,7 +1167,14 @@ int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t b
         sl.upload_timed = true;
     }
     PerFile &q = sl.pf[file];
-    XMS_HIP(s, hipMemcpyAsync(q.d_text + offset, q.h_text + offset, (size_t)bytes, hipMemcpyHostToDevice, sl.stream));
+    if (offset == 0) sl.marked[file] = 0;
+    if (zero_copy_text()) {
+        // S1 on the chunks that are complete and not the last one staged so far (the window's last chunk needs its true length
+        // and whether the window ends its file: xm_strip_run marks what is left)
+        XMS_TRY(mark_chunks(s, sl, file, offset + bytes, offset + bytes, (uint32_t)((offset + bytes) / CHUNK), false));
+    } else {
+        XMS_HIP(s, hipMemcpyAsync(q.d_text + offset, q.h_text + offset, (size_t)bytes, hipMemcpyHostToDevice, sl.stream));
+    }
     sl.uploaded[file] = offset + bytes;
     return XM_OK;
 }
@@ -1182,13 +1236,26 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
 
     hipStream_t st = sl.stream;
     if (!timed) XMS_HIP(s, hipEventRecord(sl.ev[0], st));
-    for (int f = 0; f < 2; ++f)                        // what xm_strip_upload has not sent yet
-        if (len[f] > sent[f])
-            XMS_HIP(s, hipMemcpyAsync(sl.pf[f].d_text + sent[f], sl.pf[f].h_text + sent[f], (size_t)(len[f] - sent[f]),
-                                      hipMemcpyHostToDevice, st));
+    if (!zero_copy_text()) {
+        for (int f = 0; f < 2; ++f) {                  // what xm_strip_upload has not sent yet
+            if (len[f] > sent[f])
+                XMS_HIP(s, hipMemcpyAsync(sl.pf[f].d_text + sent[f], sl.pf[f].h_text + sent[f], (size_t)(len[f] - sent[f]),
+                                          hipMemcpyHostToDevice, st));
+            sl.marked[f] = 0;                          // S1 below, on the whole copy
+        }
+    } else {
+        for (int f = 0; f < 2; ++f)
+            if (sent[f] == 0) sl.marked[f] = 0;        // nothing of this window was announced: all of it is marked here
+    }
+    // S1 on what is left of each window (zero-copy: that is where the text crosses the link; the last chunk always is left)
+    for (int f = 0; f < 2; ++f) {
+        const int rc = mark_chunks(s, sl, f, len[f], job.f[f].usable, job.f[f].n_chunks, true);
+        if (rc != XM_OK) { sl.state_cleared = false; sl.marked[0] = sl.marked[1] = 0; return rc; }
+    }
+    if (!sl.state_cleared) XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), st));   // two empty windows
+    sl.state_cleared = false;
+    sl.marked[0] = sl.marked[1] = 0;
     XMS_HIP(s, hipEventRecord(sl.ev[1], st));
-    XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), st));
-    mark_kernel<<<dim3(max_chunks, 2), SB, 0, st>>>(job);
     chunk_scan_kernel<<<2, 1024, 0, st>>>(job);
     fill_kernel<<<dim3(max_chunks, 2), SB, 0, st>>>(job);
     // a line takes at least one byte of its window: no more lines than that, no more records than both files have lines
