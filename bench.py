@@ -283,8 +283,8 @@ def e2e_sam_text(pairs=4_000_000, to_files=True, gpu_strip=True):
         strip = {"bound": "pcie", "upload_GBps": round(r["input_bytes"] / (r["phases"]["strip_upload_ms"] / 1e3) / 1e9, 2),
                  "kernels_ms_total": round(r["phases"].get("strip_kernels_ms", 0.0), 2),
                  "kernels_GBps_of_text": round(r["input_bytes"] / (max(r["phases"].get("strip_kernels_ms", 0.0), 1e-9) / 1e3) / 1e9, 1),
-                 "what": "SAM text uploaded piece by piece while the host threads read the next piece (compare e2e.pcie_ceiling."
-                         "h2d_pinned_GBps); the strip kernels run behind each window's upload"}
+                 "what": "SAM text read over the link by the first strip kernel, piece by piece while the host threads read the next piece "
+                         "into page-locked memory (compare e2e.pcie_ceiling.h2d_pinned_GBps); the other strip kernels run behind each window"}
     return {"read_pairs_per_s": r["value"], "input_GBps": r["input_GBps"], "pairs": r["units"], "threads": r["threads"], "phases": r["phases"],
             "strip": strip,
             "seconds": round(r["seconds"], 4), "outputs": r["outputs"], "output_bytes": r["output_bytes"],
@@ -292,8 +292,9 @@ def e2e_sam_text(pairs=4_000_000, to_files=True, gpu_strip=True):
             "text_bytes_out_per_pair": round(r["output_bytes"] / max(r["units"], 1), 1),
             "output_GBps": r["output_bytes"] / r["seconds"] / 1e9,
             "stripper": "gpu" if gpu_strip else "host",
-            "what": ("two SAM text files (2x150 bp, tiled 50 k-pair twin) -> pread into page-locked memory -> H2D of the TEXT -> "
-                     "strip kernels -> fused pass on the columns in HBM -> D2H of line tables + lists -> six SAM outputs") if gpu_strip
+            "what": ("two SAM text files (2x150 bp, tiled 50 k-pair twin) -> pread into page-locked memory -> the TEXT read over the link by the "
+                     "strip kernels -> fused pass on the columns in HBM -> the six outputs gathered on the GPU (xm_strip_fetch_bins), one stream per "
+                     "window back over the link -> six SAM outputs") if gpu_strip
                     else "two SAM text files (2x150 bp, tiled 50 k-pair twin) -> C++ host stripper -> H2D of columns -> fused pass "
                          "-> D2H -> six SAM outputs"}
 
@@ -974,7 +975,8 @@ def main():
                               "threads": r["threads"], "phases": r["phases"],
                               "what": "two BAM files (the reference's fixtures tiled 48 000 times, record-aligned BGZF blocks as samtools writes "
                                       "them) -> BGZF blocks inflated, records found and stripped ON THE GPU (xm_bamdev), columns stay in HBM -> "
-                                      "fused pass -> the host prints the records' SAM text -> six SAM outputs on /dev/null"}
+                                      "fused pass -> the records' SAM text printed and the six outputs gathered ON THE GPU (xm_bamdev_fetch_bins), one stream per "
+                                      "window back over the link -> six SAM outputs on /dev/null"}
                 for key, kw, what in (("bam_cigar_scores", {"cigar_scores": True}, "the same input with the --cigar_scores plugin (NM + the records' CIGAR "
                                                                               "words packed into the CIGAR columns on the device)"),
                                       ("bam_single_end", {"single_end": True}, "the same files as single-end input: the skipping walk, as the "

@@ -21,6 +21,26 @@ static void on_abort(int sig)
         if (write(g_fd[k], head, sizeof head - 1) < 0) continue;
         backtrace_symbols_fd(frames, n, g_fd[k]);
     }
+    /* What native code printed to stderr while the dying test ran -- glibc's "free(): invalid pointer", the HSA runtime's "Memory
+     * access fault by GPU node", ROCclr's queue error callback -- went into pytest's capture file (descriptor 2 is that temporary
+     * file during a test, opened read-write) and would die with the process: its tail is copied to the same places. */
+    if (g_fd[0] >= 0 || g_fd[1] >= 0) {
+        static char buf[8192];
+        static const char head2[] = "--- stderr captured during the dying test (tail) ---\n";
+        const off_t end = lseek(2, 0, SEEK_CUR);
+        if (end > 0) {
+            off_t at = end > (off_t)(8 * sizeof buf) ? end - (off_t)(8 * sizeof buf) : 0;
+            for (int k = 0; k < 2; ++k)
+                if (g_fd[k] >= 0 && write(g_fd[k], head2, sizeof head2 - 1) < 0) g_fd[k] = -1;
+            while (at < end) {
+                const ssize_t n = pread(2, buf, sizeof buf < (size_t)(end - at) ? sizeof buf : (size_t)(end - at), at);
+                if (n <= 0) break;
+                for (int k = 0; k < 2; ++k)
+                    if (g_fd[k] >= 0 && write(g_fd[k], buf, (size_t)n) < 0) g_fd[k] = -1;
+                at += n;
+            }
+        }
+    }
     signal(sig, SIG_DFL);
 }
 
