@@ -11,8 +11,12 @@ if REPO not in sys.path:
 # ROCclr's errors (level 1 = errors only) go to a file that travels back from the GPU box, glibc's own fatal messages to stderr
 # instead of the controlling terminal.  Set before anything loads the runtime; harmless where there is no GPU.
 _LOG_DIR = os.path.join(REPO, "gpurun_out")
-os.environ.setdefault("AMD_LOG_LEVEL", "1")
-os.environ.setdefault("AMD_LOG_LEVEL_FILE", os.path.join(_LOG_DIR, "amd_log_tests.txt"))
+try:
+    os.makedirs(_LOG_DIR, exist_ok=True)
+    os.environ.setdefault("AMD_LOG_LEVEL", "1")
+    os.environ.setdefault("AMD_LOG_LEVEL_FILE", os.path.join(_LOG_DIR, "amd_log_tests.txt"))
+except OSError:                                                       # a read-only checkout: the runtime keeps its defaults
+    pass
 os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
 
 
