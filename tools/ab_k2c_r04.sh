@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON the GPU box: the single-end step (K1 + K2b + staged K2c) of the round-4 tree (build/r04tree = `git archive 1631e56`, built in
+# Runs ON the GPU box: the single-end step (K1 + K2b + staged K2c) of the round-4 tree (build/r04tree: `mkdir -p build/r04tree && git archive 1631e56 | tar -x -C build/r04tree && (cd build/r04tree && python -m xenomapper_amd.build)`, built in
 # place) against the current tree, alternating on one box -- whether anything is left of round 5's K2c regression.
 cd "$(dirname "$0")/.."
 ARGS="--workload se --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-verify --no-extra-workloads"

@@ -26,7 +26,7 @@ cat "$OUT/${TAG}_bam_kernel_stats.csv"
 tail -1 "$OUT/bench_bam.json" | cut -c1-300
 # the timed (second) pass as the GPU saw it: busy time, share per kernel, overlap, idle gaps (tools/trace_gaps.py)
 T=$(find "$OUT/bam" -name "*kernel_trace.csv" | head -1)
-python3 "$ROOT/tools/trace_gaps.py" "$T" --second-pass --top 14 > "$OUT/${TAG}_bam_timeline.txt" 2>&1
+python3 "$ROOT/tools/trace_gaps.py" "$T" --second-pass --top 14 --timeline 90 > "$OUT/${TAG}_bam_timeline.txt" 2>&1
 cat "$OUT/${TAG}_bam_timeline.txt"
 rm -f "$T"
 echo done

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--top", type=int, default=12)
     ap.add_argument("--second-pass", action="store_true", help="only the second half of the trace by launches of inflate_kernel")
+    ap.add_argument("--timeline", type=int, default=0, help="also list the first N launches of at least --min-us, with start and end")
+    ap.add_argument("--min-us", type=float, default=200.0)
     a = ap.parse_args()
     rows = []
     with open(a.trace) as fh:
@@ -54,6 +56,15 @@ def main():
           ((t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0), (t1 - t0 - busy) / 1e6, len(gaps), sum(v[0] for v in per.values()) / 1e6))
     for name, (ns, calls) in sorted(per.items(), key=lambda kv: -kv[1][0])[:a.top]:
         print("  %-48s %5d calls %9.2f ms  %5.1f %% of busy  mean %8.1f us" % (name, calls, ns / 1e6, 100.0 * ns / busy, ns / calls / 1e3))
+    if a.timeline:
+        print("timeline (ms from the first launch; launches of >= %.0f us):" % a.min_us)
+        shown = 0
+        for s_, e_, name in rows:
+            if (e_ - s_) / 1e3 >= a.min_us:
+                print("  %9.2f .. %9.2f  %8.2f ms  %s" % ((s_ - t0) / 1e6, (e_ - t0) / 1e6, (e_ - s_) / 1e6, name))
+                shown += 1
+                if shown >= a.timeline:
+                    break
     print("longest idle gaps:")
     for g, at, before, after in sorted(gaps, reverse=True)[:a.top]:
         print("  %8.2f ms at %8.1f ms  after %-32s before %s" % (g / 1e6, at / 1e6, before, after))

@@ -221,21 +221,42 @@ struct RefTable {
     uint32_t n;
 };
 
+// Where the printer reads a record from: the inflated window in global memory, by unaligned loads of 1 to 16 bytes.  Positions count
+// from the byte behind the record's block_size word.
+typedef uint32_t v4u32_any __attribute__((ext_vector_type(4), aligned(1)));
+struct GlobalRec {
+    const uint8_t *r;
+    __device__ __forceinline__ uint32_t u8(uint32_t p) const { return r[p]; }
+    __device__ __forceinline__ uint32_t u16(uint32_t p) const { return ld16(r + p); }
+    __device__ __forceinline__ uint32_t u32(uint32_t p) const { return ld32(r + p); }
+    __device__ __forceinline__ v4u32_any u128(uint32_t p) const { return *reinterpret_cast<const v4u32_any *>(r + p); }
+};
+__device__ __forceinline__ uint32_t base_letter(uint32_t code)          // "=ACMGRSVTWYHKDBN"
+{
+    const unsigned long long lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;
+    return (uint32_t)(((code < 8u ? lo : hi) >> (8u * (code & 7u))) & 0xFFu);
+}
+
 struct CountChars {
     uint32_t n = 0;
     __device__ __forceinline__ void ch(uint32_t) { ++n; }
-    __device__ __forceinline__ void bytes(const uint8_t *, uint32_t len) { n += len; }
-    __device__ __forceinline__ void seq(const uint8_t *, uint32_t len) { n += len; }
-    __device__ __forceinline__ void qual(const uint8_t *, uint32_t len) { n += len; }
+    __device__ __forceinline__ void gbytes(const uint8_t *, uint32_t len) { n += len; }
+    template <typename R> __device__ __forceinline__ void bytes(const R &, uint32_t, uint32_t len) { n += len; }
+    template <typename R> __device__ __forceinline__ void seq(const R &, uint32_t, uint32_t len) { n += len; }
+    template <typename R> __device__ __forceinline__ void qual(const R &, uint32_t, uint32_t len) { n += len; }
 };
 
 struct __attribute__((packed, aligned(1))) U32Store { uint32_t v; };
-// bytes gathered four at a time: a lane's line is written with (unaligned) dword stores -- a store instruction of 64 lanes touches 64
-// cache lines whatever its width
+// A lane writes its line front to back, reading its record front to back: 64 lanes = 64 streams, every access a cache line of its
+// own.  With 100 000 lanes in flight no line survives in a cache between two touches, so HBM traffic is (accesses x sector), not
+// bytes: with four bytes per access G2 fetched 11.4 GB and wrote 5.0 GB per window for 0.55 GB of records and 0.9 GB of text (PMC,
+// profiles/r06_bam_pmc.txt).  Hence the long fields -- bases, qualities, names: 3/4 of a line -- move SIXTEEN bytes per access
+// (unaligned dwordx4 on both sides); the short ones are gathered four at a time.
 struct WriteChars {
     uint8_t *o;
     unsigned long long acc = 0;
     uint32_t k = 0;                              // bytes waiting in acc (< 4 between calls)
+    uint32_t wide_min = 16u;                     // A/B: 0xFFFFFFFF switches the 16-byte paths off
     __device__ __forceinline__ void word(uint32_t w, uint32_t n_bytes)          // n_bytes <= 4, the bytes above them zero
     {
         acc |= (unsigned long long)w << (8u * k);
@@ -247,40 +268,72 @@ struct WriteChars {
             k -= 4u;
         }
     }
+    __device__ __forceinline__ void wide(const v4u32_any &v)                    // 16 bytes at once, behind the bytes still waiting
+    {
+        for (uint32_t j = 0; j < k; ++j) o[j] = (uint8_t)(acc >> (8u * j));
+        o += k;
+        k = 0;
+        acc = 0;
+        *reinterpret_cast<v4u32_any *>(o) = v;
+        o += 16;
+    }
     __device__ __forceinline__ void ch(uint32_t c) { word(c & 0xFFu, 1u); }
-    __device__ __forceinline__ void bytes(const uint8_t *p, uint32_t len)
+    __device__ __forceinline__ void gbytes(const uint8_t *p, uint32_t len)
     {
         uint32_t j = 0;
         for (; j + 4u <= len; j += 4u) word(ld32(p + j), 4u);
         for (; j < len; ++j) word(p[j], 1u);
     }
-    __device__ __forceinline__ void seq(const uint8_t *p, uint32_t len)
+    template <typename R> __device__ __forceinline__ void bytes(const R &rec, uint32_t p, uint32_t len)
     {
-        // "=ACMGRSVTWYHKDBN", eight letters a word; two bases a byte, the first in the high nibble
-        const unsigned long long lo = 0x565352474D43413Dull, hi = 0x4E42444B48595754ull;
         uint32_t j = 0;
-        for (; j + 4u <= len; j += 4u) {
-            const uint32_t two = ld16(p + (j >> 1));
-            uint32_t w = 0;
-            for (uint32_t q = 0; q < 4u; ++q) {
-                const uint32_t code = (two >> (8u * (q >> 1) + ((q & 1u) ? 0u : 4u))) & 15u;
-                w |= (uint32_t)(((code < 8u ? lo : hi) >> (8u * (code & 7u))) & 0xFFu) << (8u * q);
+        for (; j + 16u <= len && wide_min == 16u; j += 16u) wide(rec.u128(p + j));
+        for (; j + 4u <= len; j += 4u) word(rec.u32(p + j), 4u);
+        for (; j < len; ++j) word(rec.u8(p + j), 1u);
+    }
+    template <typename R> __device__ __forceinline__ void seq(const R &rec, uint32_t p, uint32_t len)
+    {
+        // two bases a byte, the first in the high nibble; 16 bytes of them are 32 letters
+        uint32_t j = 0;
+        for (; j + 32u <= len && wide_min == 16u; j += 32u) {
+            const v4u32_any in = rec.u128(p + (j >> 1));
+            uint32_t w8[8];
+#pragma unroll
+            for (uint32_t d = 0; d < 4u; ++d) {
+                const uint32_t x = in[d];
+                w8[2u * d] = base_letter((x >> 4) & 15u) | (base_letter(x & 15u) << 8) | (base_letter((x >> 12) & 15u) << 16) |
+                             (base_letter((x >> 8) & 15u) << 24);
+                w8[2u * d + 1u] = base_letter((x >> 20) & 15u) | (base_letter((x >> 16) & 15u) << 8) | (base_letter(x >> 28) << 16) |
+                                  (base_letter((x >> 24) & 15u) << 24);
             }
+            v4u32_any a, b;
+            a[0] = w8[0]; a[1] = w8[1]; a[2] = w8[2]; a[3] = w8[3];
+            b[0] = w8[4]; b[1] = w8[5]; b[2] = w8[6]; b[3] = w8[7];
+            wide(a);
+            wide(b);
+        }
+        for (; j + 4u <= len; j += 4u) {
+            const uint32_t two = rec.u16(p + (j >> 1));
+            uint32_t w = 0;
+            for (uint32_t q = 0; q < 4u; ++q) w |= base_letter((two >> (8u * (q >> 1) + ((q & 1u) ? 0u : 4u))) & 15u) << (8u * q);
             word(w, 4u);
         }
-        for (; j < len; ++j) {
-            const uint32_t code = (p[j >> 1] >> ((j & 1u) ? 0u : 4u)) & 15u;
-            word((uint32_t)(((code < 8u ? lo : hi) >> (8u * (code & 7u))) & 0xFFu), 1u);
-        }
+        for (; j < len; ++j) word(base_letter((rec.u8(p + (j >> 1)) >> ((j & 1u) ? 0u : 4u)) & 15u), 1u);
     }
-    __device__ __forceinline__ void qual(const uint8_t *p, uint32_t len)
+    template <typename R> __device__ __forceinline__ void qual(const R &rec, uint32_t p, uint32_t len)
     {
         uint32_t j = 0;
+        for (; j + 16u <= len && wide_min == 16u; j += 16u) {
+            v4u32_any q = rec.u128(p + j);
+#pragma unroll
+            for (uint32_t d = 0; d < 4u; ++d) q[d] = ((q[d] & 0x7F7F7F7Fu) + 0x21212121u) ^ (q[d] & 0x80808080u);
+            wide(q);
+        }
         for (; j + 4u <= len; j += 4u) {
-            const uint32_t q4 = ld32(p + j);
+            const uint32_t q4 = rec.u32(p + j);
             word(((q4 & 0x7F7F7F7Fu) + 0x21212121u) ^ (q4 & 0x80808080u), 4u);          // + 33 in every byte, no carry across bytes
         }
-        for (; j < len; ++j) word((p[j] + 33u) & 0xFFu, 1u);
+        for (; j < len; ++j) word((rec.u8(p + j) + 33u) & 0xFFu, 1u);
     }
     __device__ __forceinline__ void finish() { for (uint32_t j = 0; j < k; ++j) o[j] = (uint8_t)(acc >> (8u * j)); }
 };
@@ -308,20 +361,20 @@ template <typename S> __device__ __forceinline__ void put_i32(S &s, int32_t v)
     if (v < 0) { s.ch('-'); put_u32(s, (uint32_t)(-(v + 1)) + 1u); } else put_u32(s, (uint32_t)v);
 }
 
-// one value of type t at r + p (inside the record: parse_record has walked the fields): false = a type this printer leaves to the host
-template <typename S> __device__ __forceinline__ bool put_scalar(S &s, const uint8_t *r, uint32_t &p, uint32_t t)
+// one value of type t at position p of the record (parse_record has walked the fields): false = a type this printer leaves to the host
+template <typename R, typename S> __device__ __forceinline__ bool put_scalar(S &s, const R &rec, uint32_t &p, uint32_t t)
 {
     switch (t) {
-    case 'A': s.ch(r[p]); p += 1u; return true;
-    case 'c': put_i32(s, (int8_t)r[p]); p += 1u; return true;
-    case 'C': put_u32(s, r[p]); p += 1u; return true;
-    case 's': put_i32(s, (int16_t)ld16(r + p)); p += 2u; return true;
-    case 'S': put_u32(s, ld16(r + p)); p += 2u; return true;
-    case 'i': put_i32(s, (int32_t)ld32(r + p)); p += 4u; return true;
-    case 'I': put_u32(s, ld32(r + p)); p += 4u; return true;
+    case 'A': s.ch(rec.u8(p)); p += 1u; return true;
+    case 'c': put_i32(s, (int8_t)rec.u8(p)); p += 1u; return true;
+    case 'C': put_u32(s, rec.u8(p)); p += 1u; return true;
+    case 's': put_i32(s, (int16_t)rec.u16(p)); p += 2u; return true;
+    case 'S': put_u32(s, rec.u16(p)); p += 2u; return true;
+    case 'i': put_i32(s, (int32_t)rec.u32(p)); p += 4u; return true;
+    case 'I': put_u32(s, rec.u32(p)); p += 4u; return true;
     case 'f': {                                  // printf("%g") of the value, exact (xm_fmtg.h)
-        const xmfmt::Text16 t = xmfmt::fmt_g_f32(ld32(r + p));
-        for (uint32_t k = 0; k < t.n; ++k) s.ch(t.at(k));
+        const xmfmt::Text16 t16 = xmfmt::fmt_g_f32(rec.u32(p));
+        for (uint32_t k = 0; k < t16.n; ++k) s.ch(t16.at(k));
         p += 4u;
         return true;
     }
@@ -329,28 +382,26 @@ template <typename S> __device__ __forceinline__ bool put_scalar(S &s, const uin
     }
 }
 
-// the record whose block_size word is at raw + off -> its SAM line with the '\n'; false: leave the record to the host printer
-template <typename S> __device__ bool sam_line(const uint8_t *__restrict__ raw, uint32_t off, const RefTable refs, S &s)
+// the record of `size` bytes behind its block_size word -> its SAM line with the '\n'; false: leave the record to the host printer
+template <typename R, typename S> __device__ bool sam_line(const R &rec, uint32_t size, const RefTable refs, S &s)
 {
-    const uint32_t size = ld32(raw + off);
-    const uint8_t *r = raw + off + 4u;
-    const int32_t ref_id = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
-    const uint32_t l_read_name = r[8], mapq = r[9], n_cigar = ld16(r + 12), flag = ld16(r + 14), l_seq = ld32(r + 16);
-    const int32_t next_ref = (int32_t)ld32(r + 20), next_pos = (int32_t)ld32(r + 24), tlen = (int32_t)ld32(r + 28);
+    const int32_t ref_id = (int32_t)rec.u32(0), pos = (int32_t)rec.u32(4);
+    const uint32_t l_read_name = rec.u8(8), mapq = rec.u8(9), n_cigar = rec.u16(12), flag = rec.u16(14), l_seq = rec.u32(16);
+    const int32_t next_ref = (int32_t)rec.u32(20), next_pos = (int32_t)rec.u32(24), tlen = (int32_t)rec.u32(28);
     uint32_t p = 32u, nl = 0;
-    while (nl < l_read_name && r[p + nl] != 0u) ++nl;
-    s.bytes(r + p, nl);
+    while (nl < l_read_name && rec.u8(p + nl) != 0u) ++nl;
+    s.bytes(rec, p, nl);
     p += l_read_name;
     s.ch('\t'); put_u32(s, flag);
     s.ch('\t');
     if (ref_id < 0 || (uint32_t)ref_id >= refs.n) s.ch('*');
-    else s.bytes(refs.names + refs.at[ref_id], refs.at[ref_id + 1] - refs.at[ref_id]);
+    else s.gbytes(refs.names + refs.at[ref_id], refs.at[ref_id + 1] - refs.at[ref_id]);
     s.ch('\t'); put_i64(s, (long long)pos + 1);
     s.ch('\t'); put_u32(s, mapq);
     s.ch('\t');
     if (n_cigar == 0u) s.ch('*');
     for (uint32_t k = 0; k < n_cigar; ++k) {
-        const uint32_t v = ld32(r + p + 4u * k);
+        const uint32_t v = rec.u32(p + 4u * k);
         put_u32(s, v >> 4);
         const unsigned long long lo = 0x3D5048534E44494Dull, hi = 0x3F3F3F3F3F3F4258ull;               // "MIDNSHP=" "XB??????"
         s.ch((uint32_t)((((v & 8u) ? hi : lo) >> (8u * (v & 7u))) & 0xFFu));
@@ -359,38 +410,45 @@ template <typename S> __device__ bool sam_line(const uint8_t *__restrict__ raw, 
     s.ch('\t');
     if (next_ref < 0 || (uint32_t)next_ref >= refs.n) s.ch('*');
     else if (next_ref == ref_id) s.ch('=');
-    else s.bytes(refs.names + refs.at[next_ref], refs.at[next_ref + 1] - refs.at[next_ref]);
+    else s.gbytes(refs.names + refs.at[next_ref], refs.at[next_ref + 1] - refs.at[next_ref]);
     s.ch('\t'); put_i64(s, (long long)next_pos + 1);
     s.ch('\t'); put_i32(s, tlen);
     s.ch('\t');
     if (l_seq == 0u) s.ch('*');
-    s.seq(r + p, l_seq);
+    s.seq(rec, p, l_seq);
     p += (l_seq + 1u) / 2u;
     s.ch('\t');
-    if (l_seq == 0u || r[p] == 0xFFu) s.ch('*'); else s.qual(r + p, l_seq);
+    if (l_seq == 0u || rec.u8(p) == 0xFFu) s.ch('*'); else s.qual(rec, p, l_seq);
     p += l_seq;
     while (p + 3u <= size) {
-        const uint32_t type = r[p + 2];
-        s.ch('\t'); s.ch(r[p]); s.ch(r[p + 1]); s.ch(':');
+        const uint32_t type = rec.u8(p + 2);
+        s.ch('\t'); s.ch(rec.u8(p)); s.ch(rec.u8(p + 1)); s.ch(':');
         p += 3u;
-        if (type == 'A') { s.ch('A'); s.ch(':'); put_scalar(s, r, p, 'A'); }
-        else if (type == 'c' || type == 'C' || type == 's' || type == 'S' || type == 'i' || type == 'I') { s.ch('i'); s.ch(':'); put_scalar(s, r, p, type); }
-        else if (type == 'f') { s.ch('f'); s.ch(':'); put_scalar(s, r, p, 'f'); }
+        if (type == 'A') { s.ch('A'); s.ch(':'); put_scalar(s, rec, p, 'A'); }
+        else if (type == 'c' || type == 'C' || type == 's' || type == 'S' || type == 'i' || type == 'I') { s.ch('i'); s.ch(':'); put_scalar(s, rec, p, type); }
+        else if (type == 'f') { s.ch('f'); s.ch(':'); put_scalar(s, rec, p, 'f'); }
         else if (type == 'Z' || type == 'H') {
             s.ch(type); s.ch(':');
             uint32_t l = 0;
-            while (p + l < size && r[p + l] != 0u) ++l;
-            s.bytes(r + p, l);
+            while (p + l < size && rec.u8(p + l) != 0u) ++l;
+            s.bytes(rec, p, l);
             p += l + 1u;
         } else if (type == 'B') {
-            const uint32_t sub = r[p], cnt = ld32(r + p + 1);
+            const uint32_t sub = rec.u8(p), cnt = rec.u32(p + 1);
             p += 5u;
             s.ch('B'); s.ch(':'); s.ch(sub);
-            for (uint32_t k = 0; k < cnt; ++k) { s.ch(','); if (!put_scalar(s, r, p, sub)) return false; }
+            for (uint32_t k = 0; k < cnt; ++k) { s.ch(','); if (!put_scalar(s, rec, p, sub)) return false; }
         } else return false;                                                 // d: the host prints what printf("%g") would
     }
     s.ch('\n');
     return true;
+}
+
+// the record whose block_size word is at raw + off, read where it lies in the window
+template <typename S> __device__ __forceinline__ bool sam_line_at(const uint8_t *__restrict__ raw, uint32_t off, const RefTable refs, S &s)
+{
+    const GlobalRec rec = {raw + off + 4u};
+    return sam_line(rec, ld32(raw + off), refs, s);
 }
 
 // T1: wsize[i] (want_kernel: the record's bytes when a sink takes it, else 0) becomes the length of its line; state[13] != 0: a
@@ -402,7 +460,7 @@ text_size_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ r
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n || wsize[i] == 0u) return;
     CountChars c;
-    if (!sam_line(raw, rec_off[i], refs, c)) atomicOr(&state[13], 1u);
+    if (!sam_line_at(raw, rec_off[i], refs, c)) atomicOr(&state[13], 1u);
     wsize[i] = c.n;
 }
 
@@ -417,7 +475,7 @@ text_fill_kernel(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ r
     if (len == 0u || at == NO_RECORD || at + len > text_cap) { wsize[i] = 0u; place[i] = 0u; return; }
     WriteChars w;
     w.o = text + at;
-    (void)sam_line(raw, rec_off[i], refs, w);
+    (void)sam_line_at(raw, rec_off[i], refs, w);
     w.finish();
     wsize[i] = len - 1u;
 }
@@ -451,13 +509,18 @@ unit_size_kernel(const uint32_t *__restrict__ idx, const unsigned long long *__r
     if ((threadIdx.x & 63u) == 0u && t) atomicAdd(total64, t);
 }
 
-// G2: a lane per (unit, line of the unit): paired units have two lines per file, single-end units one
+// G2: a lane per (unit, line of the unit): paired units have two lines per file, single-end units one.
+// (Round 6 also built a form that stages a wave's 64 records and lines in LDS -- coalesced 16-byte copies in and out, the printing
+// LDS to LDS a byte at a time: byte-exact, and slower: ~8 ms a window against 6.1, the byte-wise LDS round trips are a dependent
+// chain of ~800 steps per lane, and its 53 KB of LDS per wave cannot start beside the inflate chains, which hold 158 of a CU's
+// 160 KB.  profiles/r06_ab_fill_stage.txt.)
 __global__ void __launch_bounds__(256)
 line_fill_kernel(const uint8_t *__restrict__ raw1, const uint8_t *__restrict__ raw2, const uint32_t *__restrict__ rec_off1,
                  const uint32_t *__restrict__ rec_off2, const RefTable refs1, const RefTable refs2,
                  const uint32_t *__restrict__ idx, const unsigned long long *__restrict__ off, uint32_t n_units, uint32_t n_records, int paired,
                  uint32_t sink_mask, const uint32_t *__restrict__ ws1, const uint32_t *__restrict__ ws2,
-                 const uint32_t *__restrict__ usize, const uint32_t *__restrict__ uplace, uint8_t *__restrict__ out, uint32_t out_cap)
+                 const uint32_t *__restrict__ usize, const uint32_t *__restrict__ uplace, uint8_t *__restrict__ out, uint32_t out_cap,
+                 uint32_t wide_min)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t p = paired ? g >> 1 : g, j = paired ? g & 1u : 0u;
@@ -476,7 +539,8 @@ line_fill_kernel(const uint8_t *__restrict__ raw1, const uint8_t *__restrict__ r
         if (mine != 0u) {
             WriteChars w;
             w.o = out + at + (j ? first : 0u);
-            (void)sam_line(f ? raw2 : raw1, (f ? rec_off2 : rec_off1)[r], f ? refs2 : refs1, w);
+            w.wide_min = wide_min;
+            (void)sam_line_at(f ? raw2 : raw1, (f ? rec_off2 : rec_off1)[r], f ? refs2 : refs1, w);
             w.finish();
         }
         at += first + ws[i];                                                       // behind file 1's lines of the unit: file 2's
@@ -1523,7 +1587,8 @@ int xm_bamdev_fetch_bins(xm_bamdev *b, int slot, uint64_t n_records, int paired,
     for (int k = 0; k < 8; ++k) out->bin_off[k] = sl.h_state[16 + k];
     line_fill_kernel<<<((paired ? 2u : 1u) * n_units + 255u) / 256u, 256, 0, st>>>(
         sl.pf[0].d_raw, sl.pf[1].d_raw, sl.pf[0].v_rec_off, sl.pf[1].v_rec_off, refs[0], refs[1], sl.d_idx, d_off, n_units, n, paired ? 1 : 0, sink_mask,
-        sl.pf[0].d_wsize, sl.pf[1].d_wsize, sl.d_usize, sl.d_uplace, sl.d_packed_all, (uint32_t)out_cap);
+        sl.pf[0].d_wsize, sl.pf[1].d_wsize, sl.d_usize, sl.d_uplace, sl.d_packed_all, (uint32_t)out_cap,
+        []() -> uint32_t { static const bool off = [] { const char *v = getenv("XM_BAMDEV_FILL_WIDE"); return v && v[0] == '0'; }(); return off ? 0xFFFFFFFFu : 16u; }());
     // the stream goes to the host on the copy stream behind the kernels (beside the next window's inflate launch on the other slot)
     XMB_HIP(b, hipEventRecord(sl.ev_inflated, st));
     XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
@@ -1532,7 +1597,7 @@ int xm_bamdev_fetch_bins(xm_bamdev *b, int slot, uint64_t n_records, int paired,
         if (wg == 0u) XMB_HIP(b, hipMemcpyAsync(sl.h_packed_all, sl.d_packed_all, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
         else {
             const uint64_t n16 = (total + 15u) / 16u;                       // (the buffers end 64 bytes behind out_cap)
-            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(wg, (n16 + 255u) / 256u), 256, 0, sl.copy_stream>>>(
+            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(4u * wg, (n16 + 63u) / 64u), 64, 0, sl.copy_stream>>>(
                 reinterpret_cast<const v4u32 *>(sl.d_packed_all), reinterpret_cast<v4u32 *>(sl.h_packed_all), n16);
         }
     }

@@ -90,14 +90,23 @@ bin_start_kernel(const uint32_t *__restrict__ uplace, const unsigned long long *
 
 // G3: the stream to the host's page-locked buffer (device-mapped), 16 bytes per lane and step, both sides 16-byte aligned.  Its own
 // kernel instead of hipMemcpyAsync, whose shader blit takes whatever share of the chip it likes beside the next window's inflate
-// launch: this one is a fixed, small number of workgroups (XM_BAMDEV_COPY_WG), each streaming its contiguous share.
+// launch: this one is a fixed, small number of ONE-WAVE workgroups (XM_BAMDEV_COPY_WG of them x 4), each streaming its contiguous
+// share with four pieces per lane in flight.  One wave per workgroup because the inflate launch beside it is persistent and holds
+// every wave slot its LDS allows -- 31 of a CU's 32: a single wave finds the free slot at once, a workgroup of four waits until four
+// chains on one CU have run out of blocks, i.e. for the end of the launch it was meant to run beside.
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 out_copy_kernel(const v4u32 *__restrict__ src, v4u32 *__restrict__ dst, uint64_t n16)
 {
     const uint64_t per = (n16 + gridDim.x - 1u) / gridDim.x;
     const uint64_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
-    for (uint64_t k = lo + threadIdx.x; k < hi; k += 256u) dst[k] = __builtin_nontemporal_load(src + k);
+    uint64_t k = lo + threadIdx.x;
+    for (; k + 192u < hi; k += 256u) {
+        const v4u32 a = __builtin_nontemporal_load(src + k), b = __builtin_nontemporal_load(src + k + 64u),
+                    c = __builtin_nontemporal_load(src + k + 128u), d = __builtin_nontemporal_load(src + k + 192u);
+        dst[k] = a; dst[k + 64u] = b; dst[k + 128u] = c; dst[k + 192u] = d;
+    }
+    for (; k < hi; k += 64u) dst[k] = __builtin_nontemporal_load(src + k);
 }
 
 // Workgroups of out_copy_kernel.  Measured on the BAM path (4.5 GB of BAM -> 9.8 GB of text to /dev/null, same box, two runs each,

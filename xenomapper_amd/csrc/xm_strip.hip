@@ -1429,7 +1429,7 @@ int xm_strip_fetch_bins(xm_strip *s, int slot, uint64_t n_records, int paired, u
         if (wg == 0u) XMS_HIP(s, hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
         else {
             const uint64_t n16 = (total + 15u) / 16u;
-            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(wg, (n16 + 255u) / 256u), 256, 0, sl.copy_stream>>>(
+            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(4u * wg, (n16 + 63u) / 64u), 64, 0, sl.copy_stream>>>(
                 reinterpret_cast<const v4u32 *>(sl.d_out), reinterpret_cast<v4u32 *>(sl.h_out), n16);
         }
     }
