@@ -482,3 +482,36 @@ def test_outputs_gathered_on_the_device_equal_the_oracle_and_the_host_writer(tmp
                 assert prof.get("sam_windows_device_bins", 0) == prof["sam_windows"], prof
             else:
                 assert 0 < prof.get("sam_windows_device_bins", 0) < prof["sam_windows"], prof
+
+
+def test_overlapping_units_outgrow_the_output_stream_and_go_to_the_host_writer(tmp_path, monkeypatch):
+    """Every record carries the same name, so every record closes a unit with the one in front (xenomapper.py:402-405: `previous`
+    always advances) and every line is printed twice; with equal scores in both files every unit is `unresolved` and prints from BOTH
+    files (:439-444): four times the text of a window, twice what the device's output stream holds -- xm_strip_fetch_bins declines
+    (status 2), the host writer takes those windows, and the outputs equal the oracle's.  The same file with only the
+    primary-specific sink given fits and stays on the device."""
+    import io
+    from tests import helpers as H
+    from tests.test_file_fuzz_gpu import oracle_run, SCORERS
+    from xenomapper_amd import xenomapper as xm
+    monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 1 << 20)
+    line = "samename\t%d\tchr1\t%d\t30\t50M\t=\t%d\t0\t" + "ACGT" * 12 + "AC\t" + "F" * 50 + "\tAS:i:-5\tXS:i:-9\n"
+    text = "".join(line % (99 if k % 2 == 0 else 147, 100 + k, 300 + k) for k in range(40_000))
+    paths = []
+    for k in (0, 1):
+        p = tmp_path / ("o%d.sam" % k)
+        p.write_text(text)
+        paths.append(str(p))
+    want_texts, want_counts, want_err = oracle_run(text, text, "pe", SCORERS["get_tag"], H.NEG, False)
+    assert want_err is None and sum(want_counts.values()) == 39_999 and len(want_texts[H.STATES.index("unresolved")]) > 4 * len(text) - 1000
+    outs = {name: io.StringIO() for name in H.STATES}
+    counts = xm.classify_sam_files(paths[0], paths[1], paired=True, **outs)
+    prof = dict(xm.LAST_FILE_PROFILE)
+    assert dict(counts) == dict(want_counts)
+    assert [outs[name].getvalue() for name in H.STATES] == want_texts
+    assert prof.get("sam_windows", 0) >= 3 and prof.get("sam_windows_device_bins", 0) < prof["sam_windows"], prof
+    # one sink only: nothing of `unresolved` is printed, the stream is empty and fits
+    only = io.StringIO()
+    counts = xm.classify_sam_files(paths[0], paths[1], primary_specific=only, paired=True)
+    assert dict(counts) == dict(want_counts) and only.getvalue() == want_texts[0]
+    assert xm.LAST_FILE_PROFILE.get("sam_windows_device_bins", 0) == xm.LAST_FILE_PROFILE.get("sam_windows", -1)

@@ -382,14 +382,34 @@ template <typename R, typename S> __device__ __forceinline__ bool put_scalar(S &
     }
 }
 
+// bytes in front of the first NUL at or behind position p, `limit` at most: sixteen bytes per access (the exact SWAR zero-byte test:
+// borrows only run upwards, so the LOWEST flagged byte of a word is a true zero)
+template <typename R> __device__ __forceinline__ uint32_t span_to_nul(const R &rec, uint32_t p, uint32_t limit)
+{
+    for (uint32_t at = 0; at < limit; at += 16u) {
+        const v4u32_any v = rec.u128(p + at);
+#pragma unroll
+        for (uint32_t d = 0; d < 4u; ++d) {
+            const uint32_t z = (v[d] - 0x01010101u) & ~v[d] & 0x80808080u;
+            if (z != 0u) {
+                const uint32_t found = at + 4u * d + ((uint32_t)__builtin_ctz(z) >> 3);
+                return found < limit ? found : limit;
+            }
+        }
+    }
+    return limit;
+}
+
 // the record of `size` bytes behind its block_size word -> its SAM line with the '\n'; false: leave the record to the host printer
 template <typename R, typename S> __device__ bool sam_line(const R &rec, uint32_t size, const RefTable refs, S &s)
 {
-    const int32_t ref_id = (int32_t)rec.u32(0), pos = (int32_t)rec.u32(4);
-    const uint32_t l_read_name = rec.u8(8), mapq = rec.u8(9), n_cigar = rec.u16(12), flag = rec.u16(14), l_seq = rec.u32(16);
-    const int32_t next_ref = (int32_t)rec.u32(20), next_pos = (int32_t)rec.u32(24), tlen = (int32_t)rec.u32(28);
-    uint32_t p = 32u, nl = 0;
-    while (nl < l_read_name && rec.u8(p + nl) != 0u) ++nl;
+    // the 32 fixed bytes in two accesses (refID, pos, l_read_name, mapq, bin, n_cigar_op, flag | l_seq, next_refID, next_pos, tlen)
+    const v4u32_any c0 = rec.u128(0), c1 = rec.u128(16);
+    const int32_t ref_id = (int32_t)c0[0], pos = (int32_t)c0[1];
+    const uint32_t l_read_name = c0[2] & 0xFFu, mapq = (c0[2] >> 8) & 0xFFu, n_cigar = c0[3] & 0xFFFFu, flag = c0[3] >> 16, l_seq = c1[0];
+    const int32_t next_ref = (int32_t)c1[1], next_pos = (int32_t)c1[2], tlen = (int32_t)c1[3];
+    uint32_t p = 32u;
+    const uint32_t nl = span_to_nul(rec, p, l_read_name);
     s.bytes(rec, p, nl);
     p += l_read_name;
     s.ch('\t'); put_u32(s, flag);
@@ -421,16 +441,15 @@ template <typename R, typename S> __device__ bool sam_line(const R &rec, uint32_
     if (l_seq == 0u || rec.u8(p) == 0xFFu) s.ch('*'); else s.qual(rec, p, l_seq);
     p += l_seq;
     while (p + 3u <= size) {
-        const uint32_t type = rec.u8(p + 2);
-        s.ch('\t'); s.ch(rec.u8(p)); s.ch(rec.u8(p + 1)); s.ch(':');
+        const uint32_t head = rec.u32(p), type = (head >> 16) & 0xFFu;         // tag, tag, type (and a byte of the value) in one access
+        s.ch('\t'); s.ch(head & 0xFFu); s.ch((head >> 8) & 0xFFu); s.ch(':');
         p += 3u;
         if (type == 'A') { s.ch('A'); s.ch(':'); put_scalar(s, rec, p, 'A'); }
         else if (type == 'c' || type == 'C' || type == 's' || type == 'S' || type == 'i' || type == 'I') { s.ch('i'); s.ch(':'); put_scalar(s, rec, p, type); }
         else if (type == 'f') { s.ch('f'); s.ch(':'); put_scalar(s, rec, p, 'f'); }
         else if (type == 'Z' || type == 'H') {
             s.ch(type); s.ch(':');
-            uint32_t l = 0;
-            while (p + l < size && rec.u8(p + l) != 0u) ++l;
+            const uint32_t l = span_to_nul(rec, p, size > p ? size - p : 0u);
             s.bytes(rec, p, l);
             p += l + 1u;
         } else if (type == 'B') {
@@ -634,10 +653,22 @@ struct FileRecs {
     const uint8_t *flag;
 };
 
+// n bytes at p and at q equal?  Sixteen bytes per access (unaligned dwordx4; the last access may reach up to 15 bytes behind the
+// names -- still inside the window, whose buffer ends 64 bytes behind its last record): a byte at a time, every byte of the three
+// names a lane compares was a sector of its own to fetch, 4.3 GB per window (PMC, profiles/r06_bam_pmc.txt).
 __device__ __forceinline__ bool same_name(const uint8_t *p, const uint8_t *q, uint32_t n)
 {
     uint32_t diff = 0;
-    for (uint32_t k = 0; k < n; ++k) diff |= (uint32_t)(p[k] ^ q[k]);
+    for (uint32_t k = 0; k < n; k += 16u) {
+        const v4u32_any a = *reinterpret_cast<const v4u32_any *>(p + k), b = *reinterpret_cast<const v4u32_any *>(q + k);
+        const uint32_t rem = n - k;                                          // bytes of this piece that belong to the names (>= 1)
+#pragma unroll
+        for (uint32_t d = 0; d < 4u; ++d) {
+            const uint32_t valid = rem > 4u * d ? (rem - 4u * d < 4u ? rem - 4u * d : 4u) : 0u;
+            const uint32_t mask = valid >= 4u ? 0xFFFFFFFFu : ((1u << (8u * valid)) - 1u);
+            diff |= (a[d] ^ b[d]) & mask;
+        }
+    }
     return diff == 0u;
 }
 
