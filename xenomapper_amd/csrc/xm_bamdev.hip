@@ -791,6 +791,7 @@ struct Slot {
     uint64_t up_len[2] = {0, 0};
     int last_score_mode = XMS_SCORE_AS_XS;   // of the last run: which columns xm_bamdev_classify reads
     bool raw_issued = false;                 // ev_raw has been recorded at least once (stays true: waiting for a past event costs nothing)
+    bool fill_issued = false;                // ev_inflated was recorded behind a G2 launch (xm_bamdev_fetch_bins) at least once
     bool have_columns = false;
     bool classified = false;                 // the fused pass has run on the slot's columns (its compact category stream is in d_bins4)
 };
@@ -1146,6 +1147,14 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     // ---- stage: carry, compressed bytes, block tables; inflate + CRC; the record chain --------------------------------
     // this slot's previous window has left d_raw (its copy to the host ended long ago: the caller has printed from it)
     if (sl.raw_issued) XMB_HIP(b, hipStreamWaitEvent(st, sl.ev_raw, 0));
+    {
+        // The OTHER slot's printer (G2 of the window in front) first: beside this window's inflate launch the two take 28 ms + 18 ms
+        // where one after the other they take 6 + 17 (the decoder's window reads wait behind the printer's 6.6 GB of traffic: an
+        // issue-bound launch turns latency-bound); profiles/r06_ab_serial_fill.txt.  XM_BAMDEV_SERIAL_FILL=0: side by side.
+        static const bool serial = [] { const char *v = getenv("XM_BAMDEV_SERIAL_FILL"); return !(v && v[0] == '0'); }();
+        Slot &other = b->slot[slot ^ 1];
+        if (serial && other.fill_issued) XMB_HIP(b, hipStreamWaitEvent(st, other.ev_inflated, 0));
+    }
     XMB_HIP(b, hipEventRecord(sl.ev[0], st));
     for (int f = 0; f < 2; ++f) {
         const xm_bamdev_input &x = in[f];
@@ -1622,6 +1631,7 @@ int xm_bamdev_fetch_bins(xm_bamdev *b, int slot, uint64_t n_records, int paired,
         []() -> uint32_t { static const bool off = [] { const char *v = getenv("XM_BAMDEV_FILL_WIDE"); return v && v[0] == '0'; }(); return off ? 0xFFFFFFFFu : 16u; }());
     // the stream goes to the host on the copy stream behind the kernels (beside the next window's inflate launch on the other slot)
     XMB_HIP(b, hipEventRecord(sl.ev_inflated, st));
+    sl.fill_issued = true;
     XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
     if (total) {
         const uint32_t wg = out_copy_workgroups();
