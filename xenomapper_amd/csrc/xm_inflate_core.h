@@ -277,7 +277,11 @@ struct Chain {
     }
     XMI_HD uint32_t byte_at(uint32_t pos) const       // a byte produced earlier
     {
-#if defined(XMI_GLOBAL_WINDOW) && XMI_DEVICE
+#if defined(XMI_TIMING_NO_FAR_READS)
+        // TIMING ONLY, the bytes are WRONG: every source byte from the ring, none read back from global memory -- what the far
+        // reads cost the launch (tools/ab_inflate_far.sh; round 5 measured 4 ms of 30.6 for the serial token loop)
+        return (uint32_t)m->oring[pos & (ORING - 1u)];
+#elif defined(XMI_GLOBAL_WINDOW) && XMI_DEVICE
         uint32_t b;
         if (pos >= gsafe) {
             b = m->oring[pos & (ORING - 1u)];
