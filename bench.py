@@ -742,6 +742,9 @@ def compact_line(full):
     if e is not None:          # [ms_per_step, median, frac by ms_per_step on its OWN bytes (34 B/pair), verified]: segmented lists, one launch
         w["runs"] = ([_r(e["ms_per_step"]), _r(e.get("ms_per_step_median")), _r(e["roofline_step"]["frac_by_ms_per_step"], 4),
                       e["verified_vs_oracle"]] if "error" not in e else [None, None, None, str(e["error"])[:80]])
+    e = (full.get("workloads") or {}).get("graph")
+    if e is not None:          # [ms_per_step of the same call replayed from a HIP graph, verified]
+        w["graph"] = [_r(e["ms_per_step"]), e["verified_vs_oracle"]] if "error" not in e else [None, str(e["error"])[:80]]
     if w:
         line["workloads"] = w
     e2e = full.get("e2e")
@@ -1069,6 +1072,39 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:                                   # noqa: BLE001
             extra["runs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if default_run and world == 1:
+        # the same fused call captured ONCE into a HIP graph and replayed (the *_dev entry points only enqueue work; a caller that
+        # classifies batch after batch into the same buffers can do this): what the three launches' gaps cost.  Its own entry --
+        # `value` stays the eager call's.
+        try:
+            w5 = Workload("cfg2", ctx, dev, n_pairs, rank, None, 1)
+            ctx.timing_enable(False)                                 # (no event pairs inside the capture)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                            # warm-up outside the capture, as torch asks for
+                for _ in range(3):
+                    w5.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                w5.step()
+            for _ in range(5):
+                graph.replay()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                graph.replay()
+            fence()
+            el5 = time.perf_counter() - t0
+            ok5 = None if args.no_verify else bool(w5.verify())
+            extra["graph"] = {"workload": w5.describe(), "step": w5.call_name() + " captured into a HIP graph, replayed", "steps": 20, "warmup": 5,
+                              "ms_per_step": 1e3 * el5 / 20, "value": w5.units_per_step * 20 / el5, "unit": "read-pairs/s",
+                              "verified_vs_oracle": ok5}
+            del graph, w5
+            torch.cuda.empty_cache()
+        except Exception as e:                                   # noqa: BLE001
+            extra["graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if plain_default:
         try:
             total = 400_000_000 - 400_000_000 % (Workload.PARTS * 32)
