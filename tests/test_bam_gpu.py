@@ -670,3 +670,52 @@ def test_a_float_tag_takes_one_window_to_the_host_printer_not_the_run(tmp_path, 
     assert got[1] == ref[1]
     assert prof.get("bam_windows", 0) >= 4
     assert prof.get("bam_windows_device_text", 0) == prof["bam_windows"] and prof.get("bam_windows_host_text", 0) == 0
+
+
+@pytest.mark.parametrize("damage", ["trailer", "payload"])
+def test_a_block_that_fails_its_crc_is_an_error_with_either_front_end(tmp_path, monkeypatch, damage):
+    """BGZF carries a CRC-32 per block (SAM specification 4.1; htslib checks it, so the reference -- which reads BAM through
+    `samtools view` -- never sees bytes that fail it).  A file whose ONE damaged block still inflates (stored DEFLATE blocks: a
+    flipped payload byte is still a valid stream; or the CRC word of the trailer itself is flipped) must end the run with
+    ValueError on the GPU front end (crc32_kernel against the member trailers) as with the host decoder, and nothing of the
+    damaged window may have been written; the windows in front of it are (several windows: 256 KB each)."""
+    import bench_bam
+    from xenomapper_amd import xenomapper as xm
+    raw = gzip.decompress(open(os.path.join(DATA, "paired_end_testdata_human.bam"), "rb").read())
+    l_text, = __import__("struct").unpack_from("<i", raw, 4)
+    at = 8 + l_text
+    n_ref, = __import__("struct").unpack_from("<i", raw, at)
+    at += 4
+    for _ in range(n_ref):
+        l_name, = __import__("struct").unpack_from("<i", raw, at)
+        at += 4 + l_name + 4
+    head = bench_bam.bgzf_blocks(raw[:at])
+    records = bench_bam.record_aligned_blocks(raw[at:], level=0)                  # stored blocks: every payload byte is literal
+    copies = 12
+    good = head + records * copies + bench_bam.BGZF_EOF
+    # the damaged copy is the ninth: behind several whole windows
+    where = len(head) + 8 * len(records)
+    first_len = __import__("struct").unpack_from("<H", good, where + 16)[0] + 1   # BSIZE + 1 of the first member of that copy
+    bad = bytearray(good)
+    if damage == "trailer":
+        bad[where + first_len - 8] ^= 0x01                                        # the CRC-32 word of the member trailer
+    else:
+        bad[where + 18 + 5 + 200] ^= 0x20                                         # a byte of the stored payload (18 header + 5 stored-block bytes in front)
+    paths = []
+    for name, image in (("ok.bam", good), ("bad.bam", bytes(bad))):
+        p = str(tmp_path / name)
+        with open(p, "wb") as fh:
+            fh.write(image)
+        paths.append(p)
+    monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 256 << 10)
+    monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 256 << 10)
+    clean = run_path([paths[0], paths[0]], gpu=True)
+    assert isinstance(clean[0], dict) and sum(clean[0].values()) == copies * 238
+    for gpu in (True, False):
+        for pair in ([paths[1], paths[0]], [paths[0], paths[1]]):
+            got = run_path(pair, gpu=gpu)
+            assert got[0] == "ValueError", (gpu, damage, got[0])
+            # whatever was written is a prefix of the clean run's outputs, whole lines only, and stops short of the damaged copy
+            for b in range(6):
+                assert clean[1][b].startswith(got[1][b]) and (got[1][b] == "" or got[1][b].endswith("\n"))
+            assert sum(t.count("\n") for t in got[1]) <= 2 * 9 * 238
