@@ -1139,6 +1139,13 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     hipStream_t st = sl.stream;
     static const bool profile = getenv("XM_BAMDEV_PROFILE") != nullptr;
     const bool zero_copy = zero_copy_input();
+    // The block, walk and segment tables (24 + ~110 bytes a block, 4 bytes a segment) are read by the kernels where the host wrote
+    // them -- page-locked, device-mapped -- instead of being copied up first: a copy of 0.1-2 MB is ONE workgroup of the runtime's
+    // blit pulling 4 KB per round trip of the link, 0.3-2.8 ms each and four of them in front of every inflate launch
+    // (profiles/r06_bam_timeline.txt); a chain's own read of its 134 bytes is one round trip per block.  XM_BAMDEV_ZEROCOPY_TABLES=0: copy.
+    static const bool tables_in_place = [] { const char *v = getenv("XM_BAMDEV_ZEROCOPY_TABLES"); return !(v && v[0] == '0'); }();
+    const xm_bgzf_block *blocks_at = tables_in_place ? sl.h_blocks : sl.d_blocks;
+    const xm_bgzf_walk *walk_at = tables_in_place ? sl.h_walk : sl.d_walk;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     double t_staged = 0, t_issued = 0, t_sync1 = 0;
@@ -1235,14 +1242,16 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
         if (x.comp_len > up && !zero_copy)
             XMB_HIP(b, hipMemcpyAsync(q.d_comp + up, q.h_comp + up, (size_t)(x.comp_len - up), hipMemcpyHostToDevice, st));
         sl.up_len[f] = 0;
-        XMB_HIP(b, hipMemcpyAsync(q.d_seg, q.h_seg, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
+        if (!tables_in_place) XMB_HIP(b, hipMemcpyAsync(q.d_seg, q.h_seg, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
     }
     t_staged = since();
     if (n_all) {
-        XMB_HIP(b, hipMemcpyAsync(sl.d_blocks, sl.h_blocks, (size_t)n_all * sizeof(xm_bgzf_block), hipMemcpyHostToDevice, st));
-        XMB_HIP(b, hipMemcpyAsync(sl.d_walk, sl.h_walk, (size_t)n_all * sizeof(xm_bgzf_walk), hipMemcpyHostToDevice, st));
-        int rc = xm_bgzf_inflate_walk_dev(b->ctx, st, zero_copy ? sl.pf[0].h_comp : sl.d_comp_all, sl.d_blocks, n_all, sl.d_raw_all, sl.d_status, sl.d_work, sl.d_walk);
-        if (rc == XM_OK) rc = xm_bgzf_crc32_dev(b->ctx, st, sl.d_raw_all, sl.d_blocks, n_all, sl.d_crc);
+        if (!tables_in_place) {
+            XMB_HIP(b, hipMemcpyAsync(sl.d_blocks, sl.h_blocks, (size_t)n_all * sizeof(xm_bgzf_block), hipMemcpyHostToDevice, st));
+            XMB_HIP(b, hipMemcpyAsync(sl.d_walk, sl.h_walk, (size_t)n_all * sizeof(xm_bgzf_walk), hipMemcpyHostToDevice, st));
+        }
+        int rc = xm_bgzf_inflate_walk_dev(b->ctx, st, zero_copy ? sl.pf[0].h_comp : sl.d_comp_all, blocks_at, n_all, sl.d_raw_all, sl.d_status, sl.d_work, walk_at);
+        if (rc == XM_OK) rc = xm_bgzf_crc32_dev(b->ctx, st, sl.d_raw_all, blocks_at, n_all, sl.d_crc);
         if (rc != XM_OK) return rc;
         XMB_HIP(b, hipMemcpyAsync(sl.h_status, sl.d_status, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
         XMB_HIP(b, hipMemcpyAsync(sl.h_crc, sl.d_crc, (size_t)n_all * 4, hipMemcpyDeviceToHost, st));
@@ -1252,6 +1261,7 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
         const uint32_t n_seg = q.h_summary[8];
+        const uint32_t *seg_at = tables_in_place ? q.h_seg : q.d_seg;
         XMB_HIP(b, hipMemsetAsync(q.d_summary, 0, 8 * sizeof(uint32_t), st));
         if (n_seg) {
             // counts, exits, record starts and fields of the blocks' segments came with the inflate launch; the pieces of the
@@ -1259,16 +1269,16 @@ int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score
             const uint32_t n_carry_seg = q.h_summary[9];
             const uint32_t rec_cap = (uint32_t)std::min<uint64_t>(sl.record_cap, 0xFFFFFFFFull);
             if (n_carry_seg)
-                walk_kernel<false><<<(n_carry_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_carry_seg, q.d_cnt, q.d_exit,
+                walk_kernel<false><<<(n_carry_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, seg_at, n_carry_seg, q.d_cnt, q.d_exit,
                                                                                           nullptr, nullptr, 0u);
-            scan_kernel<<<1, 1024, 0, st>>>(q.d_cnt, q.d_exit, q.d_seg, n_seg, q.d_base, q.d_summary);
+            scan_kernel<<<1, 1024, 0, st>>>(q.d_cnt, q.d_exit, seg_at, n_seg, q.d_base, q.d_summary);
             if (n_carry_seg)
-                walk_kernel<true><<<(n_carry_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, q.d_seg, n_carry_seg, nullptr, nullptr,
+                walk_kernel<true><<<(n_carry_seg + WALK_T - 1u) / WALK_T, WALK_T, 0, st>>>(q.d_raw, (uint32_t)q.raw_len, seg_at, n_carry_seg, nullptr, nullptr,
                                                                                          q.d_base, q.d_rec_off, rec_cap);
             if (n_seg > n_carry_seg) {
                 const SlotArrays sa = {q.d_s_off, q.d_s_name_off, q.d_s_name_len, q.d_s_a, q.d_s_x, q.d_s_flag,
                                        cigar ? q.d_s_ncig : nullptr, cigar ? q.d_s_cig_at : nullptr};
-                gather_kernel<<<(n_seg - n_carry_seg + 3u) / 4u, 256, 0, st>>>(sa, q.d_seg, n_carry_seg, n_seg, q.d_cnt, q.d_base, q.d_rec_off, q.d_name_off,
+                gather_kernel<<<(n_seg - n_carry_seg + 3u) / 4u, 256, 0, st>>>(sa, seg_at, n_carry_seg, n_seg, q.d_cnt, q.d_base, q.d_rec_off, q.d_name_off,
                                                                                q.d_name_len, q.d_a, q.d_x, q.d_rflag, q.d_ncig, q.d_cig_at, rec_cap);
             }
         }

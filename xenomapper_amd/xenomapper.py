@@ -1156,6 +1156,7 @@ class _GpuBamFile(object):
         self.by_lines = None                                         # record table of a window parsed by the text rules
         self.pending = None
         self.ahead = None                                            # (staging address, file offset, bytes, the slot's capacities, blocks, CRCs, indexed bytes) read ahead for the next window
+        self.ahead_hits = self.ahead_misses = 0                      # windows whose blocks read_ahead had in place / that stage() had to index and read itself
         self.last_comp = 0                                           # compressed bytes of the last window staged
 
     def _reference_names(self, blocks, at):
@@ -1224,9 +1225,11 @@ class _GpuBamFile(object):
                 uploaded = min(ahead[2], comp_len)                     # read_ahead sent what it read to the device as well
                 self.ahead = None
                 self.pending = nxt
+                self.ahead_hits += 1
                 return {"comp_len": comp_len, "blocks": blocks, "crc": crc, "carry_slot": carry_slot, "carry_off": carry_off,
                         "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": 0, "uploaded": uploaded}
         if budget and not self.at_end:
+            self.ahead_misses += 1
             blocks, crc, nxt, _total = _ffi.bgzf_index(self.data, self.cursor, budget + self.skip, max_blocks)
             if len(blocks):
                 c0 = int(blocks["cdata_off"][0])
@@ -1241,7 +1244,7 @@ class _GpuBamFile(object):
                 "carry_len": carry_len, "eof": nxt >= self.data.shape[0], "skip": self.skip if len(blocks) else 0,
                 "uploaded": uploaded}
 
-    def read_ahead(self, dev, slot, file, reader):
+    def read_ahead(self, dev, slot, file, reader, grow=1.0):
         """The compressed bytes of the NEXT window (from `pending`, where the window just staged ends) read into the other
         slot's staging buffer -- by a thread of its own, while the GPU has the window just staged: stage() of the next window
         then finds them in place.  The amount is a guess (what the last window took); stage() reads whatever is missing."""
@@ -1250,7 +1253,8 @@ class _GpuBamFile(object):
         if at is None or at + 18 > self.data.shape[0] or not self.last_comp:
             return
         room = dev.capacity(slot)[0]
-        n = min(self.data.shape[0] - at, self.last_comp + self.last_comp // 16 + (1 << 20), room)
+        # (grow: the next window is asked to be that much larger than the one just staged -- the run's first windows double)
+        n = min(self.data.shape[0] - at, int(self.last_comp * grow) + self.last_comp // 16 + (1 << 20), room)
         if n <= 0:
             return
         dst = dev._L.xm_bamdev_staging(dev._h, slot, file)
@@ -1384,8 +1388,10 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         want = max(want, BAM_GPU_WINDOW_BYTES)
         # the first windows are small: nothing can be printed or written before the first window is through the GPU, so the
         # pipeline is filled with a quarter and a half window before the full ones (which use the chip best) follow
+        grow = 1.0                                                   # the window behind this one over this one, for the read-ahead
         if bam_windows[0] < 2 and want >= (64 << 20):
             want = want >> (2 - bam_windows[0])
+            grow = 2.0 if os.environ.get("XENOMAPPER_BAM_AHEAD_GROW", "1") != "0" else 1.0
         bam_windows[0] += 1
         with prof("window"):
             if bam_ahead[0] is not None:                             # the read-ahead into this slot's staging buffers has ended
@@ -1406,10 +1412,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             scale = [p / max(per_rec) for p in per_rec] if min(per_rec) > 0 else [1.0, 1.0]
             inputs = [src.stage(bamdev, which, f, parsers[which], int(want * scale[f]) + src.carry[2], max_blocks)
                       for f, src in enumerate(sources)]
+            prof["bam_carry_bytes"] = prof.get("bam_carry_bytes", 0) + sum(int(x["carry_len"]) for x in inputs)
         if bam_reader is not None and not all(x["eof"] for x in inputs):
-            def ahead_job(slot=which ^ 1):
+            def ahead_job(slot=which ^ 1, grow=grow):
                 for f, src in enumerate(sources):
-                    src.read_ahead(bamdev, slot, f, bam_reader)
+                    src.read_ahead(bamdev, slot, f, bam_reader, grow)
             bam_ahead[0] = bam_ahead_pool.submit(ahead_job)
         with prof("strip"):
             blk = bamdev.run(which, inputs, score_mode, paired, paired, min(FILE_MAX_RECORDS, raw_cap // 36 + 2), wait_raw=False,
@@ -1718,6 +1725,9 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             for prs in parsers + ([reader_pool] if reader_pool is not None else []):
                 prs.close()
             for src in sources:
+                if hasattr(src, "ahead_hits"):
+                    prof["bam_ahead_hits"] = prof.get("bam_ahead_hits", 0) + src.ahead_hits
+                    prof["bam_ahead_misses"] = prof.get("bam_ahead_misses", 0) + src.ahead_misses
                 src.close()
         total = time.perf_counter() - t_all
         prof["other"] = total - sum(v for k, v in prof.items() if not k.endswith("_ms") and not k.startswith("bam_") and not k.startswith("sam_"))   # negative: helper-thread phases overlap the rest
