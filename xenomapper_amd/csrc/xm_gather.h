@@ -109,16 +109,18 @@ out_copy_kernel(const v4u32 *__restrict__ src, v4u32 *__restrict__ dst, uint64_t
     for (; k < hi; k += 64u) dst[k] = __builtin_nontemporal_load(src + k);
 }
 
-// Workgroups of out_copy_kernel.  Measured on the BAM path (4.5 GB of BAM -> 9.8 GB of text to /dev/null, same box, two runs each,
-// profiles/r06_ab_bam_bins.txt): the runtime's blit 22.6-23.0 M pairs/s, 256 workgroups 26.2-26.7, 64: 25.6-27.5, 32: 27.9-28.7,
-// 16: 28.6-30.2, 8: 27.3-28.7, 4: 25.8-26.0 (the link no longer full), 2: 18.2 -- the fewer wave slots the copy holds, the less
-// the inflate launch beside it is slowed, down to where the copy itself cannot keep the link busy.  XM_BAMDEV_COPY_WG overrides
-// (0: hipMemcpyAsync instead).
+// Workgroups (x 4) of out_copy_kernel.  The copy's stores wait in the same queues towards the fabric as the stores of the inflate launch
+// beside it: the more of them are in flight, the slower that launch, whether it reads its input over the link or from HBM
+// (profiles/r06_ab_copy_wg.txt, 4.5 GB of BAM -> 9.8 GB of text to /dev/null, one box, alternating): 1 x 4 waves 30.2-30.4 M pairs/s
+// (the copy itself is the longest party), 2 x 4: 38.5-39.4, 3 x 4: 37.6-37.8, 4 x 4: 36.8-37.2, 8 x 4: 34.4, 16 x 4: 31.8-31.9 (the
+// default until the printer was ordered in front of the inflate launch: then it was the best of the sweep, r06_ab_bam_bins.txt).
+// Eight waves, one per XCD, keep the link at ~50 GB/s and the GPU's window (19.5 ms) and the copy's (18 ms) level.  The SAM path
+// shares the setting and does not care (r06_ab_sam_copy_wg.txt).  XM_BAMDEV_COPY_WG overrides (0: hipMemcpyAsync instead).
 static uint32_t out_copy_workgroups()
 {
     static const uint32_t wg = [] {
         const char *v = getenv("XM_BAMDEV_COPY_WG");
-        const long n = v && *v ? strtol(v, nullptr, 10) : 16;
+        const long n = v && *v ? strtol(v, nullptr, 10) : 2;
         return (uint32_t)(n < 0 ? 0 : n > 4096 ? 4096 : n);
     }();
     return wg;
