@@ -142,11 +142,16 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)       // 
     return p;
 }
 
+typedef uint32_t crc_v4u32_any __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t crc_u32_any __attribute__((aligned(1)));
+
 __global__ void __launch_bounds__(256)
 crc32_kernel(const uint8_t *__restrict__ out, const xm_bgzf_block *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ crc_out)
 {
-    // one workgroup per block, thread t takes the t-th 256th of it (whole 4-byte words, the last thread the odd tail); four
-    // bytes per step through four tables ("slicing by 4": T[k][v] = CRC of byte v followed by k zero bytes)
+    // one workgroup per block, thread t takes the t-th of 256 equal pieces (whole 4-byte words) counted from the block's END -- the
+    // first pieces of a block are the short or empty ones; four bytes per step through four tables ("slicing by 4": T[k][v] = CRC
+    // of byte v followed by k zero bytes), the bytes fetched 16 per lane and load (a lane's piece is contiguous: a byte per load
+    // made every load 64 cache lines for 64 bytes, and the texture path, not the arithmetic, set this kernel's time)
     __shared__ uint32_t T[4][256];
     __shared__ uint32_t wave_x[4];
     {
@@ -167,8 +172,10 @@ crc32_kernel(const uint8_t *__restrict__ out, const xm_bgzf_block *__restrict__ 
     if (b >= n_blocks) return;
     const xm_bgzf_block d = blocks[b];
     const uint32_t t = threadIdx.x;
-    const uint32_t piece = ((d.isize + 255u) / 256u + 3u) & ~3u;
-    const uint32_t lo = min(t * piece, d.isize), hi = min(lo + piece, d.isize);
+    const uint32_t piece = ((d.isize + 255u) / 256u + 3u) & ~3u;              // 256 * piece >= isize
+    const uint32_t behind = (255u - t) * piece;                               // bytes of the block behind this thread's piece
+    const uint32_t hi = d.isize > behind ? d.isize - behind : 0u;
+    const uint32_t lo = hi > piece ? hi - piece : 0u;
     const uint8_t *p = out + d.out_off;
     // the ordinary CRC-32 of the piece (an empty piece: 0); CRC(A || B) = CRC(A) * x^(8 |B|) + CRC(B) over GF(2), so the block's
     // CRC is the sum of every piece's CRC times x^(8 * bytes behind the piece)
@@ -176,18 +183,33 @@ crc32_kernel(const uint8_t *__restrict__ out, const xm_bgzf_block *__restrict__ 
     if (hi > lo) {
         c = 0xFFFFFFFFu;
         uint32_t i = lo;
-        for (; i + 4u <= hi; i += 4u) {
-            c ^= (uint32_t)p[i] | ((uint32_t)p[i + 1] << 8) | ((uint32_t)p[i + 2] << 16) | ((uint32_t)p[i + 3] << 24);
+        auto word = [&](uint32_t w) {
+            c ^= w;
             c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
+        };
+        for (; i + 16u <= hi; i += 16u) {
+            const crc_v4u32_any v = *reinterpret_cast<const crc_v4u32_any *>(p + i);
+            word(v.x); word(v.y); word(v.z); word(v.w);
         }
+        for (; i + 4u <= hi; i += 4u) word(*reinterpret_cast<const crc_u32_any *>(p + i));
         for (; i < hi; ++i) c = T[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
         c ^= 0xFFFFFFFFu;
     }
-    uint32_t n = d.isize - hi, pw = 0x80000000u /* x^0 */, sq = 0x00800000u /* x^8 */;
-    while (n) {
-        if (n & 1u) pw = gf2_mulmod(pw, sq);
-        sq = gf2_mulmod(sq, sq);
-        n >>= 1;
+    // x^(8 * behind) = q^(255 - t) with q = x^(8 * piece): q and its squares are the same for the whole workgroup (scalar work),
+    // a thread multiplies the ones its exponent's bits select
+    uint32_t q = 0x80000000u /* x^0 */;
+    {
+        uint32_t e = piece, s = 0x00800000u /* x^8 */;
+        while (e) {
+            if (e & 1u) q = gf2_mulmod(q, s);
+            s = gf2_mulmod(s, s);
+            e >>= 1;
+        }
+    }
+    uint32_t pw = 0x80000000u;
+    for (uint32_t k = 255u - t, bit = 0; bit < 8u; ++bit, k >>= 1) {
+        if (k & 1u) pw = gf2_mulmod(pw, q);
+        q = gf2_mulmod(q, q);
     }
     c = gf2_mulmod(c, pw);
     c ^= __shfl_xor(c, 1, 64);  c ^= __shfl_xor(c, 2, 64);  c ^= __shfl_xor(c, 4, 64);
