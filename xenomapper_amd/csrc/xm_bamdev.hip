@@ -966,7 +966,6 @@ int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
         e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
         for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_wait, hipEventBlockingSync | hipEventDisableTiming);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_inflated, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_raw, hipEventBlockingSync | hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.up_stream, hipStreamNonBlocking);
@@ -981,6 +980,12 @@ int xm_bamdev_create(xm_ctx *ctx, int device_id, xm_bamdev **out)
             e = hipMalloc((void **)&q.d_summary, 16 * sizeof(uint32_t));
             if (e == hipSuccess) e = xmpin::host_malloc((void **)&q.h_summary, 16 * sizeof(uint32_t));
         }
+    }
+    if (e == hipSuccess) {
+        // one copy stream for both slots, one that runs beside either slot's compute stream (xm_gather.h: tried, not assumed)
+        const hipStream_t compute[2] = {b->slot[0].stream, b->slot[1].stream};
+        e = create_copy_stream(&b->slot[0].copy_stream, compute, 2);
+        b->slot[1].copy_stream = b->slot[0].copy_stream;
     }
     if (e != hipSuccess) {
         xm_bamdev_destroy(b);
@@ -1011,7 +1016,7 @@ int xm_bamdev_destroy(xm_bamdev *b)
         if (sl.ev_wait) (void)hipEventDestroy(sl.ev_wait);
         if (sl.ev_inflated) (void)hipEventDestroy(sl.ev_inflated);
         if (sl.ev_raw) (void)hipEventDestroy(sl.ev_raw);
-        if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
+        if (k == 1 && sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);       // shared by the slots: once, behind both
         for (int f = 0; f < 2; ++f)
             if (sl.ev_up[f]) (void)hipEventDestroy(sl.ev_up[f]);
         if (sl.up_stream) (void)hipStreamDestroy(sl.up_stream);
@@ -1029,7 +1034,7 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
     XMB_HIP(b, hipSetDevice(b->device));
     Slot &sl = b->slot[slot];
     XMB_HIP(b, hipStreamSynchronize(sl.stream));
-    XMB_HIP(b, hipStreamSynchronize(sl.copy_stream));
+    if (sl.raw_issued) XMB_HIP(b, hipEventSynchronize(sl.ev_raw));            // THIS slot's last copy (the copy stream also carries the other slot's)
     XMB_HIP(b, hipStreamSynchronize(sl.up_stream));
     sl.have_columns = false;
     if (comp_bytes > sl.comp_cap) {

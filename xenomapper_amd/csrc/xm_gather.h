@@ -3,6 +3,7 @@
 // launches over a uint32 array), where each bin's text begins, and the copy of the finished stream into the host's page-locked,
 // device-mapped buffer.  Every kernel lives in an anonymous namespace: each translation unit that includes this gets its own.
 #pragma once
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -124,6 +125,87 @@ static uint32_t out_copy_workgroups()
         return (uint32_t)(n < 0 ? 0 : n > 4096 ? 4096 : n);
     }();
     return wg;
+}
+
+// ---- the stream the output copy runs on ----
+// The copy of window k has to run BESIDE the compute stream's work on window k + 1, and it does only if the two streams lie on
+// different hardware queues.  The runtime deals streams onto a few queues (four per priority by default) by rules of its own, and which
+// two share one depends on how many streams the process has made before: inside bench.py the copy stream of one slot came to lie on
+// the queue of the other slot's compute stream, whose inflate launch then waited for the whole copy -- every other window 38 ms
+// instead of 21, 31 M pairs/s instead of 40 (profiles/r06_ab_queue_collision.txt, tools/probe_queue_collision.py).  So the library
+// does not guess: it makes candidates (the first with the greatest priority, whose queues are apart from the ordinary ones on this
+// runtime) and TRIES each against the compute streams -- a kernel on the compute stream waits (bounded: 3 ms) for a word that a
+// kernel on the candidate sets; on one queue the second cannot start before the first has ended, and the word is never seen.
+// One copy stream serves both slots (two copies never need to overlap).  XM_COPY_STREAM_PROBE=0: the first candidate untested (A/B).
+__global__ void __launch_bounds__(64)
+probe_wait_kernel(volatile uint32_t *started_host, uint32_t *word, uint32_t *seen, unsigned long long max_ticks)
+{
+    if (threadIdx.x != 0u) return;
+    *started_host = 1u;
+    __threadfence_system();
+    const unsigned long long t0 = wall_clock64();                              // 100 MHz
+    uint32_t v = 0;
+    while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(16);
+    *seen = v;
+}
+
+__global__ void __launch_bounds__(64)
+probe_set_kernel(uint32_t *word)
+{
+    if (threadIdx.x == 0u) __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true: work on `b` ran while a kernel on `a` was still running (or the test could not be made: then nothing is known against b)
+static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
+{
+    uint32_t *d = nullptr, *h = nullptr;
+    if (hipMalloc((void **)&d, 2 * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return true; }
+    if (hipHostMalloc((void **)&h, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return true; }
+    bool beside = true;
+    h[0] = 0; h[1] = 0;
+    if (hipMemsetAsync(d, 0, 2 * sizeof(uint32_t), a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess) {
+        probe_wait_kernel<<<1, 64, 0, a>>>(h, d, d + 1, 300000ull);            // at most 3 ms
+        const auto t0 = std::chrono::steady_clock::now();
+        bool running = false;
+        while (!(running = *(volatile uint32_t *)h != 0u) &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.05) { }
+        probe_set_kernel<<<1, 64, 0, b>>>(d);
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        uint32_t seen = 1;
+        if (running && hipMemcpy(&seen, d + 1, sizeof seen, hipMemcpyDeviceToHost) == hipSuccess) beside = seen != 0u;
+    }
+    (void)hipGetLastError();
+    (void)hipFree(d);
+    (void)hipHostFree(h);
+    return beside;
+}
+
+static hipError_t create_copy_stream(hipStream_t *st, const hipStream_t *compute, int n_compute)
+{
+    static const bool probe = [] { const char *v = getenv("XM_COPY_STREAM_PROBE"); return !(v && v[0] == '0'); }();
+    constexpr int TRIES = 8;
+    hipStream_t tried[TRIES] = {};
+    int n = 0, pick = -1;
+    hipError_t e = hipSuccess;
+    for (; n < TRIES && pick < 0; ++n) {
+        int least = 0, greatest = 0;
+        if (n == 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            e = hipStreamCreateWithPriority(&tried[n], hipStreamNonBlocking, greatest);
+        else
+            e = hipStreamCreateWithFlags(&tried[n], hipStreamNonBlocking);
+        if (e != hipSuccess) break;
+        bool ok = true;
+        for (int c = 0; probe && ok && c < n_compute; ++c) ok = streams_run_side_by_side(compute[c], tried[n]);
+        if (ok) pick = n;
+    }
+    if (pick < 0 && n > 0 && tried[0]) pick = 0;                                // none runs beside: the first one, as before
+    for (int k = 0; k < TRIES; ++k)
+        if (tried[k] && k != pick) (void)hipStreamDestroy(tried[k]);
+    if (pick < 0) return e != hipSuccess ? e : hipErrorUnknown;
+    *st = tried[pick];
+    return hipSuccess;
 }
 
 }  // namespace

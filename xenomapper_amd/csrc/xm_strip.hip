@@ -1089,9 +1089,15 @@ int xm_strip_create(xm_ctx *ctx, int device_id, xm_strip **out)
         if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_off_counts, 74 * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_gstate, 16 * sizeof(uint32_t));
         if (e == hipSuccess) e = xmpin::host_malloc((void **)&sl.h_gstate, 16 * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_filled, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_out, hipEventBlockingSync | hipEventDisableTiming);
+    }
+    if (e == hipSuccess) {
+        // one copy stream for all slots, one that runs beside every slot's compute stream (xm_gather.h: tried, not assumed)
+        hipStream_t compute[XMS_SLOTS];
+        for (int k = 0; k < XMS_SLOTS; ++k) compute[k] = s->slot[k].stream;
+        e = create_copy_stream(&s->slot[0].copy_stream, compute, XMS_SLOTS);
+        for (int k = 1; k < XMS_SLOTS; ++k) s->slot[k].copy_stream = s->slot[0].copy_stream;
     }
     if (e != hipSuccess) {
         xm_strip_destroy(s);
@@ -1118,7 +1124,7 @@ int xm_strip_destroy(xm_strip *s)
         dfree(sl.d_gstate); hfree(sl.h_gstate);
         if (sl.ev_filled) (void)hipEventDestroy(sl.ev_filled);
         if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
-        if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
+        if (k == XMS_SLOTS - 1 && sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);    // shared by the slots: once, behind all
         for (int i = 0; i < 3; ++i)
             if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1135,7 +1141,7 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
     XMS_HIP(s, hipSetDevice(s->device));
     Slot &sl = s->slot[slot];
     XMS_HIP(s, hipStreamSynchronize(sl.stream));
-    XMS_HIP(s, hipStreamSynchronize(sl.copy_stream));
+    if (sl.out_issued) XMS_HIP(s, hipEventSynchronize(sl.ev_out));            // THIS slot's last copy (the copy stream also carries the other slots')
     // a window begins here: whatever an abandoned one (a read that failed half way, a run that was never issued) had
     // sent is forgotten, or the next upload from offset 0 would be refused for ever
     sl.uploaded[0] = sl.uploaded[1] = 0;
