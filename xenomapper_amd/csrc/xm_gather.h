@@ -133,10 +133,12 @@ static uint32_t out_copy_workgroups()
 // two share one depends on how many streams the process has made before: inside bench.py the copy stream of one slot came to lie on
 // the queue of the other slot's compute stream, whose inflate launch then waited for the whole copy -- every other window 38 ms
 // instead of 21, 31 M pairs/s instead of 40 (profiles/r06_ab_queue_collision.txt, tools/probe_queue_collision.py).  So the library
-// does not guess: it makes candidates (the first with the greatest priority, whose queues are apart from the ordinary ones on this
-// runtime) and TRIES each against the compute streams -- a kernel on the compute stream waits (bounded: 3 ms) for a word that a
-// kernel on the candidate sets; on one queue the second cannot start before the first has ended, and the word is never seen.
-// One copy stream serves both slots (two copies never need to overlap).  XM_COPY_STREAM_PROBE=0: the first candidate untested (A/B).
+// does not guess: it makes candidates and TRIES each against the compute streams -- a kernel on the compute stream waits (bounded:
+// 3 ms) for a word that a kernel on the candidate sets; on one queue the second cannot start before the first has ended, and the
+// word is never seen.  One copy stream serves both slots (two copies never need to overlap).  With 0 - 9 streams made by the
+// process beforehand the BAM path then runs at 39.0 - 40.6 M pairs/s throughout; a first candidate of the greatest priority (its
+// queues are apart from the ordinary ones on this runtime; XM_COPY_STREAM_PRIORITY=1) passes the test but copies 8 % slower in some
+// of those processes (34.8 - 38.9), and is not the default.  XM_COPY_STREAM_PROBE=0: the first candidate untested (A/B).
 __global__ void __launch_bounds__(64)
 probe_wait_kernel(volatile uint32_t *started_host, uint32_t *word, uint32_t *seen, unsigned long long max_ticks)
 {
@@ -185,13 +187,14 @@ static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
 static hipError_t create_copy_stream(hipStream_t *st, const hipStream_t *compute, int n_compute)
 {
     static const bool probe = [] { const char *v = getenv("XM_COPY_STREAM_PROBE"); return !(v && v[0] == '0'); }();
+    static const bool prio = [] { const char *v = getenv("XM_COPY_STREAM_PRIORITY"); return v && v[0] == '1'; }();
     constexpr int TRIES = 8;
     hipStream_t tried[TRIES] = {};
     int n = 0, pick = -1;
     hipError_t e = hipSuccess;
     for (; n < TRIES && pick < 0; ++n) {
         int least = 0, greatest = 0;
-        if (n == 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        if (n == 0 && prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
             e = hipStreamCreateWithPriority(&tried[n], hipStreamNonBlocking, greatest);
         else
             e = hipStreamCreateWithFlags(&tried[n], hipStreamNonBlocking);
