@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define XMB_ABI_VERSION 2   /* 2: xm_bamdev_fetch_bins; f and B:f fields printed on the device */
+#define XMB_ABI_VERSION 3   /* 2: xm_bamdev_fetch_bins; f and B:f fields printed on the device.  3: raw1 / raw2 exist from the
+                               first xm_bamdev_fetch_raw on (xm_bamdev_raw) */
 
 /* One BGZF block of the compressed image (24 bytes; the layout the kernels read). */
 typedef struct {
@@ -134,9 +135,10 @@ typedef struct {
     int32_t  weird;                  /* 1: a record the text rules might read differently: use the host decoder for this window  */
     int32_t  reserved;
     uint64_t n_exceptions;           /* pairs whose flags carry XMS_LINE_EX_A / _EX_X on either record                           */
-    const uint8_t  *raw1, *raw2;     /* page-locked host copies of the inflated windows -- filled only when asked for
-                                        (xm_bamdev_fetch_raw), complete once xm_bamdev_raw_wait(slot) has returned, valid until
-                                        the slot runs again                                                                       */
+    const uint8_t  *raw1, *raw2;     /* page-locked host copies of the inflated windows -- allocated and filled only when asked
+                                        for (xm_bamdev_fetch_raw; until the slot's first one they are NULL here: take the
+                                        addresses from xm_bamdev_raw afterwards), complete once xm_bamdev_raw_wait(slot) has
+                                        returned, valid until the slot runs again                                               */
     const uint32_t *rec_off1, *rec_off2;   /* start of every record (its block_size word) in raw*: n_rec* entries              */
     const uint8_t  *flags1, *flags2;       /* per yielded pair: XMS_LINE_NORMAL | exception bits (XMS_LINE_EX_A / _EX_X)        */
     float ms_inflate, ms_kernels;    /* device time of the inflate + CRC launches, and of the record kernels (HIP events)       */
@@ -180,8 +182,11 @@ int xm_bamdev_upload(xm_bamdev *b, int slot, int file, uint64_t bytes);
  * writer needs of them is asked for afterwards, one of */
 int xm_bamdev_run(xm_bamdev *b, int slot, const xm_bamdev_input in[2], int score_mode, int paired, int skip_repeated, int keep_halo,
                   uint64_t max_records, xm_bamdev_block *out);
-/* (a) the whole windows into raw1 / raw2 (a window the host has to walk or print whole: unaligned, weird, exceptions) */
+/* (a) the whole windows into raw1 / raw2 (a window the host has to walk or print whole: unaligned, weird, exceptions).  The two
+ * page-locked buffers (a third of what a slot would pin otherwise) are made by the slot's first call, for the capacity reserved;
+ * XM_ERR_OOM when they cannot be.  xm_bamdev_raw: their addresses (NULL before). */
 int xm_bamdev_fetch_raw(xm_bamdev *b, int slot);
+const uint8_t *xm_bamdev_raw(xm_bamdev *b, int slot, int file);
 /* (b) after xm_bamdev_classify: only the records a sink takes -- a unit's lines come from one file (primary bins: file 1, secondary
  * bins: file 2, unresolved: both; xenomapper.py:423-448), sink_mask bit b = sink b is given -- packed next to each other:
  * raw1 / raw2 = the packed records, off1 / off2[i] = where record i went (0xFFFFFFFF: no sink takes it), bytes1 / bytes2 */

@@ -278,6 +278,49 @@ def test_file_path_many_windows_byte_identical_with_either_front_end(tmp_path, m
     assert sum(want[0].values()) == 40 * 238
 
 
+def test_uncompressed_bam_outgrows_the_staging_once_and_whole_windows_are_pinned_only_when_asked_for(tmp_path, monkeypatch):
+    """The page-locked memory a slot holds: (1) the staging for compressed bytes is reserved for half the inflated size -- `samtools
+    view -u` output (stored DEFLATE blocks: as large as the records) outgrows it, the engine reserves for the worst case and stages
+    the window again, outputs equal to the host decoder's; (2) the host copies of whole inflated windows (xm_bamdev_fetch_raw) exist
+    only from the first window that needs them: none after runs whose windows all went the device's way, both after a window with
+    blocks that cut records."""
+    import bench_bam
+    from xenomapper_amd import xenomapper as xm
+    xm.release_buffers()
+    monkeypatch.setattr(xm, "BAM_GPU_WINDOW_BYTES", 2 << 20)         # (the staging: half of 2 + 1 MB and the carried tail, + 64 KB)
+    monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 2 << 20)
+
+    def files(level, aligned=True):
+        paths = []
+        for tag in ("human", "mouse"):
+            p = str(tmp_path / ("%s_l%d_%d.bam" % (tag, level, aligned)))
+            bench_bam.tiled_bam(os.path.join(DATA, "paired_end_testdata_%s.bam" % tag), p, 800, aligned=aligned, level=level)
+            paths.append(p)
+        return paths
+
+    def raw_pinned():
+        dev = xm.default_bamdev()
+        return [bool(dev._L.xm_bamdev_raw(dev._h, slot, f)) for slot in (0, 1) for f in (0, 1)]
+
+    compressed, stored = files(6), files(0)
+    want = run_path(compressed, gpu=False)
+    got = run_path(compressed, gpu=True)
+    assert got == want
+    assert xm.LAST_FILE_PROFILE.get("bam_staging_regrown", 0) == 0 and xm.LAST_FILE_PROFILE["bam_windows"] >= 6
+    assert raw_pinned() == [False] * 4
+    got = run_path(stored, gpu=True)
+    assert got == want                                               # the same records, stored
+    assert xm.LAST_FILE_PROFILE.get("bam_staging_regrown", 0) == 1 and xm.LAST_FILE_PROFILE.get("bam_windows_raw", 0) == 0
+    assert raw_pinned() == [False] * 4
+    assert run_path(stored, gpu=True) == want                        # (the buffers are large enough now)
+    assert xm.LAST_FILE_PROFILE.get("bam_staging_regrown", 0) == 0
+    cut = files(6, aligned=False)                                    # blocks that cut records: whole windows come back for the host to walk
+    got = run_path(cut, gpu=True)
+    assert xm.LAST_FILE_PROFILE.get("bam_windows_raw", 0) > 0 and any(raw_pinned())
+    assert got == run_path(cut, gpu=False)
+    xm.release_buffers()
+
+
 @settings(max_examples=int(os.environ.get("XM_FUZZ_EXAMPLES", "60")), deadline=None, suppress_health_check=list(HealthCheck))
 @given(images=st.one_of(bam_file_pair(aligned=True), bam_file_pair(aligned="share"), bam_file_pair()), tag=st.sampled_from(["AS", "ZS", "NM"]),
        conservative=st.booleans(), walk=st.sampled_from(["paired", "paired", "single", "paired skipping"]))

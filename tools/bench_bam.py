@@ -50,10 +50,10 @@ def record_aligned_blocks(payload, level=6, limit=0xff00):
     return b"".join(bgzf_blocks(payload[a:b], level, chunk=limit) for a, b in cuts)
 
 
-def tiled_bam(src, dst, copies, aligned=True):
+def tiled_bam(src, dst, copies, aligned=True, level=6):
     """aligned: record-aligned blocks (what samtools writes; the GPU BAM path's record walk is parallel over such blocks);
     False: blocks of a fixed size that cut through records (what htsjdk writes; the device reports them and the host
-    walks the chain)."""
+    walks the chain).  level: zlib's (0: stored blocks, `samtools view -u`)."""
     raw = gzip.decompress(open(src, "rb").read())
     assert raw[:4] == b"BAM\x01"
     l_text, = struct.unpack_from("<i", raw, 4)
@@ -64,7 +64,7 @@ def tiled_bam(src, dst, copies, aligned=True):
         l_name, = struct.unpack_from("<i", raw, at)
         at += 4 + l_name + 4
     head = bgzf_blocks(raw[:at])
-    records = record_aligned_blocks(raw[at:]) if aligned else bgzf_blocks(raw[at:])
+    records = record_aligned_blocks(raw[at:], level) if aligned else bgzf_blocks(raw[at:], level)
     with open(dst, "wb") as fh:
         fh.write(head)
         for _ in range(copies):

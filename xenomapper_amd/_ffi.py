@@ -165,6 +165,7 @@ def lib():
         "xm_bamdev_run": ([P, I, P, I, I, I, I, U64, P], I),
         "xm_bamdev_raw_wait": ([P, I], I),
         "xm_bamdev_fetch_raw": ([P, I], I),
+        "xm_bamdev_raw": ([P, I, I], P),
         "xm_bamdev_fetch_wanted": ([P, I, U64, I, ctypes.c_uint32, P], I),
         "xm_bamdev_upload": ([P, I, I, U64], I),
         "xm_bamdev_set_refs": ([P, I, P, P, ctypes.c_uint32], I),
@@ -196,7 +197,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_fetch_bins", "xm_strip_out_wait", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
-            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_fetch_text", "xm_bamdev_fetch_bins", "xm_bamdev_set_refs", "xm_bamdev_upload", "xm_bamdev_classify",
+            "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_fetch_text", "xm_bamdev_fetch_bins", "xm_bamdev_set_refs", "xm_bamdev_upload", "xm_bamdev_classify",
             "xm_bamdev_columns", "xm_bamdev_cigar_columns", "xm_bamdev_last_error")
 
 
@@ -1125,14 +1126,21 @@ class BamDev(object):
         rc = self._L.xm_bamdev_run(self._h, slot, ctypes.byref(arr), int(score_mode), int(bool(paired)), int(bool(skip_repeated)),
                                    int(bool(keep_halo)), int(max_records), ctypes.byref(raw))
         self._check(rc, "xm_bamdev_run")
+        blk = BamDevBlock(self, slot, raw)
         if wait_raw:                                                 # the whole inflated windows on the host (tests; windows the host walks)
-            self.fetch_raw(slot)
+            self.fetch_raw(slot, blk)
             self.raw_wait(slot)
-        return BamDevBlock(self, slot, raw)
+        return blk
 
-    def fetch_raw(self, slot):
-        """Ask for the whole inflated windows in raw1 / raw2 of the slot's block (complete after raw_wait)."""
+    def fetch_raw(self, slot, block=None):
+        """Ask for the whole inflated windows in raw1 / raw2 of the slot's block (complete after raw_wait).  The slot's two
+        page-locked buffers for them are made by its first call (a run whose windows all take the device's way never pins
+        them): `block.raw_addr` is set here, not by run()."""
         self._check(self._L.xm_bamdev_fetch_raw(self._h, int(slot)), "xm_bamdev_fetch_raw")
+        addr = (self._L.xm_bamdev_raw(self._h, int(slot), 0), self._L.xm_bamdev_raw(self._h, int(slot), 1))
+        if block is not None:
+            block.raw_addr = addr
+        return addr
 
     def fetch_wanted(self, slot, n_records, paired, sink_mask):
         """After classify(): only the records a sink takes, packed (xm_bamdev_fetch_wanted) -> ((address of file 1's packed

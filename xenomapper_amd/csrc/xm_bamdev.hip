@@ -1055,7 +1055,7 @@ int xm_bamdev_reserve(xm_bamdev *b, int slot, uint64_t comp_bytes, uint64_t raw_
         XMB_TRY(dalloc(b, sl.d_raw_all, (size_t)(2 * sl.raw_stride)));
         for (int f = 0; f < 2; ++f) {
             sl.pf[f].d_raw = sl.d_raw_all + f * sl.raw_stride;
-            XMB_TRY(halloc(b, sl.pf[f].h_raw, (size_t)raw_bytes + 64));
+            hfree(sl.pf[f].h_raw);                                           // made again, for the new capacity, by the next xm_bamdev_fetch_raw
         }
         sl.packed_stride = (raw_bytes + 64u + 255u) & ~(uint64_t)255;
         XMB_TRY(dalloc(b, sl.d_packed_all, (size_t)(2 * sl.packed_stride))); XMB_TRY(halloc(b, sl.h_packed_all, (size_t)(2 * sl.packed_stride)));
@@ -1456,6 +1456,8 @@ int xm_bamdev_fetch_raw(xm_bamdev *b, int slot)
     if (!b || slot < 0 || slot > 1) return XM_ERR_INVALID_ARG;
     Slot &sl = b->slot[slot];
     XMB_HIP(b, hipSetDevice(b->device));
+    for (int f = 0; f < 2; ++f)                                             // the host copies of whole windows: only a slot that is asked has them
+        if (!sl.pf[f].h_raw) XMB_TRY(halloc(b, sl.pf[f].h_raw, (size_t)sl.raw_cap + 64));
     XMB_HIP(b, hipEventRecord(sl.ev_inflated, sl.stream));
     XMB_HIP(b, hipStreamWaitEvent(sl.copy_stream, sl.ev_inflated, 0));
     for (int f = 0; f < 2; ++f)
@@ -1464,6 +1466,12 @@ int xm_bamdev_fetch_raw(xm_bamdev *b, int slot)
     XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));
     sl.raw_issued = true;
     return XM_OK;
+}
+
+const uint8_t *xm_bamdev_raw(xm_bamdev *b, int slot, int file)
+{
+    if (!b || slot < 0 || slot > 1 || file < 0 || file > 1) return nullptr;
+    return b->slot[slot].pf[file].h_raw;
 }
 
 int xm_bamdev_fetch_wanted(xm_bamdev *b, int slot, uint64_t n_records, int paired, uint32_t sink_mask, xm_bamdev_text *out)

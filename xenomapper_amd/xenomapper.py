@@ -1127,6 +1127,11 @@ BAM_GPU_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_BAM_WINDOW_MB", "512")) <<
 _BAM_TEXT_BUFFERS = {}
 
 
+class _CompressedBytesOutgrowStaging(Exception):
+    """_GpuBamFile.stage(): the window's compressed bytes do not fit the slot's staging buffer (reserved for half the inflated
+    bytes: BAM that hardly compresses) -- the caller reserves for the worst case and stages again."""
+
+
 class _GpuBamFile(object):
     """One BAM file of the GPU BAM path (include/xenomapper_bgzf.h): a cursor over its BGZF blocks.  Per window the host only
     walks the member headers of the next blocks (xm_bgzf_index) and reads their compressed bytes into the slot's page-locked
@@ -1219,7 +1224,7 @@ class _GpuBamFile(object):
             whole = k == len(a_blocks) and self.cursor + a_end >= self.data.shape[0]       # the file ends with the last block indexed
             if k and (int(ends[k - 1]) >= budget or whole):
                 blocks, crc = a_blocks[:k].copy(), a_crc[:k].copy()
-                comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1])
+                comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1])     # (<= what read_ahead read: it fits)
                 nxt = self.cursor + comp_len + 8                       # behind the last member's CRC-32 and ISIZE
                 self.last_comp = comp_len
                 uploaded = min(ahead[2], comp_len)                     # read_ahead sent what it read to the device as well
@@ -1234,6 +1239,9 @@ class _GpuBamFile(object):
             if len(blocks):
                 c0 = int(blocks["cdata_off"][0])
                 comp_len = int(blocks["cdata_off"][-1]) + int(blocks["cdata_len"][-1]) - c0
+                if comp_len > dev.capacity(slot)[0]:
+                    self.ahead_misses -= 1
+                    raise _CompressedBytesOutgrowStaging(comp_len)
                 blocks = blocks.copy()
                 blocks["cdata_off"] -= np.uint64(c0)
                 parser.pread(self.fd, c0, dst, comp_len)
@@ -1367,6 +1375,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
     bam_reader = _host.Parser(8) if bamdev is not None and os.environ.get("XENOMAPPER_BAM_READ_AHEAD", "1") != "0" else None
     bam_ahead_pool = ThreadPoolExecutor(max_workers=1) if bam_reader is not None else None
     bam_ahead = [None]                                               # the read-ahead in flight
+    bam_comp_worst_case = [False]                                    # a window's compressed bytes outgrew the staging reserved for half the inflated size
 
     def print_records(which, f, raw_addr, rec_off_addr, n, sparse=False, wanted=None):
         """SAM text of records [0, n) of a window decoded on the GPU -> (text array, line_off, line_len)."""
@@ -1403,15 +1412,26 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 bam_ahead[0] = None
             carried = max(src.carry[2] for src in sources)
             raw_cap = want + carried + (1 << 20)
-            comp_cap = raw_cap                                   # DEFLATE never expands a block by more than a few bytes
+            # DEFLATE never expands a block by more than a few bytes; BAM as the aligners and samtools write it is a third of its
+            # inflated size, so the page-locked staging is reserved for half and grows (once per process) for input that is not
+            comp_cap = raw_cap if bam_comp_worst_case[0] else raw_cap // 2 + (64 << 10)
             max_blocks = raw_cap // 65536 + raw_cap // 4096 + 64
             bamdev.reserve(which, comp_cap, raw_cap, max_blocks, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
             # the two files hold the same reads at different bytes per record: each gets a window in proportion, so that the
             # windows hold about as many records and neither file drags a growing tail from window to window
             per_rec = [src.bytes_per_record for src in sources]
             scale = [p / max(per_rec) for p in per_rec] if min(per_rec) > 0 else [1.0, 1.0]
-            inputs = [src.stage(bamdev, which, f, parsers[which], int(want * scale[f]) + src.carry[2], max_blocks)
-                      for f, src in enumerate(sources)]
+            try:
+                inputs = [src.stage(bamdev, which, f, parsers[which], int(want * scale[f]) + src.carry[2], max_blocks)
+                          for f, src in enumerate(sources)]
+            except _CompressedBytesOutgrowStaging:
+                bam_comp_worst_case[0] = True
+                prof["bam_staging_regrown"] = prof.get("bam_staging_regrown", 0) + 1
+                bamdev.reserve(which, raw_cap, raw_cap, max_blocks, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
+                for src in sources:
+                    src.ahead = None                                 # (read into the buffers that were just replaced)
+                inputs = [src.stage(bamdev, which, f, parsers[which], int(want * scale[f]) + src.carry[2], max_blocks)
+                          for f, src in enumerate(sources)]
             prof["bam_carry_bytes"] = prof.get("bam_carry_bytes", 0) + sum(int(x["carry_len"]) for x in inputs)
         if bam_reader is not None and not all(x["eof"] for x in inputs):
             def ahead_job(slot=which ^ 1, grow=grow):
@@ -1436,7 +1456,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             # (--cigar_scores: an NM or XS value the kernels do not vouch for sends the window the same way, as on the SAM path)
             with prof("parse"):
                 # the whole windows as text, then the text rules (exactly the host path's semantics for this window)
-                bamdev.fetch_raw(which)
+                bamdev.fetch_raw(which, blk)
                 bamdev.raw_wait(which)                               # the inflated bytes must have arrived
                 texts, tables = [], []
                 for f in (0, 1):
@@ -1484,7 +1504,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 prof[key] = prof.get(key, 0) + 1
         else:
             prof["bam_windows_raw"] = prof.get("bam_windows_raw", 0) + 1
-            bamdev.fetch_raw(which)                                  # values the text rules must decide, or nothing: the whole windows
+            bamdev.fetch_raw(which, blk)                                  # values the text rules must decide, or nothing: the whole windows
 
         def finish():
             # the records' SAM text, printed by the host threads when the block is settled -- in the main thread, while the
