@@ -1398,6 +1398,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         # the first windows are small: nothing can be printed or written before the first window is through the GPU, so the
         # pipeline is filled with a quarter and a half window before the full ones (which use the chip best) follow
         grow = 1.0                                                   # the window behind this one over this one, for the read-ahead
+        full = want
         if bam_windows[0] < 2 and want >= (64 << 20):
             want = want >> (2 - bam_windows[0])
             grow = 2.0 if os.environ.get("XENOMAPPER_BAM_AHEAD_GROW", "1") != "0" else 1.0
@@ -1411,7 +1412,13 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         src.ahead = None
                 bam_ahead[0] = None
             carried = max(src.carry[2] for src in sources)
+            # (room for a tail of a sixteenth of the window: a tail a little longer than the last one is no reason to make every buffer again)
+            carried = max(carried, full // 16)
             raw_cap = want + carried + (1 << 20)
+            if want < full and max(src.data.shape[0] - src.cursor for src in sources) * 2 >= full:
+                # a full window will follow in this slot: its buffers are made once, for that, not for the quarter and again
+                # for the whole (page-locking is the first run's largest cost: 0.50 s of 0.80 on 4.5 GB of BAM)
+                raw_cap = full + carried + (1 << 20)
             # DEFLATE never expands a block by more than a few bytes; BAM as the aligners and samtools write it is a third of its
             # inflated size, so the page-locked staging is reserved for half and grows (once per process) for input that is not
             comp_cap = raw_cap if bam_comp_worst_case[0] else raw_cap // 2 + (64 << 10)
