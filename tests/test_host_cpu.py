@@ -302,7 +302,7 @@ def test_mapped_writer_extends_files_ahead_and_cuts_them_back(tmp_path):
         fake = _FakeParser(2 << 20)
         assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True
         state = ahead[id(sink)]
-        assert state.settle() == 4 + 3 * (2 << 20) == os.path.getsize(path)      # content + twice the last call, ahead
+        assert state.settle(4 + 3 * (2 << 20)) == 4 + 3 * (2 << 20) == os.path.getsize(path)      # content + twice the last call, ahead
         sink.write("small\n")                                                    # a bin too small for the mapping
         assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True  # fits what is there already
         fake.need = 9 << 20
@@ -336,9 +336,9 @@ def test_fallocate_is_the_system_call_and_reports_what_it_cannot_do(tmp_path):
         os.close(fd)
 
 
-def test_small_bins_wait_for_the_extension_running_ahead(tmp_path):
-    """A bin below the mapping threshold is written through the sink by the caller: _emit_into_file must first have waited
-    for the helper thread that is allocating further down the same file."""
+def test_small_bins_wait_for_the_extension_running_ahead(tmp_path, monkeypatch):
+    """A bin below the mapping threshold is written through the sink by the caller: _emit_into_file must first have stopped the
+    extension that is running further down the same file, and waited for its piece in flight."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
     from xenomapper_amd import xenomapper as xm
@@ -351,21 +351,59 @@ def test_small_bins_wait_for_the_extension_running_ahead(tmp_path):
         assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True
         state = ahead[id(sink)]
         state.settle()
-        released = []
+        released, real = [], xm._fallocate
 
-        def slow():
+        def slow(fd, off, length):
             gate.wait(5)
-            released.append(True)
-            return state.size
-        state.job = pool.submit(slow)                                # an extension that is still under way
+            released.append((off, length))
+            return real(fd, off, length)
+        monkeypatch.setattr(xm, "_fallocate", slow)
+        state.extend_later(pool, state.size + (3 << 20))              # an extension that is still under way
         fake.need = 100                                               # too small for the mapping
         threading.Timer(0.2, gate.set).start()
         assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is False
-        assert released and state.job is None                        # it waited for the helper before handing back
+        assert len(released) == 1 and not state.busy                 # it waited for the piece in flight; no further piece follows
         sink.write("small\n")
         state.finish(sink)
     pool.shutdown()
     assert path.read_bytes() == b"@HD\n" + b"x" * (2 << 20) + b"small\n"
+
+
+def test_files_are_extended_in_pieces_towards_the_size_the_run_predicts(tmp_path, monkeypatch):
+    """With the fraction of the input read so far, the file is extended towards content / fraction (+ 2 %), piece by piece (each a
+    job of its own: several files take turns in the pool), never further than AHEAD_MOST past the content; a writer that needs
+    bytes the extension has reached does not wait for the rest; at the end of the input nothing is added; finish() cuts back."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from xenomapper_amd import xenomapper as xm
+    monkeypatch.setattr(xm, "AHEAD_PIECE", 1 << 20)
+    monkeypatch.setattr(xm, "AHEAD_MOST", 16 << 20)
+    calls, real = [], xm._fallocate
+
+    def counted(fd, off, length):
+        calls.append((off, length))
+        return real(fd, off, length)
+    monkeypatch.setattr(xm, "_fallocate", counted)
+    path = tmp_path / "bin.sam"
+    ahead, pool = {}, ThreadPoolExecutor(max_workers=2)
+    with open(path, "wt") as sink:
+        fake = _FakeParser(2 << 20)
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool, progress=0.25) is True
+        state = ahead[id(sink)]
+        want = int((2 << 20) / 0.25 * 1.02)
+        assert state.settle(want) == want == os.path.getsize(path)
+        assert calls[0] == (0, 2 << 20) and all(n <= (1 << 20) for _off, n in calls[1:]) and len(calls) >= 7
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool, progress=0.26) is True      # predicted 16.1 MB: the 8.4 there do
+        n_before = len(calls)
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool, progress=0.001) is True     # predicted 6 GB: capped
+        assert state.settle((6 << 20) + (16 << 20)) == (6 << 20) + (16 << 20)
+        assert len(calls) > n_before
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool, progress=1.0) is True       # the end: nothing more ahead
+        size = state.settle()
+        assert size == (6 << 20) + (16 << 20) == os.path.getsize(path)
+        state.finish(sink)
+    pool.shutdown()
+    assert path.read_bytes() == b"x" * (8 << 20)
 
 
 def test_mapped_writer_never_extends_an_append_mode_file_ahead(tmp_path):

@@ -32,6 +32,7 @@ import os
 import re
 import stat
 import sys
+import threading
 import time
 from collections import Counter
 from concurrent.futures import ThreadPoolExecutor
@@ -711,6 +712,13 @@ def _write_bytes(sink, data):
 
 
 MMAP_EMIT_MIN_BYTES = 1 << 20        # below this one buffered write is cheaper than mapping the file
+AHEAD_PIECE = int(os.environ.get("XENOMAPPER_AHEAD_PIECE_MB", "32")) << 20    # bytes per background extension job
+AHEAD_MOST = int(os.environ.get("XENOMAPPER_AHEAD_MOST_MB", "1024")) << 20     # an output file is never extended further than this past its content
+# 1: extend the output files towards the size the run predicts from the fraction of the input it has read, instead of twice the last
+# call's bytes ahead.  Measured on one (slow) box, alternating (profiles/r06_ab_ahead_predict.txt): SAM text in 6.0 - 7.2 against
+# 5.3 - 6.1 M pairs/s, BAM in 10.5 - 12.4 against 13.6 - 15.9 -- the further the extension runs ahead, the more it takes from the
+# threads filling the pages behind it.  Not the default.
+AHEAD_PREDICT = os.environ.get("XENOMAPPER_AHEAD_PREDICT", "0") == "1"
 AHEAD_FACTOR = int(os.environ.get("XENOMAPPER_AHEAD", "2"))      # output files are kept this many calls' worth of bytes longer than their content
 
 
@@ -746,30 +754,73 @@ def _fallocate(fd, offset, length):
 
 class _AheadFile(object):
     """An output file that is kept LONGER than its content while a run is writing it: fallocate is one kernel thread
-    zeroing pages (~18 GB/s on tmpfs) and used to sit in front of every bin of every block; extended in the background,
-    ahead of the writer, it is off the critical path.  finish() cuts the file back to its content.  Until then the file
-    ends in NUL bytes: a process killed between two blocks leaves them behind (the content in front of them is complete
-    lines); only finish() -- reached on every exit of the run, exceptions included -- truncates."""
+    instantiating pages (7 - 18 GB/s on tmpfs) and used to sit in front of every bin of every block; extended in the background,
+    ahead of the writer, it is off the critical path.  The extension runs in pieces of AHEAD_PIECE bytes, each a job of its own
+    in the helper pool (so the files take turns and the writer waits for the piece it needs, not for the whole extension),
+    towards a target the writer moves: what the file will hold at the end if the rest of the input fills it as the part read
+    so far has (the run knows how far it is through its input), at most AHEAD_MOST bytes ahead of the content.  finish() cuts
+    the file back to its content.  Until then the file ends in NUL bytes: a process killed between two blocks leaves them
+    behind (the content in front of them is complete lines); only finish() -- reached on every exit of the run, exceptions
+    included -- truncates."""
 
     def __init__(self, fd2, size):
-        self.fd2, self.size, self.job = fd2, size, None
+        self.fd2, self.size, self.target = fd2, size, size
+        self.busy = False                                 # a piece is queued or being allocated
+        self.cv = threading.Condition()
 
-    def settle(self):
-        """Wait for the background extension; -> the file's size."""
-        if self.job is not None:
-            job, self.job = self.job, None
+    def _piece(self, pool):
+        with self.cv:
+            start, n = self.size, min(AHEAD_PIECE, self.target - self.size)
+        ok = n > 0
+        if ok:
             try:
-                self.size = max(self.size, job.result())
+                _fallocate(self.fd2, start, n)             # EOPNOTSUPP, ENOSPC: no extension ahead; the one really needed will say so
             except OSError:
-                pass                                   # no room ahead: the extension that is really needed will say so
-        return self.size
+                ok = False
+        with self.cv:
+            if ok:
+                self.size = max(self.size, start + n)
+            else:
+                self.target = self.size
+            again = ok and self.size < self.target
+            if again:
+                try:
+                    pool.submit(self._piece, pool)          # behind the other files' pieces and the unmapping jobs
+                except RuntimeError:                        # the pool is shutting down
+                    again = False
+            self.busy = again
+            self.cv.notify_all()
+
+    def settle(self, upto=None):
+        """Wait until the file is `upto` bytes long (None: stop extending, and wait for the piece in flight); -> the file's size.
+        A size below `upto` = the background extension does not reach that far and is idle now: the caller extends the file itself."""
+        with self.cv:
+            if upto is None:
+                self.target = self.size                   # no further pieces
+            while self.busy and (upto is None or self.size < upto):
+                self.cv.wait()
+            return self.size
+
+    def grew(self, size):
+        """The caller extended the file itself (settle() had returned less than it needed)."""
+        with self.cv:
+            self.size = max(self.size, size)
+            self.target = max(self.target, self.size)
+
+    def cut(self, size):
+        """The file was cut back to `size` (an emit that failed; no piece is in flight: settle() first)."""
+        with self.cv:
+            self.size = self.target = size
 
     def extend_later(self, pool, upto):
-        if self.job is None and upto > self.size:
-            def work(fd2=self.fd2, start=self.size, n=upto - self.size):
-                _fallocate(fd2, start, n)              # EOPNOTSUPP: no extension ahead (settle() swallows it)
-                return start + n
-            self.job = pool.submit(work)
+        with self.cv:
+            self.target = max(self.target, upto)
+            if not self.busy and self.target > self.size:
+                self.busy = True
+                try:
+                    pool.submit(self._piece, pool)
+                except RuntimeError:
+                    self.busy = False
 
     def finish(self, sink):
         self.settle()
@@ -780,15 +831,16 @@ class _AheadFile(object):
             os.close(self.fd2)
 
 
-def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, ready=None):
+def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, ready=None, progress=None):
     """The text of one bin's units written by the writer's threads STRAIGHT into the output file: the file is extended,
     its new pages are mapped, and xmh_emit gathers the lines into them in parallel -- no intermediate buffer and no
     single write(2) stream (which tops out at ~5 GB/s on one file and made the file path write-bound).  Only for a
     regular file positioned at its end, with an ASCII-compatible encoding and at least MMAP_EMIT_MIN_BYTES to write;
     False = not handled (the caller writes through the sink as before).  XENOMAPPER_MMAP_EMIT=0 switches it off.
-    ahead: {id(sink): _AheadFile} of the run -- with it the file stays extended past its content between calls (twice the
-    bytes of the last call, allocated by ahead_pool's thread while the next block is classified); the run cuts the files
-    back when it ends (_AheadFile.finish).
+    ahead: {id(sink): _AheadFile} of the run -- with it the file stays extended past its content between calls (towards the size
+    it will have if the rest of the input -- progress: the fraction read so far -- fills it at the same rate; without a
+    fraction, twice the bytes of the last call), allocated by ahead_pool's threads while the next blocks are classified; the
+    run cuts the files back when it ends (_AheadFile.finish).
     ready: the bin's text as it stands (uint8 array: the outputs of the window were gathered on the device, xm_bamdev_fetch_bins /
     xm_strip_fetch_bins) -- then the threads only copy it into the file's pages.  (Positional writes of the same ranges instead --
     one stream per file, or 8 MB chunks over 6 / 16 / 32 threads -- take 3.4 GB in 0.18 s when nothing else runs on the box
@@ -826,7 +878,7 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
             opened = True
             size = pos
         else:
-            fd2, size = state.fd2, state.settle()
+            fd2, size = state.fd2, state.settle(pos + need)
         if pos + need > size:
             try:
                 _fallocate(fd2, size, pos + need - size)           # extends the file AND allocates its pages in one go: the
@@ -842,12 +894,14 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
         mm = mmap.mmap(fd2, pos + need - start, offset=start, access=mmap.ACCESS_WRITE)
     except (OSError, ValueError, AttributeError, io.UnsupportedOperation):
         if fd2 is not None:
+            if state is not None:
+                state.settle()                         # (no piece in flight while the file is cut)
             try:
                 os.ftruncate(fd2, pos)                 # the file is as the sink left it; the caller writes the text
             except OSError:
                 pass
             if state is not None:
-                state.size = pos
+                state.cut(pos)
             elif opened:
                 os.close(fd2)
         return False
@@ -868,9 +922,11 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
         _EMIT_CLOCK["emit_fill"] = _EMIT_CLOCK.get("emit_fill", 0.0) + t0 - t1
     except BaseException:
         mm.close()
+        if state is not None:
+            state.settle()
         os.ftruncate(fd2, pos)                         # nothing of this bin's text stays behind
         if state is not None:
-            state.size = pos
+            state.cut(pos)
         else:
             os.close(fd2)
         raise
@@ -885,8 +941,15 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
                                                            and not fcntl.fcntl(sink.fileno(), fcntl.F_GETFL) & os.O_APPEND):
         if state is None:
             state = ahead[id(sink)] = _AheadFile(fd2, size)
-        state.size = size
-        state.extend_later(ahead_pool, pos + need + AHEAD_FACTOR * need)
+        state.grew(size)
+        end = pos + need
+        if progress is not None and 0.0 < progress < 1.0:
+            upto = min(max(int(end / progress * 1.02), end + need // 2), end + AHEAD_MOST)
+        elif progress is not None:
+            upto = end                                 # the input has been read: nothing follows
+        else:
+            upto = end + AHEAD_FACTOR * need
+        state.extend_later(ahead_pool, upto)
     elif state is None:
         os.close(fd2)
     return True
@@ -936,6 +999,19 @@ class _PhaseClock(dict):
             yield
         finally:
             self[name] = self.get(name, 0.0) + time.perf_counter() - start
+
+
+def _input_fraction(sources):
+    """How far the run is through its input files (0 .. 1), or None when the sources do not say."""
+    done = total = 0
+    for src in sources:
+        if isinstance(src, _SamSource):
+            done, total = done + src.pos, total + int(src.raw.shape[0])
+        elif isinstance(src, _GpuBamFile):
+            done, total = done + src.cursor, total + int(src.data.shape[0])
+        else:
+            return None
+    return min(max(done / total, 0.0), 1.0) if total else None
 
 
 class _SamSource(object):
@@ -1677,7 +1753,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     if sinks[b] and boff[b + 1] > boff[b]:
                         piece = text[boff[b]:boff[b + 1]]
                         with prof("emit"):
-                            done = _emit_into_file(parser, paired, b, None, sinks[b], ahead, ahead_pool, ready=piece)
+                            done = _emit_into_file(parser, paired, b, None, sinks[b], ahead, ahead_pool, ready=piece, progress=run_progress[0])
                         if not done:
                             with prof("write"):
                                 _write_bytes(sinks[b], piece)
@@ -1687,7 +1763,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     if limit is not None:
                         seg = seg[seg < limit]
                     with prof("emit"):
-                        done = _emit_into_file(parser, paired, b, seg, sinks[b], ahead, ahead_pool)
+                        done = _emit_into_file(parser, paired, b, seg, sinks[b], ahead, ahead_pool, progress=run_progress[0])
                         text = None if done else parser.emit(paired, b, seg, reuse=True)
                     with prof("write"):
                         _write_bytes(sinks[b], text)
@@ -1700,6 +1776,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
 
     which = 0
     future = None
+    run_progress = [None]                                            # fraction of the input behind the block being settled (None: not known)
     try:
         while True:
             try:
@@ -1723,6 +1800,8 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 for f in (0, 1):
                     sources[f].advance(block.consumed[f], block.consumed_lines[f])
                 future = pool.submit(parse_next, which ^ 1, window)   # parse the next window while this one is classified
+            if AHEAD_PREDICT:
+                run_progress[0] = 1.0 if last else _input_fraction(sources)
             pending = settle(block, raws, pos, parsers[which], pending)
             if pending is not None:
                 raise pending
