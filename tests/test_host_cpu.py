@@ -289,13 +289,14 @@ def test_mapped_writer_falls_back_to_a_sparse_extension_only_where_preallocation
     assert data[:4] == b"@HD\n" and data[4:4 + (2 << 20)] == b"x" * (2 << 20) and data[-5:] == b"tail\n"
 
 
-def test_mapped_writer_extends_files_ahead_and_cuts_them_back(tmp_path):
+def test_mapped_writer_extends_files_ahead_and_cuts_them_back(tmp_path, monkeypatch):
     """With the run's `ahead` table the output file stays longer than its content between calls (allocated by a helper
     thread); ordinary writes in between land at the content's end, and finish() leaves exactly the content."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     from xenomapper_amd import xenomapper as xm
     path = tmp_path / "bin.sam"
+    monkeypatch.setattr(xm, "AHEAD_FACTOR", 2.0)
     ahead, pool = {}, ThreadPoolExecutor(max_workers=1)
     with open(path, "wt") as sink:
         sink.write("@HD\n")

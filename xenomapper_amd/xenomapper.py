@@ -712,14 +712,19 @@ def _write_bytes(sink, data):
 
 
 MMAP_EMIT_MIN_BYTES = 1 << 20        # below this one buffered write is cheaper than mapping the file
-AHEAD_PIECE = int(os.environ.get("XENOMAPPER_AHEAD_PIECE_MB", "32")) << 20    # bytes per background extension job
+# bytes per background extension job (0: the whole extension in one).  Pieces let the writer go on as soon as the bytes it needs
+# are there, but every fallocate call beside the threads that fill the pages slows those: 32 MB pieces 5.9 - 7.0 M pairs/s, 8 MB
+# 5.5 - 6.0, one piece 7.7 - 7.9 (SAM text in, six files on tmpfs out, one box, profiles/r06_ab_ahead_piece.txt)
+AHEAD_PIECE = (int(os.environ.get("XENOMAPPER_AHEAD_PIECE_MB", "0")) << 20) or (1 << 62)
 AHEAD_MOST = int(os.environ.get("XENOMAPPER_AHEAD_MOST_MB", "1024")) << 20     # an output file is never extended further than this past its content
 # 1: extend the output files towards the size the run predicts from the fraction of the input it has read, instead of twice the last
 # call's bytes ahead.  Measured on one (slow) box, alternating (profiles/r06_ab_ahead_predict.txt): SAM text in 6.0 - 7.2 against
 # 5.3 - 6.1 M pairs/s, BAM in 10.5 - 12.4 against 13.6 - 15.9 -- the further the extension runs ahead, the more it takes from the
 # threads filling the pages behind it.  Not the default.
 AHEAD_PREDICT = os.environ.get("XENOMAPPER_AHEAD_PREDICT", "0") == "1"
-AHEAD_FACTOR = int(os.environ.get("XENOMAPPER_AHEAD", "2"))      # output files are kept this many calls' worth of bytes longer than their content
+# (how far ahead: the further, the colder the pages when the writer's threads reach them -- x 2 fills at 0.22 - 0.31 s per 3.4 GB,
+# x 0.5 .. 1.5 at 0.14 - 0.18, with more waiting for the extension in exchange; x 1: profiles/r06_ab_ahead_factor.txt)
+AHEAD_FACTOR = float(os.environ.get("XENOMAPPER_AHEAD", "1"))      # output files are kept this many calls' worth of bytes longer than their content
 
 
 _EMIT_CLOCK = {}            # seconds inside _emit_into_file by step, since the run began (shown with the phases of the run)
@@ -948,7 +953,7 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
         elif progress is not None:
             upto = end                                 # the input has been read: nothing follows
         else:
-            upto = end + AHEAD_FACTOR * need
+            upto = end + int(AHEAD_FACTOR * need)
         state.extend_later(ahead_pool, upto)
     elif state is None:
         os.close(fd2)
