@@ -147,7 +147,9 @@ def bam_tag(draw):
     if kind == "f":
         return tag + b"f" + struct.pack("<f", draw(_FLOATS))
     if kind == "Z":
-        return tag + b"Z" + draw(st.text(alphabet="abcXYZ09 :;,*", max_size=12)).encode() + b"\0"
+        # (now and then a value longer than the device printer's 64-byte trips)
+        return tag + b"Z" + draw(st.one_of(st.text(alphabet="abcXYZ09 :;,*", max_size=12), st.text(alphabet="abcXYZ09 :;,*", max_size=12),
+                                           st.text(alphabet="abcXYZ09 :;,*", min_size=60, max_size=150))).encode() + b"\0"
     if kind == "H":
         return tag + b"H" + draw(st.text(alphabet="0123456789ABCDEF", max_size=8)).encode() + b"\0"
     sub = draw(st.sampled_from(list("cCsSiIf")))
@@ -161,9 +163,10 @@ def bam_tag(draw):
 
 @st.composite
 def bam_record(draw, n_ref):
-    name = draw(st.text(alphabet="abcXYZ019:/._", min_size=1, max_size=30)).encode() + b"\0"
+    name = draw(st.one_of(st.text(alphabet="abcXYZ019:/._", min_size=1, max_size=30), st.text(alphabet="abcXYZ019:/._", min_size=1, max_size=30),
+                          st.text(alphabet="abcXYZ019:/._", min_size=64, max_size=200))).encode() + b"\0"
     cigar = draw(st.lists(st.tuples(st.integers(0, 2**28 - 1), st.integers(0, 9)), max_size=6))
-    l_seq = draw(st.sampled_from([0, 1, 2, 7, 50, 151]))
+    l_seq = draw(st.sampled_from([0, 1, 2, 7, 50, 151, 127, 128, 129, 300]))
     seq = bytes(draw(st.lists(st.integers(0, 255), min_size=(l_seq + 1) // 2, max_size=(l_seq + 1) // 2)))
     if l_seq and draw(st.booleans()):
         qual = bytes([0xFF] * l_seq)

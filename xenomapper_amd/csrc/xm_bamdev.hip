@@ -287,6 +287,10 @@ struct WriteChars {
     template <typename R> __device__ __forceinline__ void bytes(const R &rec, uint32_t p, uint32_t len)
     {
         uint32_t j = 0;
+        for (; j + 64u <= len && wide_min == 16u; j += 64u) {                    // (64 bytes fetched at once: see qual())
+            const v4u32_any a = rec.u128(p + j), b = rec.u128(p + j + 16u), c = rec.u128(p + j + 32u), d = rec.u128(p + j + 48u);
+            wide(a); wide(b); wide(c); wide(d);
+        }
         for (; j + 16u <= len && wide_min == 16u; j += 16u) wide(rec.u128(p + j));
         for (; j + 4u <= len; j += 4u) word(rec.u32(p + j), 4u);
         for (; j < len; ++j) word(rec.u8(p + j), 1u);
@@ -295,8 +299,7 @@ struct WriteChars {
     {
         // two bases a byte, the first in the high nibble; 16 bytes of them are 32 letters
         uint32_t j = 0;
-        for (; j + 32u <= len && wide_min == 16u; j += 32u) {
-            const v4u32_any in = rec.u128(p + (j >> 1));
+        auto letters32 = [&](const v4u32_any &in) {
             uint32_t w8[8];
 #pragma unroll
             for (uint32_t d = 0; d < 4u; ++d) {
@@ -311,7 +314,13 @@ struct WriteChars {
             b[0] = w8[4]; b[1] = w8[5]; b[2] = w8[6]; b[3] = w8[7];
             wide(a);
             wide(b);
+        };
+        for (; j + 128u <= len && wide_min == 16u; j += 128u) {                  // (64 bytes fetched at once: see qual())
+            const uint32_t at = p + (j >> 1);
+            const v4u32_any i0 = rec.u128(at), i1 = rec.u128(at + 16u), i2 = rec.u128(at + 32u), i3 = rec.u128(at + 48u);
+            letters32(i0); letters32(i1); letters32(i2); letters32(i3);
         }
+        for (; j + 32u <= len && wide_min == 16u; j += 32u) letters32(rec.u128(p + (j >> 1)));
         for (; j + 4u <= len; j += 4u) {
             const uint32_t two = rec.u16(p + (j >> 1));
             uint32_t w = 0;
@@ -323,12 +332,19 @@ struct WriteChars {
     template <typename R> __device__ __forceinline__ void qual(const R &rec, uint32_t p, uint32_t len)
     {
         uint32_t j = 0;
-        for (; j + 16u <= len && wide_min == 16u; j += 16u) {
-            v4u32_any q = rec.u128(p + j);
+        auto plus33 = [&](v4u32_any q) {
 #pragma unroll
             for (uint32_t d = 0; d < 4u; ++d) q[d] = ((q[d] & 0x7F7F7F7Fu) + 0x21212121u) ^ (q[d] & 0x80808080u);
             wide(q);
+        };
+        // 64 bytes fetched at once where the field has them: a lane is on cache lines of its own (the records of 64 lanes lie ~330
+        // bytes apart), and with 16 bytes per trip a line had left the L2 before its next quarter was asked for -- every byte of a
+        // record was fetched from HBM more than once (profiles/r06_bam_pmc.txt)
+        for (; j + 64u <= len && wide_min == 16u; j += 64u) {
+            const v4u32_any a = rec.u128(p + j), b = rec.u128(p + j + 16u), c = rec.u128(p + j + 32u), d = rec.u128(p + j + 48u);
+            plus33(a); plus33(b); plus33(c); plus33(d);
         }
+        for (; j + 16u <= len && wide_min == 16u; j += 16u) plus33(rec.u128(p + j));
         for (; j + 4u <= len; j += 4u) {
             const uint32_t q4 = rec.u32(p + j);
             word(((q4 & 0x7F7F7F7Fu) + 0x21212121u) ^ (q4 & 0x80808080u), 4u);          // + 33 in every byte, no carry across bytes

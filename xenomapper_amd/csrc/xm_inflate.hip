@@ -187,6 +187,14 @@ crc32_kernel(const uint8_t *__restrict__ out, const xm_bgzf_block *__restrict__ 
             c ^= w;
             c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
         };
+        for (; i + 64u <= hi; i += 64u) {
+            // 64 bytes fetched at once: the lanes' pieces are 256 bytes apart, so every lane is on a cache line of its own, and with
+            // 16 bytes per trip the line had left the L2 again before its next quarter was asked for (3.0 GB fetched per GB)
+            const crc_v4u32_any v0 = *reinterpret_cast<const crc_v4u32_any *>(p + i), v1 = *reinterpret_cast<const crc_v4u32_any *>(p + i + 16u),
+                                v2 = *reinterpret_cast<const crc_v4u32_any *>(p + i + 32u), v3 = *reinterpret_cast<const crc_v4u32_any *>(p + i + 48u);
+            word(v0.x); word(v0.y); word(v0.z); word(v0.w); word(v1.x); word(v1.y); word(v1.z); word(v1.w);
+            word(v2.x); word(v2.y); word(v2.z); word(v2.w); word(v3.x); word(v3.y); word(v3.z); word(v3.w);
+        }
         for (; i + 16u <= hi; i += 16u) {
             const crc_v4u32_any v = *reinterpret_cast<const crc_v4u32_any *>(p + i);
             word(v.x); word(v.y); word(v.z); word(v.w);
