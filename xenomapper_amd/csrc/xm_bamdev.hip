@@ -1677,8 +1677,8 @@ int xm_bamdev_fetch_bins(xm_bamdev *b, int slot, uint64_t n_records, int paired,
         if (wg == 0u) XMB_HIP(b, hipMemcpyAsync(sl.h_packed_all, sl.d_packed_all, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
         else {
             const uint64_t n16 = (total + 15u) / 16u;                       // (the buffers end 64 bytes behind out_cap)
-            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(4u * wg, (n16 + 63u) / 64u), 64, 0, sl.copy_stream>>>(
-                reinterpret_cast<const v4u32 *>(sl.d_packed_all), reinterpret_cast<v4u32 *>(sl.h_packed_all), n16);
+            out_copy_launch((uint32_t)std::min<uint64_t>(out_copy_waves(wg), (n16 + 63u) / 64u), sl.copy_stream,
+                            reinterpret_cast<const v4u32 *>(sl.d_packed_all), reinterpret_cast<v4u32 *>(sl.h_packed_all), n16);
         }
     }
     XMB_HIP(b, hipEventRecord(sl.ev_raw, sl.copy_stream));

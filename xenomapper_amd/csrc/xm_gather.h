@@ -96,12 +96,21 @@ bin_start_kernel(const uint32_t *__restrict__ uplace, const unsigned long long *
 // every wave slot its LDS allows -- 31 of a CU's 32: a single wave finds the free slot at once, a workgroup of four waits until four
 // chains on one CU have run out of blocks, i.e. for the end of the launch it was meant to run beside.
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+template <int DEEP>
 __global__ void __launch_bounds__(64)
-out_copy_kernel(const v4u32 *__restrict__ src, v4u32 *__restrict__ dst, uint64_t n16)
+out_copy_kernel_t(const v4u32 *__restrict__ src, v4u32 *__restrict__ dst, uint64_t n16)
 {
     const uint64_t per = (n16 + gridDim.x - 1u) / gridDim.x;
     const uint64_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
     uint64_t k = lo + threadIdx.x;
+    if (DEEP == 8)
+        for (; k + 448u < hi; k += 512u) {
+            v4u32 r[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = __builtin_nontemporal_load(src + k + 64u * q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[k + 64u * q] = r[q];
+        }
     for (; k + 192u < hi; k += 256u) {
         const v4u32 a = __builtin_nontemporal_load(src + k), b = __builtin_nontemporal_load(src + k + 64u),
                     c = __builtin_nontemporal_load(src + k + 128u), d = __builtin_nontemporal_load(src + k + 192u);
@@ -110,13 +119,28 @@ out_copy_kernel(const v4u32 *__restrict__ src, v4u32 *__restrict__ dst, uint64_t
     for (; k < hi; k += 64u) dst[k] = __builtin_nontemporal_load(src + k);
 }
 
+static uint32_t out_copy_waves(uint32_t wg)                                     // XM_BAMDEV_COPY_WAVES (A/B): the waves themselves, not workgroups x 4
+{
+    static const long waves = [] { const char *v = getenv("XM_BAMDEV_COPY_WAVES"); return v && *v ? strtol(v, nullptr, 10) : 0L; }();
+    return waves > 0 ? (uint32_t)(waves > 16384 ? 16384 : waves) : 4u * wg;
+}
+
+static void out_copy_launch(uint32_t grid, hipStream_t st, const v4u32 *src, v4u32 *dst, uint64_t n16)
+{
+    static const bool deep = [] { const char *v = getenv("XM_BAMDEV_COPY_DEEP"); return v && v[0] == '8'; }();   // A/B: eight pieces per lane in flight
+    if (deep) out_copy_kernel_t<8><<<grid, 64, 0, st>>>(src, dst, n16);
+    else out_copy_kernel_t<4><<<grid, 64, 0, st>>>(src, dst, n16);
+}
+
 // Workgroups (x 4) of out_copy_kernel.  The copy's stores wait in the same queues towards the fabric as the stores of the inflate launch
 // beside it: the more of them are in flight, the slower that launch, whether it reads its input over the link or from HBM
 // (profiles/r06_ab_copy_wg.txt, 4.5 GB of BAM -> 9.8 GB of text to /dev/null, one box, alternating): 1 x 4 waves 30.2-30.4 M pairs/s
 // (the copy itself is the longest party), 2 x 4: 38.5-39.4, 3 x 4: 37.6-37.8, 4 x 4: 36.8-37.2, 8 x 4: 34.4, 16 x 4: 31.8-31.9 (the
 // default until the printer was ordered in front of the inflate launch: then it was the best of the sweep, r06_ab_bam_bins.txt).
 // Eight waves, one per XCD, keep the link at ~50 GB/s and the GPU's window (19.5 ms) and the copy's (18 ms) level.  The SAM path
-// shares the setting and does not care (r06_ab_sam_copy_wg.txt).  XM_BAMDEV_COPY_WG overrides (0: hipMemcpyAsync instead).
+// shares the setting and does not care (r06_ab_sam_copy_wg.txt).  XM_BAMDEV_COPY_WG overrides (0: hipMemcpyAsync instead); A/B only:
+// XM_BAMDEV_COPY_WAVES (any number of waves) and XM_BAMDEV_COPY_DEEP=8 (eight pieces per lane in flight) -- 8 x 4 is on a flat
+// optimum (r06_ab_copy_deep.txt: 10 x 4 and 6 x 8 the same, 8 x 8 and 6 x 4 3 - 8 % slower).
 static uint32_t out_copy_workgroups()
 {
     static const uint32_t wg = [] {

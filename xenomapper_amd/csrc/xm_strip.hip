@@ -1435,8 +1435,8 @@ int xm_strip_fetch_bins(xm_strip *s, int slot, uint64_t n_records, int paired, u
         if (wg == 0u) XMS_HIP(s, hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
         else {
             const uint64_t n16 = (total + 15u) / 16u;
-            out_copy_kernel<<<(uint32_t)std::min<uint64_t>(4u * wg, (n16 + 63u) / 64u), 64, 0, sl.copy_stream>>>(
-                reinterpret_cast<const v4u32 *>(sl.d_out), reinterpret_cast<v4u32 *>(sl.h_out), n16);
+            out_copy_launch((uint32_t)std::min<uint64_t>(out_copy_waves(wg), (n16 + 63u) / 64u), sl.copy_stream,
+                            reinterpret_cast<const v4u32 *>(sl.d_out), reinterpret_cast<v4u32 *>(sl.h_out), n16);
         }
     }
     XMS_HIP(s, hipEventRecord(sl.ev_out, sl.copy_stream));
