@@ -760,13 +760,13 @@ def _fallocate(fd, offset, length):
 class _AheadFile(object):
     """An output file that is kept LONGER than its content while a run is writing it: fallocate is one kernel thread
     instantiating pages (7 - 18 GB/s on tmpfs) and used to sit in front of every bin of every block; extended in the background,
-    ahead of the writer, it is off the critical path.  The extension runs in pieces of AHEAD_PIECE bytes, each a job of its own
-    in the helper pool (so the files take turns and the writer waits for the piece it needs, not for the whole extension),
-    towards a target the writer moves: what the file will hold at the end if the rest of the input fills it as the part read
-    so far has (the run knows how far it is through its input), at most AHEAD_MOST bytes ahead of the content.  finish() cuts
-    the file back to its content.  Until then the file ends in NUL bytes: a process killed between two blocks leaves them
-    behind (the content in front of them is complete lines); only finish() -- reached on every exit of the run, exceptions
-    included -- truncates."""
+    ahead of the writer, it is off the critical path.  The extension is a job in the helper pool towards a target the writer
+    moves: XENOMAPPER_AHEAD (1) calls' worth of bytes past the content -- further ahead, the pages are cold again when the
+    writer's threads fill them.  (Measured and not the default: the extension in pieces, XENOMAPPER_AHEAD_PIECE_MB, each a job
+    of its own so that the writer waits for the piece it needs only; a target predicted from the fraction of the input read
+    so far, XENOMAPPER_AHEAD_PREDICT, at most AHEAD_MOST bytes ahead.)  finish() cuts the file back to its content.  Until
+    then the file ends in NUL bytes: a process killed between two blocks leaves them behind (the content in front of them is
+    complete lines); only finish() -- reached on every exit of the run, exceptions included -- truncates."""
 
     def __init__(self, fd2, size):
         self.fd2, self.size, self.target = fd2, size, size
