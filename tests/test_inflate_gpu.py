@@ -236,6 +236,35 @@ def test_random_bytes_as_deflate_data_end_with_a_status(ctx):
     assert int((status != 0).sum()) > 400
 
 
+def test_crc32_of_blocks_of_every_size_class_at_every_alignment(ctx):
+    """xm_bgzf_crc32_dev by itself (its pieces are counted from the block's END, fetched 64 / 16 / 4 / 1 bytes a trip, and combined
+    with powers of x shared by the workgroup): blocks of 0 .. 65 536 bytes around every boundary of those trips, each at an
+    address of its own modulo 16, against zlib.crc32."""
+    import torch
+    from xenomapper_amd import _ffi
+    rng = np.random.default_rng(7)
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1020, 1023, 1024, 1025, 1027,
+             4095, 4096, 4097, 16383, 16384, 16385, 16639, 16640, 16641, 65023, 65279, 65280, 65281, 65535, 65536]
+    sizes += [int(x) for x in rng.integers(0, 65537, 60)]
+    data = rng.integers(0, 256, sum(sizes) + 17 * len(sizes) + 64, dtype=np.uint8)
+    blocks = np.zeros(len(sizes), dtype=_ffi.BGZF_BLOCK)
+    at = 0
+    for k, n in enumerate(sizes):
+        at += 1 + (k * 5) % 16                                           # every residue modulo 16 comes up
+        blocks["out_off"][k], blocks["isize"][k] = at, n
+        at += n
+    dev = torch.device("cuda:0")
+    out = torch.from_numpy(data).to(dev)
+    d_blocks = torch.from_numpy(blocks.view(np.uint8)).to(dev)
+    crc = torch.zeros(len(sizes), dtype=torch.int32, device=dev)
+    ctx.bgzf_crc32_dev(out, d_blocks, crc)
+    torch.cuda.synchronize()
+    got = crc.cpu().numpy().view(np.uint32)
+    want = np.array([zlib.crc32(data[int(b["out_off"]):int(b["out_off"]) + int(b["isize"])].tobytes()) for b in blocks], dtype=np.uint32)
+    assert np.array_equal(got, want), [(sizes[k], int(blocks["out_off"][k]) % 16) for k in np.nonzero(got != want)[0]]
+    assert len(set(int(o) % 16 for o in blocks["out_off"])) == 16
+
+
 def test_empty_input_and_empty_blocks(ctx):
     from xenomapper_amd import _ffi
     eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
