@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define XMS_ABI_VERSION 2   /* 2: xm_strip_fetch_bins / xm_strip_out_wait */
+#define XMS_ABI_VERSION 3   /* 2: xm_strip_fetch_bins / xm_strip_out_wait.  3: xm_strip_begin_behind / xm_strip_set_lead */
 #define XMS_SLOTS 2
 #define XMS_MAX_WINDOW 0xFFFF0000ull
 
@@ -85,6 +85,20 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
 
 /* Page-locked staging buffer of a slot for file 0 / 1 (window_bytes long): the caller copies the window there. */
 char *xm_strip_staging(xm_strip *s, int slot, int file);
+
+/* Reading AHEAD (XMS_ABI_VERSION 3).  The next window begins somewhere in the last bytes of the current one -- its walk says where
+ * -- so a caller that wants to read the next window's bytes while the current one is still being stripped reads the bytes BEHIND
+ * the current window into the other slot's staging buffer, `room` bytes into it (a multiple of 64 KiB):
+ *   xm_strip_begin_behind(s, slot, file, room);                     a new window of this file; its bytes [0, room) come later
+ *   xm_strip_upload(s, slot, file, room + k, n) ...                  piece by piece as they are read, as always
+ *   ... the current window's xm_strip_run returns: the next one starts `tail` bytes in front of what was read ...
+ *   copy those `tail` <= room bytes to staging + room - tail;  xm_strip_set_lead(s, slot, file, room - tail);
+ *   xm_strip_run(s, slot, room + bytes read, ...)
+ * The window is then the whole buffer [0, len) of which the first `lead` bytes are no text: no line begins or ends there, every
+ * offset the run reports (consumed*, line_off*) still counts from the buffer's first byte, so consumed* - lead bytes of text are
+ * done.  A lead holds for one run.  Needs the default zero-copy mode (XM_STRIP_ZEROCOPY=0: XM_ERR_INVALID_ARG from the run). */
+int xm_strip_begin_behind(xm_strip *s, int slot, int file, uint64_t room);
+int xm_strip_set_lead(xm_strip *s, int slot, int file, uint64_t lead);
 
 /* Start the upload of bytes [offset, offset + bytes) of a staged window (asynchronous, on the slot's stream): called piece by
  * piece, in order from offset 0, while the host is still copying the rest of the window into the staging buffer, it hides

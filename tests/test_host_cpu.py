@@ -27,7 +27,7 @@ def test_hip_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_ffi.EXPORTED) == names
-    assert _ffi.lib().xm_abi_version() == 6 and _ffi.lib().xms_abi_version() == 2
+    assert _ffi.lib().xm_abi_version() == 6 and _ffi.lib().xms_abi_version() == 3
     assert b"gfx950" in _ffi.lib().xm_strerror(-2)
 
 

@@ -482,6 +482,22 @@ def test_outputs_gathered_on_the_device_equal_the_oracle_and_the_host_writer(tmp
                 assert prof.get("sam_windows_device_bins", 0) == prof["sam_windows"], prof
             else:
                 assert 0 < prof.get("sam_windows_device_bins", 0) < prof["sam_windows"], prof
+            assert prof.get("sam_windows_read_ahead", 0) == 0
+        # XENOMAPPER_SAM_READ_AHEAD=1: every window's bytes read, and sent over the link, while the window in front is stripped --
+        # behind a gap in the other slot's buffer, the tail of the window in front put into the gap when its walk has said where
+        # it stopped (xm_strip_begin_behind / xm_strip_set_lead: the first `lead` bytes of the buffer are no text).  The same
+        # outputs; most windows go that way (not the first two, not those behind a window the host writer still reads).
+        monkeypatch.setenv("XENOMAPPER_GPU_SAM_BINS", "1")
+        monkeypatch.setenv("XENOMAPPER_SAM_READ_AHEAD", "1")
+        outs = {name: io.StringIO() for name in H.STATES}
+        counts = xm.classify_sam_files(paths[0], paths[1], paired=paired, conservative=mode == "pe_conservative", **outs)
+        prof = dict(xm.LAST_FILE_PROFILE)
+        assert dict(counts) == dict(want_counts) and [outs[name].getvalue() for name in H.STATES] == want_texts
+        if mixed == 0.0:
+            assert prof.get("sam_windows_read_ahead", 0) >= prof["sam_windows"] * 2 // 3, prof
+        else:
+            assert prof.get("sam_windows_read_ahead", 0) > 0, prof
+        monkeypatch.delenv("XENOMAPPER_SAM_READ_AHEAD")
 
 
 def test_overlapping_units_outgrow_the_output_stream_and_go_to_the_host_writer(tmp_path, monkeypatch):
@@ -495,6 +511,7 @@ def test_overlapping_units_outgrow_the_output_stream_and_go_to_the_host_writer(t
     from tests.test_file_fuzz_gpu import oracle_run, SCORERS
     from xenomapper_amd import xenomapper as xm
     monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 1 << 20)
+    xm.release_buffers()                                             # (the process-wide stripper may have grown in a test before: this one counts on its sizes)
     line = "samename\t%d\tchr1\t%d\t30\t50M\t=\t%d\t0\t" + "ACGT" * 12 + "AC\t" + "F" * 50 + "\tAS:i:-5\tXS:i:-9\n"
     text = "".join(line % (99 if k % 2 == 0 else 147, 100 + k, 300 + k) for k in range(40_000))
     paths = []

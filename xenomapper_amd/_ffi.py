@@ -142,6 +142,8 @@ def lib():
         "xm_strip_destroy": ([P], I),
         "xm_strip_reserve": ([P, I, U64, U64], I),
         "xm_strip_staging": ([P, I, I], P),
+        "xm_strip_begin_behind": ([P, I, I, U64], I),
+        "xm_strip_set_lead": ([P, I, I, U64], I),
         "xm_strip_upload": ([P, I, I, U64, U64], I),
         "xm_strip_run": ([P, I, U64, I, U64, I, I, I, I, I, U64, P], I),
         "xm_strip_cigar_columns": ([P, I, I, U64, P, P, P, P, U64, ctypes.POINTER(U64)], I),
@@ -194,7 +196,7 @@ EXPORTED = ("xm_abi_version", "xm_strerror", "xm_last_hip_error", "xm_ctx_create
             "xm_stream_probe_dev", "xm_workspace_is_clean", "xm_workspace_release",
             "xm_comm_unique_id", "xm_comm_init", "xm_comm_destroy", "xm_comm_size", "xm_allreduce_counts",
             "xm_timing_enable", "xm_timing_select", "xm_timing_reset", "xm_timing_read",
-            "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_upload", "xm_strip_run",
+            "xms_abi_version", "xm_strip_create", "xm_strip_destroy", "xm_strip_reserve", "xm_strip_staging", "xm_strip_begin_behind", "xm_strip_set_lead", "xm_strip_upload", "xm_strip_run",
             "xm_strip_classify", "xm_strip_fetch_bins", "xm_strip_out_wait", "xm_strip_columns", "xm_strip_cigar_columns", "xm_strip_device_columns", "xm_strip_last_error",
             "xm_bgzf_index", "xm_bgzf_index_prefix", "xm_bgzf_inflate_dev", "xm_bgzf_inflate_walk_dev", "xm_bgzf_crc32_dev", "xm_bgzf_strerror",
             "xm_bamdev_create", "xm_bamdev_destroy", "xm_bamdev_reserve", "xm_bamdev_staging", "xm_bamdev_run", "xm_bamdev_raw_wait", "xm_bamdev_fetch_raw", "xm_bamdev_raw", "xm_bamdev_fetch_wanted", "xm_bamdev_fetch_text", "xm_bamdev_fetch_bins", "xm_bamdev_set_refs", "xm_bamdev_upload", "xm_bamdev_classify",
@@ -914,12 +916,24 @@ class Stripper(object):
             self._check(self._L.xm_strip_reserve(self._h, slot, want[0], want[1]), "xm_strip_reserve")
             self._cap[slot] = want
 
+    def fits(self, slot, window_bytes, max_records):
+        """The slot's buffers hold that much already (reserve() would not touch them)."""
+        return window_bytes <= self._cap[slot][0] and max_records <= self._cap[slot][1]
+
     def staging_address(self, slot, file):
         return self._L.xm_strip_staging(self._h, slot, file)
 
     def staging(self, slot, file):
         """The slot's page-locked text buffer of one file as a uint8 array."""
         return _host_view(self.staging_address(slot, file), self._cap[slot][0], np.uint8)
+
+    def begin_behind(self, slot, file, room):
+        """A new window of this file whose bytes [0, room) come later (xm_strip_begin_behind): uploads go on from `room`."""
+        self._check(self._L.xm_strip_begin_behind(self._h, slot, file, int(room)), "xm_strip_begin_behind")
+
+    def set_lead(self, slot, file, lead):
+        """The first `lead` bytes of the window staged for the next run are no text (xm_strip_set_lead)."""
+        self._check(self._L.xm_strip_set_lead(self._h, slot, file, int(lead)), "xm_strip_set_lead")
 
     def upload(self, slot, file, offset, n):
         """Start sending staged bytes [offset, offset + n) of one window to the device (in order, from 0)."""

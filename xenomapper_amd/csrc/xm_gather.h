@@ -208,6 +208,7 @@ static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
     return beside;
 }
 
+// (also what makes a compute stream that has to run beside others: the SAM front end's second slot)
 static hipError_t create_copy_stream(hipStream_t *st, const hipStream_t *compute, int n_compute)
 {
     static const bool probe = [] { const char *v = getenv("XM_COPY_STREAM_PROBE"); return !(v && v[0] == '0'); }();

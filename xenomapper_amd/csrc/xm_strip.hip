@@ -55,6 +55,7 @@ enum { SUM_N = 0, SUM_CONS1, SUM_CONS2, SUM_CL1, SUM_CL2, SUM_ENDED, SUM_STARVED
 struct FileView {                                     // one file's window, its line index and its per-line records, on the device
     const uint8_t *text;
     uint32_t len, usable, eof, n_chunks;
+    uint32_t lead;                                    // the window's text begins here (0 unless xm_strip_set_lead said otherwise): bytes in front are no text
     uint16_t *mask16;
     uint32_t *chunk_cnt, *chunk_base;
     uint32_t *lend, *lnext;                           // cap_lines entries each
@@ -115,6 +116,7 @@ struct MarkArgs {
     uint32_t *chunk_cnt;
     uint32_t *state;
     uint32_t len, usable, file, chunk0, n_chunks;     // chunks [chunk0, chunk0 + n_chunks) of a window of `len` bytes
+    uint32_t lead;                                    // bytes in front of the window's text: no terminators, no non-ASCII test there
 };
 
 __global__ void __launch_bounds__(SB) mark_kernel(const MarkArgs a)
@@ -145,12 +147,15 @@ __global__ void __launch_bounds__(SB) mark_kernel(const MarkArgs a)
             lfm |= ((((zn >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * q);
             him |= (((((w[q] & 0x80808080u) >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * q);
         }
+        // (a window begun behind a gap: the bytes in front of `lead` are whatever the buffer held)
+        const uint32_t text = p0 >= a.lead ? 0xFFFFu : (p0 + 16u <= a.lead ? 0u : 0xFFFFu & ~((1u << (a.lead - p0)) - 1u));
+        crm &= text; lfm &= text; him &= text;
         const uint32_t in_len = p0 + 16u <= a.len ? 0xFFFFu : (1u << (a.len - p0)) - 1u;           // p < len (p0 < len here)
         const uint32_t in_use = p0 + 16u <= a.usable ? 0xFFFFu : (p0 < a.usable ? (1u << (a.usable - p0)) - 1u : 0u);
         hi |= (him & in_len) ? 0x80u : 0u;
         any_cr |= crm & in_len;
         // '\r' always ends a line (alone or as the first half of "\r\n"); '\n' unless it is that second half
-        const uint32_t prev_cr = ((lfm & 1u) && p0 && a.src[p0 - 1u] == 13u) ? 1u : 0u;      // the byte in front of the group
+        const uint32_t prev_cr = ((lfm & 1u) && p0 > a.lead && a.src[p0 - 1u] == 13u) ? 1u : 0u;      // the byte in front of the group
         const uint32_t m = (crm | (lfm & ~((crm << 1) | prev_cr))) & in_use;
         a.mask16[g] = (uint16_t)m;
         cnt += (uint32_t)__popc(m);
@@ -230,10 +235,10 @@ __device__ __forceinline__ Lines lines_of(const FileView &f, uint32_t n_terms, u
     L.n_terms = n_terms;
     if (n_terms >= cap_lines) {                       // more lines than the tables hold: the end of the window is never reached
         L.count = n_terms;
-        L.complete_end = 0;
+        L.complete_end = f.lead;
         return L;
     }
-    const uint32_t last_next = n_terms ? f.lnext[n_terms - 1u] : 0u;
+    const uint32_t last_next = n_terms ? f.lnext[n_terms - 1u] : f.lead;
     const bool extra = f.eof && last_next < f.len;
     L.count = n_terms + (extra ? 1u : 0u);
     L.complete_end = extra ? f.len : last_next;
@@ -242,7 +247,7 @@ __device__ __forceinline__ Lines lines_of(const FileView &f, uint32_t n_terms, u
 
 __device__ __forceinline__ void line_span(const FileView &f, const Lines &L, uint32_t i, uint32_t &start, uint32_t &len)
 {
-    start = i ? f.lnext[i - 1u] : 0u;
+    start = i ? f.lnext[i - 1u] : f.lead;
     len = (i < L.n_terms ? f.lend[i] : f.len) - start;
 }
 
@@ -756,7 +761,7 @@ __global__ void summary_kernel(const Job job)
         if (halo) i = job.skip ? job.f[f].sel[ks - 1u] : ks - 1u;
         else if (job.skip) i = ks < W.R[f] ? job.f[f].sel[ks] : W.L[f].count;
         else i = ks;
-        cons[f] = i < W.L[f].count ? (uint64_t)(i ? job.f[f].lnext[i - 1u] : 0u) : (uint64_t)W.L[f].complete_end;
+        cons[f] = i < W.L[f].count ? (uint64_t)(i ? job.f[f].lnext[i - 1u] : job.f[f].lead) : (uint64_t)W.L[f].complete_end;
         cl[f] = min(i, W.L[f].count);
     }
     uint64_t *s = job.summary;
@@ -845,7 +850,8 @@ sam_line_copy_kernel(const uint8_t *__restrict__ text1, const uint8_t *__restric
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 struct PerFile {
-    char *h_text = nullptr;                            // page-locked staging
+    char *h_text = nullptr;                            // page-locked staging (+ 64 bytes: S1 reads whole 16-byte words)
+    uint64_t lead = 0;                                 // bytes in front of this window's text (xm_strip_set_lead; 0 unless said)
     uint8_t *d_text = nullptr;
     uint16_t *d_mask = nullptr;
     uint32_t *d_chunk_cnt = nullptr, *d_chunk_base = nullptr;
@@ -885,6 +891,7 @@ struct Slot {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_filled = nullptr, ev_out = nullptr;
     bool out_issued = false, classified = false;
+    uint32_t held[2] = {0, 0};                         // chunks [0, held) of a window begun with xm_strip_begin_behind wait for the run (S1 needs the lead)
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     uint64_t uploaded[2] = {0, 0};                     // bytes of the staged windows already on their way (xm_strip_upload)
@@ -978,7 +985,8 @@ int grow_window(xm_strip *s, Slot &sl, uint64_t bytes)
     sl.cigar_ready = false;
     for (int f = 0; f < 2; ++f) {
         PerFile &q = sl.pf[f];
-        XMS_TRY(halloc(s, q.h_text, (size_t)cap));
+        XMS_TRY(halloc(s, q.h_text, (size_t)cap + 64));
+        q.lead = 0;
         XMS_TRY(dalloc(s, q.d_text, (size_t)cap + 256));              // S1 / S4 read whole 16-byte words / load steps
         XMS_TRY(dalloc(s, q.d_mask, (size_t)cap / 16 + 16));
         XMS_TRY(dalloc(s, q.d_chunk_cnt, n_chunks * WAVES));
@@ -1043,10 +1051,20 @@ bool zero_copy_text()
 
 // S1 for chunks [marked, upto_chunk) of one file's window, with `len` / `usable` as the kernel is to see them; last: upto_chunk is
 // the window's chunk count (else the chunk holding the last staged byte is left for later)
+int mark_range(xm_strip *s, Slot &sl, int file, uint64_t len, uint64_t usable, uint32_t chunk0, uint32_t upto_chunk);
+
 int mark_chunks(xm_strip *s, Slot &sl, int file, uint64_t len, uint64_t usable, uint32_t upto_chunk, bool last)
 {
     if (!last && upto_chunk > 0) --upto_chunk;
     if (upto_chunk <= sl.marked[file]) return XM_OK;
+    XMS_TRY(mark_range(s, sl, file, len, usable, sl.marked[file], upto_chunk));
+    sl.marked[file] = upto_chunk;
+    return XM_OK;
+}
+
+int mark_range(xm_strip *s, Slot &sl, int file, uint64_t len, uint64_t usable, uint32_t chunk0, uint32_t upto_chunk)
+{
+    if (upto_chunk <= chunk0) return XM_OK;
     if (!sl.state_cleared) {
         XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), sl.stream));
         sl.state_cleared = true;
@@ -1057,9 +1075,9 @@ int mark_chunks(xm_strip *s, Slot &sl, int file, uint64_t len, uint64_t usable, 
     a.copy = zero_copy_text() ? q.d_text : nullptr;
     a.mask16 = q.d_mask; a.chunk_cnt = q.d_chunk_cnt; a.state = sl.d_state;
     a.len = (uint32_t)len; a.usable = (uint32_t)usable; a.file = (uint32_t)file;
-    a.chunk0 = sl.marked[file]; a.n_chunks = upto_chunk - sl.marked[file];
+    a.chunk0 = chunk0; a.n_chunks = upto_chunk - chunk0;
+    a.lead = (uint32_t)q.lead;
     mark_kernel<<<a.n_chunks, SB, 0, sl.stream>>>(a);
-    sl.marked[file] = upto_chunk;
     return XM_OK;
 }
 
@@ -1079,7 +1097,11 @@ int xm_strip_create(xm_ctx *ctx, int device_id, xm_strip **out)
     hipError_t e = hipSetDevice(device_id);
     for (int k = 0; k < XMS_SLOTS && e == hipSuccess; ++k) {
         Slot &sl = s->slot[k];
-        e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+        // (the slots' streams work side by side since a window is read -- and crosses the link, S1 -- while the one in front is
+        // stripped: each on a hardware queue of its own, tried like the copy stream's)
+        hipStream_t before[XMS_SLOTS];
+        for (int j = 0; j < k; ++j) before[j] = s->slot[j].stream;
+        e = create_copy_stream(&sl.stream, before, k);
         for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&sl.ev[i]);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_state, ST_WORDS * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_range, 4 * sizeof(uint32_t));
@@ -1146,6 +1168,8 @@ int xm_strip_reserve(xm_strip *s, int slot, uint64_t window_bytes, uint64_t max_
     // sent is forgotten, or the next upload from offset 0 would be refused for ever
     sl.uploaded[0] = sl.uploaded[1] = 0;
     sl.marked[0] = sl.marked[1] = 0;
+    sl.pf[0].lead = sl.pf[1].lead = 0;
+    sl.held[0] = sl.held[1] = 0;
     sl.state_cleared = false;
     sl.upload_timed = false;
     // a failed growth leaves the capacity at 0 and the pointers freed or null: the next reserve allocates afresh
@@ -1160,11 +1184,33 @@ char *xm_strip_staging(xm_strip *s, int slot, int file)
     return s->slot[slot].pf[file].h_text;
 }
 
+int xm_strip_begin_behind(xm_strip *s, int slot, int file, uint64_t room)
+{
+    if (!s || slot < 0 || slot >= XMS_SLOTS || file < 0 || file > 1 || room % CHUNK != 0) return XM_ERR_INVALID_ARG;
+    Slot &sl = s->slot[slot];
+    if (room > sl.window_cap) return XM_ERR_INVALID_ARG;
+    sl.pf[file].lead = 0;
+    sl.uploaded[file] = room;                               // uploads go on from here; [0, room) arrives with xm_strip_set_lead
+    // S1 of the chunk at `room` looks at the byte in front of it (a "\r\n" cut there): that chunk waits for the run as well
+    sl.held[file] = (uint32_t)(room / CHUNK) + 1u;
+    sl.marked[file] = sl.held[file];
+    return XM_OK;
+}
+
+int xm_strip_set_lead(xm_strip *s, int slot, int file, uint64_t lead)
+{
+    if (!s || slot < 0 || slot >= XMS_SLOTS || file < 0 || file > 1) return XM_ERR_INVALID_ARG;
+    Slot &sl = s->slot[slot];
+    if (lead > sl.window_cap || (sl.held[file] != 0 && lead > (uint64_t)(sl.held[file] - 1u) * CHUNK)) return XM_ERR_INVALID_ARG;
+    sl.pf[file].lead = lead;
+    return XM_OK;
+}
+
 int xm_strip_upload(xm_strip *s, int slot, int file, uint64_t offset, uint64_t bytes)
 {
     if (!s || slot < 0 || slot >= XMS_SLOTS || file < 0 || file > 1) return XM_ERR_INVALID_ARG;
     Slot &sl = s->slot[slot];
-    if (offset == 0) sl.uploaded[file] = 0;                 // a new window of this file (the previous one may have been abandoned)
+    if (offset == 0) { sl.uploaded[file] = 0; sl.held[file] = 0; sl.pf[file].lead = 0; }    // a new window of this file (the previous one may have been abandoned)
     if (offset != sl.uploaded[file] || offset + bytes > sl.window_cap) return XM_ERR_INVALID_ARG;
     if (bytes == 0) return XM_OK;
     XMS_HIP(s, hipSetDevice(s->device));
@@ -1197,7 +1243,7 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
     sl.upload_timed = false;
     sl.last_score_mode = -1;
     sl.classified = false;
-    if (len1 > sl.window_cap || len2 > sl.window_cap || max_records == 0 || max_records > sl.record_cap || sent[0] > len1 ||
+    if (len1 > sl.window_cap || len2 > sl.window_cap || sl.pf[0].lead > len1 || sl.pf[1].lead > len2 || max_records == 0 || max_records > sl.record_cap || sent[0] > len1 ||
         sent[1] > len2)
         return XM_ERR_INVALID_ARG;
     XMS_HIP(s, hipSetDevice(s->device));
@@ -1212,6 +1258,7 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
         FileView &v = job.f[f];
         PerFile &q = sl.pf[f];
         v.text = q.d_text;
+        v.lead = (uint32_t)q.lead;
         v.len = (uint32_t)len[f];
         // a trailing '\r' may be the first half of a "\r\n" that continues in the next window
         v.usable = (!eof[f] && len[f] > 0 && q.h_text[len[f] - 1] == '\r') ? (uint32_t)len[f] - 1u : (uint32_t)len[f];
@@ -1253,11 +1300,34 @@ int xm_strip_run(xm_strip *s, int slot, uint64_t len1, int eof1, uint64_t len2, 
         for (int f = 0; f < 2; ++f)
             if (sent[f] == 0) sl.marked[f] = 0;        // nothing of this window was announced: all of it is marked here
     }
-    // S1 on what is left of each window (zero-copy: that is where the text crosses the link; the last chunk always is left)
+    // S1 on what is left of each window (zero-copy: that is where the text crosses the link; the last chunk always is left) -- of
+    // a window begun behind a gap also the chunks in front that waited for the lead
     for (int f = 0; f < 2; ++f) {
-        const int rc = mark_chunks(s, sl, f, len[f], job.f[f].usable, job.f[f].n_chunks, true);
-        if (rc != XM_OK) { sl.state_cleared = false; sl.marked[0] = sl.marked[1] = 0; return rc; }
+        int rc = XM_OK;
+        if (sl.held[f] != 0) {
+            if (!zero_copy_text()) rc = XM_ERR_INVALID_ARG;
+            else {
+                // the chunks that lie in front of the lead altogether hold no terminator: their masks and counts are zeroed, and
+                // nothing of them crosses the link; S1 begins with the chunk the text begins in
+                const uint32_t upto = std::min(sl.held[f], job.f[f].n_chunks);
+                const uint32_t c_lead = std::min((uint32_t)(sl.pf[f].lead / CHUNK), upto);
+                if (c_lead) {
+                    if (!sl.state_cleared) {
+                        XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), st));
+                        sl.state_cleared = true;
+                    }
+                    XMS_HIP(s, hipMemsetAsync(sl.pf[f].d_mask, 0, (size_t)c_lead * GROUPS * sizeof(uint16_t), st));
+                    XMS_HIP(s, hipMemsetAsync(sl.pf[f].d_chunk_cnt, 0, (size_t)c_lead * WAVES * sizeof(uint32_t), st));
+                }
+                rc = mark_range(s, sl, f, len[f], job.f[f].usable, c_lead, upto);
+            }
+            if (sl.marked[f] < sl.held[f]) sl.marked[f] = sl.held[f];
+        }
+        if (rc == XM_OK) rc = mark_chunks(s, sl, f, len[f], job.f[f].usable, job.f[f].n_chunks, true);
+        if (rc != XM_OK) { sl.state_cleared = false; sl.marked[0] = sl.marked[1] = 0; sl.held[0] = sl.held[1] = 0; return rc; }
     }
+    sl.held[0] = sl.held[1] = 0;
+    sl.pf[0].lead = sl.pf[1].lead = 0;                                        // (the job has them: the next window says its own)
     if (!sl.state_cleared) XMS_HIP(s, hipMemsetAsync(sl.d_state, 0, ST_WORDS * sizeof(uint32_t), st));   // two empty windows
     sl.state_cleared = false;
     sl.marked[0] = sl.marked[1] = 0;

@@ -670,6 +670,7 @@ BAM_LINE_LIMIT = 1 << 32            # bam_lines gives up on a single SAM line lo
 FILE_WINDOW_BYTES = int(os.environ.get("XENOMAPPER_WINDOW_MB", "128")) << 20     # bytes of each file parsed per block
 FILE_MAX_RECORDS = 1 << 22
 STAGE_PIECE = 16 << 20              # bytes copied into page-locked memory per upload of the GPU stripper
+SAM_TAIL_ROOM = 16 << 20            # room in front of bytes read ahead for the tail of the window before them (at most a window)
 
 
 def _record_start(raw):
@@ -1438,6 +1439,18 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
 
     # SAM text: the outputs gathered on the device as well (every bin needs a sink of its own; XENOMAPPER_GPU_SAM_BINS=0: the host gathers)
     sam_bins_on_device = stripper is not None and distinct and os.environ.get("XENOMAPPER_GPU_SAM_BINS", "1") != "0"
+    # ... and, with XENOMAPPER_SAM_READ_AHEAD=1, the bytes behind a window read (by a reader pool and a thread of their own) and
+    # sent over the link while it is stripped, instead of when it has said where it stopped.  Built to take the windows' serial
+    # dependency out of the run (a fifth of it, during which nothing is read), byte-exact, and measured: 13.6 - 18.7 against
+    # 13.1 - 14.3 M pairs/s to /dev/null on a box whose reads are slow, 14.4 - 17.7 against 17.2 - 20.0 on two where they are not
+    # (the reads, the link and the copy home then run all at once and each gets slower: profiles/r06_ab_sam_read_ahead.txt), no
+    # difference to files.  Not the default.
+    sam_spec, sam_slot_free, spec_reader, spec_pool = {}, {}, None, None
+    sam_prev_end, sam_last_tail = [None, None], [0, 0]
+    if (sam_bins_on_device and bamdev is None and os.environ.get("XENOMAPPER_SAM_READ_AHEAD", "0") == "1"
+            and os.environ.get("XM_STRIP_ZEROCOPY", "1") != "0"):
+        spec_reader = _host.Parser(int(os.environ.get("XENOMAPPER_SAM_READ_AHEAD_THREADS", "0")) or n_threads)
+        spec_pool = ThreadPoolExecutor(max_workers=1)
     bam_text = _BAM_TEXT_BUFFERS                                     # (slot, file) -> [text bytes, line_off, line_len] of the GPU BAM path
     bam_windows = [0]                                                # windows run so far
     # the records' SAM text is printed on the device when the reference names could be read (XENOMAPPER_GPU_BAM_TEXT=0: by the
@@ -1629,21 +1642,78 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
         blk.finish = finish
         return blk, texts, [0, 0], eofs
 
+    def read_behind(slot, ends, counts, room):
+        """The bytes BEHIND the window that is being stripped -- [ends[f], ends[f] + counts[f]) of either file -- read into the other
+        slot's staging buffers, `room` bytes into them, and sent on to the device piece by piece as always: the next window begins
+        somewhere in the last bytes of this one (its walk will say where), so its tail is put in front of these bytes when it is
+        known (parse_next; include/xenomapper_strip.h, "reading ahead").  Runs beside the strip kernels, the fused pass and the
+        hand-over of the window in front, which used to be a fifth of a run during which nothing was read."""
+        t_r = time.perf_counter()
+        for f in (0, 1):
+            base = stripper.staging_address(slot, f)
+            stripper.begin_behind(slot, f, room)
+            for at in range(0, counts[f], STAGE_PIECE):
+                piece = min(STAGE_PIECE, counts[f] - at)
+                spec_reader.pread(sources[f].fileno(), ends[f] + at, base + room + at, piece)
+                stripper.upload(slot, f, room + at, piece)
+        prof["sam_read_behind"] = prof.get("sam_read_behind", 0.0) + time.perf_counter() - t_r
+
+    def drop_stripper():
+        """The stripper is given up for the rest of the run (and of the process): not while a read into its buffers is under way."""
+        nonlocal stripper
+        for sp in sam_spec.values():
+            try:
+                sp["job"].result()
+            except Exception:                                        # noqa: BLE001
+                pass
+        sam_spec.clear()
+        _forget_stripper(stripper)
+        stripper = None
+
     def parse_next(which, want):
         nonlocal stripper
         if bamdev is not None:
             return parse_next_bamdev(which, want)
         with prof("window"):
             wins = [src.window(want) for src in sources]
+        lead = [0, 0]                                                # bytes in front of each window's text in its staging buffer
+        ahead_of_us = sam_spec.pop(which, None)                      # bytes read behind the window in front, into this slot
+        if ahead_of_us is not None:
+            t_w = time.perf_counter()
+            try:
+                ahead_of_us["job"].result()
+            except Exception:                                        # noqa: BLE001 -- a read that failed: this window is read again
+                ahead_of_us = None
+            prof["sam_wait_read"] = prof.get("sam_wait_read", 0.0) + time.perf_counter() - t_w
+        for f in (0, 1):                                             # what the window in front left over of either file
+            if sam_prev_end[f] is not None:
+                sam_last_tail[f] = max(sam_prev_end[f] - wins[f][1], 0)
+        if ahead_of_us is not None and stripper is not None:
+            tails = [ahead_of_us["ends"][f] - wins[f][1] for f in (0, 1)]
+            if all(0 <= t <= ahead_of_us["room"] for t in tails):
+                # the window = its tail (read now: a few KB) + what was read ahead, right-aligned in the room in front of that
+                sizes = [int(src.raw.shape[0]) for src in sources]
+                for f in (0, 1):
+                    lead[f] = ahead_of_us["room"] - tails[f]
+                    n_f = tails[f] + ahead_of_us["counts"][f]
+                    wins[f] = (wins[f][0], wins[f][1], n_f, wins[f][1] + n_f >= sizes[f])
+                prof["sam_windows_read_ahead"] = prof.get("sam_windows_read_ahead", 0) + 1
+            else:
+                ahead_of_us = None                                   # the walk stopped further back than the room in front allows
         if stripper is not None and max(w[2] for w in wins) <= _ffi.STRIP_MAX_WINDOW:
             # no line of a record is shorter than two bytes with its terminator
             records = min(FILE_MAX_RECORDS, max(w[2] for w in wins) // 2 + 2)
             try:
-                stripper.reserve(which, max(w[2] for w in wins), records)
+                need = max(lead[f] + wins[f][2] for f in (0, 1))
+                if spec_reader is not None and want <= _ffi.STRIP_MAX_WINDOW // 2:
+                    # (room for a window read ahead behind a gap, from the start: the buffers of a slot are never made again
+                    # while the main thread may still hold the window before -- see below)
+                    need = max(need, min(SAM_TAIL_ROOM, max(want, 1 << 16)) + want)
+                stripper.reserve(which, need, max(records, min(FILE_MAX_RECORDS, need // 2 + 2)))
             except MemoryError:                                      # page-locked or device memory ran out: the host threads strip
-                _forget_stripper(stripper)
-                stripper = None
+                drop_stripper()
         blk = None
+        sam_slot_free[which] = False                                 # until this window is known to go to the writer as six ranges
         if stripper is not None and max(w[2] for w in wins) <= _ffi.STRIP_MAX_WINDOW:
             try:
                 with prof("stage"):
@@ -1651,21 +1721,45 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                     # page of the inputs is mapped, and the writer gathers its lines from the staging buffer
                     for f, w in enumerate(wins):
                         base = stripper.staging_address(which, f)
+                        if ahead_of_us is not None:                  # all but the tail is there (and on the device) already
+                            if tails[f]:
+                                (reader_pool or parsers[which]).pread(sources[f].fileno(), w[1], base + lead[f], tails[f])
+                            stripper.set_lead(which, f, lead[f])
+                            continue
                         for at in range(0, w[2], STAGE_PIECE):
                             piece = min(STAGE_PIECE, w[2] - at)
                             (reader_pool or parsers[which]).pread(sources[f].fileno(), w[1] + at, base + at, piece)
                             stripper.upload(which, f, at, piece)
+                    # the bytes behind this window, into the other slot, while this one is stripped and handed over -- if the window
+                    # that slot held went to the writer as six ranges (then nobody reads its text any more) and both files go on
+                    other = which ^ 1
+                    if (spec_reader is not None and sam_slot_free.get(other, True) and not wins[0][3] and not wins[1][3]
+                            and want <= _ffi.STRIP_MAX_WINDOW // 2):
+                        room = min(SAM_TAIL_ROOM, max(want, 1 << 16))
+                        # (the main thread may still be counting the categories of the window that slot held, in the slot's
+                        # page-locked tables: only into buffers that are large enough as they stand)
+                        if stripper.fits(other, room + want, min(FILE_MAX_RECORDS, (room + want) // 2 + 2)):
+                            ends = [w[1] + w[2] for w in wins]
+                            # the two files hold the same reads at different bytes per record: the one whose windows leave the
+                            # longer tails gets that much less, or its tail would grow from window to window
+                            counts = [min(max(want - sam_last_tail[f], want // 2), int(sources[f].raw.shape[0]) - ends[f])
+                                      for f in (0, 1)]
+                            sam_spec[other] = {"ends": ends, "counts": counts, "room": room,
+                                               "job": spec_pool.submit(read_behind, other, ends, counts, room)}
+                sam_prev_end[0], sam_prev_end[1] = wins[0][1] + wins[0][2], wins[1][1] + wins[1][2]
                 with prof("strip"):
-                    blk = stripper.run(which, wins[0][2], wins[0][3], wins[1][2], wins[1][3], score_mode, paired, skip_repeated,
-                                       paired, records)
+                    blk = stripper.run(which, lead[0] + wins[0][2], wins[0][3], lead[1] + wins[1][2], wins[1][3], score_mode, paired,
+                                       skip_repeated, paired, records)
+                    if lead[0] or lead[1]:                           # (offsets count from the buffer's first byte: so much TEXT is done)
+                        blk.consumed = (blk.consumed[0] - lead[0], blk.consumed[1] - lead[1])
                     prof["strip_upload_ms"] = prof.get("strip_upload_ms", 0.0) + blk.ms_upload
                     prof["strip_kernels_ms"] = prof.get("strip_kernels_ms", 0.0) + blk.ms_kernels
             except (MemoryError, OSError):
                 # the --cigar_scores arrays did not fit (MemoryError from the run), or a read into the staging buffer failed
                 # half way: this window and the rest of the run go through the host stripper, and the half-staged stripper
                 # is not kept for later runs of the process
-                _forget_stripper(stripper)
-                stripper, blk = None, None
+                drop_stripper()
+                blk = None
         if blk is not None:
             if blk.non_ascii:
                 raise _host.NonAsciiInput()
@@ -1680,6 +1774,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 if bins[0] == 0:
                     blk.bins = bins
                     prof["sam_windows_device_bins"] = prof.get("sam_windows_device_bins", 0) + 1
+                    sam_slot_free[which] = True                      # nobody reads this slot's staged text again
 
                     def finish(strip=stripper, slot=which):
                         t_w = time.perf_counter()
@@ -1692,8 +1787,9 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 # more lines than the device tables hold, or a --cigar_scores block with a value the kernels do not vouch for:
                 # this window goes through the host stripper (the text is in the staging buffers already)
                 with prof("parse"):
-                    blk = parsers[which].parse(staged[0], 0, wins[0][2], wins[0][3], staged[1], 0, wins[1][2], wins[1][3],
+                    blk = parsers[which].parse(staged[0], lead[0], wins[0][2], wins[0][3], staged[1], lead[1], wins[1][2], wins[1][3],
                                                score_mode, paired, skip_repeated, paired, FILE_MAX_RECORDS)
+                return blk, staged, lead, [w[3] for w in wins]       # (the host stripper's offsets count from where it was told to begin)
             return blk, staged, [0, 0], [w[3] for w in wins]
         with prof("parse"):
             blk = None
@@ -1830,6 +1926,14 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                         trouble = trouble or exc
             ahead_pool.shutdown(wait=True)
             pool.shutdown(wait=True)
+            if spec_pool is not None:
+                for sp in sam_spec.values():
+                    try:
+                        sp["job"].result()
+                    except Exception:                                # noqa: BLE001
+                        pass
+                spec_pool.shutdown(wait=True)
+                spec_reader.close()
             if bam_ahead_pool is not None:
                 bam_ahead_pool.shutdown(wait=True)
                 bam_reader.close()
