@@ -352,14 +352,16 @@ def test_small_bins_wait_for_the_extension_running_ahead(tmp_path, monkeypatch):
         assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True
         state = ahead[id(sink)]
         state.settle()
-        released, real = [], xm._fallocate
+        released, real, entered = [], xm._fallocate, threading.Event()
 
         def slow(fd, off, length):
+            entered.set()
             gate.wait(5)
             released.append((off, length))
             return real(fd, off, length)
         monkeypatch.setattr(xm, "_fallocate", slow)
         state.extend_later(pool, state.size + (3 << 20))              # an extension that is still under way
+        assert entered.wait(5)                                        # (... really under way: the helper thread is inside fallocate)
         fake.need = 100                                               # too small for the mapping
         threading.Timer(0.2, gate.set).start()
         assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is False
