@@ -1007,6 +1007,14 @@ class _PhaseClock(dict):
             self[name] = self.get(name, 0.0) + time.perf_counter() - start
 
 
+def _quietly(fn, *args):
+    """fn(*args) in a helper thread whose failure is not the run's: whoever needs what it was to prepare does it again and raises."""
+    try:
+        fn(*args)
+    except Exception:                                                # noqa: BLE001
+        pass
+
+
 def _input_fraction(sources):
     """How far the run is through its input files (0 .. 1), or None when the sources do not say."""
     done = total = 0
@@ -1518,6 +1526,11 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
             comp_cap = raw_cap if bam_comp_worst_case[0] else raw_cap // 2 + (64 << 10)
             max_blocks = raw_cap // 65536 + raw_cap // 4096 + 64
             bamdev.reserve(which, comp_cap, raw_cap, max_blocks, min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
+            if bam_windows[0] == 1 and bam_ahead_pool is not None and not all(src.at_end for src in sources):
+                # the run's first window: the OTHER slot's buffers are made now, by the helper thread, beside this window's work
+                # (page-locking them is a quarter of a process's first run; the read-ahead behind this window then has where to read to)
+                bam_ahead_pool.submit(_quietly, bamdev.reserve, which ^ 1, comp_cap, raw_cap, max_blocks,
+                                      min(FILE_MAX_RECORDS, raw_cap // 36 + 2))
             # the two files hold the same reads at different bytes per record: each gets a window in proportion, so that the
             # windows hold about as many records and neither file drags a growing tail from window to window
             per_rec = [src.bytes_per_record for src in sources]
