@@ -140,9 +140,11 @@ def get_sam_header(samfile):
     return header
 
 
-def _bam_reader(bamfile):
+def _bam_reader(bamfile, header_only=False):
     """Native BGZF/BAM decoder over a binary file object (no samtools needed).  A regular file is memory-mapped
-    (nothing is read up front, nothing stays resident); anything else (a pipe, BytesIO) is read whole."""
+    (nothing is read up front, nothing stays resident); anything else (a pipe, BytesIO) is read whole.
+    header_only: the handle that knows the header alone -- the file's blocks are not indexed (walking a multi-gigabyte
+    file's block headers through a mapping, and taking the mapping down again, was 0.3 s of the command line's 1.8 on 4.5 GB)."""
     from . import _host
     data = None
     try:
@@ -157,12 +159,12 @@ def _bam_reader(bamfile):
     if data is None:
         data = np.frombuffer(bamfile.read(), dtype=np.uint8)
         bamfile.seek(0)
-    return _host.BamReader(data)
+    return _host.BamReader(data, header_only=header_only)
 
 
 def get_bam_header(bamfile):
     """Header lines of a BAM file, as `samtools view -H` prints them (ref :48-54)."""
-    reader = _bam_reader(bamfile)
+    reader = _bam_reader(bamfile, header_only=True)
     try:
         return [line for line in reader.header().split("\n") if line]
     finally:
