@@ -22,6 +22,7 @@ pr.disable()
 sys.stderr = real_stderr
 st = pstats.Stats(pr, stream=sys.stdout).sort_stats("cumulative")
 st.print_stats(28)
+st.print_callees("_emit_into_file")
 for n in names:
     f = "/dev/shm/xm_clipp_out_" + n + ".sam"
     if os.path.exists(f): os.unlink(f)

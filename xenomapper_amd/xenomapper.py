@@ -719,6 +719,7 @@ MMAP_EMIT_MIN_BYTES = 1 << 20        # below this one buffered write is cheaper 
 # are there, but every fallocate call beside the threads that fill the pages slows those: 32 MB pieces 5.9 - 7.0 M pairs/s, 8 MB
 # 5.5 - 6.0, one piece 7.7 - 7.9 (SAM text in, six files on tmpfs out, one box, profiles/r06_ab_ahead_piece.txt)
 AHEAD_PIECE = (int(os.environ.get("XENOMAPPER_AHEAD_PIECE_MB", "0")) << 20) or (1 << 62)
+MAP_AHEAD = int(os.environ.get("XENOMAPPER_MAP_AHEAD_MB", "1024")) << 20       # the writer's mapping of an output file reaches this far from where it was made (0: a mapping per call)
 AHEAD_MOST = int(os.environ.get("XENOMAPPER_AHEAD_MOST_MB", "1024")) << 20     # an output file is never extended further than this past its content
 # 1: extend the output files towards the size the run predicts from the fraction of the input it has read, instead of twice the last
 # call's bytes ahead.  Measured on one (slow) box, alternating (profiles/r06_ab_ahead_predict.txt): SAM text in 6.0 - 7.2 against
@@ -734,6 +735,31 @@ _EMIT_CLOCK = {}            # seconds inside _emit_into_file by step, since the 
 
 
 _libc_fallocate = None
+_libc_map = None
+
+
+def _map_file(fd, length, offset):
+    """mmap(2) of [offset, offset + length) of a file, shared and writable -> address.  The system call itself (not the mmap
+    module, which keeps a duplicate of the descriptor per mapping): the writer holds one long mapping per output file."""
+    global _libc_map
+    import ctypes
+    if _libc_map is None:
+        lib = ctypes.CDLL(None, use_errno=True)
+        lib.mmap.restype = ctypes.c_void_p
+        lib.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64]
+        lib.munmap.restype = ctypes.c_int
+        lib.munmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        _libc_map = lib
+    addr = _libc_map.mmap(None, length, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_SHARED, fd, offset)
+    if addr is None or addr == ctypes.c_void_p(-1).value:
+        e = ctypes.get_errno()
+        raise OSError(e, os.strerror(e))
+    return addr
+
+
+def _unmap_file(addr, length):
+    if _libc_map is not None and addr:
+        _libc_map.munmap(addr, length)
 
 
 def _fallocate(fd, offset, length):
@@ -775,6 +801,38 @@ class _AheadFile(object):
         self.fd2, self.size, self.target = fd2, size, size
         self.busy = False                                 # a piece is queued or being allocated
         self.cv = threading.Condition()
+        self.mapped = None                                # (address, file offset, length) of the writer's current mapping
+
+    def window(self, pos, need, pool):
+        """-> the address of file byte `pos`, of a mapping that holds [pos, pos + need).  One LONG mapping per file (MAP_AHEAD
+        bytes from where it was made), kept from call to call: a mapping per bin and window meant a munmap per bin and window in
+        the helper threads, and every mmap of the next bin waited for the one before to let go of the process's mapping lock --
+        2.5 ms a call, a third of the writer's time (profiles/r06_ab_map_reuse.txt).  The mapping may reach beyond the file's
+        end; only [pos, pos + need), which the caller has extended the file to, is touched."""
+        m = self.mapped
+        if m is None or pos < m[1] or pos + need > m[1] + m[2]:
+            start = pos - pos % mmap.ALLOCATIONGRANULARITY
+            length = max(pos + need - start, MAP_AHEAD)
+            addr = _map_file(self.fd2, length, start)
+            if m is not None:
+                self._drop(m, pool)
+            m = self.mapped = (addr, start, length)
+        return m[0] + (pos - m[1])
+
+    @staticmethod
+    def _drop(m, pool):
+        try:
+            pool.submit(_unmap_file, m[0], m[2])           # (taking ~10^5 pages out of the page table costs as much as a third of their fill)
+        except RuntimeError:
+            _unmap_file(m[0], m[2])
+
+    def unmap(self, pool=None):
+        m, self.mapped = self.mapped, None
+        if m is not None:
+            if pool is not None:
+                self._drop(m, pool)
+            else:
+                _unmap_file(m[0], m[2])
 
     def _piece(self, pool):
         with self.cv:
@@ -830,8 +888,9 @@ class _AheadFile(object):
                 except RuntimeError:
                     self.busy = False
 
-    def finish(self, sink):
+    def finish(self, sink, pool=None):
         self.settle()
+        self.unmap(pool)
         try:
             sink.flush()
             os.ftruncate(self.fd2, sink.buffer.tell())
@@ -898,8 +957,15 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
                     raise
                 os.ftruncate(fd2, pos + need)
             size = pos + need
-        start = pos - pos % mmap.ALLOCATIONGRANULARITY
-        mm = mmap.mmap(fd2, pos + need - start, offset=start, access=mmap.ACCESS_WRITE)
+        t_m = time.perf_counter()
+        own = None                                     # (address, length) of a mapping made for this call alone
+        if state is not None and MAP_AHEAD > 0 and ahead_pool is not None:
+            dst = state.window(pos, need, ahead_pool)  # the file's long mapping (made now, if the last one ends before pos + need)
+        else:
+            start = pos - pos % mmap.ALLOCATIONGRANULARITY
+            own = (_map_file(fd2, pos + need - start, start), pos + need - start)
+            dst = own[0] + (pos - start)
+        _EMIT_CLOCK["emit_map"] = _EMIT_CLOCK.get("emit_map", 0.0) + time.perf_counter() - t_m
     except (OSError, ValueError, AttributeError, io.UnsupportedOperation):
         if fd2 is not None:
             if state is not None:
@@ -916,21 +982,19 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
     t1 = time.perf_counter()
     _EMIT_CLOCK["emit_extend"] = _EMIT_CLOCK.get("emit_extend", 0.0) + t1 - t0
     try:
-        view = np.frombuffer(mm, dtype=np.uint8)
-        try:
-            if ready is not None:
-                parser.copy(view.ctypes.data + (pos - start), ready, 0, need)
-                wrote = need
-            else:
-                wrote = parser.emit_to(paired, b, idx, view.ctypes.data + (pos - start), need)
-        finally:
-            del view
+        if ready is not None:
+            parser.copy(dst, ready, 0, need)
+            wrote = need
+        else:
+            wrote = parser.emit_to(paired, b, idx, dst, need)
         assert wrote == need
         t0 = time.perf_counter()
         _EMIT_CLOCK["emit_fill"] = _EMIT_CLOCK.get("emit_fill", 0.0) + t0 - t1
     except BaseException:
-        mm.close()
+        if own is not None:
+            _unmap_file(*own)
         if state is not None:
+            state.unmap()
             state.settle()
         os.ftruncate(fd2, pos)                         # nothing of this bin's text stays behind
         if state is not None:
@@ -938,10 +1002,11 @@ def _emit_into_file(parser, paired, b, seg, sink, ahead=None, ahead_pool=None, r
         else:
             os.close(fd2)
         raise
-    if ahead is not None and ahead_pool is not None:
-        ahead_pool.submit(mm.close)                    # taking ~10^5 pages out of the page table costs as much as a third of the fill
-    else:
-        mm.close()
+    if own is not None:
+        if ahead is not None and ahead_pool is not None:
+            ahead_pool.submit(_unmap_file, *own)       # taking ~10^5 pages out of the page table costs as much as a third of the fill
+        else:
+            _unmap_file(*own)
     _EMIT_CLOCK["emit_unmap"] = _EMIT_CLOCK.get("emit_unmap", 0.0) + time.perf_counter() - t0
     raw.seek(pos + need)
     # (a descriptor in append mode writes at the END of the file whatever its position: it must never be longer than its content)
@@ -1936,7 +2001,7 @@ def _run_files(mode, path1, path2, sinks, min_score, tag_func, skip_repeated, n_
                 state = ahead.pop(id(sink), None)
                 if state is not None:
                     try:
-                        state.finish(sink)
+                        state.finish(sink, ahead_pool)
                     except OSError as exc:
                         trouble = trouble or exc
             ahead_pool.shutdown(wait=True)
