@@ -409,6 +409,47 @@ def test_files_are_extended_in_pieces_towards_the_size_the_run_predicts(tmp_path
     assert path.read_bytes() == b"x" * (8 << 20)
 
 
+def test_the_writer_keeps_one_long_mapping_per_file_and_survives_a_fill_that_fails(tmp_path, monkeypatch):
+    """One mapping per output file, MAP_AHEAD bytes long from where it was made, serves the calls until the content runs off its
+    end (then the next one is made and the old one unmapped by the helper pool); a fill that raises leaves nothing of its bin
+    behind, drops the mapping, and the next call maps again; finish() unmaps and cuts the file to its content."""
+    from concurrent.futures import ThreadPoolExecutor
+    from xenomapper_amd import xenomapper as xm
+    monkeypatch.setattr(xm, "MAP_AHEAD", 5 << 20)
+    made, gone, real_map, real_unmap = [], [], xm._map_file, xm._unmap_file
+    monkeypatch.setattr(xm, "_map_file", lambda fd, length, offset: made.append((offset, length)) or real_map(fd, length, offset))
+    monkeypatch.setattr(xm, "_unmap_file", lambda addr, length: gone.append(length) or real_unmap(addr, length))
+    path = tmp_path / "bin.sam"
+    ahead, pool = {}, ThreadPoolExecutor(max_workers=1)
+    with open(path, "wt") as sink:
+        sink.write("@HD\n")
+        fake = _FakeParser(2 << 20)
+        for _ in range(4):                                           # 8 MB: the first call's own mapping, then two long ones
+            assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True
+        state = ahead[id(sink)]
+        assert [m[1] for m in made] == [4 + (2 << 20), 5 << 20, 5 << 20] and state.mapped is not None
+
+        class Boom(RuntimeError):
+            pass
+
+        def failing(paired, b, idx, dst, cap):
+            raise Boom()
+        good = fake.emit_to
+        fake.emit_to = failing
+        with pytest.raises(Boom):
+            xm._emit_into_file(fake, True, 0, None, sink, ahead, pool)
+        assert state.mapped is None and sink.buffer.tell() == 4 + (8 << 20)
+        fake.emit_to = good
+        assert xm._emit_into_file(fake, True, 0, None, sink, ahead, pool) is True     # maps again, writes behind the content
+        assert len(made) == 4 and state.mapped is not None
+        sink.write("tail\n")
+        state.finish(sink, pool)
+        assert state.mapped is None
+    pool.shutdown()
+    assert len(gone) == len(made)                                    # every mapping was taken down
+    assert path.read_bytes() == b"@HD\n" + b"x" * (10 << 20) + b"tail\n"
+
+
 def test_mapped_writer_never_extends_an_append_mode_file_ahead(tmp_path):
     """O_APPEND writes go to the end of the FILE: such a sink must never be longer than its content."""
     import os
