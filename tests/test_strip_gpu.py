@@ -452,6 +452,7 @@ def test_outputs_gathered_on_the_device_equal_the_oracle_and_the_host_writer(tmp
     from tests.test_file_fuzz_gpu import oracle_run, SCORERS
     from xenomapper_amd import xenomapper as xm
     monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 1 << 20)
+    monkeypatch.delenv("XENOMAPPER_SAM_READ_AHEAD", raising=False)    # (the default first, the option below)
     paired = mode != "se"
     for mixed in (0.0, 0.0002):
         t1, t2, _info = H.synth.sam_text_pair(n_pairs=30_000, seed=17, profile="bowtie2", paired=paired, read_len=100, mixed_ws=mixed,
@@ -497,7 +498,7 @@ def test_outputs_gathered_on_the_device_equal_the_oracle_and_the_host_writer(tmp
             assert prof.get("sam_windows_read_ahead", 0) >= prof["sam_windows"] * 2 // 3, prof
         else:
             assert prof.get("sam_windows_read_ahead", 0) > 0, prof
-        monkeypatch.delenv("XENOMAPPER_SAM_READ_AHEAD")
+        monkeypatch.delenv("XENOMAPPER_SAM_READ_AHEAD", raising=False)
 
 
 def test_overlapping_units_outgrow_the_output_stream_and_go_to_the_host_writer(tmp_path, monkeypatch):
@@ -511,6 +512,7 @@ def test_overlapping_units_outgrow_the_output_stream_and_go_to_the_host_writer(t
     from tests.test_file_fuzz_gpu import oracle_run, SCORERS
     from xenomapper_amd import xenomapper as xm
     monkeypatch.setattr(xm, "FILE_WINDOW_BYTES", 1 << 20)
+    monkeypatch.delenv("XENOMAPPER_SAM_READ_AHEAD", raising=False)    # (with it the buffers hold a window and the room in front of it)
     xm.release_buffers()                                             # (the process-wide stripper may have grown in a test before: this one counts on its sizes)
     line = "samename\t%d\tchr1\t%d\t30\t50M\t=\t%d\t0\t" + "ACGT" * 12 + "AC\t" + "F" * 50 + "\tAS:i:-5\tXS:i:-9\n"
     text = "".join(line % (99 if k % 2 == 0 else 147, 100 + k, 300 + k) for k in range(40_000))
